@@ -1,0 +1,184 @@
+/*
+ * linemod_hip.h -- C ABI of the MI355X-native LINE-MOD detector (liblinemod_hip.so).
+ *
+ * Drop-in boundary: this library replaces the object the reference holds as
+ *     cv::Ptr<cv::linemod::Detector> detector;      /root/reference/include/HighLevelLinemod.h:102
+ * Every entry point below names the cv::linemod::Detector call of the reference it stands in for
+ * (complete list of calls crossing that seam: SURVEY.md section 8b).  Plain C types only: opaque
+ * handle, caller-owned buffers with explicit strides/capacities, int status (0 = LM_OK), no
+ * exceptions across the ABI; lm_last_error() returns the text of the last failure on the calling
+ * thread.  All compute runs in hand-written HIP kernels for gfx950; there is NO CPU fallback --
+ * every compute entry point fails with LM_ERR_NO_DEVICE when no HIP device is usable.
+ *
+ * Image formats (SURVEY.md 8b "Conventions"): colour = 8-bit BGR interleaved (CV_8UC3 as
+ * delivered by cv::VideoCapture, detector.cpp:24), depth = uint16 millimetres (CV_16UC1,
+ * detector.cpp:25-26).  Strides are in bytes.
+ */
+#ifndef LINEMOD_HIP_H
+#define LINEMOD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LM_MAX_LEVELS 4
+#define LM_MAX_FEATURES 63 /* upstream CV_Assert(features.size() <= 63): 63*4 = 252 fits a byte */
+
+enum {
+    LM_OK = 0,
+    LM_ERR_INVALID = 1,    /* bad argument / violated precondition (the upstream CV_Assert cases)   */
+    LM_ERR_NO_DEVICE = 2,  /* no usable HIP device: the product path has no CPU fallback            */
+    LM_ERR_HIP = 3,        /* a HIP runtime call failed                                              */
+    LM_ERR_OVERFLOW = 4,   /* more candidates/matches than the configured capacity    */
+    LM_ERR_IO = 5,
+    LM_ERR_EXTRACT = 6     /* addTemplate could not extract enough features (upstream returns -1)   */
+};
+
+/* cv::linemod::Feature {int x, y, label} */
+typedef struct lm_feature { int32_t x, y, label; } lm_feature;
+/* cv::linemod::Template header: {width, height, pyramid_level, features.size()} */
+typedef struct lm_template_desc { int32_t width, height, pyramid_level, num_features; } lm_template_desc;
+/* cv::linemod::Match {x, y, similarity, class_id, template_id}; class_id as index into lm_class_id() */
+typedef struct lm_match_t { int32_t x, y; float similarity; int32_t template_id; int32_t class_idx; } lm_match_t;
+typedef struct lm_rect { int32_t x, y, width, height; } lm_rect;
+
+typedef struct lm_config {
+    int32_t width, height;        /* level-0 frame size; fixed per detector (buffers are sized for it)      */
+    int32_t num_modalities;       /* 1 = {ColorGradient}; 2 = {ColorGradient, DepthNormal}                   */
+    int32_t pyramid_levels;       /* T_pyramid.size(); the reference uses 2                                  */
+    int32_t T[LM_MAX_LEVELS];     /* {5,8} RGB-D, {2,8} colour only  (HighLevelLinemod.cpp:32,40)            */
+    float   weak_threshold;       /* ColorGradient: 10                                                       */
+    int32_t num_features;         /* ColorGradient: 63                                                       */
+    float   strong_threshold;     /* ColorGradient: 55                                                       */
+    int32_t distance_threshold;   /* DepthNormal: 2000                                                       */
+    int32_t difference_threshold; /* DepthNormal: 50                                                         */
+    int32_t depth_num_features;   /* DepthNormal: 63                                                         */
+    int32_t extract_threshold;    /* DepthNormal: 2                                                          */
+    int32_t device;               /* HIP device ordinal                                                      */
+    int32_t shard_rank;           /* template-bank shard held by this detector: templates of every class     */
+    int32_t shard_size;           /*   are split into shard_size contiguous template_id ranges (8e)          */
+    int32_t max_candidates;       /* capacity of the device candidate buffer (0 = default 1<<20)             */
+    int32_t max_matches;          /* capacity of the device match buffer     (0 = default 1<<18)             */
+    int32_t frame_slots;          /* resident-frame slots for lm_match_batch (0 = default 8)                 */
+} lm_config;
+
+typedef struct lm_detector lm_detector;
+
+const char* lm_last_error(void);
+const char* lm_version(void);
+
+/* Fills the reference's two constructions (HighLevelLinemod.cpp:26-43): color_only=0 ->
+ * {ColorGradient, DepthNormal}, T={5,8}; color_only=1 -> {ColorGradient}, T={2,8}. */
+void lm_default_config(lm_config* cfg, int color_only, int width, int height);
+
+/* cv::linemod::Detector(modalities, T_pyramid)            HighLevelLinemod.cpp:33-34,41-42 */
+int  lm_create(const lm_config* cfg, lm_detector** out);
+/* cv::Ptr::release()                                      HighLevelLinemod.cpp:50          */
+void lm_destroy(lm_detector* det);
+
+/* SIMILARITY_LUT / NORMAL_LUT are data parameters. */
+int lm_set_similarity_lut(lm_detector* det, const uint8_t lut[256]);
+int lm_set_normal_lut(lm_detector* det, const uint8_t lut[8000]);
+int lm_get_similarity_lut(const lm_detector* det, uint8_t lut[256]);
+int lm_get_normal_lut(const lm_detector* det, uint8_t lut[8000]);
+
+/* Detector::numClasses()  HighLevelLinemod.cpp:60,527 ; numTemplates() :65 ; classIds() :55,145,262,526 */
+int         lm_num_classes(const lm_detector* det);
+int         lm_num_templates(const lm_detector* det);                   /* total, all classes, whole bank */
+int         lm_class_num_templates(const lm_detector* det, int class_idx);
+const char* lm_class_id(const lm_detector* det, int class_idx);
+int         lm_find_class(const lm_detector* det, const char* class_id); /* -1 if absent */
+/* Detector::getT(level) :184 ; getModalities().size() :119 ; pyramidLevels() */
+int lm_get_T(const lm_detector* det, int level);
+int lm_num_modalities(const lm_detector* det);
+int lm_pyramid_levels(const lm_detector* det);
+
+/* Detector::readClass / bulk template upload              HighLevelLinemod.cpp:299
+ * Appends n_templates pre-extracted template pyramids to class `class_id` (created if new).
+ * descs: n_templates * pyramid_levels * num_modalities entries ordered [template][level*M + modality];
+ * features: concatenated in the same order.  Template ids continue from the class's current count.
+ * Returns the class index in *class_idx_out (may be NULL). */
+int lm_add_class(lm_detector* det, const char* class_id, int n_templates, const lm_template_desc* descs,
+                 const lm_feature* features, int* class_idx_out);
+
+/* Detector::addTemplate(sources, class_id, object_mask, &bounding_box) -> template_id or -1
+ *                                                         HighLevelLinemod.cpp:93-97
+ * Quantisation runs on the GPU, feature selection on the host.  depth may be NULL for a colour-only
+ * detector; mask may be NULL.  *template_id_out = -1 and status LM_ERR_EXTRACT when extraction fails. */
+int lm_add_template(lm_detector* det, const char* class_id, const uint8_t* bgr, size_t bgr_stride,
+                    const uint16_t* depth, size_t depth_stride, const uint8_t* mask, size_t mask_stride,
+                    int* template_id_out, lm_rect* bbox_out);
+
+/* Detector::getTemplates(class_id, template_id)[level*M + modality]   HighLevelLinemod.cpp:115-116,181-183
+ * features may be NULL to query the count. */
+int lm_get_template(const lm_detector* det, int class_idx, int template_id, int level, int modality,
+                    int* width, int* height, lm_feature* features, int* num_features);
+
+/* Detector::match(sources, threshold, matches, class_ids)             HighLevelLinemod.cpp:152
+ * class_idx >= 0: that class only (the reference always passes exactly one id, :145); -1: all classes.
+ * Host frame in, sorted unique matches out (total order SURVEY.md A.9: similarity desc, template_id
+ * asc, class asc, y asc, x asc; adjacent-unique on (x, y, similarity, class)).  *n_out receives the
+ * number of matches found; if it exceeds `cap` only the first cap are written and LM_ERR_OVERFLOW
+ * is returned.  With shard_size > 1 only this shard's templates are searched (ids stay global). */
+int lm_match(lm_detector* det, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
+             float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
+
+/* Resident-frame path used by the benchmark and by batch-of-frames serving: upload once, match many. */
+int lm_upload_frame(lm_detector* det, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
+                    size_t depth_stride);
+int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
+/* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame
+ * records, counts n_slots entries. */
+int lm_match_batch(lm_detector* det, int n_slots, float threshold, int class_idx, lm_match_t* out, size_t cap_per_frame,
+                   int32_t* counts);
+
+/* R-way merge of per-shard sorted lists + adjacent-unique: the step after the all-gather (8e).  Host-side. */
+int lm_merge_matches(const lm_match_t* lists, const int32_t* counts, int n_lists, size_t stride, lm_match_t* out,
+                     size_t cap, size_t* n_out);
+
+/* Template-bank persistence (Detector::write/writeClass/read/readClass, HighLevelLinemod.cpp:260,267,294,299):
+ * own compact binary format, see DESIGN.md. */
+int lm_save_bank(const lm_detector* det, const char* path);
+int lm_load_bank(lm_detector* det, const char* path);
+
+/* ---- stage-level hooks (parity tests diff intermediate buffers against the oracle) ------------ */
+/* a3 ColorGradient quantisation of an arbitrary w x h BGR image (dense).  magnitude may be NULL. */
+int lm_stage_color_quantize(lm_detector* det, const uint8_t* bgr, int w, int h, float weak_threshold,
+                            uint8_t* quantized, float* magnitude);
+/* a4 cv::pyrDown of a dense BGR image -> (w/2) x (h/2) */
+int lm_stage_pyrdown(lm_detector* det, const uint8_t* bgr, int w, int h, uint8_t* out);
+/* a5 DepthNormal quantisation of a dense uint16 image */
+int lm_stage_depth_quantize(lm_detector* det, const uint16_t* depth, int w, int h, uint8_t* quantized);
+/* a8+a9+a10 spread(T) -> response maps -> linearize; out is 8 * T*T * (w/T)*(h/T) bytes [ori][memory][pos] */
+int lm_stage_linear_memories(lm_detector* det, const uint8_t* quantized, int w, int h, int T, uint8_t* out);
+/* Runs a3-a10 on the frame in `slot` and stops (no matching). */
+int lm_prepare_slot(lm_detector* det, int slot);
+/* Reads back an intermediate buffer of `slot` after lm_prepare_slot / lm_match_slot:
+ * what 0 = quantized image [h][w], 2 = linear memories [ori][memory][pos] (pads stripped).
+ * Returns the byte size in *size_out; copies min(size, cap). */
+int lm_debug_read(lm_detector* det, int slot, int what, int level, int modality, uint8_t* out, size_t cap,
+                  size_t* size_out);
+/* a11-a13 only: candidates of the global scan at the lowest level as (template_id, class_idx, x, y)
+ * quadruples of int32, sorted; for parity tests of the scan kernel in isolation. */
+int lm_stage_scan(lm_detector* det, int slot, float threshold, int class_idx, int32_t* out, size_t cap_records,
+                  size_t* n_out);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------------- */
+/* Times `iters` back-to-back launches of the similarity-scan kernel alone on the linear memories of
+ * `slot` with HIP events on the launch stream; returns the average launch duration in microseconds
+ * and the algorithmic bytes one launch reads (sum over templates/modalities of F*P). */
+int lm_time_scan(lm_detector* det, int slot, float threshold, int class_idx, int iters, int variant,
+                 double* avg_us_out, double* algorithmic_bytes_out);
+/* Per-stage average microseconds of the last lm_match_slot-style pipeline, measured with HIP events
+ * over `iters` runs: out[0]=preprocess (a3-a10), out[1]=scan, out[2]=refine, out[3]=sort+copy. */
+int lm_time_stages(lm_detector* det, int slot, float threshold, int class_idx, int iters, double out_us[4]);
+/* Selects the similarity-scan kernel variant used by lm_match* (0 = default; see lm_kernels.hip). */
+int lm_set_scan_variant(lm_detector* det, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINEMOD_HIP_H */

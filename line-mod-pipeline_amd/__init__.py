@@ -1,0 +1,370 @@
+"""line-mod-pipeline_amd -- MI355X-native LINE-MOD detector (host-side Python binding).
+
+The product is liblinemod_hip.so (hand-written HIP kernels for gfx950 behind the C ABI of
+include/linemod_hip.h).  This package is only the ctypes view of that ABI used by tests, bench.py
+and the multi-GPU shard driver; it contains no compute and no fallback: if the library is missing
+the import fails, and if no HIP device is present every compute call raises LinemodError.
+
+Import with importlib (the directory name is not a Python identifier):
+    lm = importlib.import_module("line-mod-pipeline_amd")
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblinemod_hip.so")
+
+LM_OK, LM_ERR_INVALID, LM_ERR_NO_DEVICE, LM_ERR_HIP, LM_ERR_OVERFLOW, LM_ERR_IO, LM_ERR_EXTRACT = range(7)
+
+MATCH_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("similarity", "<f4"), ("template_id", "<i4"),
+                        ("class_idx", "<i4")])
+FEATURE_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("label", "<i4")])
+DESC_DTYPE = np.dtype([("width", "<i4"), ("height", "<i4"), ("pyramid_level", "<i4"), ("num_features", "<i4")])
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("num_modalities", C.c_int32),
+                ("pyramid_levels", C.c_int32), ("T", C.c_int32 * 4), ("weak_threshold", C.c_float),
+                ("num_features", C.c_int32), ("strong_threshold", C.c_float), ("distance_threshold", C.c_int32),
+                ("difference_threshold", C.c_int32), ("depth_num_features", C.c_int32),
+                ("extract_threshold", C.c_int32), ("device", C.c_int32), ("shard_rank", C.c_int32),
+                ("shard_size", C.c_int32), ("max_candidates", C.c_int32), ("max_matches", C.c_int32),
+                ("frame_slots", C.c_int32)]
+
+
+class Rect(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class LinemodError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("liblinemod_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+# Every symbol include/linemod_hip.h declares (tests check that the library exports all of them).
+EXPORTS = [
+    "lm_last_error", "lm_version", "lm_default_config", "lm_create", "lm_destroy", "lm_set_similarity_lut",
+    "lm_set_normal_lut", "lm_get_similarity_lut", "lm_get_normal_lut", "lm_num_classes", "lm_num_templates",
+    "lm_class_num_templates", "lm_class_id", "lm_find_class", "lm_get_T", "lm_num_modalities",
+    "lm_pyramid_levels", "lm_add_class", "lm_add_template", "lm_get_template", "lm_match", "lm_upload_frame",
+    "lm_match_slot", "lm_match_batch", "lm_merge_matches", "lm_save_bank", "lm_load_bank",
+    "lm_stage_color_quantize", "lm_stage_pyrdown", "lm_stage_depth_quantize", "lm_stage_linear_memories",
+    "lm_prepare_slot", "lm_debug_read", "lm_stage_scan", "lm_time_scan", "lm_time_stages", "lm_set_scan_variant",
+]
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads liblinemod_hip.so; raises OSError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise OSError("liblinemod_hip.so not built (%s): run `python line-mod-pipeline_amd/build.py` "
+                      "or __graft_entry__.build(); there is no CPU fallback" % p)
+    lib = C.CDLL(p)
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    lib.lm_last_error.restype = C.c_char_p
+    lib.lm_version.restype = C.c_char_p
+    lib.lm_default_config.argtypes = [C.POINTER(Config), i, i, i]
+    lib.lm_default_config.restype = None
+    lib.lm_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.lm_destroy.argtypes = [vp]
+    lib.lm_destroy.restype = None
+    for name in ("lm_set_similarity_lut", "lm_set_normal_lut", "lm_get_similarity_lut", "lm_get_normal_lut"):
+        getattr(lib, name).argtypes = [vp, vp]
+    lib.lm_num_classes.argtypes = [vp]
+    lib.lm_num_templates.argtypes = [vp]
+    lib.lm_class_num_templates.argtypes = [vp, i]
+    lib.lm_class_id.argtypes = [vp, i]
+    lib.lm_class_id.restype = C.c_char_p
+    lib.lm_find_class.argtypes = [vp, C.c_char_p]
+    lib.lm_get_T.argtypes = [vp, i]
+    lib.lm_num_modalities.argtypes = [vp]
+    lib.lm_pyramid_levels.argtypes = [vp]
+    lib.lm_add_class.argtypes = [vp, C.c_char_p, i, vp, vp, C.POINTER(i)]
+    lib.lm_add_template.argtypes = [vp, C.c_char_p, vp, sz, vp, sz, vp, sz, C.POINTER(i), C.POINTER(Rect)]
+    lib.lm_get_template.argtypes = [vp, i, i, i, i, C.POINTER(i), C.POINTER(i), vp, C.POINTER(i)]
+    lib.lm_match.argtypes = [vp, vp, sz, vp, sz, f, i, vp, sz, C.POINTER(sz)]
+    lib.lm_upload_frame.argtypes = [vp, i, vp, sz, vp, sz]
+    lib.lm_match_slot.argtypes = [vp, i, f, i, vp, sz, C.POINTER(sz)]
+    lib.lm_match_batch.argtypes = [vp, i, f, i, vp, sz, vp]
+    lib.lm_merge_matches.argtypes = [vp, vp, i, sz, vp, sz, C.POINTER(sz)]
+    lib.lm_save_bank.argtypes = [vp, C.c_char_p]
+    lib.lm_load_bank.argtypes = [vp, C.c_char_p]
+    lib.lm_stage_color_quantize.argtypes = [vp, vp, i, i, f, vp, vp]
+    lib.lm_stage_pyrdown.argtypes = [vp, vp, i, i, vp]
+    lib.lm_stage_depth_quantize.argtypes = [vp, vp, i, i, vp]
+    lib.lm_stage_linear_memories.argtypes = [vp, vp, i, i, i, vp]
+    lib.lm_prepare_slot.argtypes = [vp, i]
+    lib.lm_debug_read.argtypes = [vp, i, i, i, i, vp, sz, C.POINTER(sz)]
+    lib.lm_stage_scan.argtypes = [vp, i, f, i, vp, sz, C.POINTER(sz)]
+    lib.lm_time_scan.argtypes = [vp, i, f, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.lm_time_stages.argtypes = [vp, i, f, i, i, C.POINTER(C.c_double)]
+    lib.lm_set_scan_variant.argtypes = [vp, i]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def default_config(color_only=False, width=640, height=480, **overrides):
+    cfg = Config()
+    load_library().lm_default_config(C.byref(cfg), 1 if color_only else 0, width, height)
+    for k, v in overrides.items():
+        if k == "T":
+            cfg.pyramid_levels = len(v)
+            for i_, t in enumerate(v):
+                cfg.T[i_] = t
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+def merge_matches(lists):
+    """R-way merge + adjacent-unique of per-shard sorted match arrays (host side of SURVEY.md 8e)."""
+    lib = load_library()
+    stride = max([len(l) for l in lists] + [1])
+    buf = np.zeros((len(lists), stride), MATCH_DTYPE)
+    counts = np.zeros(len(lists), np.int32)
+    for k, l in enumerate(lists):
+        buf[k, :len(l)] = l
+        counts[k] = len(l)
+    out = np.zeros(int(counts.sum()) + 1, MATCH_DTYPE)
+    n = C.c_size_t()
+    rc = lib.lm_merge_matches(_ptr(buf), _ptr(counts), len(lists), stride, _ptr(out), out.size, C.byref(n))
+    if rc:
+        raise LinemodError(rc, lib.lm_last_error().decode())
+    return out[:n.value].copy()
+
+
+class Detector:
+    """cv::linemod::Detector as the reference uses it, on the GPU (see include/linemod_hip.h)."""
+
+    def __init__(self, cfg=None, **kw):
+        self.lib = load_library()
+        self.cfg = cfg if cfg is not None else default_config(**kw)
+        h = C.c_void_p()
+        self._check(self.lib.lm_create(C.byref(self.cfg), C.byref(h)))
+        self.h = h
+
+    def _check(self, rc):
+        if rc:
+            raise LinemodError(rc, self.lib.lm_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- queries -------------------------------------------------------------------------------
+    @property
+    def width(self):
+        return self.cfg.width
+
+    @property
+    def height(self):
+        return self.cfg.height
+
+    @property
+    def num_modalities(self):
+        return self.lib.lm_num_modalities(self.h)
+
+    @property
+    def pyramid_levels(self):
+        return self.lib.lm_pyramid_levels(self.h)
+
+    def get_T(self, level):
+        return self.lib.lm_get_T(self.h, level)
+
+    def num_classes(self):
+        return self.lib.lm_num_classes(self.h)
+
+    def num_templates(self):
+        return self.lib.lm_num_templates(self.h)
+
+    def class_num_templates(self, ci):
+        return self.lib.lm_class_num_templates(self.h, ci)
+
+    def class_ids(self):
+        return [self.lib.lm_class_id(self.h, k).decode() for k in range(self.num_classes())]
+
+    def find_class(self, class_id):
+        return self.lib.lm_find_class(self.h, class_id.encode())
+
+    # ---- tables --------------------------------------------------------------------------------
+    def set_similarity_lut(self, lut):
+        lut = _c(lut, np.uint8)
+        assert lut.size == 256
+        self._check(self.lib.lm_set_similarity_lut(self.h, _ptr(lut)))
+
+    def set_normal_lut(self, lut):
+        lut = _c(lut, np.uint8)
+        assert lut.size == 8000
+        self._check(self.lib.lm_set_normal_lut(self.h, _ptr(lut)))
+
+    def similarity_lut(self):
+        out = np.zeros(256, np.uint8)
+        self._check(self.lib.lm_get_similarity_lut(self.h, _ptr(out)))
+        return out
+
+    def normal_lut(self):
+        out = np.zeros(8000, np.uint8)
+        self._check(self.lib.lm_get_normal_lut(self.h, _ptr(out)))
+        return out
+
+    # ---- bank ----------------------------------------------------------------------------------
+    def add_class(self, class_id, descs, features):
+        descs = _c(descs, DESC_DTYPE)
+        features = _c(features, FEATURE_DTYPE)
+        per = self.cfg.pyramid_levels * self.cfg.num_modalities
+        if descs.size % per or int(descs["num_features"].sum()) != features.size:
+            raise ValueError("descs/features do not describe whole template pyramids")
+        ci = C.c_int()
+        self._check(self.lib.lm_add_class(self.h, class_id.encode(), descs.size // per, _ptr(descs), _ptr(features),
+                                          C.byref(ci)))
+        return ci.value
+
+    def add_template(self, class_id, bgr, depth=None, mask=None):
+        bgr = _c(bgr, np.uint8)
+        depth = None if depth is None else _c(depth, np.uint16)
+        mask = None if mask is None else _c(mask, np.uint8)
+        tid, bb = C.c_int(-1), Rect()
+        rc = self.lib.lm_add_template(self.h, class_id.encode(), _ptr(bgr), 0, _ptr(depth), 0, _ptr(mask), 0,
+                                      C.byref(tid), C.byref(bb))
+        if rc == LM_ERR_EXTRACT:
+            return -1, (0, 0, 0, 0)
+        self._check(rc)
+        return tid.value, (bb.x, bb.y, bb.width, bb.height)
+
+    def get_template(self, ci, tid, level, modality):
+        w, h, n = C.c_int(), C.c_int(), C.c_int()
+        self._check(self.lib.lm_get_template(self.h, ci, tid, level, modality, C.byref(w), C.byref(h), None, C.byref(n)))
+        feats = np.zeros(n.value, FEATURE_DTYPE)
+        self._check(self.lib.lm_get_template(self.h, ci, tid, level, modality, C.byref(w), C.byref(h), _ptr(feats),
+                                             C.byref(n)))
+        return w.value, h.value, feats
+
+    def save_bank(self, path):
+        self._check(self.lib.lm_save_bank(self.h, str(path).encode()))
+
+    def load_bank(self, path):
+        self._check(self.lib.lm_load_bank(self.h, str(path).encode()))
+
+    # ---- matching ------------------------------------------------------------------------------
+    def match(self, bgr, depth, threshold, class_idx=-1, cap=1 << 16):
+        bgr = _c(bgr, np.uint8)
+        depth = None if depth is None else _c(depth, np.uint16)
+        if bgr.shape != (self.cfg.height, self.cfg.width, 3):
+            raise ValueError("frame size does not match the detector")
+        out = np.zeros(cap, MATCH_DTYPE)
+        n = C.c_size_t()
+        rc = self.lib.lm_match(self.h, _ptr(bgr), 0, _ptr(depth), 0, threshold, class_idx, _ptr(out), cap, C.byref(n))
+        if rc == LM_ERR_OVERFLOW and n.value > cap:
+            return self.match(bgr, depth, threshold, class_idx, cap=n.value)
+        self._check(rc)
+        return out[:n.value].copy()
+
+    def upload_frame(self, slot, bgr, depth=None):
+        bgr = _c(bgr, np.uint8)
+        depth = None if depth is None else _c(depth, np.uint16)
+        if bgr.shape != (self.cfg.height, self.cfg.width, 3):
+            raise ValueError("frame size does not match the detector")
+        self._check(self.lib.lm_upload_frame(self.h, slot, _ptr(bgr), 0, _ptr(depth), 0))
+
+    def match_slot(self, slot, threshold, class_idx=-1, cap=1 << 16):
+        out = np.zeros(cap, MATCH_DTYPE)
+        n = C.c_size_t()
+        rc = self.lib.lm_match_slot(self.h, slot, threshold, class_idx, _ptr(out), cap, C.byref(n))
+        if rc == LM_ERR_OVERFLOW and n.value > cap:
+            return self.match_slot(slot, threshold, class_idx, cap=n.value)
+        self._check(rc)
+        return out[:n.value].copy()
+
+    def match_batch(self, n_slots, threshold, class_idx=-1, cap_per_frame=4096, out=None, counts=None):
+        if out is None:
+            out = np.zeros((n_slots, cap_per_frame), MATCH_DTYPE)
+        if counts is None:
+            counts = np.zeros(n_slots, np.int32)
+        self._check(self.lib.lm_match_batch(self.h, n_slots, threshold, class_idx, _ptr(out), cap_per_frame, _ptr(counts)))
+        return out, counts
+
+    # ---- stage hooks ---------------------------------------------------------------------------
+    def stage_color_quantize(self, bgr, weak_threshold=10.0, want_magnitude=False):
+        bgr = _c(bgr, np.uint8)
+        h, w, _ = bgr.shape
+        q = np.empty((h, w), np.uint8)
+        mag = np.empty((h, w), np.float32) if want_magnitude else None
+        self._check(self.lib.lm_stage_color_quantize(self.h, _ptr(bgr), w, h, weak_threshold, _ptr(q), _ptr(mag)))
+        return (q, mag) if want_magnitude else q
+
+    def stage_pyrdown(self, bgr):
+        bgr = _c(bgr, np.uint8)
+        h, w, _ = bgr.shape
+        out = np.empty((h // 2, w // 2, 3), np.uint8)
+        self._check(self.lib.lm_stage_pyrdown(self.h, _ptr(bgr), w, h, _ptr(out)))
+        return out
+
+    def stage_depth_quantize(self, depth):
+        depth = _c(depth, np.uint16)
+        h, w = depth.shape
+        out = np.empty((h, w), np.uint8)
+        self._check(self.lib.lm_stage_depth_quantize(self.h, _ptr(depth), w, h, _ptr(out)))
+        return out
+
+    def stage_linear_memories(self, quantized, T):
+        q = _c(quantized, np.uint8)
+        h, w = q.shape
+        out = np.empty((8, T * T, (h // T) * (w // T)), np.uint8)
+        self._check(self.lib.lm_stage_linear_memories(self.h, _ptr(q), w, h, T, _ptr(out)))
+        return out
+
+    def prepare_slot(self, slot):
+        self._check(self.lib.lm_prepare_slot(self.h, slot))
+
+    def debug_read(self, slot, what, level, modality):
+        n = C.c_size_t()
+        self._check(self.lib.lm_debug_read(self.h, slot, what, level, modality, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.uint8)
+        self._check(self.lib.lm_debug_read(self.h, slot, what, level, modality, _ptr(out), out.size, C.byref(n)))
+        return out
+
+    def stage_scan(self, slot, threshold, class_idx=-1, cap=1 << 20):
+        out = np.zeros((cap, 4), np.int32)
+        n = C.c_size_t()
+        self._check(self.lib.lm_stage_scan(self.h, slot, threshold, class_idx, _ptr(out), cap, C.byref(n)))
+        if n.value > cap:
+            return self.stage_scan(slot, threshold, class_idx, cap=n.value)
+        return out[:n.value].copy()
+
+    # ---- measurement ---------------------------------------------------------------------------
+    def time_scan(self, slot, threshold, class_idx=-1, iters=50, variant=0):
+        us, by = C.c_double(), C.c_double()
+        self._check(self.lib.lm_time_scan(self.h, slot, threshold, class_idx, iters, variant, C.byref(us), C.byref(by)))
+        return us.value, by.value
+
+    def time_stages(self, slot, threshold, class_idx=-1, iters=20):
+        out = (C.c_double * 4)()
+        self._check(self.lib.lm_time_stages(self.h, slot, threshold, class_idx, iters, out))
+        return list(out)
+
+    def set_scan_variant(self, variant):
+        self._check(self.lib.lm_set_scan_variant(self.h, variant))

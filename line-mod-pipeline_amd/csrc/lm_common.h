@@ -1,0 +1,64 @@
+// lm_common.h -- types shared by the HIP kernels and the host side of liblinemod_hip.so.
+//
+// HBM layout of one resident frame slot (all offsets in bytes, every block 256-B aligned):
+//   bgr[l]      level-l BGR image, dense [h_l][w_l][3] u8 (level 0 uploaded, l>0 by k_pyrdown)
+//   depth       level-0 depth, dense [h][w] u16
+//   quant[l][m] quantised image of modality m at level l, dense [h_l][w_l] u8 (one-hot or 0)
+//   lm[l]       linear-memory arena of level l:
+//                 [modality m][orientation o][memory g = (y%T)*T + x%T][position (y/T)*W + x/T]  u8
+//               each orientation block is followed by PAD zero bytes and the level ends with one
+//               more zero block; reads that upstream would make past an orientation's T*T x W*H
+//               cv::Mat land in those zeros (see oracle lm_read()).
+#pragma once
+#include <stdint.h>
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define LM_SCAN_CHUNK 1024      // positions one wave covers in the similarity scan (64 lanes x 16 B)
+#define LM_SCAN_FPAD 8          // feature lists are padded to a multiple of this with zero-block offsets
+#define LM_SORT_CAP 4096        // matches sorted by the single-workgroup LDS bitonic sort
+#define LM_DROPPED 0xFFFFFFFFu
+
+struct LmLevelGeom {
+    int w, h;          // quantised image size at this level
+    int T;             // spread size = linear-memory stride
+    int W, H;          // w/T, h/T
+    u32 wh;            // W*H = bytes per linear memory
+    u32 ori_stride;    // T*T*wh + pad
+    u32 mod_stride;    // 8*ori_stride
+    u32 zero_off;      // offset (inside the level arena) of a zero block of >= wh + 2*LM_SCAN_CHUNK bytes
+    u32 arena_bytes;   // M*mod_stride + zero block
+};
+
+// One candidate / refined match in flight between the scan and the sort.
+struct LmCand {
+    u32 ti;      // bank-local template index, LM_DROPPED once filtered out
+    int x, y;    // position at the level it was last refined at
+    float sim;   // similarity as upstream stores it at that point
+};
+
+// Refinement feature at a level above the lowest: byte offset of the unshifted feature inside the
+// level arena (modality and orientation block included) plus its template coordinates for the
+// bounds check of similarityLocal.
+struct LmRefFeat {
+    u32 off;
+    int16_t x, y;
+};
+
+struct LmRefMeta {
+    int width, height;   // tp[start].width/height: first modality's template size at this level
+    int nfeat_total;     // sum over modalities of features.size() at this level
+    u32 start[2];        // first LmRefFeat of modality m
+    u32 count[2];
+};
+
+// Device header read back after every match.
+struct LmHeader {
+    u32 cand_count;      // candidates produced by the scan (may exceed capacity)
+    u32 match_count;     // refined matches that passed the threshold (may exceed capacity)
+    u32 out_count;       // matches after sort + unique (only when sorted on device)
+    u32 sorted_on_device;
+};

@@ -1,0 +1,280 @@
+// lm_host.cpp -- host-only parts of liblinemod_hip.so (see lm_host.h).
+#include "lm_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace lmh {
+
+int Bank::find(const std::string& id) const {
+    for (size_t i = 0; i < classes.size(); ++i)
+        if (classes[i].id == id) return (int)i;
+    return -1;
+}
+
+int Bank::add_pyramid(const std::string& id, TemplatePyramid&& tp) {
+    int ci = find(id);
+    if (ci < 0) { classes.push_back(ClassEntry{id, {}}); ci = (int)classes.size() - 1; }
+    classes[ci].pyramids.push_back(std::move(tp));
+    return (int)classes[ci].pyramids.size() - 1;
+}
+
+int Bank::add_class(const std::string& id, int n_templates, const lm_template_desc* descs, const lm_feature* features,
+                    int levels, int modalities, std::string& err) {
+    const int per = levels * modalities;
+    // validate first so a bad call leaves the bank untouched
+    size_t fo = 0;
+    for (int t = 0; t < n_templates; ++t)
+        for (int k = 0; k < per; ++k) {
+            const lm_template_desc& ds = descs[(size_t)t * per + k];
+            if (ds.num_features < 0 || ds.num_features > LM_MAX_FEATURES) {
+                err = "template with more than 63 features (upstream CV_Assert(features.size() <= 63))";
+                return -1;
+            }
+            if (ds.pyramid_level != k / modalities) { err = "template descs must be ordered [level*M + modality]"; return -1; }
+            for (int f = 0; f < ds.num_features; ++f) {
+                const lm_feature& ft = features[fo + f];
+                if (ft.label < 0 || ft.label > 7) { err = "feature label outside 0..7"; return -1; }
+                if (ft.x < 0 || ft.y < 0 || ft.x > 32767 || ft.y > 32767) { err = "feature coordinate outside 0..32767"; return -1; }
+            }
+            fo += ds.num_features;
+        }
+    for (int t = 0; t < n_templates; ++t)
+        for (int l = 0; l < levels; ++l) {
+            int nf = 0;
+            for (int m = 0; m < modalities; ++m) nf += descs[(size_t)t * per + l * modalities + m].num_features;
+            if (nf == 0) { err = "template without features at a pyramid level (similarity would divide by zero)"; return -1; }
+        }
+    int ci = find(id);
+    if (ci < 0) { classes.push_back(ClassEntry{id, {}}); ci = (int)classes.size() - 1; }
+    fo = 0;
+    for (int t = 0; t < n_templates; ++t) {
+        TemplatePyramid tp(per);
+        for (int k = 0; k < per; ++k) {
+            const lm_template_desc& ds = descs[(size_t)t * per + k];
+            tp[k].width = ds.width; tp[k].height = ds.height; tp[k].pyramid_level = ds.pyramid_level;
+            tp[k].features.assign(features + fo, features + fo + ds.num_features);
+            fo += ds.num_features;
+        }
+        classes[ci].pyramids.push_back(std::move(tp));
+    }
+    return ci;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host bank -> device bank of this shard.
+//   scan (lowest level, upstream similarity()):  per (template, modality) a list of byte offsets
+//     off = m*mod_stride + label*ori_stride + ((y%T)*T + x%T)*W*H + (y/T)*W + x/T
+//   into the level arena, padded to `fpad` with offsets of the arena's zero block;
+//     P = span_y*W + span_x + 1 = template_positions.
+//   refine (levels above the lowest, upstream similarityLocal()): the same offset for the
+//     unshifted feature plus (x, y) for the bounds test after the patch offset is applied.
+// ------------------------------------------------------------------------------------------------
+bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom* geom, DeviceBankHost& out,
+                       std::string& err) {
+    const int M = cfg.num_modalities, L = cfg.pyramid_levels;
+    out = DeviceBankHost();
+    const LmLevelGeom& gl = geom[L - 1];
+    int maxf = 1;
+    for (const ClassEntry& c : bank.classes)
+        for (const TemplatePyramid& tp : c.pyramids)
+            for (int m = 0; m < M; ++m) maxf = std::max(maxf, (int)tp[(size_t)(L - 1) * M + m].features.size());
+    out.fpad = (maxf + LM_SCAN_FPAD - 1) / LM_SCAN_FPAD * LM_SCAN_FPAD;
+    const int nc = (int)bank.classes.size();
+    out.class_item_lo.assign(nc, 0); out.class_item_hi.assign(nc, 0);
+    out.class_t_lo.assign(nc, 0); out.class_t_hi.assign(nc, 0);
+    out.class_alg_bytes.assign(nc, 0.0);
+    for (int ci = 0; ci < nc; ++ci) {
+        const ClassEntry& c = bank.classes[ci];
+        int lo, hi;
+        shard_range((int)c.pyramids.size(), cfg.shard_rank, cfg.shard_size, &lo, &hi);
+        out.class_t_lo[ci] = (int)out.t_global.size();
+        out.class_item_lo[ci] = (int)out.item_t.size();
+        for (int tid = lo; tid < hi; ++tid) {
+            const TemplatePyramid& tp = c.pyramids[tid];
+            if ((int)tp.size() != L * M) { err = "template pyramid size mismatch"; return false; }
+            const u32 ti = (u32)out.t_global.size();
+            out.t_global.push_back(tid);
+            out.t_class.push_back(ci);
+            // ---- scan level
+            const Template& t0 = tp[(size_t)(L - 1) * M];
+            int n_total = 0;
+            int P = 0;
+            double fcount = 0;
+            for (int m = 0; m < M; ++m) {
+                const Template& t = tp[(size_t)(L - 1) * M + m];
+                n_total += (int)t.features.size();
+                // upstream computes the span per modality from that modality's own template size; all
+                // templates of one pyramid level share width/height after cropTemplates, so use each
+                // modality's own value and require them equal.
+                if (t.width != t0.width || t.height != t0.height) { err = "modalities of one pyramid level must share width/height"; return false; }
+                int wf = (t.width - 1) / gl.T + 1, hf = (t.height - 1) / gl.T + 1;
+                int span_x = gl.W - wf, span_y = gl.H - hf;
+                P = span_y * gl.W + span_x + 1;
+                if (P > (int)gl.wh) P = (int)gl.wh;
+                if (P < 0) P = 0;
+                int k = 0;
+                for (const lm_feature& f : t.features) {
+                    if (f.x < 0 || f.x >= gl.w || f.y < 0 || f.y >= gl.h) continue;  // similarity(): "discard feature if out of bounds"
+                    u32 off = (u32)m * gl.mod_stride + (u32)f.label * gl.ori_stride +
+                              (u32)((f.y % gl.T) * gl.T + (f.x % gl.T)) * gl.wh + (u32)(f.y / gl.T) * gl.W + (u32)(f.x / gl.T);
+                    out.scan_off.push_back(off);
+                    ++k;
+                }
+                fcount += k;
+                for (; k < out.fpad; ++k) out.scan_off.push_back(gl.zero_off);
+            }
+            out.scan_P.push_back(P);
+            out.scan_n.push_back(n_total);
+            out.class_alg_bytes[ci] += fcount * (double)P;
+            for (int ch = 0; ch * LM_SCAN_CHUNK < P; ++ch) { out.item_t.push_back(ti); out.item_chunk.push_back((u32)ch); }
+            // ---- refinement levels
+            for (int l = 0; l + 1 < L; ++l) {
+                const LmLevelGeom& g = geom[l];
+                LmRefMeta mt;
+                std::memset(&mt, 0, sizeof(mt));
+                mt.width = tp[(size_t)l * M].width;
+                mt.height = tp[(size_t)l * M].height;
+                for (int m = 0; m < M; ++m) {
+                    const Template& t = tp[(size_t)l * M + m];
+                    mt.nfeat_total += (int)t.features.size();
+                    mt.start[m] = (u32)out.ref_feat[l].size();
+                    mt.count[m] = (u32)t.features.size();
+                    for (const lm_feature& f : t.features) {
+                        LmRefFeat rf;
+                        rf.off = (u32)m * g.mod_stride + (u32)f.label * g.ori_stride +
+                                 (u32)((f.y % g.T) * g.T + (f.x % g.T)) * g.wh + (u32)(f.y / g.T) * g.W + (u32)(f.x / g.T);
+                        rf.x = (int16_t)f.x; rf.y = (int16_t)f.y;
+                        out.ref_feat[l].push_back(rf);
+                    }
+                }
+                out.ref_meta[l].push_back(mt);
+            }
+        }
+        out.class_t_hi[ci] = (int)out.t_global.size();
+        out.class_item_hi[ci] = (int)out.item_t.size();
+    }
+    return true;
+}
+
+// SIMILARITY_LUT default: linear max(0, 4 - |ori - bit|) (layout [ori][lo 16 | hi 16]).
+void default_similarity_lut(u8 lut[256]) {
+    for (int ori = 0; ori < 8; ++ori)
+        for (int half = 0; half < 2; ++half)
+            for (int v = 0; v < 16; ++v) {
+                int best = 0;
+                for (int b = 0; b < 4; ++b)
+                    if (v & (1 << b)) best = std::max(best, std::max(0, 4 - std::abs(ori - (half * 4 + b))));
+                lut[32 * ori + 16 * half + v] = (u8)best;
+            }
+}
+
+// NORMAL_LUT default (our documented rule): azimuth of the cell centre, 8 bins.
+void default_normal_lut(u8 lut[8000]) {
+    const double PI = 3.14159265358979323846;
+    for (int v3 = 0; v3 < 20; ++v3)
+        for (int v2 = 0; v2 < 20; ++v2)
+            for (int v1 = 0; v1 < 20; ++v1) {
+                double nx = (v1 + 0.5 - 10.0) / 10.0, ny = (v2 + 0.5 - 10.0) / 10.0;
+                double a = std::atan2(ny, nx);
+                if (a < 0) a += 2 * PI;
+                int bin = (int)std::floor(a / (PI / 4.0));
+                if (bin > 7) bin = 7;
+                lut[v3 * 400 + v2 * 20 + v1] = (u8)(1u << bin);
+            }
+}
+
+bool match_less(const lm_match_t& a, const lm_match_t& b) {
+    if (a.similarity != b.similarity) return a.similarity > b.similarity;
+    if (a.template_id != b.template_id) return a.template_id < b.template_id;
+    if (a.class_idx != b.class_idx) return a.class_idx < b.class_idx;
+    if (a.y != b.y) return a.y < b.y;
+    return a.x < b.x;
+}
+bool match_eq(const lm_match_t& a, const lm_match_t& b) {
+    return a.x == b.x && a.y == b.y && a.similarity == b.similarity && a.class_idx == b.class_idx;
+}
+void sort_unique(std::vector<lm_match_t>& v) {
+    std::sort(v.begin(), v.end(), match_less);
+    v.erase(std::unique(v.begin(), v.end(), match_eq), v.end());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bank file: "LMBK0001" | u32 levels | u32 modalities | u32 T[levels] | u32 n_classes |
+//   per class { u32 id_len | id bytes | u32 n_templates | descs[n*levels*M] | u32 n_features | features[] }
+// little endian, descs/features in the lm_template_desc / lm_feature layouts.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct File {
+    FILE* f;
+    explicit File(FILE* fp) : f(fp) {}
+    ~File() { if (f) fclose(f); }
+};
+bool wr(FILE* f, const void* p, size_t n) { return n == 0 || fwrite(p, 1, n, f) == n; }
+bool rd(FILE* f, void* p, size_t n) { return n == 0 || fread(p, 1, n, f) == n; }
+}  // namespace
+
+bool save_bank(const Bank& bank, const lm_config& cfg, const char* path, std::string& err) {
+    File fh(fopen(path, "wb"));
+    if (!fh.f) { err = std::string("cannot open for writing: ") + path; return false; }
+    const u32 L = (u32)cfg.pyramid_levels, M = (u32)cfg.num_modalities;
+    bool ok = wr(fh.f, "LMBK0001", 8) && wr(fh.f, &L, 4) && wr(fh.f, &M, 4);
+    for (u32 l = 0; l < L; ++l) { u32 t = (u32)cfg.T[l]; ok = ok && wr(fh.f, &t, 4); }
+    u32 nc = (u32)bank.classes.size();
+    ok = ok && wr(fh.f, &nc, 4);
+    for (const ClassEntry& c : bank.classes) {
+        u32 len = (u32)c.id.size(), nt = (u32)c.pyramids.size();
+        ok = ok && wr(fh.f, &len, 4) && wr(fh.f, c.id.data(), len) && wr(fh.f, &nt, 4);
+        std::vector<lm_template_desc> descs;
+        std::vector<lm_feature> feats;
+        for (const TemplatePyramid& tp : c.pyramids)
+            for (const Template& t : tp) {
+                descs.push_back(lm_template_desc{t.width, t.height, t.pyramid_level, (int32_t)t.features.size()});
+                feats.insert(feats.end(), t.features.begin(), t.features.end());
+            }
+        u32 nf = (u32)feats.size();
+        ok = ok && wr(fh.f, descs.data(), descs.size() * sizeof(lm_template_desc)) && wr(fh.f, &nf, 4) &&
+             wr(fh.f, feats.data(), feats.size() * sizeof(lm_feature));
+    }
+    if (!ok) { err = std::string("short write: ") + path; return false; }
+    return true;
+}
+
+bool load_bank(Bank& bank, const lm_config& cfg, const char* path, std::string& err) {
+    File fh(fopen(path, "rb"));
+    if (!fh.f) { err = std::string("cannot open: ") + path; return false; }
+    char magic[8];
+    u32 L = 0, M = 0;
+    if (!rd(fh.f, magic, 8) || std::memcmp(magic, "LMBK0001", 8) != 0) { err = "not a linemod bank file"; return false; }
+    if (!rd(fh.f, &L, 4) || !rd(fh.f, &M, 4)) { err = "truncated bank file"; return false; }
+    if ((int)L != cfg.pyramid_levels || (int)M != cfg.num_modalities) { err = "bank was written for a different detector (levels/modalities)"; return false; }
+    for (u32 l = 0; l < L; ++l) {
+        u32 t = 0;
+        if (!rd(fh.f, &t, 4)) { err = "truncated bank file"; return false; }
+        if ((int)t != cfg.T[l]) { err = "bank was written for a different T pyramid"; return false; }
+    }
+    u32 nc = 0;
+    if (!rd(fh.f, &nc, 4)) { err = "truncated bank file"; return false; }
+    Bank nb;
+    for (u32 c = 0; c < nc; ++c) {
+        u32 len = 0, nt = 0, nf = 0;
+        if (!rd(fh.f, &len, 4) || len > 4096) { err = "corrupt bank file"; return false; }
+        std::string id(len, '\0');
+        if (!rd(fh.f, &id[0], len) || !rd(fh.f, &nt, 4)) { err = "truncated bank file"; return false; }
+        std::vector<lm_template_desc> descs((size_t)nt * L * M);
+        if (!rd(fh.f, descs.data(), descs.size() * sizeof(lm_template_desc)) || !rd(fh.f, &nf, 4)) { err = "truncated bank file"; return false; }
+        unsigned long long want = 0;
+        for (const auto& ds : descs) want += (unsigned)std::max(ds.num_features, 0);
+        if (want != nf) { err = "corrupt bank file (feature count)"; return false; }
+        std::vector<lm_feature> feats(nf);
+        if (!rd(fh.f, feats.data(), feats.size() * sizeof(lm_feature))) { err = "truncated bank file"; return false; }
+        if (nb.add_class(id, (int)nt, descs.data(), feats.data(), (int)L, (int)M, err) < 0) return false;
+        if (nt == 0 && nb.find(id) < 0) nb.classes.push_back(ClassEntry{id, {}});
+    }
+    bank = std::move(nb);
+    return true;
+}
+
+}  // namespace lmh

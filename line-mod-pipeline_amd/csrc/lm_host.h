@@ -1,0 +1,68 @@
+// lm_host.h -- host-only parts of liblinemod_hip.so: the template bank as the caller sees it
+// (classes -> template pyramids -> features, cv::linemod::Detector's class_templates map), its
+// translation into the device bank of one shard, the bank file format, the default tables and the
+// host-side sort/merge of match records.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/linemod_hip.h"
+#include "lm_common.h"
+
+namespace lmh {
+
+struct Template {  // cv::linemod::Template
+    int width = 0, height = 0, pyramid_level = 0;
+    std::vector<lm_feature> features;
+};
+typedef std::vector<Template> TemplatePyramid;  // [level * M + modality]
+
+struct ClassEntry {
+    std::string id;
+    std::vector<TemplatePyramid> pyramids;  // index = template_id
+};
+
+struct Bank {
+    std::vector<ClassEntry> classes;
+    int find(const std::string& id) const;
+    // returns class index or -1 (err set)
+    int add_class(const std::string& id, int n_templates, const lm_template_desc* descs, const lm_feature* features,
+                  int levels, int modalities, std::string& err);
+    int add_pyramid(const std::string& id, TemplatePyramid&& tp);  // returns template id
+};
+
+// Host image of the device bank of one shard (uploaded verbatim by lm_detector.hip).
+struct DeviceBankHost {
+    int fpad = LM_SCAN_FPAD;
+    std::vector<int> t_global, t_class;            // [nt] global template id / class index
+    std::vector<u32> scan_off;                     // [nt][M][fpad]
+    std::vector<int> scan_P, scan_n;               // [nt]
+    std::vector<u32> item_t, item_chunk;           // scan work items, contiguous per class
+    std::vector<int> class_item_lo, class_item_hi; // [n_classes]
+    std::vector<int> class_t_lo, class_t_hi;       // bank-local template range per class
+    std::vector<double> class_alg_bytes;           // sum_t sum_m F_m(t) * P(t) per class
+    std::vector<LmRefMeta> ref_meta[LM_MAX_LEVELS];
+    std::vector<LmRefFeat> ref_feat[LM_MAX_LEVELS];
+};
+
+// Contiguous template_id range of shard `rank` of `size` for a class of n templates.
+inline void shard_range(int n, int rank, int size, int* lo, int* hi) {
+    *lo = (int)((long long)n * rank / size);
+    *hi = (int)((long long)n * (rank + 1) / size);
+}
+
+bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom* geom, DeviceBankHost& out,
+                       std::string& err);
+
+void default_similarity_lut(u8 lut[256]);
+void default_normal_lut(u8 lut[8000]);
+
+// Total order of SURVEY.md A.9 and upstream Match::operator==.
+bool match_less(const lm_match_t& a, const lm_match_t& b);
+bool match_eq(const lm_match_t& a, const lm_match_t& b);
+void sort_unique(std::vector<lm_match_t>& v);
+
+bool save_bank(const Bank& bank, const lm_config& cfg, const char* path, std::string& err);
+bool load_bank(Bank& bank, const lm_config& cfg, const char* path, std::string& err);
+
+}  // namespace lmh

@@ -1,0 +1,653 @@
+// lm_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the LINE-MOD match path.
+//
+// One kernel per upstream stage group:
+//   k_pyrdown            a4   cv::pyrDown of the BGR source
+//   k_color_quantize     a3   GaussianBlur 7x7 + Sobel + max-channel + fastAtan2 + 3x3 vote, LDS-tiled
+//   k_depth_quantize     a5   bilateral normals + NORMAL_LUT + 5x5 median, LDS-tiled
+//   k_linear_memories    a6-a10  NN pyrDown read + spread(T) + response LUT + linearize, one row band per WG
+//   k_scan               a11-a13 similarity scan of the lowest level fused with the threshold scan (HOT)
+//   k_refine             a14  similarityLocal 16x16 + first-max argmax + rescore + threshold filter
+//   k_sort_unique        a15  LDS bitonic sort + adjacent-unique under the total order of SURVEY.md A.9
+//
+// All arithmetic is integer/byte except two float islands (fastAtan2 polynomial, normal
+// normalisation) which use the explicit round-to-nearest intrinsics in the oracle's operation order,
+// so every stage is bit-identical to oracle/linemod_oracle.cpp.  No MFMA: this is OR / LUT / u8 add.
+#include <hip/hip_runtime.h>
+#include "lm_common.h"
+#include "lm_kernels.h"
+
+namespace {
+
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(1))) U32x4U { u32x4 v; };
+struct __attribute__((packed, aligned(1))) U32x2U { u32x2 v; };
+struct __attribute__((packed, aligned(1))) U32U { u32 v; };
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int refl101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) { if (p < 0) p = -p; else p = 2 * n - 2 - p; }
+    return p;
+}
+__device__ __forceinline__ u32x4 ld16u(const u8* p) { return reinterpret_cast<const U32x4U*>(p)->v; }
+__device__ __forceinline__ u32x2 ld8u(const u8* p) { return reinterpret_cast<const U32x2U*>(p)->v; }
+__device__ __forceinline__ u32 ld4u(const u8* p) { return reinterpret_cast<const U32U*>(p)->v; }
+
+// ------------------------------------------------------------------------------------------------
+// a4  cv::pyrDown, CV_8UC3: 5x5 [1 4 6 4 1]^2, BORDER_REFLECT_101, (sum + 128) >> 8
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyrdown(const u8* __restrict__ src, int sw, int sh, u8* __restrict__ dst,
+                                                  int dw, int dh) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const int K[5] = {1, 4, 6, 4, 1};
+    int xs[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) xs[i] = refl101(2 * x + i - 2, sw) * 3;
+    int s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const u8* row = src + (size_t)refl101(2 * y + j - 2, sh) * sw * 3;
+        int r0 = 0, r1 = 0, r2 = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const u8* p = row + xs[i];
+            r0 += K[i] * p[0]; r1 += K[i] * p[1]; r2 += K[i] * p[2];
+        }
+        s0 += K[j] * r0; s1 += K[j] * r1; s2 += K[j] * r2;
+    }
+    u8* o = dst + ((size_t)y * dw + x) * 3;
+    o[0] = (u8)((s0 + 128) >> 8); o[1] = (u8)((s1 + 128) >> 8); o[2] = (u8)((s2 + 128) >> 8);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a3  ColorGradient::process.  One 64x16 output tile per workgroup; the 7x7 blur (+-3), the Sobel
+// (+-1) and the vote (+-1) need a 5-pixel halo, all staged through LDS.
+// ------------------------------------------------------------------------------------------------
+#define CT_W 64
+#define CT_H 16
+#define RAW_W (CT_W + 10)
+#define RAW_H (CT_H + 10)
+#define SM_W (CT_W + 4)
+#define SM_H (CT_H + 4)
+#define Q_W (CT_W + 2)
+#define Q_H (CT_H + 2)
+
+// cv::fastAtan2 polynomial in degrees -- same operation order as oracle fast_atan2_deg().
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180.0 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180.0 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180.0 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180.0 / 3.14159265358979323846);
+    const float eps = (float)2.2204460492503131e-16;
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_color_quantize(const u8* __restrict__ bgr, int w, int h, float thr2,
+                                                         u8* __restrict__ quant, float* __restrict__ mag) {
+    __shared__ u8 raw[RAW_H][RAW_W * 3];
+    __shared__ u16 hb[RAW_H][SM_W * 3];
+    __shared__ u8 sm[SM_H][SM_W * 3];
+    __shared__ u8 qn[Q_H][Q_W];
+    const int tid = threadIdx.x;
+    const int ox = blockIdx.x * CT_W, oy = blockIdx.y * CT_H;
+
+    // raw tile, replicate-clamped coordinates
+    for (int i = tid; i < RAW_H * RAW_W; i += 256) {
+        int ry = i / RAW_W, rx = i - ry * RAW_W;
+        int gy = clampi(oy - 5 + ry, 0, h - 1), gx = clampi(ox - 5 + rx, 0, w - 1);
+        const u8* p = bgr + ((size_t)gy * w + gx) * 3;
+        raw[ry][rx * 3 + 0] = p[0]; raw[ry][rx * 3 + 1] = p[1]; raw[ry][rx * 3 + 2] = p[2];
+    }
+    __syncthreads();
+    // horizontal 7-tap {8,28,56,72,56,28,8} at the CLAMPED centre column (Sobel replicates the
+    // smoothed image, so smoothed(-1) must equal smoothed(0), not a blur centred outside)
+    for (int i = tid; i < RAW_H * SM_W; i += 256) {
+        int ry = i / SM_W, tx = i - ry * SM_W;
+        int cx = (clampi(ox - 2 + tx, 0, w - 1) - (ox - 5)) * 3;
+        const u8* r = &raw[ry][0];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int s = 8 * (r[cx - 9 + c] + r[cx + 9 + c]) + 28 * (r[cx - 6 + c] + r[cx + 6 + c]) +
+                    56 * (r[cx - 3 + c] + r[cx + 3 + c]) + 72 * r[cx + c];
+            hb[ry][tx * 3 + c] = (u16)s;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < SM_H * SM_W; i += 256) {
+        int ty = i / SM_W, tx = i - ty * SM_W;
+        int cy = clampi(oy - 2 + ty, 0, h - 1) - (oy - 5);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int k = tx * 3 + c;
+            u32 s = 8u * (hb[cy - 3][k] + hb[cy + 3][k]) + 28u * (hb[cy - 2][k] + hb[cy + 2][k]) +
+                    56u * (hb[cy - 1][k] + hb[cy + 1][k]) + 72u * hb[cy][k];
+            sm[ty][k] = (u8)((s + 32768u) >> 16);
+        }
+    }
+    __syncthreads();
+    // Sobel (CV_16S) on the three channels, strongest channel, orientation, 16 -> 8 bins
+    const float scale = (float)(16.0 / 360.0);
+    for (int i = tid; i < Q_H * Q_W; i += 256) {
+        int qy = i / Q_W, qx = i - qy * Q_W;
+        int gy = oy - 1 + qy, gx = ox - 1 + qx;
+        u8 out = 0;
+        if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
+            int bdx = 0, bdy = 0, bm = -1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                int a00 = sm[qy][qx * 3 + c], a01 = sm[qy][qx * 3 + 3 + c], a02 = sm[qy][qx * 3 + 6 + c];
+                int a10 = sm[qy + 1][qx * 3 + c], a12 = sm[qy + 1][qx * 3 + 6 + c];
+                int a20 = sm[qy + 2][qx * 3 + c], a21 = sm[qy + 2][qx * 3 + 3 + c], a22 = sm[qy + 2][qx * 3 + 6 + c];
+                int dx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
+                int dy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
+                int m = dx * dx + dy * dy;
+                // upstream cascade: B if >= both, else G if >= both, else R  ==  first strict maximum wins ties
+                if (m > bm) { bm = m; bdx = dx; bdy = dy; }
+            }
+            float ang = fast_atan2_deg((float)bdy, (float)bdx);
+            float qf = rintf(__fadd_rn(__fmul_rn(ang, scale), 0.0f));
+            int q = (int)qf;
+            q = q < 0 ? 0 : (q > 255 ? 255 : q);
+            bool border = (gy == 0) | (gy == h - 1) | (gx == 0) | (gx == w - 1);
+            out = border ? 0 : (u8)(q & 7);
+            float fm = (float)bm;
+            if (fm > thr2) out |= 0x80;
+            if (mag && qy >= 1 && qy <= CT_H && qx >= 1 && qx <= CT_W) mag[(size_t)gy * w + gx] = fm;
+        }
+        qn[qy][qx] = out;
+    }
+    __syncthreads();
+    // 3x3 majority vote (>= 5 of 9) gated by magnitude
+    for (int i = tid; i < CT_H * CT_W; i += 256) {
+        int ty = i / CT_W, tx = i - ty * CT_W;
+        int gy = oy + ty, gx = ox + tx;
+        if (gy >= h || gx >= w) continue;
+        u8 res = 0;
+        if (gy >= 1 && gy <= h - 2 && gx >= 1 && gx <= w - 2 && (qn[ty + 1][tx + 1] & 0x80)) {
+            u32 cnt = 0;  // eight 4-bit counters
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int ii = 0; ii < 3; ++ii) cnt += 1u << (4 * (qn[ty + j][tx + ii] & 7));
+            int best = 0, idx = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                int v = (cnt >> (4 * b)) & 15;
+                if (best < v) { best = v; idx = b; }
+            }
+            if (best >= 5) res = (u8)(1u << idx);
+        }
+        quant[(size_t)gy * w + gx] = res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a5  DepthNormal::process -> quantizedNormals + medianBlur(5).
+// ------------------------------------------------------------------------------------------------
+#define DT_W 64
+#define DT_H 16
+#define N_W (DT_W + 4)
+#define N_H (DT_H + 4)
+
+__device__ __forceinline__ u8 normal_at(const u16* __restrict__ depth, int w, int h, int y, int x, int dist_thr,
+                                        int diff_thr, const u8* __restrict__ lut) {
+    if (y < 5 || y >= h - 6 || x < 5 || x >= w - 6) return 0;
+    long long d = depth[(size_t)y * w + x];
+    if (!(d < dist_thr)) return 0;
+    long long A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+    for (int jj = -1; jj <= 1; ++jj)
+#pragma unroll
+        for (int ii = -1; ii <= 1; ++ii) {
+            if (ii == 0 && jj == 0) continue;
+            long long i = ii * 5, j = jj * 5;
+            long long delta = (long long)depth[(size_t)(y + j) * w + (x + i)] - d;
+            long long ad = delta < 0 ? -delta : delta;
+            long long f = ad < diff_thr ? 1 : 0;
+            long long fi = f * i, fj = f * j;
+            A0 += fi * i; A1 += fi * j; A3 += fj * j;
+            b0 += fi * delta; b1 += fj * delta;
+        }
+    long long det = A0 * A3 - A1 * A1;
+    long long ddx = A3 * b0 - A1 * b1;
+    long long ddy = -A1 * b0 + A0 * b1;
+    float nx = (float)(1150 * ddx);
+    float ny = (float)(1150 * ddy);
+    float nz = (float)(-det * d);
+    float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+    if (!(len > 0)) return 0;
+    float inv = __fdiv_rn(1.0f, len);
+    nx = __fmul_rn(nx, inv); ny = __fmul_rn(ny, inv); nz = __fmul_rn(nz, inv);
+    int v1 = (int)__fadd_rn(__fmul_rn(nx, 10.f), 10.f);
+    int v2 = (int)__fadd_rn(__fmul_rn(ny, 10.f), 10.f);
+    int v3 = (int)__fadd_rn(__fmul_rn(nz, 20.f), 20.f);
+    int flat = v3 * 400 + v2 * 20 + v1;
+    return (flat >= 0 && flat < 8000) ? lut[flat] : 0;
+}
+
+__global__ __launch_bounds__(256) void k_depth_quantize(const u16* __restrict__ depth, int w, int h, int dist_thr,
+                                                         int diff_thr, const u8* __restrict__ lut,
+                                                         u8* __restrict__ quant) {
+    __shared__ u8 nt[N_H][N_W];
+    const int tid = threadIdx.x;
+    const int ox = blockIdx.x * DT_W, oy = blockIdx.y * DT_H;
+    for (int i = tid; i < N_H * N_W; i += 256) {
+        int ty = i / N_W, tx = i - ty * N_W;
+        int gy = clampi(oy - 2 + ty, 0, h - 1), gx = clampi(ox - 2 + tx, 0, w - 1);  // medianBlur: BORDER_REPLICATE
+        nt[ty][tx] = normal_at(depth, w, h, gy, gx, dist_thr, diff_thr, lut);
+    }
+    __syncthreads();
+    for (int i = tid; i < DT_H * DT_W; i += 256) {
+        int ty = i / DT_W, tx = i - ty * DT_W;
+        int gy = oy + ty, gx = ox + tx;
+        if (gy >= h || gx >= w) continue;
+        u32 v[25];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int ii = 0; ii < 5; ++ii) v[j * 5 + ii] = nt[ty + j][tx + ii];
+        // median of 25 = largest t with #{v >= t} >= 13, built bit by bit
+        u32 res = 0;
+#pragma unroll
+        for (int bit = 7; bit >= 0; --bit) {
+            u32 cand = res | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 25; ++k) cnt += (v[k] >= cand) ? 1 : 0;
+            if (cnt >= 13) res = cand;
+        }
+        quant[(size_t)gy * w + gx] = (u8)res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a6-a10  One workgroup per band of T image rows (= one row of every linear memory).
+//   LDS: response table (256 x u64: byte o = response of orientation o to spread value v),
+//        (2T-1) source rows, their horizontal OR.
+// Thread unit = (row-in-band j, column phase c0, four consecutive memory columns) so each of the 8
+// orientation stores is one aligned dword and a wave writes runs of W contiguous bytes.
+// ------------------------------------------------------------------------------------------------
+template <int SRC_SHIFT>
+__global__ __launch_bounds__(256) void k_linear_memories(const u8* __restrict__ q, int qpitch, int w, int h, int T,
+                                                          const u64* __restrict__ resp_tab, u8* __restrict__ lm,
+                                                          u32 ori_stride) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const int W = w / T;
+    const u32 wh = (u32)W * (u32)(h / T);
+    const int rows = 2 * T - 1;
+    const int pitch = (w + T + 3) & ~3;
+    u64* tab = reinterpret_cast<u64*>(smem);
+    u8* qs = smem + 2048;
+    u8* ho = qs + rows * pitch;
+    const int tid = threadIdx.x;
+    const int band = blockIdx.x;
+    const int y0 = band * T;
+
+    for (int i = tid; i < 256; i += 256) tab[i] = resp_tab[i];
+    for (int i = tid; i < rows * pitch; i += 256) {
+        int yy = i / pitch, xx = i - yy * pitch;
+        int gy = y0 + yy;
+        u8 v = 0;
+        if (gy < h && xx < w) v = SRC_SHIFT ? q[(size_t)(2 * gy) * qpitch + 2 * xx] : q[(size_t)gy * qpitch + xx];
+        qs[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < rows * w; i += 256) {
+        int yy = i / w, xx = i - yy * w;
+        const u8* p = qs + yy * pitch + xx;
+        u8 v = 0;
+        for (int c = 0; c < T; ++c) v |= p[c];
+        ho[yy * pitch + xx] = v;
+    }
+    __syncthreads();
+    if ((W & 3) == 0) {
+        const int W4 = W >> 2;
+        const int units = T * T * W4;
+        for (int u = tid; u < units; u += 256) {
+            int k4 = u % W4, g = u / W4;
+            int j = g / T, c0 = g - j * T;
+            u64 e[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int x = (4 * k4 + i) * T + c0;
+                const u8* p = ho + j * pitch + x;
+                u8 sv = 0;
+                for (int r = 0; r < T; ++r) sv |= p[r * pitch];
+                e[i] = tab[sv];
+            }
+            u8* dst = lm + (size_t)g * wh + (size_t)band * W + 4 * k4;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                u32 v = (u32)((e[0] >> (8 * o)) & 0xFF) | ((u32)((e[1] >> (8 * o)) & 0xFF) << 8) |
+                        ((u32)((e[2] >> (8 * o)) & 0xFF) << 16) | ((u32)((e[3] >> (8 * o)) & 0xFF) << 24);
+                *reinterpret_cast<u32*>(dst + (size_t)o * ori_stride) = v;
+            }
+        }
+    } else {
+        const int units = T * T * W;
+        for (int u = tid; u < units; u += 256) {
+            int k = u % W, g = u / W;
+            int j = g / T, c0 = g - j * T;
+            const u8* p = ho + j * pitch + k * T + c0;
+            u8 sv = 0;
+            for (int r = 0; r < T; ++r) sv |= p[r * pitch];
+            u64 e = tab[sv];
+            u8* dst = lm + (size_t)g * wh + (size_t)band * W + k;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) dst[(size_t)o * ori_stride] = (u8)(e >> (8 * o));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a11-a13  HOT KERNEL.  One wave per (template, chunk of 1024 positions): lane l owns positions
+// [16 l, 16 l + 16) of the chunk.  For every feature the wave reads 1 KiB contiguous from the
+// feature's linear memory at a wave-uniform byte offset (scalar-loaded from the bank) and adds it
+// byte-wise: four u32 adds carry sixteen u8 lanes, 63 features x 4 = 252 never overflows a byte.
+// Modalities are then widened to u16 and summed (a12) and compared with the raw threshold (a13)
+// without ever materialising the similarity map.  Feature lists are padded to a multiple of 8 with
+// offsets into the arena's zero block so the inner loop has no tail.
+// ------------------------------------------------------------------------------------------------
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
+    if (wave >= a.n_items) return;
+    const u32 ti = a.item_t[a.item_lo + wave];
+    const u32 chunk = a.item_chunk[a.item_lo + wave];
+    const int P = a.scan_P[ti];
+    const int n = a.scan_n[ti];
+    const int thr = a.raw_thr_by_n[n];
+    const u32 j0 = chunk * LM_SCAN_CHUNK + (u32)lane * 16u;
+    const u8* base = a.lm + j0;
+
+    u32 tl[4] = {0, 0, 0, 0}, th[4] = {0, 0, 0, 0};  // u16 pairs: bytes {0,2} and {1,3} of each dword
+    for (int m = 0; m < a.M; ++m) {
+        const u32* offs = a.scan_off + ((size_t)ti * a.M + m) * a.fpad;
+        u32x4 acc = {0, 0, 0, 0};
+        for (int f = 0; f < a.fpad; f += UNROLL) {
+            u32x4 v[UNROLL];
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) v[k] = ld16u(base + offs[f + k]);
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) acc += v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tl[k] += acc[k] & 0x00FF00FFu;
+            th[k] += (acc[k] >> 8) & 0x00FF00FFu;
+        }
+    }
+    // threshold scan: strict >, positions >= P hold 0 upstream (never a candidate since thr >= 0)
+    u32 hit = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int s0 = (int)(tl[k] & 0xFFFF), s1 = (int)(th[k] & 0xFFFF), s2 = (int)(tl[k] >> 16), s3 = (int)(th[k] >> 16);
+        hit |= (s0 > thr ? 1u : 0u) << (4 * k) | (s1 > thr ? 1u : 0u) << (4 * k + 1) |
+               (s2 > thr ? 1u : 0u) << (4 * k + 2) | (s3 > thr ? 1u : 0u) << (4 * k + 3);
+    }
+    // drop positions at or beyond template_positions
+    int valid = P - (int)j0;  // number of valid positions in this lane's 16
+    if (valid <= 0) hit = 0;
+    else if (valid < 16) hit &= (1u << valid) - 1u;
+    if (!__any(hit != 0)) return;
+    const int offset = a.T / 2 + (a.T % 2 - 1);
+    while (hit) {
+        int b = __ffs(hit) - 1;
+        hit &= hit - 1;
+        int k = b >> 2, bb = b & 3;
+        int raw = (bb == 0) ? (int)(tl[k] & 0xFFFF) : (bb == 1) ? (int)(th[k] & 0xFFFF) : (bb == 2) ? (int)(tl[k] >> 16) : (int)(th[k] >> 16);
+        int j = (int)j0 + b;
+        int r = j / a.W, c = j - r * a.W;
+        u32 slot = atomicAdd(a.cand_count, 1u);
+        if (slot < a.cand_cap) {
+            LmCand cd;
+            cd.ti = ti;
+            cd.x = c * a.T + offset;
+            cd.y = r * a.T + offset;
+            cd.sim = __fadd_rn(__fdiv_rn(__fmul_rn((float)raw, 100.f), (float)(4 * n)), 0.5f);
+            a.cand[slot] = cd;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a14  One wave per candidate: lane l holds the 4 patch positions (row l/4, cols 4(l%4)..+3) of the
+// 16x16 patch; each feature is one unaligned dword load per lane (a 16-byte row segment per 4 lanes).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        u32 o = (u32)__shfl_xor((int)v, s, 64);
+        v = v > o ? v : o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void emit_key(const LmRefineArgs& a, u32 ti, int x, int y, float sim) {
+    u32 slot = atomicAdd(a.match_count, 1u);
+    if (slot < a.match_cap) {
+        u32 sb = __float_as_uint(sim);
+        u64 hi = ((u64)(~sb) << 32) | (u32)a.t_global[ti];
+        u64 lo = ((u64)(u32)a.t_class[ti] << 48) | ((u64)((u32)(y + 0x800000) & 0xFFFFFFu) << 24) |
+                 (u64)((u32)(x + 0x800000) & 0xFFFFFFu);
+        a.keys[2 * (size_t)slot] = hi;
+        a.keys[2 * (size_t)slot + 1] = lo;
+    }
+}
+
+template <bool LAST>
+__global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
+    const int lane = threadIdx.x & 63;
+    const u32 wave0 = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
+    const u32 nwaves = gridDim.x * 4u;
+    u32 n = *a.cand_count;
+    if (n > a.cand_cap) n = a.cand_cap;
+    const int T = a.g.T, W = a.g.W;
+    const int border = 8 * T;
+    const int offset = T / 2 + (T % 2 - 1);
+    const int lane_off = (lane >> 2) * W + (lane & 3) * 4;
+    for (u32 i = wave0; i < n; i += nwaves) {
+        LmCand c = a.cand[i];
+        u32 ti = (u32)__builtin_amdgcn_readfirstlane((int)c.ti);
+        if (ti == LM_DROPPED) continue;
+        int cx = __builtin_amdgcn_readfirstlane(c.x), cy = __builtin_amdgcn_readfirstlane(c.y);
+        const LmRefMeta mt = a.meta[ti];
+        int max_x = a.g.w - mt.width - border, max_y = a.g.h - mt.height - border;
+        int x = cx * 2 + 1, y = cy * 2 + 1;
+        x = x > border ? x : border; y = y > border ? y : border;
+        x = x < max_x ? x : max_x;  y = y < max_y ? y : max_y;
+        int bx = x / T - 8, by = y / T - 8;
+        int off_x = bx * T, off_y = by * T;
+        const u8* base = a.lm + (by * W + bx) + lane_off;
+        u32 tl = 0, th = 0;
+        for (int m = 0; m < a.M; ++m) {
+            const LmRefFeat* fp = a.feats + mt.start[m];
+            const int cnt = (int)mt.count[m];
+            u32 acc = 0;
+            for (int f = 0; f < cnt; ++f) {
+                LmRefFeat ft = fp[f];
+                int fx = ft.x + off_x, fy = ft.y + off_y;
+                if (fx < 0 || fy < 0 || fx >= a.g.w || fy >= a.g.h) continue;  // wave-uniform
+                acc += ld4u(base + ft.off);
+            }
+            tl += acc & 0x00FF00FFu;
+            th += (acc >> 8) & 0x00FF00FFu;
+        }
+        // first maximum in row-major order: key = score << 8 | (255 - index)
+        u32 idx0 = (u32)lane * 4u;
+        u32 k0 = ((tl & 0xFFFF) << 8) | (255u - idx0);
+        u32 k1 = ((th & 0xFFFF) << 8) | (254u - idx0);
+        u32 k2 = ((tl >> 16) << 8) | (253u - idx0);
+        u32 k3 = ((th >> 16) << 8) | (252u - idx0);
+        u32 k01 = k0 > k1 ? k0 : k1, k23 = k2 > k3 ? k2 : k3;
+        u32 key = wave_max_u32(k01 > k23 ? k01 : k23);
+        int best = (int)(key >> 8);
+        int best_r = -1, best_c = -1;
+        if (best > 0) { int idx = 255 - (int)(key & 255u); best_r = idx >> 4; best_c = idx & 15; }
+        int nx = (bx + best_c) * T + offset, ny = (by + best_r) * T + offset;
+        float sim = __fdiv_rn(__fmul_rn((float)best, 100.f), (float)(4 * mt.nfeat_total));
+        if (lane == 0) {
+            if (sim < a.threshold) {
+                a.cand[i].ti = LM_DROPPED;
+            } else if (LAST) {
+                emit_key(a, ti, nx, ny, sim);
+            } else {
+                LmCand o; o.ti = ti; o.x = nx; o.y = ny; o.sim = sim;
+                a.cand[i] = o;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_emit_unrefined(LmRefineArgs a) {
+    u32 n = *a.cand_count;
+    if (n > a.cand_cap) n = a.cand_cap;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        LmCand c = a.cand[i];
+        if (c.ti != LM_DROPPED) emit_key(a, c.ti, c.x, c.y, c.sim);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a15  sort + unique.  Keys are (hi, lo) u64 pairs whose ascending order is the total order of
+// SURVEY.md A.9; equality for std::unique is (x, y, similarity, class) = (lo, hi >> 32).
+// ------------------------------------------------------------------------------------------------
+struct OutMatch { int x, y; float similarity; int template_id; int class_idx; };
+
+__global__ __launch_bounds__(1024) void k_sort_unique(const u64* __restrict__ keys, const u32* __restrict__ match_count,
+                                                       u32 match_cap, OutMatch* __restrict__ out, LmHeader* hdr) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u64* hi = reinterpret_cast<u64*>(smem);
+    u64* lo = hi + LM_SORT_CAP;
+    __shared__ u32 wave_tot[16];
+    const int tid = threadIdx.x;
+    u32 n = *match_count;
+    if (n > match_cap) n = match_cap;
+    if (n > LM_SORT_CAP) {
+        if (tid == 0) { hdr->sorted_on_device = 0; hdr->out_count = 0; }
+        return;
+    }
+    u32 N = 1;
+    while (N < n) N <<= 1;
+    for (u32 i = tid; i < N; i += 1024) {
+        hi[i] = i < n ? keys[2 * (size_t)i] : ~0ull;
+        lo[i] = i < n ? keys[2 * (size_t)i + 1] : ~0ull;
+    }
+    __syncthreads();
+    for (u32 k = 2; k <= N; k <<= 1)
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 t = tid; t < (N >> 1); t += 1024) {
+                u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
+                u32 p = i | j;
+                bool up = (i & k) == 0;
+                u64 ah = hi[i], al = lo[i], bh = hi[p], bl = lo[p];
+                bool gt = ah > bh || (ah == bh && al > bl);
+                if (gt == up) { hi[i] = bh; lo[i] = bl; hi[p] = ah; lo[p] = al; }
+            }
+            __syncthreads();
+        }
+    // adjacent-unique + compaction (block-wide exclusive scan of keep flags, chunks of 1024)
+    u32 base = 0;
+    for (u32 c0 = 0; c0 < n; c0 += 1024) {
+        u32 i = c0 + tid;
+        u32 keep = 0;
+        if (i < n) keep = (i == 0) || !(lo[i] == lo[i - 1] && (hi[i] >> 32) == (hi[i - 1] >> 32));
+        unsigned long long bal = __ballot(keep);
+        int lane = tid & 63, wv = tid >> 6;
+        u32 pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wv] = __popcll(bal);
+        __syncthreads();
+        u32 woff = 0, tot = 0;
+        for (int k = 0; k < 16; ++k) { u32 t = wave_tot[k]; if (k < wv) woff += t; tot += t; }
+        if (keep) {
+            u64 h = hi[i], l = lo[i];
+            OutMatch m;
+            m.similarity = __uint_as_float(~(u32)(h >> 32));
+            m.template_id = (int)(u32)h;
+            m.class_idx = (int)(l >> 48);
+            m.y = (int)((l >> 24) & 0xFFFFFFu) - 0x800000;
+            m.x = (int)(l & 0xFFFFFFu) - 0x800000;
+            out[base + woff + pre] = m;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) { hdr->sorted_on_device = 1; hdr->out_count = base; }
+}
+
+}  // namespace
+
+// ================================================================================================
+// launchers
+// ================================================================================================
+void lmk_pyrdown(hipStream_t s, const u8* src, int sw, int sh, u8* dst) {
+    int dw = sw / 2, dh = sh / 2;
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4);
+    hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, src, sw, sh, dst, dw, dh);
+}
+
+void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_threshold, u8* quant, float* mag) {
+    dim3 grid((w + CT_W - 1) / CT_W, (h + CT_H - 1) / CT_H);
+    hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, w, h, weak_threshold * weak_threshold, quant, mag);
+}
+
+void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_thr, int diff_thr, const u8* lut,
+                        u8* quant) {
+    dim3 grid((w + DT_W - 1) / DT_W, (h + DT_H - 1) / DT_H);
+    hipLaunchKernelGGL(k_depth_quantize, grid, dim3(256), 0, s, depth, w, h, dist_thr, diff_thr, lut, quant);
+}
+
+void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, int w, int h, int T,
+                         const u64* resp_tab, u8* lm, u32 ori_stride) {
+    int pitch = (w + T + 3) & ~3;
+    size_t shmem = 2048 + 2 * (size_t)(2 * T - 1) * pitch;
+    dim3 grid(h / T);
+    if (src_shift)
+        hipLaunchKernelGGL(k_linear_memories<1>, grid, dim3(256), shmem, s, q, qpitch, w, h, T, resp_tab, lm, ori_stride);
+    else
+        hipLaunchKernelGGL(k_linear_memories<0>, grid, dim3(256), shmem, s, q, qpitch, w, h, T, resp_tab, lm, ori_stride);
+}
+
+void lmk_scan(hipStream_t s, const LmScanArgs& a, int variant) {
+    if (a.n_items <= 0) return;
+    dim3 grid((a.n_items + 3) / 4);
+    switch (variant) {
+        case 1: hipLaunchKernelGGL(k_scan<4>, grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(k_scan<2>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(k_scan<8>, grid, dim3(256), 0, s, a); break;
+    }
+}
+
+void lmk_refine(hipStream_t s, const LmRefineArgs& a, bool last) {
+    dim3 grid(1024);  // 4096 persistent waves stride over the candidate list
+    if (last) hipLaunchKernelGGL(k_refine<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_refine<false>, grid, dim3(256), 0, s, a);
+}
+
+void lmk_emit_unrefined(hipStream_t s, const LmRefineArgs& a) {
+    hipLaunchKernelGGL(k_emit_unrefined, dim3(256), dim3(256), 0, s, a);
+}
+
+void lmk_sort_unique(hipStream_t s, const u64* keys, const u32* match_count, u32 match_cap, void* out_matches,
+                     LmHeader* hdr) {
+    size_t shmem = (size_t)LM_SORT_CAP * 16;
+    hipLaunchKernelGGL(k_sort_unique, dim3(1), dim3(1024), shmem, s, keys, match_count, match_cap,
+                       reinterpret_cast<OutMatch*>(out_matches), hdr);
+}
