@@ -1,0 +1,75 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def lm():
+    """The product package (ctypes view of liblinemod_hip.so).  Builds the library if missing."""
+    sys.path.insert(0, os.path.join(ROOT, "line-mod-pipeline_amd"))
+    mod = importlib.import_module("line-mod-pipeline_amd")
+    if not os.path.exists(mod.LIB_PATH):
+        importlib.import_module("line-mod-pipeline_amd.build").build()
+    mod.load_library()
+    return mod
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module("line-mod-pipeline_amd.synth")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure only)."""
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def frame0():
+    f = np.load(os.path.join(GOLDEN, "frame0.npz"))
+    return f["bgr"], f["depth"]
+
+
+@pytest.fixture(scope="session")
+def golden0():
+    return np.load(os.path.join(GOLDEN, "frame0_golden.npz"))
+
+
+def crop_masks(width, height, seed, n):
+    """Same seeded crop windows as tests/golden/make_golden.py."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        w = int(rng.integers(60, 160)); h = int(rng.integers(60, 160))
+        x0 = int(rng.integers(45, width - w - 45)); y0 = int(rng.integers(45, height - h - 45))
+        m = np.zeros((height, width), np.uint8)
+        m[y0:y0 + h, x0:x0 + w] = 255
+        out.append(m)
+    return out
+
+
+def assert_matches_equal(a, b, sim_tol=0.0):
+    """Bit-identical (x, y, template_id, class_idx) and order; similarity within sim_tol (north star
+    asks 1e-5; both sides compute best*100/(4n) in float with the same operations, so 0 holds)."""
+    assert len(a) == len(b), "match count differs: %d vs %d" % (len(a), len(b))
+    for k in ("x", "y", "template_id", "class_idx"):
+        assert np.array_equal(a[k], b[k]), "field %s differs" % k
+    if sim_tol == 0.0:
+        assert np.array_equal(a["similarity"], b["similarity"])
+    else:
+        assert np.allclose(a["similarity"], b["similarity"], atol=sim_tol, rtol=0)

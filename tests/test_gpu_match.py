@@ -1,0 +1,241 @@
+"""GPU parity of the whole hot path (Detector::match) against the CPU oracle and the committed golden
+vectors: bit-identical (x, y, template_id, class) and order, identical similarity bits (the north star
+allows 1e-5).  Everything goes through the C ABI of liblinemod_hip.so."""
+import numpy as np
+import pytest
+
+from conftest import assert_matches_equal, crop_masks
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(lm, orc, color_only, size=(640, 480), **kw):
+    d = lm.Detector(color_only=color_only, width=size[0], height=size[1], **kw)
+    o = orc.Detector(color_only=color_only)
+    return d, o
+
+
+def _quantized(o, bgr, depth, color_only):
+    o.prepare(bgr, None if color_only else depth)
+    out = {}
+    for l in range(2):
+        w, h = bgr.shape[1] >> l, bgr.shape[0] >> l
+        for m in range(1 if color_only else 2):
+            out[(l, m)] = o.stage(0, l, m).reshape(h, w)
+    return out
+
+
+@pytest.mark.parametrize("name,color_only", [("rgbd", False), ("color", True)])
+def test_golden_frame0(lm, frame0, golden0, name, color_only):
+    """Reference's own frame + committed template bank -> committed match list."""
+    bgr, depth = frame0
+    d = lm.Detector(color_only=color_only)
+    d.add_class("lagergehaeuse.ply", golden0[name + "_descs"], golden0[name + "_features"])
+    got = d.match(bgr, None if color_only else depth, 80.0, class_idx=0)
+    assert_matches_equal(got, golden0[name + "_matches"])
+    d.close()
+
+
+@pytest.mark.parametrize("color_only", [False, True])
+def test_known_answer_via_gpu_add_template(lm, orc, frame0, color_only):
+    """Detector::addTemplate on the GPU path reproduces the oracle's templates, and each one is found
+    at its crop origin with similarity 100."""
+    bgr, depth = frame0
+    d, o = _pair(lm, orc, color_only)
+    boxes = []
+    for m in crop_masks(640, 480, 11, 8):
+        tid, bb = d.add_template("obj", bgr, None if color_only else depth, m)
+        otid, obb = o.add_template("obj", bgr, None if color_only else depth, m)
+        assert tid == otid and (tid < 0 or bb == obb)
+        if tid >= 0:
+            boxes.append(bb)
+    assert len(boxes) >= 3
+    for tid in range(len(boxes)):
+        for level in range(2):
+            for mod in range(1 if color_only else 2):
+                a, b = d.get_template(0, tid, level, mod), o.get_template(0, tid, level, mod)
+                assert a[:2] == b[:2] and np.array_equal(a[2], b[2])
+    got = d.match(bgr, None if color_only else depth, 90.0)
+    assert_matches_equal(got, o.match(bgr, None if color_only else depth, 90.0))
+    T0 = d.get_T(0)
+    for tid, bb in enumerate(boxes):
+        best = got[got["template_id"] == tid][0]
+        assert best["similarity"] == 100.0
+        assert abs(int(best["x"]) - bb[0]) < T0 and abs(int(best["y"]) - bb[1]) < T0
+    d.close()
+
+
+@pytest.mark.parametrize("color_only,size,n,thr", [
+    (False, (640, 480), 300, 80.0),
+    (False, (640, 480), 300, 55.0),
+    (True, (640, 480), 300, 70.0),
+    (True, (1280, 960), 200, 75.0),
+])
+def test_synthetic_bank_parity(lm, orc, synth, color_only, size, n, thr):
+    """Seeded synthetic frame + bank (10 % crops of the frame so real matches exist)."""
+    bgr, depth = synth.make_frame(size[0], size[1], seed=1234)
+    d, o = _pair(lm, orc, color_only, size)
+    q = _quantized(o, bgr, depth, color_only)
+    M = 1 if color_only else 2
+    descs, feats, crops = synth.make_bank(n, M, 2, seed=4321, quantized=q, crop_fraction=0.15, frame_size=size,
+                                          T0=d.get_T(0))
+    assert len(crops) > 5
+    d.add_class("c", descs, feats)
+    o.add_class("c", descs, feats)
+    got = d.match(bgr, None if color_only else depth, thr)
+    exp = o.match(bgr, None if color_only else depth, thr)
+    assert len(exp) >= len(crops)
+    assert_matches_equal(got, exp)
+    # scan stage in isolation: candidate set before refinement
+    d.upload_frame(1, bgr, None if color_only else depth)
+    d.prepare_slot(1)
+    cands = d.stage_scan(1, thr)
+    assert len(cands) >= len(exp) // 4
+    d.close()
+
+
+def test_low_threshold_many_candidates(lm, orc, synth):
+    """Threshold 0 floods the refinement stage (no NMS upstream): exercises compaction, the
+    > LM_SORT_CAP host-sort path and duplicate removal."""
+    bgr, depth = synth.make_frame(640, 480, seed=21)
+    d, o = _pair(lm, orc, True)
+    descs, feats, _ = synth.make_bank(150, 1, 2, seed=8)
+    d.add_class("c", descs, feats)
+    o.add_class("c", descs, feats)
+    for thr in (0.0, 20.0, 50.0):
+        exp = o.match(bgr, None, thr, threads=8)
+        got = d.match(bgr, None, thr, cap=1 << 18)
+        assert_matches_equal(got, exp)
+        if thr == 0.0:
+            assert len(exp) > 4096      # beyond LM_SORT_CAP: host-side sort of the device keys
+    d.close()
+
+
+def test_multi_class_and_class_selection(lm, orc, synth, frame0):
+    bgr, depth = frame0
+    d, o = _pair(lm, orc, False)
+    q = _quantized(o, bgr, depth, False)
+    for k, seed in enumerate((1, 2, 3)):
+        descs, feats, _ = synth.make_bank(50, 2, 2, seed=seed, quantized=q, crop_fraction=0.3)
+        assert d.add_class("model%d.ply" % k, descs, feats) == k
+        o.add_class("model%d.ply" % k, descs, feats)
+    for ci in (0, 1, 2, -1):
+        assert_matches_equal(d.match(bgr, depth, 75.0, class_idx=ci), o.match(bgr, depth, 75.0, class_idx=ci))
+    with pytest.raises(lm.LinemodError):
+        d.match(bgr, depth, 75.0, class_idx=3)
+    d.close()
+
+
+def test_edge_cases(lm, orc, synth, frame0):
+    bgr, depth = frame0
+    d, o = _pair(lm, orc, False)
+    assert len(d.match(bgr, depth, 80.0)) == 0                      # empty bank
+    # templates larger than the frame allows: span <= 0 -> never a candidate; huge ones clamp oddly upstream
+    descs, feats, _ = synth.make_bank(6, 2, 2, seed=5, fixed_l0_size=(620, 470))
+    d.add_class("big", descs, feats); o.add_class("big", descs, feats)
+    assert_matches_equal(d.match(bgr, depth, 0.0), o.match(bgr, depth, 0.0))
+    descs, feats, _ = synth.make_bank(6, 2, 2, seed=6, fixed_l0_size=(700, 500))
+    d.add_class("toobig", descs, feats); o.add_class("toobig", descs, feats)
+    assert_matches_equal(d.match(bgr, depth, 0.0), o.match(bgr, depth, 0.0))
+    # features with fewer than the default counts (ragged feature lists)
+    descs, feats, _ = synth.make_bank(30, 2, 2, seed=7, num_features=21)
+    d.add_class("ragged", descs, feats); o.add_class("ragged", descs, feats)
+    assert_matches_equal(d.match(bgr, depth, 30.0), o.match(bgr, depth, 30.0))
+    # missing depth for an RGB-D detector: sources.size() != modalities.size()
+    with pytest.raises(lm.LinemodError) as e:
+        d.match(bgr, None, 80.0)
+    assert e.value.code == lm.LM_ERR_INVALID
+    with pytest.raises(lm.LinemodError):
+        d.match(bgr, depth, -1.0)
+    d.close()
+
+
+def test_overflow_is_reported(lm, synth):
+    bgr, depth = synth.make_frame(640, 480, seed=21)
+    d = lm.Detector(lm.default_config(color_only=True, max_candidates=1000))
+    descs, feats, _ = synth.make_bank(40, 1, 2, seed=8)
+    d.add_class("c", descs, feats)
+    with pytest.raises(lm.LinemodError) as e:
+        d.match(bgr, None, 0.0)
+    assert e.value.code == lm.LM_ERR_OVERFLOW
+    d.close()
+
+
+def test_wraparound_templates(lm, orc, synth):
+    """Upstream scans template_positions contiguous bytes, so wide templates match 'across' the right
+    border; bit parity means reproducing that (SURVEY.md section 7 'wrap-around semantics')."""
+    bgr, depth = synth.make_frame(640, 480, seed=33)
+    d, o = _pair(lm, orc, True)
+    descs, feats, _ = synth.make_bank(25, 1, 2, seed=9, fixed_l0_size=(600, 60))
+    d.add_class("wide", descs, feats); o.add_class("wide", descs, feats)
+    exp = o.match(bgr, None, 10.0)
+    assert len(exp) > 0
+    assert_matches_equal(d.match(bgr, None, 10.0), exp)
+    d.close()
+
+
+def test_custom_luts_end_to_end(lm, orc, frame0, golden0):
+    bgr, depth = frame0
+    d, o = _pair(lm, orc, False)
+    d.add_class("c", golden0["rgbd_descs"], golden0["rgbd_features"])
+    o.add_class("c", golden0["rgbd_descs"], golden0["rgbd_features"])
+    for variant in (1, 2):
+        lut = orc.similarity_lut(variant)
+        d.set_similarity_lut(lut); o.set_similarity_lut(lut)
+        assert_matches_equal(d.match(bgr, depth, 70.0), o.match(bgr, depth, 70.0))
+    d.close()
+
+
+def test_resident_slots_and_batch(lm, orc, synth):
+    size = (640, 480)
+    d, o = _pair(lm, orc, False, size)
+    frames = [synth.make_frame(size[0], size[1], seed=100 + i) for i in range(4)]
+    q = _quantized(o, frames[0][0], frames[0][1], False)
+    descs, feats, _ = synth.make_bank(200, 2, 2, seed=12, quantized=q, crop_fraction=0.2)
+    d.add_class("c", descs, feats); o.add_class("c", descs, feats)
+    for i, (bgr, depth) in enumerate(frames):
+        d.upload_frame(i, bgr, depth)
+    out, counts = d.match_batch(4, 70.0)
+    for i, (bgr, depth) in enumerate(frames):
+        exp = o.match(bgr, depth, 70.0)
+        assert counts[i] == len(exp)
+        assert_matches_equal(out[i, :counts[i]], exp)
+        assert_matches_equal(d.match_slot(i, 70.0), exp)        # slots stay resident, repeatable
+    d.close()
+
+
+def test_sharded_detectors_union_equals_single(lm, orc, synth, frame0):
+    """SURVEY.md 8e on one GPU: R detectors each holding one contiguous template_id shard; merging
+    their lists reproduces the unsharded result exactly (ids stay global)."""
+    bgr, depth = frame0
+    o = orc.Detector(color_only=False)
+    q = _quantized(o, bgr, depth, False)
+    descs, feats, _ = synth.make_bank(101, 2, 2, seed=13, quantized=q, crop_fraction=0.3)
+    o.add_class("c", descs, feats)
+    full = o.match(bgr, depth, 70.0)
+    assert len(full) > 10
+    for R in (2, 3):
+        parts = []
+        for r in range(R):
+            d = lm.Detector(lm.default_config(color_only=False, shard_rank=r, shard_size=R))
+            d.add_class("c", descs, feats)
+            parts.append(d.match(bgr, depth, 70.0))
+            d.close()
+        assert_matches_equal(lm.merge_matches(parts), full)
+
+
+def test_other_pyramids(lm, orc, synth):
+    """Not only the reference's two constructions: 1 and 3 pyramid levels, other T."""
+    bgr, depth = synth.make_frame(640, 480, seed=55)
+    for T in ([8], [4, 8], [2, 4, 8]):
+        L = len(T)
+        d = lm.Detector(lm.default_config(color_only=False, T=T))
+        o = orc.Detector(color_only=False, T=T)
+        o.prepare(bgr, depth)
+        q = {(l, m): o.stage(0, l, m).reshape(480 >> l, 640 >> l) for l in range(L) for m in range(2)}
+        descs, feats, _ = synth.make_bank(60, 2, L, seed=14, quantized=q, crop_fraction=0.3, T0=T[0])
+        d.add_class("c", descs, feats); o.add_class("c", descs, feats)
+        exp = o.match(bgr, depth, 60.0)
+        assert len(exp) > 0
+        assert_matches_equal(d.match(bgr, depth, 60.0), exp)
+        d.close()

@@ -1,0 +1,134 @@
+"""GPU parity, stage by stage: every HIP kernel against the CPU oracle on the same inputs, bit-exact.
+All calls go through the C ABI (include/linemod_hip.h) of liblinemod_hip.so."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def det(lm):
+    d = lm.Detector(color_only=False)
+    yield d
+    d.close()
+
+
+def _rand_bgr(rng, h, w, smooth=True):
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if smooth:  # blocky structure so that the >=5/9 vote keeps something
+        img = np.kron(rng.integers(0, 256, (h // 8 + 1, w // 8 + 1, 3), dtype=np.uint8),
+                      np.ones((8, 8, 1), np.uint8))[:h, :w]
+        img = (img.astype(np.int32) + rng.integers(-3, 4, img.shape)).clip(0, 255).astype(np.uint8)
+    return np.ascontiguousarray(img)
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (240, 320), (960, 1280), (37, 53), (16, 64), (130, 70), (8, 8)])
+def test_color_quantize_parity(det, orc, shape):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    for smooth in (True, False):
+        bgr = _rand_bgr(rng, shape[0], shape[1], smooth)
+        q, mag = det.stage_color_quantize(bgr, want_magnitude=True)
+        eq, emag = orc.color_quantize(bgr, want_magnitude=True)
+        assert np.array_equal(q, eq)
+        assert np.array_equal(mag, emag)
+
+
+def test_color_quantize_frame0_and_thresholds(det, orc, frame0):
+    bgr, _ = frame0
+    assert np.array_equal(det.stage_color_quantize(bgr), orc.color_quantize(bgr))
+    for thr in (0.0, 3.5, 30.0, 200.0):
+        assert np.array_equal(det.stage_color_quantize(bgr, weak_threshold=thr), orc.color_quantize(bgr, thr))
+
+
+def test_color_quantize_all_angles(det, orc):
+    """Synthetic gradients in every direction (incl. exact bin boundaries of the fastAtan2 polynomial)."""
+    h, w = 64, 512
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.zeros((h, w, 3), np.uint8)
+    for k in range(8):
+        a = 2 * np.pi * (k * 64 + xx[:, k * 64:(k + 1) * 64] - k * 64) / 512.0
+        blk = 128 + 100 * np.sin(0.35 * ((xx[:, k * 64:(k + 1) * 64]) * np.cos(a) + yy[:, k * 64:(k + 1) * 64] * np.sin(a)))
+        img[:, k * 64:(k + 1) * 64, k % 3] = blk.clip(0, 255)
+    q = det.stage_color_quantize(img)
+    e = orc.color_quantize(img)
+    assert np.array_equal(q, e)
+    assert len(np.unique(e)) >= 8
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (960, 1280), (36, 52), (17, 80)])
+def test_pyrdown_parity(det, orc, shape):
+    rng = np.random.default_rng(shape[1])
+    bgr = rng.integers(0, 256, (shape[0], shape[1], 3), dtype=np.uint8)
+    assert np.array_equal(det.stage_pyrdown(bgr), orc.pyrdown(bgr))
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (960, 1280), (40, 48), (23, 91), (12, 12)])
+def test_depth_quantize_parity(det, orc, synth, shape):
+    rng = np.random.default_rng(shape[0])
+    h, w = shape
+    _, depth = synth.make_frame(max(w, 64), max(h, 64), seed=shape[0] + 5)
+    depth = np.ascontiguousarray(depth[:h, :w])
+    assert np.array_equal(det.stage_depth_quantize(depth), orc.depth_quantize(depth))
+    noisy = rng.integers(0, 2600, (h, w)).astype(np.uint16)     # hits d >= 2000, |delta| >= 50, zeros
+    assert np.array_equal(det.stage_depth_quantize(noisy), orc.depth_quantize(noisy))
+    steps = (600 + 49 * rng.integers(0, 3, (h, w))).astype(np.uint16)   # right at the difference threshold
+    assert np.array_equal(det.stage_depth_quantize(steps), orc.depth_quantize(steps))
+
+
+def test_depth_quantize_frame0_and_custom_lut(lm, orc, frame0):
+    _, depth = frame0
+    d = lm.Detector(color_only=False)
+    assert np.array_equal(d.stage_depth_quantize(depth), orc.depth_quantize(depth))
+    rng = np.random.default_rng(9)
+    lut = rng.integers(0, 256, 8000).astype(np.uint8)            # arbitrary bytes: median must be a true median
+    d.set_normal_lut(lut)
+    assert np.array_equal(d.stage_depth_quantize(depth), orc.depth_quantize(depth, lut=lut))
+    d.close()
+
+
+@pytest.mark.parametrize("w,h,T", [(640, 480, 5), (320, 240, 8), (640, 480, 2), (1280, 960, 2), (640, 480, 8),
+                                   (40, 16, 8), (35, 21, 7), (48, 36, 3), (64, 64, 1), (24, 8, 4)])
+def test_linear_memories_parity(det, orc, w, h, T):
+    rng = np.random.default_rng(w * 7 + T)
+    q = ((1 << rng.integers(0, 8, (h, w))) * (rng.random((h, w)) < 0.35)).astype(np.uint8)
+    got = det.stage_linear_memories(q, T)
+    spr = orc.spread(q, T)
+    resp = orc.response_maps(spr)
+    exp = np.stack([orc.linearize(resp[o], T) for o in range(8)])
+    assert np.array_equal(got, exp)
+    # not only one-hot input: any byte is a valid spread source
+    q2 = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    got2 = det.stage_linear_memories(q2, T)
+    resp2 = orc.response_maps(orc.spread(q2, T))
+    assert np.array_equal(got2, np.stack([orc.linearize(resp2[o], T) for o in range(8)]))
+
+
+def test_linear_memories_custom_lut(lm, orc):
+    d = lm.Detector(color_only=False)
+    lut = orc.similarity_lut(1)
+    d.set_similarity_lut(lut)
+    rng = np.random.default_rng(4)
+    q = ((1 << rng.integers(0, 8, (48, 80))) * (rng.random((48, 80)) < 0.4)).astype(np.uint8)
+    resp = orc.response_maps(orc.spread(q, 8), lut)
+    assert np.array_equal(d.stage_linear_memories(q, 8), np.stack([orc.linearize(resp[o], 8) for o in range(8)]))
+    d.close()
+
+
+@pytest.mark.parametrize("color_only,size", [(False, (640, 480)), (True, (640, 480)), (True, (1280, 960))])
+def test_full_preprocess_parity(lm, orc, synth, frame0, color_only, size):
+    """a3-a10 end to end on a resident frame: quantised images and all linear memories, every level."""
+    w, h = size
+    if size == (640, 480):
+        bgr, depth = frame0
+    else:
+        bgr, depth = synth.make_frame(w, h, seed=77)
+    d = lm.Detector(color_only=color_only, width=w, height=h)
+    o = orc.Detector(color_only=color_only)
+    d.upload_frame(0, bgr, None if color_only else depth)
+    d.prepare_slot(0)
+    o.prepare(bgr, None if color_only else depth)
+    for level in range(2):
+        for mod in range(1 if color_only else 2):
+            assert np.array_equal(d.debug_read(0, 0, level, mod), o.stage(0, level, mod)), (level, mod)
+            assert np.array_equal(d.debug_read(0, 2, level, mod), o.stage(2, level, mod)), (level, mod)
+    d.close()
