@@ -1,14 +1,19 @@
 // lm_common.h -- types shared by the HIP kernels and the host side of liblinemod_hip.so.
 //
-// HBM layout of one resident frame slot (all offsets in bytes, every block 256-B aligned):
-//   bgr[l]      level-l BGR image, dense [h_l][w_l][3] u8 (level 0 uploaded, l>0 by k_pyrdown)
-//   depth       level-0 depth, dense [h][w] u16
-//   quant[l][m] quantised image of modality m at level l, dense [h_l][w_l] u8 (one-hot or 0)
-//   lm[l]       linear-memory arena of level l:
-//                 [modality m][orientation o][memory g = (y%T)*T + x%T][position (y/T)*W + x/T]  u8
-//               each orientation block is followed by PAD zero bytes and the level ends with one
-//               more zero block; reads that upstream would make past an orientation's T*T x W*H
-//               cv::Mat land in those zeros (see oracle lm_read()).
+// HBM layout.  All frame slots live in two allocations with a fixed byte stride between slots, so a
+// batch of resident frames is processed by one launch per stage (slot = blockIdx.z):
+//   frame arena (slot stride = frame_stride), per slot, every block 256-B aligned:
+//     bgr[l]      level-l BGR image, dense [h_l][w_l][3] u8 (level 0 uploaded, l>0 by k_pyrdown)
+//     depth       level-0 depth, dense [h][w] u16
+//     quant[l][m] quantised image of modality m at level l, dense [h_l][w_l] u8 (one-hot or 0)
+//     lm[l]       linear-memory arena of level l:
+//                   [modality m][orientation o][memory g = (y%T)*T + x%T][position (y/T)*W + x/T]  u8
+//                 each orientation block is followed by `pad` zero bytes and the level ends with one
+//                 more zero block; reads that upstream would make past an orientation's T*T x W*H
+//                 cv::Mat land in those zeros (see oracle lm_read()).
+//   aux arena (slot stride = aux_stride), per slot:
+//     LmDevHeader counters, candidate list, sort keys, sorted output records
+//   plus one host-mapped pinned LmHostBlock per slot that the sort kernel writes directly.
 #pragma once
 #include <stdint.h>
 
@@ -19,7 +24,8 @@ typedef uint64_t u64;
 
 #define LM_SCAN_CHUNK 1024      // positions one wave covers in the similarity scan (64 lanes x 16 B)
 #define LM_SCAN_FPAD 8          // feature lists are padded to a multiple of this with zero-block offsets
-#define LM_SORT_CAP 4096        // matches sorted by the single-workgroup LDS bitonic sort
+#define LM_SORT_CAP 4096        // matches sorted on the device (LDS); more are sorted by the host
+#define LM_INLINE_MATCHES 2048  // records the sort kernel also writes straight into host-mapped memory
 #define LM_DROPPED 0xFFFFFFFFu
 
 struct LmLevelGeom {
@@ -27,9 +33,9 @@ struct LmLevelGeom {
     int T;             // spread size = linear-memory stride
     int W, H;          // w/T, h/T
     u32 wh;            // W*H = bytes per linear memory
-    u32 ori_stride;    // T*T*wh + pad
+    u32 ori_stride;    // T*T*wh (256-aligned) + pad
     u32 mod_stride;    // 8*ori_stride
-    u32 zero_off;      // offset (inside the level arena) of a zero block of >= wh + 2*LM_SCAN_CHUNK bytes
+    u32 zero_off;      // offset (inside the level arena) of a zero block of `pad` bytes
     u32 arena_bytes;   // M*mod_stride + zero block
 };
 
@@ -55,10 +61,25 @@ struct LmRefMeta {
     u32 count[2];
 };
 
-// Device header read back after every match.
-struct LmHeader {
+// Device counters of one slot; zero between frames (the sort kernel re-arms them).
+struct LmDevHeader {
     u32 cand_count;      // candidates produced by the scan (may exceed capacity)
     u32 match_count;     // refined matches that passed the threshold (may exceed capacity)
-    u32 out_count;       // matches after sort + unique (only when sorted on device)
-    u32 sorted_on_device;
+    u32 pad[2];
+};
+
+// Same layout as lm_match_t of the C ABI.
+struct LmOutMatch { int x, y; float similarity; int template_id; int class_idx; };
+
+struct LmHeader {
+    u32 cand_count;
+    u32 match_count;
+    u32 out_count;         // matches after sort + unique (only when sorted on the device)
+    u32 sorted_on_device;  // 0: capacity overflow or more than LM_SORT_CAP matches (host sorts the keys)
+};
+
+// Host-mapped result block of one slot, written by k_sort_unique.
+struct LmHostBlock {
+    LmHeader hdr;
+    LmOutMatch rec[LM_INLINE_MATCHES];
 };

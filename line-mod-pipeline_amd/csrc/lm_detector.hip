@@ -1,5 +1,5 @@
 // lm_detector.hip -- host side of liblinemod_hip.so: the C ABI of include/linemod_hip.h, the
-// template bank (host copy + device upload), resident frame slots and the per-frame launch sequence.
+// template bank (host copy + device upload), resident frame slots and the per-batch launch sequence.
 //
 // Mirrors cv::linemod::Detector as the reference uses it (/root/reference/src/HighLevelLinemod.cpp:
 // 33-34,41-42 ctor; :93 addTemplate; :152 match; :115,181 getTemplates; :55,60,65 class queries).
@@ -36,29 +36,10 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Slot {
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    u8* bgr[LM_MAX_LEVELS] = {};
-    u16* depth = nullptr;
-    u8* quant[LM_MAX_LEVELS][2] = {};
-    u8* lm[LM_MAX_LEVELS] = {};
-    LmCand* cand = nullptr;
-    u64* keys = nullptr;
-    lm_match_t* out = nullptr;
-    LmHeader* hdr = nullptr;
-    int* raw_thr = nullptr;
-    float raw_thr_for = -1.0f;  // threshold the device table was built for
-    // pinned host staging
-    u8* h_bgr = nullptr;
+    u8* h_bgr = nullptr;     // pinned upload staging
     u16* h_depth = nullptr;
-    LmHeader* h_hdr = nullptr;
-    lm_match_t* h_out = nullptr;   // inline_n records
-    int* h_raw_thr = nullptr;
     bool has_frame = false;
-    bool in_flight = false;
 };
-
-const u32 INLINE_N = 2048;
 
 }  // namespace
 
@@ -70,15 +51,31 @@ struct lm_detector {
     u8 normal_lut[8000];
     lmh::Bank bank;
 
-    // device state
+    // ---- device state
     bool dev_ready = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<Slot> slots;
+    // frame arena: [slot][bgr[l] | depth | quant[l][m] | lm[l]]
+    u8* frame_arena = nullptr;
+    size_t frame_stride = 0;
+    size_t off_bgr[LM_MAX_LEVELS] = {}, off_depth = 0, off_quant[LM_MAX_LEVELS][2] = {}, off_lm[LM_MAX_LEVELS] = {};
+    // aux arena: [slot][LmDevHeader | cand | keys | out]
+    u8* aux_arena = nullptr;
+    size_t aux_stride = 0;
+    size_t off_hdr = 0, off_cand = 0, off_keys = 0, off_out = 0;
+    // host-mapped result blocks
+    u8* host_blocks = nullptr;
+    size_t host_stride = 0;
+    int* d_raw_thr = nullptr;
+    int* h_raw_thr = nullptr;
+    float raw_thr_for = -1.0f;
     u64* d_resp_tab = nullptr;
     u8* d_normal_lut = nullptr;
     bool luts_dirty = true;
-    // device bank
+    // ---- device bank
     bool bank_dirty = true;
-    lmh::DeviceBankHost hb;   // host-side arrays of the shard's device bank
+    lmh::DeviceBankHost hb;
     u32* d_item_t = nullptr; u32* d_item_chunk = nullptr;
     u32* d_scan_off = nullptr; int* d_scan_P = nullptr; int* d_scan_n = nullptr;
     int* d_t_global = nullptr; int* d_t_class = nullptr;
@@ -88,6 +85,13 @@ struct lm_detector {
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
     u32 max_cand = 0, max_match = 0;
     int scan_variant = 0;
+
+    u8* bgr(int slot, int l) const { return frame_arena + (size_t)slot * frame_stride + off_bgr[l]; }
+    u16* depth(int slot) const { return reinterpret_cast<u16*>(frame_arena + (size_t)slot * frame_stride + off_depth); }
+    u8* quant(int slot, int l, int m) const { return frame_arena + (size_t)slot * frame_stride + off_quant[l][m]; }
+    u8* lm(int slot, int l) const { return frame_arena + (size_t)slot * frame_stride + off_lm[l]; }
+    u8* aux(int slot, size_t off) const { return aux_arena + (size_t)slot * aux_stride + off; }
+    LmHostBlock* host_block(int slot) const { return reinterpret_cast<LmHostBlock*>(host_blocks + (size_t)slot * host_stride); }
 };
 
 namespace {
@@ -123,30 +127,37 @@ int ensure_device(lm_detector* d) {
     if (d->cfg.device < 0 || d->cfg.device >= ndev) return fail(LM_ERR_INVALID, "device ordinal out of range");
     HIP_TRY(hipSetDevice(d->cfg.device));
     const lm_config& c = d->cfg;
-    const int M = c.num_modalities, L = c.pyramid_levels;
-    d->slots.assign(c.frame_slots, Slot());
+    const int M = c.num_modalities, L = c.pyramid_levels, S = c.frame_slots;
+    // ---- frame arena layout
+    size_t off = 0;
+    for (int l = 0; l < L; ++l) { d->off_bgr[l] = off; off += align_up((size_t)d->lw[l] * d->lh[l] * 3, 256); }
+    d->off_depth = off; off += align_up((size_t)c.width * c.height * 2, 256);
+    for (int l = 0; l < L; ++l)
+        for (int m = 0; m < M; ++m) { d->off_quant[l][m] = off; off += align_up((size_t)d->lw[l] * d->lh[l], 256); }
+    for (int l = 0; l < L; ++l) { d->off_lm[l] = off; off += align_up(d->geom[l].arena_bytes, 256); }
+    d->frame_stride = align_up(off, 4096);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->frame_arena), d->frame_stride * S));
+    HIP_TRY(hipMemset(d->frame_arena, 0, d->frame_stride * S));  // linear-memory pads / zero blocks stay zero forever
+    // ---- aux arena layout
+    off = 0;
+    d->off_hdr = off; off += 256;
+    d->off_cand = off; off += align_up((size_t)d->max_cand * sizeof(LmCand), 256);
+    d->off_keys = off; off += align_up((size_t)d->max_match * 16, 256);
+    d->off_out = off; off += align_up((size_t)LM_SORT_CAP * sizeof(LmOutMatch), 256);
+    d->aux_stride = align_up(off, 4096);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->aux_arena), d->aux_stride * S));
+    HIP_TRY(hipMemset(d->aux_arena, 0, d->aux_stride * S));      // counters start at zero; k_sort_unique re-arms them
+    d->host_stride = align_up(sizeof(LmHostBlock), 256);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d->host_blocks), d->host_stride * S, hipHostMallocMapped));
+    std::memset(d->host_blocks, 0, d->host_stride * S);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_raw_thr), 128 * sizeof(int)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d->h_raw_thr), 128 * sizeof(int)));
+    HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    for (auto& ev : d->ev) HIP_TRY(hipEventCreate(&ev));
+    d->slots.assign(S, Slot());
     for (Slot& s : d->slots) {
-        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        for (auto& ev : s.ev) HIP_TRY(hipEventCreate(&ev));
-        for (int l = 0; l < L; ++l) {
-            size_t px = (size_t)d->lw[l] * d->lh[l];
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.bgr[l]), px * 3));
-            for (int m = 0; m < M; ++m) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.quant[l][m]), px));
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.lm[l]), d->geom[l].arena_bytes));
-            HIP_TRY(hipMemset(s.lm[l], 0, d->geom[l].arena_bytes));  // pads + zero block stay zero forever
-        }
-        size_t px0 = (size_t)c.width * c.height;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.depth), px0 * 2));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.cand), (size_t)d->max_cand * sizeof(LmCand)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.keys), (size_t)d->max_match * 16));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.out), (size_t)LM_SORT_CAP * sizeof(lm_match_t)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.hdr), sizeof(LmHeader)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.raw_thr), 128 * sizeof(int)));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.h_bgr), px0 * 3));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.h_depth), px0 * 2));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.h_hdr), sizeof(LmHeader)));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.h_out), (size_t)INLINE_N * sizeof(lm_match_t)));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.h_raw_thr), 128 * sizeof(int)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.h_bgr), (size_t)c.width * c.height * 3));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.h_depth), (size_t)c.width * c.height * 2));
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_resp_tab), 256 * sizeof(u64)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_normal_lut), 8000));
@@ -197,50 +208,44 @@ int ensure_bank(lm_detector* d) {
     return LM_OK;
 }
 
-int check_slot(lm_detector* d, int slot) {
-    if (slot < 0 || slot >= (int)d->slots.size()) return fail(LM_ERR_INVALID, "slot out of range");
+int check_slots(lm_detector* d, int first, int n) {
+    if (first < 0 || n < 0 || first + n > (int)d->slots.size()) return fail(LM_ERR_INVALID, "slot out of range");
     return LM_OK;
 }
 
-// For levels >= 2 the depth modality's quantised image must exist at level l-1: materialise it.
-__global__ void k_nn_half(const u8* __restrict__ src, int sp, u8* __restrict__ dst, int dw, int dh) {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x < dw && y < dh) dst[(size_t)y * dw + x] = src[(size_t)(2 * y) * sp + 2 * x];
+// quant[l][1] for l >= 1: DepthNormalPyramid::pyrDown = NN half-size copy of the quantised image
+void enqueue_depth_pyramid(lm_detector* d, int first, int n) {
+    for (int l = 1; l < d->cfg.pyramid_levels; ++l)
+        lmk_nn_half(d->stream, d->quant(first, l - 1, 1), d->lw[l - 1], d->quant(first, l, 1), d->lw[l], d->lh[l],
+                    d->frame_stride, n);
 }
 
-void enqueue_depth_pyramid(lm_detector* d, Slot& s) {
-    // quant[l][1] for l >= 1 (only read by the stage hooks / levels >= 2 and lm_debug_read)
-    for (int l = 1; l < d->cfg.pyramid_levels; ++l) {
-        dim3 grid((d->lw[l] + 63) / 64, (d->lh[l] + 3) / 4);
-        hipLaunchKernelGGL(k_nn_half, grid, dim3(256), 0, s.stream, s.quant[l - 1][1], d->lw[l - 1], s.quant[l][1],
-                           d->lw[l], d->lh[l]);
-    }
-}
-
-// a3-a10 on the frame resident in the slot.
-void enqueue_preprocess(lm_detector* d, Slot& s) {
+// a3-a10 on the frames resident in slots [first, first + n).
+void enqueue_preprocess(lm_detector* d, int first, int n) {
     const lm_config& c = d->cfg;
     const int M = c.num_modalities, L = c.pyramid_levels;
+    const size_t fs = d->frame_stride;
     for (int l = 0; l < L; ++l) {
-        if (l > 0) lmk_pyrdown(s.stream, s.bgr[l - 1], d->lw[l - 1], d->lh[l - 1], s.bgr[l]);
-        lmk_color_quantize(s.stream, s.bgr[l], d->lw[l], d->lh[l], c.weak_threshold, s.quant[l][0], nullptr);
+        if (l > 0) lmk_pyrdown(d->stream, d->bgr(first, l - 1), d->lw[l - 1], d->lh[l - 1], d->bgr(first, l), fs, n);
+        lmk_color_quantize(d->stream, d->bgr(first, l), d->lw[l], d->lh[l], c.weak_threshold, d->quant(first, l, 0),
+                           nullptr, fs, n);
         if (M == 2 && l == 0)
-            lmk_depth_quantize(s.stream, s.depth, d->lw[0], d->lh[0], c.distance_threshold, c.difference_threshold,
-                               d->d_normal_lut, s.quant[0][1]);
+            lmk_depth_quantize(d->stream, d->depth(first), d->lw[0], d->lh[0], c.distance_threshold,
+                               c.difference_threshold, d->d_normal_lut, d->quant(first, 0, 1), fs, n);
     }
-    if (M == 2 && L > 2) enqueue_depth_pyramid(d, s);
+    if (M == 2 && L > 2) enqueue_depth_pyramid(d, first, n);
     for (int l = 0; l < L; ++l) {
         const LmLevelGeom& g = d->geom[l];
-        lmk_linear_memories(s.stream, s.quant[l][0], g.w, 0, g.w, g.h, g.T, d->d_resp_tab, s.lm[l], g.ori_stride);
+        lmk_linear_memories(d->stream, d->quant(first, l, 0), g.w, 0, g.w, g.h, g.T, d->d_resp_tab, d->lm(first, l),
+                            g.ori_stride, fs, fs, n);
         if (M == 2) {
-            // DepthNormalPyramid::pyrDown = NN resize of the quantised image, applied l times: level l
-            // reads level 0 at (y << l, x << l); with l in {0,1} that is the SRC_SHIFT template.
+            // level l of the depth modality reads the quantised image of level l-1 at (2y, 2x)
             if (l == 0)
-                lmk_linear_memories(s.stream, s.quant[0][1], g.w, 0, g.w, g.h, g.T, d->d_resp_tab,
-                                    s.lm[l] + g.mod_stride, g.ori_stride);
+                lmk_linear_memories(d->stream, d->quant(first, 0, 1), g.w, 0, g.w, g.h, g.T, d->d_resp_tab,
+                                    d->lm(first, l) + g.mod_stride, g.ori_stride, fs, fs, n);
             else
-                lmk_linear_memories(s.stream, s.quant[l - 1][1], d->lw[l - 1], 1, g.w, g.h, g.T, d->d_resp_tab,
-                                    s.lm[l] + g.mod_stride, g.ori_stride);
+                lmk_linear_memories(d->stream, d->quant(first, l - 1, 1), d->lw[l - 1], 1, g.w, g.h, g.T, d->d_resp_tab,
+                                    d->lm(first, l) + g.mod_stride, g.ori_stride, fs, fs, n);
         }
     }
 }
@@ -259,85 +264,97 @@ int item_range(lm_detector* d, int class_idx, ItemRange* r) {
     return LM_OK;
 }
 
-LmScanArgs make_scan_args(lm_detector* d, Slot& s, ItemRange r) {
+LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r) {
     const int L = d->cfg.pyramid_levels;
     const LmLevelGeom& g = d->geom[L - 1];
     LmScanArgs a;
-    a.lm = s.lm[L - 1];
+    a.lm = d->lm(first, L - 1); a.lm_slot_stride = d->frame_stride;
     a.item_t = d->d_item_t; a.item_chunk = d->d_item_chunk;
     a.item_lo = r.lo; a.n_items = r.n;
     a.scan_off = d->d_scan_off; a.scan_P = d->d_scan_P; a.scan_n = d->d_scan_n;
     a.M = d->cfg.num_modalities; a.fpad = d->hb.fpad;
-    a.raw_thr_by_n = s.raw_thr;
+    a.raw_thr_by_n = d->d_raw_thr;
     a.W = g.W; a.T = g.T;
-    a.cand = s.cand; a.cand_count = &s.hdr->cand_count; a.cand_cap = d->max_cand;
+    a.hdr = reinterpret_cast<LmDevHeader*>(d->aux(first, d->off_hdr));
+    a.cand = reinterpret_cast<LmCand*>(d->aux(first, d->off_cand));
+    a.aux_slot_stride = d->aux_stride;
+    a.cand_cap = d->max_cand;
     return a;
 }
 
-LmRefineArgs make_refine_args(lm_detector* d, Slot& s, int level, float threshold) {
+LmRefineArgs make_refine_args(lm_detector* d, int first, int level, float threshold) {
     LmRefineArgs a;
-    a.lm = s.lm[level];
+    a.lm = d->lm(first, level); a.lm_slot_stride = d->frame_stride;
     a.g = d->geom[level];
     a.M = d->cfg.num_modalities;
     a.meta = d->d_ref_meta[level]; a.feats = d->d_ref_feat[level];
-    a.cand = s.cand; a.cand_count = &s.hdr->cand_count; a.cand_cap = d->max_cand;
+    a.hdr = reinterpret_cast<LmDevHeader*>(d->aux(first, d->off_hdr));
+    a.cand = reinterpret_cast<LmCand*>(d->aux(first, d->off_cand));
+    a.keys = reinterpret_cast<u64*>(d->aux(first, d->off_keys));
+    a.aux_slot_stride = d->aux_stride;
+    a.cand_cap = d->max_cand; a.match_cap = d->max_match;
     a.threshold = threshold;
     a.t_global = d->d_t_global; a.t_class = d->d_t_class;
-    a.keys = s.keys; a.match_count = &s.hdr->match_count; a.match_cap = d->max_match;
     return a;
 }
 
-int enqueue_threshold(lm_detector* d, Slot& s, float threshold) {
+LmSortArgs make_sort_args(lm_detector* d, int first) {
+    LmSortArgs a;
+    a.hdr = reinterpret_cast<LmDevHeader*>(d->aux(first, d->off_hdr));
+    a.keys = reinterpret_cast<const u64*>(d->aux(first, d->off_keys));
+    a.out = reinterpret_cast<LmOutMatch*>(d->aux(first, d->off_out));
+    a.aux_slot_stride = d->aux_stride;
+    a.host = d->host_block(first);
+    a.host_slot_stride = d->host_stride;
+    a.cand_cap = d->max_cand; a.match_cap = d->max_match;
+    return a;
+}
+
+int enqueue_threshold(lm_detector* d, float threshold) {
     if (!(threshold >= 0.0f)) return fail(LM_ERR_INVALID, "threshold must be >= 0");
-    if (s.raw_thr_for != threshold) {
-        HIP_TRY(hipStreamSynchronize(s.stream));  // pinned table may still be read by an earlier copy
-        fill_raw_thr(s.h_raw_thr, threshold);
-        HIP_TRY(hipMemcpyAsync(s.raw_thr, s.h_raw_thr, 128 * sizeof(int), hipMemcpyHostToDevice, s.stream));
-        s.raw_thr_for = threshold;
+    if (d->raw_thr_for != threshold) {
+        HIP_TRY(hipStreamSynchronize(d->stream));  // the pinned table may still feed an earlier copy
+        fill_raw_thr(d->h_raw_thr, threshold);
+        HIP_TRY(hipMemcpyAsync(d->d_raw_thr, d->h_raw_thr, 128 * sizeof(int), hipMemcpyHostToDevice, d->stream));
+        d->raw_thr_for = threshold;
     }
     return LM_OK;
 }
 
-// a11-a15 on the slot's prepared linear memories; ends with the D2H of header + first records.
-int enqueue_match_stages(lm_detector* d, Slot& s, float threshold, ItemRange r, bool timed) {
+// a11-a15 on prepared linear memories; the sort kernel publishes the results to host-mapped memory.
+int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, ItemRange r, bool timed) {
     const int L = d->cfg.pyramid_levels;
-    HIP_TRY(hipMemsetAsync(s.hdr, 0, sizeof(LmHeader), s.stream));
-    if (timed) HIP_TRY(hipEventRecord(s.ev[1], s.stream));
-    lmk_scan(s.stream, make_scan_args(d, s, r), d->scan_variant);
-    if (timed) HIP_TRY(hipEventRecord(s.ev[2], s.stream));
+    if (timed) HIP_TRY(hipEventRecord(d->ev[1], d->stream));
+    lmk_scan(d->stream, make_scan_args(d, first, r), d->scan_variant, n);
+    if (timed) HIP_TRY(hipEventRecord(d->ev[2], d->stream));
     if (L == 1) {
-        lmk_emit_unrefined(s.stream, make_refine_args(d, s, 0, threshold));
+        lmk_emit_unrefined(d->stream, make_refine_args(d, first, 0, threshold), n);
     } else {
-        for (int l = L - 2; l >= 0; --l) lmk_refine(s.stream, make_refine_args(d, s, l, threshold), l == 0);
+        for (int l = L - 2; l >= 0; --l) lmk_refine(d->stream, make_refine_args(d, first, l, threshold), l == 0, n);
     }
-    if (timed) HIP_TRY(hipEventRecord(s.ev[3], s.stream));
-    lmk_sort_unique(s.stream, s.keys, &s.hdr->match_count, d->max_match, s.out, s.hdr);
-    HIP_TRY(hipMemcpyAsync(s.h_hdr, s.hdr, sizeof(LmHeader), hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(hipMemcpyAsync(s.h_out, s.out, (size_t)INLINE_N * sizeof(lm_match_t), hipMemcpyDeviceToHost, s.stream));
-    if (timed) HIP_TRY(hipEventRecord(s.ev[4], s.stream));
+    if (timed) HIP_TRY(hipEventRecord(d->ev[3], d->stream));
+    lmk_sort_unique(d->stream, make_sort_args(d, first), n);
+    if (timed) HIP_TRY(hipEventRecord(d->ev[4], d->stream));
     HIP_TRY(hipGetLastError());
     return LM_OK;
 }
 
-int enqueue_match(lm_detector* d, Slot& s, float threshold, int class_idx, bool timed = false) {
+int enqueue_match(lm_detector* d, int first, int n, float threshold, int class_idx, bool timed = false) {
     ItemRange r;
     int rc;
     if ((rc = item_range(d, class_idx, &r))) return rc;
-    if ((rc = enqueue_threshold(d, s, threshold))) return rc;
-    if (timed) HIP_TRY(hipEventRecord(s.ev[0], s.stream));
-    enqueue_preprocess(d, s);
-    if ((rc = enqueue_match_stages(d, s, threshold, r, timed))) return rc;
-    s.in_flight = true;
-    return LM_OK;
+    if ((rc = enqueue_threshold(d, threshold))) return rc;
+    if (timed) HIP_TRY(hipEventRecord(d->ev[0], d->stream));
+    enqueue_preprocess(d, first, n);
+    return enqueue_match_stages(d, first, n, threshold, r, timed);
 }
 
 inline bool key_less(const u64* a, const u64* b) { return a[0] < b[0] || (a[0] == b[0] && a[1] < b[1]); }
 
-// Waits for the slot and delivers the sorted unique matches.
-int finish_match(lm_detector* d, Slot& s, lm_match_t* out, size_t cap, size_t* n_out) {
-    HIP_TRY(hipStreamSynchronize(s.stream));
-    s.in_flight = false;
-    const LmHeader h = *s.h_hdr;
+// Delivers the sorted unique matches of one slot (the stream has been synchronised).
+int collect_slot(lm_detector* d, int slot, lm_match_t* out, size_t cap, size_t* n_out) {
+    const LmHostBlock* hb = d->host_block(slot);
+    const LmHeader h = hb->hdr;
     if (h.cand_count > d->max_cand)
         return fail(LM_ERR_OVERFLOW, "scan produced " + std::to_string(h.cand_count) + " candidates, capacity " +
                                          std::to_string(d->max_cand) + " (raise lm_config.max_candidates)");
@@ -348,14 +365,16 @@ int finish_match(lm_detector* d, Slot& s, lm_match_t* out, size_t cap, size_t* n
     if (h.sorted_on_device) {
         n = h.out_count;
         size_t ncopy = std::min(n, cap);
-        size_t inl = std::min<size_t>(ncopy, INLINE_N);
-        if (out && inl) std::memcpy(out, s.h_out, inl * sizeof(lm_match_t));
+        size_t inl = std::min<size_t>(ncopy, LM_INLINE_MATCHES);
+        if (out && inl) std::memcpy(out, hb->rec, inl * sizeof(lm_match_t));
         if (out && ncopy > inl)
-            HIP_TRY(hipMemcpy(out + inl, s.out + inl, (ncopy - inl) * sizeof(lm_match_t), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(out + inl, reinterpret_cast<lm_match_t*>(d->aux(slot, d->off_out)) + inl,
+                              (ncopy - inl) * sizeof(lm_match_t), hipMemcpyDeviceToHost));
     } else {
         // more than LM_SORT_CAP matches: sort + unique the keys on the host (same total order)
         std::vector<u64> keys((size_t)h.match_count * 2);
-        HIP_TRY(hipMemcpy(keys.data(), s.keys, keys.size() * sizeof(u64), hipMemcpyDeviceToHost));
+        if (h.match_count)
+            HIP_TRY(hipMemcpy(keys.data(), d->aux(slot, d->off_keys), keys.size() * sizeof(u64), hipMemcpyDeviceToHost));
         std::vector<u32> idx(h.match_count);
         for (u32 i = 0; i < h.match_count; ++i) idx[i] = i;
         std::sort(idx.begin(), idx.end(), [&](u32 a, u32 b) { return key_less(&keys[2 * (size_t)a], &keys[2 * (size_t)b]); });
@@ -382,22 +401,23 @@ int finish_match(lm_detector* d, Slot& s, lm_match_t* out, size_t cap, size_t* n
     return LM_OK;
 }
 
-int upload_frame(lm_detector* d, Slot& s, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
+int upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
                  size_t depth_stride) {
     const lm_config& c = d->cfg;
+    Slot& s = d->slots[slot];
     if (!bgr) return fail(LM_ERR_INVALID, "sources.size() != modalities.size(): colour image missing");
     if (c.num_modalities == 2 && !depth)
         return fail(LM_ERR_INVALID, "sources.size() != modalities.size(): depth image missing");
     if (bgr_stride == 0) bgr_stride = (size_t)c.width * 3;
     if (depth_stride == 0) depth_stride = (size_t)c.width * 2;
     if (bgr_stride < (size_t)c.width * 3 || depth_stride < (size_t)c.width * 2) return fail(LM_ERR_INVALID, "stride smaller than a row");
-    HIP_TRY(hipStreamSynchronize(s.stream));  // staging buffers are reused
+    HIP_TRY(hipStreamSynchronize(d->stream));  // staging buffers are reused
     for (int y = 0; y < c.height; ++y) std::memcpy(s.h_bgr + (size_t)y * c.width * 3, bgr + y * bgr_stride, (size_t)c.width * 3);
-    HIP_TRY(hipMemcpyAsync(s.bgr[0], s.h_bgr, (size_t)c.width * c.height * 3, hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(hipMemcpyAsync(d->bgr(slot, 0), s.h_bgr, (size_t)c.width * c.height * 3, hipMemcpyHostToDevice, d->stream));
     if (c.num_modalities == 2) {
         for (int y = 0; y < c.height; ++y)
             std::memcpy(s.h_depth + (size_t)y * c.width, reinterpret_cast<const u8*>(depth) + y * depth_stride, (size_t)c.width * 2);
-        HIP_TRY(hipMemcpyAsync(s.depth, s.h_depth, (size_t)c.width * c.height * 2, hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(hipMemcpyAsync(d->depth(slot), s.h_depth, (size_t)c.width * c.height * 2, hipMemcpyHostToDevice, d->stream));
     }
     s.has_frame = true;
     return LM_OK;
@@ -421,6 +441,15 @@ int ensure_scratch(lm_detector* d, size_t bytes) {
     return LM_OK;
 }
 
+int run_match(lm_detector* d, int first, int n, float threshold, int class_idx) {
+    for (int i = 0; i < n; ++i)
+        if (!d->slots[first + i].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot " + std::to_string(first + i));
+    int rc;
+    if ((rc = enqueue_match(d, first, n, threshold, class_idx))) return rc;
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return LM_OK;
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -429,7 +458,7 @@ int ensure_scratch(lm_detector* d, size_t bytes) {
 extern "C" {
 
 const char* lm_last_error(void) { return g_err.c_str(); }
-const char* lm_version(void) { return "linemod_hip 0.1 (gfx950)"; }
+const char* lm_version(void) { return "linemod_hip 0.2 (gfx950)"; }
 
 void lm_default_config(lm_config* c, int color_only, int width, int height) {
     std::memset(c, 0, sizeof(*c));
@@ -452,9 +481,10 @@ int lm_create(const lm_config* cfg, lm_detector** out) {
     if (c.pyramid_levels < 1 || c.pyramid_levels > LM_MAX_LEVELS) return fail(LM_ERR_INVALID, "pyramid_levels out of range");
     if (c.width <= 0 || c.height <= 0) return fail(LM_ERR_INVALID, "bad frame size");
     if (c.shard_size < 1 || c.shard_rank < 0 || c.shard_rank >= c.shard_size) return fail(LM_ERR_INVALID, "bad shard rank/size");
-    if (c.max_candidates <= 0) c.max_candidates = 1 << 20;
+    if (c.max_candidates <= 0) c.max_candidates = 1 << 18;
     if (c.max_matches <= 0) c.max_matches = 1 << 18;
     if (c.frame_slots <= 0) c.frame_slots = 8;
+    if (c.frame_slots > 1024) return fail(LM_ERR_INVALID, "frame_slots out of range");
     lm_detector* d = new lm_detector();
     d->cfg = c;
     d->max_cand = (u32)c.max_candidates;
@@ -472,13 +502,15 @@ int lm_create(const lm_config* cfg, lm_detector** out) {
         LmLevelGeom& g = d->geom[l];
         g.w = w; g.h = h; g.T = T; g.W = w / T; g.H = h / T;
         g.wh = (u32)g.W * (u32)g.H;
-        size_t pad = align_up((size_t)g.wh + 2 * LM_SCAN_CHUNK + 64, 256);
+        // pad: one full linear memory (a scan may start W*H-1 bytes into the last memory and read
+        // template_positions <= W*H bytes) + the 16-row patch of the refinement + vector-load slack
+        size_t pad = align_up((size_t)g.wh + 16 * (size_t)g.W + 2 * LM_SCAN_CHUNK + 64, 256);
         size_t ori = align_up((size_t)T * T * g.wh, 256) + pad;
+        size_t arena = (size_t)c.num_modalities * 8 * ori + pad;
+        if (arena > 0xFFFFFFFFull) { delete d; return fail(LM_ERR_INVALID, "frame too large for 32-bit arena offsets"); }
         g.ori_stride = (u32)ori;
         g.mod_stride = (u32)(8 * ori);
         g.zero_off = (u32)((size_t)c.num_modalities * g.mod_stride);
-        size_t arena = (size_t)g.zero_off + pad;
-        if (arena > 0xFFFFFFFFull) { delete d; return fail(LM_ERR_INVALID, "frame too large for 32-bit arena offsets"); }
         g.arena_bytes = (u32)arena;
     }
     lmh::default_similarity_lut(d->sim_lut);
@@ -492,16 +524,11 @@ void lm_destroy(lm_detector* d) {
     if (d->dev_ready) {
         hipSetDevice(d->cfg.device);
         hipDeviceSynchronize();
-        for (Slot& s : d->slots) {
-            for (int l = 0; l < LM_MAX_LEVELS; ++l) {
-                hipFree(s.bgr[l]); hipFree(s.lm[l]);
-                for (int m = 0; m < 2; ++m) hipFree(s.quant[l][m]);
-            }
-            hipFree(s.depth); hipFree(s.cand); hipFree(s.keys); hipFree(s.out); hipFree(s.hdr); hipFree(s.raw_thr);
-            hipHostFree(s.h_bgr); hipHostFree(s.h_depth); hipHostFree(s.h_hdr); hipHostFree(s.h_out); hipHostFree(s.h_raw_thr);
-            for (auto& ev : s.ev) if (ev) hipEventDestroy(ev);
-            if (s.stream) hipStreamDestroy(s.stream);
-        }
+        for (Slot& s : d->slots) { hipHostFree(s.h_bgr); hipHostFree(s.h_depth); }
+        hipFree(d->frame_arena); hipFree(d->aux_arena); hipHostFree(d->host_blocks);
+        hipFree(d->d_raw_thr); hipHostFree(d->h_raw_thr);
+        for (auto& ev : d->ev) if (ev) hipEventDestroy(ev);
+        if (d->stream) hipStreamDestroy(d->stream);
         free_device_bank(d);
         hipFree(d->d_resp_tab); hipFree(d->d_normal_lut); hipFree(d->d_scratch);
     }
@@ -559,37 +586,36 @@ int lm_add_template(lm_detector* d, const char* class_id, const uint8_t* bgr, si
     if (!class_id) return fail(LM_ERR_INVALID, "null class id");
     const lm_config& c = d->cfg;
     const int M = c.num_modalities, L = c.pyramid_levels;
-    Slot& s = d->slots[0];
-    if ((rc = upload_frame(d, s, bgr, bgr_stride, depth, depth_stride))) return rc;
-    s.has_frame = false;  // slot 0 now holds a template image, not a scene frame
+    if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride))) return rc;
+    d->slots[0].has_frame = false;  // slot 0 now holds a template image, not a scene frame
     // quantise every level on the GPU, keeping the gradient magnitude this time
     size_t mag_off[LM_MAX_LEVELS], total = 0;
     for (int l = 0; l < L; ++l) { mag_off[l] = total; total += align_up((size_t)d->lw[l] * d->lh[l] * sizeof(float), 256); }
     if ((rc = ensure_scratch(d, total))) return rc;
     u8* scratch = static_cast<u8*>(d->d_scratch);
     for (int l = 0; l < L; ++l) {
-        if (l > 0) lmk_pyrdown(s.stream, s.bgr[l - 1], d->lw[l - 1], d->lh[l - 1], s.bgr[l]);
-        lmk_color_quantize(s.stream, s.bgr[l], d->lw[l], d->lh[l], c.weak_threshold, s.quant[l][0],
-                           reinterpret_cast<float*>(scratch + mag_off[l]));
+        if (l > 0) lmk_pyrdown(d->stream, d->bgr(0, l - 1), d->lw[l - 1], d->lh[l - 1], d->bgr(0, l), 0, 1);
+        lmk_color_quantize(d->stream, d->bgr(0, l), d->lw[l], d->lh[l], c.weak_threshold, d->quant(0, l, 0),
+                           reinterpret_cast<float*>(scratch + mag_off[l]), 0, 1);
     }
     if (M == 2) {
-        lmk_depth_quantize(s.stream, s.depth, d->lw[0], d->lh[0], c.distance_threshold, c.difference_threshold,
-                           d->d_normal_lut, s.quant[0][1]);
-        enqueue_depth_pyramid(d, s);
+        lmk_depth_quantize(d->stream, d->depth(0), d->lw[0], d->lh[0], c.distance_threshold, c.difference_threshold,
+                           d->d_normal_lut, d->quant(0, 0, 1), 0, 1);
+        enqueue_depth_pyramid(d, 0, 1);
     }
     std::vector<lmh::ExtractLevel> lv(L);
     for (int l = 0; l < L; ++l) {
         size_t px = (size_t)d->lw[l] * d->lh[l];
         lv[l].w = d->lw[l]; lv[l].h = d->lh[l];
         lv[l].color_q.resize(px); lv[l].color_mag.resize(px);
-        HIP_TRY(hipMemcpyAsync(lv[l].color_q.data(), s.quant[l][0], px, hipMemcpyDeviceToHost, s.stream));
-        HIP_TRY(hipMemcpyAsync(lv[l].color_mag.data(), scratch + mag_off[l], px * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(hipMemcpyAsync(lv[l].color_q.data(), d->quant(0, l, 0), px, hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipMemcpyAsync(lv[l].color_mag.data(), scratch + mag_off[l], px * sizeof(float), hipMemcpyDeviceToHost, d->stream));
         if (M == 2) {
             lv[l].depth_q.resize(px);
-            HIP_TRY(hipMemcpyAsync(lv[l].depth_q.data(), s.quant[l][1], px, hipMemcpyDeviceToHost, s.stream));
+            HIP_TRY(hipMemcpyAsync(lv[l].depth_q.data(), d->quant(0, l, 1), px, hipMemcpyDeviceToHost, d->stream));
         }
     }
-    HIP_TRY(hipStreamSynchronize(s.stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
     HIP_TRY(hipGetLastError());
     if (mask) {  // mask pyramid: resize(..., INTER_NEAREST) per level
         if (mask_stride == 0) mask_stride = (size_t)c.width;
@@ -631,19 +657,17 @@ int lm_upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_str
                     size_t depth_stride) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = check_slot(d, slot))) return rc;
-    return upload_frame(d, d->slots[slot], bgr, bgr_stride, depth, depth_stride);
+    if ((rc = check_slots(d, slot, 1))) return rc;
+    return upload_frame(d, slot, bgr, bgr_stride, depth, depth_stride);
 }
 
 int lm_match_slot(lm_detector* d, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = check_slot(d, slot))) return rc;
+    if ((rc = check_slots(d, slot, 1))) return rc;
     if ((rc = ensure_bank(d))) return rc;
-    Slot& s = d->slots[slot];
-    if (!s.has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
-    if ((rc = enqueue_match(d, s, threshold, class_idx))) return rc;
-    return finish_match(d, s, out, cap, n_out);
+    if ((rc = run_match(d, slot, 1, threshold, class_idx))) return rc;
+    return collect_slot(d, slot, out, cap, n_out);
 }
 
 int lm_match(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
@@ -651,10 +675,9 @@ int lm_match(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
     if ((rc = ensure_bank(d))) return rc;
-    Slot& s = d->slots[0];
-    if ((rc = upload_frame(d, s, bgr, bgr_stride, depth, depth_stride))) return rc;
-    if ((rc = enqueue_match(d, s, threshold, class_idx))) return rc;
-    return finish_match(d, s, out, cap, n_out);
+    if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride))) return rc;
+    if ((rc = run_match(d, 0, 1, threshold, class_idx))) return rc;
+    return collect_slot(d, 0, out, cap, n_out);
 }
 
 int lm_match_batch(lm_detector* d, int n_slots, float threshold, int class_idx, lm_match_t* out, size_t cap_per_frame,
@@ -662,16 +685,14 @@ int lm_match_batch(lm_detector* d, int n_slots, float threshold, int class_idx, 
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
     if ((rc = ensure_bank(d))) return rc;
-    if (n_slots < 0 || n_slots > (int)d->slots.size()) return fail(LM_ERR_INVALID, "n_slots exceeds frame_slots");
-    for (int i = 0; i < n_slots; ++i) {
-        if (!d->slots[i].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot " + std::to_string(i));
-        if ((rc = enqueue_match(d, d->slots[i], threshold, class_idx))) return rc;
-    }
+    if ((rc = check_slots(d, 0, n_slots))) return rc;
+    if (n_slots == 0) return LM_OK;
+    if ((rc = run_match(d, 0, n_slots, threshold, class_idx))) return rc;
     int first_err = LM_OK;
     std::string first_msg;
     for (int i = 0; i < n_slots; ++i) {
         size_t n = 0;
-        rc = finish_match(d, d->slots[i], out ? out + (size_t)i * cap_per_frame : nullptr, cap_per_frame, &n);
+        rc = collect_slot(d, i, out ? out + (size_t)i * cap_per_frame : nullptr, cap_per_frame, &n);
         if (counts) counts[i] = (int32_t)n;
         if (rc && !first_err) { first_err = rc; first_msg = g_err; }
     }
@@ -715,12 +736,12 @@ int lm_stage_color_quantize(lm_detector* d, const uint8_t* bgr, int w, int h, fl
     if ((rc = ready_for_compute(d))) return rc;
     if (!bgr || !quantized || w <= 0 || h <= 0) return fail(LM_ERR_INVALID, "bad argument");
     size_t px = (size_t)w * h;
-    size_t o_q = align_up(px * 3, 256), o_m = o_q + align_up(px, 256);
+    size_t o_q = align_up(px * 3 + 256, 256), o_m = o_q + align_up(px, 256);
     if ((rc = ensure_scratch(d, o_m + px * 4))) return rc;
     u8* base = static_cast<u8*>(d->d_scratch);
-    hipStream_t st = d->slots[0].stream;
+    hipStream_t st = d->stream;
     HIP_TRY(hipMemcpyAsync(base, bgr, px * 3, hipMemcpyHostToDevice, st));
-    lmk_color_quantize(st, base, w, h, weak_threshold, base + o_q, magnitude ? reinterpret_cast<float*>(base + o_m) : nullptr);
+    lmk_color_quantize(st, base, w, h, weak_threshold, base + o_q, magnitude ? reinterpret_cast<float*>(base + o_m) : nullptr, 0, 1);
     HIP_TRY(hipMemcpyAsync(quantized, base + o_q, px, hipMemcpyDeviceToHost, st));
     if (magnitude) HIP_TRY(hipMemcpyAsync(magnitude, base + o_m, px * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -736,9 +757,9 @@ int lm_stage_pyrdown(lm_detector* d, const uint8_t* bgr, int w, int h, uint8_t* 
     size_t o_o = align_up(px * 3, 256);
     if ((rc = ensure_scratch(d, o_o + opx * 3))) return rc;
     u8* base = static_cast<u8*>(d->d_scratch);
-    hipStream_t st = d->slots[0].stream;
+    hipStream_t st = d->stream;
     HIP_TRY(hipMemcpyAsync(base, bgr, px * 3, hipMemcpyHostToDevice, st));
-    lmk_pyrdown(st, base, w, h, base + o_o);
+    lmk_pyrdown(st, base, w, h, base + o_o, 0, 1);
     HIP_TRY(hipMemcpyAsync(out, base + o_o, opx * 3, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -753,10 +774,10 @@ int lm_stage_depth_quantize(lm_detector* d, const uint16_t* depth, int w, int h,
     size_t o_q = align_up(px * 2, 256);
     if ((rc = ensure_scratch(d, o_q + px))) return rc;
     u8* base = static_cast<u8*>(d->d_scratch);
-    hipStream_t st = d->slots[0].stream;
+    hipStream_t st = d->stream;
     HIP_TRY(hipMemcpyAsync(base, depth, px * 2, hipMemcpyHostToDevice, st));
     lmk_depth_quantize(st, reinterpret_cast<u16*>(base), w, h, d->cfg.distance_threshold, d->cfg.difference_threshold,
-                       d->d_normal_lut, base + o_q);
+                       d->d_normal_lut, base + o_q, 0, 1);
     HIP_TRY(hipMemcpyAsync(quantized, base + o_q, px, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -771,9 +792,9 @@ int lm_stage_linear_memories(lm_detector* d, const uint8_t* quantized, int w, in
     size_t o_l = align_up(px, 256);
     if ((rc = ensure_scratch(d, o_l + 8 * px))) return rc;
     u8* base = static_cast<u8*>(d->d_scratch);
-    hipStream_t st = d->slots[0].stream;
+    hipStream_t st = d->stream;
     HIP_TRY(hipMemcpyAsync(base, quantized, px, hipMemcpyHostToDevice, st));
-    lmk_linear_memories(st, base, w, 0, w, h, T, d->d_resp_tab, base + o_l, (u32)px);  // dense: ori_stride = T*T*W*H
+    lmk_linear_memories(st, base, w, 0, w, h, T, d->d_resp_tab, base + o_l, (u32)px, 0, 0, 1);  // dense: ori_stride = T*T*W*H
     HIP_TRY(hipMemcpyAsync(out, base + o_l, 8 * px, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -783,11 +804,10 @@ int lm_stage_linear_memories(lm_detector* d, const uint8_t* quantized, int w, in
 int lm_prepare_slot(lm_detector* d, int slot) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = check_slot(d, slot))) return rc;
-    Slot& s = d->slots[slot];
-    if (!s.has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
-    enqueue_preprocess(d, s);
-    HIP_TRY(hipStreamSynchronize(s.stream));
+    if ((rc = check_slots(d, slot, 1))) return rc;
+    if (!d->slots[slot].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
+    enqueue_preprocess(d, slot, 1);
+    HIP_TRY(hipStreamSynchronize(d->stream));
     HIP_TRY(hipGetLastError());
     return LM_OK;
 }
@@ -795,20 +815,19 @@ int lm_prepare_slot(lm_detector* d, int slot) {
 int lm_debug_read(lm_detector* d, int slot, int what, int level, int modality, uint8_t* out, size_t cap, size_t* size_out) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = check_slot(d, slot))) return rc;
+    if ((rc = check_slots(d, slot, 1))) return rc;
     if (level < 0 || level >= d->cfg.pyramid_levels || modality < 0 || modality >= d->cfg.num_modalities)
         return fail(LM_ERR_INVALID, "level/modality out of range");
-    Slot& s = d->slots[slot];
-    HIP_TRY(hipStreamSynchronize(s.stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
     const LmLevelGeom& g = d->geom[level];
     if (what == 0) {
         size_t n = (size_t)g.w * g.h;
         if (size_out) *size_out = n;
         if (modality == 1 && level > 0) {  // materialise the NN pyramid of the depth modality on demand
-            enqueue_depth_pyramid(d, s);
-            HIP_TRY(hipStreamSynchronize(s.stream));
+            enqueue_depth_pyramid(d, slot, 1);
+            HIP_TRY(hipStreamSynchronize(d->stream));
         }
-        if (out) HIP_TRY(hipMemcpy(out, s.quant[level][modality], std::min(n, cap), hipMemcpyDeviceToHost));
+        if (out) HIP_TRY(hipMemcpy(out, d->quant(slot, level, modality), std::min(n, cap), hipMemcpyDeviceToHost));
         return LM_OK;
     }
     if (what == 2) {
@@ -818,7 +837,7 @@ int lm_debug_read(lm_detector* d, int slot, int what, int level, int modality, u
         if (out) {
             if (cap < n) return fail(LM_ERR_INVALID, "buffer too small");
             for (int o = 0; o < 8; ++o)
-                HIP_TRY(hipMemcpy(out + o * blk, s.lm[level] + (size_t)modality * g.mod_stride + (size_t)o * g.ori_stride, blk,
+                HIP_TRY(hipMemcpy(out + o * blk, d->lm(slot, level) + (size_t)modality * g.mod_stride + (size_t)o * g.ori_stride, blk,
                                   hipMemcpyDeviceToHost));
         }
         return LM_OK;
@@ -829,22 +848,20 @@ int lm_debug_read(lm_detector* d, int slot, int what, int level, int modality, u
 int lm_stage_scan(lm_detector* d, int slot, float threshold, int class_idx, int32_t* out, size_t cap_records, size_t* n_out) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = check_slot(d, slot))) return rc;
+    if ((rc = check_slots(d, slot, 1))) return rc;
     if ((rc = ensure_bank(d))) return rc;
-    Slot& s = d->slots[slot];
     ItemRange r;
     if ((rc = item_range(d, class_idx, &r))) return rc;
-    if ((rc = enqueue_threshold(d, s, threshold))) return rc;
-    HIP_TRY(hipMemsetAsync(s.hdr, 0, sizeof(LmHeader), s.stream));
-    lmk_scan(s.stream, make_scan_args(d, s, r), d->scan_variant);
-    LmHeader h;
-    HIP_TRY(hipMemcpyAsync(s.h_hdr, s.hdr, sizeof(LmHeader), hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(hipStreamSynchronize(s.stream));
+    if ((rc = enqueue_threshold(d, threshold))) return rc;
+    lmk_scan(d->stream, make_scan_args(d, slot, r), d->scan_variant, 1);
+    LmDevHeader h;
+    HIP_TRY(hipMemcpyAsync(&h, d->aux(slot, d->off_hdr), sizeof(h), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
     HIP_TRY(hipGetLastError());
-    h = *s.h_hdr;
+    HIP_TRY(hipMemset(d->aux(slot, d->off_hdr), 0, sizeof(LmDevHeader)));  // re-arm the counters ourselves
     if (h.cand_count > d->max_cand) return fail(LM_ERR_OVERFLOW, "candidate buffer overflow");
     std::vector<LmCand> cand(h.cand_count);
-    if (h.cand_count) HIP_TRY(hipMemcpy(cand.data(), s.cand, cand.size() * sizeof(LmCand), hipMemcpyDeviceToHost));
+    if (h.cand_count) HIP_TRY(hipMemcpy(cand.data(), d->aux(slot, d->off_cand), cand.size() * sizeof(LmCand), hipMemcpyDeviceToHost));
     struct Rec { int32_t tid, cls, x, y; };
     std::vector<Rec> recs(cand.size());
     for (size_t i = 0; i < cand.size(); ++i)
@@ -864,23 +881,23 @@ int lm_time_scan(lm_detector* d, int slot, float threshold, int class_idx, int i
                  double* algorithmic_bytes_out) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = check_slot(d, slot))) return rc;
+    if ((rc = check_slots(d, slot, 1))) return rc;
     if ((rc = ensure_bank(d))) return rc;
     if (iters <= 0) return fail(LM_ERR_INVALID, "iters must be positive");
-    Slot& s = d->slots[slot];
     ItemRange r;
     if ((rc = item_range(d, class_idx, &r))) return rc;
-    if ((rc = enqueue_threshold(d, s, threshold))) return rc;
-    LmScanArgs a = make_scan_args(d, s, r);
-    HIP_TRY(hipMemsetAsync(s.hdr, 0, sizeof(LmHeader), s.stream));
-    for (int i = 0; i < 3; ++i) lmk_scan(s.stream, a, variant);
-    HIP_TRY(hipEventRecord(s.ev[0], s.stream));
-    for (int i = 0; i < iters; ++i) lmk_scan(s.stream, a, variant);
-    HIP_TRY(hipEventRecord(s.ev[1], s.stream));
-    HIP_TRY(hipStreamSynchronize(s.stream));
+    if ((rc = enqueue_threshold(d, threshold))) return rc;
+    LmScanArgs a = make_scan_args(d, slot, r);
+    a.cand_cap = 0;  // timing only: count candidates, store none (the list would overflow across iterations)
+    for (int i = 0; i < 3; ++i) lmk_scan(d->stream, a, variant, 1);
+    HIP_TRY(hipEventRecord(d->ev[0], d->stream));
+    for (int i = 0; i < iters; ++i) lmk_scan(d->stream, a, variant, 1);
+    HIP_TRY(hipEventRecord(d->ev[1], d->stream));
+    HIP_TRY(hipMemsetAsync(d->aux(slot, d->off_hdr), 0, sizeof(LmDevHeader), d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
     HIP_TRY(hipGetLastError());
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, s.ev[0], s.ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
     if (avg_us_out) *avg_us_out = (double)ms * 1000.0 / iters;
     if (algorithmic_bytes_out) {
         double b = 0;
@@ -894,18 +911,17 @@ int lm_time_scan(lm_detector* d, int slot, float threshold, int class_idx, int i
 int lm_time_stages(lm_detector* d, int slot, float threshold, int class_idx, int iters, double out_us[4]) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = check_slot(d, slot))) return rc;
+    if ((rc = check_slots(d, slot, 1))) return rc;
     if ((rc = ensure_bank(d))) return rc;
     if (iters <= 0 || !out_us) return fail(LM_ERR_INVALID, "bad argument");
-    Slot& s = d->slots[slot];
-    if (!s.has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
+    if (!d->slots[slot].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
     double acc[4] = {0, 0, 0, 0};
     for (int it = 0; it < iters; ++it) {
-        if ((rc = enqueue_match(d, s, threshold, class_idx, true))) return rc;
-        if ((rc = finish_match(d, s, nullptr, 0, nullptr))) return rc;
+        if ((rc = enqueue_match(d, slot, 1, threshold, class_idx, true))) return rc;
+        HIP_TRY(hipStreamSynchronize(d->stream));
         for (int k = 0; k < 4; ++k) {
             float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, s.ev[k], s.ev[k + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, d->ev[k], d->ev[k + 1]));
             acc[k] += (double)ms * 1000.0;
         }
     }
@@ -913,7 +929,6 @@ int lm_time_stages(lm_detector* d, int slot, float threshold, int class_idx, int
     return LM_OK;
 }
 
-// Not part of the public header's stable surface: selects the scan kernel variant used by lm_match_t*.
 int lm_set_scan_variant(lm_detector* d, int variant) { if (!d) return LM_ERR_INVALID; d->scan_variant = variant; return LM_OK; }
 
 }  // extern "C"

@@ -1,23 +1,30 @@
 // lm_kernels.h -- host-callable launchers of the gfx950 kernels in lm_kernels.hip.
+// Every launcher processes `nslots` consecutive frame slots (grid.z) whose buffers are `*_slot_stride`
+// bytes apart; pass stride 0 / nslots 1 for a single set of buffers.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "lm_common.h"
 
 // a4: cv::pyrDown on dense BGR (sw x sh) -> (sw/2 x sh/2)
-void lmk_pyrdown(hipStream_t s, const u8* src, int sw, int sh, u8* dst);
+void lmk_pyrdown(hipStream_t s, const u8* src, int sw, int sh, u8* dst, size_t slot_stride, int nslots);
+// DepthNormalPyramid::pyrDown: nearest-neighbour half-size copy of a quantised image
+void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, int dh, size_t slot_stride, int nslots);
 // a3: ColorGradient quantisation of a dense w x h BGR image; mag may be null
-void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_threshold, u8* quant, float* mag);
+void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_threshold, u8* quant, float* mag,
+                        size_t slot_stride, int nslots);
 // a5: DepthNormal quantisation (normals + LUT + 5x5 median)
 void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_thr, int diff_thr, const u8* normal_lut,
-                        u8* quant);
+                        u8* quant, size_t slot_stride, int nslots);
 // a6+a8+a9+a10: (optional NN half-size read of `q`) -> spread(T) -> 8 response maps -> linear memories.
 // q is the quantised image to read with row pitch qpitch: src_shift 0 = this level's image, 1 = the finer
 // level's image sampled at (2y, 2x).  lm points at the modality's first orientation block.
 void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, int w, int h, int T,
-                         const u64* resp_tab, u8* lm, u32 ori_stride);
+                         const u64* resp_tab, u8* lm, u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
+                         int nslots);
 
 struct LmScanArgs {
-    const u8* lm;            // lowest level arena
+    const u8* lm;            // lowest level arena of slot 0
+    size_t lm_slot_stride;
     const u32* item_t;       // work items: bank-local template index
     const u32* item_chunk;   //             chunk of LM_SCAN_CHUNK positions
     int item_lo, n_items;
@@ -27,35 +34,45 @@ struct LmScanArgs {
     int M, fpad;
     const int* raw_thr_by_n; // [128]
     int W, T;
+    LmDevHeader* hdr;        // slot 0; aux_slot_stride apart
     LmCand* cand;
-    u32* cand_count;
+    size_t aux_slot_stride;
     u32 cand_cap;
 };
 // a11+a12+a13: similarity scan over the lowest level fused with the threshold scan.
-// variant selects the load strategy (0 = 16 B/lane unaligned vector loads; others see lm_kernels.hip).
-void lmk_scan(hipStream_t s, const LmScanArgs& a, int variant);
+// variant selects the unroll depth of the feature loop (0: 8 loads in flight, 1: 4, 2: 2).
+void lmk_scan(hipStream_t s, const LmScanArgs& a, int variant, int nslots);
 
 struct LmRefineArgs {
-    const u8* lm;            // arena of the level being refined at
+    const u8* lm;            // arena of the level being refined at, slot 0
+    size_t lm_slot_stride;
     LmLevelGeom g;
     int M;
     const LmRefMeta* meta;   // [nt] for this level
     const LmRefFeat* feats;
+    LmDevHeader* hdr;
     LmCand* cand;
-    const u32* cand_count;
+    u64* keys;               // [match_cap][2]
+    size_t aux_slot_stride;
     u32 cand_cap;
+    u32 match_cap;
     float threshold;
-    // LAST level only: emit sort keys
     const int* t_global;
     const int* t_class;
-    u64* keys;               // [match_cap][2]
-    u32* match_count;
-    u32 match_cap;
 };
 // a14: similarityLocal + argmax + rescore (+ threshold filter); last=true also emits sort keys.
-void lmk_refine(hipStream_t s, const LmRefineArgs& a, bool last);
+void lmk_refine(hipStream_t s, const LmRefineArgs& a, bool last, int nslots);
 // pyramid_levels == 1: candidates become matches unrefined.
-void lmk_emit_unrefined(hipStream_t s, const LmRefineArgs& a);
-// a15: sort + adjacent-unique of up to LM_SORT_CAP keys in one workgroup; writes lm_match-layout records.
-void lmk_sort_unique(hipStream_t s, const u64* keys, const u32* match_count, u32 match_cap, void* out_matches,
-                     LmHeader* hdr);
+void lmk_emit_unrefined(hipStream_t s, const LmRefineArgs& a, int nslots);
+
+struct LmSortArgs {
+    LmDevHeader* hdr;
+    const u64* keys;
+    LmOutMatch* out;         // [LM_SORT_CAP] per slot
+    size_t aux_slot_stride;
+    LmHostBlock* host;       // host-mapped, slot 0
+    size_t host_slot_stride;
+    u32 cand_cap, match_cap;
+};
+// a15: sort + adjacent-unique of up to LM_SORT_CAP keys, one workgroup per slot.
+void lmk_sort_unique(hipStream_t s, const LmSortArgs& a, int nslots);

@@ -1,27 +1,29 @@
 // lm_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the LINE-MOD match path.
 //
 // One kernel per upstream stage group:
-//   k_pyrdown            a4   cv::pyrDown of the BGR source
-//   k_color_quantize     a3   GaussianBlur 7x7 + Sobel + max-channel + fastAtan2 + 3x3 vote, LDS-tiled
-//   k_depth_quantize     a5   bilateral normals + NORMAL_LUT + 5x5 median, LDS-tiled
-//   k_linear_memories    a6-a10  NN pyrDown read + spread(T) + response LUT + linearize, one row band per WG
+//   k_pyrdown            a4      cv::pyrDown of the BGR source
+//   k_color_quantize     a3      GaussianBlur 7x7 + Sobel + max-channel + fastAtan2 + 3x3 vote, LDS-tiled
+//   k_depth_quantize     a5      bilateral normals + NORMAL_LUT + 5x5 median, LDS-tiled
+//   k_linear_memories    a6-a10  NN pyrDown read + spread(T) + response LUT + linearize
 //   k_scan               a11-a13 similarity scan of the lowest level fused with the threshold scan (HOT)
-//   k_refine             a14  similarityLocal 16x16 + first-max argmax + rescore + threshold filter
-//   k_sort_unique        a15  LDS bitonic sort + adjacent-unique under the total order of SURVEY.md A.9
+//   k_refine             a14     similarityLocal 16x16 + first-max argmax + rescore + threshold filter
+//   k_sort_unique        a15     rank / bitonic sort in LDS + adjacent-unique (total order of SURVEY.md A.9)
+//
+// Every kernel takes the buffers of frame slot 0 plus the byte stride between slots and processes
+// slot blockIdx.z, so a batch of resident frames is one launch per stage.
 //
 // All arithmetic is integer/byte except two float islands (fastAtan2 polynomial, normal
 // normalisation) which use the explicit round-to-nearest intrinsics in the oracle's operation order,
 // so every stage is bit-identical to oracle/linemod_oracle.cpp.  No MFMA: this is OR / LUT / u8 add.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "lm_common.h"
 #include "lm_kernels.h"
 
 namespace {
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(1))) U32x4U { u32x4 v; };
-struct __attribute__((packed, aligned(1))) U32x2U { u32x2 v; };
 struct __attribute__((packed, aligned(1))) U32U { u32 v; };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -31,14 +33,21 @@ __device__ __forceinline__ int refl101(int p, int n) {
     return p;
 }
 __device__ __forceinline__ u32x4 ld16u(const u8* p) { return reinterpret_cast<const U32x4U*>(p)->v; }
-__device__ __forceinline__ u32x2 ld8u(const u8* p) { return reinterpret_cast<const U32x2U*>(p)->v; }
 __device__ __forceinline__ u32 ld4u(const u8* p) { return reinterpret_cast<const U32U*>(p)->v; }
+
+template <typename T>
+__device__ __forceinline__ T* slot_ptr(T* p, size_t slot_stride) {
+    return reinterpret_cast<T*>(reinterpret_cast<u8*>(const_cast<typename std::remove_const<T>::type*>(p)) +
+                                (size_t)blockIdx.z * slot_stride);
+}
 
 // ------------------------------------------------------------------------------------------------
 // a4  cv::pyrDown, CV_8UC3: 5x5 [1 4 6 4 1]^2, BORDER_REFLECT_101, (sum + 128) >> 8
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pyrdown(const u8* __restrict__ src, int sw, int sh, u8* __restrict__ dst,
-                                                  int dw, int dh) {
+__global__ __launch_bounds__(256) void k_pyrdown(const u8* __restrict__ src0, int sw, int sh, u8* __restrict__ dst0,
+                                                  int dw, int dh, size_t slot_stride) {
+    const u8* src = slot_ptr(src0, slot_stride);
+    u8* dst = slot_ptr(dst0, slot_stride);
     int x = blockIdx.x * 64 + (threadIdx.x & 63);
     int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= dw || y >= dh) return;
@@ -63,17 +72,19 @@ __global__ __launch_bounds__(256) void k_pyrdown(const u8* __restrict__ src, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// a3  ColorGradient::process.  One 64x16 output tile per workgroup; the 7x7 blur (+-3), the Sobel
-// (+-1) and the vote (+-1) need a 5-pixel halo, all staged through LDS.
+// a3  ColorGradient::process.  One 32x8 output tile per 256-thread workgroup (1200 workgroups at
+// 640x480 so several are resident per CU and hide each other's barriers).  The 7x7 blur (+-3), the
+// Sobel (+-1) and the vote (+-1) need a 5-pixel halo, all staged through LDS.
 // ------------------------------------------------------------------------------------------------
-#define CT_W 64
-#define CT_H 16
-#define RAW_W (CT_W + 10)
-#define RAW_H (CT_H + 10)
-#define SM_W (CT_W + 4)
-#define SM_H (CT_H + 4)
-#define Q_W (CT_W + 2)
-#define Q_H (CT_H + 2)
+#define CT_W 32
+#define CT_H 8
+#define RAW_W (CT_W + 10)   // 42 px = 126 B per row
+#define RAW_H (CT_H + 10)   // 18
+#define RAW_PITCH 128
+#define SM_W (CT_W + 4)     // 36
+#define SM_H (CT_H + 4)     // 12
+#define Q_W (CT_W + 2)      // 34
+#define Q_H (CT_H + 2)      // 10
 
 // cv::fastAtan2 polynomial in degrees -- same operation order as oracle fast_atan2_deg().
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
@@ -98,24 +109,46 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-__global__ __launch_bounds__(256) void k_color_quantize(const u8* __restrict__ bgr, int w, int h, float thr2,
-                                                         u8* __restrict__ quant, float* __restrict__ mag) {
-    __shared__ u8 raw[RAW_H][RAW_W * 3];
+__global__ __launch_bounds__(256) void k_color_quantize(const u8* __restrict__ bgr0, int w, int h, float thr2,
+                                                         u8* __restrict__ quant0, float* __restrict__ mag0,
+                                                         size_t slot_stride) {
+    __shared__ __attribute__((aligned(16))) u8 raw[RAW_H][RAW_PITCH];
     __shared__ u16 hb[RAW_H][SM_W * 3];
-    __shared__ u8 sm[SM_H][SM_W * 3];
-    __shared__ u8 qn[Q_H][Q_W];
+    __shared__ u8 sm[SM_H][SM_W * 3 + 4];
+    __shared__ u8 qn[Q_H][Q_W + 2];
+    const u8* bgr = slot_ptr(bgr0, slot_stride);
+    u8* quant = slot_ptr(quant0, slot_stride);
+    float* mag = mag0 ? slot_ptr(mag0, slot_stride) : nullptr;
     const int tid = threadIdx.x;
     const int ox = blockIdx.x * CT_W, oy = blockIdx.y * CT_H;
 
-    // raw tile, replicate-clamped coordinates
-    for (int i = tid; i < RAW_H * RAW_W; i += 256) {
-        int ry = i / RAW_W, rx = i - ry * RAW_W;
-        int gy = clampi(oy - 5 + ry, 0, h - 1), gx = clampi(ox - 5 + rx, 0, w - 1);
-        const u8* p = bgr + ((size_t)gy * w + gx) * 3;
-        raw[ry][rx * 3 + 0] = p[0]; raw[ry][rx * 3 + 1] = p[1]; raw[ry][rx * 3 + 2] = p[2];
+    // ---- raw tile (replicate-clamped coordinates)
+    const bool interior = (ox >= 5) && (ox + CT_W + 6 < w) && (oy >= 5) && (oy + CT_H + 5 <= h);
+    if (interior) {
+        // 18 rows x 32 dwords (126 B used): all loads issued before the LDS stores
+        const u8* base = bgr + ((size_t)(oy - 5) * w + (ox - 5)) * 3;
+        u32 v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int i = tid + k * 256;
+            int r = i >> 5, c = i & 31;
+            v[k] = (i < RAW_H * 32) ? ld4u(base + (size_t)r * w * 3 + 4 * c) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int i = tid + k * 256;
+            if (i < RAW_H * 32) reinterpret_cast<u32*>(&raw[i >> 5][0])[i & 31] = v[k];
+        }
+    } else {
+        for (int i = tid; i < RAW_H * RAW_W; i += 256) {
+            int ry = i / RAW_W, rx = i - ry * RAW_W;
+            int gy = clampi(oy - 5 + ry, 0, h - 1), gx = clampi(ox - 5 + rx, 0, w - 1);
+            const u8* p = bgr + ((size_t)gy * w + gx) * 3;
+            raw[ry][rx * 3 + 0] = p[0]; raw[ry][rx * 3 + 1] = p[1]; raw[ry][rx * 3 + 2] = p[2];
+        }
     }
     __syncthreads();
-    // horizontal 7-tap {8,28,56,72,56,28,8} at the CLAMPED centre column (Sobel replicates the
+    // ---- horizontal 7-tap {8,28,56,72,56,28,8} at the CLAMPED centre column (Sobel replicates the
     // smoothed image, so smoothed(-1) must equal smoothed(0), not a blur centred outside)
     for (int i = tid; i < RAW_H * SM_W; i += 256) {
         int ry = i / SM_W, tx = i - ry * SM_W;
@@ -141,7 +174,7 @@ __global__ __launch_bounds__(256) void k_color_quantize(const u8* __restrict__ b
         }
     }
     __syncthreads();
-    // Sobel (CV_16S) on the three channels, strongest channel, orientation, 16 -> 8 bins
+    // ---- Sobel (CV_16S) on the three channels, strongest channel, orientation, 16 -> 8 bins
     const float scale = (float)(16.0 / 360.0);
     for (int i = tid; i < Q_H * Q_W; i += 256) {
         int qy = i / Q_W, qx = i - qy * Q_W;
@@ -157,7 +190,7 @@ __global__ __launch_bounds__(256) void k_color_quantize(const u8* __restrict__ b
                 int dx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
                 int dy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
                 int m = dx * dx + dy * dy;
-                // upstream cascade: B if >= both, else G if >= both, else R  ==  first strict maximum wins ties
+                // upstream cascade: B if >= both, else G if >= both, else R  ==  first maximum wins ties
                 if (m > bm) { bm = m; bdx = dx; bdy = dy; }
             }
             float ang = fast_atan2_deg((float)bdy, (float)bdx);
@@ -173,154 +206,202 @@ __global__ __launch_bounds__(256) void k_color_quantize(const u8* __restrict__ b
         qn[qy][qx] = out;
     }
     __syncthreads();
-    // 3x3 majority vote (>= 5 of 9) gated by magnitude
-    for (int i = tid; i < CT_H * CT_W; i += 256) {
-        int ty = i / CT_W, tx = i - ty * CT_W;
+    // ---- 3x3 majority vote (>= 5 of 9) gated by magnitude: one output pixel per thread
+    {
+        int ty = tid >> 5, tx = tid & 31;
         int gy = oy + ty, gx = ox + tx;
-        if (gy >= h || gx >= w) continue;
-        u8 res = 0;
-        if (gy >= 1 && gy <= h - 2 && gx >= 1 && gx <= w - 2 && (qn[ty + 1][tx + 1] & 0x80)) {
-            u32 cnt = 0;  // eight 4-bit counters
+        if (gy < h && gx < w) {
+            u8 res = 0;
+            if (gy >= 1 && gy <= h - 2 && gx >= 1 && gx <= w - 2 && (qn[ty + 1][tx + 1] & 0x80)) {
+                u32 cnt = 0;  // eight 4-bit counters
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+                for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int ii = 0; ii < 3; ++ii) cnt += 1u << (4 * (qn[ty + j][tx + ii] & 7));
-            int best = 0, idx = 0;
+                    for (int ii = 0; ii < 3; ++ii) cnt += 1u << (4 * (qn[ty + j][tx + ii] & 7));
+                int best = 0, idx = 0;
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                int v = (cnt >> (4 * b)) & 15;
-                if (best < v) { best = v; idx = b; }
+                for (int b = 0; b < 8; ++b) {
+                    int v = (cnt >> (4 * b)) & 15;
+                    if (best < v) { best = v; idx = b; }
+                }
+                if (best >= 5) res = (u8)(1u << idx);
             }
-            if (best >= 5) res = (u8)(1u << idx);
+            quant[(size_t)gy * w + gx] = res;
         }
-        quant[(size_t)gy * w + gx] = res;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// a5  DepthNormal::process -> quantizedNormals + medianBlur(5).
+// a5  DepthNormal::process -> quantizedNormals + medianBlur(5).  32x8 outputs per workgroup; the
+// depth tile (+-7) and the raw normals (+-2) live in LDS.
 // ------------------------------------------------------------------------------------------------
-#define DT_W 64
-#define DT_H 16
-#define N_W (DT_W + 4)
-#define N_H (DT_H + 4)
+#define DT_W 32
+#define DT_H 8
+#define N_W (DT_W + 4)    // 36
+#define N_H (DT_H + 4)    // 12
+#define D_W (DT_W + 14)   // 46
+#define D_H (DT_H + 14)   // 22
+#define D_PITCH 48
 
-__device__ __forceinline__ u8 normal_at(const u16* __restrict__ depth, int w, int h, int y, int x, int dist_thr,
-                                        int diff_thr, const u8* __restrict__ lut) {
-    if (y < 5 || y >= h - 6 || x < 5 || x >= w - 6) return 0;
-    long long d = depth[(size_t)y * w + x];
-    if (!(d < dist_thr)) return 0;
-    long long A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
-#pragma unroll
-    for (int jj = -1; jj <= 1; ++jj)
-#pragma unroll
-        for (int ii = -1; ii <= 1; ++ii) {
-            if (ii == 0 && jj == 0) continue;
-            long long i = ii * 5, j = jj * 5;
-            long long delta = (long long)depth[(size_t)(y + j) * w + (x + i)] - d;
-            long long ad = delta < 0 ? -delta : delta;
-            long long f = ad < diff_thr ? 1 : 0;
-            long long fi = f * i, fj = f * j;
-            A0 += fi * i; A1 += fi * j; A3 += fj * j;
-            b0 += fi * delta; b1 += fj * delta;
-        }
-    long long det = A0 * A3 - A1 * A1;
-    long long ddx = A3 * b0 - A1 * b1;
-    long long ddy = -A1 * b0 + A0 * b1;
-    float nx = (float)(1150 * ddx);
-    float ny = (float)(1150 * ddy);
-    float nz = (float)(-det * d);
-    float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
-    if (!(len > 0)) return 0;
-    float inv = __fdiv_rn(1.0f, len);
-    nx = __fmul_rn(nx, inv); ny = __fmul_rn(ny, inv); nz = __fmul_rn(nz, inv);
-    int v1 = (int)__fadd_rn(__fmul_rn(nx, 10.f), 10.f);
-    int v2 = (int)__fadd_rn(__fmul_rn(ny, 10.f), 10.f);
-    int v3 = (int)__fadd_rn(__fmul_rn(nz, 20.f), 20.f);
-    int flat = v3 * 400 + v2 * 20 + v1;
-    return (flat >= 0 && flat < 8000) ? lut[flat] : 0;
-}
-
-__global__ __launch_bounds__(256) void k_depth_quantize(const u16* __restrict__ depth, int w, int h, int dist_thr,
+__global__ __launch_bounds__(256) void k_depth_quantize(const u16* __restrict__ depth0, int w, int h, int dist_thr,
                                                          int diff_thr, const u8* __restrict__ lut,
-                                                         u8* __restrict__ quant) {
-    __shared__ u8 nt[N_H][N_W];
+                                                         u8* __restrict__ quant0, size_t slot_stride) {
+    __shared__ u16 dt[D_H][D_PITCH];
+    __shared__ u8 nt[N_H][N_W + 4];
+    const u16* depth = slot_ptr(depth0, slot_stride);
+    u8* quant = slot_ptr(quant0, slot_stride);
     const int tid = threadIdx.x;
     const int ox = blockIdx.x * DT_W, oy = blockIdx.y * DT_H;
+    // depth tile: 22 x 46 values, 4 independent loads per thread
+    {
+        u16 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int i = tid + k * 256;
+            int r = i / D_W, c = i - r * D_W;
+            int gy = oy - 7 + r, gx = ox - 7 + c;
+            v[k] = (i < D_H * D_W && gy >= 0 && gy < h && gx >= 0 && gx < w) ? depth[(size_t)gy * w + gx] : (u16)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int i = tid + k * 256;
+            if (i < D_H * D_W) { int r = i / D_W; dt[r][i - r * D_W] = v[k]; }
+        }
+    }
+    __syncthreads();
     for (int i = tid; i < N_H * N_W; i += 256) {
         int ty = i / N_W, tx = i - ty * N_W;
         int gy = clampi(oy - 2 + ty, 0, h - 1), gx = clampi(ox - 2 + tx, 0, w - 1);  // medianBlur: BORDER_REPLICATE
-        nt[ty][tx] = normal_at(depth, w, h, gy, gx, dist_thr, diff_thr, lut);
+        u8 out = 0;
+        if (gy >= 5 && gy < h - 6 && gx >= 5 && gx < w - 6) {
+            const int ly = gy - (oy - 7), lx = gx - (ox - 7);
+            int d = dt[ly][lx];
+            if (d < dist_thr) {
+                int A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+                for (int jj = -1; jj <= 1; ++jj)
+#pragma unroll
+                    for (int ii = -1; ii <= 1; ++ii) {
+                        if (ii == 0 && jj == 0) continue;
+                        int di = ii * 5, dj = jj * 5;
+                        int delta = (int)dt[ly + dj][lx + di] - d;
+                        int ad = delta < 0 ? -delta : delta;
+                        int f = ad < diff_thr ? 1 : 0;
+                        int fi = f * di, fj = f * dj;
+                        A0 += fi * di; A1 += fi * dj; A3 += fj * dj;
+                        b0 += fi * delta; b1 += fj * delta;
+                    }
+                // |b| <= 30 * 65535, A <= 150: the 2x2 solve fits 32 bits; the scaled normal needs 64
+                int det = A0 * A3 - A1 * A1;
+                int ddx = A3 * b0 - A1 * b1;
+                int ddy = -A1 * b0 + A0 * b1;
+                float nx = (float)(1150LL * ddx);
+                float ny = (float)(1150LL * ddy);
+                float nz = (float)(-(long long)det * d);
+                float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+                if (len > 0) {
+                    float inv = __fdiv_rn(1.0f, len);
+                    nx = __fmul_rn(nx, inv); ny = __fmul_rn(ny, inv); nz = __fmul_rn(nz, inv);
+                    int v1 = (int)__fadd_rn(__fmul_rn(nx, 10.f), 10.f);
+                    int v2 = (int)__fadd_rn(__fmul_rn(ny, 10.f), 10.f);
+                    int v3 = (int)__fadd_rn(__fmul_rn(nz, 20.f), 20.f);
+                    int flat = v3 * 400 + v2 * 20 + v1;
+                    out = (flat >= 0 && flat < 8000) ? lut[flat] : 0;
+                }
+            }
+        }
+        nt[ty][tx] = out;
     }
     __syncthreads();
-    for (int i = tid; i < DT_H * DT_W; i += 256) {
-        int ty = i / DT_W, tx = i - ty * DT_W;
+    {
+        int ty = tid >> 5, tx = tid & 31;
         int gy = oy + ty, gx = ox + tx;
-        if (gy >= h || gx >= w) continue;
-        u32 v[25];
+        if (gy < h && gx < w) {
+            u32 v[25];
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
+            for (int j = 0; j < 5; ++j)
 #pragma unroll
-            for (int ii = 0; ii < 5; ++ii) v[j * 5 + ii] = nt[ty + j][tx + ii];
-        // median of 25 = largest t with #{v >= t} >= 13, built bit by bit
-        u32 res = 0;
+                for (int ii = 0; ii < 5; ++ii) v[j * 5 + ii] = nt[ty + j][tx + ii];
+            // median of 25 = largest t with #{v >= t} >= 13, built bit by bit
+            u32 res = 0;
 #pragma unroll
-        for (int bit = 7; bit >= 0; --bit) {
-            u32 cand = res | (1u << bit);
-            int cnt = 0;
+            for (int bit = 7; bit >= 0; --bit) {
+                u32 cand = res | (1u << bit);
+                int cnt = 0;
 #pragma unroll
-            for (int k = 0; k < 25; ++k) cnt += (v[k] >= cand) ? 1 : 0;
-            if (cnt >= 13) res = cand;
+                for (int k = 0; k < 25; ++k) cnt += (v[k] >= cand) ? 1 : 0;
+                if (cnt >= 13) res = cand;
+            }
+            quant[(size_t)gy * w + gx] = (u8)res;
         }
-        quant[(size_t)gy * w + gx] = (u8)res;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// a6-a10  One workgroup per band of T image rows (= one row of every linear memory).
+// a6-a10  One workgroup per (band of T image rows, segment of `seg` memory columns).
 //   LDS: response table (256 x u64: byte o = response of orientation o to spread value v),
-//        (2T-1) source rows, their horizontal OR.
+//        (2T-1) source rows of the segment (+T-1 halo columns), their horizontal OR.
 // Thread unit = (row-in-band j, column phase c0, four consecutive memory columns) so each of the 8
-// orientation stores is one aligned dword and a wave writes runs of W contiguous bytes.
+// orientation stores is one aligned dword and consecutive lanes write consecutive dwords.
 // ------------------------------------------------------------------------------------------------
+#define LMK_MAX_LOADS 8
 template <int SRC_SHIFT>
-__global__ __launch_bounds__(256) void k_linear_memories(const u8* __restrict__ q, int qpitch, int w, int h, int T,
-                                                          const u64* __restrict__ resp_tab, u8* __restrict__ lm,
-                                                          u32 ori_stride) {
+__global__ __launch_bounds__(256) void k_linear_memories(const u8* __restrict__ q0, int qpitch, int w, int h, int T,
+                                                          int seg, const u64* __restrict__ resp_tab,
+                                                          u8* __restrict__ lm0, u32 ori_stride, size_t q_slot_stride,
+                                                          size_t lm_slot_stride) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const u8* q = slot_ptr(q0, q_slot_stride);
+    u8* lm = slot_ptr(lm0, lm_slot_stride);
     const int W = w / T;
     const u32 wh = (u32)W * (u32)(h / T);
     const int rows = 2 * T - 1;
-    const int pitch = (w + T + 3) & ~3;
+    const int pitch = (seg * T + T + 3) & ~3;
     u64* tab = reinterpret_cast<u64*>(smem);
     u8* qs = smem + 2048;
     u8* ho = qs + rows * pitch;
     const int tid = threadIdx.x;
-    const int band = blockIdx.x;
+    const int band = blockIdx.y;
+    const int col0 = blockIdx.x * seg;                       // first memory column of this segment
+    const int ncols = (W - col0) < seg ? (W - col0) : seg;   // memory columns in this segment
+    const int px0 = col0 * T, npx = ncols * T;
     const int y0 = band * T;
+    const int lw = npx + T - 1;                              // source columns needed (halo to the right)
 
-    for (int i = tid; i < 256; i += 256) tab[i] = resp_tab[i];
-    for (int i = tid; i < rows * pitch; i += 256) {
-        int yy = i / pitch, xx = i - yy * pitch;
-        int gy = y0 + yy;
-        u8 v = 0;
-        if (gy < h && xx < w) v = SRC_SHIFT ? q[(size_t)(2 * gy) * qpitch + 2 * xx] : q[(size_t)gy * qpitch + xx];
-        qs[i] = v;
+    tab[tid] = resp_tab[tid];
+    {   // source rows: up to LMK_MAX_LOADS independent byte loads per thread
+        const int total = rows * lw;
+        u8 v[LMK_MAX_LOADS];
+#pragma unroll
+        for (int k = 0; k < LMK_MAX_LOADS; ++k) {
+            int i = tid + k * 256;
+            int yy = i / lw, xx = i - yy * lw;
+            int gy = y0 + yy, gx = px0 + xx;
+            u8 val = 0;
+            if (i < total && gy < h && gx < w)
+                val = SRC_SHIFT ? q[(size_t)(2 * gy) * qpitch + 2 * gx] : q[(size_t)gy * qpitch + gx];
+            v[k] = val;
+        }
+#pragma unroll
+        for (int k = 0; k < LMK_MAX_LOADS; ++k) {
+            int i = tid + k * 256;
+            if (i < total) { int yy = i / lw; qs[yy * pitch + (i - yy * lw)] = v[k]; }
+        }
     }
     __syncthreads();
-    for (int i = tid; i < rows * w; i += 256) {
-        int yy = i / w, xx = i - yy * w;
+    for (int i = tid; i < rows * npx; i += 256) {
+        int yy = i / npx, xx = i - yy * npx;
         const u8* p = qs + yy * pitch + xx;
         u8 v = 0;
         for (int c = 0; c < T; ++c) v |= p[c];
         ho[yy * pitch + xx] = v;
     }
     __syncthreads();
-    if ((W & 3) == 0) {
-        const int W4 = W >> 2;
-        const int units = T * T * W4;
+    if ((W & 3) == 0 && (seg & 3) == 0) {
+        const int C4 = ncols >> 2;
+        const int units = T * T * C4;
         for (int u = tid; u < units; u += 256) {
-            int k4 = u % W4, g = u / W4;
+            int k4 = u % C4, g = u / C4;
             int j = g / T, c0 = g - j * T;
             u64 e[4];
 #pragma unroll
@@ -331,7 +412,7 @@ __global__ __launch_bounds__(256) void k_linear_memories(const u8* __restrict__ 
                 for (int r = 0; r < T; ++r) sv |= p[r * pitch];
                 e[i] = tab[sv];
             }
-            u8* dst = lm + (size_t)g * wh + (size_t)band * W + 4 * k4;
+            u8* dst = lm + (size_t)g * wh + (size_t)band * W + col0 + 4 * k4;
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
                 u32 v = (u32)((e[0] >> (8 * o)) & 0xFF) | ((u32)((e[1] >> (8 * o)) & 0xFF) << 8) |
@@ -340,15 +421,15 @@ __global__ __launch_bounds__(256) void k_linear_memories(const u8* __restrict__ 
             }
         }
     } else {
-        const int units = T * T * W;
+        const int units = T * T * ncols;
         for (int u = tid; u < units; u += 256) {
-            int k = u % W, g = u / W;
+            int k = u % ncols, g = u / ncols;
             int j = g / T, c0 = g - j * T;
             const u8* p = ho + j * pitch + k * T + c0;
             u8 sv = 0;
             for (int r = 0; r < T; ++r) sv |= p[r * pitch];
             u64 e = tab[sv];
-            u8* dst = lm + (size_t)g * wh + (size_t)band * W + k;
+            u8* dst = lm + (size_t)g * wh + (size_t)band * W + col0 + k;
 #pragma unroll
             for (int o = 0; o < 8; ++o) dst[(size_t)o * ori_stride] = (u8)(e >> (8 * o));
         }
@@ -375,7 +456,9 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
     const int n = a.scan_n[ti];
     const int thr = a.raw_thr_by_n[n];
     const u32 j0 = chunk * LM_SCAN_CHUNK + (u32)lane * 16u;
-    const u8* base = a.lm + j0;
+    const u8* base = a.lm + (size_t)blockIdx.z * a.lm_slot_stride + j0;
+    LmDevHeader* hdr = slot_ptr(a.hdr, a.aux_slot_stride);
+    LmCand* cand = slot_ptr(a.cand, a.aux_slot_stride);
 
     u32 tl[4] = {0, 0, 0, 0}, th[4] = {0, 0, 0, 0};  // u16 pairs: bytes {0,2} and {1,3} of each dword
     for (int m = 0; m < a.M; ++m) {
@@ -402,7 +485,6 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
         hit |= (s0 > thr ? 1u : 0u) << (4 * k) | (s1 > thr ? 1u : 0u) << (4 * k + 1) |
                (s2 > thr ? 1u : 0u) << (4 * k + 2) | (s3 > thr ? 1u : 0u) << (4 * k + 3);
     }
-    // drop positions at or beyond template_positions
     int valid = P - (int)j0;  // number of valid positions in this lane's 16
     if (valid <= 0) hit = 0;
     else if (valid < 16) hit &= (1u << valid) - 1u;
@@ -415,21 +497,23 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
         int raw = (bb == 0) ? (int)(tl[k] & 0xFFFF) : (bb == 1) ? (int)(th[k] & 0xFFFF) : (bb == 2) ? (int)(tl[k] >> 16) : (int)(th[k] >> 16);
         int j = (int)j0 + b;
         int r = j / a.W, c = j - r * a.W;
-        u32 slot = atomicAdd(a.cand_count, 1u);
+        u32 slot = atomicAdd(&hdr->cand_count, 1u);
         if (slot < a.cand_cap) {
             LmCand cd;
             cd.ti = ti;
             cd.x = c * a.T + offset;
             cd.y = r * a.T + offset;
             cd.sim = __fadd_rn(__fdiv_rn(__fmul_rn((float)raw, 100.f), (float)(4 * n)), 0.5f);
-            a.cand[slot] = cd;
+            cand[slot] = cd;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // a14  One wave per candidate: lane l holds the 4 patch positions (row l/4, cols 4(l%4)..+3) of the
-// 16x16 patch; each feature is one unaligned dword load per lane (a 16-byte row segment per 4 lanes).
+// 16x16 patch.  The modality's feature records are loaded one per lane, bounds-checked in parallel
+// (features shifted out of the frame read the arena's zero block instead), then broadcast with
+// v_readlane so the patch loads (one unaligned dword per lane per feature) issue back to back.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 #pragma unroll
@@ -440,15 +524,16 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
     return v;
 }
 
-__device__ __forceinline__ void emit_key(const LmRefineArgs& a, u32 ti, int x, int y, float sim) {
-    u32 slot = atomicAdd(a.match_count, 1u);
+__device__ __forceinline__ void emit_key(const LmRefineArgs& a, LmDevHeader* hdr, u64* keys, u32 ti, int x, int y,
+                                         float sim) {
+    u32 slot = atomicAdd(&hdr->match_count, 1u);
     if (slot < a.match_cap) {
         u32 sb = __float_as_uint(sim);
         u64 hi = ((u64)(~sb) << 32) | (u32)a.t_global[ti];
         u64 lo = ((u64)(u32)a.t_class[ti] << 48) | ((u64)((u32)(y + 0x800000) & 0xFFFFFFu) << 24) |
                  (u64)((u32)(x + 0x800000) & 0xFFFFFFu);
-        a.keys[2 * (size_t)slot] = hi;
-        a.keys[2 * (size_t)slot + 1] = lo;
+        keys[2 * (size_t)slot] = hi;
+        keys[2 * (size_t)slot + 1] = lo;
     }
 }
 
@@ -457,14 +542,18 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
     const int lane = threadIdx.x & 63;
     const u32 wave0 = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
     const u32 nwaves = gridDim.x * 4u;
-    u32 n = *a.cand_count;
+    LmDevHeader* hdr = slot_ptr(a.hdr, a.aux_slot_stride);
+    LmCand* cand = slot_ptr(a.cand, a.aux_slot_stride);
+    u64* keys = slot_ptr(a.keys, a.aux_slot_stride);
+    const u8* lm = a.lm + (size_t)blockIdx.z * a.lm_slot_stride;
+    u32 n = hdr->cand_count;
     if (n > a.cand_cap) n = a.cand_cap;
     const int T = a.g.T, W = a.g.W;
     const int border = 8 * T;
     const int offset = T / 2 + (T % 2 - 1);
-    const int lane_off = (lane >> 2) * W + (lane & 3) * 4;
+    const u32 lane_off = (u32)((lane >> 2) * W + (lane & 3) * 4);
     for (u32 i = wave0; i < n; i += nwaves) {
-        LmCand c = a.cand[i];
+        LmCand c = cand[i];
         u32 ti = (u32)__builtin_amdgcn_readfirstlane((int)c.ti);
         if (ti == LM_DROPPED) continue;
         int cx = __builtin_amdgcn_readfirstlane(c.x), cy = __builtin_amdgcn_readfirstlane(c.y);
@@ -475,17 +564,26 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
         x = x < max_x ? x : max_x;  y = y < max_y ? y : max_y;
         int bx = x / T - 8, by = y / T - 8;
         int off_x = bx * T, off_y = by * T;
-        const u8* base = a.lm + (by * W + bx) + lane_off;
+        const u32 shift = (u32)(by * W + bx);   // two's complement: feature offset + shift >= 0 for kept features
         u32 tl = 0, th = 0;
         for (int m = 0; m < a.M; ++m) {
-            const LmRefFeat* fp = a.feats + mt.start[m];
             const int cnt = (int)mt.count[m];
+            LmRefFeat ft;
+            ft.off = 0; ft.x = 0; ft.y = 0;
+            if (lane < cnt) ft = a.feats[mt.start[m] + lane];
+            int fx = ft.x + off_x, fy = ft.y + off_y;
+            bool ok = (lane < cnt) && fx >= 0 && fy >= 0 && fx < a.g.w && fy < a.g.h;
+            u32 eff = ok ? ft.off + shift : a.g.zero_off;
             u32 acc = 0;
-            for (int f = 0; f < cnt; ++f) {
-                LmRefFeat ft = fp[f];
-                int fx = ft.x + off_x, fy = ft.y + off_y;
-                if (fx < 0 || fy < 0 || fx >= a.g.w || fy >= a.g.h) continue;  // wave-uniform
-                acc += ld4u(base + ft.off);
+            for (int f = 0; f < cnt; f += 8) {
+                u32 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    u32 o = (u32)__builtin_amdgcn_readlane((int)eff, f + k);
+                    v[k] = ld4u(lm + o + lane_off);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += v[k];
             }
             tl += acc & 0x00FF00FFu;
             th += (acc >> 8) & 0x00FF00FFu;
@@ -505,64 +603,94 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
         float sim = __fdiv_rn(__fmul_rn((float)best, 100.f), (float)(4 * mt.nfeat_total));
         if (lane == 0) {
             if (sim < a.threshold) {
-                a.cand[i].ti = LM_DROPPED;
+                cand[i].ti = LM_DROPPED;
             } else if (LAST) {
-                emit_key(a, ti, nx, ny, sim);
+                emit_key(a, hdr, keys, ti, nx, ny, sim);
             } else {
                 LmCand o; o.ti = ti; o.x = nx; o.y = ny; o.sim = sim;
-                a.cand[i] = o;
+                cand[i] = o;
             }
         }
     }
 }
 
 __global__ __launch_bounds__(256) void k_emit_unrefined(LmRefineArgs a) {
-    u32 n = *a.cand_count;
+    LmDevHeader* hdr = slot_ptr(a.hdr, a.aux_slot_stride);
+    LmCand* cand = slot_ptr(a.cand, a.aux_slot_stride);
+    u64* keys = slot_ptr(a.keys, a.aux_slot_stride);
+    u32 n = hdr->cand_count;
     if (n > a.cand_cap) n = a.cand_cap;
     for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        LmCand c = a.cand[i];
-        if (c.ti != LM_DROPPED) emit_key(a, c.ti, c.x, c.y, c.sim);
+        LmCand c = cand[i];
+        if (c.ti != LM_DROPPED) emit_key(a, hdr, keys, c.ti, c.x, c.y, c.sim);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// a15  sort + unique.  Keys are (hi, lo) u64 pairs whose ascending order is the total order of
-// SURVEY.md A.9; equality for std::unique is (x, y, similarity, class) = (lo, hi >> 32).
+// a15  sort + unique, one workgroup per frame slot.  Keys are (hi, lo) u64 pairs whose ascending
+// order is the total order of SURVEY.md A.9; equality for std::unique is (x, y, similarity, class)
+// = (lo, hi >> 32).  n <= 1024: rank sort (every thread counts the keys before its own: two
+// barriers in total); n <= LM_SORT_CAP: bitonic network; above that the host sorts the keys.
+// The kernel also publishes the header to host-mapped memory together with the first
+// LM_INLINE_MATCHES records and re-arms the device counters for the next frame.
 // ------------------------------------------------------------------------------------------------
-struct OutMatch { int x, y; float similarity; int template_id; int class_idx; };
-
-__global__ __launch_bounds__(1024) void k_sort_unique(const u64* __restrict__ keys, const u32* __restrict__ match_count,
-                                                       u32 match_cap, OutMatch* __restrict__ out, LmHeader* hdr) {
+__global__ __launch_bounds__(1024) void k_sort_unique(LmSortArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u64* hi = reinterpret_cast<u64*>(smem);
     u64* lo = hi + LM_SORT_CAP;
     __shared__ u32 wave_tot[16];
+    LmDevHeader* hdr = slot_ptr(a.hdr, a.aux_slot_stride);
+    const u64* keys = slot_ptr(a.keys, a.aux_slot_stride);
+    LmOutMatch* out = slot_ptr(a.out, a.aux_slot_stride);
+    LmHostBlock* hb = reinterpret_cast<LmHostBlock*>(reinterpret_cast<u8*>(a.host) + (size_t)blockIdx.z * a.host_slot_stride);
     const int tid = threadIdx.x;
-    u32 n = *match_count;
-    if (n > match_cap) n = match_cap;
-    if (n > LM_SORT_CAP) {
-        if (tid == 0) { hdr->sorted_on_device = 0; hdr->out_count = 0; }
+    const u32 cand_count = hdr->cand_count, match_count = hdr->match_count;
+    u32 n = match_count;
+    if (n > a.match_cap) n = a.match_cap;
+    __syncthreads();  // everyone has read the counters
+    if (tid == 0) { hdr->cand_count = 0; hdr->match_count = 0; }
+    if (n > LM_SORT_CAP || cand_count > a.cand_cap || match_count > a.match_cap) {
+        if (tid == 0) {
+            hb->hdr.cand_count = cand_count; hb->hdr.match_count = match_count;
+            hb->hdr.out_count = 0; hb->hdr.sorted_on_device = 0;
+        }
         return;
     }
-    u32 N = 1;
-    while (N < n) N <<= 1;
-    for (u32 i = tid; i < N; i += 1024) {
-        hi[i] = i < n ? keys[2 * (size_t)i] : ~0ull;
-        lo[i] = i < n ? keys[2 * (size_t)i + 1] : ~0ull;
-    }
-    __syncthreads();
-    for (u32 k = 2; k <= N; k <<= 1)
-        for (u32 j = k >> 1; j > 0; j >>= 1) {
-            for (u32 t = tid; t < (N >> 1); t += 1024) {
-                u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
-                u32 p = i | j;
-                bool up = (i & k) == 0;
-                u64 ah = hi[i], al = lo[i], bh = hi[p], bl = lo[p];
-                bool gt = ah > bh || (ah == bh && al > bl);
-                if (gt == up) { hi[i] = bh; lo[i] = bl; hi[p] = ah; lo[p] = al; }
-            }
-            __syncthreads();
+    if (n <= 1024) {
+        u64 mh = ~0ull, ml = ~0ull;
+        if ((u32)tid < n) { mh = keys[2 * (size_t)tid]; ml = keys[2 * (size_t)tid + 1]; }
+        hi[tid] = mh; lo[tid] = ml;
+        __syncthreads();
+        u32 rank = 0;
+        for (u32 j = 0; j < n; ++j) {
+            u64 h = hi[j], l = lo[j];
+            bool before = h < mh || (h == mh && (l < ml || (l == ml && j < (u32)tid)));
+            rank += before ? 1u : 0u;
         }
+        __syncthreads();
+        if ((u32)tid < n) { hi[rank] = mh; lo[rank] = ml; }
+        __syncthreads();
+    } else {
+        u32 N = 1;
+        while (N < n) N <<= 1;
+        for (u32 i = tid; i < N; i += 1024) {
+            hi[i] = i < n ? keys[2 * (size_t)i] : ~0ull;
+            lo[i] = i < n ? keys[2 * (size_t)i + 1] : ~0ull;
+        }
+        __syncthreads();
+        for (u32 k = 2; k <= N; k <<= 1)
+            for (u32 j = k >> 1; j > 0; j >>= 1) {
+                for (u32 t = tid; t < (N >> 1); t += 1024) {
+                    u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
+                    u32 p = i | j;
+                    bool up = (i & k) == 0;
+                    u64 ah = hi[i], al = lo[i], bh = hi[p], bl = lo[p];
+                    bool gt = ah > bh || (ah == bh && al > bl);
+                    if (gt == up) { hi[i] = bh; lo[i] = bl; hi[p] = ah; lo[p] = al; }
+                }
+                __syncthreads();
+            }
+    }
     // adjacent-unique + compaction (block-wide exclusive scan of keep flags, chunks of 1024)
     u32 base = 0;
     for (u32 c0 = 0; c0 < n; c0 += 1024) {
@@ -578,18 +706,32 @@ __global__ __launch_bounds__(1024) void k_sort_unique(const u64* __restrict__ ke
         for (int k = 0; k < 16; ++k) { u32 t = wave_tot[k]; if (k < wv) woff += t; tot += t; }
         if (keep) {
             u64 h = hi[i], l = lo[i];
-            OutMatch m;
+            LmOutMatch m;
             m.similarity = __uint_as_float(~(u32)(h >> 32));
             m.template_id = (int)(u32)h;
             m.class_idx = (int)(l >> 48);
             m.y = (int)((l >> 24) & 0xFFFFFFu) - 0x800000;
             m.x = (int)(l & 0xFFFFFFu) - 0x800000;
-            out[base + woff + pre] = m;
+            u32 pos = base + woff + pre;
+            out[pos] = m;
+            if (pos < LM_INLINE_MATCHES) hb->rec[pos] = m;
         }
         base += tot;
         __syncthreads();
     }
-    if (tid == 0) { hdr->sorted_on_device = 1; hdr->out_count = base; }
+    if (tid == 0) {
+        hb->hdr.cand_count = cand_count; hb->hdr.match_count = match_count;
+        hb->hdr.out_count = base; hb->hdr.sorted_on_device = 1;
+    }
+}
+
+// materialises the NN pyramid of the depth modality's quantised image (levels >= 2, stage hooks)
+__global__ void k_nn_half(const u8* __restrict__ src0, int sp, u8* __restrict__ dst0, int dw, int dh,
+                          size_t slot_stride) {
+    const u8* src = slot_ptr(src0, slot_stride);
+    u8* dst = slot_ptr(dst0, slot_stride);
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < dw && y < dh) dst[(size_t)y * dw + x] = src[(size_t)(2 * y) * sp + 2 * x];
 }
 
 }  // namespace
@@ -597,37 +739,56 @@ __global__ __launch_bounds__(1024) void k_sort_unique(const u64* __restrict__ ke
 // ================================================================================================
 // launchers
 // ================================================================================================
-void lmk_pyrdown(hipStream_t s, const u8* src, int sw, int sh, u8* dst) {
+void lmk_pyrdown(hipStream_t s, const u8* src, int sw, int sh, u8* dst, size_t slot_stride, int nslots) {
     int dw = sw / 2, dh = sh / 2;
-    dim3 grid((dw + 63) / 64, (dh + 3) / 4);
-    hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, src, sw, sh, dst, dw, dh);
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4, nslots);
+    hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, src, sw, sh, dst, dw, dh, slot_stride);
 }
 
-void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_threshold, u8* quant, float* mag) {
-    dim3 grid((w + CT_W - 1) / CT_W, (h + CT_H - 1) / CT_H);
-    hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, w, h, weak_threshold * weak_threshold, quant, mag);
+void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, int dh, size_t slot_stride, int nslots) {
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4, nslots);
+    hipLaunchKernelGGL(k_nn_half, grid, dim3(256), 0, s, src, src_pitch, dst, dw, dh, slot_stride);
+}
+
+void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_threshold, u8* quant, float* mag,
+                        size_t slot_stride, int nslots) {
+    dim3 grid((w + CT_W - 1) / CT_W, (h + CT_H - 1) / CT_H, nslots);
+    hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, w, h, weak_threshold * weak_threshold, quant, mag,
+                       slot_stride);
 }
 
 void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_thr, int diff_thr, const u8* lut,
-                        u8* quant) {
-    dim3 grid((w + DT_W - 1) / DT_W, (h + DT_H - 1) / DT_H);
-    hipLaunchKernelGGL(k_depth_quantize, grid, dim3(256), 0, s, depth, w, h, dist_thr, diff_thr, lut, quant);
+                        u8* quant, size_t slot_stride, int nslots) {
+    dim3 grid((w + DT_W - 1) / DT_W, (h + DT_H - 1) / DT_H, nslots);
+    hipLaunchKernelGGL(k_depth_quantize, grid, dim3(256), 0, s, depth, w, h, dist_thr, diff_thr, lut, quant,
+                       slot_stride);
 }
 
 void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, int w, int h, int T,
-                         const u64* resp_tab, u8* lm, u32 ori_stride) {
-    int pitch = (w + T + 3) & ~3;
+                         const u64* resp_tab, u8* lm, u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
+                         int nslots) {
+    const int W = w / T;
+    // segment width: about 1024 linear-memory bytes per (band, segment), a multiple of 4 columns, and
+    // few enough source bytes for LMK_MAX_LOADS loads per thread
+    int seg = (1024 / (T * T)) & ~3;
+    if (seg < 4) seg = 4;
+    while (seg > 4 && (2 * T - 1) * (seg * T + T - 1) > LMK_MAX_LOADS * 256) seg -= 4;
+    if (seg > W) seg = (W + 3) & ~3;
+    int nseg = (W + seg - 1) / seg;
+    int pitch = (seg * T + T + 3) & ~3;
     size_t shmem = 2048 + 2 * (size_t)(2 * T - 1) * pitch;
-    dim3 grid(h / T);
+    dim3 grid(nseg, h / T, nslots);
     if (src_shift)
-        hipLaunchKernelGGL(k_linear_memories<1>, grid, dim3(256), shmem, s, q, qpitch, w, h, T, resp_tab, lm, ori_stride);
+        hipLaunchKernelGGL(k_linear_memories<1>, grid, dim3(256), shmem, s, q, qpitch, w, h, T, seg, resp_tab, lm,
+                           ori_stride, q_slot_stride, lm_slot_stride);
     else
-        hipLaunchKernelGGL(k_linear_memories<0>, grid, dim3(256), shmem, s, q, qpitch, w, h, T, resp_tab, lm, ori_stride);
+        hipLaunchKernelGGL(k_linear_memories<0>, grid, dim3(256), shmem, s, q, qpitch, w, h, T, seg, resp_tab, lm,
+                           ori_stride, q_slot_stride, lm_slot_stride);
 }
 
-void lmk_scan(hipStream_t s, const LmScanArgs& a, int variant) {
+void lmk_scan(hipStream_t s, const LmScanArgs& a, int variant, int nslots) {
     if (a.n_items <= 0) return;
-    dim3 grid((a.n_items + 3) / 4);
+    dim3 grid((a.n_items + 3) / 4, 1, nslots);
     switch (variant) {
         case 1: hipLaunchKernelGGL(k_scan<4>, grid, dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL(k_scan<2>, grid, dim3(256), 0, s, a); break;
@@ -635,19 +796,17 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a, int variant) {
     }
 }
 
-void lmk_refine(hipStream_t s, const LmRefineArgs& a, bool last) {
-    dim3 grid(1024);  // 4096 persistent waves stride over the candidate list
+void lmk_refine(hipStream_t s, const LmRefineArgs& a, bool last, int nslots) {
+    dim3 grid(512, 1, nslots);  // 2048 persistent waves per frame stride over its candidate list
     if (last) hipLaunchKernelGGL(k_refine<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_refine<false>, grid, dim3(256), 0, s, a);
 }
 
-void lmk_emit_unrefined(hipStream_t s, const LmRefineArgs& a) {
-    hipLaunchKernelGGL(k_emit_unrefined, dim3(256), dim3(256), 0, s, a);
+void lmk_emit_unrefined(hipStream_t s, const LmRefineArgs& a, int nslots) {
+    hipLaunchKernelGGL(k_emit_unrefined, dim3(64, 1, nslots), dim3(256), 0, s, a);
 }
 
-void lmk_sort_unique(hipStream_t s, const u64* keys, const u32* match_count, u32 match_cap, void* out_matches,
-                     LmHeader* hdr) {
+void lmk_sort_unique(hipStream_t s, const LmSortArgs& a, int nslots) {
     size_t shmem = (size_t)LM_SORT_CAP * 16;
-    hipLaunchKernelGGL(k_sort_unique, dim3(1), dim3(1024), shmem, s, keys, match_count, match_cap,
-                       reinterpret_cast<OutMatch*>(out_matches), hdr);
+    hipLaunchKernelGGL(k_sort_unique, dim3(1, 1, nslots), dim3(1024), shmem, s, a);
 }
