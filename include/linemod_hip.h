@@ -175,6 +175,16 @@ int lm_time_scan(lm_detector* det, int slot, float threshold, int class_idx, int
 /* Per-stage average microseconds of the last lm_match_slot-style pipeline, measured with HIP events
  * over `iters` runs: out[0]=preprocess (a3-a10), out[1]=scan, out[2]=refine, out[3]=sort+copy. */
 int lm_time_stages(lm_detector* det, int slot, float threshold, int class_idx, int iters, double out_us[4]);
+/* Live profile of lm_match / lm_match_slot / lm_match_batch: when enabled every call brackets its
+ * stages with HIP events on the launch stream and accumulates, per call: stage_us[0] preprocess
+ * (a3-a10), [1] similarity scan (ONE kernel launch covering all frames of the call), [2] refinement,
+ * [3] sort+publish; the algorithmic bytes the scan launches read; launches and frames.
+ * lm_set_profiling(det, x) also resets the accumulators. */
+int lm_set_profiling(lm_detector* det, int enable);
+int lm_get_profile(lm_detector* det, double stage_us[4], double* scan_algorithmic_bytes, int64_t* launches,
+                   int64_t* frames);
+/* Counters of the last match on `slot`: scan candidates and refined matches before sort + unique. */
+int lm_last_counts(lm_detector* det, int slot, uint32_t* candidates, uint32_t* matches_before_unique);
 /* Selects the similarity-scan kernel variant used by lm_match* (0 = default; see lm_kernels.hip). */
 int lm_set_scan_variant(lm_detector* det, int variant);
 

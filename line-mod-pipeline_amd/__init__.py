@@ -53,6 +53,7 @@ EXPORTS = [
     "lm_match_slot", "lm_match_batch", "lm_merge_matches", "lm_save_bank", "lm_load_bank",
     "lm_stage_color_quantize", "lm_stage_pyrdown", "lm_stage_depth_quantize", "lm_stage_linear_memories",
     "lm_prepare_slot", "lm_debug_read", "lm_stage_scan", "lm_time_scan", "lm_time_stages", "lm_set_scan_variant",
+    "lm_last_counts", "lm_set_profiling", "lm_get_profile",
 ]
 
 _lib = None
@@ -107,6 +108,10 @@ def load_library(path=None):
     lib.lm_time_scan.argtypes = [vp, i, f, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.lm_time_stages.argtypes = [vp, i, f, i, i, C.POINTER(C.c_double)]
     lib.lm_set_scan_variant.argtypes = [vp, i]
+    lib.lm_last_counts.argtypes = [vp, i, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.lm_set_profiling.argtypes = [vp, i]
+    lib.lm_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int64)]
     if path is None:
         _lib = lib
     return lib
@@ -365,6 +370,23 @@ class Detector:
         out = (C.c_double * 4)()
         self._check(self.lib.lm_time_stages(self.h, slot, threshold, class_idx, iters, out))
         return list(out)
+
+    def last_counts(self, slot=0):
+        """(scan candidates, refined matches before sort+unique) of the last match on `slot`."""
+        a, b = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.lm_last_counts(self.h, slot, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_profiling(self, enable=True):
+        self._check(self.lib.lm_set_profiling(self.h, 1 if enable else 0))
+
+    def get_profile(self):
+        """dict(stage_us=[preprocess, scan, refine, sort], scan_bytes, launches, frames) accumulated by
+        the match calls since set_profiling()."""
+        st = (C.c_double * 4)()
+        by, la, fr = C.c_double(), C.c_int64(), C.c_int64()
+        self._check(self.lib.lm_get_profile(self.h, st, C.byref(by), C.byref(la), C.byref(fr)))
+        return dict(stage_us=list(st), scan_bytes=by.value, launches=la.value, frames=fr.value)
 
     def set_scan_variant(self, variant):
         self._check(self.lib.lm_set_scan_variant(self.h, variant))

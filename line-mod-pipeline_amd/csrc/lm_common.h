@@ -32,9 +32,11 @@ struct LmLevelGeom {
     int w, h;          // quantised image size at this level
     int T;             // spread size = linear-memory stride
     int W, H;          // w/T, h/T
+    int spread_only;   // 0: lowest level, 8 response memories per modality (scan); 1: refinement level,
+                       //    one spread linear memory per modality (response LUT applied in k_refine)
     u32 wh;            // W*H = bytes per linear memory
-    u32 ori_stride;    // T*T*wh (256-aligned) + pad
-    u32 mod_stride;    // 8*ori_stride
+    u32 ori_stride;    // response arena: T*T*wh (256-aligned) + pad; unused for spread arenas
+    u32 mod_stride;    // response arena: 8*ori_stride; spread arena: T*T*wh (256-aligned) + pad
     u32 zero_off;      // offset (inside the level arena) of a zero block of `pad` bytes
     u32 arena_bytes;   // M*mod_stride + zero block
 };
@@ -47,8 +49,8 @@ struct LmCand {
 };
 
 // Refinement feature at a level above the lowest: byte offset of the unshifted feature inside the
-// level arena (modality and orientation block included) plus its template coordinates for the
-// bounds check of similarityLocal.
+// level's spread arena (modality block included) in bits 0..28, its label in bits 29..31, plus its
+// template coordinates for the bounds check of similarityLocal.
 struct LmRefFeat {
     u32 off;
     int16_t x, y;

@@ -71,6 +71,7 @@ struct lm_detector {
     int* h_raw_thr = nullptr;
     float raw_thr_for = -1.0f;
     u64* d_resp_tab = nullptr;
+    u32* d_sim_lut = nullptr;
     u8* d_normal_lut = nullptr;
     bool luts_dirty = true;
     // ---- device bank
@@ -85,6 +86,11 @@ struct lm_detector {
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
     u32 max_cand = 0, max_match = 0;
     int scan_variant = 0;
+    // live profile of lm_match* (lm_set_profiling): per-stage HIP-event time, scan launches and bytes
+    bool profiling = false;
+    double prof_us[4] = {0, 0, 0, 0};
+    double prof_scan_bytes = 0;
+    long long prof_launches = 0, prof_frames = 0;
 
     u8* bgr(int slot, int l) const { return frame_arena + (size_t)slot * frame_stride + off_bgr[l]; }
     u16* depth(int slot) const { return reinterpret_cast<u16*>(frame_arena + (size_t)slot * frame_stride + off_depth); }
@@ -160,6 +166,7 @@ int ensure_device(lm_detector* d) {
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.h_depth), (size_t)c.width * c.height * 2));
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_resp_tab), 256 * sizeof(u64)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_sim_lut), 256));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_normal_lut), 8000));
     HIP_TRY(hipDeviceSynchronize());
     d->dev_ready = true;
@@ -181,6 +188,7 @@ int ensure_luts(lm_detector* d) {
     }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(d->d_resp_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d->d_sim_lut, d->sim_lut, 256, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d->d_normal_lut, d->normal_lut, 8000, hipMemcpyHostToDevice));
     d->luts_dirty = false;
     return LM_OK;
@@ -236,16 +244,17 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
     if (M == 2 && L > 2) enqueue_depth_pyramid(d, first, n);
     for (int l = 0; l < L; ++l) {
         const LmLevelGeom& g = d->geom[l];
-        lmk_linear_memories(d->stream, d->quant(first, l, 0), g.w, 0, g.w, g.h, g.T, d->d_resp_tab, d->lm(first, l),
+        const bool sp = g.spread_only != 0;
+        lmk_linear_memories(d->stream, d->quant(first, l, 0), g.w, 0, sp, g.w, g.h, g.T, d->d_resp_tab, d->lm(first, l),
                             g.ori_stride, fs, fs, n);
         if (M == 2) {
             // level l of the depth modality reads the quantised image of level l-1 at (2y, 2x)
             if (l == 0)
-                lmk_linear_memories(d->stream, d->quant(first, 0, 1), g.w, 0, g.w, g.h, g.T, d->d_resp_tab,
+                lmk_linear_memories(d->stream, d->quant(first, 0, 1), g.w, 0, sp, g.w, g.h, g.T, d->d_resp_tab,
                                     d->lm(first, l) + g.mod_stride, g.ori_stride, fs, fs, n);
             else
-                lmk_linear_memories(d->stream, d->quant(first, l - 1, 1), d->lw[l - 1], 1, g.w, g.h, g.T, d->d_resp_tab,
-                                    d->lm(first, l) + g.mod_stride, g.ori_stride, fs, fs, n);
+                lmk_linear_memories(d->stream, d->quant(first, l - 1, 1), d->lw[l - 1], 1, sp, g.w, g.h, g.T,
+                                    d->d_resp_tab, d->lm(first, l) + g.mod_stride, g.ori_stride, fs, fs, n);
         }
     }
 }
@@ -288,6 +297,7 @@ LmRefineArgs make_refine_args(lm_detector* d, int first, int level, float thresh
     a.g = d->geom[level];
     a.M = d->cfg.num_modalities;
     a.meta = d->d_ref_meta[level]; a.feats = d->d_ref_feat[level];
+    a.sim_lut = d->d_sim_lut;
     a.hdr = reinterpret_cast<LmDevHeader*>(d->aux(first, d->off_hdr));
     a.cand = reinterpret_cast<LmCand*>(d->aux(first, d->off_cand));
     a.keys = reinterpret_cast<u64*>(d->aux(first, d->off_keys));
@@ -445,8 +455,23 @@ int run_match(lm_detector* d, int first, int n, float threshold, int class_idx) 
     for (int i = 0; i < n; ++i)
         if (!d->slots[first + i].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot " + std::to_string(first + i));
     int rc;
-    if ((rc = enqueue_match(d, first, n, threshold, class_idx))) return rc;
+    if ((rc = enqueue_match(d, first, n, threshold, class_idx, d->profiling))) return rc;
     HIP_TRY(hipStreamSynchronize(d->stream));
+    if (d->profiling) {  // HIP events on the launch stream bracket every stage (ev[0..4])
+        for (int k = 0; k < 4; ++k) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, d->ev[k], d->ev[k + 1]));
+            d->prof_us[k] += (double)ms * 1000.0;
+        }
+        ItemRange r;
+        if ((rc = item_range(d, class_idx, &r))) return rc;
+        double b = 0;
+        if (class_idx < 0) for (double v : d->hb.class_alg_bytes) b += v;
+        else b = d->hb.class_alg_bytes[class_idx];
+        d->prof_scan_bytes += b * n;
+        d->prof_launches += 1;
+        d->prof_frames += n;
+    }
     return LM_OK;
 }
 
@@ -506,10 +531,14 @@ int lm_create(const lm_config* cfg, lm_detector** out) {
         // template_positions <= W*H bytes) + the 16-row patch of the refinement + vector-load slack
         size_t pad = align_up((size_t)g.wh + 16 * (size_t)g.W + 2 * LM_SCAN_CHUNK + 64, 256);
         size_t ori = align_up((size_t)T * T * g.wh, 256) + pad;
-        size_t arena = (size_t)c.num_modalities * 8 * ori + pad;
-        if (arena > 0xFFFFFFFFull) { delete d; return fail(LM_ERR_INVALID, "frame too large for 32-bit arena offsets"); }
+        // the lowest level is scanned (8 response memories per modality); the levels above it are only
+        // refined at and keep one spread linear memory per modality (1/8 of the bytes)
+        g.spread_only = (l + 1 < c.pyramid_levels) ? 1 : 0;
+        size_t mod = g.spread_only ? ori : 8 * ori;
+        size_t arena = (size_t)c.num_modalities * mod + pad;
+        if (arena > (g.spread_only ? 0x1FFFFFFFull : 0xFFFFFFFFull)) { delete d; return fail(LM_ERR_INVALID, "frame too large for the arena offset encoding"); }
         g.ori_stride = (u32)ori;
-        g.mod_stride = (u32)(8 * ori);
+        g.mod_stride = (u32)mod;
         g.zero_off = (u32)((size_t)c.num_modalities * g.mod_stride);
         g.arena_bytes = (u32)arena;
     }
@@ -530,7 +559,7 @@ void lm_destroy(lm_detector* d) {
         for (auto& ev : d->ev) if (ev) hipEventDestroy(ev);
         if (d->stream) hipStreamDestroy(d->stream);
         free_device_bank(d);
-        hipFree(d->d_resp_tab); hipFree(d->d_normal_lut); hipFree(d->d_scratch);
+        hipFree(d->d_resp_tab); hipFree(d->d_sim_lut); hipFree(d->d_normal_lut); hipFree(d->d_scratch);
     }
     delete d;
 }
@@ -538,6 +567,8 @@ void lm_destroy(lm_detector* d) {
 int lm_set_similarity_lut(lm_detector* d, const uint8_t lut[256]) {
     if (!d || !lut) return fail(LM_ERR_INVALID, "null argument");
     for (int i = 0; i < 256; ++i) if (lut[i] > 4) return fail(LM_ERR_INVALID, "similarity LUT entries must be <= 4 (63*4 must fit a byte)");
+    // an empty spread value must score 0: reads past a linear memory land in zero padding (upstream: undefined)
+    for (int o = 0; o < 8; ++o) if (lut[32 * o] || lut[32 * o + 16]) return fail(LM_ERR_INVALID, "similarity LUT must map an empty nibble to 0");
     std::memcpy(d->sim_lut, lut, 256); d->luts_dirty = true; return LM_OK;
 }
 int lm_set_normal_lut(lm_detector* d, const uint8_t lut[8000]) {
@@ -794,7 +825,7 @@ int lm_stage_linear_memories(lm_detector* d, const uint8_t* quantized, int w, in
     u8* base = static_cast<u8*>(d->d_scratch);
     hipStream_t st = d->stream;
     HIP_TRY(hipMemcpyAsync(base, quantized, px, hipMemcpyHostToDevice, st));
-    lmk_linear_memories(st, base, w, 0, w, h, T, d->d_resp_tab, base + o_l, (u32)px, 0, 0, 1);  // dense: ori_stride = T*T*W*H
+    lmk_linear_memories(st, base, w, 0, false, w, h, T, d->d_resp_tab, base + o_l, (u32)px, 0, 0, 1);  // dense: ori_stride = T*T*W*H
     HIP_TRY(hipMemcpyAsync(out, base + o_l, 8 * px, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -830,15 +861,34 @@ int lm_debug_read(lm_detector* d, int slot, int what, int level, int modality, u
         if (out) HIP_TRY(hipMemcpy(out, d->quant(slot, level, modality), std::min(n, cap), hipMemcpyDeviceToHost));
         return LM_OK;
     }
+    if (what == 1) {  // spread linear memory [memory][pos] (refinement levels only)
+        size_t blk = (size_t)g.T * g.T * g.wh;
+        if (!g.spread_only) return fail(LM_ERR_INVALID, "the lowest level keeps response memories, not the spread memory");
+        if (size_out) *size_out = blk;
+        if (out) {
+            if (cap < blk) return fail(LM_ERR_INVALID, "buffer too small");
+            HIP_TRY(hipMemcpy(out, d->lm(slot, level) + (size_t)modality * g.mod_stride, blk, hipMemcpyDeviceToHost));
+        }
+        return LM_OK;
+    }
     if (what == 2) {
         size_t blk = (size_t)g.T * g.T * g.wh;
         size_t n = 8 * blk;
         if (size_out) *size_out = n;
         if (out) {
             if (cap < n) return fail(LM_ERR_INVALID, "buffer too small");
-            for (int o = 0; o < 8; ++o)
-                HIP_TRY(hipMemcpy(out + o * blk, d->lm(slot, level) + (size_t)modality * g.mod_stride + (size_t)o * g.ori_stride, blk,
-                                  hipMemcpyDeviceToHost));
+            if (g.spread_only) {
+                // refinement levels hold the spread memory; expand it with the response LUT here (debug path)
+                std::vector<u8> sp(blk);
+                HIP_TRY(hipMemcpy(sp.data(), d->lm(slot, level) + (size_t)modality * g.mod_stride, blk, hipMemcpyDeviceToHost));
+                for (int o = 0; o < 8; ++o)
+                    for (size_t i = 0; i < blk; ++i)
+                        out[o * blk + i] = std::max(d->sim_lut[32 * o + (sp[i] & 15)], d->sim_lut[32 * o + 16 + (sp[i] >> 4)]);
+            } else {
+                for (int o = 0; o < 8; ++o)
+                    HIP_TRY(hipMemcpy(out + o * blk, d->lm(slot, level) + (size_t)modality * g.mod_stride + (size_t)o * g.ori_stride, blk,
+                                      hipMemcpyDeviceToHost));
+            }
         }
         return LM_OK;
     }
@@ -926,6 +976,31 @@ int lm_time_stages(lm_detector* d, int slot, float threshold, int class_idx, int
         }
     }
     for (int k = 0; k < 4; ++k) out_us[k] = acc[k] / iters;
+    return LM_OK;
+}
+
+int lm_last_counts(lm_detector* d, int slot, uint32_t* candidates, uint32_t* matches_before_unique) {
+    if (!d || !d->dev_ready || slot < 0 || slot >= (int)d->slots.size()) return fail(LM_ERR_INVALID, "bad argument");
+    const LmHeader& h = d->host_block(slot)->hdr;
+    if (candidates) *candidates = h.cand_count;
+    if (matches_before_unique) *matches_before_unique = h.match_count;
+    return LM_OK;
+}
+
+int lm_set_profiling(lm_detector* d, int enable) {
+    if (!d) return fail(LM_ERR_INVALID, "null detector");
+    d->profiling = enable != 0;
+    for (double& v : d->prof_us) v = 0;
+    d->prof_scan_bytes = 0; d->prof_launches = 0; d->prof_frames = 0;
+    return LM_OK;
+}
+
+int lm_get_profile(lm_detector* d, double stage_us[4], double* scan_algorithmic_bytes, int64_t* launches, int64_t* frames) {
+    if (!d) return fail(LM_ERR_INVALID, "null detector");
+    if (stage_us) for (int k = 0; k < 4; ++k) stage_us[k] = d->prof_us[k];
+    if (scan_algorithmic_bytes) *scan_algorithmic_bytes = d->prof_scan_bytes;
+    if (launches) *launches = d->prof_launches;
+    if (frames) *frames = d->prof_frames;
     return LM_OK;
 }
 

@@ -144,8 +144,12 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
                     mt.count[m] = (u32)t.features.size();
                     for (const lm_feature& f : t.features) {
                         LmRefFeat rf;
-                        rf.off = (u32)m * g.mod_stride + (u32)f.label * g.ori_stride +
-                                 (u32)((f.y % g.T) * g.T + (f.x % g.T)) * g.wh + (u32)(f.y / g.T) * g.W + (u32)(f.x / g.T);
+                        // spread arena: [modality][memory (y%T)*T + x%T][(y/T)*W + x/T]; label rides in the top bits
+                        rf.off = ((u32)m * g.mod_stride + (u32)((f.y % g.T) * g.T + (f.x % g.T)) * g.wh +
+                                  (u32)(f.y / g.T) * g.W + (u32)(f.x / g.T)) |
+                                 ((u32)f.label << 29);
+                        if ((u64)m * g.mod_stride + (u64)((f.y % g.T) * g.T + (f.x % g.T)) * g.wh + (u64)(f.y / g.T) * g.W +
+                                (u64)(f.x / g.T) >= (1ull << 29)) { err = "feature too far outside the frame"; return false; }
                         rf.x = (int16_t)f.x; rf.y = (int16_t)f.y;
                         out.ref_feat[l].push_back(rf);
                     }

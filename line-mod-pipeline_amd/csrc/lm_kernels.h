@@ -18,7 +18,8 @@ void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_
 // a6+a8+a9+a10: (optional NN half-size read of `q`) -> spread(T) -> 8 response maps -> linear memories.
 // q is the quantised image to read with row pitch qpitch: src_shift 0 = this level's image, 1 = the finer
 // level's image sampled at (2y, 2x).  lm points at the modality's first orientation block.
-void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, int w, int h, int T,
+// spread_only: write one spread linear memory (refinement levels) instead of 8 response memories.
+void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, bool spread_only, int w, int h, int T,
                          const u64* resp_tab, u8* lm, u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
                          int nslots);
 
@@ -50,6 +51,7 @@ struct LmRefineArgs {
     int M;
     const LmRefMeta* meta;   // [nt] for this level
     const LmRefFeat* feats;
+    const u32* sim_lut;      // SIMILARITY_LUT as 64 dwords: [ori][lo 16 B | hi 16 B]
     LmDevHeader* hdr;
     LmCand* cand;
     u64* keys;               // [match_cap][2]

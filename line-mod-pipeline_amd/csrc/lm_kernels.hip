@@ -345,7 +345,10 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const u16* __restrict__ 
 // orientation stores is one aligned dword and consecutive lanes write consecutive dwords.
 // ------------------------------------------------------------------------------------------------
 #define LMK_MAX_LOADS 8
-template <int SRC_SHIFT>
+// SPREAD_ONLY = false: the 8 response linear memories (lowest pyramid level, read by the scan).
+// SPREAD_ONLY = true : one "spread linear memory" holding the spread byte itself (levels that are
+//   only refined at): 1/8 of the bytes; k_refine applies the response LUT in registers.
+template <int SRC_SHIFT, bool SPREAD_ONLY>
 __global__ __launch_bounds__(256) void k_linear_memories(const u8* __restrict__ q0, int qpitch, int w, int h, int T,
                                                           int seg, const u64* __restrict__ resp_tab,
                                                           u8* __restrict__ lm0, u32 ori_stride, size_t q_slot_stride,
@@ -403,21 +406,26 @@ __global__ __launch_bounds__(256) void k_linear_memories(const u8* __restrict__ 
         for (int u = tid; u < units; u += 256) {
             int k4 = u % C4, g = u / C4;
             int j = g / T, c0 = g - j * T;
-            u64 e[4];
+            u8 sv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int x = (4 * k4 + i) * T + c0;
                 const u8* p = ho + j * pitch + x;
-                u8 sv = 0;
-                for (int r = 0; r < T; ++r) sv |= p[r * pitch];
-                e[i] = tab[sv];
+                u8 acc = 0;
+                for (int r = 0; r < T; ++r) acc |= p[r * pitch];
+                sv[i] = acc;
             }
             u8* dst = lm + (size_t)g * wh + (size_t)band * W + col0 + 4 * k4;
+            if (SPREAD_ONLY) {
+                *reinterpret_cast<u32*>(dst) = (u32)sv[0] | ((u32)sv[1] << 8) | ((u32)sv[2] << 16) | ((u32)sv[3] << 24);
+            } else {
+                u64 e0 = tab[sv[0]], e1 = tab[sv[1]], e2 = tab[sv[2]], e3 = tab[sv[3]];
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                u32 v = (u32)((e[0] >> (8 * o)) & 0xFF) | ((u32)((e[1] >> (8 * o)) & 0xFF) << 8) |
-                        ((u32)((e[2] >> (8 * o)) & 0xFF) << 16) | ((u32)((e[3] >> (8 * o)) & 0xFF) << 24);
-                *reinterpret_cast<u32*>(dst + (size_t)o * ori_stride) = v;
+                for (int o = 0; o < 8; ++o) {
+                    u32 v = (u32)((e0 >> (8 * o)) & 0xFF) | ((u32)((e1 >> (8 * o)) & 0xFF) << 8) |
+                            ((u32)((e2 >> (8 * o)) & 0xFF) << 16) | ((u32)((e3 >> (8 * o)) & 0xFF) << 24);
+                    *reinterpret_cast<u32*>(dst + (size_t)o * ori_stride) = v;
+                }
             }
         }
     } else {
@@ -428,10 +436,14 @@ __global__ __launch_bounds__(256) void k_linear_memories(const u8* __restrict__ 
             const u8* p = ho + j * pitch + k * T + c0;
             u8 sv = 0;
             for (int r = 0; r < T; ++r) sv |= p[r * pitch];
-            u64 e = tab[sv];
             u8* dst = lm + (size_t)g * wh + (size_t)band * W + col0 + k;
+            if (SPREAD_ONLY) {
+                dst[0] = sv;
+            } else {
+                u64 e = tab[sv];
 #pragma unroll
-            for (int o = 0; o < 8; ++o) dst[(size_t)o * ori_stride] = (u8)(e >> (8 * o));
+                for (int o = 0; o < 8; ++o) dst[(size_t)o * ori_stride] = (u8)(e >> (8 * o));
+            }
         }
     }
 }
@@ -511,9 +523,13 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // a14  One wave per candidate: lane l holds the 4 patch positions (row l/4, cols 4(l%4)..+3) of the
-// 16x16 patch.  The modality's feature records are loaded one per lane, bounds-checked in parallel
-// (features shifted out of the frame read the arena's zero block instead), then broadcast with
-// v_readlane so the patch loads (one unaligned dword per lane per feature) issue back to back.
+// 16x16 patch.  Refinement levels keep SPREAD linear memories (1 byte per position instead of 8
+// response bytes: the whole level stays L2-resident and a patch load touches 1/8 of the lines); the
+// response max(LUT_lo[v & 15], LUT_hi[v >> 4]) is evaluated in registers with v_perm_b32, four
+// positions per instruction -- the same 16-entry nibble lookups upstream does with pshufb.
+// The modality's feature records are loaded one per lane, bounds-checked in parallel (features
+// shifted out of the frame read the arena's zero block: spread 0 -> response 0), then broadcast
+// with v_readlane so the patch loads (one unaligned dword per lane per feature) issue back to back.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 #pragma unroll
@@ -522,6 +538,21 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
         v = v > o ? v : o;
     }
     return v;
+}
+
+// table[idx] for four 4-bit indices at once; t0..t3 hold the 16 table bytes
+__device__ __forceinline__ u32 lookup16x4(u32 idx4, u32 t0, u32 t1, u32 t2, u32 t3) {
+    u32 sel = idx4 & 0x07070707u;
+    u32 a = __builtin_amdgcn_perm(t1, t0, sel);      // entries 0..7
+    u32 b = __builtin_amdgcn_perm(t3, t2, sel);      // entries 8..15
+    u32 m = ((idx4 >> 3) & 0x01010101u) * 0xFFu;     // 0xFF where idx >= 8
+    return (b & m) | (a & ~m);
+}
+// per-byte max of two dwords whose bytes are < 128
+__device__ __forceinline__ u32 bytemax4(u32 a, u32 b) {
+    u32 d = (a | 0x80808080u) - b;
+    u32 m = ((d >> 7) & 0x01010101u) * 0xFFu;        // 0xFF where a >= b
+    return (a & m) | (b & ~m);
 }
 
 __device__ __forceinline__ void emit_key(const LmRefineArgs& a, LmDevHeader* hdr, u64* keys, u32 ti, int x, int y,
@@ -539,7 +570,10 @@ __device__ __forceinline__ void emit_key(const LmRefineArgs& a, LmDevHeader* hdr
 
 template <bool LAST>
 __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
+    __shared__ __attribute__((aligned(16))) u32 lut_s[64];   // SIMILARITY_LUT: [ori][lo 16 B | hi 16 B]
     const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) lut_s[threadIdx.x] = a.sim_lut[threadIdx.x];
+    __syncthreads();
     const u32 wave0 = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
     const u32 nwaves = gridDim.x * 4u;
     LmDevHeader* hdr = slot_ptr(a.hdr, a.aux_slot_stride);
@@ -552,6 +586,7 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
     const int border = 8 * T;
     const int offset = T / 2 + (T % 2 - 1);
     const u32 lane_off = (u32)((lane >> 2) * W + (lane & 3) * 4);
+    const u32x4* lut4 = reinterpret_cast<const u32x4*>(lut_s);
     for (u32 i = wave0; i < n; i += nwaves) {
         LmCand c = cand[i];
         u32 ti = (u32)__builtin_amdgcn_readfirstlane((int)c.ti);
@@ -573,7 +608,8 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
             if (lane < cnt) ft = a.feats[mt.start[m] + lane];
             int fx = ft.x + off_x, fy = ft.y + off_y;
             bool ok = (lane < cnt) && fx >= 0 && fy >= 0 && fx < a.g.w && fy < a.g.h;
-            u32 eff = ok ? ft.off + shift : a.g.zero_off;
+            const u32 eff = ok ? (ft.off & 0x1FFFFFFFu) + shift : a.g.zero_off;
+            const u32 lab = ft.off >> 29;
             u32 acc = 0;
             for (int f = 0; f < cnt; f += 8) {
                 u32 v[8];
@@ -583,7 +619,13 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
                     v[k] = ld4u(lm + o + lane_off);
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc += v[k];
+                for (int k = 0; k < 8; ++k) {
+                    u32 lb = (u32)__builtin_amdgcn_readlane((int)lab, f + k);
+                    u32x4 tlo = lut4[2 * lb], thi = lut4[2 * lb + 1];
+                    u32 rl = lookup16x4(v[k] & 0x0F0F0F0Fu, tlo[0], tlo[1], tlo[2], tlo[3]);
+                    u32 rh = lookup16x4((v[k] >> 4) & 0x0F0F0F0Fu, thi[0], thi[1], thi[2], thi[3]);
+                    acc += bytemax4(rl, rh);
+                }
             }
             tl += acc & 0x00FF00FFu;
             th += (acc >> 8) & 0x00FF00FFu;
@@ -764,7 +806,7 @@ void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_
                        slot_stride);
 }
 
-void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, int w, int h, int T,
+void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, bool spread_only, int w, int h, int T,
                          const u64* resp_tab, u8* lm, u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
                          int nslots) {
     const int W = w / T;
@@ -778,12 +820,12 @@ void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, 
     int pitch = (seg * T + T + 3) & ~3;
     size_t shmem = 2048 + 2 * (size_t)(2 * T - 1) * pitch;
     dim3 grid(nseg, h / T, nslots);
-    if (src_shift)
-        hipLaunchKernelGGL(k_linear_memories<1>, grid, dim3(256), shmem, s, q, qpitch, w, h, T, seg, resp_tab, lm,
-                           ori_stride, q_slot_stride, lm_slot_stride);
-    else
-        hipLaunchKernelGGL(k_linear_memories<0>, grid, dim3(256), shmem, s, q, qpitch, w, h, T, seg, resp_tab, lm,
-                           ori_stride, q_slot_stride, lm_slot_stride);
+#define LMK_LAUNCH(SH, SP)                                                                                    \
+    hipLaunchKernelGGL((k_linear_memories<SH, SP>), grid, dim3(256), shmem, s, q, qpitch, w, h, T, seg, resp_tab, lm, \
+                       ori_stride, q_slot_stride, lm_slot_stride)
+    if (src_shift) { if (spread_only) LMK_LAUNCH(1, true); else LMK_LAUNCH(1, false); }
+    else           { if (spread_only) LMK_LAUNCH(0, true); else LMK_LAUNCH(0, false); }
+#undef LMK_LAUNCH
 }
 
 void lmk_scan(hipStream_t s, const LmScanArgs& a, int variant, int nslots) {

@@ -1,0 +1,63 @@
+"""Worker of tests/test_dist.py: one rank of a world_size-R gloo group on CPU.
+
+Exercises the product's shard-gather layer (line-mod-pipeline_amd/dist.py) exactly as bench.py uses it
+on RCCL, with the CPU oracle standing in for the per-shard GPU matcher (allowed: tests only)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    lm = importlib.import_module("line-mod-pipeline_amd")
+    synth = importlib.import_module("line-mod-pipeline_amd.synth")
+    distmod = importlib.import_module("line-mod-pipeline_amd.dist")
+    from oracle import oracle as O
+
+    B, thr, cap = 3, 70.0, 2048
+    frames = [synth.make_frame(640, 480, seed=300 + i) for i in range(B)]
+    o = O.Detector(color_only=False)
+    o.prepare(*frames[0])
+    q = {(l, m): o.stage(0, l, m).reshape(480 >> l, 640 >> l) for l in range(2) for m in range(2)}
+    descs, feats, _ = synth.make_bank(90, 2, 2, seed=17, quantized=q, crop_fraction=0.3)
+    o.add_class("c", descs, feats)
+    n = o.class_num_templates(0)
+    lo, hi = distmod.shard_range(n, rank, world)
+
+    def local_match(n_frames, threshold, class_idx):
+        rec = np.zeros((n_frames, cap), lm.MATCH_DTYPE)
+        cnt = np.zeros(n_frames, np.int32)
+        for i in range(n_frames):
+            m = o.match(frames[i][0], frames[i][1], threshold, class_idx, tid_lo=lo, tid_hi=hi)
+            rec[i, :len(m)] = m
+            cnt[i] = len(m)
+        return rec, cnt
+
+    sd = distmod.ShardedDetector(local_match, lm.merge_matches, cap=cap)
+    merged = sd.match_batch(B, thr, 0)
+    ok = True
+    for i in range(B):
+        full = o.match(frames[i][0], frames[i][1], thr, 0)
+        ok &= len(full) > 0 and merged[i].tobytes() == full.tobytes()
+    # capacity overflow must be loud (K must cover all matches)
+    small = distmod.ShardGather(lm.merge_matches, cap=1)
+    try:
+        small.gather_merge(*local_match(B, thr, 0))
+        ok = False
+    except OverflowError:
+        pass
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RANK %d %s" % (rank, "OK" if ok else "FAIL"), flush=True)
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

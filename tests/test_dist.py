@@ -1,0 +1,51 @@
+"""Multi-process CPU test of the N>1 path: template-bank shards -> all-gather of the
+per-shard match lists -> merge == unsharded result.  gloo backend, world sizes 2 and 3."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gather_gloo(world, lm, orc):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py")]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for k in range(world):
+        assert "RANK %d OK" % k in r.stdout
+
+
+def test_shard_ranges_partition(lm):
+    distmod = __import__("importlib").import_module("line-mod-pipeline_amd.dist")
+    for n in (0, 1, 7, 3000, 24300):
+        for R in (1, 2, 3, 4, 8):
+            ranges = [distmod.shard_range(n, r, R) for r in range(R)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(R - 1))
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_rank_gather_is_identity(lm):
+    distmod = __import__("importlib").import_module("line-mod-pipeline_amd.dist")
+    g = distmod.ShardGather(lm.merge_matches, cap=16)
+    rec = np.zeros((2, 16), lm.MATCH_DTYPE)
+    rec["x"][0, :3] = [1, 2, 3]
+    out = g.gather_merge(rec, np.array([3, 0], np.int32))
+    assert len(out) == 2 and len(out[0]) == 3 and len(out[1]) == 0

@@ -28,7 +28,7 @@ def run(color_only, size, n, fixed):
         b, dp = synth.make_frame(size[0], size[1], seed=1234 + i)
         d.upload_frame(i, b, dp if M == 2 else None)
     m = d.match_slot(0, 80.0)
-    print("matches", len(m), m[:3])
+    print("matches", len(m), m[:3], "counts", d.last_counts(0))
     for v in (0, 1, 2):
         us, by = d.time_scan(0, 80.0, iters=50, variant=v)
         print("scan variant %d: %.2f us, %.1f MB algorithmic -> %.2f TB/s" % (v, us, by / 1e6, by / us / 1e6))
