@@ -1,0 +1,113 @@
+// HighLevelLinemod.h -- C++ host facade over the C ABI (include/linemod_hip.h).
+//
+// Mirrors the public interface of the reference's wrapper class
+//     class HighLevelLineMOD            /root/reference/include/HighLevelLinemod.h:21-99
+// (same method names, argument meaning and bool/void error behaviour) without OpenCV or GLM types,
+// neither of which exists on the GPU box.  Where the reference holds
+//     cv::Ptr<cv::linemod::Detector> detector;   (HighLevelLinemod.h:102)
+// this class holds an lm_detector* and every call that crossed that seam goes through liblinemod_hip.so.
+//
+// Round-1 scope: the hot path behind detectTemplate (Detector::match) and the
+// detector queries.  The host glue around it that section 8f lists as "next" -- in-plane-rotated
+// template generation (f3), match post-processing into ObjectPose (f1), OpenCV YAML persistence (f2) --
+// is declared here with the reference's signatures and marked where it is not built yet.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/linemod_hip.h"
+
+namespace lmamd {
+
+// cv::Mat stand-in: a borrowed view.  type 0 = CV_8UC3 (BGR), 1 = CV_16UC1 (depth mm), 2 = CV_8UC1 (mask).
+struct Image {
+    const void* data = nullptr;
+    int width = 0, height = 0;
+    size_t stride = 0;  // bytes per row, 0 = dense
+    int type = 0;
+};
+
+struct Vec3 { float x = 0, y = 0, z = 0; };
+struct Quat { float w = 1, x = 0, y = 0, z = 0; };
+struct Rect { int x = 0, y = 0, width = 0, height = 0; };
+
+// defines.h:37-45
+struct ObjectPose {
+    Vec3 translation;
+    Quat quaternions;
+    Rect boundingBox;
+};
+
+// defines.h:47-57 (the fields the hot path reads)
+struct CameraParameters {
+    float fx = 0, fy = 0, cx = 0, cy = 0;
+    uint16_t videoWidth = 640, videoHeight = 480;
+};
+
+// defines.h:59-83 (the fields HighLevelLineMOD's constructor copies, HighLevelLinemod.cpp:5-24)
+struct TemplateGenerationSettings {
+    std::string modelFolder;
+    bool onlyUseColorModality = false;
+    uint16_t stepSize = 50;
+    int16_t angleStart = -45, angleStop = 45, angleStep = 10;
+    float detectorThreshold = 80.f;
+    uint16_t percentToPassCheck = 50;
+    uint16_t numberWantedPoses = 1;
+    float radiusThresholdNewObject = 45.f;
+    float discardGroupRatio = 35.f;
+    bool useDepthImprovement = true;
+    float depthOffset = 30.f;
+    int device = 0;          // not in the reference: HIP device ordinal
+    int shardRank = 0;       // not in the reference: template-bank shard of this process
+    int shardSize = 1;
+};
+
+class HighLevelLineMOD {
+public:
+    // HighLevelLinemod.cpp:3-46: {ColorGradient, DepthNormal} with T={5,8}, or {ColorGradient} with T={2,8}
+    HighLevelLineMOD(CameraParameters const& in_camParams, TemplateGenerationSettings const& in_templateSettings);
+    ~HighLevelLineMOD();
+    HighLevelLineMOD(const HighLevelLineMOD&) = delete;
+    HighLevelLineMOD& operator=(const HighLevelLineMOD&) = delete;
+
+    std::vector<std::string> getClassIds();   // :53-56
+    uint16_t getNumClasses();                 // :58-61
+    uint32_t getNumTemplates();               // :63-66
+
+    // :138-190.  in_imgs = {colour} or {colour, depth}; a colour-only detector ignores the depth image for
+    // matching exactly like the reference (:146-151).  Returns true iff the raw match list is non-empty.
+    bool detectTemplate(std::vector<Image>& in_imgs, uint16_t in_classNumber);
+
+    // The raw, sorted, unique match list of the last detectTemplate (the reference keeps it in the private
+    // member `matches`, HighLevelLinemod.h:166, and feeds it to its post-processing).
+    const std::vector<lm_match_t>& getMatches() const { return matches; }
+
+    // :256-320.  Template bank in this library's own format next to the reference's file names:
+    // "linemod_templates.lmbk" (the OpenCV YAML reader/writer is section 8f-2, next).
+    void writeLinemod();
+    void readLinemod();
+
+    // :68-110.  One template per call from a rendered colour+depth pair, WITHOUT the in-plane rotation
+    // sweep (warpAffine glue is section 8f-3, next): equivalent to the reference with
+    // angleStart == angleStop == 0.  Returns false when extraction fails (upstream -1).
+    bool addTemplate(std::vector<Image>& in_images, const std::string& in_modelName, Vec3 in_cameraPosition);
+    void pushBackTemplates();                 // :517-521
+
+    // :322-325.  Match post-processing into poses is section 8f-1 (next): empty until then.
+    std::vector<std::vector<ObjectPose>> getObjectPoses() { return posesMultipleObj; }
+
+    lm_detector* handle() { return detector; }
+    const std::string& lastError() const { return error; }
+
+private:
+    lm_detector* detector = nullptr;
+    bool onlyColorModality;
+    uint16_t videoWidth, videoHeight;
+    float detectorThreshold;
+    std::vector<lm_match_t> matches;
+    std::vector<std::vector<ObjectPose>> posesMultipleObj;
+    std::string error;
+};
+
+}  // namespace lmamd
