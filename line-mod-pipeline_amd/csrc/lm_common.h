@@ -22,7 +22,7 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-#define LM_SCAN_CHUNK 1024      // positions one wave covers in the similarity scan (64 lanes x 16 B)
+#define LM_SCAN_CHUNK 1008      // positions one wave covers in the similarity scan (63 lanes x 16 B; lane 63 feeds lane 62)
 #define LM_SCAN_FPAD 8          // feature lists are padded to a multiple of this with zero-block offsets
 #define LM_SORT_CAP 4096        // matches sorted on the device (LDS); more are sorted by the host
 #define LM_INLINE_MATCHES 2048  // records the sort kernel also writes straight into host-mapped memory

@@ -39,6 +39,7 @@ struct LmScanArgs {
     LmCand* cand;
     size_t aux_slot_stride;
     u32 cand_cap;
+    int wgs_per_slot, nslots; // filled by lmk_scan
 };
 // a11+a12+a13: similarity scan over the lowest level fused with the threshold scan.
 // variant selects the unroll depth of the feature loop (0: 8 loads in flight, 1: 4, 2: 2).

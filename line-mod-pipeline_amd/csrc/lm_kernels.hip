@@ -34,6 +34,18 @@ __device__ __forceinline__ int refl101(int p, int n) {
 }
 __device__ __forceinline__ u32x4 ld16u(const u8* p) { return reinterpret_cast<const U32x4U*>(p)->v; }
 __device__ __forceinline__ u32 ld4u(const u8* p) { return reinterpret_cast<const U32U*>(p)->v; }
+// dword-aligned wide loads: byte-misaligned vector loads are split by the memory pipeline and run at
+// less than half rate on gfx950 (measured: 16.7 -> 7.6 us per frame for the scan), dword alignment is
+// enough for full rate; the byte shift is applied in registers with v_alignbyte_b32.
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) U32x4A4 { u32x4 v; };
+struct __attribute__((packed, aligned(4))) U32x2A4 { u32x2 v; };
+__device__ __forceinline__ u32x4 ld16a4(const u8* p) { return reinterpret_cast<const U32x4A4*>(p)->v; }
+__device__ __forceinline__ u32x2 ld8a4(const u8* p) { return reinterpret_cast<const U32x2A4*>(p)->v; }
+// value of lane + 1 (0 for lane 63): v_mov_b32_dpp wave_shl:1
+__device__ __forceinline__ u32 next_lane(u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
 
 template <typename T>
 __device__ __forceinline__ T* slot_ptr(T* p, size_t slot_stride) {
@@ -449,18 +461,34 @@ __global__ __launch_bounds__(256) void k_linear_memories(const u8* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// a11-a13  HOT KERNEL.  One wave per (template, chunk of 1024 positions): lane l owns positions
+// a11-a13  HOT KERNEL.  One wave per (template, chunk of 1008 positions): lane l < 63 owns positions
 // [16 l, 16 l + 16) of the chunk.  For every feature the wave reads 1 KiB contiguous from the
-// feature's linear memory at a wave-uniform byte offset (scalar-loaded from the bank) and adds it
-// byte-wise: four u32 adds carry sixteen u8 lanes, 63 features x 4 = 252 never overflows a byte.
+// feature's linear memory at a wave-uniform byte offset (scalar-loaded from the bank), rounded down
+// to a dword so the load runs at full rate; the 0..3 byte shift is undone in registers
+// (v_alignbyte_b32 with the scalar shift; the 17th..19th byte comes from the next lane by DPP
+// wave_shl:1, which is why lane 63 only feeds lane 62).  The realigned dwords are added byte-wise:
+// four u32 adds carry sixteen u8 lanes, 63 features x 4 = 252 never overflows a byte.
 // Modalities are then widened to u16 and summed (a12) and compared with the raw threshold (a13)
 // without ever materialising the similarity map.  Feature lists are padded to a multiple of 8 with
 // offsets into the arena's zero block so the inner loop has no tail.
 // ------------------------------------------------------------------------------------------------
-template <int UNROLL>
+// Workgroup -> (slot, items) mapping.  XCD_MAP: a 1-D grid whose block b is assumed to run on XCD b % 8
+// (observed round-robin dispatch; only speed depends on it): each XCD then works on one frame slot at a
+// time, so its 4 MB L2 holds that frame's 1.2 MB of linear memories + the bank instead of all slots'.
+template <int UNROLL, bool XCD_MAP>
 __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
+    u32 slot, wg;
+    if (XCD_MAP) {
+        const u32 G = (u32)a.wgs_per_slot, B = (u32)a.nslots;
+        const u32 b = blockIdx.x, x = b & 7u, k = b >> 3;
+        if ((B & 7u) == 0) { slot = x + 8u * (k / G); wg = k % G; }          // XCD x owns slots = x mod 8
+        else { const u32 r = 8u / B; slot = x % B; wg = k * r + x / B; }     // B in {1,2,4}: r XCDs share a slot
+        if (wg >= G || slot >= B) return;
+    } else {
+        slot = blockIdx.z; wg = blockIdx.x;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane((int)((wg * 256u + threadIdx.x) >> 6));
     if (wave >= a.n_items) return;
     const u32 ti = a.item_t[a.item_lo + wave];
     const u32 chunk = a.item_chunk[a.item_lo + wave];
@@ -468,9 +496,9 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
     const int n = a.scan_n[ti];
     const int thr = a.raw_thr_by_n[n];
     const u32 j0 = chunk * LM_SCAN_CHUNK + (u32)lane * 16u;
-    const u8* base = a.lm + (size_t)blockIdx.z * a.lm_slot_stride + j0;
-    LmDevHeader* hdr = slot_ptr(a.hdr, a.aux_slot_stride);
-    LmCand* cand = slot_ptr(a.cand, a.aux_slot_stride);
+    const u8* base = a.lm + (size_t)slot * a.lm_slot_stride + j0;
+    LmDevHeader* hdr = reinterpret_cast<LmDevHeader*>(reinterpret_cast<u8*>(a.hdr) + (size_t)slot * a.aux_slot_stride);
+    LmCand* cand = reinterpret_cast<LmCand*>(reinterpret_cast<u8*>(a.cand) + (size_t)slot * a.aux_slot_stride);
 
     u32 tl[4] = {0, 0, 0, 0}, th[4] = {0, 0, 0, 0};  // u16 pairs: bytes {0,2} and {1,3} of each dword
     for (int m = 0; m < a.M; ++m) {
@@ -478,10 +506,21 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
         u32x4 acc = {0, 0, 0, 0};
         for (int f = 0; f < a.fpad; f += UNROLL) {
             u32x4 v[UNROLL];
+            u32 sh[UNROLL];
 #pragma unroll
-            for (int k = 0; k < UNROLL; ++k) v[k] = ld16u(base + offs[f + k]);
+            for (int k = 0; k < UNROLL; ++k) {
+                const u32 o = offs[f + k];
+                sh[k] = o & 3u;
+                v[k] = ld16a4(base + (o & ~3u));
+            }
 #pragma unroll
-            for (int k = 0; k < UNROLL; ++k) acc += v[k];
+            for (int k = 0; k < UNROLL; ++k) {
+                const u32 nx = next_lane(v[k][0]);
+                acc[0] += __builtin_amdgcn_alignbyte(v[k][1], v[k][0], sh[k]);
+                acc[1] += __builtin_amdgcn_alignbyte(v[k][2], v[k][1], sh[k]);
+                acc[2] += __builtin_amdgcn_alignbyte(v[k][3], v[k][2], sh[k]);
+                acc[3] += __builtin_amdgcn_alignbyte(nx, v[k][3], sh[k]);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -498,6 +537,7 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
                (s2 > thr ? 1u : 0u) << (4 * k + 2) | (s3 > thr ? 1u : 0u) << (4 * k + 3);
     }
     int valid = P - (int)j0;  // number of valid positions in this lane's 16
+    if (lane == 63) valid = 0;  // lane 63 only supplies lane 62's spill-over bytes
     if (valid <= 0) hit = 0;
     else if (valid < 16) hit &= (1u << valid) - 1u;
     if (!__any(hit != 0)) return;
@@ -615,8 +655,10 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
                 u32 v[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    u32 o = (u32)__builtin_amdgcn_readlane((int)eff, f + k);
-                    v[k] = ld4u(lm + o + lane_off);
+                    // dword-aligned 8-byte load + v_alignbyte instead of a byte-misaligned dword load
+                    const u32 t = (u32)__builtin_amdgcn_readlane((int)eff, f + k) + lane_off;
+                    const u32x2 d = ld8a4(lm + (t & ~3u));
+                    v[k] = __builtin_amdgcn_alignbyte(d[1], d[0], t & 3u);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -828,14 +870,22 @@ void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, 
 #undef LMK_LAUNCH
 }
 
-void lmk_scan(hipStream_t s, const LmScanArgs& a, int variant, int nslots) {
-    if (a.n_items <= 0) return;
-    dim3 grid((a.n_items + 3) / 4, 1, nslots);
-    switch (variant) {
-        case 1: hipLaunchKernelGGL(k_scan<4>, grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(k_scan<2>, grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(k_scan<8>, grid, dim3(256), 0, s, a); break;
-    }
+void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
+    if (a_in.n_items <= 0) return;
+    LmScanArgs a = a_in;
+    const int G = (a.n_items + 3) / 4;
+    a.wgs_per_slot = G; a.nslots = nslots;
+    // variant bits 0-1: feature-loop unroll (0: 8 loads in flight, 1: 4, 2: 2); bit 2: plain (slot = grid.z)
+    // mapping instead of the XCD-aware one
+    const bool xcd = !(variant & 4) && (nslots == 1 || nslots == 2 || nslots == 4 || (nslots % 8) == 0);
+    dim3 grid = xcd ? dim3(((nslots % 8) == 0) ? (unsigned)(G * nslots) : 8u * (unsigned)((G + 8 / nslots - 1) / (8 / nslots)))
+                    : dim3(G, 1, nslots);
+    const int u = variant & 3;
+#define SCAN_LAUNCH(U)                                                                      \
+    do { if (xcd) hipLaunchKernelGGL((k_scan<U, true>), grid, dim3(256), 0, s, a);  \
+         else hipLaunchKernelGGL((k_scan<U, false>), grid, dim3(256), 0, s, a); } while (0)
+    if (u == 1) SCAN_LAUNCH(4); else if (u == 2) SCAN_LAUNCH(2); else SCAN_LAUNCH(8);
+#undef SCAN_LAUNCH
 }
 
 void lmk_refine(hipStream_t s, const LmRefineArgs& a, bool last, int nslots) {
