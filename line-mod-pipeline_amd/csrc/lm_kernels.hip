@@ -461,6 +461,115 @@ __global__ __launch_bounds__(256) void k_linear_memories(const u8* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// a6-a10, fast path: T and the segment width are compile-time (the reference's T = 2, 5, 8 plus 4), so
+// every index division is by a constant, and the separable OR runs on dwords (4 pixels per op, byte
+// shifts by v_alignbyte_b32).  Needs w, W and the source pitch to be multiples of 4; everything else
+// goes through the generic k_linear_memories above.
+// ------------------------------------------------------------------------------------------------
+template <int T, int SEG, int SRC_SHIFT, bool SPREAD_ONLY>
+__global__ __launch_bounds__(256) void k_lm_fast(const u8* __restrict__ q0, int qpitch, int w, int h,
+                                                  const u64* __restrict__ resp_tab, u8* __restrict__ lm0,
+                                                  u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride) {
+    constexpr int ROWS = 2 * T - 1;
+    constexpr int TW = SEG * T;                    // pixels per segment
+    constexpr int NDW = (TW + T - 1 + 3) / 4;      // source dwords per row including the right halo
+    constexpr int PD = NDW + 2;                    // LDS pitch in dwords: two zero dwords for the funnel reads
+    constexpr int NLOAD = (ROWS * PD + 255) / 256;
+    __shared__ u64 tab[SPREAD_ONLY ? 1 : 256];
+    __shared__ u32 qs[ROWS][PD];
+    __shared__ u32 ho[ROWS][PD];
+    __shared__ u32 sp[T][PD];
+    const u8* q = slot_ptr(q0, q_slot_stride);
+    u8* lm = slot_ptr(lm0, lm_slot_stride);
+    const int tid = threadIdx.x;
+    const int W = w / T;
+    const u32 wh = (u32)W * (u32)(h / T);
+    const int band = blockIdx.y;
+    const int col0 = blockIdx.x * SEG;
+    const int ncols = (W - col0) < SEG ? (W - col0) : SEG;
+    const int px0 = col0 * T, y0 = band * T;
+
+    if (!SPREAD_ONLY) tab[tid] = resp_tab[tid];
+    {
+        u32 v[NLOAD];
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+            const int i = tid + k * 256;
+            const int r = i / PD, c = i - r * PD;
+            const int gy = y0 + r, gx = px0 + 4 * c;
+            u32 val = 0;
+            if (i < ROWS * PD && c < NDW && gy < h && gx < w) {
+                if (SRC_SHIFT) {   // NN half-size read: pixels (2gy, 2gx .. 2gx+6 step 2)
+                    const u32* sp2 = reinterpret_cast<const u32*>(q + (size_t)(2 * gy) * qpitch + 2 * gx);
+                    val = __builtin_amdgcn_perm(sp2[1], sp2[0], 0x06040200u);
+                } else {
+                    val = *reinterpret_cast<const u32*>(q + (size_t)gy * qpitch + gx);
+                }
+            }
+            v[k] = val;
+        }
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+            const int i = tid + k * 256;
+            if (i < ROWS * PD) { const int r = i / PD; qs[r][i - r * PD] = v[k]; }
+        }
+    }
+    __syncthreads();
+    // horizontal OR over T pixels, 4 pixels per thread-op
+    for (int i = tid; i < ROWS * NDW; i += 256) {
+        const int r = i / NDW, c = i - r * NDW;
+        const u32 d0 = qs[r][c], d1 = qs[r][c + 1], d2 = qs[r][c + 2];
+        u32 hor = d0;
+#pragma unroll
+        for (int k = 1; k < T; ++k) {
+            if (k < 4) hor |= __builtin_amdgcn_alignbyte(d1, d0, (u32)k);
+            else if (k == 4) hor |= d1;
+            else hor |= __builtin_amdgcn_alignbyte(d2, d1, (u32)(k - 4));
+        }
+        ho[r][c] = hor;
+    }
+    __syncthreads();
+    // vertical OR over T rows
+    for (int i = tid; i < T * NDW; i += 256) {
+        const int j = i / NDW, c = i - j * NDW;
+        u32 v = 0;
+#pragma unroll
+        for (int r = 0; r < T; ++r) v |= ho[j + r][c];
+        sp[j][c] = v;
+    }
+    __syncthreads();
+    // linearize: unit = (row-in-band j, column phase c0, 4 consecutive memory columns)
+    constexpr int C4 = SEG / 4;
+    for (int u = tid; u < T * T * C4; u += 256) {
+        const int k4 = u % C4, g = u / C4;
+        const int j = g / T, c0 = g - j * T;
+        if (4 * k4 >= ncols) continue;
+        const u8* row = reinterpret_cast<const u8*>(&sp[j][0]);
+        const u32 s0 = row[(4 * k4 + 0) * T + c0], s1 = row[(4 * k4 + 1) * T + c0];
+        const u32 s2 = row[(4 * k4 + 2) * T + c0], s3 = row[(4 * k4 + 3) * T + c0];
+        u8* dst = lm + (size_t)g * wh + (size_t)band * W + col0 + 4 * k4;
+        if (SPREAD_ONLY) {
+            *reinterpret_cast<u32*>(dst) = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+        } else {
+            const u64 e0 = tab[s0], e1 = tab[s1], e2 = tab[s2], e3 = tab[s3];
+            const u32 a0 = (u32)e0, a1 = (u32)e1, a2 = (u32)e2, a3 = (u32)e3;
+            const u32 b0 = (u32)(e0 >> 32), b1 = (u32)(e1 >> 32), b2 = (u32)(e2 >> 32), b3 = (u32)(e3 >> 32);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                // byte o of a0,a1 | byte o of a2,a3: perm selectors pick src1 bytes as 0..3, src0 bytes as 4..7
+                const u32 sel = (u32)o | ((u32)(o + 4) << 8);
+                u32 lo = __builtin_amdgcn_perm(a1, a0, sel) & 0xFFFFu;
+                u32 hi = __builtin_amdgcn_perm(a3, a2, sel) << 16;
+                *reinterpret_cast<u32*>(dst + (size_t)o * ori_stride) = lo | hi;
+                u32 lo2 = __builtin_amdgcn_perm(b1, b0, sel) & 0xFFFFu;
+                u32 hi2 = __builtin_amdgcn_perm(b3, b2, sel) << 16;
+                *reinterpret_cast<u32*>(dst + (size_t)(o + 4) * ori_stride) = lo2 | hi2;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // a11-a13  HOT KERNEL.  One wave per (template, chunk of 1008 positions): lane l < 63 owns positions
 // [16 l, 16 l + 16) of the chunk.  For every feature the wave reads 1 KiB contiguous from the
 // feature's linear memory at a wave-uniform byte offset (scalar-loaded from the bank), rounded down
@@ -848,10 +957,38 @@ void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_
                        slot_stride);
 }
 
+template <int T, int SEG>
+static void lm_fast_launch(hipStream_t s, const u8* q, int qpitch, int src_shift, bool spread_only, int w, int h,
+                           const u64* resp_tab, u8* lm, u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
+                           int nslots) {
+    const int W = w / T;
+    dim3 grid((W + SEG - 1) / SEG, h / T, nslots);
+#define LMF(SH, SP)                                                                                           \
+    hipLaunchKernelGGL((k_lm_fast<T, SEG, SH, SP>), grid, dim3(256), 0, s, q, qpitch, w, h, resp_tab, lm, ori_stride, \
+                       q_slot_stride, lm_slot_stride)
+    if (src_shift) { if (spread_only) LMF(1, true); else LMF(1, false); }
+    else           { if (spread_only) LMF(0, true); else LMF(0, false); }
+#undef LMF
+}
+
 void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, bool spread_only, int w, int h, int T,
                          const u64* resp_tab, u8* lm, u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
                          int nslots) {
     const int W = w / T;
+    const bool aligned = (w % 4 == 0) && (W % 4 == 0) && (qpitch % 4 == 0) && (((uintptr_t)q & 3) == 0) &&
+                         (q_slot_stride % 4 == 0);
+    if (aligned) {
+#define LMF_ARGS s, q, qpitch, src_shift, spread_only, w, h, resp_tab, lm, ori_stride, q_slot_stride, lm_slot_stride, nslots
+        switch (T) {
+            case 2: lm_fast_launch<2, 128>(LMF_ARGS); return;
+            case 4: lm_fast_launch<4, 64>(LMF_ARGS); return;
+            case 5: lm_fast_launch<5, 48>(LMF_ARGS); return;
+            case 8: lm_fast_launch<8, 16>(LMF_ARGS); return;
+            default: break;
+        }
+#undef LMF_ARGS
+    }
+    // generic path (any T, any width)
     // segment width: about 1024 linear-memory bytes per (band, segment), a multiple of 4 columns, and
     // few enough source bytes for LMK_MAX_LOADS loads per thread
     int seg = (1024 / (T * T)) & ~3;
