@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=8, help="frames per step (resident in HBM)")
+    ap.add_argument("--batch", type=int, default=32, help="frames per step (resident in HBM)")
     ap.add_argument("--templates", type=int, default=3000, help="templates per GPU")
     ap.add_argument("--threshold", type=float, default=80.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,12 +126,13 @@ def main():
     scan_us = prof["stage_us"][1] / max(prof["launches"], 1)
     bytes_per_launch = prof["scan_bytes"] / max(prof["launches"], 1)
     achieved = bytes_per_launch / (scan_us * 1e-6) / 1e9 if scan_us > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(B)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "k_scan", "avg_launch_us": round(scan_us, 2),
                 "algorithmic_bytes_per_launch": bytes_per_launch, "frames_per_launch": B,
                 "note": "linear memories of the scanned level (1.2 MB/frame) are L2-resident: algorithmic bytes "
-                        "are served by L2, HBM traffic is far lower (see DESIGN.md)"}
+                        "are served by L2, HBM traffic is ~1% of them (see DESIGN.md)"}
     stage_us_per_frame = [round(v / max(prof["frames"], 1), 2) for v in prof["stage_us"]]
 
     result = None
@@ -163,6 +164,24 @@ def main():
     return result
 
 
+def pmc_traffic(frames_per_launch):
+    """HBM bytes per k_scan launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/summarize_pmc.py: 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes).  PMC counters cannot be read
+    from inside the process, so this is null unless a committed pass matches frames_per_launch."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_batch*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("frames_per_launch") != frames_per_launch:
+            continue
+        for k, v in d.get("kernels", {}).items():
+            if k.startswith("k_scan"):
+                return v["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def cpu_baseline(args, frames, descs, feats, det, lm):
     """The CPU oracle (kind "port": a restatement, the reference itself cannot be built here) on this
     host's cores, bounded sample, same frames and bank; its match list must equal the GPU's first."""
@@ -174,25 +193,34 @@ def cpu_baseline(args, frames, descs, feats, det, lm):
         orc.add_class("synthetic.ply", descs, feats)
         bgr, depth = frames[0]
         gpu = det.match_slot(0, args.threshold, 0)
-        exp = orc.match(bgr, depth, args.threshold, 0, threads=cores)
+        exp = orc.match(bgr, depth, args.threshold, 0, threads=min(cores, 16))
         if gpu.tobytes() != exp.tobytes():
             return {"error": "GPU match list differs from the oracle: timing not accepted"}
+        # all logical CPUs is not always fastest (SMT / cgroup limits): take the best of a few team sizes
+        best_t, threads = None, cores
+        for th in sorted({cores, max(cores // 2, 1), max(cores // 4, 1)}):
+            t1 = time.perf_counter()
+            orc.match(bgr, depth, args.threshold, 0, threads=th)
+            t = time.perf_counter() - t1
+            if best_t is None or t < best_t:
+                best_t, threads = t, th
         t0 = time.perf_counter()
         n = 0
         while True:
             b, d = frames[n % len(frames)]
-            orc.match(b, d, args.threshold, 0, threads=cores)
+            orc.match(b, d, args.threshold, 0, threads=threads)
             n += 1
-            if time.perf_counter() - t0 >= args.cpu_seconds or n >= 200:
+            if time.perf_counter() - t0 >= args.cpu_seconds or n >= 5000:
                 break
         dt = time.perf_counter() - t0
         t1 = time.perf_counter()
         orc.match(bgr, depth, args.threshold, 0, threads=1)
         single = time.perf_counter() - t1
-        return {"value": round(n / dt, 3), "unit": "detections/s", "cores": cores, "kind": "port",
-                "sample": "%d full frames (a3-a15, same bank of %d templates) in %.1f s, OpenMP over templates; "
-                          "upstream-faithful single-thread run: %.3f s/frame; GPU and CPU match lists identical" %
-                          (n, args.templates, dt, single)}
+        return {"value": round(n / dt, 3), "unit": "detections/s", "cores": threads, "kind": "port",
+                "sample": "%d full frames (a3-a15, same bank of %d templates) in %.1f s; OpenMP over templates and "
+                          "over image rows, %d threads (fastest of {1/4, 1/2, all} of %d logical CPUs); upstream-"
+                          "faithful single-thread run: %.3f s/frame; GPU and CPU match lists identical" %
+                          (n, args.templates, dt, threads, cores, single)}
     except Exception as e:  # the bench line must still be printed
         return {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -27,6 +27,11 @@
 namespace {
 
 thread_local std::string g_err;
+// Threads the image stages may use (the match stage takes its own `threads` argument).  Upstream's
+// matchClass is serial but the OpenCV imgproc primitives it calls (GaussianBlur, Sobel, pyrDown, ...)
+// are internally threaded, so the all-cores CPU baseline threads these row loops as well.
+int g_threads = 1;
+#define ORC_PAR_FOR _Pragma("omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)")
 void set_err(const std::string& s) { g_err = s; }
 
 typedef uint8_t u8;
@@ -135,6 +140,7 @@ void orc_default_normal_lut(uint8_t lut[8000]) {
 void orc_gaussian7_u8c3(const uint8_t* src, int w, int h, uint8_t* dst) {
     static const int K[7] = {8, 28, 56, 72, 56, 28, 8};
     std::vector<u16> tmp((size_t)w * h * 3);
+    ORC_PAR_FOR
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x)
             for (int c = 0; c < 3; ++c) {
@@ -142,6 +148,7 @@ void orc_gaussian7_u8c3(const uint8_t* src, int w, int h, uint8_t* dst) {
                 for (int i = 0; i < 7; ++i) s += K[i] * src[((size_t)y * w + clampi(x + i - 3, 0, w - 1)) * 3 + c];
                 tmp[((size_t)y * w + x) * 3 + c] = (u16)s;  // <= 255*256
             }
+    ORC_PAR_FOR
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x)
             for (int c = 0; c < 3; ++c) {
@@ -153,6 +160,7 @@ void orc_gaussian7_u8c3(const uint8_t* src, int w, int h, uint8_t* dst) {
 
 // a3: Sobel(smoothed, CV_16S, ksize 3, scale 1, BORDER_REPLICATE), dx and dy (A.2 step 2).
 void orc_sobel3_s16c3(const uint8_t* s, int w, int h, int16_t* dx, int16_t* dy) {
+    ORC_PAR_FOR
     for (int y = 0; y < h; ++y) {
         int ym = clampi(y - 1, 0, h - 1), yp = clampi(y + 1, 0, h - 1);
         for (int x = 0; x < w; ++x) {
@@ -218,6 +226,7 @@ void orc_color_quantize(const uint8_t* bgr, int w, int h, float weak_threshold, 
     std::vector<float> mag(n);
     std::vector<u8> q(n);
     const float scale = (float)(16.0 / 360.0);
+    ORC_PAR_FOR
     for (size_t i = 0; i < n; ++i) {
         // step 3: channel with the largest dx^2+dy^2; ties B, then G, then R (>= cascade)
         int m0 = dx[3 * i] * dx[3 * i] + dy[3 * i] * dy[3 * i];
@@ -241,6 +250,7 @@ void orc_color_quantize(const uint8_t* bgr, int w, int h, float weak_threshold, 
     // step 6: 3x3 majority vote gated by magnitude
     const float thr = weak_threshold * weak_threshold;
     std::memset(quantized, 0, n);
+    ORC_PAR_FOR
     for (int y = 1; y < h - 1; ++y)
         for (int x = 1; x < w - 1; ++x) {
             if (!(mag[(size_t)y * w + x] > thr)) continue;
@@ -259,6 +269,7 @@ void orc_color_quantize(const uint8_t* bgr, int w, int h, float weak_threshold, 
 void orc_pyrdown_u8c3(const uint8_t* src, int w, int h, uint8_t* dst) {
     static const int K[5] = {1, 4, 6, 4, 1};
     int dw = w / 2, dh = h / 2;
+    ORC_PAR_FOR
     for (int y = 0; y < dh; ++y)
         for (int x = 0; x < dw; ++x)
             for (int c = 0; c < 3; ++c) {
@@ -279,6 +290,7 @@ void orc_depth_quantize(const uint16_t* depth, int w, int h, int distance_thresh
     size_t n = (size_t)w * h;
     std::vector<u8> raw(n, 0);
     const int r = 5;
+    ORC_PAR_FOR
     for (int y = r; y < h - r - 1; ++y)
         for (int x = r; x < w - r - 1; ++x) {
             long d = depth[(size_t)y * w + x];
@@ -318,6 +330,7 @@ void orc_depth_quantize(const uint16_t* depth, int w, int h, int distance_thresh
             raw[(size_t)y * w + x] = out;
         }
     // medianBlur(dst, dst, 5): BORDER_REPLICATE
+    ORC_PAR_FOR
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
             u8 v[25];
@@ -339,14 +352,16 @@ void orc_resize_nn_half(const uint8_t* src, int w, int h, uint8_t* dst) {
 // a8: spread + orUnaligned8u: dst(y,x) = OR_{0<=r,c<T, in bounds} src(y+r, x+c).
 void orc_spread(const uint8_t* src, int w, int h, int T, uint8_t* dst) {
     std::memset(dst, 0, (size_t)w * h);
-    for (int r = 0; r < T; ++r)
-        for (int c = 0; c < T; ++c)
-            for (int y = 0; y + r < h; ++y)
+    ORC_PAR_FOR
+    for (int y = 0; y < h; ++y)   // same ORs as upstream's T*T shifted orUnaligned8u passes, regrouped per output row
+        for (int r = 0; r < T && y + r < h; ++r)
+            for (int c = 0; c < T; ++c)
                 for (int x = 0; x + c < w; ++x) dst[(size_t)y * w + x] |= src[(size_t)(y + r) * w + x + c];
 }
 
 // a9: computeResponseMaps: maps[ori][i] = max(LUT[32 ori + lo], LUT[32 ori + 16 + hi]).
 void orc_response_maps(const uint8_t* spread, int n, const uint8_t* lut, uint8_t* maps) {
+    ORC_PAR_FOR
     for (int ori = 0; ori < 8; ++ori)
         for (int i = 0; i < n; ++i) {
             u8 lo = spread[i] & 15, hi = (spread[i] & 240) >> 4;
@@ -696,7 +711,10 @@ int orc_match_prepared(orc_detector* d, float threshold, int class_idx, int tid_
 
 int orc_match_frame(orc_detector* d, const uint8_t* bgr, const uint16_t* depth, int w, int h, float threshold,
               int class_idx, int tid_lo, int tid_hi, int threads, orc_match* out, int cap) {
-    if (orc_prepare_frame(d, bgr, depth, w, h) != 0) return -1;
+    g_threads = threads > 1 ? threads : 1;
+    int rc = orc_prepare_frame(d, bgr, depth, w, h);
+    g_threads = 1;
+    if (rc != 0) return -1;
     return orc_match_prepared(d, threshold, class_idx, tid_lo, tid_hi, threads, out, cap);
 }
 

@@ -293,9 +293,18 @@ class Detector:
             return self.match_prepared(threshold, class_idx, tid_lo, tid_hi, threads, cap=n)
         return out[:n].copy()
 
-    def match(self, bgr, depth, threshold, class_idx=-1, tid_lo=0, tid_hi=INT32_MAX, threads=1):
-        self.prepare(bgr, depth)
-        return self.match_prepared(threshold, class_idx, tid_lo, tid_hi, threads)
+    def match(self, bgr, depth, threshold, class_idx=-1, tid_lo=0, tid_hi=INT32_MAX, threads=1, cap=1 << 16):
+        """Detector::match; threads > 1 also threads the image stages (orc_match_frame)."""
+        bgr = _c(bgr, np.uint8); h, w, _ = bgr.shape
+        depth = None if depth is None else _c(depth, np.uint16)
+        out = np.zeros(cap, MATCH_DTYPE)
+        n = self.lib.orc_match_frame(self.h, _ptr(bgr), _ptr(depth), w, h, threshold, class_idx, tid_lo, tid_hi,
+                                     threads, _ptr(out), cap)
+        if n < 0:
+            raise RuntimeError(self.lib.orc_last_error().decode())
+        if n > cap:
+            return self.match(bgr, depth, threshold, class_idx, tid_lo, tid_hi, threads, cap=n)
+        return out[:n].copy()
 
     def stage(self, what, level, modality):
         n = self.lib.orc_get_stage(self.h, what, level, modality, None, 0)

@@ -1,0 +1,20 @@
+import sys, time, importlib, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+from oracle import oracle as O
+synth = importlib.import_module("line-mod-pipeline_amd.synth")
+lib = O.build(arch="-march=native")
+bgr, depth = synth.make_frame(640,480,seed=1234)
+o = O.Detector(color_only=False, lib_path=lib)
+o.prepare(bgr, depth)
+q = {(l,m): o.stage(0,l,m).reshape(480>>l, 640>>l) for l in range(2) for m in range(2)}
+descs, feats, crops = synth.make_bank(3000, 2, 2, seed=4321, fixed_l0_size=(96,96), quantized=q, crop_fraction=0.1)
+o.add_class("c", descs, feats)
+print("cpus", os.cpu_count())
+for th in (1, 4, 8, 16, 32, 64, 128, 256):
+    ts=[]
+    for _ in range(3):
+        t=time.time(); m = o.match(bgr, depth, 80.0, 0, threads=th); ts.append(time.time()-t)
+    t=time.time(); o.prepare(bgr, depth); tp=time.time()-t
+    t=time.time(); o.match_prepared(80.0, 0, threads=th); tm=time.time()-t
+    print("threads %3d: full %.3f s (min of 3)   [serial prepare %.3f, match-only %.3f]  matches %d" % (th, min(ts), tp, tm, len(m)))
