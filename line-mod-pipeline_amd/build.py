@@ -13,7 +13,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "liblinemod_hip.so")
 HIP_SOURCES = ["lm_kernels.hip", "lm_detector.hip"]
 CXX_SOURCES = ["lm_host.cpp", "lm_extract.cpp"]
-HEADERS = ["lm_common.h", "lm_kernels.h", "lm_host.h", "lm_extract.h", os.path.join("..", "..", "include", "linemod_hip.h")]
+HEADERS = ["lm_common.h", "lm_kernels.h", "lm_host.h", "lm_extract.h", "lm_median25.h", os.path.join("..", "..", "include", "linemod_hip.h")]
 # -ffp-contract=off: the two float islands (fastAtan2 polynomial, normal normalisation, raw threshold)
 # must round exactly like the oracle, which is built the same way.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]

@@ -19,6 +19,7 @@
 #include <type_traits>
 #include "lm_common.h"
 #include "lm_kernels.h"
+#include "lm_median25.h"
 
 namespace {
 
@@ -244,16 +245,20 @@ __global__ __launch_bounds__(256) void k_color_quantize(const u8* __restrict__ b
 }
 
 // ------------------------------------------------------------------------------------------------
-// a5  DepthNormal::process -> quantizedNormals + medianBlur(5).  32x8 outputs per workgroup; the
+// a5  DepthNormal::process -> quantizedNormals + medianBlur(5).  64x8 outputs per workgroup; the
 // depth tile (+-7) and the raw normals (+-2) live in LDS.
 // ------------------------------------------------------------------------------------------------
-#define DT_W 32
+#define DT_W 64
 #define DT_H 8
-#define N_W (DT_W + 4)    // 36
+#define N_W (DT_W + 4)    // 68
 #define N_H (DT_H + 4)    // 12
-#define D_W (DT_W + 14)   // 46
+#define D_W (DT_W + 14)   // 78
 #define D_H (DT_H + 14)   // 22
-#define D_PITCH 48
+#define D_PITCH 80
+#define D_LOADS ((D_H * D_W + 255) / 256)
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+#define LM_CE(a, b) { us2 t_ = __builtin_elementwise_min(a, b); b = __builtin_elementwise_max(a, b); a = t_; }
 
 __global__ __launch_bounds__(256) void k_depth_quantize(const u16* __restrict__ depth0, int w, int h, int dist_thr,
                                                          int diff_thr, const u8* __restrict__ lut,
@@ -264,18 +269,18 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const u16* __restrict__ 
     u8* quant = slot_ptr(quant0, slot_stride);
     const int tid = threadIdx.x;
     const int ox = blockIdx.x * DT_W, oy = blockIdx.y * DT_H;
-    // depth tile: 22 x 46 values, 4 independent loads per thread
+    // depth tile: 22 x 78 values, independent loads first
     {
-        u16 v[4];
+        u16 v[D_LOADS];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < D_LOADS; ++k) {
             int i = tid + k * 256;
             int r = i / D_W, c = i - r * D_W;
             int gy = oy - 7 + r, gx = ox - 7 + c;
             v[k] = (i < D_H * D_W && gy >= 0 && gy < h && gx >= 0 && gx < w) ? depth[(size_t)gy * w + gx] : (u16)0;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < D_LOADS; ++k) {
             int i = tid + k * 256;
             if (i < D_H * D_W) { int r = i / D_W; dt[r][i - r * D_W] = v[k]; }
         }
@@ -326,25 +331,24 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const u16* __restrict__ 
     }
     __syncthreads();
     {
-        int ty = tid >> 5, tx = tid & 31;
-        int gy = oy + ty, gx = ox + tx;
-        if (gy < h && gx < w) {
-            u32 v[25];
+        // 5x5 median of two horizontally adjacent pixels per thread: a 132-exchange selection network
+        // (lm_median25.h) on packed 16-bit lanes (v_pk_min_u16 / v_pk_max_u16)
+        const int ty = tid >> 5, tx = (tid & 31) * 2;
+        const int gy = oy + ty, gx = ox + tx;
+        us2 v[25];
 #pragma unroll
-            for (int j = 0; j < 5; ++j)
+        for (int j = 0; j < 5; ++j) {
+            unsigned short b[6];
 #pragma unroll
-                for (int ii = 0; ii < 5; ++ii) v[j * 5 + ii] = nt[ty + j][tx + ii];
-            // median of 25 = largest t with #{v >= t} >= 13, built bit by bit
-            u32 res = 0;
+            for (int ii = 0; ii < 6; ++ii) b[ii] = nt[ty + j][tx + ii];
 #pragma unroll
-            for (int bit = 7; bit >= 0; --bit) {
-                u32 cand = res | (1u << bit);
-                int cnt = 0;
-#pragma unroll
-                for (int k = 0; k < 25; ++k) cnt += (v[k] >= cand) ? 1 : 0;
-                if (cnt >= 13) res = cand;
-            }
-            quant[(size_t)gy * w + gx] = (u8)res;
+            for (int ii = 0; ii < 5; ++ii) { us2 p; p[0] = b[ii]; p[1] = b[ii + 1]; v[j * 5 + ii] = p; }
+        }
+        LM_MEDIAN25_NETWORK(v)
+        const us2 med = v[LM_MEDIAN25_OUT];
+        if (gy < h) {
+            if (gx < w) quant[(size_t)gy * w + gx] = (u8)med[0];
+            if (gx + 1 < w) quant[(size_t)gy * w + gx + 1] = (u8)med[1];
         }
     }
 }
