@@ -60,6 +60,7 @@ struct lm_detector {
     u8* frame_arena = nullptr;
     size_t frame_stride = 0;
     size_t off_bgr[LM_MAX_LEVELS] = {}, off_depth = 0, off_quant[LM_MAX_LEVELS][2] = {}, off_lm[LM_MAX_LEVELS] = {};
+    size_t off_cscratch = 0;   // colour-quantisation scratch (hb / vs / vd / qn), sized for level 0, reused per level
     // aux arena: [slot][LmDevHeader | cand | keys | out]
     u8* aux_arena = nullptr;
     size_t aux_stride = 0;
@@ -96,6 +97,7 @@ struct lm_detector {
     u16* depth(int slot) const { return reinterpret_cast<u16*>(frame_arena + (size_t)slot * frame_stride + off_depth); }
     u8* quant(int slot, int l, int m) const { return frame_arena + (size_t)slot * frame_stride + off_quant[l][m]; }
     u8* lm(int slot, int l) const { return frame_arena + (size_t)slot * frame_stride + off_lm[l]; }
+    u8* cscratch(int slot) const { return frame_arena + (size_t)slot * frame_stride + off_cscratch; }
     u8* aux(int slot, size_t off) const { return aux_arena + (size_t)slot * aux_stride + off; }
     LmHostBlock* host_block(int slot) const { return reinterpret_cast<LmHostBlock*>(host_blocks + (size_t)slot * host_stride); }
 };
@@ -141,6 +143,7 @@ int ensure_device(lm_detector* d) {
     for (int l = 0; l < L; ++l)
         for (int m = 0; m < M; ++m) { d->off_quant[l][m] = off; off += align_up((size_t)d->lw[l] * d->lh[l], 256); }
     for (int l = 0; l < L; ++l) { d->off_lm[l] = off; off += align_up(d->geom[l].arena_bytes, 256); }
+    d->off_cscratch = off; off += align_up(lmk_color_scratch_bytes(c.width, c.height), 256);
     d->frame_stride = align_up(off, 4096);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->frame_arena), d->frame_stride * S));
     HIP_TRY(hipMemset(d->frame_arena, 0, d->frame_stride * S));  // linear-memory pads / zero blocks stay zero forever
@@ -236,7 +239,7 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
     for (int l = 0; l < L; ++l) {
         if (l > 0) lmk_pyrdown(d->stream, d->bgr(first, l - 1), d->lw[l - 1], d->lh[l - 1], d->bgr(first, l), fs, n);
         lmk_color_quantize(d->stream, d->bgr(first, l), d->lw[l], d->lh[l], c.weak_threshold, d->quant(first, l, 0),
-                           nullptr, fs, n);
+                           nullptr, d->cscratch(first), fs, n);
         if (M == 2 && l == 0)
             lmk_depth_quantize(d->stream, d->depth(first), d->lw[0], d->lh[0], c.distance_threshold,
                                c.difference_threshold, d->d_normal_lut, d->quant(first, 0, 1), fs, n);
@@ -627,7 +630,7 @@ int lm_add_template(lm_detector* d, const char* class_id, const uint8_t* bgr, si
     for (int l = 0; l < L; ++l) {
         if (l > 0) lmk_pyrdown(d->stream, d->bgr(0, l - 1), d->lw[l - 1], d->lh[l - 1], d->bgr(0, l), 0, 1);
         lmk_color_quantize(d->stream, d->bgr(0, l), d->lw[l], d->lh[l], c.weak_threshold, d->quant(0, l, 0),
-                           reinterpret_cast<float*>(scratch + mag_off[l]), 0, 1);
+                           reinterpret_cast<float*>(scratch + mag_off[l]), d->cscratch(0), 0, 1);
     }
     if (M == 2) {
         lmk_depth_quantize(d->stream, d->depth(0), d->lw[0], d->lh[0], c.distance_threshold, c.difference_threshold,
@@ -767,12 +770,13 @@ int lm_stage_color_quantize(lm_detector* d, const uint8_t* bgr, int w, int h, fl
     if ((rc = ready_for_compute(d))) return rc;
     if (!bgr || !quantized || w <= 0 || h <= 0) return fail(LM_ERR_INVALID, "bad argument");
     size_t px = (size_t)w * h;
-    size_t o_q = align_up(px * 3 + 256, 256), o_m = o_q + align_up(px, 256);
-    if ((rc = ensure_scratch(d, o_m + px * 4))) return rc;
+    size_t o_q = align_up(px * 3 + 256, 256), o_m = o_q + align_up(px, 256), o_s = o_m + align_up(px * 4, 256);
+    if ((rc = ensure_scratch(d, o_s + lmk_color_scratch_bytes(w, h)))) return rc;
     u8* base = static_cast<u8*>(d->d_scratch);
     hipStream_t st = d->stream;
     HIP_TRY(hipMemcpyAsync(base, bgr, px * 3, hipMemcpyHostToDevice, st));
-    lmk_color_quantize(st, base, w, h, weak_threshold, base + o_q, magnitude ? reinterpret_cast<float*>(base + o_m) : nullptr, 0, 1);
+    lmk_color_quantize(st, base, w, h, weak_threshold, base + o_q, magnitude ? reinterpret_cast<float*>(base + o_m) : nullptr,
+                       base + o_s, 0, 1);
     HIP_TRY(hipMemcpyAsync(quantized, base + o_q, px, hipMemcpyDeviceToHost, st));
     if (magnitude) HIP_TRY(hipMemcpyAsync(magnitude, base + o_m, px * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -9,9 +9,12 @@
 void lmk_pyrdown(hipStream_t s, const u8* src, int sw, int sh, u8* dst, size_t slot_stride, int nslots);
 // DepthNormalPyramid::pyrDown: nearest-neighbour half-size copy of a quantised image
 void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, int dh, size_t slot_stride, int nslots);
-// a3: ColorGradient quantisation of a dense w x h BGR image; mag may be null
+// a3: ColorGradient quantisation of a dense w x h BGR image; mag may be null.  `scratch` (per slot,
+// lmk_color_scratch_bytes(w, h), slot_stride apart like everything else) enables the 4-pass streaming
+// form when w % 4 == 0; without it (or for other widths) the fused LDS-tiled kernel runs.
+size_t lmk_color_scratch_bytes(int w, int h);
 void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_threshold, u8* quant, float* mag,
-                        size_t slot_stride, int nslots);
+                        u8* scratch, size_t slot_stride, int nslots);
 // a5: DepthNormal quantisation (normals + LUT + 5x5 median)
 void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_thr, int diff_thr, const u8* normal_lut,
                         u8* quant, size_t slot_stride, int nslots);

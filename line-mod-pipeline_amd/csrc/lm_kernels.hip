@@ -245,6 +245,164 @@ __global__ __launch_bounds__(256) void k_color_quantize(const u8* __restrict__ b
 }
 
 // ------------------------------------------------------------------------------------------------
+// a3, streaming form (used when w % 4 == 0; the fused LDS-tiled k_color_quantize above is the generic
+// fallback and the reference for the arithmetic).  Four simple passes through L2-resident scratch:
+//   k_cblur_h  horizontal 7-tap on the interleaved BGR byte stream: the taps of byte p are bytes
+//              p-9, p-6, ..., p+9 whatever the channel, so a thread does 4 bytes at once (SWAR on
+//              u16 pairs, v_alignbyte_b32 for the odd offsets)                 -> hb  u16 [h][3w]
+//   k_cblur_v  vertical 7-tap + rounding, fused with the vertical halves of the Sobel
+//              VS = S(y-1) + 2 S(y) + S(y+1), VD = S(y+1) - S(y-1)            -> vs, vd i16 [h][3w]
+//   k_corient  dx = VS(x+1) - VS(x-1), dy = VD(x-1) + 2 VD(x) + VD(x+1), strongest channel,
+//              fastAtan2, 16 -> 8 bins, magnitude flag                         -> qn  u8 [h][w]
+//   k_cvote    3x3 majority vote gated by the flag                             -> quant
+// Replicate borders exactly as the fused kernel: blur taps clamp, Sobel reads S at clamped coordinates.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cblur_h(const u8* __restrict__ bgr0, int w, int h, u16* __restrict__ hb0,
+                                                  size_t in_stride, size_t tmp_stride) {
+    const u8* bgr = slot_ptr(bgr0, in_stride);
+    u16* hb = slot_ptr(hb0, tmp_stride);
+    const int rowdw = (w * 3) >> 2;
+    const int d = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (d >= rowdw) return;
+    const u8* row = bgr + (size_t)y * w * 3;
+    u32 e_sum, o_sum;
+    if (d >= 3 && d + 3 < rowdw) {
+        const u32* r32 = reinterpret_cast<const u32*>(row);
+        const u32 D0 = r32[d - 3], D1 = r32[d - 2], D2 = r32[d - 1], D3 = r32[d], D4 = r32[d + 1], D5 = r32[d + 2],
+                  D6 = r32[d + 3];
+        const u32 tm9 = __builtin_amdgcn_alignbyte(D1, D0, 3u), tm6 = __builtin_amdgcn_alignbyte(D2, D1, 2u);
+        const u32 tm3 = __builtin_amdgcn_alignbyte(D3, D2, 1u), tp3 = __builtin_amdgcn_alignbyte(D4, D3, 3u);
+        const u32 tp6 = __builtin_amdgcn_alignbyte(D5, D4, 2u), tp9 = __builtin_amdgcn_alignbyte(D6, D5, 1u);
+#define LM_EV(t) ((t) & 0x00FF00FFu)
+#define LM_OD(t) (((t) >> 8) & 0x00FF00FFu)
+        e_sum = 8u * (LM_EV(tm9) + LM_EV(tp9)) + 28u * (LM_EV(tm6) + LM_EV(tp6)) + 56u * (LM_EV(tm3) + LM_EV(tp3)) + 72u * LM_EV(D3);
+        o_sum = 8u * (LM_OD(tm9) + LM_OD(tp9)) + 28u * (LM_OD(tm6) + LM_OD(tp6)) + 56u * (LM_OD(tm3) + LM_OD(tp3)) + 72u * LM_OD(D3);
+#undef LM_EV
+#undef LM_OD
+    } else {   // first / last dwords of a row: per byte, replicate-clamped taps
+        u32 r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = 4 * d + k, x = p / 3, c = p - 3 * x;
+            const int K[7] = {8, 28, 56, 72, 56, 28, 8};
+            u32 sacc = 0;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) sacc += (u32)K[i] * row[3 * clampi(x + i - 3, 0, w - 1) + c];
+            r[k] = sacc;
+        }
+        e_sum = r[0] | (r[2] << 16);
+        o_sum = r[1] | (r[3] << 16);
+    }
+    u32* o = reinterpret_cast<u32*>(hb + (size_t)y * w * 3 + 4 * d);
+    o[0] = (e_sum & 0xFFFFu) | (o_sum << 16);
+    o[1] = (e_sum >> 16) | (o_sum & 0xFFFF0000u);
+}
+
+#define CV_ROWS 8   // output rows per thread of k_cblur_v
+__global__ __launch_bounds__(256) void k_cblur_v(const u16* __restrict__ hb0, int w, int h, int16_t* __restrict__ vs0,
+                                                  int16_t* __restrict__ vd0, size_t tmp_stride) {
+    const u16* hb = slot_ptr(hb0, tmp_stride);
+    int16_t* vs = slot_ptr(vs0, tmp_stride);
+    int16_t* vd = slot_ptr(vd0, tmp_stride);
+    const int ncol = (w * 3) >> 2;                       // groups of 4 byte positions
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ncol) return;
+    const int y0 = blockIdx.y * CV_ROWS;
+    const size_t pitch = (size_t)w * 3;
+    int sm1[4] = {0, 0, 0, 0}, s0[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = -1; r <= CV_ROWS; ++r) {
+        const int sy = clampi(y0 + r, 0, h - 1);          // Sobel reads the smoothed image at clamped rows
+        u32 acc[4] = {0, 0, 0, 0};
+        const u32 K[7] = {8, 28, 56, 72, 56, 28, 8};
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const int hy = clampi(sy + t - 3, 0, h - 1);  // GaussianBlur: BORDER_REPLICATE
+            const u32* p = reinterpret_cast<const u32*>(hb + (size_t)hy * pitch + 4 * j);
+            const u32 a = p[0], b = p[1];
+            acc[0] += K[t] * (a & 0xFFFFu); acc[1] += K[t] * (a >> 16);
+            acc[2] += K[t] * (b & 0xFFFFu); acc[3] += K[t] * (b >> 16);
+        }
+        int s1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s1[k] = (int)((acc[k] + 32768u) >> 16);
+        if (r >= 1) {
+            const int y = y0 + r - 1;
+            if (y < h) {
+                u32* ovs = reinterpret_cast<u32*>(vs + (size_t)y * pitch + 4 * j);
+                u32* ovd = reinterpret_cast<u32*>(vd + (size_t)y * pitch + 4 * j);
+                int a0 = sm1[0] + 2 * s0[0] + s1[0], a1 = sm1[1] + 2 * s0[1] + s1[1];
+                int a2 = sm1[2] + 2 * s0[2] + s1[2], a3 = sm1[3] + 2 * s0[3] + s1[3];
+                int d0 = s1[0] - sm1[0], d1 = s1[1] - sm1[1], d2 = s1[2] - sm1[2], d3 = s1[3] - sm1[3];
+                ovs[0] = (u32)(a0 & 0xFFFF) | ((u32)a1 << 16);
+                ovs[1] = (u32)(a2 & 0xFFFF) | ((u32)a3 << 16);
+                ovd[0] = (u32)(d0 & 0xFFFF) | ((u32)d1 << 16);
+                ovd[1] = (u32)(d2 & 0xFFFF) | ((u32)d3 << 16);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sm1[k] = s0[k]; s0[k] = s1[k]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_corient(const int16_t* __restrict__ vs0, const int16_t* __restrict__ vd0, int w,
+                                                  int h, float thr2, u8* __restrict__ qn0, float* __restrict__ mag0,
+                                                  size_t tmp_stride, size_t mag_stride) {
+    const int16_t* vs = slot_ptr(vs0, tmp_stride);
+    const int16_t* vd = slot_ptr(vd0, tmp_stride);
+    u8* qn = slot_ptr(qn0, tmp_stride);
+    float* mag = mag0 ? slot_ptr(mag0, mag_stride) : nullptr;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int16_t* vsr = vs + (size_t)y * w * 3;
+    const int16_t* vdr = vd + (size_t)y * w * 3;
+    const int xm = (x > 0 ? x - 1 : 0) * 3, xc = x * 3, xp = (x + 1 < w ? x + 1 : w - 1) * 3;
+    int bdx = 0, bdy = 0, bm = -1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int dx = (int)vsr[xp + c] - (int)vsr[xm + c];
+        int dy = (int)vdr[xm + c] + 2 * (int)vdr[xc + c] + (int)vdr[xp + c];
+        int m = dx * dx + dy * dy;
+        if (m > bm) { bm = m; bdx = dx; bdy = dy; }   // first maximum wins ties = upstream's >= cascade
+    }
+    const float scale = (float)(16.0 / 360.0);
+    float ang = fast_atan2_deg((float)bdy, (float)bdx);
+    float qf = rintf(__fadd_rn(__fmul_rn(ang, scale), 0.0f));
+    int q = (int)qf;
+    q = q < 0 ? 0 : (q > 255 ? 255 : q);
+    const bool border = (y == 0) | (y == h - 1) | (x == 0) | (x == w - 1);
+    u8 out = border ? 0 : (u8)(q & 7);
+    const float fm = (float)bm;
+    if (fm > thr2) out |= 0x80;
+    qn[(size_t)y * w + x] = out;
+    if (mag) mag[(size_t)y * w + x] = fm;
+}
+
+__global__ __launch_bounds__(256) void k_cvote(const u8* __restrict__ qn0, int w, int h, u8* __restrict__ quant0,
+                                                size_t tmp_stride, size_t out_stride) {
+    const u8* qn = slot_ptr(qn0, tmp_stride);
+    u8* quant = slot_ptr(quant0, out_stride);
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    u8 res = 0;
+    if (y >= 1 && y <= h - 2 && x >= 1 && x <= w - 2 && (qn[(size_t)y * w + x] & 0x80)) {
+        u32 cnt = 0;  // eight 4-bit counters
+#pragma unroll
+        for (int j = -1; j <= 1; ++j)
+#pragma unroll
+            for (int i = -1; i <= 1; ++i) cnt += 1u << (4 * (qn[(size_t)(y + j) * w + x + i] & 7));
+        int best = 0, idx = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            int v = (cnt >> (4 * b)) & 15;
+            if (best < v) { best = v; idx = b; }
+        }
+        if (best >= 5) res = (u8)(1u << idx);
+    }
+    quant[(size_t)y * w + x] = res;
+}
+
+// ------------------------------------------------------------------------------------------------
 // a5  DepthNormal::process -> quantizedNormals + medianBlur(5).  64x8 outputs per workgroup; the
 // depth tile (+-7) and the raw normals (+-2) live in LDS.
 // ------------------------------------------------------------------------------------------------
@@ -947,11 +1105,30 @@ void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, i
     hipLaunchKernelGGL(k_nn_half, grid, dim3(256), 0, s, src, src_pitch, dst, dw, dh, slot_stride);
 }
 
+size_t lmk_color_scratch_bytes(int w, int h) {
+    // hb u16 [h][3w] | vs i16 [h][3w] | vd i16 [h][3w] | qn u8 [h][w], each 256-B aligned
+    size_t px = (size_t)w * h;
+    return 3 * ((px * 6 + 255) / 256 * 256) + (px + 255) / 256 * 256;
+}
+
 void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_threshold, u8* quant, float* mag,
-                        size_t slot_stride, int nslots) {
+                        u8* scratch, size_t slot_stride, int nslots) {
+    const float thr2 = weak_threshold * weak_threshold;
+    if (scratch && (w % 4) == 0 && ((uintptr_t)bgr & 3) == 0 && (slot_stride % 4) == 0) {
+        const size_t px = (size_t)w * h, a6 = (px * 6 + 255) / 256 * 256;
+        u16* hb = reinterpret_cast<u16*>(scratch);
+        int16_t* vs = reinterpret_cast<int16_t*>(scratch + a6);
+        int16_t* vd = reinterpret_cast<int16_t*>(scratch + 2 * a6);
+        u8* qn = scratch + 3 * a6;
+        const int rowdw = (w * 3) / 4;
+        hipLaunchKernelGGL(k_cblur_h, dim3((rowdw + 255) / 256, h, nslots), dim3(256), 0, s, bgr, w, h, hb, slot_stride, slot_stride);
+        hipLaunchKernelGGL(k_cblur_v, dim3((rowdw + 255) / 256, (h + CV_ROWS - 1) / CV_ROWS, nslots), dim3(256), 0, s, hb, w, h, vs, vd, slot_stride);
+        hipLaunchKernelGGL(k_corient, dim3((w + 255) / 256, h, nslots), dim3(256), 0, s, vs, vd, w, h, thr2, qn, mag, slot_stride, slot_stride);
+        hipLaunchKernelGGL(k_cvote, dim3((w + 255) / 256, h, nslots), dim3(256), 0, s, qn, w, h, quant, slot_stride, slot_stride);
+        return;
+    }
     dim3 grid((w + CT_W - 1) / CT_W, (h + CT_H - 1) / CT_H, nslots);
-    hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, w, h, weak_threshold * weak_threshold, quant, mag,
-                       slot_stride);
+    hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, w, h, thr2, quant, mag, slot_stride);
 }
 
 void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_thr, int diff_thr, const u8* lut,
