@@ -2,7 +2,11 @@
 #include "HighLevelLinemod.h"
 
 #include <cstdio>
+#include <cstring>
+#include <fstream>
 #include <stdexcept>
+
+#include "PostProcess.h"
 
 namespace lmamd {
 
@@ -10,16 +14,27 @@ HighLevelLineMOD::HighLevelLineMOD(CameraParameters const& cam, TemplateGenerati
     : onlyColorModality(ts.onlyUseColorModality),
       videoWidth(cam.videoWidth),
       videoHeight(cam.videoHeight),
-      detectorThreshold(ts.detectorThreshold) {
+      fy(cam.fy),
+      settings(ts),
+      detectorThreshold(ts.detectorThreshold),
+      templates(new std::vector<TemplatePose>()),
+      modelTemplates(new std::vector<std::vector<TemplatePose>>()),
+      modProps(new std::vector<ModelProperties>()) {
     lm_config cfg;
     lm_default_config(&cfg, onlyColorModality ? 1 : 0, videoWidth, videoHeight);  // T = {2,8} / {5,8}
     cfg.device = ts.device;
     cfg.shard_rank = ts.shardRank;
     cfg.shard_size = ts.shardSize;
-    if (lm_create(&cfg, &detector) != LM_OK) throw std::runtime_error(lm_last_error());
+    if (lm_create(&cfg, &detector) != LM_OK) {
+        delete templates; delete modelTemplates; delete modProps;
+        throw std::runtime_error(lm_last_error());
+    }
 }
 
-HighLevelLineMOD::~HighLevelLineMOD() { lm_destroy(detector); }  // detector.release(), :50
+HighLevelLineMOD::~HighLevelLineMOD() {
+    lm_destroy(detector);  // detector.release(), :50
+    delete templates; delete modelTemplates; delete modProps;
+}
 
 std::vector<std::string> HighLevelLineMOD::getClassIds() {
     std::vector<std::string> ids;
@@ -34,54 +49,150 @@ bool HighLevelLineMOD::detectTemplate(std::vector<Image>& in_imgs, uint16_t in_c
     matches.clear();
     if (in_imgs.empty()) { error = "no images"; return false; }
     const Image& color = in_imgs[0];
+    const Image* depth_img = in_imgs.size() >= 2 ? &in_imgs[1] : nullptr;
     // a colour-only detector pops the depth image before match() and pushes it back afterwards (:146-156)
-    const Image* depth = (!onlyColorModality && in_imgs.size() >= 2) ? &in_imgs[1] : nullptr;
+    const Image* match_depth = onlyColorModality ? nullptr : depth_img;
     if (color.width != videoWidth || color.height != videoHeight) { error = "frame size differs from the detector's"; return false; }
     size_t cap = 4096, n = 0;
     for (;;) {
         matches.resize(cap);
         int rc = lm_match(detector, static_cast<const uint8_t*>(color.data), color.stride,
-                          depth ? static_cast<const uint16_t*>(depth->data) : nullptr, depth ? depth->stride : 0,
-                          detectorThreshold, in_classNumber, matches.data(), cap, &n);
+                          match_depth ? static_cast<const uint16_t*>(match_depth->data) : nullptr,
+                          match_depth ? match_depth->stride : 0, detectorThreshold, in_classNumber, matches.data(), cap, &n);
         if (rc == LM_ERR_OVERFLOW && n > cap) { cap = n; continue; }  // the reference consumes ALL matches
         if (rc != LM_OK) { error = lm_last_error(); matches.clear(); return false; }
         break;
     }
     matches.resize(n);
-    return !matches.empty();  // :157,187-189
+    if (matches.empty()) return false;  // :157,187-189
+    // :157-175 post-processing, when this class has template poses (built by addTemplate or read back)
+    if (in_classNumber < modelTemplates->size() && !(*modelTemplates)[in_classNumber].empty()) {
+        PostProcessSettings ps;
+        ps.onlyColorModality = onlyColorModality;
+        ps.videoWidth = videoWidth; ps.videoHeight = videoHeight; ps.fy = fy;
+        ps.stepSize = settings.stepSize; ps.percentToPassCheck = settings.percentToPassCheck;
+        ps.numberWantedPoses = settings.numberWantedPoses;
+        ps.radiusThresholdNewObject = settings.radiusThresholdNewObject;
+        ps.discardGroupRatio = settings.discardGroupRatio;
+        ps.useDepthImprovement = settings.useDepthImprovement; ps.depthOffset = settings.depthOffset;
+        ModelProperties props;
+        if (in_classNumber < modProps->size()) props = (*modProps)[in_classNumber];
+        PostProcessor pp(detector, ps);
+        posesMultipleObj = pp.run(matches, static_cast<const uint8_t*>(color.data), color.stride,
+                                  depth_img ? static_cast<const uint16_t*>(depth_img->data) : nullptr,
+                                  depth_img ? depth_img->stride : 0, (*modelTemplates)[in_classNumber], props);
+    }
+    return true;
 }
 
 void HighLevelLineMOD::writeLinemod() {
     if (lm_save_bank(detector, "linemod_templates.lmbk") != LM_OK) { error = lm_last_error(); std::printf("ERROR::%s\n", error.c_str()); }
-}
-void HighLevelLineMOD::readLinemod() {
-    if (lm_load_bank(detector, "linemod_templates.lmbk") != LM_OK) { error = lm_last_error(); std::printf("ERROR::%s\n", error.c_str()); }
+    // linemod_tempPosFile.bin: u32 nClasses; per class {u64 n; n raw Template records}  (:272-284)
+    std::ofstream f("linemod_tempPosFile.bin", std::ios::binary | std::ios::out);
+    uint32_t nvec = (uint32_t)modelTemplates->size();
+    f.write(reinterpret_cast<const char*>(&nvec), sizeof(nvec));
+    for (const auto& v : *modelTemplates) {
+        uint64_t n = v.size();
+        f.write(reinterpret_cast<const char*>(&n), sizeof(n));
+        f.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(n * sizeof(TemplatePose)));
+    }
 }
 
-bool HighLevelLineMOD::addTemplate(std::vector<Image>& in_images, const std::string& in_modelName, Vec3) {
+void HighLevelLineMOD::readLinemod() {
+    templates->clear();
+    modelTemplates->clear();
+    if (lm_load_bank(detector, "linemod_templates.lmbk") != LM_OK) { error = lm_last_error(); std::printf("ERROR::%s\n", error.c_str()); }
+    std::ifstream f("linemod_tempPosFile.bin", std::ios::in | std::ios::binary);
+    uint32_t nvec = 0;
+    if (f && f.read(reinterpret_cast<char*>(&nvec), sizeof(nvec))) {
+        for (uint32_t c = 0; c < nvec; ++c) {
+            uint64_t n = 0;
+            if (!f.read(reinterpret_cast<char*>(&n), sizeof(n)) || n > (1ull << 28)) break;
+            std::vector<TemplatePose> v((size_t)n);
+            if (n && !f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(n * sizeof(TemplatePose)))) break;
+            modelTemplates->push_back(std::move(v));
+        }
+    }
+    readColorRanges();
+}
+
+// models/<class id minus ".ply">.yml : "lower color range: [ h, s, v, 0 ]", "upper color range: [...]" (:523-543)
+void HighLevelLineMOD::readColorRanges() {
+    modProps->clear();
+    for (const std::string& id : getClassIds()) {
+        ModelProperties p;
+        std::string stem = id.size() > 4 ? id.substr(0, id.size() - 4) : id;
+        std::ifstream f(settings.modelFolder + stem + ".yml");
+        std::string line;
+        while (f && std::getline(f, line)) {
+            double* dst = nullptr;
+            if (line.rfind("lower color range:", 0) == 0) dst = p.lowerColorRange;
+            else if (line.rfind("upper color range:", 0) == 0) dst = p.upperColorRange;
+            if (!dst) continue;
+            size_t b = line.find('[');
+            if (b == std::string::npos) continue;
+            std::sscanf(line.c_str() + b + 1, " %lf , %lf , %lf", &dst[0], &dst[1], &dst[2]);
+        }
+        modProps->push_back(p);
+    }
+}
+
+void HighLevelLineMOD::setColorRange(uint16_t classNumber, const double lo[3], const double hi[3]) {
+    if (modProps->size() <= classNumber) modProps->resize((size_t)classNumber + 1);
+    for (int k = 0; k < 3; ++k) { (*modProps)[classNumber].lowerColorRange[k] = lo[k]; (*modProps)[classNumber].upperColorRange[k] = hi[k]; }
+}
+
+bool HighLevelLineMOD::addTemplate(std::vector<Image>& in_images, const std::string& in_modelName, Vec3 in_cameraPosition) {
     if (in_images.size() < 2) { error = "addTemplate needs {colour, depth}"; return false; }
     const Image& color = in_images[0];
     const Image& depth = in_images[1];
-    // mask = depth > 0 (threshold(in_images[1], mask, 1, 65535, THRESH_BINARY), :78-79; depth 1 mm counts as background)
-    std::vector<uint8_t> mask((size_t)depth.width * depth.height);
-    size_t dstride = depth.stride ? depth.stride : (size_t)depth.width * 2;
-    for (int y = 0; y < depth.height; ++y) {
-        const uint16_t* row = reinterpret_cast<const uint16_t*>(static_cast<const uint8_t*>(depth.data) + y * dstride);
-        for (int x = 0; x < depth.width; ++x) mask[(size_t)y * depth.width + x] = row[x] > 1 ? 255 : 0;
+    const int w = depth.width, h = depth.height;
+    // mask = depth > 1 (threshold(in_images[1], mask, 1, 65535, THRESH_BINARY) then 8-bit, :78-79),
+    // eroded once (3x3, border does not erode) like :91
+    std::vector<uint16_t> dense((size_t)w * h);
+    size_t dstride = depth.stride ? depth.stride : (size_t)w * 2;
+    for (int y = 0; y < h; ++y) std::memcpy(&dense[(size_t)y * w], static_cast<const uint8_t*>(depth.data) + y * dstride, (size_t)w * 2);
+    std::vector<uint8_t> mask((size_t)w * h), er((size_t)w * h);
+    for (size_t i = 0; i < mask.size(); ++i) mask[i] = dense[i] > 1 ? 255 : 0;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            uint8_t v = 255;
+            for (int j = -1; j <= 1; ++j)
+                for (int i = -1; i <= 1; ++i) {
+                    int yy = y + j, xx = x + i;
+                    if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;   // morphologyDefaultBorderValue: ignored
+                    v = std::min(v, mask[(size_t)yy * w + xx]);
+                }
+            er[(size_t)y * w + x] = v;
+        }
+    // the reference feeds the colour image thresholded to binary (:77); the renderer's object is white-on-black
+    std::vector<uint8_t> bin((size_t)w * h * 3);
+    size_t cstride = color.stride ? color.stride : (size_t)w * 3;
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* row = static_cast<const uint8_t*>(color.data) + y * cstride;
+        for (int x = 0; x < w * 3; ++x) bin[(size_t)y * w * 3 + x] = row[x] > 1 ? 255 : 0;
     }
     int tid = -1;
     lm_rect bb;
-    int rc = lm_add_template(detector, in_modelName.c_str(), static_cast<const uint8_t*>(color.data), color.stride,
-                             onlyColorModality ? nullptr : static_cast<const uint16_t*>(depth.data), depth.stride,
-                             mask.data(), 0, &tid, &bb);
+    int rc = lm_add_template(detector, in_modelName.c_str(), bin.data(), 0, onlyColorModality ? nullptr : dense.data(), 0,
+                             er.data(), 0, &tid, &bb);
     if (rc != LM_OK || tid < 0) {
         error = lm_last_error();
         std::printf("ERROR::Cant create Template\n");  // :99
         return false;
     }
+    TemplatePose tp;
+    std::memset(&tp, 0, sizeof(tp));
+    tp.bb[0] = bb.x; tp.bb[1] = bb.y; tp.bb[2] = bb.width; tp.bb[3] = bb.height;
+    tp.medianDepth = median_mat(dense.data(), w, h, Rect{bb.x, bb.y, bb.width, bb.height}, 5);   // :104
+    calculate_template_pose(in_cameraPosition, 0, tp.translation, tp.quat_xyzw);                   // :105-106 with angle 0
+    templates->push_back(tp);                                                                       // :107
     return true;
 }
 
-void HighLevelLineMOD::pushBackTemplates() {}  // per-template poses belong to post-processing (8f-1)
+void HighLevelLineMOD::pushBackTemplates() {   // :517-521
+    modelTemplates->push_back(*templates);
+    templates->clear();
+}
 
 }  // namespace lmamd

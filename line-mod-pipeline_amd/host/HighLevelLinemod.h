@@ -7,10 +7,10 @@
 //     cv::Ptr<cv::linemod::Detector> detector;   (HighLevelLinemod.h:102)
 // this class holds an lm_detector* and every call that crossed that seam goes through liblinemod_hip.so.
 //
-// Round-1 scope: the hot path behind detectTemplate (Detector::match) and the
-// detector queries.  The host glue around it that section 8f lists as "next" -- in-plane-rotated
-// template generation (f3), match post-processing into ObjectPose (f1), OpenCV YAML persistence (f2) --
-// is declared here with the reference's signatures and marked where it is not built yet.
+// Scope: the hot path behind detectTemplate (Detector::match, GPU), the detector
+// queries, and the host glue of 8f-1 (match post-processing into ObjectPose, PostProcess.{h,cpp}).
+// Still "next": the in-plane rotation sweep of addTemplate (8f-3: needs cv::warpAffine's fixed-point
+// bilinear resampling) and OpenCV's YAML template file (8f-2).
 #pragma once
 #include <cstdint>
 #include <string>
@@ -47,7 +47,7 @@ struct CameraParameters {
 
 // defines.h:59-83 (the fields HighLevelLineMOD's constructor copies, HighLevelLinemod.cpp:5-24)
 struct TemplateGenerationSettings {
-    std::string modelFolder;
+    std::string modelFolder = "models/";
     bool onlyUseColorModality = false;
     uint16_t stepSize = 50;
     int16_t angleStart = -45, angleStop = 45, angleStep = 10;
@@ -63,6 +63,9 @@ struct TemplateGenerationSettings {
     int shardSize = 1;
 };
 
+struct TemplatePose;       // PostProcess.h
+struct ModelProperties;    // PostProcess.h
+
 class HighLevelLineMOD {
 public:
     // HighLevelLinemod.cpp:3-46: {ColorGradient, DepthNormal} with T={5,8}, or {ColorGradient} with T={2,8}
@@ -76,26 +79,28 @@ public:
     uint32_t getNumTemplates();               // :63-66
 
     // :138-190.  in_imgs = {colour} or {colour, depth}; a colour-only detector ignores the depth image for
-    // matching exactly like the reference (:146-151).  Returns true iff the raw match list is non-empty.
+    // matching exactly like the reference (:146-151) but still uses it for the depth check (:394-399).
+    // Runs the match on the GPU, then the reference's post-processing (grouping, colour / depth checks,
+    // poses) when template poses are known for the class.  Returns true iff the raw match list is non-empty.
     bool detectTemplate(std::vector<Image>& in_imgs, uint16_t in_classNumber);
 
-    // The raw, sorted, unique match list of the last detectTemplate (the reference keeps it in the private
-    // member `matches`, HighLevelLinemod.h:166, and feeds it to its post-processing).
+    // The raw, sorted, unique match list of the last detectTemplate (the reference's private `matches`).
     const std::vector<lm_match_t>& getMatches() const { return matches; }
+    std::vector<std::vector<ObjectPose>> getObjectPoses() { return posesMultipleObj; }   // :322-325
 
-    // :256-320.  Template bank in this library's own format next to the reference's file names:
-    // "linemod_templates.lmbk" (the OpenCV YAML reader/writer is section 8f-2, next).
+    // :256-320.  Template bank in this library's own format ("linemod_templates.lmbk"; OpenCV's YAML is
+    // 8f-2, next) plus the reference's own raw pose file "linemod_tempPosFile.bin" (:272-284, :302-318).
     void writeLinemod();
     void readLinemod();
 
     // :68-110.  One template per call from a rendered colour+depth pair, WITHOUT the in-plane rotation
-    // sweep (warpAffine glue is section 8f-3, next): equivalent to the reference with
-    // angleStart == angleStop == 0.  Returns false when extraction fails (upstream -1).
+    // sweep (8f-3, next): equivalent to the reference with angleStart == angleStop == 0.  Computes the
+    // template pose and median depth like the reference (:102-107).  false when extraction fails.
     bool addTemplate(std::vector<Image>& in_images, const std::string& in_modelName, Vec3 in_cameraPosition);
     void pushBackTemplates();                 // :517-521
 
-    // :322-325.  Match post-processing into poses is section 8f-1 (next): empty until then.
-    std::vector<std::vector<ObjectPose>> getObjectPoses() { return posesMultipleObj; }
+    // readColorRanges (:523-543) reads models/<name>.yml; this sets the same data directly.
+    void setColorRange(uint16_t classNumber, const double lowerHSV[3], const double upperHSV[3]);
 
     lm_detector* handle() { return detector; }
     const std::string& lastError() const { return error; }
@@ -104,10 +109,16 @@ private:
     lm_detector* detector = nullptr;
     bool onlyColorModality;
     uint16_t videoWidth, videoHeight;
+    float fy;
+    TemplateGenerationSettings settings;
     float detectorThreshold;
     std::vector<lm_match_t> matches;
     std::vector<std::vector<ObjectPose>> posesMultipleObj;
+    std::vector<TemplatePose>* templates;                     // current class being generated (:164 `templates`)
+    std::vector<std::vector<TemplatePose>>* modelTemplates;   // :165
+    std::vector<ModelProperties>* modProps;                   // :169
     std::string error;
+    void readColorRanges();
 };
 
 }  // namespace lmamd

@@ -1,0 +1,379 @@
+// PostProcess.cpp -- see PostProcess.h.  Restates the reference's match post-processing
+// (/root/reference/src/HighLevelLinemod.cpp) and the pieces of OpenCV / GLM it leans on.
+#include "PostProcess.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+
+namespace lmamd {
+
+// ==================================================================================================
+// mini GLM (column-major m[col][row], right-handed)
+// ==================================================================================================
+Vec3 cross(const Vec3& a, const Vec3& b) { return Vec3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+float length(const Vec3& v) { return std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z); }
+static float dot(const Vec3& a, const Vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+Vec3 normalize(const Vec3& v) {
+    float inv = 1.0f / std::sqrt(dot(v, v));   // glm: v * inversesqrt(dot(v, v))
+    return Vec3{v.x * inv, v.y * inv, v.z * inv};
+}
+
+Mat4 lookAt(const Vec3& eye, const Vec3& center, const Vec3& up) {   // glm::lookAtRH
+    Vec3 f = normalize(Vec3{center.x - eye.x, center.y - eye.y, center.z - eye.z});
+    Vec3 s = normalize(cross(f, up));
+    Vec3 u = cross(s, f);
+    Mat4 r;
+    std::memset(&r, 0, sizeof(r));
+    r.m[0][0] = s.x; r.m[1][0] = s.y; r.m[2][0] = s.z;
+    r.m[0][1] = u.x; r.m[1][1] = u.y; r.m[2][1] = u.z;
+    r.m[0][2] = -f.x; r.m[1][2] = -f.y; r.m[2][2] = -f.z;
+    r.m[3][0] = -dot(s, eye); r.m[3][1] = -dot(u, eye); r.m[3][2] = dot(f, eye);
+    r.m[3][3] = 1.0f;
+    return r;
+}
+
+Mat4 mul(const Mat4& a, const Mat4& b) {   // (a * b)[c][r] = sum_k a[k][r] * b[c][k]
+    Mat4 o;
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) {
+            float s = 0;
+            for (int k = 0; k < 4; ++k) s += a.m[k][r] * b.m[c][k];
+            o.m[c][r] = s;
+        }
+    return o;
+}
+
+Mat4 transpose(const Mat4& a) {
+    Mat4 o;
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) o.m[c][r] = a.m[r][c];
+    return o;
+}
+
+Mat4 toMat4(const Quat& q) {   // glm::mat4_cast
+    Mat4 r;
+    std::memset(&r, 0, sizeof(r));
+    float qxx = q.x * q.x, qyy = q.y * q.y, qzz = q.z * q.z, qxz = q.x * q.z, qxy = q.x * q.y, qyz = q.y * q.z;
+    float qwx = q.w * q.x, qwy = q.w * q.y, qwz = q.w * q.z;
+    r.m[0][0] = 1 - 2 * (qyy + qzz); r.m[0][1] = 2 * (qxy + qwz); r.m[0][2] = 2 * (qxz - qwy);
+    r.m[1][0] = 2 * (qxy - qwz); r.m[1][1] = 1 - 2 * (qxx + qzz); r.m[1][2] = 2 * (qyz + qwx);
+    r.m[2][0] = 2 * (qxz + qwy); r.m[2][1] = 2 * (qyz - qwx); r.m[2][2] = 1 - 2 * (qxx + qyy);
+    r.m[3][3] = 1.0f;
+    return r;
+}
+
+Quat toQuat(const Mat4& m4) {   // glm::quat_cast(mat3(m))
+    const float (*m)[4] = m4.m;
+    float fourX = m[0][0] - m[1][1] - m[2][2], fourY = m[1][1] - m[0][0] - m[2][2];
+    float fourZ = m[2][2] - m[0][0] - m[1][1], fourW = m[0][0] + m[1][1] + m[2][2];
+    int biggest = 0;
+    float big = fourW;
+    if (fourX > big) { big = fourX; biggest = 1; }
+    if (fourY > big) { big = fourY; biggest = 2; }
+    if (fourZ > big) { big = fourZ; biggest = 3; }
+    float bv = std::sqrt(big + 1.0f) * 0.5f, mult = 0.25f / bv;
+    Quat q;
+    switch (biggest) {
+        case 0: q.w = bv; q.x = (m[1][2] - m[2][1]) * mult; q.y = (m[2][0] - m[0][2]) * mult; q.z = (m[0][1] - m[1][0]) * mult; break;
+        case 1: q.x = bv; q.w = (m[1][2] - m[2][1]) * mult; q.y = (m[0][1] + m[1][0]) * mult; q.z = (m[2][0] + m[0][2]) * mult; break;
+        case 2: q.y = bv; q.w = (m[2][0] - m[0][2]) * mult; q.x = (m[0][1] + m[1][0]) * mult; q.z = (m[1][2] + m[2][1]) * mult; break;
+        default: q.z = bv; q.w = (m[0][1] - m[1][0]) * mult; q.x = (m[2][0] + m[0][2]) * mult; q.y = (m[1][2] + m[2][1]) * mult; break;
+    }
+    return q;
+}
+
+Vec3 rotate(const Vec3& v, float angle, const Vec3& normal) {   // glm::rotate(v, angle, normal): mat3(rotate(angle, normal)) * v
+    float c = std::cos(angle), s = std::sin(angle);
+    Vec3 a = normalize(normal);
+    Vec3 t{(1 - c) * a.x, (1 - c) * a.y, (1 - c) * a.z};
+    float R[3][3];   // [col][row]
+    R[0][0] = c + t.x * a.x; R[0][1] = t.x * a.y + s * a.z; R[0][2] = t.x * a.z - s * a.y;
+    R[1][0] = t.y * a.x - s * a.z; R[1][1] = c + t.y * a.y; R[1][2] = t.y * a.z + s * a.x;
+    R[2][0] = t.z * a.x + s * a.y; R[2][1] = t.z * a.y - s * a.x; R[2][2] = c + t.z * a.z;
+    return Vec3{R[0][0] * v.x + R[1][0] * v.y + R[2][0] * v.z, R[0][1] * v.x + R[1][1] * v.y + R[2][1] * v.z,
+                R[0][2] * v.x + R[1][2] * v.y + R[2][2] * v.z};
+}
+
+// ==================================================================================================
+// image helpers
+// ==================================================================================================
+// cv::cvtColor(COLOR_BGR2HSV) for CV_8U (RGB2HSV_b: 12-bit fixed-point division tables, H in [0,180))
+// followed by cv::inRange with scalar bounds (HighLevelLinemod.cpp:159-161).
+void bgr2hsv_inrange(const uint8_t* bgr, int w, int h, size_t stride, const double lower[3], const double upper[3],
+                     std::vector<uint8_t>& mask) {
+    static int sdiv[256], hdiv[256];
+    static bool init = false;
+    const int shift = 12;
+    if (!init) {
+        sdiv[0] = hdiv[0] = 0;
+        for (int i = 1; i < 256; ++i) {
+            sdiv[i] = (int)std::lrint((255 << shift) / (1.0 * i));
+            hdiv[i] = (int)std::lrint((180 << shift) / (6.0 * i));
+        }
+        init = true;
+    }
+    int lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) { lo[k] = (int)std::lrint(lower[k]); hi[k] = (int)std::lrint(upper[k]); }
+    if (stride == 0) stride = (size_t)w * 3;
+    mask.assign((size_t)w * h, 0);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* p = bgr + y * stride;
+        for (int x = 0; x < w; ++x, p += 3) {
+            int b = p[0], g = p[1], r = p[2];
+            int v = std::max(b, std::max(g, r)), vmin = std::min(b, std::min(g, r));
+            int diff = v - vmin;
+            int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+            int s = (diff * sdiv[v] + (1 << (shift - 1))) >> shift;
+            int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+            hh = (hh * hdiv[diff] + (1 << (shift - 1))) >> shift;
+            hh += hh < 0 ? 180 : 0;
+            int H = hh < 0 ? 0 : (hh > 255 ? 255 : hh);
+            bool in = H >= lo[0] && H <= hi[0] && s >= lo[1] && s <= hi[1] && v >= lo[2] && v <= hi[2];
+            mask[(size_t)y * w + x] = in ? 255 : 0;
+        }
+    }
+}
+
+void translate_u8c3(const uint8_t* src, int w, int h, int ox, int oy, std::vector<uint8_t>& dst) {
+    dst.assign((size_t)w * h * 3, 0);
+    for (int y = 0; y < h; ++y) {
+        int sy = y - oy;
+        if (sy < 0 || sy >= h) continue;
+        for (int x = 0; x < w; ++x) {
+            int sx = x - ox;
+            if (sx < 0 || sx >= w) continue;
+            std::memcpy(&dst[((size_t)y * w + x) * 3], &src[((size_t)sy * w + sx) * 3], 3);
+        }
+    }
+}
+void translate_u16(const uint16_t* src, int w, int h, int ox, int oy, std::vector<uint16_t>& dst) {
+    dst.assign((size_t)w * h, 0);
+    for (int y = 0; y < h; ++y) {
+        int sy = y - oy;
+        if (sy < 0 || sy >= h) continue;
+        for (int x = 0; x < w; ++x) {
+            int sx = x - ox;
+            if (sx >= 0 && sx < w) dst[(size_t)y * w + x] = src[(size_t)sy * w + sx];
+        }
+    }
+}
+
+// medianMat (:336-349).  NOTE the reference's quirk, kept on purpose: it partitions at n/4 but returns
+// element n/position (position = 5), i.e. some element of the lower quarter in whatever order
+// std::nth_element left it.  Using the same std::nth_element on the same row-major data reproduces
+// it when built against the same standard library.
+uint16_t median_mat(const uint16_t* depth, int w, int h, Rect bb, uint8_t position) {
+    int x0 = std::max(bb.x, 0), y0 = std::max(bb.y, 0);
+    int x1 = std::min(bb.x + bb.width, w), y1 = std::min(bb.y + bb.height, h);   // cv::Mat ROI would assert; we clip
+    std::vector<uint16_t> v;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            uint16_t d = depth[(size_t)y * w + x];
+            v.push_back(d > 1 ? d : (uint16_t)65535);   // threshold(.., 1, 65535) inverted and added with saturation
+        }
+    if (v.empty() || position == 0) return 65535;
+    std::nth_element(v.begin(), v.begin() + v.size() / 4, v.end());
+    return v[v.size() / position];
+}
+
+std::vector<Pt> convex_hull(std::vector<Pt> p) {   // Andrew's monotone chain, counter-clockwise, collinear points dropped
+    std::sort(p.begin(), p.end(), [](const Pt& a, const Pt& b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
+    p.erase(std::unique(p.begin(), p.end(), [](const Pt& a, const Pt& b) { return a.x == b.x && a.y == b.y; }), p.end());
+    if (p.size() < 3) return p;
+    auto crs = [](const Pt& o, const Pt& a, const Pt& b) { return (long long)(a.x - o.x) * (b.y - o.y) - (long long)(a.y - o.y) * (b.x - o.x); };
+    std::vector<Pt> hull(2 * p.size());
+    size_t k = 0;
+    for (size_t i = 0; i < p.size(); ++i) {
+        while (k >= 2 && crs(hull[k - 2], hull[k - 1], p[i]) <= 0) --k;
+        hull[k++] = p[i];
+    }
+    for (size_t i = p.size() - 1, t = k + 1; i > 0; --i) {
+        while (k >= t && crs(hull[k - 2], hull[k - 1], p[i - 1]) <= 0) --k;
+        hull[k++] = p[i - 1];
+    }
+    hull.resize(k - 1);
+    return hull;
+}
+
+// templateMask (:113-135) = fillPoly of the hull into a full-frame mask; colorCheck then counts the
+// mask and mask & colour.  Here: the closed polygon (scanline interior + 8-connected boundary lines, as
+// fillPoly draws both) rasterised into the hull's bounding box only.
+void hull_counts(const std::vector<Pt>& hull, const uint8_t* color_mask, int w, int h, long* in_hull, long* in_both) {
+    *in_hull = 0; *in_both = 0;
+    if (hull.empty()) return;
+    int x0 = INT_MAX, y0 = INT_MAX, x1 = INT_MIN, y1 = INT_MIN;
+    for (const Pt& p : hull) { x0 = std::min(x0, p.x); y0 = std::min(y0, p.y); x1 = std::max(x1, p.x); y1 = std::max(y1, p.y); }
+    const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+    std::vector<uint8_t> m((size_t)bw * bh, 0);
+    auto set = [&](int x, int y) { m[(size_t)(y - y0) * bw + (x - x0)] = 1; };
+    const size_t n = hull.size();
+    for (int y = y0; y <= y1; ++y) {   // interior: exact intersection of the row with the convex polygon
+        double lo = 1e300, hi = -1e300;
+        for (size_t i = 0; i < n; ++i) {
+            const Pt& a = hull[i];
+            const Pt& b = hull[(i + 1) % n];
+            if (a.y == b.y) { if (a.y == y) { lo = std::min(lo, (double)std::min(a.x, b.x)); hi = std::max(hi, (double)std::max(a.x, b.x)); } continue; }
+            if (y < std::min(a.y, b.y) || y > std::max(a.y, b.y)) continue;
+            double x = a.x + (double)(y - a.y) * (b.x - a.x) / (double)(b.y - a.y);
+            lo = std::min(lo, x); hi = std::max(hi, x);
+        }
+        if (n == 1) { lo = hi = hull[0].x; }
+        if (lo > hi) continue;
+        for (int x = (int)std::ceil(lo - 1e-9); x <= (int)std::floor(hi + 1e-9); ++x) set(x, y);
+    }
+    for (size_t i = 0; i < n && n > 1; ++i) {   // boundary: 8-connected Bresenham between consecutive vertices
+        Pt a = hull[i], b = hull[(i + 1) % n];
+        int dx = std::abs(b.x - a.x), dy = -std::abs(b.y - a.y), sx = a.x < b.x ? 1 : -1, sy = a.y < b.y ? 1 : -1, err = dx + dy;
+        for (;;) {
+            set(a.x, a.y);
+            if (a.x == b.x && a.y == b.y) break;
+            int e2 = 2 * err;
+            if (e2 >= dy) { err += dy; a.x += sx; }
+            if (e2 <= dx) { err += dx; a.y += sy; }
+        }
+    }
+    for (int y = std::max(y0, 0); y <= std::min(y1, h - 1); ++y)
+        for (int x = std::max(x0, 0); x <= std::min(x1, w - 1); ++x)
+            if (m[(size_t)(y - y0) * bw + (x - x0)]) {
+                ++*in_hull;
+                if (color_mask[(size_t)y * w + x]) ++*in_both;
+            }
+}
+
+// ==================================================================================================
+// grouping (:206-253)
+// ==================================================================================================
+std::vector<MatchGroup> group_similar_matches(const std::vector<lm_match_t>& matches, float radius) {
+    std::vector<MatchGroup> groups;
+    for (size_t i = 0; i < matches.size(); ++i) {
+        const uint16_t numCurrentGroups = (uint16_t)groups.size();   // uint16_t in the reference (:212)
+        bool found = false;
+        for (size_t q = 0; q < numCurrentGroups; ++q) {
+            double dx = matches[i].x - groups[q].position.x, dy = matches[i].y - groups[q].position.y;
+            if (std::sqrt(dx * dx + dy * dy) < radius) {   // cv::norm(Point) < radiusThresholdNewObject
+                groups[q].matchIndices.push_back((uint32_t)i);
+                found = true;
+                break;
+            }
+        }
+        if (!found) groups.push_back(MatchGroup{Pt{matches[i].x, matches[i].y}, {(uint32_t)i}});
+    }
+    return groups;
+}
+
+std::vector<MatchGroup> discard_small_groups(const std::vector<MatchGroup>& groups, float ratio) {
+    size_t biggest = 0;
+    for (const MatchGroup& g : groups) biggest = std::max(biggest, g.matchIndices.size());
+    std::vector<MatchGroup> out;
+    for (const MatchGroup& g : groups) {
+        float r = (float)(g.matchIndices.size() * 100 / biggest);   // integer division first (:246)
+        if (r > ratio) out.push_back(g);
+    }
+    return out;
+}
+
+void calculate_template_pose(Vec3 cam, int16_t inplaneRot, float t[3], float q[4]) {   // :351-379
+    t[0] = 0.f; t[1] = 0.f; t[2] = length(cam);
+    if (cam.x == 0 && cam.z == 0) cam.x = 0.00000000001f;   // looking straight up or down fails the cross product
+    const Vec3 up{0.f, 1.f, 0.f};
+    Vec3 camUp = normalize(cross(cam, cross(cam, up)));
+    Vec3 rotatedUp = rotate(Vec3{-camUp.x, -camUp.y, -camUp.z}, (float)inplaneRot * 0.01745329251994329576923690768489f, normalize(cam));
+    Mat4 view = lookAt(cam, Vec3{0, 0, 0}, rotatedUp);
+    // openglCoordinatesystem2opencv (:371-379)
+    Mat4 ct;
+    std::memset(&ct, 0, sizeof(ct));
+    ct.m[0][0] = 1.f; ct.m[1][1] = -1.f; ct.m[2][2] = -1.f; ct.m[3][3] = 1.f;
+    Quat qq = toQuat(transpose(mul(transpose(view), ct)));
+    q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
+}
+
+// ==================================================================================================
+// PostProcessor
+// ==================================================================================================
+bool PostProcessor::color_check(const lm_match_t& m, const std::vector<uint8_t>& color_mask) {
+    std::vector<Pt> pts;
+    const int M = lm_num_modalities(det);
+    for (int mod = 0; mod < M; ++mod) {   // templates[m].features for m < num_modalities = the level-0 templates (:120-126)
+        int n = 0, tw = 0, th = 0;
+        if (lm_get_template(det, m.class_idx, m.template_id, 0, mod, &tw, &th, nullptr, &n) != LM_OK) return false;
+        std::vector<lm_feature> f((size_t)n);
+        lm_get_template(det, m.class_idx, m.template_id, 0, mod, &tw, &th, f.data(), &n);
+        for (const lm_feature& ft : f) pts.push_back(Pt{ft.x + m.x, ft.y + m.y});
+    }
+    long in_hull = 0, in_both = 0;
+    hull_counts(convex_hull(pts), color_mask.data(), st.videoWidth, st.videoHeight, &in_hull, &in_both);
+    if (in_hull == 0) return false;                        // the reference would divide by zero
+    float nonZer = (float)(in_both * 100 / in_hull);        // integer division first (:432)
+    return nonZer > (float)st.percentToPassCheck;
+}
+
+bool PostProcessor::depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth) {
+    const TemplatePose& tp = t[(size_t)m.template_id];
+    if (st.useDepthImprovement) {
+        Rect bb{m.x, m.y, tp.bb[2], tp.bb[3]};
+        int32_t depthDiff = (int32_t)((float)((int32_t)median_mat(depth, st.videoWidth, st.videoHeight, bb, 5) - (int32_t)tp.medianDepth) - st.depthOffset);
+        *tempDepth = (int32_t)(tp.translation[2] + (float)depthDiff);
+        return std::abs(depthDiff) < (int32_t)st.stepSize;
+    }
+    *tempDepth = (int32_t)tp.translation[2];
+    return true;
+}
+
+ObjectPose PostProcessor::make_pose(const lm_match_t& m, const std::vector<TemplatePose>& t, int32_t tempDepth) {
+    const TemplatePose& tp = t[(size_t)m.template_id];
+    const int halfW = st.videoWidth / 2, halfH = st.videoHeight / 2;
+    // matchToPixelCoord (:497-503)
+    float pixelX = (float)(m.x + halfW - tp.bb[0]);
+    float pixelY = (float)(m.y + halfH - tp.bb[1]);
+    // pixelDistToCenter (:505-510), calcTrueZ (:512-515), calcPosition (:474-485)
+    float cx = pixelX - (float)halfW, cy = pixelY - (float)halfH;
+    float offsetFromCenter = std::sqrt(cx * cx + cy * cy);
+    float direct = (float)tempDepth;
+    ObjectPose pose;
+    pose.translation.z = std::sqrt(direct * direct - (offsetFromCenter * offsetFromCenter));
+    float mmOffsetFromCenter = pose.translation.z / st.fy;
+    pose.translation.x = (pixelX - (float)halfW) * mmOffsetFromCenter;
+    pose.translation.y = (pixelY - (float)halfH) * mmOffsetFromCenter;
+    // calcRotation (:488-495)
+    Mat4 adjust = lookAt(Vec3{-pose.translation.x, -pose.translation.y, pose.translation.z}, Vec3{0, 0, 0}, Vec3{0, 1, 0});
+    Quat tq; tq.x = tp.quat_xyzw[0]; tq.y = tp.quat_xyzw[1]; tq.z = tp.quat_xyzw[2]; tq.w = tp.quat_xyzw[3];
+    pose.quaternions = toQuat(mul(adjust, toMat4(tq)));
+    pose.boundingBox = Rect{m.x, m.y, tp.bb[2], tp.bb[3]};
+    return pose;
+}
+
+std::vector<std::vector<ObjectPose>> PostProcessor::run(const std::vector<lm_match_t>& matches, const uint8_t* bgr,
+                                                        size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
+                                                        const std::vector<TemplatePose>& templates, const ModelProperties& props) {
+    std::vector<std::vector<ObjectPose>> poses;
+    if (matches.empty()) return poses;
+    const int w = st.videoWidth, h = st.videoHeight;
+    std::vector<uint8_t> color_mask;
+    bgr2hsv_inrange(bgr, w, h, bgr_stride, props.lowerColorRange, props.upperColorRange, color_mask);   // :159-161
+    std::vector<uint16_t> dense_depth;
+    if (depth) {
+        if (depth_stride == 0) depth_stride = (size_t)w * 2;
+        dense_depth.resize((size_t)w * h);
+        for (int y = 0; y < h; ++y)
+            std::memcpy(&dense_depth[(size_t)y * w], reinterpret_cast<const uint8_t*>(depth) + y * depth_stride, (size_t)w * 2);
+    }
+    std::vector<MatchGroup> groups = discard_small_groups(group_similar_matches(matches, st.radiusThresholdNewObject), st.discardGroupRatio);
+    for (const MatchGroup& g : groups) {   // :165-174, applyPostProcessing (:382-421)
+        std::vector<ObjectPose> objPoses;
+        for (uint32_t idx : g.matchIndices) {
+            const lm_match_t& m = matches[idx];
+            if ((size_t)m.template_id >= templates.size()) continue;
+            int32_t tempDepth = (int32_t)templates[(size_t)m.template_id].translation[2];
+            bool ok = color_check(m, color_mask);
+            if (ok && depth) ok = depth_check(m, dense_depth.data(), templates, &tempDepth);   // && short-circuit like the reference
+            if (ok) objPoses.push_back(make_pose(m, templates, tempDepth));
+            if (objPoses.size() == st.numberWantedPoses) break;
+        }
+        if (!objPoses.empty()) poses.push_back(objPoses);
+    }
+    return poses;
+}
+
+}  // namespace lmamd

@@ -1,0 +1,101 @@
+// PostProcess.h -- host glue around the hot path: what the reference's
+// HighLevelLineMOD does with the match list after detector->match() returns
+// (/root/reference/src/HighLevelLinemod.cpp:157-175, 206-253, 336-349, 351-379, 382-515) and the
+// principal-point shift of PoseDetection (/root/reference/src/PoseDetection.cpp:54-59,192-197).
+//
+// Plain C++17, no OpenCV / GLM: the few pieces of both that the reference uses are restated here
+// (8-bit BGR->HSV + inRange, convex hull + polygon fill, nth_element quartile, lookAt / quaternion
+// maths).  OpenCV and GLM are absent from the build image, so -- like the oracle -- these restatements
+// are PARITY UNPINNED against the real libraries; each function says what it restates.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/linemod_hip.h"
+#include "HighLevelLinemod.h"
+
+namespace lmamd {
+
+// HighLevelLinemod.h:130-148 `struct Template`; written raw to linemod_tempPosFile.bin (:272-284):
+// glm::vec3 (12 B) | glm::qua<float> x,y,z,w (16 B) | cv::Rect (16 B) | uint16 | pad  = 48 B
+struct TemplatePose {
+    float translation[3];
+    float quat_xyzw[4];
+    int32_t bb[4];          // x, y, width, height
+    uint16_t medianDepth;
+    uint16_t pad;
+};
+static_assert(sizeof(TemplatePose) == 48, "layout of the reference's raw Template record");
+
+// models/<name>.yml: HSV range of the object (HighLevelLinemod.cpp:523-543)
+struct ModelProperties {
+    double lowerColorRange[3] = {0, 0, 0};
+    double upperColorRange[3] = {255, 255, 255};
+};
+
+struct PostProcessSettings {   // the TemplateGenerationSettings fields the post-processing reads
+    bool onlyColorModality = false;
+    uint16_t videoWidth = 640, videoHeight = 480;
+    float fy = 1045.69141f;
+    uint16_t stepSize = 50;
+    uint16_t percentToPassCheck = 50;
+    uint16_t numberWantedPoses = 1;
+    float radiusThresholdNewObject = 45.f;
+    float discardGroupRatio = 35.f;
+    bool useDepthImprovement = true;
+    float depthOffset = 30.f;
+};
+
+// ---- mini GLM ------------------------------------------------------------------------------------
+struct Mat4 { float m[4][4]; };   // column-major like glm: m[col][row]
+Vec3 cross(const Vec3& a, const Vec3& b);
+Vec3 normalize(const Vec3& v);
+float length(const Vec3& v);
+Mat4 lookAt(const Vec3& eye, const Vec3& center, const Vec3& up);   // glm::lookAt (right-handed)
+Mat4 mul(const Mat4& a, const Mat4& b);
+Mat4 transpose(const Mat4& a);
+Mat4 toMat4(const Quat& q);                                          // glm::mat4_cast
+Quat toQuat(const Mat4& m);                                          // glm::quat_cast of the upper 3x3
+Vec3 rotate(const Vec3& v, float angle, const Vec3& axis);           // glm::rotate (gtx/rotate_vector)
+
+// ---- image helpers -------------------------------------------------------------------------------
+// cvtColor(BGR2HSV) on 8-bit + inRange(lower, upper): 255 where all three HSV channels are in range.
+void bgr2hsv_inrange(const uint8_t* bgr, int w, int h, size_t stride, const double lower[3], const double upper[3],
+                     std::vector<uint8_t>& mask);
+// PoseDetection::translateImg: integer shift with zero fill (warpAffine with a pure translation).
+void translate_u8c3(const uint8_t* src, int w, int h, int ox, int oy, std::vector<uint8_t>& dst);
+void translate_u16(const uint16_t* src, int w, int h, int ox, int oy, std::vector<uint16_t>& dst);
+// HighLevelLineMOD::medianMat (:336-349): zeros -> 65535, crop, nth_element at n/4, returns element n/position.
+uint16_t median_mat(const uint16_t* depth, int w, int h, Rect bb, uint8_t position);
+struct Pt { int x, y; };
+std::vector<Pt> convex_hull(std::vector<Pt> pts);                   // cv::convexHull (hull vertices, ccw, no collinear points)
+// templateMask (:113-135) restricted to the hull's bounding box: returns (pixels in hull, pixels in hull
+// with colour mask set) -- the two countNonZero of colorCheck (:424-434).
+void hull_counts(const std::vector<Pt>& hull, const uint8_t* color_mask, int w, int h, long* in_hull, long* in_both);
+
+// ---- the reference's post-processing pipeline -----------------------------------------------------
+struct MatchGroup { Pt position; std::vector<uint32_t> matchIndices; };   // PotentialMatch, HighLevelLinemod.h:150-160
+std::vector<MatchGroup> group_similar_matches(const std::vector<lm_match_t>& matches, float radius);      // :206-229
+std::vector<MatchGroup> discard_small_groups(const std::vector<MatchGroup>& groups, float ratio);          // :232-253
+
+// calculateTemplatePose (:351-379): pose of a template rendered from `cameraPosition` with in-plane angle.
+void calculate_template_pose(Vec3 cameraPosition, int16_t inplaneRot, float translation_out[3], float quat_xyzw_out[4]);
+
+class PostProcessor {
+public:
+    PostProcessor(lm_detector* det, const PostProcessSettings& s) : det(det), st(s) {}
+    // detectTemplate's tail (:157-175): colour mask, grouping, per-group colour/depth checks, poses.
+    std::vector<std::vector<ObjectPose>> run(const std::vector<lm_match_t>& matches, const uint8_t* bgr, size_t bgr_stride,
+                                             const uint16_t* depth, size_t depth_stride,
+                                             const std::vector<TemplatePose>& templates, const ModelProperties& props);
+
+private:
+    bool color_check(const lm_match_t& m, const std::vector<uint8_t>& color_mask);                          // :424-434
+    bool depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth);  // :437-457
+    ObjectPose make_pose(const lm_match_t& m, const std::vector<TemplatePose>& t, int32_t tempDepth);       // :459-515
+    lm_detector* det;
+    PostProcessSettings st;
+};
+
+}  // namespace lmamd

@@ -1,0 +1,103 @@
+// CPU unit tests of line-mod-pipeline_amd/host/PostProcess.* (SURVEY.md 8f-1 host glue).
+// Exits non-zero on the first failed check; prints "OK" otherwise.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../line-mod-pipeline_amd/host/PostProcess.h"
+
+using namespace lmamd;
+#define CHECK(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+static bool near(float a, float b, float eps = 1e-5f) { return std::fabs(a - b) <= eps; }
+
+int main() {
+    // ---- BGR -> HSV (OpenCV 8-bit convention: H in [0,180)) + inRange
+    {
+        const uint8_t px[5 * 3] = {0, 0, 255, /*red*/ 0, 255, 0, /*green*/ 255, 0, 0, /*blue*/ 128, 128, 128, /*gray*/ 0, 255, 255 /*yellow*/};
+        std::vector<uint8_t> m;
+        double lo[3] = {0, 0, 0}, hi[3] = {255, 255, 255};
+        bgr2hsv_inrange(px, 5, 1, 0, lo, hi, m);
+        for (int i = 0; i < 5; ++i) CHECK(m[i] == 255);
+        double lo2[3] = {55, 200, 200}, hi2[3] = {65, 255, 255};   // H = 60: green only
+        bgr2hsv_inrange(px, 5, 1, 0, lo2, hi2, m);
+        CHECK(m[0] == 0 && m[1] == 255 && m[2] == 0 && m[3] == 0 && m[4] == 0);
+        double lo3[3] = {0, 0, 0}, hi3[3] = {255, 150, 255};       // the shipped model file: S <= 150
+        bgr2hsv_inrange(px, 5, 1, 0, lo3, hi3, m);
+        CHECK(m[0] == 0 && m[3] == 255);                            // saturated red fails, gray passes
+        double lo4[3] = {115, 0, 0}, hi4[3] = {125, 255, 255};      // H = 120: blue; H = 30: yellow
+        bgr2hsv_inrange(px, 5, 1, 0, lo4, hi4, m);
+        CHECK(m[2] == 255 && m[4] == 0);
+    }
+    // ---- convex hull + fill counts
+    {
+        std::vector<Pt> pts = {{10, 10}, {20, 10}, {20, 20}, {10, 20}, {15, 15}, {12, 18}, {15, 10}};
+        std::vector<Pt> hull = convex_hull(pts);
+        CHECK(hull.size() == 4);
+        std::vector<uint8_t> cm(64 * 64, 0);
+        for (int y = 0; y < 64; ++y) for (int x = 0; x < 16; ++x) cm[y * 64 + x] = 255;   // left part coloured
+        long a = 0, b = 0;
+        hull_counts(hull, cm.data(), 64, 64, &a, &b);
+        CHECK(a == 11 * 11);            // closed square 10..20
+        CHECK(b == 6 * 11);             // columns 10..15
+        std::vector<Pt> tri = convex_hull({{0, 0}, {8, 0}, {0, 8}});
+        hull_counts(tri, cm.data(), 64, 64, &a, &b);
+        CHECK(a == 45 && b == 45);      // lattice points of the closed triangle x + y <= 8
+        std::vector<Pt> off = convex_hull({{60, 60}, {70, 60}, {70, 70}, {60, 70}});   // partly outside the image
+        hull_counts(off, cm.data(), 64, 64, &a, &b);
+        CHECK(a == 16 && b == 0);
+    }
+    // ---- grouping (:206-253)
+    {
+        std::vector<lm_match_t> ms;
+        auto add = [&](int x, int y) { lm_match_t m; m.x = x; m.y = y; m.similarity = 90; m.template_id = 0; m.class_idx = 0; ms.push_back(m); };
+        add(0, 0); add(10, 0); add(100, 0); add(44, 0); add(45, 0); add(130, 10); add(5, 5); add(300, 300);
+        std::vector<MatchGroup> g = group_similar_matches(ms, 45.f);
+        CHECK(g.size() == 4);                       // {0,1,3,6}, {2,5}, {4}, {7}: distance 45 is not < 45
+        CHECK(g[0].matchIndices.size() == 4 && g[1].matchIndices.size() == 2 && g[2].matchIndices.size() == 1);
+        CHECK(g[2].position.x == 45);
+        std::vector<MatchGroup> k = discard_small_groups(g, 35.f);
+        CHECK(k.size() == 2);                       // 4 -> 100, 2 -> 50 kept; 1 -> 25 dropped
+        std::vector<MatchGroup> k2 = discard_small_groups(g, 50.f);
+        CHECK(k2.size() == 1);                      // 50 is not > 50
+    }
+    // ---- medianMat quirk (:336-349)
+    {
+        std::vector<uint16_t> d(20 * 10);
+        for (int i = 0; i < 200; ++i) d[i] = (uint16_t)(1000 - i);
+        d[5] = 0; d[6] = 1;                          // holes count as 65535
+        Rect bb{0, 0, 20, 10};
+        uint16_t v = median_mat(d.data(), 20, 10, bb, 5);
+        CHECK(v <= 1000 - 150);                      // some element of the lower quarter (values 801..850 are the 50 smallest)
+        CHECK(v >= 801);
+        Rect clip{15, 5, 20, 20};                    // partly outside: clipped instead of cv::Mat's assert
+        CHECK(median_mat(d.data(), 20, 10, clip, 5) >= 801);
+    }
+    // ---- mini GLM
+    {
+        Vec3 r = rotate(Vec3{1, 0, 0}, 1.57079632679f, Vec3{0, 0, 1});
+        CHECK(near(r.x, 0, 1e-6f) && near(r.y, 1, 1e-6f) && near(r.z, 0, 1e-6f));
+        Mat4 v = lookAt(Vec3{0, 0, 5}, Vec3{0, 0, 0}, Vec3{0, 1, 0});
+        CHECK(near(v.m[0][0], 1) && near(v.m[1][1], 1) && near(v.m[2][2], 1) && near(v.m[3][2], -5));
+        Quat q; q.w = 0.5f; q.x = 0.5f; q.y = -0.5f; q.z = 0.5f;
+        Quat b = toQuat(toMat4(q));
+        CHECK(near(b.w, q.w) && near(b.x, q.x) && near(b.y, q.y) && near(b.z, q.z));
+        Mat4 I = mul(toMat4(q), transpose(toMat4(q)));
+        CHECK(near(I.m[0][0], 1) && near(I.m[1][0], 0) && near(I.m[2][1], 0) && near(I.m[2][2], 1));
+        float t[3], qq[4];
+        calculate_template_pose(Vec3{0, 0, 700}, 0, t, qq);
+        CHECK(near(t[0], 0) && near(t[1], 0) && near(t[2], 700));
+        CHECK(near(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3], 1, 1e-5f));
+        calculate_template_pose(Vec3{0, 650, 0}, -45, t, qq);           // straight above: the cross-product guard (:358-362)
+        CHECK(near(t[2], 650) && std::isfinite(qq[0]) && std::isfinite(qq[3]));
+    }
+    // ---- translateImg (PoseDetection.cpp:192-197)
+    {
+        std::vector<uint16_t> d(4 * 3), o;
+        for (int i = 0; i < 12; ++i) d[i] = (uint16_t)(i + 1);
+        translate_u16(d.data(), 4, 3, 1, -1, o);
+        CHECK(o[0] == 0 && o[1] == 5 && o[2] == 6 && o[3] == 7 && o[8] == 0 && o[11] == 0);
+    }
+    std::printf("OK\n");
+    return 0;
+}

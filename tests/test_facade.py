@@ -17,6 +17,7 @@ def driver(lm, tmp_path_factory):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe,
                            os.path.join(ROOT, "tests", "cpp", "facade_driver.cpp"),
                            os.path.join(ROOT, "line-mod-pipeline_amd", "host", "HighLevelLinemod.cpp"),
+                           os.path.join(ROOT, "line-mod-pipeline_amd", "host", "PostProcess.cpp"),
                            "-L" + libdir, "-llinemod_hip", "-Wl,-rpath," + libdir])
     return exe, d
 
@@ -61,3 +62,45 @@ def test_facade_detect_matches_golden(lm, golden0, frame0, driver, name, color_o
     for g, e in zip(got, exp):
         assert (int(g[0]), int(g[1]), int(g[3]), int(g[4])) == (e["x"], e["y"], e["template_id"], e["class_idx"])
         assert np.float32(g[2]) == e["similarity"]
+
+
+def test_postprocess_helpers_cpu(lm, tmp_path):
+    """SURVEY.md 8f-1 host glue (PostProcess.cpp): HSV/inRange, hull fill counts, grouping with the
+    reference's integer-percent rules, medianMat's quartile quirk, mini-GLM pose maths."""
+    exe = str(tmp_path / "postprocess_test")
+    libdir = os.path.dirname(lm.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "postprocess_test.cpp"),
+                           os.path.join(ROOT, "line-mod-pipeline_amd", "host", "PostProcess.cpp"),
+                           "-L" + libdir, "-llinemod_hip", "-Wl,-rpath," + libdir])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "OK", r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_facade_end_to_end_selftest(lm, tmp_path):
+    """addTemplate -> detectTemplate -> getObjectPoses on a synthetic rendered object moved by (+40,+30):
+    the pose must sit where the object went, at the template depth minus depthOffset (:446-449)."""
+    exe = str(tmp_path / "facade_selftest")
+    libdir = os.path.dirname(lm.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "facade_selftest.cpp"),
+                           os.path.join(ROOT, "line-mod-pipeline_amd", "host", "HighLevelLinemod.cpp"),
+                           os.path.join(ROOT, "line-mod-pipeline_amd", "host", "PostProcess.cpp"),
+                           "-L" + libdir, "-llinemod_hip", "-Wl,-rpath," + libdir])
+    r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout.splitlines()
+    assert out[0] == "templates 1"
+    assert out[1].startswith("found 1")
+    best = out[2].split()
+    assert float(best[3]) == 100.0
+    poses = [l.split() for l in out if l.startswith("pose ")]
+    assert len(poses) >= 1
+    t = [float(v) for v in poses[0][2:5]]
+    bb = [int(v) for v in poses[0][11:15]]
+    # bbox origin moved by (+40, +30) up to the T0 = 5 lattice; depth = 700 - depthOffset(30)
+    assert abs(t[2] - 670.0) < 3.0
+    assert abs(t[0] - 40 * t[2] / 1045.69141) < 4.0 and abs(t[1] - 30 * t[2] / 1045.69141) < 4.0
+    assert bb[2] > 100 and bb[3] > 80
+    assert "reloaded classes 1 templates 1" in r.stdout and "reloaded found 1 groups 1" in r.stdout
