@@ -1,12 +1,14 @@
 // HighLevelLinemod.cpp -- see HighLevelLinemod.h.  Plain C++17, links against liblinemod_hip.so only.
 #include "HighLevelLinemod.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
 
 #include "PostProcess.h"
+#include "TemplateGenerator.h"
 
 namespace lmamd {
 
@@ -147,46 +149,53 @@ bool HighLevelLineMOD::addTemplate(std::vector<Image>& in_images, const std::str
     const Image& color = in_images[0];
     const Image& depth = in_images[1];
     const int w = depth.width, h = depth.height;
-    // mask = depth > 1 (threshold(in_images[1], mask, 1, 65535, THRESH_BINARY) then 8-bit, :78-79),
-    // eroded once (3x3, border does not erode) like :91
+    // colorToBinary = threshold(colour, 1, 255); mask = threshold(depth, 1, 65535) as 8-bit  (:77-79)
     std::vector<uint16_t> dense((size_t)w * h);
     size_t dstride = depth.stride ? depth.stride : (size_t)w * 2;
     for (int y = 0; y < h; ++y) std::memcpy(&dense[(size_t)y * w], static_cast<const uint8_t*>(depth.data) + y * dstride, (size_t)w * 2);
-    std::vector<uint8_t> mask((size_t)w * h), er((size_t)w * h);
+    std::vector<uint8_t> mask((size_t)w * h), bin((size_t)w * h * 3);
     for (size_t i = 0; i < mask.size(); ++i) mask[i] = dense[i] > 1 ? 255 : 0;
-    for (int y = 0; y < h; ++y)
-        for (int x = 0; x < w; ++x) {
-            uint8_t v = 255;
-            for (int j = -1; j <= 1; ++j)
-                for (int i = -1; i <= 1; ++i) {
-                    int yy = y + j, xx = x + i;
-                    if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;   // morphologyDefaultBorderValue: ignored
-                    v = std::min(v, mask[(size_t)yy * w + xx]);
-                }
-            er[(size_t)y * w + x] = v;
-        }
-    // the reference feeds the colour image thresholded to binary (:77); the renderer's object is white-on-black
-    std::vector<uint8_t> bin((size_t)w * h * 3);
     size_t cstride = color.stride ? color.stride : (size_t)w * 3;
     for (int y = 0; y < h; ++y) {
         const uint8_t* row = static_cast<const uint8_t*>(color.data) + y * cstride;
         for (int x = 0; x < w * 3; ++x) bin[(size_t)y * w * 3 + x] = row[x] > 1 ? 255 : 0;
     }
-    int tid = -1;
-    lm_rect bb;
-    int rc = lm_add_template(detector, in_modelName.c_str(), bin.data(), 0, onlyColorModality ? nullptr : dense.data(), 0,
-                             er.data(), 0, &tid, &bb);
-    if (rc != LM_OK || tid < 0) {
-        error = lm_last_error();
-        std::printf("ERROR::Cant create Template\n");  // :99
-        return false;
+    std::vector<uint8_t> maskRotated, colorRotated, er((size_t)w * h);
+    std::vector<uint16_t> depthRotated;
+    // one template per in-plane rotation (generateRotMatForInplaneRotation :327-334, loop :81-108)
+    int q = 0;
+    for (int angle = settings.angleStart; angle <= settings.angleStop; angle += std::max<int>(settings.angleStep, 1), ++q) {
+        warp_rotate_u8(mask.data(), w, h, 1, (float)angle, maskRotated);
+        warp_rotate_u8(bin.data(), w, h, 3, (float)angle, colorRotated);
+        warp_rotate_u16(dense.data(), w, h, (float)angle, depthRotated);
+        for (int y = 0; y < h; ++y)   // erode(maskRotated, 3x3, 1 iteration), border pixels do not erode (:91)
+            for (int x = 0; x < w; ++x) {
+                uint8_t v = 255;
+                for (int j = -1; j <= 1; ++j)
+                    for (int i = -1; i <= 1; ++i) {
+                        int yy = y + j, xx = x + i;
+                        if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+                        v = std::min(v, maskRotated[(size_t)yy * w + xx]);
+                    }
+                er[(size_t)y * w + x] = v;
+            }
+        int tid = -1;
+        lm_rect bb;
+        int rc = lm_add_template(detector, in_modelName.c_str(), colorRotated.data(), 0,
+                                 onlyColorModality ? nullptr : depthRotated.data(), 0, er.data(), 0, &tid, &bb);
+        if (rc != LM_OK || tid < 0) {
+            error = lm_last_error();
+            std::printf("ERROR::Cant create Template\n");  // :99
+            return false;
+        }
+        TemplatePose tp;
+        std::memset(&tp, 0, sizeof(tp));
+        tp.bb[0] = bb.x; tp.bb[1] = bb.y; tp.bb[2] = bb.width; tp.bb[3] = bb.height;
+        tp.medianDepth = median_mat(depthRotated.data(), w, h, Rect{bb.x, bb.y, bb.width, bb.height}, 5);   // :104
+        const int16_t currentInplaneAngle = (int16_t)(-(settings.angleStart + q * settings.angleStep));    // :105
+        calculate_template_pose(in_cameraPosition, currentInplaneAngle, tp.translation, tp.quat_xyzw);       // :106
+        templates->push_back(tp);                                                                             // :107
     }
-    TemplatePose tp;
-    std::memset(&tp, 0, sizeof(tp));
-    tp.bb[0] = bb.x; tp.bb[1] = bb.y; tp.bb[2] = bb.width; tp.bb[3] = bb.height;
-    tp.medianDepth = median_mat(dense.data(), w, h, Rect{bb.x, bb.y, bb.width, bb.height}, 5);   // :104
-    calculate_template_pose(in_cameraPosition, 0, tp.translation, tp.quat_xyzw);                   // :105-106 with angle 0
-    templates->push_back(tp);                                                                       // :107
     return true;
 }
 

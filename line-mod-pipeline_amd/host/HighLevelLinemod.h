@@ -8,9 +8,9 @@
 // this class holds an lm_detector* and every call that crossed that seam goes through liblinemod_hip.so.
 //
 // Scope: the hot path behind detectTemplate (Detector::match, GPU), the detector
-// queries, and the host glue of 8f-1 (match post-processing into ObjectPose, PostProcess.{h,cpp}).
-// Still "next": the in-plane rotation sweep of addTemplate (8f-3: needs cv::warpAffine's fixed-point
-// bilinear resampling) and OpenCV's YAML template file (8f-2).
+// queries, the host glue of 8f-1 (match post-processing into ObjectPose, PostProcess.{h,cpp}) and of
+// 8f-3 (addTemplate with its in-plane rotation sweep; the resampler lives in TemplateGenerator.cpp).
+// Still "next": OpenCV's YAML template file (8f-2).
 #pragma once
 #include <cstdint>
 #include <string>
@@ -93,9 +93,9 @@ public:
     void writeLinemod();
     void readLinemod();
 
-    // :68-110.  One template per call from a rendered colour+depth pair, WITHOUT the in-plane rotation
-    // sweep (8f-3, next): equivalent to the reference with angleStart == angleStop == 0.  Computes the
-    // template pose and median depth like the reference (:102-107).  false when extraction fails.
+    // :68-110.  From one rendered colour+depth pair: one template per in-plane rotation angleStart..angleStop
+    // (warpAffine of mask / binarised colour / depth, erode, Detector::addTemplate), with the template
+    // pose and median depth the post-processing needs (:102-107).  false as soon as one extraction fails.
     bool addTemplate(std::vector<Image>& in_images, const std::string& in_modelName, Vec3 in_cameraPosition);
     void pushBackTemplates();                 // :517-521
 

@@ -1,0 +1,81 @@
+// TemplateGenerator.h -- offline template generation without OpenGL / assimp / OpenCV
+// (SURVEY.md section 8f-3 and 8f-4).  Stand-ins, with the reference's names and call structure, for
+//   ModelImporter      (/root/reference/src/ModelImporter.cpp:13-82, assimp)   -> load_ply_ascii
+//   CameraViewPoints   (/root/reference/src/CameraViewPoints.cpp)              -> CameraViewPoints
+//   OpenGLRender       (/root/reference/src/OpenglRender.cpp:9-11,49-141,334-345, shader/depth.fs)
+//                                                                               -> SoftRender (z-buffer rasteriser)
+//   cv::getRotationMatrix2D + cv::warpAffine (HighLevelLinemod.cpp:81-91,327-334) -> warp_rotate_*
+//   TemplateGenerator::run (/root/reference/src/TemplateGenerator.cpp:41-62)   -> TemplateGenerator::run
+// All of it is offline host code (not on the measured path) and, like the oracle, PARITY UNPINNED against
+// the real OpenGL rasteriser / OpenCV resampler: sub-pixel coverage and bilinear rounding may differ.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "HighLevelLinemod.h"
+
+namespace lmamd {
+
+struct Mesh {
+    std::vector<Vec3> vertices;
+    std::vector<uint32_t> indices;   // triangles
+};
+bool load_ply_ascii(const std::string& path, Mesh& mesh, std::string* err = nullptr);
+
+// models/<name>.yml: symmetry description used to prune the viewpoint sphere (CameraViewPoints.cpp:34-67)
+struct SymmetryProperties {
+    bool rotationallySymmetrical = false;
+    Vec3 planesOfSymmetry{0, 0, 0};
+};
+
+class CameraViewPoints {
+public:
+    void setModelProperties(const SymmetryProperties& p) { modProps = p; }
+    void createCameraViewPoints(float in_radius, uint8_t in_subdivions);   // :11-32
+    std::vector<Vec3>& getVertices() { return vertices; }
+
+private:
+    struct Index { uint32_t a, b, c; };
+    void createVerticesForRotSym();        // :75-82
+    void icosahedronPointsFromRadius();    // :69-73
+    void createIcosahedron();              // :84-124
+    void subdivide();                      // :143-214
+    int32_t checkForDuplicate(uint32_t vertSize);   // :126-141
+    void adjustVecToRadius(uint32_t index);          // :216-225
+    void removeSuperfluousVertices();      // :34-52
+    std::vector<Vec3> vertices;
+    std::vector<Index> indices;
+    SymmetryProperties modProps;
+    float radius = 0, icosahedronPointA = 0, icosahedronPointB = 0;
+    uint8_t numSubdivisions = 0;
+};
+
+// Software stand-in for OpenGLRender: perspective(fovy = 2 atan(h / 2fy), w/h, 100, 10000) * lookAt(cam, 0, +y),
+// white unlit mesh, depth image = linear eye depth in millimetres (shader/depth.fs), rows flipped like the
+// reference's glReadPixels + flip.  Background colour 0 / depth 0.
+class SoftRender {
+public:
+    explicit SoftRender(const CameraParameters& cam);
+    // renderColorToFrontBuff + renderDepthToFrontBuff (camera-position overloads, :49-69, :97-117)
+    void render(const Mesh& mesh, Vec3 camPosition, std::vector<uint8_t>& bgr, std::vector<uint16_t>& depth) const;
+    int width, height;
+
+private:
+    float proj[4][4];   // column-major
+};
+
+// cv::warpAffine(src, dst, cv::getRotationMatrix2D(center, angleDegrees, 1.0), size): bilinear, constant 0 border
+void warp_rotate_u8(const uint8_t* src, int w, int h, int channels, float angleDegrees, std::vector<uint8_t>& dst);
+void warp_rotate_u16(const uint16_t* src, int w, int h, float angleDegrees, std::vector<uint16_t>& dst);
+
+// TemplateGenerator::run for one model: radii startDistance..endDistance step stepSize, every viewpoint,
+// every in-plane rotation (HighLevelLineMOD::addTemplate sweeps them).  Returns the number of templates added.
+struct GeneratorSettings {
+    uint16_t startDistance = 500, endDistance = 1200, stepSize = 50;
+    uint8_t subdivisions = 3;
+};
+int generate_templates(HighLevelLineMOD& line, const SoftRender& render, const Mesh& mesh, const std::string& modelName,
+                       const SymmetryProperties& sym, const GeneratorSettings& gs);
+
+}  // namespace lmamd

@@ -31,6 +31,7 @@ int main() {
     cam.fx = 1044.87f; cam.fy = 1045.69141f; cam.cx = 320; cam.cy = 240;
     TemplateGenerationSettings ts;
     ts.detectorThreshold = 85.f;
+    ts.angleStart = 0; ts.angleStop = 0;   // a single, unrotated template
     HighLevelLineMOD line(cam, ts);
     std::vector<uint8_t> bgr; std::vector<uint16_t> depth;
     draw(bgr, depth, 320, 240);

@@ -18,6 +18,7 @@ def driver(lm, tmp_path_factory):
                            os.path.join(ROOT, "tests", "cpp", "facade_driver.cpp"),
                            os.path.join(ROOT, "line-mod-pipeline_amd", "host", "HighLevelLinemod.cpp"),
                            os.path.join(ROOT, "line-mod-pipeline_amd", "host", "PostProcess.cpp"),
+                           os.path.join(ROOT, "line-mod-pipeline_amd", "host", "TemplateGenerator.cpp"),
                            "-L" + libdir, "-llinemod_hip", "-Wl,-rpath," + libdir])
     return exe, d
 
@@ -71,7 +72,9 @@ def test_postprocess_helpers_cpu(lm, tmp_path):
     libdir = os.path.dirname(lm.LIB_PATH)
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe,
                            os.path.join(ROOT, "tests", "cpp", "postprocess_test.cpp"),
+                           os.path.join(ROOT, "line-mod-pipeline_amd", "host", "HighLevelLinemod.cpp"),
                            os.path.join(ROOT, "line-mod-pipeline_amd", "host", "PostProcess.cpp"),
+                           os.path.join(ROOT, "line-mod-pipeline_amd", "host", "TemplateGenerator.cpp"),
                            "-L" + libdir, "-llinemod_hip", "-Wl,-rpath," + libdir])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "OK", r.stdout + r.stderr
@@ -87,6 +90,7 @@ def test_facade_end_to_end_selftest(lm, tmp_path):
                            os.path.join(ROOT, "tests", "cpp", "facade_selftest.cpp"),
                            os.path.join(ROOT, "line-mod-pipeline_amd", "host", "HighLevelLinemod.cpp"),
                            os.path.join(ROOT, "line-mod-pipeline_amd", "host", "PostProcess.cpp"),
+                           os.path.join(ROOT, "line-mod-pipeline_amd", "host", "TemplateGenerator.cpp"),
                            "-L" + libdir, "-llinemod_hip", "-Wl,-rpath," + libdir])
     r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -104,3 +108,42 @@ def test_facade_end_to_end_selftest(lm, tmp_path):
     assert abs(t[0] - 40 * t[2] / 1045.69141) < 4.0 and abs(t[1] - 30 * t[2] / 1045.69141) < 4.0
     assert bb[2] > 100 and bb[3] > 80
     assert "reloaded classes 1 templates 1" in r.stdout and "reloaded found 1 groups 1" in r.stdout
+
+
+@pytest.mark.gpu
+def test_reference_benchmark_pose0(lm, frame0, tmp_path):
+    """The reference's only result fixture: benchmark/img0.png + depth0.png with ground
+    truth benchmark/pose0.yml.  Templates of models/lagergehaeuse.ply are rendered with the software
+    stand-ins (13 viewpoints x 4 radii x 10 in-plane rotations), the part is detected with the SHIPPED
+    configuration (colour-only modality, threshold 80, linemod_settings.yml) and the pose must agree with
+    the ground truth (position within 10 mm; the part is rotationally symmetric, so only its axis is
+    compared: within 15 degrees)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "lagergehaeuse.npz"))
+    bgr, depth = frame0
+    with open(tmp_path / "mesh.bin", "wb") as fh:
+        fh.write(np.array([len(g["vertices"]), len(g["faces"])], np.uint32).tobytes())
+        fh.write(g["vertices"].astype(np.float32).tobytes())
+        fh.write(g["faces"].astype(np.int32).tobytes())
+    bgr.tofile(tmp_path / "bgr.raw")
+    depth.tofile(tmp_path / "depth.raw")
+    exe = str(tmp_path / "pose_e2e")
+    libdir = os.path.dirname(lm.LIB_PATH)
+    host = os.path.join(ROOT, "line-mod-pipeline_amd", "host")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(ROOT, "tests", "cpp", "pose_e2e.cpp"),
+                           os.path.join(host, "HighLevelLinemod.cpp"), os.path.join(host, "PostProcess.cpp"),
+                           os.path.join(host, "TemplateGenerator.cpp"), "-L" + libdir, "-llinemod_hip",
+                           "-Wl,-rpath," + libdir])
+    r = subprocess.run([exe, "mesh.bin", "bgr.raw", "depth.raw", "1", "550", "700", "80"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = [l for l in r.stdout.splitlines() if not l.startswith("ERROR")]
+    assert out[0] == "templates 520"
+    assert out[1].startswith("found 1")
+    poses = [l.split() for l in out if l.startswith("pose ")]
+    assert len(poses) >= 1
+    t = np.array([float(v) for v in poses[0][2:5]])
+    axis = np.array([float(v) for v in poses[0][16:19]])
+    gt_axis = g["gt_rotation"][:, 1]                       # the model's symmetry axis (y) in camera coordinates
+    assert np.linalg.norm(t - g["gt_position"]) < 10.0, (t, g["gt_position"])
+    ang = np.degrees(np.arccos(min(1.0, abs(float(axis @ gt_axis)) / np.linalg.norm(axis))))
+    assert ang < 15.0, ang
