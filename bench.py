@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="frames per step (resident in HBM)")
     ap.add_argument("--templates", type=int, default=3000, help="templates per GPU")
     ap.add_argument("--threshold", type=float, default=80.0)
+    ap.add_argument("--byte-responses", action="store_true", help="LM_FLAG_BYTE_RESPONSES: byte scan kernel (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     args = ap.parse_args()
@@ -74,7 +75,7 @@ def main():
     W, H, M, B = 640, 480, 2, args.batch
     n_total = args.templates * world
     cfg = lm.default_config(color_only=False, width=W, height=H, device=local_rank, shard_rank=rank,
-                            shard_size=world, frame_slots=max(B, 1))
+                            shard_size=world, frame_slots=max(B, 1), flags=1 if args.byte_responses else 0)
     det = lm.Detector(cfg)
 
     # ---- workload: seeded synthetic frames + fixed-geometry bank

@@ -63,7 +63,12 @@ typedef struct lm_config {
     int32_t max_candidates;       /* capacity of the device candidate buffer (0 = default 1<<20)             */
     int32_t max_matches;          /* capacity of the device match buffer     (0 = default 1<<18)             */
     int32_t frame_slots;          /* resident-frame slots for lm_match_batch (0 = default 8)                 */
+    int32_t flags;                /* LM_FLAG_* (0 = defaults)                                                */
 } lm_config;
+
+/* Keep the lowest pyramid level's response memories at one byte per position (upstream's layout) instead
+ * of the default two positions per byte.  Results are identical; this only selects the scan kernel. */
+#define LM_FLAG_BYTE_RESPONSES 1
 
 typedef struct lm_detector lm_detector;
 

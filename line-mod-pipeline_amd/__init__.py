@@ -31,7 +31,9 @@ class Config(C.Structure):
                 ("difference_threshold", C.c_int32), ("depth_num_features", C.c_int32),
                 ("extract_threshold", C.c_int32), ("device", C.c_int32), ("shard_rank", C.c_int32),
                 ("shard_size", C.c_int32), ("max_candidates", C.c_int32), ("max_matches", C.c_int32),
-                ("frame_slots", C.c_int32)]
+                ("frame_slots", C.c_int32), ("flags", C.c_int32)]
+
+FLAG_BYTE_RESPONSES = 1
 
 
 class Rect(C.Structure):

@@ -34,7 +34,9 @@ struct LmLevelGeom {
     int W, H;          // w/T, h/T
     int spread_only;   // 0: lowest level, 8 response memories per modality (scan); 1: refinement level,
                        //    one spread linear memory per modality (response LUT applied in k_refine)
-    u32 wh;            // W*H = bytes per linear memory
+    int nibble;        // lowest level only: response memories packed two positions per byte (position 2k in
+                       //    the low nibble of byte k); strides below stay in bytes, bank offsets are in nibbles
+    u32 wh;            // W*H = positions per linear memory
     u32 ori_stride;    // response arena: T*T*wh (256-aligned) + pad; unused for spread arenas
     u32 mod_stride;    // response arena: 8*ori_stride; spread arena: T*T*wh (256-aligned) + pad
     u32 zero_off;      // offset (inside the level arena) of a zero block of `pad` bytes

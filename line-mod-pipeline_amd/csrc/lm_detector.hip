@@ -247,7 +247,7 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
     if (M == 2 && L > 2) enqueue_depth_pyramid(d, first, n);
     for (int l = 0; l < L; ++l) {
         const LmLevelGeom& g = d->geom[l];
-        const bool sp = g.spread_only != 0;
+        const int sp = g.spread_only ? 1 : g.nibble ? 2 : 0;
         lmk_linear_memories(d->stream, d->quant(first, l, 0), g.w, 0, sp, g.w, g.h, g.T, d->d_resp_tab, d->lm(first, l),
                             g.ori_stride, fs, fs, n);
         if (M == 2) {
@@ -284,7 +284,7 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r) {
     a.item_t = d->d_item_t; a.item_chunk = d->d_item_chunk;
     a.item_lo = r.lo; a.n_items = r.n;
     a.scan_off = d->d_scan_off; a.scan_P = d->d_scan_P; a.scan_n = d->d_scan_n;
-    a.M = d->cfg.num_modalities; a.fpad = d->hb.fpad;
+    a.M = d->cfg.num_modalities; a.fpad = d->hb.fpad; a.nibble = g.nibble;
     a.raw_thr_by_n = d->d_raw_thr;
     a.W = g.W; a.T = g.T;
     a.hdr = reinterpret_cast<LmDevHeader*>(d->aux(first, d->off_hdr));
@@ -533,13 +533,15 @@ int lm_create(const lm_config* cfg, lm_detector** out) {
         // pad: one full linear memory (a scan may start W*H-1 bytes into the last memory and read
         // template_positions <= W*H bytes) + the 16-row patch of the refinement + vector-load slack
         size_t pad = align_up((size_t)g.wh + 16 * (size_t)g.W + 2 * LM_SCAN_CHUNK + 64, 256);
-        size_t ori = align_up((size_t)T * T * g.wh, 256) + pad;
         // the lowest level is scanned (8 response memories per modality); the levels above it are only
         // refined at and keep one spread linear memory per modality (1/8 of the bytes)
         g.spread_only = (l + 1 < c.pyramid_levels) ? 1 : 0;
+        // responses are <= 4: the scanned level packs two positions per byte when the linearize fast path applies
+        g.nibble = (!g.spread_only && !(c.flags & LM_FLAG_BYTE_RESPONSES) && lmk_nibble_supported(w, h, T)) ? 1 : 0;
+        size_t ori = align_up(((size_t)T * T * g.wh) >> g.nibble, 256) + pad;
         size_t mod = g.spread_only ? ori : 8 * ori;
         size_t arena = (size_t)c.num_modalities * mod + pad;
-        if (arena > (g.spread_only ? 0x1FFFFFFFull : 0xFFFFFFFFull)) { delete d; return fail(LM_ERR_INVALID, "frame too large for the arena offset encoding"); }
+        if (arena > (g.spread_only ? 0x1FFFFFFFull : g.nibble ? 0x7FFFFFFFull : 0xFFFFFFFFull)) { delete d; return fail(LM_ERR_INVALID, "frame too large for the arena offset encoding"); }
         g.ori_stride = (u32)ori;
         g.mod_stride = (u32)mod;
         g.zero_off = (u32)((size_t)c.num_modalities * g.mod_stride);
@@ -829,7 +831,7 @@ int lm_stage_linear_memories(lm_detector* d, const uint8_t* quantized, int w, in
     u8* base = static_cast<u8*>(d->d_scratch);
     hipStream_t st = d->stream;
     HIP_TRY(hipMemcpyAsync(base, quantized, px, hipMemcpyHostToDevice, st));
-    lmk_linear_memories(st, base, w, 0, false, w, h, T, d->d_resp_tab, base + o_l, (u32)px, 0, 0, 1);  // dense: ori_stride = T*T*W*H
+    lmk_linear_memories(st, base, w, 0, 0, w, h, T, d->d_resp_tab, base + o_l, (u32)px, 0, 0, 1);  // dense: ori_stride = T*T*W*H
     HIP_TRY(hipMemcpyAsync(out, base + o_l, 8 * px, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
@@ -888,6 +890,13 @@ int lm_debug_read(lm_detector* d, int slot, int what, int level, int modality, u
                 for (int o = 0; o < 8; ++o)
                     for (size_t i = 0; i < blk; ++i)
                         out[o * blk + i] = std::max(d->sim_lut[32 * o + (sp[i] & 15)], d->sim_lut[32 * o + 16 + (sp[i] >> 4)]);
+            } else if (g.nibble) {
+                std::vector<u8> pk(blk / 2);
+                for (int o = 0; o < 8; ++o) {
+                    HIP_TRY(hipMemcpy(pk.data(), d->lm(slot, level) + (size_t)modality * g.mod_stride + (size_t)o * g.ori_stride,
+                                      blk / 2, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < blk / 2; ++i) { out[o * blk + 2 * i] = pk[i] & 15; out[o * blk + 2 * i + 1] = pk[i] >> 4; }
+                }
             } else {
                 for (int o = 0; o < 8; ++o)
                     HIP_TRY(hipMemcpy(out + o * blk, d->lm(slot, level) + (size_t)modality * g.mod_stride + (size_t)o * g.ori_stride, blk,

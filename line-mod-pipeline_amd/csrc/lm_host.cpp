@@ -81,7 +81,10 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
     for (const ClassEntry& c : bank.classes)
         for (const TemplatePyramid& tp : c.pyramids)
             for (int m = 0; m < M; ++m) maxf = std::max(maxf, (int)tp[(size_t)(L - 1) * M + m].features.size());
-    out.fpad = (maxf + LM_SCAN_FPAD - 1) / LM_SCAN_FPAD * LM_SCAN_FPAD;
+    // byte scan: lists padded to LM_SCAN_FPAD; nibble scan (k_scan4): to a multiple of 3, offsets in nibbles
+    const int fq = gl.nibble ? 3 : LM_SCAN_FPAD;
+    const u32 osc = gl.nibble ? 2u : 1u;
+    out.fpad = (maxf + fq - 1) / fq * fq;
     const int nc = (int)bank.classes.size();
     out.class_item_lo.assign(nc, 0); out.class_item_hi.assign(nc, 0);
     out.class_t_lo.assign(nc, 0); out.class_t_hi.assign(nc, 0);
@@ -118,13 +121,13 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
                 int k = 0;
                 for (const lm_feature& f : t.features) {
                     if (f.x < 0 || f.x >= gl.w || f.y < 0 || f.y >= gl.h) continue;  // similarity(): "discard feature if out of bounds"
-                    u32 off = (u32)m * gl.mod_stride + (u32)f.label * gl.ori_stride +
+                    u32 off = osc * ((u32)m * gl.mod_stride + (u32)f.label * gl.ori_stride) +
                               (u32)((f.y % gl.T) * gl.T + (f.x % gl.T)) * gl.wh + (u32)(f.y / gl.T) * gl.W + (u32)(f.x / gl.T);
                     out.scan_off.push_back(off);
                     ++k;
                 }
                 fcount += k;
-                for (; k < out.fpad; ++k) out.scan_off.push_back(gl.zero_off);
+                for (; k < out.fpad; ++k) out.scan_off.push_back(osc * gl.zero_off);
             }
             out.scan_P.push_back(P);
             out.scan_n.push_back(n_total);

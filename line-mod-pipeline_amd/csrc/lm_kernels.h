@@ -22,7 +22,10 @@ void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_
 // q is the quantised image to read with row pitch qpitch: src_shift 0 = this level's image, 1 = the finer
 // level's image sampled at (2y, 2x).  lm points at the modality's first orientation block.
 // spread_only: write one spread linear memory (refinement levels) instead of 8 response memories.
-void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, bool spread_only, int w, int h, int T,
+// mode 0: 8 response memories (1 byte per position); 1: one spread memory; 2: response memories packed two
+// positions per byte for the nibble scan (only when lmk_nibble_supported).
+bool lmk_nibble_supported(int w, int h, int T);
+void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, int mode, int w, int h, int T,
                          const u64* resp_tab, u8* lm, u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
                          int nslots);
 
@@ -32,6 +35,7 @@ struct LmScanArgs {
     const u32* item_t;       // work items: bank-local template index
     const u32* item_chunk;   //             chunk of LM_SCAN_CHUNK positions
     int item_lo, n_items;
+    int nibble;              // 1: two positions per byte (k_scan4), scan_off in nibbles, fpad % 3 == 0
     const u32* scan_off;     // [nt][M][fpad] byte offsets into the arena
     const int* scan_P;       // [nt] template_positions
     const int* scan_n;       // [nt] total number of features at the lowest level

@@ -309,6 +309,40 @@ __global__ __launch_bounds__(256) void k_cblur_v(const u16* __restrict__ hb0, in
     if (j >= ncol) return;
     const int y0 = blockIdx.y * CV_ROWS;
     const size_t pitch = (size_t)w * 3;
+    if (y0 >= 4 && y0 + CV_ROWS + 4 <= h) {
+        // interior band (block-uniform): no clamping anywhere, so every hb row is loaded once into
+        // registers and the CV_ROWS + 2 smoothed rows come from that window
+        u32 v[CV_ROWS + 8][4];
+#pragma unroll
+        for (int i = 0; i < CV_ROWS + 8; ++i) {
+            const u32* p = reinterpret_cast<const u32*>(hb + (size_t)(y0 - 4 + i) * pitch + 4 * j);
+            const u32 a = p[0], b = p[1];
+            v[i][0] = a & 0xFFFFu; v[i][1] = a >> 16; v[i][2] = b & 0xFFFFu; v[i][3] = b >> 16;
+        }
+        int s[CV_ROWS + 2][4];
+#pragma unroll
+        for (int r = 0; r < CV_ROWS + 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32 acc = 8u * (v[r][k] + v[r + 6][k]) + 28u * (v[r + 1][k] + v[r + 5][k]) +
+                                56u * (v[r + 2][k] + v[r + 4][k]) + 72u * v[r + 3][k];
+                s[r][k] = (int)((acc + 32768u) >> 16);
+            }
+#pragma unroll
+        for (int r = 0; r < CV_ROWS; ++r) {
+            const int y = y0 + r;
+            u32* ovs = reinterpret_cast<u32*>(vs + (size_t)y * pitch + 4 * j);
+            u32* ovd = reinterpret_cast<u32*>(vd + (size_t)y * pitch + 4 * j);
+            int a[4], d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[k] = s[r][k] + 2 * s[r + 1][k] + s[r + 2][k]; d[k] = s[r + 2][k] - s[r][k]; }
+            ovs[0] = (u32)(a[0] & 0xFFFF) | ((u32)a[1] << 16);
+            ovs[1] = (u32)(a[2] & 0xFFFF) | ((u32)a[3] << 16);
+            ovd[0] = (u32)(d[0] & 0xFFFF) | ((u32)d[1] << 16);
+            ovd[1] = (u32)(d[2] & 0xFFFF) | ((u32)d[3] << 16);
+        }
+        return;
+    }
     int sm1[4] = {0, 0, 0, 0}, s0[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = -1; r <= CV_ROWS; ++r) {
@@ -628,7 +662,9 @@ __global__ __launch_bounds__(256) void k_linear_memories(const u8* __restrict__ 
 // shifts by v_alignbyte_b32).  Needs w, W and the source pitch to be multiples of 4; everything else
 // goes through the generic k_linear_memories above.
 // ------------------------------------------------------------------------------------------------
-template <int T, int SEG, int SRC_SHIFT, bool SPREAD_ONLY>
+// MODE 0: 8 response memories, one byte per position; 1: one spread memory; 2: 8 response memories packed
+// two positions per byte (responses are <= 4; position 2k in the low nibble of byte k) for k_scan4.
+template <int T, int SEG, int SRC_SHIFT, int MODE>
 __global__ __launch_bounds__(256) void k_lm_fast(const u8* __restrict__ q0, int qpitch, int w, int h,
                                                   const u64* __restrict__ resp_tab, u8* __restrict__ lm0,
                                                   u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride) {
@@ -637,6 +673,7 @@ __global__ __launch_bounds__(256) void k_lm_fast(const u8* __restrict__ q0, int 
     constexpr int NDW = (TW + T - 1 + 3) / 4;      // source dwords per row including the right halo
     constexpr int PD = NDW + 2;                    // LDS pitch in dwords: two zero dwords for the funnel reads
     constexpr int NLOAD = (ROWS * PD + 255) / 256;
+    constexpr bool SPREAD_ONLY = MODE == 1;
     __shared__ u64 tab[SPREAD_ONLY ? 1 : 256];
     __shared__ u32 qs[ROWS][PD];
     __shared__ u32 ho[ROWS][PD];
@@ -700,6 +737,34 @@ __global__ __launch_bounds__(256) void k_lm_fast(const u8* __restrict__ q0, int 
         sp[j][c] = v;
     }
     __syncthreads();
+    if (MODE == 2) {
+        // linearize, nibble-packed: unit = (row-in-band j, column phase c0, 8 consecutive memory columns)
+        constexpr int C8 = SEG / 8;
+        for (int u = tid; u < T * T * C8; u += 256) {
+            const int k8 = u % C8, g = u / C8;
+            const int j = g / T, c0 = g - j * T;
+            if (8 * k8 >= ncols) continue;
+            const u8* row = reinterpret_cast<const u8*>(&sp[j][0]);
+            u64 e[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)   // byte o of e[i] = response o of columns 2i (low nibble) and 2i+1
+                e[i] = tab[row[(8 * k8 + 2 * i) * T + c0]] | (tab[row[(8 * k8 + 2 * i + 1) * T + c0]] << 4);
+            const u32 a0 = (u32)e[0], a1 = (u32)e[1], a2 = (u32)e[2], a3 = (u32)e[3];
+            const u32 b0 = (u32)(e[0] >> 32), b1 = (u32)(e[1] >> 32), b2 = (u32)(e[2] >> 32), b3 = (u32)(e[3] >> 32);
+            u8* dst = lm + (((size_t)g * wh + (size_t)band * W + col0 + 8 * k8) >> 1);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const u32 sel = (u32)o | ((u32)(o + 4) << 8);
+                u32 lo = __builtin_amdgcn_perm(a1, a0, sel) & 0xFFFFu;
+                u32 hi = __builtin_amdgcn_perm(a3, a2, sel) << 16;
+                *reinterpret_cast<u32*>(dst + (size_t)o * ori_stride) = lo | hi;
+                u32 lo2 = __builtin_amdgcn_perm(b1, b0, sel) & 0xFFFFu;
+                u32 hi2 = __builtin_amdgcn_perm(b3, b2, sel) << 16;
+                *reinterpret_cast<u32*>(dst + (size_t)(o + 4) * ori_stride) = lo2 | hi2;
+            }
+        }
+        return;
+    }
     // linearize: unit = (row-in-band j, column phase c0, 4 consecutive memory columns)
     constexpr int C4 = SEG / 4;
     for (int u = tid; u < T * T * C4; u += 256) {
@@ -828,6 +893,109 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
             cd.y = r * a.T + offset;
             cd.sim = __fadd_rn(__fdiv_rn(__fmul_rn((float)raw, 100.f), (float)(4 * n)), 0.5f);
             cand[slot] = cd;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a11-a13, nibble form of the hot kernel (LmLevelGeom::nibble): responses are <= 4, so the lowest
+// level stores two positions per byte and a feature costs the wave 512 B instead of 1 KiB.  Same
+// decomposition as k_scan (lane l < 63 owns 16 positions = 8 bytes = 2 dwords); bank offsets are in
+// nibbles, the load address is rounded down to a dword and the 0..7 nibble shift is undone with
+// v_alignbit_b32 (the 17th.. nibble comes from the next lane by DPP).  Three features are added
+// nibble-wise (3 * 4 = 12 < 16), then split into even / odd positions and added byte-wise (63 * 4 = 252).
+// Feature lists are padded to a multiple of 3.
+// ------------------------------------------------------------------------------------------------
+template <bool XCD_MAP>
+__global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
+    const int lane = threadIdx.x & 63;
+    u32 slot, wg;
+    if (XCD_MAP) {
+        const u32 G = (u32)a.wgs_per_slot, B = (u32)a.nslots;
+        const u32 b = blockIdx.x, x = b & 7u, k = b >> 3;
+        if ((B & 7u) == 0) { slot = x + 8u * (k / G); wg = k % G; }
+        else { const u32 r = 8u / B; slot = x % B; wg = k * r + x / B; }
+        if (wg >= G || slot >= B) return;
+    } else {
+        slot = blockIdx.z; wg = blockIdx.x;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane((int)((wg * 256u + threadIdx.x) >> 6));
+    if (wave >= a.n_items) return;
+    const u32 ti = a.item_t[a.item_lo + wave];
+    const u32 chunk = a.item_chunk[a.item_lo + wave];
+    const int P = a.scan_P[ti];
+    const int n = a.scan_n[ti];
+    const int thr = a.raw_thr_by_n[n];
+    const u32 j0 = chunk * LM_SCAN_CHUNK + (u32)lane * 16u;
+    const u8* base = a.lm + (size_t)slot * a.lm_slot_stride + (j0 >> 1);
+    LmDevHeader* hdr = reinterpret_cast<LmDevHeader*>(reinterpret_cast<u8*>(a.hdr) + (size_t)slot * a.aux_slot_stride);
+    LmCand* cand = reinterpret_cast<LmCand*>(reinterpret_cast<u8*>(a.cand) + (size_t)slot * a.aux_slot_stride);
+
+    // u16 pairs: position 8k + i of the lane lives in t[k][i & 3], half i >> 2
+    u32 t[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int m = 0; m < a.M; ++m) {
+        const u32* offs = a.scan_off + ((size_t)ti * a.M + m) * a.fpad;
+        u32 bl[2] = {0, 0}, bh[2] = {0, 0};   // byte lanes: even / odd positions of dword k
+#define LM_SCAN4_BLOCK(NF)                                                                   \
+        {                                                                                    \
+            u32x2 v[NF];                                                                     \
+            u32 sh[NF];                                                                      \
+            _Pragma("unroll") for (int k = 0; k < NF; ++k) {                                 \
+                const u32 o = offs[f + k];                                                   \
+                sh[k] = (o & 7u) << 2;                                                       \
+                v[k] = ld8a4(base + ((o >> 3) << 2));                                        \
+            }                                                                                \
+            _Pragma("unroll") for (int g3 = 0; g3 < NF; g3 += 3) {                           \
+                u32 n0 = 0, n1 = 0;                                                          \
+                _Pragma("unroll") for (int k = g3; k < g3 + 3; ++k) {                        \
+                    const u32 nx = next_lane(v[k][0]);                                       \
+                    n0 += __builtin_amdgcn_alignbit(v[k][1], v[k][0], sh[k]);                \
+                    n1 += __builtin_amdgcn_alignbit(nx, v[k][1], sh[k]);                     \
+                }                                                                            \
+                bl[0] += n0 & 0x0F0F0F0Fu; bh[0] += (n0 >> 4) & 0x0F0F0F0Fu;                 \
+                bl[1] += n1 & 0x0F0F0F0Fu; bh[1] += (n1 >> 4) & 0x0F0F0F0Fu;                 \
+            }                                                                                \
+        }
+        int f = 0;
+        for (; f + 12 <= a.fpad; f += 12) LM_SCAN4_BLOCK(12)
+        for (; f < a.fpad; f += 3) LM_SCAN4_BLOCK(3)
+#undef LM_SCAN4_BLOCK
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            t[k][0] += bl[k] & 0x00FF00FFu; t[k][2] += (bl[k] >> 8) & 0x00FF00FFu;
+            t[k][1] += bh[k] & 0x00FF00FFu; t[k][3] += (bh[k] >> 8) & 0x00FF00FFu;
+        }
+    }
+    u32 hit = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int sv = (i >> 2) ? (int)(t[k][i & 3] >> 16) : (int)(t[k][i & 3] & 0xFFFF);
+            hit |= (sv > thr ? 1u : 0u) << (8 * k + i);
+        }
+    int valid = P - (int)j0;
+    if (lane == 63) valid = 0;
+    if (valid <= 0) hit = 0;
+    else if (valid < 16) hit &= (1u << valid) - 1u;
+    if (!__any(hit != 0)) return;
+    const int offset = a.T / 2 + (a.T % 2 - 1);
+    while (hit) {
+        const int b = __ffs(hit) - 1;
+        hit &= hit - 1;
+        const u32 tv = (b & 8) ? ((b & 3) == 0 ? t[1][0] : (b & 3) == 1 ? t[1][1] : (b & 3) == 2 ? t[1][2] : t[1][3])
+                               : ((b & 3) == 0 ? t[0][0] : (b & 3) == 1 ? t[0][1] : (b & 3) == 2 ? t[0][2] : t[0][3]);
+        const int raw = (b & 4) ? (int)(tv >> 16) : (int)(tv & 0xFFFF);
+        const int j = (int)j0 + b;
+        const int r = j / a.W, c = j - r * a.W;
+        const u32 pos = atomicAdd(&hdr->cand_count, 1u);
+        if (pos < a.cand_cap) {
+            LmCand cd;
+            cd.ti = ti;
+            cd.x = c * a.T + offset;
+            cd.y = r * a.T + offset;
+            cd.sim = __fadd_rn(__fdiv_rn(__fmul_rn((float)raw, 100.f), (float)(4 * n)), 0.5f);
+            cand[pos] = cd;
         }
     }
 }
@@ -1139,27 +1307,34 @@ void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_
 }
 
 template <int T, int SEG>
-static void lm_fast_launch(hipStream_t s, const u8* q, int qpitch, int src_shift, bool spread_only, int w, int h,
+static void lm_fast_launch(hipStream_t s, const u8* q, int qpitch, int src_shift, int mode, int w, int h,
                            const u64* resp_tab, u8* lm, u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
                            int nslots) {
     const int W = w / T;
     dim3 grid((W + SEG - 1) / SEG, h / T, nslots);
-#define LMF(SH, SP)                                                                                           \
-    hipLaunchKernelGGL((k_lm_fast<T, SEG, SH, SP>), grid, dim3(256), 0, s, q, qpitch, w, h, resp_tab, lm, ori_stride, \
+#define LMF(SH, MD)                                                                                           \
+    hipLaunchKernelGGL((k_lm_fast<T, SEG, SH, MD>), grid, dim3(256), 0, s, q, qpitch, w, h, resp_tab, lm, ori_stride, \
                        q_slot_stride, lm_slot_stride)
-    if (src_shift) { if (spread_only) LMF(1, true); else LMF(1, false); }
-    else           { if (spread_only) LMF(0, true); else LMF(0, false); }
+    if (src_shift) { if (mode == 1) LMF(1, 1); else if (mode == 2) LMF(1, 2); else LMF(1, 0); }
+    else           { if (mode == 1) LMF(0, 1); else if (mode == 2) LMF(0, 2); else LMF(0, 0); }
 #undef LMF
 }
 
-void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, bool spread_only, int w, int h, int T,
+bool lmk_nibble_supported(int w, int h, int T) {
+    (void)h;
+    const int W = w / T;
+    return (T == 2 || T == 4 || T == 5 || T == 8) && (w % 4 == 0) && (W % 8 == 0);
+}
+
+void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, int mode, int w, int h, int T,
                          const u64* resp_tab, u8* lm, u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
                          int nslots) {
     const int W = w / T;
+    const bool spread_only = mode == 1;
     const bool aligned = (w % 4 == 0) && (W % 4 == 0) && (qpitch % 4 == 0) && (((uintptr_t)q & 3) == 0) &&
                          (q_slot_stride % 4 == 0);
     if (aligned) {
-#define LMF_ARGS s, q, qpitch, src_shift, spread_only, w, h, resp_tab, lm, ori_stride, q_slot_stride, lm_slot_stride, nslots
+#define LMF_ARGS s, q, qpitch, src_shift, mode, w, h, resp_tab, lm, ori_stride, q_slot_stride, lm_slot_stride, nslots
         switch (T) {
             case 2: lm_fast_launch<2, 128>(LMF_ARGS); return;
             case 4: lm_fast_launch<4, 64>(LMF_ARGS); return;
@@ -1198,6 +1373,11 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
     const bool xcd = !(variant & 4) && (nslots == 1 || nslots == 2 || nslots == 4 || (nslots % 8) == 0);
     dim3 grid = xcd ? dim3(((nslots % 8) == 0) ? (unsigned)(G * nslots) : 8u * (unsigned)((G + 8 / nslots - 1) / (8 / nslots)))
                     : dim3(G, 1, nslots);
+    if (a.nibble) {
+        if (xcd) hipLaunchKernelGGL((k_scan4<true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_scan4<false>), grid, dim3(256), 0, s, a);
+        return;
+    }
     const int u = variant & 3;
 #define SCAN_LAUNCH(U)                                                                      \
     do { if (xcd) hipLaunchKernelGGL((k_scan<U, true>), grid, dim3(256), 0, s, a);  \

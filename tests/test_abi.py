@@ -180,4 +180,4 @@ def test_merge_matches_equals_oracle_merge(lm, orc):
 
 def test_struct_layouts(lm, orc):
     assert lm.MATCH_DTYPE.itemsize == 20 and lm.FEATURE_DTYPE.itemsize == 12 and lm.DESC_DTYPE.itemsize == 16
-    assert C.sizeof(lm.Config) == 4 * 21   # 21 int32/float fields of lm_config
+    assert C.sizeof(lm.Config) == 4 * 22   # 22 int32/float fields of lm_config

@@ -65,16 +65,18 @@ def test_known_answer_via_gpu_add_template(lm, orc, frame0, color_only):
     d.close()
 
 
-@pytest.mark.parametrize("color_only,size,n,thr", [
-    (False, (640, 480), 300, 80.0),
-    (False, (640, 480), 300, 55.0),
-    (True, (640, 480), 300, 70.0),
-    (True, (1280, 960), 200, 75.0),
+@pytest.mark.parametrize("color_only,size,n,thr,flags", [
+    (False, (640, 480), 300, 80.0, 0),
+    (False, (640, 480), 300, 55.0, 0),
+    (True, (640, 480), 300, 70.0, 0),
+    (True, (1280, 960), 200, 75.0, 0),
+    (False, (640, 480), 300, 55.0, 1),     # LM_FLAG_BYTE_RESPONSES: byte scan kernel
+    (True, (640, 480), 300, 70.0, 1),
 ])
-def test_synthetic_bank_parity(lm, orc, synth, color_only, size, n, thr):
+def test_synthetic_bank_parity(lm, orc, synth, color_only, size, n, thr, flags):
     """Seeded synthetic frame + bank (10 % crops of the frame so real matches exist)."""
     bgr, depth = synth.make_frame(size[0], size[1], seed=1234)
-    d, o = _pair(lm, orc, color_only, size)
+    d, o = _pair(lm, orc, color_only, size, flags=flags)
     q = _quantized(o, bgr, depth, color_only)
     M = 1 if color_only else 2
     descs, feats, crops = synth.make_bank(n, M, 2, seed=4321, quantized=q, crop_fraction=0.15, frame_size=size,

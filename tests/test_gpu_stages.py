@@ -114,15 +114,16 @@ def test_linear_memories_custom_lut(lm, orc):
     d.close()
 
 
+@pytest.mark.parametrize("flags", [0, 1])   # 0: nibble-packed responses on the scanned level, 1: LM_FLAG_BYTE_RESPONSES
 @pytest.mark.parametrize("color_only,size", [(False, (640, 480)), (True, (640, 480)), (True, (1280, 960))])
-def test_full_preprocess_parity(lm, orc, synth, frame0, color_only, size):
+def test_full_preprocess_parity(lm, orc, synth, frame0, color_only, size, flags):
     """a3-a10 end to end on a resident frame: quantised images and all linear memories, every level."""
     w, h = size
     if size == (640, 480):
         bgr, depth = frame0
     else:
         bgr, depth = synth.make_frame(w, h, seed=77)
-    d = lm.Detector(color_only=color_only, width=w, height=h)
+    d = lm.Detector(color_only=color_only, width=w, height=h, flags=flags)
     o = orc.Detector(color_only=color_only)
     d.upload_frame(0, bgr, None if color_only else depth)
     d.prepare_slot(0)
