@@ -119,6 +119,7 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
                 if (P > (int)gl.wh) P = (int)gl.wh;
                 if (P < 0) P = 0;
                 int k = 0;
+                const size_t list_begin = out.scan_off.size();
                 for (const lm_feature& f : t.features) {
                     if (f.x < 0 || f.x >= gl.w || f.y < 0 || f.y >= gl.h) continue;  // similarity(): "discard feature if out of bounds"
                     u32 off = osc * ((u32)m * gl.mod_stride + (u32)f.label * gl.ori_stride) +
@@ -127,6 +128,10 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
                     ++k;
                 }
                 fcount += k;
+                // the sum is order-independent: ascending offsets make the waves resident on one CU (they start
+                // together and step through their lists in step) read from the same few linear memories at a
+                // time, so part of the traffic is served by the CU's L1 instead of L2
+                std::sort(out.scan_off.begin() + (ptrdiff_t)list_begin, out.scan_off.end());
                 for (; k < out.fpad; ++k) out.scan_off.push_back(osc * gl.zero_off);
             }
             out.scan_P.push_back(P);

@@ -43,9 +43,10 @@ struct __attribute__((packed, aligned(4))) U32x4A4 { u32x4 v; };
 struct __attribute__((packed, aligned(4))) U32x2A4 { u32x2 v; };
 __device__ __forceinline__ u32x4 ld16a4(const u8* p) { return reinterpret_cast<const U32x4A4*>(p)->v; }
 __device__ __forceinline__ u32x2 ld8a4(const u8* p) { return reinterpret_cast<const U32x2A4*>(p)->v; }
-// value of lane + 1 (0 for lane 63): v_mov_b32_dpp wave_shl:1
+// value of lane + 1 (0 for lane 63): v_mov_b32_dpp wave_shl:1 bound_ctrl:1 -- every lane is written, so the
+// destination needs no initialisation
 __device__ __forceinline__ u32 next_lane(u32 v) {
-    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+    return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true);
 }
 
 template <typename T>
@@ -832,7 +833,10 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
     const int n = a.scan_n[ti];
     const int thr = a.raw_thr_by_n[n];
     const u32 j0 = chunk * LM_SCAN_CHUNK + (u32)lane * 16u;
-    const u8* base = a.lm + (size_t)slot * a.lm_slot_stride + j0;
+    // buffer addressing: descriptor base = this wave's chunk, voffset = the lane's 16 bytes, soffset = feature
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u8*>(a.lm + (size_t)slot * a.lm_slot_stride + (size_t)(chunk * LM_SCAN_CHUNK)), 0, 0x7FFFFFFF, 0x00020000);
+    const u32 lane_off = (u32)lane * 16u;
     LmDevHeader* hdr = reinterpret_cast<LmDevHeader*>(reinterpret_cast<u8*>(a.hdr) + (size_t)slot * a.aux_slot_stride);
     LmCand* cand = reinterpret_cast<LmCand*>(reinterpret_cast<u8*>(a.cand) + (size_t)slot * a.aux_slot_stride);
 
@@ -847,7 +851,7 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
             for (int k = 0; k < UNROLL; ++k) {
                 const u32 o = offs[f + k];
                 sh[k] = o & 3u;
-                v[k] = ld16a4(base + (o & ~3u));
+                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, o & ~3u, 0);
             }
 #pragma unroll
             for (int k = 0; k < UNROLL; ++k) {
@@ -906,7 +910,7 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
 // nibble-wise (3 * 4 = 12 < 16), then split into even / odd positions and added byte-wise (63 * 4 = 252).
 // Feature lists are padded to a multiple of 3.
 // ------------------------------------------------------------------------------------------------
-template <bool XCD_MAP>
+template <int FB, bool XCD_MAP>
 __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
     const int lane = threadIdx.x & 63;
     u32 slot, wg;
@@ -927,7 +931,11 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
     const int n = a.scan_n[ti];
     const int thr = a.raw_thr_by_n[n];
     const u32 j0 = chunk * LM_SCAN_CHUNK + (u32)lane * 16u;
-    const u8* base = a.lm + (size_t)slot * a.lm_slot_stride + (j0 >> 1);
+    // buffer addressing: descriptor base = this wave's chunk (SGPRs), voffset = the lane's 8 bytes, soffset =
+    // the feature's dword-aligned byte offset -- the per-feature address costs no VALU instruction
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u8*>(a.lm + (size_t)slot * a.lm_slot_stride + (size_t)((chunk * LM_SCAN_CHUNK) >> 1)), 0, 0x7FFFFFFF, 0x00020000);
+    const u32 lane_off = (u32)lane * 8u;
     LmDevHeader* hdr = reinterpret_cast<LmDevHeader*>(reinterpret_cast<u8*>(a.hdr) + (size_t)slot * a.aux_slot_stride);
     LmCand* cand = reinterpret_cast<LmCand*>(reinterpret_cast<u8*>(a.cand) + (size_t)slot * a.aux_slot_stride);
 
@@ -943,7 +951,7 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
             _Pragma("unroll") for (int k = 0; k < NF; ++k) {                                 \
                 const u32 o = offs[f + k];                                                   \
                 sh[k] = (o & 7u) << 2;                                                       \
-                v[k] = ld8a4(base + ((o >> 3) << 2));                                        \
+                v[k] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_off, (o >> 3) << 2, 0);      \
             }                                                                                \
             _Pragma("unroll") for (int g3 = 0; g3 < NF; g3 += 3) {                           \
                 u32 n0 = 0, n1 = 0;                                                          \
@@ -957,8 +965,11 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
             }                                                                                \
         }
         int f = 0;
-        for (; f + 12 <= a.fpad; f += 12) LM_SCAN4_BLOCK(12)
-        for (; f < a.fpad; f += 3) LM_SCAN4_BLOCK(3)
+        for (; f + FB <= a.fpad; f += FB) LM_SCAN4_BLOCK(FB)
+        if (FB > 24 && f + 24 <= a.fpad) { LM_SCAN4_BLOCK(24) f += 24; }
+        if (FB > 12 && f + 12 <= a.fpad) { LM_SCAN4_BLOCK(12) f += 12; }
+        if (f + 6 <= a.fpad) { LM_SCAN4_BLOCK(6) f += 6; }
+        if (f < a.fpad) LM_SCAN4_BLOCK(3)
 #undef LM_SCAN4_BLOCK
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -1374,8 +1385,12 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
     dim3 grid = xcd ? dim3(((nslots % 8) == 0) ? (unsigned)(G * nslots) : 8u * (unsigned)((G + 8 / nslots - 1) / (8 / nslots)))
                     : dim3(G, 1, nslots);
     if (a.nibble) {
-        if (xcd) hipLaunchKernelGGL((k_scan4<true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_scan4<false>), grid, dim3(256), 0, s, a);
+#define SCAN4_LAUNCH(FB)                                                                        \
+    do { if (xcd) hipLaunchKernelGGL((k_scan4<FB, true>), grid, dim3(256), 0, s, a);            \
+         else hipLaunchKernelGGL((k_scan4<FB, false>), grid, dim3(256), 0, s, a); } while (0)
+        const int fb = variant & 3;
+        if (fb == 1) SCAN4_LAUNCH(24); else if (fb == 2) SCAN4_LAUNCH(33); else SCAN4_LAUNCH(12);
+#undef SCAN4_LAUNCH
         return;
     }
     const int u = variant & 3;
