@@ -85,6 +85,65 @@ __global__ __launch_bounds__(256) void k_pyrdown(const u8* __restrict__ src0, in
     o[0] = (u8)((s0 + 128) >> 8); o[1] = (u8)((s1 + 128) >> 8); o[2] = (u8)((s2 + 128) >> 8);
 }
 
+// cv::pyrDown, one lane = 8 output pixels (sw % 16 == 0): the 20 source pixels 16g-2 .. 16g+17 are 60 bytes
+// at byte 10 of five aligned 16-byte blocks starting at 48 g - 16.  Vertical 1 4 6 4 1 first, on packed
+// bytes (u16 pairs, sums <= 4080), then the horizontal taps on the extracted 16-bit sums.
+__global__ __launch_bounds__(256) void k_pyrdown8(const u8* __restrict__ src0, int sw, int sh, u8* __restrict__ dst0,
+                                                   int dw, int dh, size_t slot_stride) {
+    const u8* src = slot_ptr(src0, slot_stride);
+    u8* dst = slot_ptr(dst0, slot_stride);
+    const int ng = dw >> 3;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int y = gid / ng, g = gid - y * ng;
+    if (y >= dh) return;
+    const u32 K[5] = {1, 4, 6, 4, 1};
+    u32 ev[20], od[20];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const u8* row = src + (size_t)refl101(2 * y + j - 2, sh) * sw * 3 + 48 * g - 16;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            // block 0 only holds pixels 16g-2, 16g-1 and block 4 only 16g+16, 16g+17: replaced below at the row ends
+            const bool ok = !(k == 0 && g == 0) && !(k == 4 && g == ng - 1);
+            const u32x4 d = ok ? *reinterpret_cast<const u32x4*>(row + 16 * k) : u32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32 e = d[q] & 0x00FF00FFu, o = (d[q] >> 8) & 0x00FF00FFu;
+                if (j == 0) { ev[4 * k + q] = e; od[4 * k + q] = o; }
+                else { ev[4 * k + q] += K[j] * e; od[4 * k + q] += K[j] * o; }
+            }
+        }
+    }
+    int V[19][3];   // window pixel i = source x 16g - 2 + i
+#pragma unroll
+    for (int i = 0; i < 19; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int bb = 10 + 3 * i + c;
+            const u32 d = (bb & 1) ? od[bb >> 2] : ev[bb >> 2];
+            V[i][c] = (int)((bb & 2) ? (d >> 16) : (d & 0xFFFFu));
+        }
+    if (g == 0) {           // BORDER_REFLECT_101: x = -2 -> 2, -1 -> 1
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { V[0][c] = V[4][c]; V[1][c] = V[3][c]; }
+    }
+    if (g == ng - 1) {      // x = sw -> sw - 2
+#pragma unroll
+        for (int c = 0; c < 3; ++c) V[18][c] = V[16][c];
+    }
+    u32 o[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int sum = V[2 * p][c] + 4 * V[2 * p + 1][c] + 6 * V[2 * p + 2][c] + 4 * V[2 * p + 3][c] + V[2 * p + 4][c];
+            const int bi = 3 * p + c;
+            o[bi >> 2] |= (u32)((sum + 128) >> 8) << (8 * (bi & 3));
+        }
+    u32x2* out = reinterpret_cast<u32x2*>(dst + ((size_t)y * dw + 8 * g) * 3);
+    out[0] = u32x2{o[0], o[1]}; out[1] = u32x2{o[2], o[3]}; out[2] = u32x2{o[4], o[5]};
+}
+
 // ------------------------------------------------------------------------------------------------
 // a3  ColorGradient::process.  One 32x8 output tile per 256-thread workgroup (1200 workgroups at
 // 640x480 so several are resident per CU and hide each other's barriers).  The 7x7 blur (+-3), the
@@ -246,106 +305,81 @@ __global__ __launch_bounds__(256) void k_color_quantize(const u8* __restrict__ b
 }
 
 // ------------------------------------------------------------------------------------------------
-// a3, streaming form (used when w % 4 == 0; the fused LDS-tiled k_color_quantize above is the generic
-// fallback and the reference for the arithmetic).  Four simple passes through L2-resident scratch:
+// a3, streaming form (used when w % 16 == 0; the fused LDS-tiled k_color_quantize above is the generic
+// fallback and the reference for the arithmetic).  Four passes through L2-resident scratch:
 //   k_cblur_h  horizontal 7-tap on the interleaved BGR byte stream: the taps of byte p are bytes
-//              p-9, p-6, ..., p+9 whatever the channel, so a thread does 4 bytes at once (SWAR on
-//              u16 pairs, v_alignbyte_b32 for the odd offsets)                 -> hb  u16 [h][3w]
+//              p-9, p-6, ..., p+9 whatever the channel (SWAR on u16 pairs, v_alignbyte_b32 for the
+//              odd offsets)                                                    -> hb  u16 [h][3w]
 //   k_cblur_v  vertical 7-tap + rounding, fused with the vertical halves of the Sobel
 //              VS = S(y-1) + 2 S(y) + S(y+1), VD = S(y+1) - S(y-1)            -> vs, vd i16 [h][3w]
 //   k_corient  dx = VS(x+1) - VS(x-1), dy = VD(x-1) + 2 VD(x) + VD(x+1), strongest channel,
 //              fastAtan2, 16 -> 8 bins, magnitude flag                         -> qn  u8 [h][w]
 //   k_cvote    3x3 majority vote gated by the flag                             -> quant
 // Replicate borders exactly as the fused kernel: blur taps clamp, Sobel reads S at clamped coordinates.
+//
+// Load shape.  The vector L1 takes one cycle per 4 lanes of a load instruction whatever the width per
+// lane (measured: TCP_TOTAL_CACHE_ACCESSES = 16 per wave-load + one per 128-B line crossed), so a
+// byte or short load per lane runs at 1/16 .. 1/8 of the rate of a 16-byte one.  Every pass
+// therefore gives a lane 16 contiguous bytes per load (global_load_dwordx4) and 8 or 16 outputs.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// one lane = 16 bytes of a row (3w % 16 == 0)
 __global__ __launch_bounds__(256) void k_cblur_h(const u8* __restrict__ bgr0, int w, int h, u16* __restrict__ hb0,
                                                   size_t in_stride, size_t tmp_stride) {
     const u8* bgr = slot_ptr(bgr0, in_stride);
     u16* hb = slot_ptr(hb0, tmp_stride);
-    const int rowdw = (w * 3) >> 2;
-    const int d = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (d >= rowdw) return;
+    const int nblk = (w * 3) >> 4;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int y = gid / nblk, b = gid - y * nblk;
+    if (y >= h) return;
     const u8* row = bgr + (size_t)y * w * 3;
-    u32 e_sum, o_sum;
-    if (d >= 3 && d + 3 < rowdw) {
-        const u32* r32 = reinterpret_cast<const u32*>(row);
-        const u32 D0 = r32[d - 3], D1 = r32[d - 2], D2 = r32[d - 1], D3 = r32[d], D4 = r32[d + 1], D5 = r32[d + 2],
-                  D6 = r32[d + 3];
+    const u32x4 c = ld16(row + 16 * b);
+    u32 W[10];
+    if (b > 0) {
+        const u32x4 p = ld16(row + 16 * b - 16);
+        W[0] = p[1]; W[1] = p[2]; W[2] = p[3];
+    } else {   // bytes -12..-1 replicate pixel 0 channel-wise: [B G R B][G R B G][R B G R]
+        W[0] = __builtin_amdgcn_perm(c[0], c[0], 0x00020100u);
+        W[1] = __builtin_amdgcn_perm(c[0], c[0], 0x01000201u);
+        W[2] = __builtin_amdgcn_perm(c[0], c[0], 0x02010002u);
+    }
+    W[3] = c[0]; W[4] = c[1]; W[5] = c[2]; W[6] = c[3];
+    if (b + 1 < nblk) {
+        const u32x4 n = ld16(row + 16 * b + 16);
+        W[7] = n[0]; W[8] = n[1]; W[9] = n[2];
+    } else {   // bytes 3w.. replicate the last pixel (bytes 1..3 of the last dword): [B G R B][G R B G][R B G R]
+        W[7] = __builtin_amdgcn_perm(c[3], c[3], 0x01030201u);
+        W[8] = __builtin_amdgcn_perm(c[3], c[3], 0x02010302u);
+        W[9] = __builtin_amdgcn_perm(c[3], c[3], 0x03020103u);
+    }
+    u32 o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 D0 = W[j], D1 = W[j + 1], D2 = W[j + 2], D3 = W[j + 3], D4 = W[j + 4], D5 = W[j + 5], D6 = W[j + 6];
         const u32 tm9 = __builtin_amdgcn_alignbyte(D1, D0, 3u), tm6 = __builtin_amdgcn_alignbyte(D2, D1, 2u);
         const u32 tm3 = __builtin_amdgcn_alignbyte(D3, D2, 1u), tp3 = __builtin_amdgcn_alignbyte(D4, D3, 3u);
         const u32 tp6 = __builtin_amdgcn_alignbyte(D5, D4, 2u), tp9 = __builtin_amdgcn_alignbyte(D6, D5, 1u);
 #define LM_EV(t) ((t) & 0x00FF00FFu)
 #define LM_OD(t) (((t) >> 8) & 0x00FF00FFu)
-        e_sum = 8u * (LM_EV(tm9) + LM_EV(tp9)) + 28u * (LM_EV(tm6) + LM_EV(tp6)) + 56u * (LM_EV(tm3) + LM_EV(tp3)) + 72u * LM_EV(D3);
-        o_sum = 8u * (LM_OD(tm9) + LM_OD(tp9)) + 28u * (LM_OD(tm6) + LM_OD(tp6)) + 56u * (LM_OD(tm3) + LM_OD(tp3)) + 72u * LM_OD(D3);
+        const u32 e_sum = 8u * (LM_EV(tm9) + LM_EV(tp9)) + 28u * (LM_EV(tm6) + LM_EV(tp6)) + 56u * (LM_EV(tm3) + LM_EV(tp3)) + 72u * LM_EV(D3);
+        const u32 o_sum = 8u * (LM_OD(tm9) + LM_OD(tp9)) + 28u * (LM_OD(tm6) + LM_OD(tp6)) + 56u * (LM_OD(tm3) + LM_OD(tp3)) + 72u * LM_OD(D3);
 #undef LM_EV
 #undef LM_OD
-    } else {   // first / last dwords of a row: per byte, replicate-clamped taps
-        u32 r[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int p = 4 * d + k, x = p / 3, c = p - 3 * x;
-            const int K[7] = {8, 28, 56, 72, 56, 28, 8};
-            u32 sacc = 0;
-#pragma unroll
-            for (int i = 0; i < 7; ++i) sacc += (u32)K[i] * row[3 * clampi(x + i - 3, 0, w - 1) + c];
-            r[k] = sacc;
-        }
-        e_sum = r[0] | (r[2] << 16);
-        o_sum = r[1] | (r[3] << 16);
+        o[2 * j] = (e_sum & 0xFFFFu) | (o_sum << 16);
+        o[2 * j + 1] = (e_sum >> 16) | (o_sum & 0xFFFF0000u);
     }
-    u32* o = reinterpret_cast<u32*>(hb + (size_t)y * w * 3 + 4 * d);
-    o[0] = (e_sum & 0xFFFFu) | (o_sum << 16);
-    o[1] = (e_sum >> 16) | (o_sum & 0xFFFF0000u);
+    u16* dst = hb + (size_t)y * w * 3 + 16 * b;
+    st16(dst, u32x4{o[0], o[1], o[2], o[3]});
+    st16(dst + 8, u32x4{o[4], o[5], o[6], o[7]});
 }
 
-#define CV_ROWS 8   // output rows per thread of k_cblur_v
-__global__ __launch_bounds__(256) void k_cblur_v(const u16* __restrict__ hb0, int w, int h, int16_t* __restrict__ vs0,
-                                                  int16_t* __restrict__ vd0, size_t tmp_stride) {
-    const u16* hb = slot_ptr(hb0, tmp_stride);
-    int16_t* vs = slot_ptr(vs0, tmp_stride);
-    int16_t* vd = slot_ptr(vd0, tmp_stride);
-    const int ncol = (w * 3) >> 2;                       // groups of 4 byte positions
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= ncol) return;
-    const int y0 = blockIdx.y * CV_ROWS;
-    const size_t pitch = (size_t)w * 3;
-    if (y0 >= 4 && y0 + CV_ROWS + 4 <= h) {
-        // interior band (block-uniform): no clamping anywhere, so every hb row is loaded once into
-        // registers and the CV_ROWS + 2 smoothed rows come from that window
-        u32 v[CV_ROWS + 8][4];
-#pragma unroll
-        for (int i = 0; i < CV_ROWS + 8; ++i) {
-            const u32* p = reinterpret_cast<const u32*>(hb + (size_t)(y0 - 4 + i) * pitch + 4 * j);
-            const u32 a = p[0], b = p[1];
-            v[i][0] = a & 0xFFFFu; v[i][1] = a >> 16; v[i][2] = b & 0xFFFFu; v[i][3] = b >> 16;
-        }
-        int s[CV_ROWS + 2][4];
-#pragma unroll
-        for (int r = 0; r < CV_ROWS + 2; ++r)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const u32 acc = 8u * (v[r][k] + v[r + 6][k]) + 28u * (v[r + 1][k] + v[r + 5][k]) +
-                                56u * (v[r + 2][k] + v[r + 4][k]) + 72u * v[r + 3][k];
-                s[r][k] = (int)((acc + 32768u) >> 16);
-            }
-#pragma unroll
-        for (int r = 0; r < CV_ROWS; ++r) {
-            const int y = y0 + r;
-            u32* ovs = reinterpret_cast<u32*>(vs + (size_t)y * pitch + 4 * j);
-            u32* ovd = reinterpret_cast<u32*>(vd + (size_t)y * pitch + 4 * j);
-            int a[4], d[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { a[k] = s[r][k] + 2 * s[r + 1][k] + s[r + 2][k]; d[k] = s[r + 2][k] - s[r][k]; }
-            ovs[0] = (u32)(a[0] & 0xFFFF) | ((u32)a[1] << 16);
-            ovs[1] = (u32)(a[2] & 0xFFFF) | ((u32)a[3] << 16);
-            ovd[0] = (u32)(d[0] & 0xFFFF) | ((u32)d[1] << 16);
-            ovd[1] = (u32)(d[2] & 0xFFFF) | ((u32)d[3] << 16);
-        }
-        return;
-    }
+#define CV_ROWS 8   // output rows per lane of k_cblur_v
+// Band at the top / bottom of the image: every tap clamped; 4 values (one 8-byte group) per call.
+__device__ __forceinline__ void cblur_v_edge(const u16* __restrict__ hb, int16_t* __restrict__ vs, int16_t* __restrict__ vd,
+                                             size_t pitch, int h, int y0, int j) {
     int sm1[4] = {0, 0, 0, 0}, s0[4] = {0, 0, 0, 0};
-#pragma unroll
     for (int r = -1; r <= CV_ROWS; ++r) {
         const int sy = clampi(y0 + r, 0, h - 1);          // Sobel reads the smoothed image at clamped rows
         u32 acc[4] = {0, 0, 0, 0};
@@ -380,6 +414,75 @@ __global__ __launch_bounds__(256) void k_cblur_v(const u16* __restrict__ hb0, in
     }
 }
 
+// one lane = 8 values (16 bytes of hb) x CV_ROWS output rows.  Interior bands read each of the
+// CV_ROWS + 8 hb rows once and scatter it into the 7 smoothed rows it contributes to (ring of 7 x 8
+// partial sums); a smoothed row that completes is combined with its two predecessors into VS / VD.
+__global__ __launch_bounds__(256) void k_cblur_v(const u16* __restrict__ hb0, int w, int h, int16_t* __restrict__ vs0,
+                                                  int16_t* __restrict__ vd0, size_t tmp_stride) {
+    const u16* hb = slot_ptr(hb0, tmp_stride);
+    int16_t* vs = slot_ptr(vs0, tmp_stride);
+    int16_t* vd = slot_ptr(vd0, tmp_stride);
+    const int ncol = (w * 3) >> 3;                       // groups of 8 values
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int band = gid / ncol, j = gid - band * ncol;
+    const int y0 = band * CV_ROWS;
+    if (y0 >= h) return;
+    const size_t pitch = (size_t)w * 3;
+    if (y0 < 4 || y0 + CV_ROWS + 4 > h) {
+        cblur_v_edge(hb, vs, vd, pitch, h, y0, 2 * j);
+        cblur_v_edge(hb, vs, vd, pitch, h, y0, 2 * j + 1);
+        return;
+    }
+    const u32 K[7] = {8, 28, 56, 72, 56, 28, 8};
+    u32 acc[7][8];
+    int p2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, p1[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // S(r-2), S(r-1)
+#pragma unroll
+    for (int i = 0; i < CV_ROWS + 8; ++i) {              // hb row y0 - 4 + i feeds S rows r = i - 6 .. i (image row y0 - 1 + r)
+        const u32x4 d = ld16(hb + (size_t)(y0 - 4 + i) * pitch + 8 * j);
+        u32 v[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[2 * k] = d[k] & 0xFFFFu; v[2 * k + 1] = d[k] >> 16; }
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const int r = i - t;
+            if (r < 0 || r > CV_ROWS + 1) continue;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (t == 0) acc[r % 7][k] = K[0] * v[k];
+                else acc[r % 7][k] += K[t] * v[k];
+            }
+        }
+        const int r = i - 6;                             // this S row is complete
+        if (r >= 0 && r <= CV_ROWS + 1) {
+            int s[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] = (int)((acc[r % 7][k] + 32768u) >> 16);
+            if (r >= 2) {
+                const int y = y0 + r - 2;
+                int a[8], dd[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { a[k] = p2[k] + 2 * p1[k] + s[k]; dd[k] = s[k] - p2[k]; }
+                st16(vs + (size_t)y * pitch + 8 * j,
+                     u32x4{(u32)(a[0] & 0xFFFF) | ((u32)a[1] << 16), (u32)(a[2] & 0xFFFF) | ((u32)a[3] << 16),
+                           (u32)(a[4] & 0xFFFF) | ((u32)a[5] << 16), (u32)(a[6] & 0xFFFF) | ((u32)a[7] << 16)});
+                st16(vd + (size_t)y * pitch + 8 * j,
+                     u32x4{(u32)(dd[0] & 0xFFFF) | ((u32)dd[1] << 16), (u32)(dd[2] & 0xFFFF) | ((u32)dd[3] << 16),
+                           (u32)(dd[4] & 0xFFFF) | ((u32)dd[5] << 16), (u32)(dd[6] & 0xFFFF) | ((u32)dd[7] << 16)});
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { p2[k] = p1[k]; p1[k] = s[k]; }
+        }
+    }
+}
+
+// halfword hw of a buffer of dwordx4, sign-extended
+__device__ __forceinline__ int hw_s16(const u32x4* A, int hw) {
+    const u32 d = A[hw >> 3][(hw >> 1) & 3];
+    return (hw & 1) ? ((int)d >> 16) : (int)(int16_t)(d & 0xFFFFu);
+}
+
+// one lane = 8 pixels of a row (w % 8 == 0): the 10-pixel window of VS / VD is 60 bytes starting 6 bytes
+// before pixel 8g, i.e. at byte 10 of five aligned 16-byte blocks starting at 48 g - 16.
 __global__ __launch_bounds__(256) void k_corient(const int16_t* __restrict__ vs0, const int16_t* __restrict__ vd0, int w,
                                                   int h, float thr2, u8* __restrict__ qn0, float* __restrict__ mag0,
                                                   size_t tmp_stride, size_t mag_stride) {
@@ -387,54 +490,116 @@ __global__ __launch_bounds__(256) void k_corient(const int16_t* __restrict__ vs0
     const int16_t* vd = slot_ptr(vd0, tmp_stride);
     u8* qn = slot_ptr(qn0, tmp_stride);
     float* mag = mag0 ? slot_ptr(mag0, mag_stride) : nullptr;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    const int16_t* vsr = vs + (size_t)y * w * 3;
-    const int16_t* vdr = vd + (size_t)y * w * 3;
-    const int xm = (x > 0 ? x - 1 : 0) * 3, xc = x * 3, xp = (x + 1 < w ? x + 1 : w - 1) * 3;
-    int bdx = 0, bdy = 0, bm = -1;
+    const int ng = w >> 3;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int y = gid / ng, g = gid - y * ng;
+    if (y >= h) return;
+    const u8* vsr = reinterpret_cast<const u8*>(vs + (size_t)y * w * 3) + 48 * g - 16;
+    const u8* vdr = reinterpret_cast<const u8*>(vd + (size_t)y * w * 3) + 48 * g - 16;
+    u32x4 A[5], B[5];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        int dx = (int)vsr[xp + c] - (int)vsr[xm + c];
-        int dy = (int)vdr[xm + c] + 2 * (int)vdr[xc + c] + (int)vdr[xp + c];
-        int m = dx * dx + dy * dy;
-        if (m > bm) { bm = m; bdx = dx; bdy = dy; }   // first maximum wins ties = upstream's >= cascade
+    for (int k = 0; k < 5; ++k) {
+        // block 0 only holds pixel 8g - 1, block 4 only pixel 8g + 8: outside the row they are replaced below
+        const bool ok = !(k == 0 && g == 0) && !(k == 4 && g == ng - 1);
+        A[k] = ok ? ld16(vsr + 16 * k) : u32x4{0, 0, 0, 0};
+        B[k] = ok ? ld16(vdr + 16 * k) : u32x4{0, 0, 0, 0};
     }
-    const float scale = (float)(16.0 / 360.0);
-    float ang = fast_atan2_deg((float)bdy, (float)bdx);
-    float qf = rintf(__fadd_rn(__fmul_rn(ang, scale), 0.0f));
-    int q = (int)qf;
-    q = q < 0 ? 0 : (q > 255 ? 255 : q);
-    const bool border = (y == 0) | (y == h - 1) | (x == 0) | (x == w - 1);
-    u8 out = border ? 0 : (u8)(q & 7);
-    const float fm = (float)bm;
-    if (fm > thr2) out |= 0x80;
-    qn[(size_t)y * w + x] = out;
-    if (mag) mag[(size_t)y * w + x] = fm;
+    int S[10][3], D[10][3];   // window pixel i = image x 8g - 1 + i
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { S[i][c] = hw_s16(A, 5 + 3 * i + c); D[i][c] = hw_s16(B, 5 + 3 * i + c); }
+    if (g == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { S[0][c] = S[1][c]; D[0][c] = D[1][c]; }
+    }
+    if (g == ng - 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { S[9][c] = S[8][c]; D[9][c] = D[8][c]; }
+    }
+    u32 out[2] = {0, 0};
+    float fmv[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int x = 8 * g + p;
+        int bdx = 0, bdy = 0, bm = -1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int dx = S[p + 2][c] - S[p][c];
+            int dy = D[p][c] + 2 * D[p + 1][c] + D[p + 2][c];
+            int m = dx * dx + dy * dy;
+            if (m > bm) { bm = m; bdx = dx; bdy = dy; }   // first maximum wins ties = upstream's >= cascade
+        }
+        const float scale = (float)(16.0 / 360.0);
+        float ang = fast_atan2_deg((float)bdy, (float)bdx);
+        float qf = rintf(__fadd_rn(__fmul_rn(ang, scale), 0.0f));
+        int q = (int)qf;
+        q = q < 0 ? 0 : (q > 255 ? 255 : q);
+        const bool border = (y == 0) | (y == h - 1) | (x == 0) | (x == w - 1);
+        u32 o = border ? 0u : (u32)(q & 7);
+        const float fm = (float)bm;
+        if (fm > thr2) o |= 0x80u;
+        out[p >> 2] |= o << (8 * (p & 3));
+        fmv[p] = fm;
+    }
+    *reinterpret_cast<u32x2*>(qn + (size_t)y * w + 8 * g) = u32x2{out[0], out[1]};
+    if (mag) {
+        float* mo = mag + (size_t)y * w + 8 * g;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) mo[p] = fmv[p];
+    }
 }
 
+#define CVT_ROWS 4   // output rows per lane of k_cvote
+// one lane = 16 pixels x CVT_ROWS rows (w % 16 == 0).  A pixel's label becomes a one-hot nibble counter
+// (1 << 4 label); horizontal then vertical 3-sums give the eight 4-bit counts of the 3x3 window, and
+// since at most one label can reach 5 of 9 votes, (cnt + 0x33333333) & 0x88888888 has at most one bit.
 __global__ __launch_bounds__(256) void k_cvote(const u8* __restrict__ qn0, int w, int h, u8* __restrict__ quant0,
                                                 size_t tmp_stride, size_t out_stride) {
     const u8* qn = slot_ptr(qn0, tmp_stride);
     u8* quant = slot_ptr(quant0, out_stride);
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    u8 res = 0;
-    if (y >= 1 && y <= h - 2 && x >= 1 && x <= w - 2 && (qn[(size_t)y * w + x] & 0x80)) {
-        u32 cnt = 0;  // eight 4-bit counters
+    const int ng = w >> 4;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int band = gid / ng, g = gid - band * ng;
+    const int y0 = band * CVT_ROWS;
+    if (y0 >= h) return;
+    u32 hs[3][16];        // horizontal 3-sums of rows r-1, r, r+1 (ring)
+    u32 flags[3][4];      // the rows' own bytes (bit 7 = magnitude flag)
 #pragma unroll
-        for (int j = -1; j <= 1; ++j)
+    for (int i = 0; i < CVT_ROWS + 2; ++i) {              // image row y0 - 1 + i
+        const int yy = clampi(y0 - 1 + i, 0, h - 1);      // clamped rows only feed outputs that are forced to 0
+        const u8* row = qn + (size_t)yy * w + 16 * g;
+        const u32x4 c = ld16(row);
+        const u32 lft = g > 0 ? *reinterpret_cast<const u32*>(row - 4) : 0u;
+        const u32 rgt = g + 1 < ng ? *reinterpret_cast<const u32*>(row + 16) : 0u;
+        u32 oh[18];
+        oh[0] = 1u << (((lft >> 24) & 7u) << 2);
 #pragma unroll
-            for (int i = -1; i <= 1; ++i) cnt += 1u << (4 * (qn[(size_t)(y + j) * w + x + i] & 7));
-        int best = 0, idx = 0;
+        for (int k = 0; k < 16; ++k) oh[1 + k] = 1u << (((c[k >> 2] >> (8 * (k & 3))) & 7u) << 2);
+        oh[17] = 1u << ((rgt & 7u) << 2);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            int v = (cnt >> (4 * b)) & 15;
-            if (best < v) { best = v; idx = b; }
+        for (int k = 0; k < 16; ++k) hs[i % 3][k] = oh[k] + oh[k + 1] + oh[k + 2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) flags[i % 3][k] = c[k];
+        if (i >= 2) {
+            const int y = y0 + i - 2;                     // centre row = ring slot (i - 1) % 3
+            if (y < h) {
+                u32 o[4] = {0, 0, 0, 0};
+                const bool yin = y >= 1 && y <= h - 2;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const u32 cnt = hs[0][k] + hs[1][k] + hs[2][k];
+                    const u32 m = (cnt + 0x33333333u) & 0x88888888u;
+                    const u32 fl = (flags[(i - 1) % 3][k >> 2] >> (8 * (k & 3))) & 0x80u;
+                    const int x = 16 * g + k;
+                    const bool ok = yin && x >= 1 && x <= w - 2 && fl && m;
+                    const u32 res = ok ? (1u << ((u32)(__ffs((int)m) - 1) >> 2)) : 0u;
+                    o[k >> 2] |= res << (8 * (k & 3));
+                }
+                st16(quant + (size_t)y * w + 16 * g, u32x4{o[0], o[1], o[2], o[3]});
+            }
         }
-        if (best >= 5) res = (u8)(1u << idx);
     }
-    quant[(size_t)y * w + x] = res;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1275,6 +1440,11 @@ __global__ void k_nn_half(const u8* __restrict__ src0, int sp, u8* __restrict__ 
 // ================================================================================================
 void lmk_pyrdown(hipStream_t s, const u8* src, int sw, int sh, u8* dst, size_t slot_stride, int nslots) {
     int dw = sw / 2, dh = sh / 2;
+    if ((sw % 16) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0 && (slot_stride % 16) == 0) {
+        const int lanes = (dw / 8) * dh;
+        hipLaunchKernelGGL(k_pyrdown8, dim3((lanes + 255) / 256, 1, nslots), dim3(256), 0, s, src, sw, sh, dst, dw, dh, slot_stride);
+        return;
+    }
     dim3 grid((dw + 63) / 64, (dh + 3) / 4, nslots);
     hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, src, sw, sh, dst, dw, dh, slot_stride);
 }
@@ -1293,17 +1463,21 @@ size_t lmk_color_scratch_bytes(int w, int h) {
 void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_threshold, u8* quant, float* mag,
                         u8* scratch, size_t slot_stride, int nslots) {
     const float thr2 = weak_threshold * weak_threshold;
-    if (scratch && (w % 4) == 0 && ((uintptr_t)bgr & 3) == 0 && (slot_stride % 4) == 0) {
+    if (scratch && (w % 16) == 0 && ((uintptr_t)bgr & 15) == 0 && ((uintptr_t)scratch & 15) == 0 &&
+        ((uintptr_t)quant & 15) == 0 && (slot_stride % 16) == 0) {
         const size_t px = (size_t)w * h, a6 = (px * 6 + 255) / 256 * 256;
         u16* hb = reinterpret_cast<u16*>(scratch);
         int16_t* vs = reinterpret_cast<int16_t*>(scratch + a6);
         int16_t* vd = reinterpret_cast<int16_t*>(scratch + 2 * a6);
         u8* qn = scratch + 3 * a6;
-        const int rowdw = (w * 3) / 4;
-        hipLaunchKernelGGL(k_cblur_h, dim3((rowdw + 255) / 256, h, nslots), dim3(256), 0, s, bgr, w, h, hb, slot_stride, slot_stride);
-        hipLaunchKernelGGL(k_cblur_v, dim3((rowdw + 255) / 256, (h + CV_ROWS - 1) / CV_ROWS, nslots), dim3(256), 0, s, hb, w, h, vs, vd, slot_stride);
-        hipLaunchKernelGGL(k_corient, dim3((w + 255) / 256, h, nslots), dim3(256), 0, s, vs, vd, w, h, thr2, qn, mag, slot_stride, slot_stride);
-        hipLaunchKernelGGL(k_cvote, dim3((w + 255) / 256, h, nslots), dim3(256), 0, s, qn, w, h, quant, slot_stride, slot_stride);
+        const int n_h = (w * 3 / 16) * h;                                     // 16-byte blocks of the image
+        const int n_v = (w * 3 / 8) * ((h + CV_ROWS - 1) / CV_ROWS);          // 8-value columns x bands
+        const int n_o = (w / 8) * h;                                          // 8-pixel groups
+        const int n_t = (w / 16) * ((h + CVT_ROWS - 1) / CVT_ROWS);           // 16-pixel groups x bands
+        hipLaunchKernelGGL(k_cblur_h, dim3((n_h + 255) / 256, 1, nslots), dim3(256), 0, s, bgr, w, h, hb, slot_stride, slot_stride);
+        hipLaunchKernelGGL(k_cblur_v, dim3((n_v + 255) / 256, 1, nslots), dim3(256), 0, s, hb, w, h, vs, vd, slot_stride);
+        hipLaunchKernelGGL(k_corient, dim3((n_o + 255) / 256, 1, nslots), dim3(256), 0, s, vs, vd, w, h, thr2, qn, mag, slot_stride, slot_stride);
+        hipLaunchKernelGGL(k_cvote, dim3((n_t + 255) / 256, 1, nslots), dim3(256), 0, s, qn, w, h, quant, slot_stride, slot_stride);
         return;
     }
     dim3 grid((w + CT_W - 1) / CT_W, (h + CT_H - 1) / CT_H, nslots);
