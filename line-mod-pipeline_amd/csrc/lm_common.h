@@ -23,6 +23,8 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 #define LM_SCAN_CHUNK 1008      // positions one wave covers in the similarity scan (63 lanes x 16 B; lane 63 feeds lane 62)
+#define LM_SCAN4_CHUNK 1016     // nibble scan: positions per work item (half a wave: 32 lanes x 32 positions, the last 8 are
+                                // polluted by the other half's data); two items per wave
 #define LM_SCAN_FPAD 8          // feature lists are padded to a multiple of this with zero-block offsets
 #define LM_SORT_CAP 4096        // matches sorted on the device (LDS); more are sorted by the host
 #define LM_INLINE_MATCHES 2048  // records the sort kernel also writes straight into host-mapped memory

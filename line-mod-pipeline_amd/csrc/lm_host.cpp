@@ -137,7 +137,8 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
             out.scan_P.push_back(P);
             out.scan_n.push_back(n_total);
             out.class_alg_bytes[ci] += fcount * (double)P;
-            for (int ch = 0; ch * LM_SCAN_CHUNK < P; ++ch) { out.item_t.push_back(ti); out.item_chunk.push_back((u32)ch); }
+            const int chunk = gl.nibble ? LM_SCAN4_CHUNK : LM_SCAN_CHUNK;
+            for (int ch = 0; ch * chunk < P; ++ch) { out.item_t.push_back(ti); out.item_chunk.push_back((u32)ch); }
             // ---- refinement levels
             for (int l = 0; l + 1 < L; ++l) {
                 const LmLevelGeom& g = geom[l];

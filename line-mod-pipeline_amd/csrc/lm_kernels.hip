@@ -1068,12 +1068,15 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // a11-a13, nibble form of the hot kernel (LmLevelGeom::nibble): responses are <= 4, so the lowest
-// level stores two positions per byte and a feature costs the wave 512 B instead of 1 KiB.  Same
-// decomposition as k_scan (lane l < 63 owns 16 positions = 8 bytes = 2 dwords); bank offsets are in
-// nibbles, the load address is rounded down to a dword and the 0..7 nibble shift is undone with
-// v_alignbit_b32 (the 17th.. nibble comes from the next lane by DPP).  Three features are added
-// nibble-wise (3 * 4 = 12 < 16), then split into even / odd positions and added byte-wise (63 * 4 = 252).
-// Feature lists are padded to a multiple of 3.
+// level stores two positions per byte.  The vector L1 spends one cycle per 4 lanes of a load whatever
+// the width per lane, so every lane loads 16 bytes = 32 positions, and one wave carries TWO work
+// items (template, chunk of LM_SCAN4_CHUNK positions): lanes 0..31 the first, lanes 32..63 the second
+// (P is about 1000 for a 640x480 frame at T = 8: one item per template).  Bank offsets are in nibbles;
+// the per-half load address is rounded down to a dword and the 0..7 nibble shift is undone with
+// v_alignbit_b32, the 33rd.. nibble coming from the next lane by DPP -- lane 31 receives the other
+// item's dword there, which only reaches positions >= 1017 of the chunk, hence 1016 positions per item.
+// Three features are added nibble-wise (3 * 4 = 12 < 16), then split into even / odd positions and added
+// byte-wise (63 * 4 = 252).  Feature lists are padded to a multiple of 3.
 // ------------------------------------------------------------------------------------------------
 template <int FB, bool XCD_MAP>
 __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
@@ -1089,78 +1092,94 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
         slot = blockIdx.z; wg = blockIdx.x;
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)((wg * 256u + threadIdx.x) >> 6));
-    if (wave >= a.n_items) return;
-    const u32 ti = a.item_t[a.item_lo + wave];
-    const u32 chunk = a.item_chunk[a.item_lo + wave];
-    const int P = a.scan_P[ti];
-    const int n = a.scan_n[ti];
+    if (2 * wave >= a.n_items) return;
+    const bool hasB = 2 * wave + 1 < a.n_items;
+    const int itA = a.item_lo + 2 * wave, itB = hasB ? itA + 1 : itA;
+    const u32 tiA = a.item_t[itA], tiB = a.item_t[itB];
+    const u32 chA = a.item_chunk[itA], chB = a.item_chunk[itB];
+    const bool hi = lane >= 32;
+    const u32 ti = hi ? tiB : tiA;
+    const int P = hi ? (hasB ? a.scan_P[tiB] : 0) : a.scan_P[tiA];
+    const int n = hi ? a.scan_n[tiB] : a.scan_n[tiA];
     const int thr = a.raw_thr_by_n[n];
-    const u32 j0 = chunk * LM_SCAN_CHUNK + (u32)lane * 16u;
-    // buffer addressing: descriptor base = this wave's chunk (SGPRs), voffset = the lane's 8 bytes, soffset =
-    // the feature's dword-aligned byte offset -- the per-feature address costs no VALU instruction
+    const u32 j0 = (hi ? chB : chA) * LM_SCAN4_CHUNK + (u32)(lane & 31) * 32u;   // first position of this lane
+    // one buffer descriptor for the slot's arena; voffset = the lane's 16 bytes inside its item's chunk + the
+    // feature's dword-aligned byte offset of its half
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<u8*>(a.lm + (size_t)slot * a.lm_slot_stride + (size_t)((chunk * LM_SCAN_CHUNK) >> 1)), 0, 0x7FFFFFFF, 0x00020000);
-    const u32 lane_off = (u32)lane * 8u;
+        const_cast<u8*>(a.lm + (size_t)slot * a.lm_slot_stride), 0, 0x7FFFFFFF, 0x00020000);
+    const u32 lane_base = j0 >> 1;
+    const u32 half_sel = hi ? 0xFFFFFFFFu : 0u;
+    const u32 half_shift = hi ? 8u : 0u;
     LmDevHeader* hdr = reinterpret_cast<LmDevHeader*>(reinterpret_cast<u8*>(a.hdr) + (size_t)slot * a.aux_slot_stride);
     LmCand* cand = reinterpret_cast<LmCand*>(reinterpret_cast<u8*>(a.cand) + (size_t)slot * a.aux_slot_stride);
 
     // u16 pairs: position 8k + i of the lane lives in t[k][i & 3], half i >> 2
-    u32 t[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    u32 t[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     for (int m = 0; m < a.M; ++m) {
-        const u32* offs = a.scan_off + ((size_t)ti * a.M + m) * a.fpad;
-        u32 bl[2] = {0, 0}, bh[2] = {0, 0};   // byte lanes: even / odd positions of dword k
-#define LM_SCAN4_BLOCK(NF)                                                                   \
-        {                                                                                    \
-            u32x2 v[NF];                                                                     \
-            u32 sh[NF];                                                                      \
-            _Pragma("unroll") for (int k = 0; k < NF; ++k) {                                 \
-                const u32 o = offs[f + k];                                                   \
-                sh[k] = (o & 7u) << 2;                                                       \
-                v[k] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_off, (o >> 3) << 2, 0);      \
-            }                                                                                \
-            _Pragma("unroll") for (int g3 = 0; g3 < NF; g3 += 3) {                           \
-                u32 n0 = 0, n1 = 0;                                                          \
-                _Pragma("unroll") for (int k = g3; k < g3 + 3; ++k) {                        \
-                    const u32 nx = next_lane(v[k][0]);                                       \
-                    n0 += __builtin_amdgcn_alignbit(v[k][1], v[k][0], sh[k]);                \
-                    n1 += __builtin_amdgcn_alignbit(nx, v[k][1], sh[k]);                     \
-                }                                                                            \
-                bl[0] += n0 & 0x0F0F0F0Fu; bh[0] += (n0 >> 4) & 0x0F0F0F0Fu;                 \
-                bl[1] += n1 & 0x0F0F0F0Fu; bh[1] += (n1 >> 4) & 0x0F0F0F0Fu;                 \
-            }                                                                                \
+        const u32* offsA = a.scan_off + ((size_t)tiA * a.M + m) * a.fpad;
+        const u32* offsB = a.scan_off + ((size_t)tiB * a.M + m) * a.fpad;
+        u32 bl[4] = {0, 0, 0, 0}, bh[4] = {0, 0, 0, 0};   // byte lanes: even / odd positions of dword k
+#define LM_SCAN4_BLOCK(NF)                                                                       \
+        {                                                                                        \
+            u32x4 v[NF];                                                                         \
+            u32 sh[NF];                                                                          \
+            _Pragma("unroll") for (int k = 0; k < NF; ++k) {                                     \
+                const u32 oa = offsA[f + k], ob = offsB[f + k];                                  \
+                const u32 ba = (oa >> 3) << 2, bb = (ob >> 3) << 2;          /* scalar */        \
+                const u32 shp = ((oa & 7u) << 2) | ((ob & 7u) << 10);        /* scalar */        \
+                sh[k] = shp >> half_shift;                                   /* low 5 bits used */ \
+                const u32 vo = lane_base + ((ba & ~half_sel) | (bb & half_sel));                 \
+                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);                    \
+            }                                                                                    \
+            _Pragma("unroll") for (int g3 = 0; g3 < NF; g3 += 3) {                               \
+                u32 nb[4] = {0, 0, 0, 0};                                                        \
+                _Pragma("unroll") for (int k = g3; k < g3 + 3; ++k) {                            \
+                    const u32 nx = next_lane(v[k][0]);                                           \
+                    nb[0] += __builtin_amdgcn_alignbit(v[k][1], v[k][0], sh[k]);                 \
+                    nb[1] += __builtin_amdgcn_alignbit(v[k][2], v[k][1], sh[k]);                 \
+                    nb[2] += __builtin_amdgcn_alignbit(v[k][3], v[k][2], sh[k]);                 \
+                    nb[3] += __builtin_amdgcn_alignbit(nx, v[k][3], sh[k]);                      \
+                }                                                                                \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                  \
+                    bl[q] += nb[q] & 0x0F0F0F0Fu; bh[q] += (nb[q] >> 4) & 0x0F0F0F0Fu;           \
+                }                                                                                \
+            }                                                                                    \
         }
         int f = 0;
         for (; f + FB <= a.fpad; f += FB) LM_SCAN4_BLOCK(FB)
-        if (FB > 24 && f + 24 <= a.fpad) { LM_SCAN4_BLOCK(24) f += 24; }
-        if (FB > 12 && f + 12 <= a.fpad) { LM_SCAN4_BLOCK(12) f += 12; }
-        if (f + 6 <= a.fpad) { LM_SCAN4_BLOCK(6) f += 6; }
-        if (f < a.fpad) LM_SCAN4_BLOCK(3)
+        if (FB > 6 && f + 6 <= a.fpad) { LM_SCAN4_BLOCK(6) f += 6; }
+        if (f + 3 <= a.fpad) { LM_SCAN4_BLOCK(3) f += 3; }
+        if (FB > 6 && f < a.fpad) LM_SCAN4_BLOCK(3)
 #undef LM_SCAN4_BLOCK
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < 4; ++k) {
             t[k][0] += bl[k] & 0x00FF00FFu; t[k][2] += (bl[k] >> 8) & 0x00FF00FFu;
             t[k][1] += bh[k] & 0x00FF00FFu; t[k][3] += (bh[k] >> 8) & 0x00FF00FFu;
         }
     }
     u32 hit = 0;
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int sv = (i >> 2) ? (int)(t[k][i & 3] >> 16) : (int)(t[k][i & 3] & 0xFFFF);
             hit |= (sv > thr ? 1u : 0u) << (8 * k + i);
         }
-    int valid = P - (int)j0;
-    if (lane == 63) valid = 0;
+    // positions of this item: [chunk * CHUNK, min(P, (chunk + 1) * CHUNK))
+    const int lim = min(P, (int)(((hi ? chB : chA) + 1u) * LM_SCAN4_CHUNK));
+    const int valid = lim - (int)j0;
     if (valid <= 0) hit = 0;
-    else if (valid < 16) hit &= (1u << valid) - 1u;
+    else if (valid < 32) hit &= (1u << valid) - 1u;
     if (!__any(hit != 0)) return;
     const int offset = a.T / 2 + (a.T % 2 - 1);
     while (hit) {
         const int b = __ffs(hit) - 1;
         hit &= hit - 1;
-        const u32 tv = (b & 8) ? ((b & 3) == 0 ? t[1][0] : (b & 3) == 1 ? t[1][1] : (b & 3) == 2 ? t[1][2] : t[1][3])
-                               : ((b & 3) == 0 ? t[0][0] : (b & 3) == 1 ? t[0][1] : (b & 3) == 2 ? t[0][2] : t[0][3]);
+        u32 tv = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tv = ((b >> 3) == k && (b & 3) == q) ? t[k][q] : tv;
         const int raw = (b & 4) ? (int)(tv >> 16) : (int)(tv & 0xFFFF);
         const int j = (int)j0 + b;
         const int r = j / a.W, c = j - r * a.W;
@@ -1551,7 +1570,8 @@ void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, 
 void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
     if (a_in.n_items <= 0) return;
     LmScanArgs a = a_in;
-    const int G = (a.n_items + 3) / 4;
+    const int n_waves = a.nibble ? (a.n_items + 1) / 2 : a.n_items;   // k_scan4: two items per wave
+    const int G = (n_waves + 3) / 4;
     a.wgs_per_slot = G; a.nslots = nslots;
     // variant bits 0-1: feature-loop unroll (0: 8 loads in flight, 1: 4, 2: 2); bit 2: plain (slot = grid.z)
     // mapping instead of the XCD-aware one
@@ -1563,7 +1583,7 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
     do { if (xcd) hipLaunchKernelGGL((k_scan4<FB, true>), grid, dim3(256), 0, s, a);            \
          else hipLaunchKernelGGL((k_scan4<FB, false>), grid, dim3(256), 0, s, a); } while (0)
         const int fb = variant & 3;
-        if (fb == 1) SCAN4_LAUNCH(24); else if (fb == 2) SCAN4_LAUNCH(33); else SCAN4_LAUNCH(12);
+        if (fb == 1) SCAN4_LAUNCH(12); else if (fb == 2) SCAN4_LAUNCH(3); else SCAN4_LAUNCH(6);
 #undef SCAN4_LAUNCH
         return;
     }

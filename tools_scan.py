@@ -16,7 +16,7 @@ for i in range(NB):
     b, dp = synth.make_frame(size[0], size[1], seed=1234 + i)
     d.upload_frame(i, b, dp)
 ref = None
-for variant in (0, 2):
+for variant in (0, 1, 2):
     d.set_scan_variant(variant)
     for B in (8, 32):
         for _ in range(5): out, counts = d.match_batch(B, 80.0)
