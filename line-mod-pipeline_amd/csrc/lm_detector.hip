@@ -49,6 +49,7 @@ struct lm_detector {
     int lw[LM_MAX_LEVELS], lh[LM_MAX_LEVELS];
     u8 sim_lut[256];
     u8 normal_lut[8000];
+    int lut_onehot = -1;          // cached: every NORMAL_LUT entry is 0 or one-hot (-1 = not evaluated)
     lmh::Bank bank;
 
     // ---- device state
@@ -224,6 +225,15 @@ int check_slots(lm_detector* d, int first, int n) {
     return LM_OK;
 }
 
+// upstream's NORMAL_LUT holds 0 or one-hot bytes; the streaming depth kernels rely on it (counting median)
+bool normal_lut_onehot(lm_detector* d) {
+    if (d->lut_onehot < 0) {
+        d->lut_onehot = 1;
+        for (int i = 0; i < 8000; ++i) { const u8 v = d->normal_lut[i]; if (v & (v - 1)) { d->lut_onehot = 0; break; } }
+    }
+    return d->lut_onehot != 0;
+}
+
 // quant[l][1] for l >= 1: DepthNormalPyramid::pyrDown = NN half-size copy of the quantised image
 void enqueue_depth_pyramid(lm_detector* d, int first, int n) {
     for (int l = 1; l < d->cfg.pyramid_levels; ++l)
@@ -242,7 +252,8 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
                            nullptr, d->cscratch(first), fs, n);
         if (M == 2 && l == 0)
             lmk_depth_quantize(d->stream, d->depth(first), d->lw[0], d->lh[0], c.distance_threshold,
-                               c.difference_threshold, d->d_normal_lut, d->quant(first, 0, 1), fs, n);
+                               c.difference_threshold, d->d_normal_lut, normal_lut_onehot(d), d->quant(first, 0, 1),
+                               d->cscratch(first), fs, n);
     }
     if (M == 2 && L > 2) enqueue_depth_pyramid(d, first, n);
     for (int l = 0; l < L; ++l) {
@@ -578,7 +589,7 @@ int lm_set_similarity_lut(lm_detector* d, const uint8_t lut[256]) {
 }
 int lm_set_normal_lut(lm_detector* d, const uint8_t lut[8000]) {
     if (!d || !lut) return fail(LM_ERR_INVALID, "null argument");
-    std::memcpy(d->normal_lut, lut, 8000); d->luts_dirty = true; return LM_OK;
+    std::memcpy(d->normal_lut, lut, 8000); d->luts_dirty = true; d->lut_onehot = -1; return LM_OK;
 }
 int lm_get_similarity_lut(const lm_detector* d, uint8_t lut[256]) { if (!d || !lut) return fail(LM_ERR_INVALID, "null argument"); std::memcpy(lut, d->sim_lut, 256); return LM_OK; }
 int lm_get_normal_lut(const lm_detector* d, uint8_t lut[8000]) { if (!d || !lut) return fail(LM_ERR_INVALID, "null argument"); std::memcpy(lut, d->normal_lut, 8000); return LM_OK; }
@@ -636,7 +647,7 @@ int lm_add_template(lm_detector* d, const char* class_id, const uint8_t* bgr, si
     }
     if (M == 2) {
         lmk_depth_quantize(d->stream, d->depth(0), d->lw[0], d->lh[0], c.distance_threshold, c.difference_threshold,
-                           d->d_normal_lut, d->quant(0, 0, 1), 0, 1);
+                           d->d_normal_lut, normal_lut_onehot(d), d->quant(0, 0, 1), d->cscratch(0), 0, 1);
         enqueue_depth_pyramid(d, 0, 1);
     }
     std::vector<lmh::ExtractLevel> lv(L);
@@ -808,13 +819,13 @@ int lm_stage_depth_quantize(lm_detector* d, const uint16_t* depth, int w, int h,
     if ((rc = ready_for_compute(d))) return rc;
     if (!depth || !quantized || w <= 0 || h <= 0) return fail(LM_ERR_INVALID, "bad argument");
     size_t px = (size_t)w * h;
-    size_t o_q = align_up(px * 2, 256);
-    if ((rc = ensure_scratch(d, o_q + px))) return rc;
+    size_t o_q = align_up(px * 2, 256), o_s = o_q + align_up(px, 256);
+    if ((rc = ensure_scratch(d, o_s + px))) return rc;
     u8* base = static_cast<u8*>(d->d_scratch);
     hipStream_t st = d->stream;
     HIP_TRY(hipMemcpyAsync(base, depth, px * 2, hipMemcpyHostToDevice, st));
     lmk_depth_quantize(st, reinterpret_cast<u16*>(base), w, h, d->cfg.distance_threshold, d->cfg.difference_threshold,
-                       d->d_normal_lut, base + o_q, 0, 1);
+                       d->d_normal_lut, normal_lut_onehot(d), base + o_q, base + o_s, 0, 1);
     HIP_TRY(hipMemcpyAsync(quantized, base + o_q, px, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());

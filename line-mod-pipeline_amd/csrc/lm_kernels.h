@@ -16,8 +16,10 @@ size_t lmk_color_scratch_bytes(int w, int h);
 void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_threshold, u8* quant, float* mag,
                         u8* scratch, size_t slot_stride, int nslots);
 // a5: DepthNormal quantisation (normals + LUT + 5x5 median)
-void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_thr, int diff_thr, const u8* normal_lut,
-                        u8* quant, size_t slot_stride, int nslots);
+// scratch: w*h bytes per slot (rank codes between the two streaming passes), nullptr or a NORMAL_LUT that is
+// not 0 / one-hot selects the LDS-tiled fallback kernel.
+void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_thr, int diff_thr, const u8* lut,
+                        bool lut_onehot, u8* quant, u8* scratch, size_t slot_stride, int nslots);
 // a6+a8+a9+a10: (optional NN half-size read of `q`) -> spread(T) -> 8 response maps -> linear memories.
 // q is the quantised image to read with row pitch qpitch: src_shift 0 = this level's image, 1 = the finer
 // level's image sampled at (2y, 2x).  lm points at the modality's first orientation block.

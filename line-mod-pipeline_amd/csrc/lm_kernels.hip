@@ -712,6 +712,145 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const u16* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// a5, streaming form (w % 8 == 0 and a NORMAL_LUT whose entries are 0 or one-hot, as upstream's is; the
+// LDS-tiled k_depth_quantize above is the generic fallback and the reference for the arithmetic).
+//   k_dnormal  one lane = 8 pixels of a row: the 3 x 3 taps at distance 5 come from three rows x three
+//              aligned 16-byte blocks.  Writes the label's RANK CODE e, not the one-hot byte:
+//              0 < 1 < 2 < 4 < ... < 128 are ranks 0..8; ranks 0..3 -> e = 8 rank, 4..7 -> 8 (rank-4) + 4,
+//              8 -> 32, so that 1 << e (e < 32) is a one-hot NIBBLE counter word.
+//   k_dmedian  5 x 5 median (BORDER_REPLICATE) by counting: horizontal 5-sums of the nibble words, split
+//              into byte counters (ranks 0..3 | 4..7), vertical 5-sums, prefix sums by one multiply, and
+//              the median is the first rank whose cumulative count reaches 13 (rank 8 if none does).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 hw_u16(const u32x4* A, int hw) {
+    const u32 d = A[hw >> 3][(hw >> 1) & 3];
+    return (hw & 1) ? (d >> 16) : (d & 0xFFFFu);
+}
+
+__global__ __launch_bounds__(256) void k_dnormal(const u16* __restrict__ depth0, int w, int h, int dist_thr, int diff_thr,
+                                                  const u8* __restrict__ lut, u8* __restrict__ code0, size_t in_stride,
+                                                  size_t tmp_stride) {
+    const u16* depth = slot_ptr(depth0, in_stride);
+    u8* code = slot_ptr(code0, tmp_stride);
+    const int ng = w >> 3;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int y = gid / ng, g = gid - y * ng;
+    if (y >= h) return;
+    u32 out[2] = {0, 0};
+    if (y >= 5 && y < h - 6) {
+        u32x4 R[3][3];   // rows y-5, y, y+5; pixels 8g-8 .. 8g+15
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const u8* row = reinterpret_cast<const u8*>(depth + (size_t)(y + 5 * (j - 1)) * w) + 16 * g - 16;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const bool ok = !(k == 0 && g == 0) && !(k == 2 && g == ng - 1);
+                R[j][k] = ok ? ld16(row + 16 * k) : u32x4{0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int x = 8 * g + p;
+            u32 e = 0;
+            const int d = (int)hw_u16(R[1], 8 + p);
+            if (x >= 5 && x < w - 6 && d < dist_thr) {
+                int A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+                for (int jj = -1; jj <= 1; ++jj)
+#pragma unroll
+                    for (int ii = -1; ii <= 1; ++ii) {
+                        if (ii == 0 && jj == 0) continue;
+                        const int di = ii * 5, dj = jj * 5;
+                        const int delta = (int)hw_u16(R[jj + 1], 8 + p + di) - d;
+                        const int ad = delta < 0 ? -delta : delta;
+                        const int f = ad < diff_thr ? 1 : 0;
+                        const int fi = f * di, fj = f * dj;
+                        A0 += fi * di; A1 += fi * dj; A3 += fj * dj;
+                        b0 += fi * delta; b1 += fj * delta;
+                    }
+                const int det = A0 * A3 - A1 * A1;
+                const int ddx = A3 * b0 - A1 * b1;
+                const int ddy = -A1 * b0 + A0 * b1;
+                float nx = (float)(1150LL * ddx);
+                float ny = (float)(1150LL * ddy);
+                float nz = (float)(-(long long)det * d);
+                const float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+                if (len > 0) {
+                    const float inv = __fdiv_rn(1.0f, len);
+                    nx = __fmul_rn(nx, inv); ny = __fmul_rn(ny, inv); nz = __fmul_rn(nz, inv);
+                    const int v1 = (int)__fadd_rn(__fmul_rn(nx, 10.f), 10.f);
+                    const int v2 = (int)__fadd_rn(__fmul_rn(ny, 10.f), 10.f);
+                    const int v3 = (int)__fadd_rn(__fmul_rn(nz, 20.f), 20.f);
+                    const int flat = v3 * 400 + v2 * 20 + v1;
+                    const u32 v = (flat >= 0 && flat < 8000) ? lut[flat] : 0u;
+                    const u32 rank = (u32)__ffs((int)v);                         // 0 for none, 1 + label otherwise
+                    e = rank < 4 ? 8 * rank : (rank < 8 ? 8 * (rank - 4) + 4 : 32u);
+                }
+            }
+            out[p >> 2] |= e << (8 * (p & 3));
+        }
+    }
+    *reinterpret_cast<u32x2*>(code + (size_t)y * w + 8 * g) = u32x2{out[0], out[1]};
+}
+
+#define DM_ROWS 4   // output rows per lane of k_dmedian
+__global__ __launch_bounds__(256) void k_dmedian(const u8* __restrict__ code0, int w, int h, u8* __restrict__ quant0,
+                                                  size_t tmp_stride, size_t out_stride) {
+    const u8* code = slot_ptr(code0, tmp_stride);
+    u8* quant = slot_ptr(quant0, out_stride);
+    const int ng = w >> 3;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int band = gid / ng, g = gid - band * ng;
+    const int y0 = band * DM_ROWS;
+    if (y0 >= h) return;
+    u32 ringE[5][8], ringO[5][8];   // byte counters of the last five rows' horizontal sums: ranks 0..3 | 4..7
+    u32 sumE[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sumO[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < DM_ROWS + 4; ++i) {               // image row y0 - 2 + i, replicated at the borders
+        const int yy = clampi(y0 - 2 + i, 0, h - 1);
+        const u8* row = code + (size_t)yy * w + 8 * g;
+        const u32x2 c = *reinterpret_cast<const u32x2*>(row);
+        u32 e[12];                                        // codes of pixels 8g-2 .. 8g+9
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[2 + k] = (c[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        if (g > 0) { const u32 l = *reinterpret_cast<const u32*>(row - 4); e[0] = (l >> 16) & 0xFFu; e[1] = l >> 24; }
+        else { e[0] = e[2]; e[1] = e[2]; }
+        if (g + 1 < ng) { const u32 r = *reinterpret_cast<const u32*>(row + 8); e[10] = r & 0xFFu; e[11] = (r >> 8) & 0xFFu; }
+        else { e[10] = e[9]; e[11] = e[9]; }
+        u32 oh[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) oh[k] = (e[k] & 32u) ? 0u : (1u << e[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u32 hs = oh[k] + oh[k + 1] + oh[k + 2] + oh[k + 3] + oh[k + 4];   // nibbles <= 5
+            const u32 E = hs & 0x0F0F0F0Fu, O = (hs >> 4) & 0x0F0F0F0Fu;
+            if (i >= 5) { sumE[k] -= ringE[i % 5][k]; sumO[k] -= ringO[i % 5][k]; }
+            ringE[i % 5][k] = E; ringO[i % 5][k] = O;
+            sumE[k] += E; sumO[k] += O;
+        }
+        if (i >= 4) {
+            const int y = y0 + i - 4;
+            if (y < h) {
+                u32 o[2] = {0, 0};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const u32 PE = sumE[k] * 0x01010101u;                       // prefix sums of ranks 0..3
+                    const u32 PO = sumO[k] * 0x01010101u + (PE >> 24) * 0x01010101u;
+                    const u32 mE = (PE + 0x73737373u) & 0x80808080u;            // byte >= 13
+                    const u32 mO = (PO + 0x73737373u) & 0x80808080u;
+                    u32 res;
+                    if (mE) res = (1u << ((u32)(__ffs((int)mE) - 1) >> 3)) >> 1;   // ranks 0..3 -> 0, 1, 2, 4
+                    else if (mO) res = 8u << ((u32)(__ffs((int)mO) - 1) >> 3);     // ranks 4..7 -> 8 .. 64
+                    else res = 128u;
+                    o[k >> 2] |= res << (8 * (k & 3));
+                }
+                *reinterpret_cast<u32x2*>(quant + (size_t)y * w + 8 * g) = u32x2{o[0], o[1]};
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // a6-a10  One workgroup per (band of T image rows, segment of `seg` memory columns).
 //   LDS: response table (256 x u64: byte o = response of orientation o to spread value v),
 //        (2T-1) source rows of the segment (+T-1 halo columns), their horizontal OR.
@@ -1504,7 +1643,16 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
 }
 
 void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_thr, int diff_thr, const u8* lut,
-                        u8* quant, size_t slot_stride, int nslots) {
+                        bool lut_onehot, u8* quant, u8* scratch, size_t slot_stride, int nslots) {
+    if (scratch && lut_onehot && (w % 8) == 0 && ((uintptr_t)depth & 15) == 0 && ((uintptr_t)scratch & 7) == 0 &&
+        ((uintptr_t)quant & 7) == 0 && (slot_stride % 16) == 0) {
+        const int n_n = (w / 8) * h, n_m = (w / 8) * ((h + DM_ROWS - 1) / DM_ROWS);
+        hipLaunchKernelGGL(k_dnormal, dim3((n_n + 255) / 256, 1, nslots), dim3(256), 0, s, depth, w, h, dist_thr, diff_thr,
+                           lut, scratch, slot_stride, slot_stride);
+        hipLaunchKernelGGL(k_dmedian, dim3((n_m + 255) / 256, 1, nslots), dim3(256), 0, s, scratch, w, h, quant,
+                           slot_stride, slot_stride);
+        return;
+    }
     dim3 grid((w + DT_W - 1) / DT_W, (h + DT_H - 1) / DT_H, nslots);
     hipLaunchKernelGGL(k_depth_quantize, grid, dim3(256), 0, s, depth, w, h, dist_thr, diff_thr, lut, quant,
                        slot_stride);

@@ -83,6 +83,10 @@ def test_depth_quantize_frame0_and_custom_lut(lm, orc, frame0):
     lut = rng.integers(0, 256, 8000).astype(np.uint8)            # arbitrary bytes: median must be a true median
     d.set_normal_lut(lut)
     assert np.array_equal(d.stage_depth_quantize(depth), orc.depth_quantize(depth, lut=lut))
+    # 0 / one-hot entries in another arrangement: stays on the streaming kernels (counting median)
+    lut2 = np.where(rng.random(8000) < 0.1, 0, 1 << rng.integers(0, 8, 8000)).astype(np.uint8)
+    d.set_normal_lut(lut2)
+    assert np.array_equal(d.stage_depth_quantize(depth), orc.depth_quantize(depth, lut=lut2))
     d.close()
 
 
