@@ -81,8 +81,8 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
     for (const ClassEntry& c : bank.classes)
         for (const TemplatePyramid& tp : c.pyramids)
             for (int m = 0; m < M; ++m) maxf = std::max(maxf, (int)tp[(size_t)(L - 1) * M + m].features.size());
-    // byte scan: lists padded to LM_SCAN_FPAD; nibble scan (k_scan4): to a multiple of 3, offsets in nibbles
-    const int fq = gl.nibble ? 3 : LM_SCAN_FPAD;
+    // byte scan: lists padded to LM_SCAN_FPAD; nibble scan (k_scan4): loops to the pair's own feature count, offsets in nibbles
+    const int fq = gl.nibble ? 1 : LM_SCAN_FPAD;
     const u32 osc = gl.nibble ? 2u : 1u;
     out.fpad = (maxf + fq - 1) / fq * fq;
     const int nc = (int)bank.classes.size();
@@ -103,7 +103,7 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
             out.t_class.push_back(ci);
             // ---- scan level
             const Template& t0 = tp[(size_t)(L - 1) * M];
-            int n_total = 0;
+            int n_total = 0, cnt_packed = 0;
             int P = 0;
             double fcount = 0;
             for (int m = 0; m < M; ++m) {
@@ -128,6 +128,7 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
                     ++k;
                 }
                 fcount += k;
+                cnt_packed |= k << (8 + 8 * m);
                 // the sum is order-independent: ascending offsets make the waves resident on one CU (they start
                 // together and step through their lists in step) read from the same few linear memories at a
                 // time, so part of the traffic is served by the CU's L1 instead of L2
@@ -135,7 +136,7 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
                 for (; k < out.fpad; ++k) out.scan_off.push_back(osc * gl.zero_off);
             }
             out.scan_P.push_back(P);
-            out.scan_n.push_back(n_total);
+            out.scan_n.push_back(n_total | cnt_packed);   // n (bits 0-7) | in-bounds features of modality 0 / 1 (bits 8-15 / 16-23)
             out.class_alg_bytes[ci] += fcount * (double)P;
             const int chunk = gl.nibble ? LM_SCAN4_CHUNK : LM_SCAN_CHUNK;
             for (int ch = 0; ch * chunk < P; ++ch) { out.item_t.push_back(ti); out.item_chunk.push_back((u32)ch); }

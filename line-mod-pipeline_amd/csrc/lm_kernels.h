@@ -40,7 +40,7 @@ struct LmScanArgs {
     int nibble;              // 1: two positions per byte (k_scan4), scan_off in nibbles, fpad % 3 == 0
     const u32* scan_off;     // [nt][M][fpad] byte offsets into the arena
     const int* scan_P;       // [nt] template_positions
-    const int* scan_n;       // [nt] total number of features at the lowest level
+    const int* scan_n;       // [nt] total number of features at the lowest level | per-modality in-bounds counts << 8, << 16
     int M, fpad;
     const int* raw_thr_by_n; // [128]
     int W, T;

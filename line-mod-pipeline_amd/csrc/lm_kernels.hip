@@ -306,233 +306,171 @@ __global__ __launch_bounds__(256) void k_color_quantize(const u8* __restrict__ b
 
 // ------------------------------------------------------------------------------------------------
 // a3, streaming form (used when w % 16 == 0; the fused LDS-tiled k_color_quantize above is the generic
-// fallback and the reference for the arithmetic).  Four passes through L2-resident scratch:
-//   k_cblur_h  horizontal 7-tap on the interleaved BGR byte stream: the taps of byte p are bytes
-//              p-9, p-6, ..., p+9 whatever the channel (SWAR on u16 pairs, v_alignbyte_b32 for the
-//              odd offsets)                                                    -> hb  u16 [h][3w]
-//   k_cblur_v  vertical 7-tap + rounding, fused with the vertical halves of the Sobel
-//              VS = S(y-1) + 2 S(y) + S(y+1), VD = S(y+1) - S(y-1)            -> vs, vd i16 [h][3w]
-//   k_corient  dx = VS(x+1) - VS(x-1), dy = VD(x-1) + 2 VD(x) + VD(x+1), strongest channel,
-//              fastAtan2, 16 -> 8 bins, magnitude flag                         -> qn  u8 [h][w]
+// fallback and the reference for the arithmetic).  Three passes through scratch:
+//   k_cblur    7x7 Gaussian, vertical taps on raw bytes (u16 pairs) then horizontal taps with the final
+//              rounding, both in registers                                     -> S   u8 [h][3w]
+//   k_corient  3x3 Sobel on S (replicate), strongest channel, fastAtan2, 16 -> 8 bins, magnitude flag
+//                                                                              -> qn  u8 [h][w]
 //   k_cvote    3x3 majority vote gated by the flag                             -> quant
-// Replicate borders exactly as the fused kernel: blur taps clamp, Sobel reads S at clamped coordinates.
 //
 // Load shape.  The vector L1 takes one cycle per 4 lanes of a load instruction whatever the width per
 // lane (measured: TCP_TOTAL_CACHE_ACCESSES = 16 per wave-load + one per 128-B line crossed), so a
 // byte or short load per lane runs at 1/16 .. 1/8 of the rate of a 16-byte one.  Every pass
 // therefore gives a lane 16 contiguous bytes per load (global_load_dwordx4) and 8 or 16 outputs.
+// Intermediates are kept small on purpose (8-bit S instead of 16-bit partial sums): with 32+ frames in
+// flight they do not fit the L2s and every byte written here is fabric traffic.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
-// one lane = 16 bytes of a row (3w % 16 == 0)
-__global__ __launch_bounds__(256) void k_cblur_h(const u8* __restrict__ bgr0, int w, int h, u16* __restrict__ hb0,
-                                                  size_t in_stride, size_t tmp_stride) {
+// a1+a2  GaussianBlur 7x7 -> S (the smoothed 8-bit image).  One lane = 16 bytes of a row x CB_ROWS rows.
+// Vertical taps first, on the raw bytes as u16 pairs (8 * 255 * 72.. sums <= 65280 fit 16 bits), then
+// the horizontal taps on the 16-bit column sums of the lane's 40-byte window (bytes -12 .. +27 around the
+// block: the taps of byte p are bytes p-9, p-6, ..., p+9 whatever the channel) with the final rounding.
+// The two separable passes are exact integer sums, so their order does not matter.
+#define CB_ROWS 2
+__global__ __launch_bounds__(256) void k_cblur(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
+                                                size_t in_stride, size_t tmp_stride) {
     const u8* bgr = slot_ptr(bgr0, in_stride);
-    u16* hb = slot_ptr(hb0, tmp_stride);
+    u8* S = slot_ptr(s0, tmp_stride);
     const int nblk = (w * 3) >> 4;
     const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int y = gid / nblk, b = gid - y * nblk;
-    if (y >= h) return;
-    const u8* row = bgr + (size_t)y * w * 3;
-    const u32x4 c = ld16(row + 16 * b);
-    u32 W[10];
-    if (b > 0) {
-        const u32x4 p = ld16(row + 16 * b - 16);
-        W[0] = p[1]; W[1] = p[2]; W[2] = p[3];
-    } else {   // bytes -12..-1 replicate pixel 0 channel-wise: [B G R B][G R B G][R B G R]
-        W[0] = __builtin_amdgcn_perm(c[0], c[0], 0x00020100u);
-        W[1] = __builtin_amdgcn_perm(c[0], c[0], 0x01000201u);
-        W[2] = __builtin_amdgcn_perm(c[0], c[0], 0x02010002u);
-    }
-    W[3] = c[0]; W[4] = c[1]; W[5] = c[2]; W[6] = c[3];
-    if (b + 1 < nblk) {
-        const u32x4 n = ld16(row + 16 * b + 16);
-        W[7] = n[0]; W[8] = n[1]; W[9] = n[2];
-    } else {   // bytes 3w.. replicate the last pixel (bytes 1..3 of the last dword): [B G R B][G R B G][R B G R]
-        W[7] = __builtin_amdgcn_perm(c[3], c[3], 0x01030201u);
-        W[8] = __builtin_amdgcn_perm(c[3], c[3], 0x02010302u);
-        W[9] = __builtin_amdgcn_perm(c[3], c[3], 0x03020103u);
-    }
-    u32 o[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const u32 D0 = W[j], D1 = W[j + 1], D2 = W[j + 2], D3 = W[j + 3], D4 = W[j + 4], D5 = W[j + 5], D6 = W[j + 6];
-        const u32 tm9 = __builtin_amdgcn_alignbyte(D1, D0, 3u), tm6 = __builtin_amdgcn_alignbyte(D2, D1, 2u);
-        const u32 tm3 = __builtin_amdgcn_alignbyte(D3, D2, 1u), tp3 = __builtin_amdgcn_alignbyte(D4, D3, 3u);
-        const u32 tp6 = __builtin_amdgcn_alignbyte(D5, D4, 2u), tp9 = __builtin_amdgcn_alignbyte(D6, D5, 1u);
-#define LM_EV(t) ((t) & 0x00FF00FFu)
-#define LM_OD(t) (((t) >> 8) & 0x00FF00FFu)
-        const u32 e_sum = 8u * (LM_EV(tm9) + LM_EV(tp9)) + 28u * (LM_EV(tm6) + LM_EV(tp6)) + 56u * (LM_EV(tm3) + LM_EV(tp3)) + 72u * LM_EV(D3);
-        const u32 o_sum = 8u * (LM_OD(tm9) + LM_OD(tp9)) + 28u * (LM_OD(tm6) + LM_OD(tp6)) + 56u * (LM_OD(tm3) + LM_OD(tp3)) + 72u * LM_OD(D3);
-#undef LM_EV
-#undef LM_OD
-        o[2 * j] = (e_sum & 0xFFFFu) | (o_sum << 16);
-        o[2 * j + 1] = (e_sum >> 16) | (o_sum & 0xFFFF0000u);
-    }
-    u16* dst = hb + (size_t)y * w * 3 + 16 * b;
-    st16(dst, u32x4{o[0], o[1], o[2], o[3]});
-    st16(dst + 8, u32x4{o[4], o[5], o[6], o[7]});
-}
-
-#define CV_ROWS 8   // output rows per lane of k_cblur_v
-// Band at the top / bottom of the image: every tap clamped; 4 values (one 8-byte group) per call.
-__device__ __forceinline__ void cblur_v_edge(const u16* __restrict__ hb, int16_t* __restrict__ vs, int16_t* __restrict__ vd,
-                                             size_t pitch, int h, int y0, int j) {
-    int sm1[4] = {0, 0, 0, 0}, s0[4] = {0, 0, 0, 0};
-    for (int r = -1; r <= CV_ROWS; ++r) {
-        const int sy = clampi(y0 + r, 0, h - 1);          // Sobel reads the smoothed image at clamped rows
-        u32 acc[4] = {0, 0, 0, 0};
-        const u32 K[7] = {8, 28, 56, 72, 56, 28, 8};
-#pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            const int hy = clampi(sy + t - 3, 0, h - 1);  // GaussianBlur: BORDER_REPLICATE
-            const u32* p = reinterpret_cast<const u32*>(hb + (size_t)hy * pitch + 4 * j);
-            const u32 a = p[0], b = p[1];
-            acc[0] += K[t] * (a & 0xFFFFu); acc[1] += K[t] * (a >> 16);
-            acc[2] += K[t] * (b & 0xFFFFu); acc[3] += K[t] * (b >> 16);
-        }
-        int s1[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s1[k] = (int)((acc[k] + 32768u) >> 16);
-        if (r >= 1) {
-            const int y = y0 + r - 1;
-            if (y < h) {
-                u32* ovs = reinterpret_cast<u32*>(vs + (size_t)y * pitch + 4 * j);
-                u32* ovd = reinterpret_cast<u32*>(vd + (size_t)y * pitch + 4 * j);
-                int a0 = sm1[0] + 2 * s0[0] + s1[0], a1 = sm1[1] + 2 * s0[1] + s1[1];
-                int a2 = sm1[2] + 2 * s0[2] + s1[2], a3 = sm1[3] + 2 * s0[3] + s1[3];
-                int d0 = s1[0] - sm1[0], d1 = s1[1] - sm1[1], d2 = s1[2] - sm1[2], d3 = s1[3] - sm1[3];
-                ovs[0] = (u32)(a0 & 0xFFFF) | ((u32)a1 << 16);
-                ovs[1] = (u32)(a2 & 0xFFFF) | ((u32)a3 << 16);
-                ovd[0] = (u32)(d0 & 0xFFFF) | ((u32)d1 << 16);
-                ovd[1] = (u32)(d2 & 0xFFFF) | ((u32)d3 << 16);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { sm1[k] = s0[k]; s0[k] = s1[k]; }
-    }
-}
-
-// one lane = 8 values (16 bytes of hb) x CV_ROWS output rows.  Interior bands read each of the
-// CV_ROWS + 8 hb rows once and scatter it into the 7 smoothed rows it contributes to (ring of 7 x 8
-// partial sums); a smoothed row that completes is combined with its two predecessors into VS / VD.
-__global__ __launch_bounds__(256) void k_cblur_v(const u16* __restrict__ hb0, int w, int h, int16_t* __restrict__ vs0,
-                                                  int16_t* __restrict__ vd0, size_t tmp_stride) {
-    const u16* hb = slot_ptr(hb0, tmp_stride);
-    int16_t* vs = slot_ptr(vs0, tmp_stride);
-    int16_t* vd = slot_ptr(vd0, tmp_stride);
-    const int ncol = (w * 3) >> 3;                       // groups of 8 values
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int band = gid / ncol, j = gid - band * ncol;
-    const int y0 = band * CV_ROWS;
+    const int band = gid / nblk, b = gid - band * nblk;
+    const int y0 = band * CB_ROWS;
     if (y0 >= h) return;
     const size_t pitch = (size_t)w * 3;
-    if (y0 < 4 || y0 + CV_ROWS + 4 > h) {
-        cblur_v_edge(hb, vs, vd, pitch, h, y0, 2 * j);
-        cblur_v_edge(hb, vs, vd, pitch, h, y0, 2 * j + 1);
-        return;
-    }
     const u32 K[7] = {8, 28, 56, 72, 56, 28, 8};
-    u32 acc[7][8];
-    int p2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, p1[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // S(r-2), S(r-1)
+    u32 ev[CB_ROWS][10], od[CB_ROWS][10];   // column sums of output row r: bytes {4d, 4d+2} / {4d+1, 4d+3} of window dword d
 #pragma unroll
-    for (int i = 0; i < CV_ROWS + 8; ++i) {              // hb row y0 - 4 + i feeds S rows r = i - 6 .. i (image row y0 - 1 + r)
-        const u32x4 d = ld16(hb + (size_t)(y0 - 4 + i) * pitch + 8 * j);
-        u32 v[8];
+    for (int i = 0; i < CB_ROWS + 6; ++i) {               // source row y0 - 3 + i (BORDER_REPLICATE)
+        const u8* row = bgr + (size_t)clampi(y0 - 3 + i, 0, h - 1) * pitch;
+        const u32x4 c = ld16(row + 16 * b);
+        u32 W[10];
+        if (b > 0) {
+            const u32x4 p = ld16(row + 16 * b - 16);
+            W[0] = p[1]; W[1] = p[2]; W[2] = p[3];
+        } else {   // bytes -12..-1 replicate pixel 0 channel-wise: [B G R B][G R B G][R B G R]
+            W[0] = __builtin_amdgcn_perm(c[0], c[0], 0x00020100u);
+            W[1] = __builtin_amdgcn_perm(c[0], c[0], 0x01000201u);
+            W[2] = __builtin_amdgcn_perm(c[0], c[0], 0x02010002u);
+        }
+        W[3] = c[0]; W[4] = c[1]; W[5] = c[2]; W[6] = c[3];
+        if (b + 1 < nblk) {
+            const u32x4 n = ld16(row + 16 * b + 16);
+            W[7] = n[0]; W[8] = n[1]; W[9] = n[2];
+        } else {   // bytes 3w.. replicate the last pixel (bytes 1..3 of the last dword): [B G R B][G R B G][R B G R]
+            W[7] = __builtin_amdgcn_perm(c[3], c[3], 0x01030201u);
+            W[8] = __builtin_amdgcn_perm(c[3], c[3], 0x02010302u);
+            W[9] = __builtin_amdgcn_perm(c[3], c[3], 0x03020103u);
+        }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { v[2 * k] = d[k] & 0xFFFFu; v[2 * k + 1] = d[k] >> 16; }
+        for (int d = 0; d < 10; ++d) {
+            const u32 e = W[d] & 0x00FF00FFu, o = (W[d] >> 8) & 0x00FF00FFu;
 #pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            const int r = i - t;
-            if (r < 0 || r > CV_ROWS + 1) continue;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (t == 0) acc[r % 7][k] = K[0] * v[k];
-                else acc[r % 7][k] += K[t] * v[k];
+            for (int r = 0; r < CB_ROWS; ++r) {
+                const int t = i - r;                      // tap of output row r
+                if (t < 0 || t > 6) continue;
+                if (t == 0) { ev[r][d] = K[0] * e; od[r][d] = K[0] * o; }
+                else { ev[r][d] += K[t] * e; od[r][d] += K[t] * o; }
             }
         }
-        const int r = i - 6;                             // this S row is complete
-        if (r >= 0 && r <= CV_ROWS + 1) {
-            int s[8];
+    }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s[k] = (int)((acc[r % 7][k] + 32768u) >> 16);
-            if (r >= 2) {
-                const int y = y0 + r - 2;
-                int a[8], dd[8];
+    for (int r = 0; r < CB_ROWS; ++r) {
+        const int y = y0 + r;
+        if (y >= h) break;
+        u32 o4[4];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { a[k] = p2[k] + 2 * p1[k] + s[k]; dd[k] = s[k] - p2[k]; }
-                st16(vs + (size_t)y * pitch + 8 * j,
-                     u32x4{(u32)(a[0] & 0xFFFF) | ((u32)a[1] << 16), (u32)(a[2] & 0xFFFF) | ((u32)a[3] << 16),
-                           (u32)(a[4] & 0xFFFF) | ((u32)a[5] << 16), (u32)(a[6] & 0xFFFF) | ((u32)a[7] << 16)});
-                st16(vd + (size_t)y * pitch + 8 * j,
-                     u32x4{(u32)(dd[0] & 0xFFFF) | ((u32)dd[1] << 16), (u32)(dd[2] & 0xFFFF) | ((u32)dd[3] << 16),
-                           (u32)(dd[4] & 0xFFFF) | ((u32)dd[5] << 16), (u32)(dd[6] & 0xFFFF) | ((u32)dd[7] << 16)});
+        for (int j = 0; j < 4; ++j) {
+            u32 packed = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // output byte 4j + q of the block = window byte 12 + 4j + q; taps at window bytes wb - 9 .. wb + 9
+                u32 acc = 0;
+#pragma unroll
+                for (int t = 0; t < 7; ++t) {
+                    const int wb = 12 + 4 * j + q + 3 * t - 9;
+                    const u32 dsum = (wb & 1) ? od[r][wb >> 2] : ev[r][wb >> 2];
+                    const u32 v = (wb & 2) ? (dsum >> 16) : (dsum & 0xFFFFu);
+                    acc += K[t] * v;
+                }
+                packed |= ((acc + 32768u) >> 16) << (8 * q);
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { p2[k] = p1[k]; p1[k] = s[k]; }
+            o4[j] = packed;
         }
+        st16(S + (size_t)y * pitch + 16 * b, u32x4{o4[0], o4[1], o4[2], o4[3]});
     }
 }
 
-// halfword hw of a buffer of dwordx4, sign-extended
-__device__ __forceinline__ int hw_s16(const u32x4* A, int hw) {
-    const u32 d = A[hw >> 3][(hw >> 1) & 3];
-    return (hw & 1) ? ((int)d >> 16) : (int)(int16_t)(d & 0xFFFFu);
-}
-
-// one lane = 8 pixels of a row (w % 8 == 0): the 10-pixel window of VS / VD is 60 bytes starting 6 bytes
-// before pixel 8g, i.e. at byte 10 of five aligned 16-byte blocks starting at 48 g - 16.
-__global__ __launch_bounds__(256) void k_corient(const int16_t* __restrict__ vs0, const int16_t* __restrict__ vd0, int w,
-                                                  int h, float thr2, u8* __restrict__ qn0, float* __restrict__ mag0,
-                                                  size_t tmp_stride, size_t mag_stride) {
-    const int16_t* vs = slot_ptr(vs0, tmp_stride);
-    const int16_t* vd = slot_ptr(vd0, tmp_stride);
+// a2+a3  Sobel(S, BORDER_REPLICATE) + strongest channel + fastAtan2 + 16 -> 8 bins + magnitude flag.
+// One lane = 16 pixels of a row (w % 16 == 0): rows y-1, y, y+1 of S, 48 bytes each plus the dword before
+// and after.  The vertical halves VS = S(y-1) + 2 S(y) + S(y+1) and VD + 256 = S(y+1) + 256 - S(y-1) are
+// formed on u16 pairs; window byte of pixel i (image x = 16g - 1 + i), channel c is 1 + 3i + c.
+__global__ __launch_bounds__(256) void k_corient(const u8* __restrict__ s0, int w, int h, float thr2,
+                                                  u8* __restrict__ qn0, float* __restrict__ mag0, size_t tmp_stride,
+                                                  size_t mag_stride) {
+    const u8* S = slot_ptr(s0, tmp_stride);
     u8* qn = slot_ptr(qn0, tmp_stride);
     float* mag = mag0 ? slot_ptr(mag0, mag_stride) : nullptr;
-    const int ng = w >> 3;
+    const int ng = w >> 4;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int y = gid / ng, g = gid - y * ng;
     if (y >= h) return;
-    const u8* vsr = reinterpret_cast<const u8*>(vs + (size_t)y * w * 3) + 48 * g - 16;
-    const u8* vdr = reinterpret_cast<const u8*>(vd + (size_t)y * w * 3) + 48 * g - 16;
-    u32x4 A[5], B[5];
+    const size_t pitch = (size_t)w * 3;
+    u32 R[3][14];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        // block 0 only holds pixel 8g - 1, block 4 only pixel 8g + 8: outside the row they are replaced below
-        const bool ok = !(k == 0 && g == 0) && !(k == 4 && g == ng - 1);
-        A[k] = ok ? ld16(vsr + 16 * k) : u32x4{0, 0, 0, 0};
-        B[k] = ok ? ld16(vdr + 16 * k) : u32x4{0, 0, 0, 0};
+    for (int j = 0; j < 3; ++j) {
+        const u8* row = S + (size_t)clampi(y - 1 + j, 0, h - 1) * pitch + 48 * g;
+        const u32x4 a = ld16(row), b = ld16(row + 16), c = ld16(row + 32);
+        R[j][0] = g > 0 ? *reinterpret_cast<const u32*>(row - 4) : 0u;
+        R[j][1] = a[0]; R[j][2] = a[1]; R[j][3] = a[2]; R[j][4] = a[3];
+        R[j][5] = b[0]; R[j][6] = b[1]; R[j][7] = b[2]; R[j][8] = b[3];
+        R[j][9] = c[0]; R[j][10] = c[1]; R[j][11] = c[2]; R[j][12] = c[3];
+        R[j][13] = g + 1 < ng ? *reinterpret_cast<const u32*>(row + 48) : 0u;
     }
-    int S[10][3], D[10][3];   // window pixel i = image x 8g - 1 + i
+    u32 vse[14], vso[14], vde[14], vdo[14];
 #pragma unroll
-    for (int i = 0; i < 10; ++i)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { S[i][c] = hw_s16(A, 5 + 3 * i + c); D[i][c] = hw_s16(B, 5 + 3 * i + c); }
-    if (g == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { S[0][c] = S[1][c]; D[0][c] = D[1][c]; }
+    for (int d = 0; d < 14; ++d) {
+        const u32 e0 = R[0][d] & 0x00FF00FFu, o0 = (R[0][d] >> 8) & 0x00FF00FFu;
+        const u32 e1 = R[1][d] & 0x00FF00FFu, o1 = (R[1][d] >> 8) & 0x00FF00FFu;
+        const u32 e2 = R[2][d] & 0x00FF00FFu, o2 = (R[2][d] >> 8) & 0x00FF00FFu;
+        vse[d] = e0 + 2u * e1 + e2; vso[d] = o0 + 2u * o1 + o2;
+        vde[d] = e2 + 0x01000100u - e0; vdo[d] = o2 + 0x01000100u - o0;
     }
-    if (g == ng - 1) {
+#define LM_WIN(E, O, wb) ((int)((((wb) & 1) ? O[(wb) >> 2] : E[(wb) >> 2]) >> (((wb) & 2) ? 16 : 0)) & 0xFFFF)
+    u32 out[4] = {0, 0, 0, 0};
+    float fmv[16];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { S[9][c] = S[8][c]; D[9][c] = D[8][c]; }
-    }
-    u32 out[2] = {0, 0};
-    float fmv[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int x = 8 * g + p;
+    for (int p = 0; p < 16; ++p) {
+        const int x = 16 * g + p;
+        // window pixels p (x-1), p+1 (x), p+2 (x+1); at the row ends the missing neighbour is the pixel itself
         int bdx = 0, bdy = 0, bm = -1;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            int dx = S[p + 2][c] - S[p][c];
-            int dy = D[p][c] + 2 * D[p + 1][c] + D[p + 2][c];
-            int m = dx * dx + dy * dy;
+            int sl, sr, dl, dr;
+            if (p == 0) {
+                sl = g == 0 ? LM_WIN(vse, vso, 1 + 3 * 1 + c) : LM_WIN(vse, vso, 1 + 3 * 0 + c);
+                dl = g == 0 ? LM_WIN(vde, vdo, 1 + 3 * 1 + c) : LM_WIN(vde, vdo, 1 + 3 * 0 + c);
+            } else {
+                sl = LM_WIN(vse, vso, 1 + 3 * p + c);
+                dl = LM_WIN(vde, vdo, 1 + 3 * p + c);
+            }
+            if (p == 15) {
+                sr = g == ng - 1 ? LM_WIN(vse, vso, 1 + 3 * 16 + c) : LM_WIN(vse, vso, 1 + 3 * 17 + c);
+                dr = g == ng - 1 ? LM_WIN(vde, vdo, 1 + 3 * 16 + c) : LM_WIN(vde, vdo, 1 + 3 * 17 + c);
+            } else {
+                sr = LM_WIN(vse, vso, 1 + 3 * (p + 2) + c);
+                dr = LM_WIN(vde, vdo, 1 + 3 * (p + 2) + c);
+            }
+            const int dc = LM_WIN(vde, vdo, 1 + 3 * (p + 1) + c);
+            const int dx = sr - sl;
+            const int dy = dl + 2 * dc + dr - 1024;       // four biases of 256
+            const int m = dx * dx + dy * dy;
             if (m > bm) { bm = m; bdx = dx; bdy = dy; }   // first maximum wins ties = upstream's >= cascade
         }
         const float scale = (float)(16.0 / 360.0);
-        float ang = fast_atan2_deg((float)bdy, (float)bdx);
-        float qf = rintf(__fadd_rn(__fmul_rn(ang, scale), 0.0f));
+        const float ang = fast_atan2_deg((float)bdy, (float)bdx);
+        const float qf = rintf(__fadd_rn(__fmul_rn(ang, scale), 0.0f));
         int q = (int)qf;
         q = q < 0 ? 0 : (q > 255 ? 255 : q);
         const bool border = (y == 0) | (y == h - 1) | (x == 0) | (x == w - 1);
@@ -542,11 +480,12 @@ __global__ __launch_bounds__(256) void k_corient(const int16_t* __restrict__ vs0
         out[p >> 2] |= o << (8 * (p & 3));
         fmv[p] = fm;
     }
-    *reinterpret_cast<u32x2*>(qn + (size_t)y * w + 8 * g) = u32x2{out[0], out[1]};
+#undef LM_WIN
+    st16(qn + (size_t)y * w + 16 * g, u32x4{out[0], out[1], out[2], out[3]});
     if (mag) {
-        float* mo = mag + (size_t)y * w + 8 * g;
+        float* mo = mag + (size_t)y * w + 16 * g;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) mo[p] = fmv[p];
+        for (int p = 0; p < 16; ++p) mo[p] = fmv[p];
     }
 }
 
@@ -1134,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
     const u32 ti = a.item_t[a.item_lo + wave];
     const u32 chunk = a.item_chunk[a.item_lo + wave];
     const int P = a.scan_P[ti];
-    const int n = a.scan_n[ti];
+    const int n = a.scan_n[ti] & 0xFF;
     const int thr = a.raw_thr_by_n[n];
     const u32 j0 = chunk * LM_SCAN_CHUNK + (u32)lane * 16u;
     // buffer addressing: descriptor base = this wave's chunk, voffset = the lane's 16 bytes, soffset = feature
@@ -1239,7 +1178,8 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
     const bool hi = lane >= 32;
     const u32 ti = hi ? tiB : tiA;
     const int P = hi ? (hasB ? a.scan_P[tiB] : 0) : a.scan_P[tiA];
-    const int n = hi ? a.scan_n[tiB] : a.scan_n[tiA];
+    const int cntA = a.scan_n[tiA], cntB = hasB ? a.scan_n[tiB] : 0;   // n | features of modality 0 << 8 | of 1 << 16
+    const int n = (hi ? a.scan_n[tiB] : cntA) & 0xFF;
     const int thr = a.raw_thr_by_n[n];
     const u32 j0 = (hi ? chB : chA) * LM_SCAN4_CHUNK + (u32)(lane & 31) * 32u;   // first position of this lane
     // one buffer descriptor for the slot's arena; voffset = the lane's 16 bytes inside its item's chunk + the
@@ -1272,7 +1212,7 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
             }                                                                                    \
             _Pragma("unroll") for (int g3 = 0; g3 < NF; g3 += 3) {                               \
                 u32 nb[4] = {0, 0, 0, 0};                                                        \
-                _Pragma("unroll") for (int k = g3; k < g3 + 3; ++k) {                            \
+                _Pragma("unroll") for (int k = g3; k < (g3 + 3 < NF ? g3 + 3 : NF); ++k) {       \
                     const u32 nx = next_lane(v[k][0]);                                           \
                     nb[0] += __builtin_amdgcn_alignbit(v[k][1], v[k][0], sh[k]);                 \
                     nb[1] += __builtin_amdgcn_alignbit(v[k][2], v[k][1], sh[k]);                 \
@@ -1284,11 +1224,15 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
                 }                                                                                \
             }                                                                                    \
         }
+        // features of this modality: the longer list of the pair (the shorter one is padded with zero-block offsets)
+        const int fa = (cntA >> (8 + 8 * m)) & 0xFF, fb = (cntB >> (8 + 8 * m)) & 0xFF;
+        const int F = fa > fb ? fa : fb;
         int f = 0;
-        for (; f + FB <= a.fpad; f += FB) LM_SCAN4_BLOCK(FB)
-        if (FB > 6 && f + 6 <= a.fpad) { LM_SCAN4_BLOCK(6) f += 6; }
-        if (f + 3 <= a.fpad) { LM_SCAN4_BLOCK(3) f += 3; }
-        if (FB > 6 && f < a.fpad) LM_SCAN4_BLOCK(3)
+        for (; f + FB <= F; f += FB) LM_SCAN4_BLOCK(FB)
+        if (FB > 6 && f + 6 <= F) { LM_SCAN4_BLOCK(6) f += 6; }
+        if (FB > 3 && f + 3 <= F) { LM_SCAN4_BLOCK(3) f += 3; }
+        if (F - f == 2) LM_SCAN4_BLOCK(2)
+        else if (F - f == 1) LM_SCAN4_BLOCK(1)
 #undef LM_SCAN4_BLOCK
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1613,9 +1557,9 @@ void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, i
 }
 
 size_t lmk_color_scratch_bytes(int w, int h) {
-    // hb u16 [h][3w] | vs i16 [h][3w] | vd i16 [h][3w] | qn u8 [h][w], each 256-B aligned
+    // S u8 [h][3w] | qn u8 [h][w], each 256-B aligned (also the rank-code image of the depth passes)
     size_t px = (size_t)w * h;
-    return 3 * ((px * 6 + 255) / 256 * 256) + (px + 255) / 256 * 256;
+    return (px * 3 + 255) / 256 * 256 + (px + 255) / 256 * 256;
 }
 
 void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_threshold, u8* quant, float* mag,
@@ -1623,18 +1567,14 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
     const float thr2 = weak_threshold * weak_threshold;
     if (scratch && (w % 16) == 0 && ((uintptr_t)bgr & 15) == 0 && ((uintptr_t)scratch & 15) == 0 &&
         ((uintptr_t)quant & 15) == 0 && (slot_stride % 16) == 0) {
-        const size_t px = (size_t)w * h, a6 = (px * 6 + 255) / 256 * 256;
-        u16* hb = reinterpret_cast<u16*>(scratch);
-        int16_t* vs = reinterpret_cast<int16_t*>(scratch + a6);
-        int16_t* vd = reinterpret_cast<int16_t*>(scratch + 2 * a6);
-        u8* qn = scratch + 3 * a6;
-        const int n_h = (w * 3 / 16) * h;                                     // 16-byte blocks of the image
-        const int n_v = (w * 3 / 8) * ((h + CV_ROWS - 1) / CV_ROWS);          // 8-value columns x bands
-        const int n_o = (w / 8) * h;                                          // 8-pixel groups
+        const size_t px = (size_t)w * h, a3 = (px * 3 + 255) / 256 * 256;
+        u8* S = scratch;
+        u8* qn = scratch + a3;
+        const int n_b = (w * 3 / 16) * ((h + CB_ROWS - 1) / CB_ROWS);         // 16-byte blocks x row bands
+        const int n_o = (w / 16) * h;                                         // 16-pixel groups
         const int n_t = (w / 16) * ((h + CVT_ROWS - 1) / CVT_ROWS);           // 16-pixel groups x bands
-        hipLaunchKernelGGL(k_cblur_h, dim3((n_h + 255) / 256, 1, nslots), dim3(256), 0, s, bgr, w, h, hb, slot_stride, slot_stride);
-        hipLaunchKernelGGL(k_cblur_v, dim3((n_v + 255) / 256, 1, nslots), dim3(256), 0, s, hb, w, h, vs, vd, slot_stride);
-        hipLaunchKernelGGL(k_corient, dim3((n_o + 255) / 256, 1, nslots), dim3(256), 0, s, vs, vd, w, h, thr2, qn, mag, slot_stride, slot_stride);
+        hipLaunchKernelGGL(k_cblur, dim3((n_b + 255) / 256, 1, nslots), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride);
+        hipLaunchKernelGGL(k_corient, dim3((n_o + 255) / 256, 1, nslots), dim3(256), 0, s, S, w, h, thr2, qn, mag, slot_stride, slot_stride);
         hipLaunchKernelGGL(k_cvote, dim3((n_t + 255) / 256, 1, nslots), dim3(256), 0, s, qn, w, h, quant, slot_stride, slot_stride);
         return;
     }
