@@ -188,6 +188,9 @@ int lm_time_stages(lm_detector* det, int slot, float threshold, int class_idx, i
 int lm_set_profiling(lm_detector* det, int enable);
 int lm_get_profile(lm_detector* det, double stage_us[4], double* scan_algorithmic_bytes, int64_t* launches,
                    int64_t* frames);
+/* Bytes the similarity scan's vector loads request per frame for `class_idx` (-1 = all classes): the on-chip
+ * (L2 -> L1) traffic of the hot kernel, next to the algorithmic bytes lm_get_profile reports. */
+int lm_scan_load_bytes(lm_detector* det, int class_idx, double* bytes_per_frame);
 /* Counters of the last match on `slot`: scan candidates and refined matches before sort + unique. */
 int lm_last_counts(lm_detector* det, int slot, uint32_t* candidates, uint32_t* matches_before_unique);
 /* Selects the similarity-scan kernel variant used by lm_match* (0 = default; see lm_kernels.hip). */

@@ -55,7 +55,7 @@ EXPORTS = [
     "lm_match_slot", "lm_match_batch", "lm_merge_matches", "lm_save_bank", "lm_load_bank",
     "lm_stage_color_quantize", "lm_stage_pyrdown", "lm_stage_depth_quantize", "lm_stage_linear_memories",
     "lm_prepare_slot", "lm_debug_read", "lm_stage_scan", "lm_time_scan", "lm_time_stages", "lm_set_scan_variant",
-    "lm_last_counts", "lm_set_profiling", "lm_get_profile",
+    "lm_last_counts", "lm_set_profiling", "lm_get_profile", "lm_scan_load_bytes",
 ]
 
 _lib = None
@@ -389,6 +389,12 @@ class Detector:
         by, la, fr = C.c_double(), C.c_int64(), C.c_int64()
         self._check(self.lib.lm_get_profile(self.h, st, C.byref(by), C.byref(la), C.byref(fr)))
         return dict(stage_us=list(st), scan_bytes=by.value, launches=la.value, frames=fr.value)
+
+    def scan_load_bytes(self, class_idx=-1):
+        """Bytes the scan's vector loads request per frame (L2 -> L1 traffic of the hot kernel)."""
+        v = C.c_double()
+        self._check(self.lib.lm_scan_load_bytes(self.h, class_idx, C.byref(v)))
+        return v.value
 
     def set_scan_variant(self, variant):
         self._check(self.lib.lm_set_scan_variant(self.h, variant))

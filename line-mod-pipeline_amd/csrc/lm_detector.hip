@@ -1028,6 +1028,20 @@ int lm_get_profile(lm_detector* d, double stage_us[4], double* scan_algorithmic_
     return LM_OK;
 }
 
+int lm_scan_load_bytes(lm_detector* d, int class_idx, double* bytes_per_frame) {
+    int rc;
+    if (!d || !bytes_per_frame) return fail(LM_ERR_INVALID, "null argument");
+    if ((rc = ready_for_compute(d))) return rc;
+    if ((rc = ensure_bank(d))) return rc;
+    const int nc = (int)d->hb.class_load_bytes.size();
+    if (class_idx >= nc || class_idx < -1) return fail(LM_ERR_INVALID, "class index out of range");
+    double b = 0;
+    if (class_idx < 0) for (double v : d->hb.class_load_bytes) b += v;
+    else b = d->hb.class_load_bytes[class_idx];
+    *bytes_per_frame = b;
+    return LM_OK;
+}
+
 int lm_set_scan_variant(lm_detector* d, int variant) { if (!d) return LM_ERR_INVALID; d->scan_variant = variant; return LM_OK; }
 
 }  // extern "C"

@@ -89,6 +89,7 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
     out.class_item_lo.assign(nc, 0); out.class_item_hi.assign(nc, 0);
     out.class_t_lo.assign(nc, 0); out.class_t_hi.assign(nc, 0);
     out.class_alg_bytes.assign(nc, 0.0);
+    out.class_load_bytes.assign(nc, 0.0);
     for (int ci = 0; ci < nc; ++ci) {
         const ClassEntry& c = bank.classes[ci];
         int lo, hi;
@@ -135,10 +136,13 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
                 std::sort(out.scan_off.begin() + (ptrdiff_t)list_begin, out.scan_off.end());
                 for (; k < out.fpad; ++k) out.scan_off.push_back(osc * gl.zero_off);
             }
+            const int chunk = gl.nibble ? LM_SCAN4_CHUNK : LM_SCAN_CHUNK;
             out.scan_P.push_back(P);
             out.scan_n.push_back(n_total | cnt_packed);   // n (bits 0-7) | in-bounds features of modality 0 / 1 (bits 8-15 / 16-23)
             out.class_alg_bytes[ci] += fcount * (double)P;
-            const int chunk = gl.nibble ? LM_SCAN4_CHUNK : LM_SCAN_CHUNK;
+            // what the scan's vector loads request: per feature and work item one half-wave x 16 B (nibble
+            // layout) or one wave x 16 B (byte layout)
+            out.class_load_bytes[ci] += fcount * (double)((P + chunk - 1) / chunk) * (gl.nibble ? 512.0 : 1024.0);
             for (int ch = 0; ch * chunk < P; ++ch) { out.item_t.push_back(ti); out.item_chunk.push_back((u32)ch); }
             // ---- refinement levels
             for (int l = 0; l + 1 < L; ++l) {

@@ -41,6 +41,7 @@ struct DeviceBankHost {
     std::vector<int> class_item_lo, class_item_hi; // [n_classes]
     std::vector<int> class_t_lo, class_t_hi;       // bank-local template range per class
     std::vector<double> class_alg_bytes;           // sum_t sum_m F_m(t) * P(t) per class
+    std::vector<double> class_load_bytes;          // bytes the scan's vector loads request per frame, per class
     std::vector<LmRefMeta> ref_meta[LM_MAX_LEVELS];
     std::vector<LmRefFeat> ref_feat[LM_MAX_LEVELS];
 };

@@ -71,6 +71,7 @@ struct LmRefineArgs {
     float threshold;
     const int* t_global;
     const int* t_class;
+    int blocks_per_slot, nslots;  // filled by lmk_refine
 };
 // a14: similarityLocal + argmax + rescore (+ threshold filter); last=true also emits sort keys.
 void lmk_refine(hipStream_t s, const LmRefineArgs& a, bool last, int nslots);

@@ -55,6 +55,20 @@ __device__ __forceinline__ T* slot_ptr(T* p, size_t slot_stride) {
                                 (size_t)blockIdx.z * slot_stride);
 }
 
+template <typename T>
+__device__ __forceinline__ T* slot_ptr_s(T* p, size_t slot_stride, u32 slot) {
+    return reinterpret_cast<T*>(reinterpret_cast<u8*>(const_cast<typename std::remove_const<T>::type*>(p)) +
+                                (size_t)slot * slot_stride);
+}
+// 1-D grids of G tiles x B slots with XCD affinity: block b is assumed to run on XCD b % 8 (observed round-robin
+// dispatch; only speed depends on it), so with B % 8 == 0 every tile of a slot runs on the same XCD and the
+// slot's working set (linear memories, partially written lines) lives in ONE 4 MB L2 instead of eight.
+__device__ __forceinline__ void xcd_slot_tile(u32 G, u32 B, u32& slot, u32& tile) {
+    const u32 b = blockIdx.x;
+    if ((B & 7u) == 0) { const u32 x = b & 7u, k = b >> 3; slot = x + 8u * (k / G); tile = k - (k / G) * G; }
+    else { slot = b / G; tile = b - slot * G; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // a4  cv::pyrDown, CV_8UC3: 5x5 [1 4 6 4 1]^2, BORDER_REFLECT_101, (sum + 128) >> 8
 // ------------------------------------------------------------------------------------------------
@@ -911,7 +925,8 @@ __global__ __launch_bounds__(256) void k_linear_memories(const u8* __restrict__ 
 template <int T, int SEG, int SRC_SHIFT, int MODE>
 __global__ __launch_bounds__(256) void k_lm_fast(const u8* __restrict__ q0, int qpitch, int w, int h,
                                                   const u64* __restrict__ resp_tab, u8* __restrict__ lm0,
-                                                  u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride) {
+                                                  u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
+                                                  int nseg, int nslots) {
     constexpr int ROWS = 2 * T - 1;
     constexpr int TW = SEG * T;                    // pixels per segment
     constexpr int NDW = (TW + T - 1 + 3) / 4;      // source dwords per row including the right halo
@@ -922,13 +937,15 @@ __global__ __launch_bounds__(256) void k_lm_fast(const u8* __restrict__ q0, int 
     __shared__ u32 qs[ROWS][PD];
     __shared__ u32 ho[ROWS][PD];
     __shared__ u32 sp[T][PD];
-    const u8* q = slot_ptr(q0, q_slot_stride);
-    u8* lm = slot_ptr(lm0, lm_slot_stride);
+    u32 slot, tile;
+    xcd_slot_tile((u32)(nseg * (h / T)), (u32)nslots, slot, tile);
+    const u8* q = slot_ptr_s(q0, q_slot_stride, slot);
+    u8* lm = slot_ptr_s(lm0, lm_slot_stride, slot);
     const int tid = threadIdx.x;
     const int W = w / T;
     const u32 wh = (u32)W * (u32)(h / T);
-    const int band = blockIdx.y;
-    const int col0 = blockIdx.x * SEG;
+    const int band = (int)(tile / (u32)nseg);
+    const int col0 = (int)(tile - (u32)band * (u32)nseg) * SEG;
     const int ncols = (W - col0) < SEG ? (W - col0) : SEG;
     const int px0 = col0 * T, y0 = band * T;
 
@@ -1331,12 +1348,14 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
     const int lane = threadIdx.x & 63;
     if (threadIdx.x < 64) lut_s[threadIdx.x] = a.sim_lut[threadIdx.x];
     __syncthreads();
-    const u32 wave0 = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
-    const u32 nwaves = gridDim.x * 4u;
-    LmDevHeader* hdr = slot_ptr(a.hdr, a.aux_slot_stride);
-    LmCand* cand = slot_ptr(a.cand, a.aux_slot_stride);
-    u64* keys = slot_ptr(a.keys, a.aux_slot_stride);
-    const u8* lm = a.lm + (size_t)blockIdx.z * a.lm_slot_stride;
+    u32 slot, tile;
+    xcd_slot_tile((u32)a.blocks_per_slot, (u32)a.nslots, slot, tile);
+    const u32 wave0 = (u32)__builtin_amdgcn_readfirstlane((int)((tile * 256u + threadIdx.x) >> 6));
+    const u32 nwaves = (u32)a.blocks_per_slot * 4u;
+    LmDevHeader* hdr = slot_ptr_s(a.hdr, a.aux_slot_stride, slot);
+    LmCand* cand = slot_ptr_s(a.cand, a.aux_slot_stride, slot);
+    u64* keys = slot_ptr_s(a.keys, a.aux_slot_stride, slot);
+    const u8* lm = a.lm + (size_t)slot * a.lm_slot_stride;
     u32 n = hdr->cand_count;
     if (n > a.cand_cap) n = a.cand_cap;
     const int T = a.g.T, W = a.g.W;
@@ -1603,10 +1622,11 @@ static void lm_fast_launch(hipStream_t s, const u8* q, int qpitch, int src_shift
                            const u64* resp_tab, u8* lm, u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
                            int nslots) {
     const int W = w / T;
-    dim3 grid((W + SEG - 1) / SEG, h / T, nslots);
+    const int nseg = (W + SEG - 1) / SEG;
+    dim3 grid((unsigned)(nseg * (h / T) * nslots), 1, 1);
 #define LMF(SH, MD)                                                                                           \
     hipLaunchKernelGGL((k_lm_fast<T, SEG, SH, MD>), grid, dim3(256), 0, s, q, qpitch, w, h, resp_tab, lm, ori_stride, \
-                       q_slot_stride, lm_slot_stride)
+                       q_slot_stride, lm_slot_stride, nseg, nslots)
     if (src_shift) { if (mode == 1) LMF(1, 1); else if (mode == 2) LMF(1, 2); else LMF(1, 0); }
     else           { if (mode == 1) LMF(0, 1); else if (mode == 2) LMF(0, 2); else LMF(0, 0); }
 #undef LMF
@@ -1683,8 +1703,12 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
 #undef SCAN_LAUNCH
 }
 
-void lmk_refine(hipStream_t s, const LmRefineArgs& a, bool last, int nslots) {
-    dim3 grid(512, 1, nslots);  // 2048 persistent waves per frame stride over its candidate list
+void lmk_refine(hipStream_t s, const LmRefineArgs& a_in, bool last, int nslots) {
+    LmRefineArgs a = a_in;
+    // persistent waves stride over the slot's candidate list; with the XCD-affine mapping one slot runs on one
+    // XCD (32 CUs x 32 waves), so 256 blocks = 1024 waves per slot fill it
+    a.blocks_per_slot = 256; a.nslots = nslots;
+    dim3 grid((unsigned)(a.blocks_per_slot * nslots), 1, 1);
     if (last) hipLaunchKernelGGL(k_refine<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_refine<false>, grid, dim3(256), 0, s, a);
 }
