@@ -103,11 +103,13 @@ __global__ __launch_bounds__(256) void k_pyrdown(const u8* __restrict__ src0, in
 // at byte 10 of five aligned 16-byte blocks starting at 48 g - 16.  Vertical 1 4 6 4 1 first, on packed
 // bytes (u16 pairs, sums <= 4080), then the horizontal taps on the extracted 16-bit sums.
 __global__ __launch_bounds__(256) void k_pyrdown8(const u8* __restrict__ src0, int sw, int sh, u8* __restrict__ dst0,
-                                                   int dw, int dh, size_t slot_stride) {
-    const u8* src = slot_ptr(src0, slot_stride);
-    u8* dst = slot_ptr(dst0, slot_stride);
+                                                   int dw, int dh, size_t slot_stride, int gblocks, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    const u8* src = slot_ptr_s(src0, slot_stride, slot);
+    u8* dst = slot_ptr_s(dst0, slot_stride, slot);
     const int ng = dw >> 3;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int gid = (int)(tile * 256u) + (int)threadIdx.x;
     const int y = gid / ng, g = gid - y * ng;
     if (y >= dh) return;
     const u32 K[5] = {1, 4, 6, 4, 1};
@@ -344,11 +346,13 @@ __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4
 // The two separable passes are exact integer sums, so their order does not matter.
 #define CB_ROWS 2
 __global__ __launch_bounds__(256) void k_cblur(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
-                                                size_t in_stride, size_t tmp_stride) {
-    const u8* bgr = slot_ptr(bgr0, in_stride);
-    u8* S = slot_ptr(s0, tmp_stride);
+                                                size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    const u8* bgr = slot_ptr_s(bgr0, in_stride, slot);
+    u8* S = slot_ptr_s(s0, tmp_stride, slot);
     const int nblk = (w * 3) >> 4;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int gid = (int)(tile * 256u) + (int)threadIdx.x;
     const int band = gid / nblk, b = gid - band * nblk;
     const int y0 = band * CB_ROWS;
     if (y0 >= h) return;
@@ -422,12 +426,14 @@ __global__ __launch_bounds__(256) void k_cblur(const u8* __restrict__ bgr0, int 
 // formed on u16 pairs; window byte of pixel i (image x = 16g - 1 + i), channel c is 1 + 3i + c.
 __global__ __launch_bounds__(256) void k_corient(const u8* __restrict__ s0, int w, int h, float thr2,
                                                   u8* __restrict__ qn0, float* __restrict__ mag0, size_t tmp_stride,
-                                                  size_t mag_stride) {
-    const u8* S = slot_ptr(s0, tmp_stride);
-    u8* qn = slot_ptr(qn0, tmp_stride);
-    float* mag = mag0 ? slot_ptr(mag0, mag_stride) : nullptr;
+                                                  size_t mag_stride, int gblocks, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    const u8* S = slot_ptr_s(s0, tmp_stride, slot);
+    u8* qn = slot_ptr_s(qn0, tmp_stride, slot);
+    float* mag = mag0 ? slot_ptr_s(mag0, mag_stride, slot) : nullptr;
     const int ng = w >> 4;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int gid = (int)(tile * 256u) + (int)threadIdx.x;
     const int y = gid / ng, g = gid - y * ng;
     if (y >= h) return;
     const size_t pitch = (size_t)w * 3;
@@ -508,11 +514,13 @@ __global__ __launch_bounds__(256) void k_corient(const u8* __restrict__ s0, int 
 // (1 << 4 label); horizontal then vertical 3-sums give the eight 4-bit counts of the 3x3 window, and
 // since at most one label can reach 5 of 9 votes, (cnt + 0x33333333) & 0x88888888 has at most one bit.
 __global__ __launch_bounds__(256) void k_cvote(const u8* __restrict__ qn0, int w, int h, u8* __restrict__ quant0,
-                                                size_t tmp_stride, size_t out_stride) {
-    const u8* qn = slot_ptr(qn0, tmp_stride);
-    u8* quant = slot_ptr(quant0, out_stride);
+                                                size_t tmp_stride, size_t out_stride, int gblocks, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    const u8* qn = slot_ptr_s(qn0, tmp_stride, slot);
+    u8* quant = slot_ptr_s(quant0, out_stride, slot);
     const int ng = w >> 4;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int gid = (int)(tile * 256u) + (int)threadIdx.x;
     const int band = gid / ng, g = gid - band * ng;
     const int y0 = band * CVT_ROWS;
     if (y0 >= h) return;
@@ -682,11 +690,13 @@ __device__ __forceinline__ u32 hw_u16(const u32x4* A, int hw) {
 
 __global__ __launch_bounds__(256) void k_dnormal(const u16* __restrict__ depth0, int w, int h, int dist_thr, int diff_thr,
                                                   const u8* __restrict__ lut, u8* __restrict__ code0, size_t in_stride,
-                                                  size_t tmp_stride) {
-    const u16* depth = slot_ptr(depth0, in_stride);
-    u8* code = slot_ptr(code0, tmp_stride);
+                                                  size_t tmp_stride, int gblocks, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    const u16* depth = slot_ptr_s(depth0, in_stride, slot);
+    u8* code = slot_ptr_s(code0, tmp_stride, slot);
     const int ng = w >> 3;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int gid = (int)(tile * 256u) + (int)threadIdx.x;
     const int y = gid / ng, g = gid - y * ng;
     if (y >= h) return;
     u32 out[2] = {0, 0};
@@ -724,9 +734,11 @@ __global__ __launch_bounds__(256) void k_dnormal(const u16* __restrict__ depth0,
                 const int det = A0 * A3 - A1 * A1;
                 const int ddx = A3 * b0 - A1 * b1;
                 const int ddy = -A1 * b0 + A0 * b1;
-                float nx = (float)(1150LL * ddx);
-                float ny = (float)(1150LL * ddy);
-                float nz = (float)(-(long long)det * d);
+                // same values as upstream's 64-bit integer products rounded once to float: |ddx| < 2^30 so the
+                // double product is exact; |det * d| <= 22500 * 65535 < 2^31
+                float nx = (float)((double)ddx * 1150.0);
+                float ny = (float)((double)ddy * 1150.0);
+                float nz = (float)(-(det * d));
                 const float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
                 if (len > 0) {
                     const float inv = __fdiv_rn(1.0f, len);
@@ -748,11 +760,13 @@ __global__ __launch_bounds__(256) void k_dnormal(const u16* __restrict__ depth0,
 
 #define DM_ROWS 4   // output rows per lane of k_dmedian
 __global__ __launch_bounds__(256) void k_dmedian(const u8* __restrict__ code0, int w, int h, u8* __restrict__ quant0,
-                                                  size_t tmp_stride, size_t out_stride) {
-    const u8* code = slot_ptr(code0, tmp_stride);
-    u8* quant = slot_ptr(quant0, out_stride);
+                                                  size_t tmp_stride, size_t out_stride, int gblocks, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    const u8* code = slot_ptr_s(code0, tmp_stride, slot);
+    u8* quant = slot_ptr_s(quant0, out_stride, slot);
     const int ng = w >> 3;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int gid = (int)(tile * 256u) + (int)threadIdx.x;
     const int band = gid / ng, g = gid - band * ng;
     const int y0 = band * DM_ROWS;
     if (y0 >= h) return;
@@ -1563,7 +1577,7 @@ void lmk_pyrdown(hipStream_t s, const u8* src, int sw, int sh, u8* dst, size_t s
     int dw = sw / 2, dh = sh / 2;
     if ((sw % 16) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0 && (slot_stride % 16) == 0) {
         const int lanes = (dw / 8) * dh;
-        hipLaunchKernelGGL(k_pyrdown8, dim3((lanes + 255) / 256, 1, nslots), dim3(256), 0, s, src, sw, sh, dst, dw, dh, slot_stride);
+        hipLaunchKernelGGL(k_pyrdown8, dim3((unsigned)(((lanes + 255) / 256) * nslots)), dim3(256), 0, s, src, sw, sh, dst, dw, dh, slot_stride, (lanes + 255) / 256, nslots);
         return;
     }
     dim3 grid((dw + 63) / 64, (dh + 3) / 4, nslots);
@@ -1592,9 +1606,9 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
         const int n_b = (w * 3 / 16) * ((h + CB_ROWS - 1) / CB_ROWS);         // 16-byte blocks x row bands
         const int n_o = (w / 16) * h;                                         // 16-pixel groups
         const int n_t = (w / 16) * ((h + CVT_ROWS - 1) / CVT_ROWS);           // 16-pixel groups x bands
-        hipLaunchKernelGGL(k_cblur, dim3((n_b + 255) / 256, 1, nslots), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride);
-        hipLaunchKernelGGL(k_corient, dim3((n_o + 255) / 256, 1, nslots), dim3(256), 0, s, S, w, h, thr2, qn, mag, slot_stride, slot_stride);
-        hipLaunchKernelGGL(k_cvote, dim3((n_t + 255) / 256, 1, nslots), dim3(256), 0, s, qn, w, h, quant, slot_stride, slot_stride);
+        hipLaunchKernelGGL(k_cblur, dim3((unsigned)(((n_b + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_b + 255) / 256, nslots);
+        hipLaunchKernelGGL(k_corient, dim3((unsigned)(((n_o + 255) / 256) * nslots)), dim3(256), 0, s, S, w, h, thr2, qn, mag, slot_stride, slot_stride, (n_o + 255) / 256, nslots);
+        hipLaunchKernelGGL(k_cvote, dim3((unsigned)(((n_t + 255) / 256) * nslots)), dim3(256), 0, s, qn, w, h, quant, slot_stride, slot_stride, (n_t + 255) / 256, nslots);
         return;
     }
     dim3 grid((w + CT_W - 1) / CT_W, (h + CT_H - 1) / CT_H, nslots);
@@ -1606,10 +1620,10 @@ void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_
     if (scratch && lut_onehot && (w % 8) == 0 && ((uintptr_t)depth & 15) == 0 && ((uintptr_t)scratch & 7) == 0 &&
         ((uintptr_t)quant & 7) == 0 && (slot_stride % 16) == 0) {
         const int n_n = (w / 8) * h, n_m = (w / 8) * ((h + DM_ROWS - 1) / DM_ROWS);
-        hipLaunchKernelGGL(k_dnormal, dim3((n_n + 255) / 256, 1, nslots), dim3(256), 0, s, depth, w, h, dist_thr, diff_thr,
-                           lut, scratch, slot_stride, slot_stride);
-        hipLaunchKernelGGL(k_dmedian, dim3((n_m + 255) / 256, 1, nslots), dim3(256), 0, s, scratch, w, h, quant,
-                           slot_stride, slot_stride);
+        hipLaunchKernelGGL(k_dnormal, dim3((unsigned)(((n_n + 255) / 256) * nslots)), dim3(256), 0, s, depth, w, h, dist_thr, diff_thr,
+                           lut, scratch, slot_stride, slot_stride, (n_n + 255) / 256, nslots);
+        hipLaunchKernelGGL(k_dmedian, dim3((unsigned)(((n_m + 255) / 256) * nslots)), dim3(256), 0, s, scratch, w, h, quant,
+                           slot_stride, slot_stride, (n_m + 255) / 256, nslots);
         return;
     }
     dim3 grid((w + DT_W - 1) / DT_W, (h + DT_H - 1) / DT_H, nslots);
