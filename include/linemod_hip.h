@@ -148,6 +148,18 @@ int lm_merge_matches(const lm_match_t* lists, const int32_t* counts, int n_lists
  * own compact binary format, see DESIGN.md. */
 int lm_save_bank(const lm_detector* det, const char* path);
 int lm_load_bank(lm_detector* det, const char* path);
+/* The reference's own file, "linemod_templates.yml.gz": cv::FileStorage YAML of Detector::write(fs) followed
+ * by "classes" [ { Detector::writeClass } ... ] (HighLevelLinemod.cpp:256-270), gzip when the path ends in
+ * .gz.  lm_load_yaml = Detector::read(fs.root()) + readClass per entry (HighLevelLinemod.cpp:292-303): the
+ * file's pyramid_levels, T and modality types must equal the detector's, the modality parameters are taken
+ * from the file, classes already present are left alone. */
+int lm_save_yaml(const lm_detector* det, const char* path);
+int lm_load_yaml(lm_detector* det, const char* path);
+/* Top-level entries of a cv::FileStorage YAML file (plain or .gz): what the reference reads with fs["key"] >> x
+ * from linemod_settings.yml (utility.cpp), models/<name>.yml (HighLevelLinemod.cpp:523-543) and
+ * benchmark/pose0.yml.  Numbers: a scalar, a flow sequence, or the data of an !!opencv-matrix. */
+int lm_yaml_numbers(const char* path, const char* key, double* out, size_t cap, size_t* n_out);
+int lm_yaml_string(const char* path, const char* key, char* out, size_t cap);
 
 /* ---- stage-level hooks (parity tests diff intermediate buffers against the oracle) ------------ */
 /* a3 ColorGradient quantisation of an arbitrary w x h BGR image (dense).  magnitude may be NULL. */

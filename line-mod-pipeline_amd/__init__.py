@@ -56,6 +56,7 @@ EXPORTS = [
     "lm_stage_color_quantize", "lm_stage_pyrdown", "lm_stage_depth_quantize", "lm_stage_linear_memories",
     "lm_prepare_slot", "lm_debug_read", "lm_stage_scan", "lm_time_scan", "lm_time_stages", "lm_set_scan_variant",
     "lm_last_counts", "lm_set_profiling", "lm_get_profile", "lm_scan_load_bytes",
+    "lm_save_yaml", "lm_load_yaml", "lm_yaml_numbers", "lm_yaml_string",
 ]
 
 _lib = None
@@ -138,6 +139,29 @@ def default_config(color_only=False, width=640, height=480, **overrides):
         else:
             setattr(cfg, k, v)
     return cfg
+
+
+def yaml_numbers(path, key):
+    """fs[key] of a cv::FileStorage YAML file as a float64 array (scalar, flow sequence or !!opencv-matrix data)."""
+    lib = load_library()
+    n = C.c_size_t()
+    rc = lib.lm_yaml_numbers(str(path).encode(), key.encode(), None, 0, C.byref(n))
+    if rc:
+        raise LinemodError(rc, lib.lm_last_error().decode())
+    out = np.zeros(n.value, np.float64)
+    rc = lib.lm_yaml_numbers(str(path).encode(), key.encode(), _ptr(out), out.size, C.byref(n))
+    if rc:
+        raise LinemodError(rc, lib.lm_last_error().decode())
+    return out
+
+
+def yaml_string(path, key):
+    lib = load_library()
+    buf = C.create_string_buffer(4096)
+    rc = lib.lm_yaml_string(str(path).encode(), key.encode(), buf, 4096)
+    if rc:
+        raise LinemodError(rc, lib.lm_last_error().decode())
+    return buf.value.decode()
 
 
 def merge_matches(lists):
@@ -275,6 +299,13 @@ class Detector:
 
     def load_bank(self, path):
         self._check(self.lib.lm_load_bank(self.h, str(path).encode()))
+
+    def save_yaml(self, path):
+        """cv::FileStorage layout of the reference's linemod_templates.yml.gz (gzip when path ends in .gz)."""
+        self._check(self.lib.lm_save_yaml(self.h, str(path).encode()))
+
+    def load_yaml(self, path):
+        self._check(self.lib.lm_load_yaml(self.h, str(path).encode()))
 
     # ---- matching ------------------------------------------------------------------------------
     def match(self, bgr, depth, threshold, class_idx=-1, cap=1 << 16):

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "liblinemod_hip.so")
 HIP_SOURCES = ["lm_kernels.hip", "lm_detector.hip"]
-CXX_SOURCES = ["lm_host.cpp", "lm_extract.cpp"]
+CXX_SOURCES = ["lm_host.cpp", "lm_extract.cpp", "lm_yaml.cpp"]
 HEADERS = ["lm_common.h", "lm_kernels.h", "lm_host.h", "lm_extract.h", "lm_median25.h", os.path.join("..", "..", "include", "linemod_hip.h")]
 # -ffp-contract=off: the two float islands (fastAtan2 polynomial, normal normalisation, raw threshold)
 # must round exactly like the oracle, which is built the same way.
@@ -51,7 +51,7 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-lz"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

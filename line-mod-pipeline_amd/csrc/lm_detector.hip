@@ -19,6 +19,7 @@
 #include "lm_common.h"
 #include "lm_extract.h"
 #include "lm_host.h"
+#include "lm_yaml.h"
 #include "lm_kernels.h"
 
 namespace {
@@ -773,6 +774,59 @@ int lm_load_bank(lm_detector* d, const char* path) {
     std::string err;
     if (!lmh::load_bank(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
     d->bank_dirty = true;
+    return LM_OK;
+}
+
+int lm_save_yaml(const lm_detector* d, const char* path) {
+    if (!d || !path) return fail(LM_ERR_INVALID, "null argument");
+    std::string err;
+    if (!lmy::save_templates_yaml(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
+    return LM_OK;
+}
+int lm_load_yaml(lm_detector* d, const char* path) {
+    if (!d || !path) return fail(LM_ERR_INVALID, "null argument");
+    std::string err;
+    if (!lmy::load_templates_yaml(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
+    d->bank_dirty = true;
+    return LM_OK;
+}
+
+// Top-level scalars / number lists of a cv::FileStorage YAML file (linemod_settings.yml, models/<name>.yml,
+// benchmark/pose0.yml): the host glue reads its settings through these.
+static const lmy::Node* yaml_top(const char* path, const char* key, lmy::Node& root) {
+    std::string text, err;
+    if (!lmy::read_text_file(path, text, err)) { fail(LM_ERR_IO, err); return nullptr; }
+    if (!lmy::parse(text, root, err)) { fail(LM_ERR_IO, std::string(path) + ": " + err); return nullptr; }
+    const lmy::Node* n = root.get(key);
+    if (!n) fail(LM_ERR_INVALID, std::string("no key '") + key + "' in " + path);
+    return n;
+}
+int lm_yaml_numbers(const char* path, const char* key, double* out, size_t cap, size_t* n_out) {
+    if (!path || !key) return fail(LM_ERR_INVALID, "null argument");
+    lmy::Node root;
+    const lmy::Node* n = yaml_top(path, key, root);
+    if (!n) return LM_ERR_IO;
+    if (n->kind == lmy::Node::Map && n->get("data")) n = n->get("data");   // !!opencv-matrix
+    std::vector<double> v;
+    double d;
+    if (n->kind == lmy::Node::Nums) v = n->nums;
+    else if (n->number(&d)) v.push_back(d);
+    else return fail(LM_ERR_INVALID, std::string("'") + key + "' is not numeric");
+    if (n_out) *n_out = v.size();
+    if (out) {
+        if (cap < v.size()) return fail(LM_ERR_INVALID, "buffer too small");
+        for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    }
+    return LM_OK;
+}
+int lm_yaml_string(const char* path, const char* key, char* out, size_t cap) {
+    if (!path || !key || !out || !cap) return fail(LM_ERR_INVALID, "null argument");
+    lmy::Node root;
+    const lmy::Node* n = yaml_top(path, key, root);
+    if (!n) return LM_ERR_IO;
+    if (n->kind != lmy::Node::Scalar) return fail(LM_ERR_INVALID, std::string("'") + key + "' is not a scalar");
+    if (n->scalar.size() + 1 > cap) return fail(LM_ERR_INVALID, "buffer too small");
+    std::memcpy(out, n->scalar.c_str(), n->scalar.size() + 1);
     return LM_OK;
 }
 

@@ -88,7 +88,8 @@ bool HighLevelLineMOD::detectTemplate(std::vector<Image>& in_imgs, uint16_t in_c
 }
 
 void HighLevelLineMOD::writeLinemod() {
-    if (lm_save_bank(detector, "linemod_templates.lmbk") != LM_OK) { error = lm_last_error(); std::printf("ERROR::%s\n", error.c_str()); }
+    // cv::FileStorage fs("linemod_templates.yml.gz", WRITE); detector->write(fs); classes [ { writeClass } ]  (:256-270)
+    if (lm_save_yaml(detector, "linemod_templates.yml.gz") != LM_OK) { error = lm_last_error(); std::printf("ERROR::%s\n", error.c_str()); }
     // linemod_tempPosFile.bin: u32 nClasses; per class {u64 n; n raw Template records}  (:272-284)
     std::ofstream f("linemod_tempPosFile.bin", std::ios::binary | std::ios::out);
     uint32_t nvec = (uint32_t)modelTemplates->size();
@@ -103,7 +104,8 @@ void HighLevelLineMOD::writeLinemod() {
 void HighLevelLineMOD::readLinemod() {
     templates->clear();
     modelTemplates->clear();
-    if (lm_load_bank(detector, "linemod_templates.lmbk") != LM_OK) { error = lm_last_error(); std::printf("ERROR::%s\n", error.c_str()); }
+    // detector->read(fs.root()); readClass per entry of "classes"  (:292-303)
+    if (lm_load_yaml(detector, "linemod_templates.yml.gz") != LM_OK) { error = lm_last_error(); std::printf("ERROR::%s\n", error.c_str()); }
     std::ifstream f("linemod_tempPosFile.bin", std::ios::in | std::ios::binary);
     uint32_t nvec = 0;
     if (f && f.read(reinterpret_cast<char*>(&nvec), sizeof(nvec))) {
@@ -124,19 +126,47 @@ void HighLevelLineMOD::readColorRanges() {
     for (const std::string& id : getClassIds()) {
         ModelProperties p;
         std::string stem = id.size() > 4 ? id.substr(0, id.size() - 4) : id;
-        std::ifstream f(settings.modelFolder + stem + ".yml");
-        std::string line;
-        while (f && std::getline(f, line)) {
-            double* dst = nullptr;
-            if (line.rfind("lower color range:", 0) == 0) dst = p.lowerColorRange;
-            else if (line.rfind("upper color range:", 0) == 0) dst = p.upperColorRange;
-            if (!dst) continue;
-            size_t b = line.find('[');
-            if (b == std::string::npos) continue;
-            std::sscanf(line.c_str() + b + 1, " %lf , %lf , %lf", &dst[0], &dst[1], &dst[2]);
-        }
+        const std::string file = settings.modelFolder + stem + ".yml";
+        double v[4];
+        size_t n = 0;
+        if (lm_yaml_numbers(file.c_str(), "lower color range", v, 4, &n) == LM_OK && n >= 3)
+            for (int k = 0; k < 3; ++k) p.lowerColorRange[k] = v[k];
+        if (lm_yaml_numbers(file.c_str(), "upper color range", v, 4, &n) == LM_OK && n >= 3)
+            for (int k = 0; k < 3; ++k) p.upperColorRange[k] = v[k];
         modProps->push_back(p);
     }
+}
+
+// utility.cpp readSettings: linemod_settings.yml -> CameraParameters + TemplateGenerationSettings
+bool readSettings(const std::string& file, CameraParameters& cam, TemplateGenerationSettings& ts) {
+    auto num = [&](const char* key, double* out) {
+        size_t n = 0;
+        return lm_yaml_numbers(file.c_str(), key, out, 1, &n) == LM_OK && n == 1;
+    };
+    double v;
+    if (!num("video width", &v)) return false;
+    cam.videoWidth = (uint16_t)v;
+    if (!num("video height", &v)) return false;
+    cam.videoHeight = (uint16_t)v;
+    if (num("camera fx", &v)) cam.fx = (float)v;
+    if (num("camera fy", &v)) cam.fy = (float)v;
+    if (num("camera cx", &v)) cam.cx = (float)v;
+    if (num("camera cy", &v)) cam.cy = (float)v;
+    char buf[512];
+    if (lm_yaml_string(file.c_str(), "model folder", buf, sizeof buf) == LM_OK) ts.modelFolder = buf;
+    if (num("only use color modality", &v)) ts.onlyUseColorModality = v != 0;
+    if (num("in plane rotation starting angle", &v)) ts.angleStart = (int16_t)v;
+    if (num("in plane rotation stopping angle", &v)) ts.angleStop = (int16_t)v;
+    if (num("in plane rotation angle step", &v)) ts.angleStep = (int16_t)v;
+    if (num("distance step", &v)) ts.stepSize = (uint16_t)v;
+    if (num("detector threshold", &v)) ts.detectorThreshold = (float)v;
+    if (num("percent to pass check", &v)) ts.percentToPassCheck = (uint16_t)v;
+    if (num("number of poses to compare", &v)) ts.numberWantedPoses = (uint16_t)v;
+    if (num("distance to match to be considered same object", &v)) ts.radiusThresholdNewObject = (float)v;
+    if (num("ratio to determine if group is too small", &v)) ts.discardGroupRatio = (float)v;
+    if (num("use depth improvement", &v)) ts.useDepthImprovement = v != 0;
+    if (num("depth offset", &v)) ts.depthOffset = (float)v;
+    return true;
 }
 
 void HighLevelLineMOD::setColorRange(uint16_t classNumber, const double lo[3], const double hi[3]) {

@@ -10,7 +10,8 @@
 // Scope: the hot path behind detectTemplate (Detector::match, GPU), the detector
 // queries, the host glue of 8f-1 (match post-processing into ObjectPose, PostProcess.{h,cpp}) and of
 // 8f-3 (addTemplate with its in-plane rotation sweep; the resampler lives in TemplateGenerator.cpp).
-// Still "next": OpenCV's YAML template file (8f-2).
+// and of 8f-2: writeLinemod / readLinemod use the reference's own file, linemod_templates.yml.gz, in
+// cv::FileStorage's YAML layout (csrc/lm_yaml.cpp).
 #pragma once
 #include <cstdint>
 #include <string>
@@ -88,8 +89,8 @@ public:
     const std::vector<lm_match_t>& getMatches() const { return matches; }
     std::vector<std::vector<ObjectPose>> getObjectPoses() { return posesMultipleObj; }   // :322-325
 
-    // :256-320.  Template bank in this library's own format ("linemod_templates.lmbk"; OpenCV's YAML is
-    // 8f-2, next) plus the reference's own raw pose file "linemod_tempPosFile.bin" (:272-284, :302-318).
+    // :256-320.  "linemod_templates.yml.gz" (cv::FileStorage YAML of Detector::write + writeClass) plus the
+    // reference's own raw pose file "linemod_tempPosFile.bin" (:272-284, :302-318).
     void writeLinemod();
     void readLinemod();
 
@@ -120,5 +121,8 @@ private:
     std::string error;
     void readColorRanges();
 };
+
+// utility.cpp: linemod_settings.yml -> the two settings structs (keys as in the reference's file).
+bool readSettings(const std::string& file, CameraParameters& cam, TemplateGenerationSettings& ts);
 
 }  // namespace lmamd

@@ -1,7 +1,9 @@
 // Test driver for the C++ facade (line-mod-pipeline_amd/host/HighLevelLinemod.h): the way the reference's
 // PoseDetection uses HighLevelLineMOD (/root/reference/src/PoseDetection.cpp:17,66): readLinemod(), then
 // detectTemplate(imgs, classIndex).  Usage: facade_driver <color_only 0|1> <bgr.raw> <depth.raw> <threshold>
-// Run from a directory that holds linemod_templates.lmbk.  Prints the class table and the match list.
+// Run from a directory that holds linemod_templates.yml.gz; a linemod_settings.yml there is read the way the
+// reference's utility.cpp does (camera + settings, the command line then overrides modality and threshold).
+// Prints the class table and the match list.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -19,6 +21,10 @@ int main(int argc, char** argv) {
     lmamd::CameraParameters cam;
     cam.fx = 1044.87f; cam.fy = 1045.69141f; cam.cx = 320; cam.cy = 240; cam.videoWidth = 640; cam.videoHeight = 480;
     lmamd::TemplateGenerationSettings ts;
+    if (lmamd::readSettings("linemod_settings.yml", cam, ts))
+        std::printf("settings %u %u %.5f %d %d %d %u %.1f %s\n", (unsigned)cam.videoWidth, (unsigned)cam.videoHeight, (double)cam.fy,
+                    (int)ts.angleStart, (int)ts.angleStop, (int)ts.angleStep, (unsigned)ts.stepSize, (double)ts.depthOffset,
+                    ts.modelFolder.c_str());
     ts.onlyUseColorModality = std::atoi(argv[1]) != 0;
     ts.detectorThreshold = (float)std::atof(argv[4]);
     lmamd::HighLevelLineMOD line(cam, ts);
