@@ -1313,8 +1313,8 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
 // a14  One wave per candidate: lane l holds the 4 patch positions (row l/4, cols 4(l%4)..+3) of the
 // 16x16 patch.  Refinement levels keep SPREAD linear memories (1 byte per position instead of 8
 // response bytes: the whole level stays L2-resident and a patch load touches 1/8 of the lines); the
-// response max(LUT_lo[v & 15], LUT_hi[v >> 4]) is evaluated in registers with v_perm_b32, four
-// positions per instruction -- the same 16-entry nibble lookups upstream does with pshufb.
+// response max(LUT_lo[v & 15], LUT_hi[v >> 4]) comes from an 8 x 256-byte table in LDS (one ds_read_u8
+// per position; upstream does the two 16-entry nibble lookups with pshufb).
 // The modality's feature records are loaded one per lane, bounds-checked in parallel (features
 // shifted out of the frame read the arena's zero block: spread 0 -> response 0), then broadcast
 // with v_readlane so the patch loads (one unaligned dword per lane per feature) issue back to back.
@@ -1326,21 +1326,6 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
         v = v > o ? v : o;
     }
     return v;
-}
-
-// table[idx] for four 4-bit indices at once; t0..t3 hold the 16 table bytes
-__device__ __forceinline__ u32 lookup16x4(u32 idx4, u32 t0, u32 t1, u32 t2, u32 t3) {
-    u32 sel = idx4 & 0x07070707u;
-    u32 a = __builtin_amdgcn_perm(t1, t0, sel);      // entries 0..7
-    u32 b = __builtin_amdgcn_perm(t3, t2, sel);      // entries 8..15
-    u32 m = ((idx4 >> 3) & 0x01010101u) * 0xFFu;     // 0xFF where idx >= 8
-    return (b & m) | (a & ~m);
-}
-// per-byte max of two dwords whose bytes are < 128
-__device__ __forceinline__ u32 bytemax4(u32 a, u32 b) {
-    u32 d = (a | 0x80808080u) - b;
-    u32 m = ((d >> 7) & 0x01010101u) * 0xFFu;        // 0xFF where a >= b
-    return (a & m) | (b & ~m);
 }
 
 __device__ __forceinline__ void emit_key(const LmRefineArgs& a, LmDevHeader* hdr, u64* keys, u32 ti, int x, int y,
@@ -1358,9 +1343,20 @@ __device__ __forceinline__ void emit_key(const LmRefineArgs& a, LmDevHeader* hdr
 
 template <bool LAST>
 __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
-    __shared__ __attribute__((aligned(16))) u32 lut_s[64];   // SIMILARITY_LUT: [ori][lo 16 B | hi 16 B]
+    // response of orientation o to spread byte v = max(LUT_lo[o][v & 15], LUT_hi[o][v >> 4]): 8 x 256 bytes in LDS,
+    // built once per workgroup; a feature then costs one ds_read_u8 per position instead of two 16-entry
+    // v_perm lookups and a byte max (the kernel was VALU-bound on those)
+    __shared__ u8 resp[8][256];
     const int lane = threadIdx.x & 63;
-    if (threadIdx.x < 64) lut_s[threadIdx.x] = a.sim_lut[threadIdx.x];
+    {
+        const u8* sl = reinterpret_cast<const u8*>(a.sim_lut);   // [ori][lo 16 B | hi 16 B]
+        const int v = threadIdx.x;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const u8 lo = sl[32 * o + (v & 15)], hi = sl[32 * o + 16 + (v >> 4)];
+            resp[o][v] = lo > hi ? lo : hi;
+        }
+    }
     __syncthreads();
     u32 slot, tile;
     xcd_slot_tile((u32)a.blocks_per_slot, (u32)a.nslots, slot, tile);
@@ -1376,7 +1372,6 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
     const int border = 8 * T;
     const int offset = T / 2 + (T % 2 - 1);
     const u32 lane_off = (u32)((lane >> 2) * W + (lane & 3) * 4);
-    const u32x4* lut4 = reinterpret_cast<const u32x4*>(lut_s);
     for (u32 i = wave0; i < n; i += nwaves) {
         LmCand c = cand[i];
         u32 ti = (u32)__builtin_amdgcn_readfirstlane((int)c.ti);
@@ -1390,7 +1385,7 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
         int bx = x / T - 8, by = y / T - 8;
         int off_x = bx * T, off_y = by * T;
         const u32 shift = (u32)(by * W + bx);   // two's complement: feature offset + shift >= 0 for kept features
-        u32 tl = 0, th = 0;
+        u32 s01 = 0, s23 = 0;   // u16 pairs: patch positions {0, 1} and {2, 3} of this lane (sums <= 126 * 4)
         for (int m = 0; m < a.M; ++m) {
             const int cnt = (int)mt.count[m];
             LmRefFeat ft;
@@ -1400,7 +1395,6 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
             bool ok = (lane < cnt) && fx >= 0 && fy >= 0 && fx < a.g.w && fy < a.g.h;
             const u32 eff = ok ? (ft.off & 0x1FFFFFFFu) + shift : a.g.zero_off;
             const u32 lab = ft.off >> 29;
-            u32 acc = 0;
             for (int f = 0; f < cnt; f += 8) {
                 u32 v[8];
 #pragma unroll
@@ -1412,22 +1406,21 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    u32 lb = (u32)__builtin_amdgcn_readlane((int)lab, f + k);
-                    u32x4 tlo = lut4[2 * lb], thi = lut4[2 * lb + 1];
-                    u32 rl = lookup16x4(v[k] & 0x0F0F0F0Fu, tlo[0], tlo[1], tlo[2], tlo[3]);
-                    u32 rh = lookup16x4((v[k] >> 4) & 0x0F0F0F0Fu, thi[0], thi[1], thi[2], thi[3]);
-                    acc += bytemax4(rl, rh);
+                    const u32 lb = (u32)__builtin_amdgcn_readlane((int)lab, f + k);
+                    const u8* tab = resp[lb];
+                    const u32 r0 = tab[v[k] & 0xFFu], r1 = tab[(v[k] >> 8) & 0xFFu];
+                    const u32 r2 = tab[(v[k] >> 16) & 0xFFu], r3 = tab[v[k] >> 24];
+                    s01 += r0 | (r1 << 16);
+                    s23 += r2 | (r3 << 16);
                 }
             }
-            tl += acc & 0x00FF00FFu;
-            th += (acc >> 8) & 0x00FF00FFu;
         }
         // first maximum in row-major order: key = score << 8 | (255 - index)
         u32 idx0 = (u32)lane * 4u;
-        u32 k0 = ((tl & 0xFFFF) << 8) | (255u - idx0);
-        u32 k1 = ((th & 0xFFFF) << 8) | (254u - idx0);
-        u32 k2 = ((tl >> 16) << 8) | (253u - idx0);
-        u32 k3 = ((th >> 16) << 8) | (252u - idx0);
+        u32 k0 = ((s01 & 0xFFFF) << 8) | (255u - idx0);
+        u32 k1 = ((s01 >> 16) << 8) | (254u - idx0);
+        u32 k2 = ((s23 & 0xFFFF) << 8) | (253u - idx0);
+        u32 k3 = ((s23 >> 16) << 8) | (252u - idx0);
         u32 k01 = k0 > k1 ? k0 : k1, k23 = k2 > k3 ? k2 : k3;
         u32 key = wave_max_u32(k01 > k23 ? k01 : k23);
         int best = (int)(key >> 8);
