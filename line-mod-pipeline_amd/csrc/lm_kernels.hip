@@ -1657,8 +1657,8 @@ void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, 
         switch (T) {
             case 2: lm_fast_launch<2, 128>(LMF_ARGS); return;
             case 4: lm_fast_launch<4, 64>(LMF_ARGS); return;
-            case 5: lm_fast_launch<5, 48>(LMF_ARGS); return;
-            case 8: lm_fast_launch<8, 16>(LMF_ARGS); return;
+            case 5: lm_fast_launch<5, 128>(LMF_ARGS); return;
+            case 8: lm_fast_launch<8, 40>(LMF_ARGS); return;
             default: break;
         }
 #undef LMF_ARGS
