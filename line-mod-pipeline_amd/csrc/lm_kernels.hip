@@ -1505,8 +1505,13 @@ __global__ __launch_bounds__(1024) void k_sort_unique(LmSortArgs a) {
             lo[i] = i < n ? keys[2 * (size_t)i + 1] : ~0ull;
         }
         __syncthreads();
+        // A wave's 64 pair-threads touch only "their" 128 consecutive elements while j <= 64, and a wave's LDS
+        // operations execute in order: those stages need no workgroup barrier, only the stages with j > 64 do
+        // (10 of the 66 stages of a 2048-element sort).
+        bool local_pending = false;   // stages since the last barrier were wave-local
         for (u32 k = 2; k <= N; k <<= 1)
             for (u32 j = k >> 1; j > 0; j >>= 1) {
+                if (j > 64 && local_pending) { __syncthreads(); local_pending = false; }
                 for (u32 t = tid; t < (N >> 1); t += 1024) {
                     u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
                     u32 p = i | j;
@@ -1515,8 +1520,10 @@ __global__ __launch_bounds__(1024) void k_sort_unique(LmSortArgs a) {
                     bool gt = ah > bh || (ah == bh && al > bl);
                     if (gt == up) { hi[i] = bh; lo[i] = bl; hi[p] = ah; lo[p] = al; }
                 }
-                __syncthreads();
+                if (j > 64) __syncthreads();
+                else { __builtin_amdgcn_wave_barrier(); local_pending = true; }
             }
+        __syncthreads();
     }
     // adjacent-unique + compaction (block-wide exclusive scan of keep flags, chunks of 1024)
     u32 base = 0;
