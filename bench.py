@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--threshold", type=float, default=80.0)
     ap.add_argument("--byte-responses", action="store_true", help="LM_FLAG_BYTE_RESPONSES: byte scan kernel (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--functional-gloo", action="store_true",
+                    help="functional check of the N > 1 path on a 1-GPU box: every rank uses cuda:0 and the exchange "
+                         "goes through gloo on the host (never a measurement)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     args = ap.parse_args()
 
@@ -61,12 +64,17 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.functional_gloo:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.functional_gloo:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
 
     lm = importlib.import_module("line-mod-pipeline_amd")
@@ -89,20 +97,39 @@ def main():
         det.upload_frame(i, bgr, depth)
 
     cap = 4096
-    out = np.zeros((B, cap), lm.MATCH_DTYPE)
-    counts = np.zeros(B, np.int32)
-    gather = distmod.ShardGather(lm.merge_matches, cap=cap, device=device) if world > 1 else None
+    bufs = [(np.zeros((B, cap), lm.MATCH_DTYPE), np.zeros(B, np.int32)) for _ in range(2)]
+    out, counts = bufs[0]
+    gather = None
+    if world > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        gather = distmod.ShardGather(lm.merge_matches, cap=cap, pack_fn=lm.pack_matches, merge_batch_fn=lm.merge_batch,
+                                     device=torch.device("cpu") if args.functional_gloo else device)
+        pool = ThreadPoolExecutor(1)
+    state = {"k": 0, "pending": None}
 
     def step():
-        det.match_batch(B, args.threshold, 0, cap_per_frame=cap, out=out, counts=counts)
-        if gather is not None:
-            return gather.gather_merge(out, counts)
-        return None
+        # one pass of the hot path over the batch; with N > 1 the exchange + merge of a step (two small
+        # collectives + lm_merge_batch on the host) runs on a worker thread while the GPU does the next step
+        o, c = bufs[state["k"] & 1]
+        state["k"] += 1
+        det.match_batch(B, args.threshold, 0, cap_per_frame=cap, out=o, counts=c)
+        if gather is None:
+            return None
+        prev = state["pending"]
+        res = prev.result() if prev is not None else None      # double buffer: at most one exchange in flight
+        state["pending"] = pool.submit(gather.gather_merge, o, c)
+        return res
+
+    def drain():
+        prev, state["pending"] = state["pending"], None
+        return prev.result() if prev is not None else None
 
     def fence():
+        merged_last = drain()                                   # the last step's exchange belongs to the timed region
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        return merged_last
 
     for _ in range(args.warmup):
         step()
@@ -110,19 +137,19 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        merged = step()
-    fence()
+        step()
+    merged = fence()
     dt = time.perf_counter() - t0
     prof = det.get_profile()
     det.set_profiling(False)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if args.functional_gloo else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     frames_done = B * args.steps
     fps = frames_done / dt
-    n_matches0 = int(counts[0]) if merged is None else len(merged[0])
+    n_matches0 = int(bufs[(state["k"] - 1) & 1][1][0]) if merged is None else len(merged[0])
 
     # ---- roofline of the dominant kernel (similarity scan): algorithmic bytes / HIP-event time
     scan_us = prof["stage_us"][1] / max(prof["launches"], 1)

@@ -144,6 +144,15 @@ int lm_match_batch(lm_detector* det, int n_slots, float threshold, int class_idx
 int lm_merge_matches(const lm_match_t* lists, const int32_t* counts, int n_lists, size_t stride, lm_match_t* out,
                      size_t cap, size_t* n_out);
 
+/* The same for a whole batch (8e, one call per step instead of one per frame).  lm_pack_matches turns the
+ * fixed-stride output of lm_match_batch into one contiguous run (what a rank sends); lm_merge_batch takes the
+ * R gathered runs (rank r at packed + r * rank_stride, counts[r * n_frames + i] records for frame i) and writes
+ * the merged + unique lists of all frames back to back with out_counts[i].  Host-side, multi-threaded. */
+int lm_pack_matches(const lm_match_t* recs, size_t stride, const int32_t* counts, int n_frames, lm_match_t* out,
+                    size_t cap, size_t* n_out);
+int lm_merge_batch(const lm_match_t* packed, size_t rank_stride, const int32_t* counts, int n_ranks, int n_frames,
+                   lm_match_t* out, size_t cap, int32_t* out_counts, size_t* n_out);
+
 /* Template-bank persistence (Detector::write/writeClass/read/readClass, HighLevelLinemod.cpp:260,267,294,299):
  * own compact binary format, see DESIGN.md. */
 int lm_save_bank(const lm_detector* det, const char* path);

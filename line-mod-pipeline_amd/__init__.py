@@ -56,7 +56,7 @@ EXPORTS = [
     "lm_stage_color_quantize", "lm_stage_pyrdown", "lm_stage_depth_quantize", "lm_stage_linear_memories",
     "lm_prepare_slot", "lm_debug_read", "lm_stage_scan", "lm_time_scan", "lm_time_stages", "lm_set_scan_variant",
     "lm_last_counts", "lm_set_profiling", "lm_get_profile", "lm_scan_load_bytes",
-    "lm_save_yaml", "lm_load_yaml", "lm_yaml_numbers", "lm_yaml_string",
+    "lm_save_yaml", "lm_load_yaml", "lm_yaml_numbers", "lm_yaml_string", "lm_pack_matches", "lm_merge_batch",
 ]
 
 _lib = None
@@ -162,6 +162,37 @@ def yaml_string(path, key):
     if rc:
         raise LinemodError(rc, lib.lm_last_error().decode())
     return buf.value.decode()
+
+
+def pack_matches(records, counts):
+    """[B, cap] per-frame lists + counts -> one contiguous MATCH_DTYPE array (lm_pack_matches)."""
+    lib = load_library()
+    records = np.ascontiguousarray(records)
+    counts = _c(counts, np.int32)
+    out = np.zeros(int(counts.sum()), MATCH_DTYPE)
+    n = C.c_size_t()
+    rc = lib.lm_pack_matches(_ptr(records), C.c_size_t(records.shape[1]), _ptr(counts), len(counts), _ptr(out),
+                             C.c_size_t(out.size), C.byref(n))
+    if rc:
+        raise LinemodError(rc, lib.lm_last_error().decode())
+    return out
+
+
+def merge_batch(packed, counts):
+    """packed: [R, stride] MATCH_DTYPE (rank r's frames back to back), counts: [R, B] -> (merged packed, counts[B])
+    (lm_merge_batch: per frame R-way merge + adjacent-unique)."""
+    lib = load_library()
+    packed = np.ascontiguousarray(packed)
+    counts = _c(counts, np.int32)
+    R, B = counts.shape
+    out = np.zeros(int(counts.sum()), MATCH_DTYPE)
+    oc = np.zeros(B, np.int32)
+    n = C.c_size_t()
+    rc = lib.lm_merge_batch(_ptr(packed), C.c_size_t(packed.shape[1]), _ptr(counts), R, B, _ptr(out),
+                            C.c_size_t(out.size), _ptr(oc), C.byref(n))
+    if rc:
+        raise LinemodError(rc, lib.lm_last_error().decode())
+    return out[:n.value], oc
 
 
 def merge_matches(lists):

@@ -18,6 +18,8 @@
 #include "../../include/linemod_hip.h"
 #include "lm_common.h"
 #include "lm_extract.h"
+#include <thread>
+
 #include "lm_host.h"
 #include "lm_yaml.h"
 #include "lm_kernels.h"
@@ -760,6 +762,86 @@ int lm_merge_matches(const lm_match_t* lists, const int32_t* counts, int n_lists
     if (n_out) *n_out = all.size();
     if (out) std::memcpy(out, all.data(), std::min(all.size(), cap) * sizeof(lm_match_t));
     if (all.size() > cap && out) return fail(LM_ERR_OVERFLOW, "output buffer too small");
+    return LM_OK;
+}
+
+// Per-frame lists at a fixed stride -> one contiguous run (what travels in the shard all-gather).
+int lm_pack_matches(const lm_match_t* recs, size_t stride, const int32_t* counts, int n_frames, lm_match_t* out,
+                    size_t cap, size_t* n_out) {
+    if (!recs || !counts || n_frames < 0) return fail(LM_ERR_INVALID, "null argument");
+    size_t total = 0;
+    for (int i = 0; i < n_frames; ++i) {
+        if (counts[i] < 0 || (size_t)counts[i] > stride) return fail(LM_ERR_INVALID, "count exceeds stride");
+        total += (size_t)counts[i];
+    }
+    if (n_out) *n_out = total;
+    if (!out) return LM_OK;
+    if (total > cap) return fail(LM_ERR_OVERFLOW, "output buffer too small");
+    size_t pos = 0;
+    for (int i = 0; i < n_frames; ++i) {
+        std::memcpy(out + pos, recs + (size_t)i * stride, (size_t)counts[i] * sizeof(lm_match_t));
+        pos += (size_t)counts[i];
+    }
+    return LM_OK;
+}
+
+// The merge step of a whole batch after the all-gather: rank r's packed run starts at packed + r * rank_stride
+// and holds its frames back to back (counts[r * n_frames + i] records for frame i).  Frame i of the output is the
+// R-way merge + adjacent-unique of the R sorted lists (pairwise std::merge), frames are spread over a few host
+// threads; output packed the same way with out_counts[i].
+int lm_merge_batch(const lm_match_t* packed, size_t rank_stride, const int32_t* counts, int n_ranks, int n_frames,
+                   lm_match_t* out, size_t cap, int32_t* out_counts, size_t* n_out) {
+    if (!packed || !counts || !out_counts || n_ranks <= 0 || n_frames < 0) return fail(LM_ERR_INVALID, "bad argument");
+    const size_t R = (size_t)n_ranks, F = (size_t)n_frames;
+    std::vector<size_t> start(R * F);      // start of (rank, frame) inside the rank's run
+    std::vector<size_t> bound(F + 1, 0);   // upper bound of the merged output before unique
+    for (size_t r = 0; r < R; ++r) {
+        size_t pos = 0;
+        for (size_t i = 0; i < F; ++i) {
+            const int32_t c = counts[r * F + i];
+            if (c < 0) return fail(LM_ERR_INVALID, "negative count");
+            start[r * F + i] = pos;
+            pos += (size_t)c;
+            bound[i + 1] += (size_t)c;
+        }
+        if (pos > rank_stride) return fail(LM_ERR_INVALID, "counts exceed rank_stride");
+    }
+    for (size_t i = 0; i < F; ++i) bound[i + 1] += bound[i];
+    std::vector<lm_match_t> tmp(bound[F]);
+    auto work = [&](size_t lo, size_t hi) {
+        std::vector<lm_match_t> a, b;
+        for (size_t i = lo; i < hi; ++i) {
+            a.clear();
+            for (size_t r = 0; r < R; ++r) {
+                const lm_match_t* src = packed + r * rank_stride + start[r * F + i];
+                const size_t c = (size_t)counts[r * F + i];
+                b.resize(a.size() + c);
+                std::merge(a.begin(), a.end(), src, src + c, b.begin(), lmh::match_less);
+                a.swap(b);
+            }
+            a.erase(std::unique(a.begin(), a.end(), lmh::match_eq), a.end());
+            std::copy(a.begin(), a.end(), tmp.begin() + (ptrdiff_t)bound[i]);
+            out_counts[i] = (int32_t)a.size();
+        }
+    };
+    const size_t nthreads = std::min<size_t>(F >= 16 ? 4 : 1, std::max(1u, std::thread::hardware_concurrency()));
+    if (nthreads <= 1) work(0, F);
+    else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nthreads; ++t) th.emplace_back(work, F * t / nthreads, F * (t + 1) / nthreads);
+        for (auto& x : th) x.join();
+    }
+    size_t total = 0;
+    for (size_t i = 0; i < F; ++i) total += (size_t)out_counts[i];
+    if (n_out) *n_out = total;
+    if (out) {
+        if (total > cap) return fail(LM_ERR_OVERFLOW, "output buffer too small");
+        size_t pos = 0;
+        for (size_t i = 0; i < F; ++i) {
+            std::memcpy(out + pos, tmp.data() + bound[i], (size_t)out_counts[i] * sizeof(lm_match_t));
+            pos += (size_t)out_counts[i];
+        }
+    }
     return LM_OK;
 }
 

@@ -3,11 +3,11 @@
 One process per GPU.  Every rank holds the same frames and the templates [n*r/R, n*(r+1)/R) of every
 class (contiguous template_id ranges, global ids preserved -- lm_config.shard_rank/shard_size).  The
 only exchange step of the path is the gather of the per-shard sorted match lists: one all-gather of
-the counts and one all-gather of fixed-capacity record buffers per BATCH of frames
-(torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests),
-followed by the R-way merge + adjacent-unique on every rank (lm_merge_matches, host side of the C
-ABI).  The payload is tiny (20 B per match), so the collective is latency-bound; batching the
-frames of a step into one collective is what keeps it off the critical path.
+the counts and one all-gather of the packed records per BATCH of frames (torch.distributed: backend
+"nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests), followed by the R-way merge +
+adjacent-unique on every rank (lm_merge_batch, host side of the C ABI).  The payload is tiny (20 B per
+match, a few hundred KB per 128-frame step), so the collectives are latency-bound; batching the
+frames of a step is what keeps them off the critical path.
 
 The local matcher is injected (`local_match(threshold, class_idx) -> (records[B, cap], counts[B])`):
 the product passes Detector.match_batch; the gloo tests pass the CPU oracle.
@@ -24,69 +24,93 @@ def shard_range(n, rank, size):
 
 
 class ShardGather:
-    """All-gather + merge of per-shard match lists for a batch of frames."""
+    """All-gather + merge of per-shard match lists for a batch of frames.
 
-    def __init__(self, merge_fn, group=None, cap=4096, device=None):
+    What travels is small and variable (about 20 B x matches), so the exchange is two collectives per
+    BATCH: the per-frame counts of every rank ([R, B] int32), then the packed records padded to the
+    largest rank total of this batch (rounded up so the buffers are reused).  The merge of all frames is
+    one call (`merge_batch_fn`, lm_merge_batch: threaded R-way merge + unique); with only the per-frame
+    `merge_fn` it falls back to a Python loop."""
+
+    GRANULE = 4096      # records; gather buffers grow in these steps
+
+    def __init__(self, merge_fn, group=None, cap=4096, device=None, pack_fn=None, merge_batch_fn=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
-        self.merge_fn = merge_fn
+        self.merge_fn, self.pack_fn, self.merge_batch_fn = merge_fn, pack_fn, merge_batch_fn
         self.group = group
         self.cap = cap
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = device if device is not None else torch.device("cpu")
-        self._bufs = {}
+        self._cnt = {}
+        self._rec = {}
 
-    def _buffers(self, B):
-        if B not in self._bufs:
+    def _count_buffers(self, B):
+        if B not in self._cnt:
             t = self.torch
-            # int32 view of the 20-byte records: [B, cap, 5]; counts ride in the same message
-            send = t.zeros((B, self.cap * 5 + 1), dtype=t.int32, device=self.device)
-            recv = t.zeros((self.world, B, self.cap * 5 + 1), dtype=t.int32, device=self.device)
-            host = t.zeros((B, self.cap * 5 + 1), dtype=t.int32).pin_memory() if self.device.type == "cuda" else None
-            self._bufs[B] = (send, recv, host)
-        return self._bufs[B]
+            self._cnt[B] = (t.zeros(B, dtype=t.int32, device=self.device),
+                            t.zeros((self.world, B), dtype=t.int32, device=self.device))
+        return self._cnt[B]
+
+    def _record_buffers(self, n):
+        n = max((n + self.GRANULE - 1) // self.GRANULE, 1) * self.GRANULE
+        if n not in self._rec:
+            t = self.torch
+            self._rec[n] = (t.zeros(n * 5, dtype=t.int32, device=self.device),
+                            t.zeros((self.world, n * 5), dtype=t.int32, device=self.device))
+        return (n,) + self._rec[n]
+
+    def _pack(self, records, counts):
+        if self.pack_fn is not None:
+            return self.pack_fn(records, counts)
+        parts = [records[i, :int(counts[i])] for i in range(len(counts))]
+        return np.concatenate(parts) if parts else np.zeros(0, MATCH_DTYPE)
 
     def gather_merge(self, records, counts):
         """records: structured [B, >=max(counts)] MATCH_DTYPE; counts: [B].  Returns a list of B merged
         match arrays, identical on every rank."""
         B = len(counts)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
         if int(counts.max(initial=0)) > self.cap:
             raise OverflowError("shard produced %d matches for one frame, gather capacity %d "
                                 "(SURVEY.md 8e: K must cover all matches)" % (int(counts.max()), self.cap))
         if self.world == 1:
             return [records[i, :counts[i]].copy() for i in range(B)]
         t = self.torch
-        send, recv, host = self._buffers(B)
-        stage = np.zeros((B, self.cap * 5 + 1), np.int32)
-        for i in range(B):
-            n = int(counts[i])
-            stage[i, :n * 5] = records[i, :n].view(np.int32).reshape(-1)
-            stage[i, -1] = n
-        if host is not None:
-            host.copy_(t.from_numpy(stage))
-            send.copy_(host, non_blocking=True)
-        else:
-            send.copy_(t.from_numpy(stage))
-        self.dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
-        allr = recv.cpu().numpy()
+        # 1. counts of every rank
+        csend, crecv = self._count_buffers(B)
+        csend.copy_(t.from_numpy(counts))
+        self.dist.all_gather_into_tensor(crecv.view(-1), csend, group=self.group)
+        allc = crecv.cpu().numpy()                                  # [R, B]
+        totals = allc.sum(axis=1)
+        # 2. packed records, padded to the largest rank total
+        packed = self._pack(records, counts)
+        stride, rsend, rrecv = self._record_buffers(int(totals.max()))
+        if len(packed):
+            rsend[:len(packed) * 5].copy_(t.from_numpy(packed.view(np.int32).reshape(-1)))
+        self.dist.all_gather_into_tensor(rrecv.view(-1), rsend, group=self.group)
+        allr = rrecv.cpu().numpy().view(MATCH_DTYPE).reshape(self.world, stride)
+        # 3. merge every frame
+        if self.merge_batch_fn is not None:
+            merged, mc = self.merge_batch_fn(allr, allc)
+            ends = np.cumsum(mc)
+            return [merged[e - c:e] for e, c in zip(ends, mc)]
+        starts = np.cumsum(allc, axis=1) - allc
         out = []
         for i in range(B):
-            lists = []
-            for r in range(self.world):
-                n = int(allr[r, i, -1])
-                lists.append(allr[r, i, :n * 5].copy().view(MATCH_DTYPE))
-            out.append(self.merge_fn(lists))
+            out.append(self.merge_fn([allr[r, starts[r, i]:starts[r, i] + allc[r, i]] for r in range(self.world)]))
         return out
 
 
 class ShardedDetector:
     """Drop-in for Detector.match_batch when the bank is sharded over the ranks of a process group."""
 
-    def __init__(self, local_match, merge_fn, group=None, cap=4096, device=None):
+    def __init__(self, local_match, merge_fn, group=None, cap=4096, device=None, pack_fn=None, merge_batch_fn=None):
         self.local_match = local_match
-        self.gather = ShardGather(merge_fn, group=group, cap=cap, device=device)
+        self.gather = ShardGather(merge_fn, group=group, cap=cap, device=device, pack_fn=pack_fn,
+                                  merge_batch_fn=merge_batch_fn)
 
     def match_batch(self, n_frames, threshold, class_idx=-1):
         records, counts = self.local_match(n_frames, threshold, class_idx)

@@ -40,12 +40,17 @@ def main():
             cnt[i] = len(m)
         return rec, cnt
 
-    sd = distmod.ShardedDetector(local_match, lm.merge_matches, cap=cap)
+    # the product's configuration: packing and the merge of the whole batch in C (lm_pack_matches / lm_merge_batch)
+    sd = distmod.ShardedDetector(local_match, lm.merge_matches, cap=cap, pack_fn=lm.pack_matches,
+                                 merge_batch_fn=lm.merge_batch)
     merged = sd.match_batch(B, thr, 0)
+    # and the pure-Python fallback of the same exchange
+    sd2 = distmod.ShardedDetector(local_match, lm.merge_matches, cap=cap)
+    merged2 = sd2.match_batch(B, thr, 0)
     ok = True
     for i in range(B):
         full = o.match(frames[i][0], frames[i][1], thr, 0)
-        ok &= len(full) > 0 and merged[i].tobytes() == full.tobytes()
+        ok &= len(full) > 0 and merged[i].tobytes() == full.tobytes() and merged2[i].tobytes() == full.tobytes()
     # capacity overflow must be loud (K must cover all matches)
     small = distmod.ShardGather(lm.merge_matches, cap=1)
     try:

@@ -49,3 +49,40 @@ def test_single_rank_gather_is_identity(lm):
     rec["x"][0, :3] = [1, 2, 3]
     out = g.gather_merge(rec, np.array([3, 0], np.int32))
     assert len(out) == 2 and len(out[0]) == 3 and len(out[1]) == 0
+
+
+def test_pack_and_merge_batch_equal_per_frame_merge(lm):
+    """lm_pack_matches / lm_merge_batch (one call per step) against lm_merge_matches per frame."""
+    rng = np.random.default_rng(5)
+    R, B, cap = 3, 20, 64
+
+    def shard_lists():
+        rec = np.zeros((B, cap), lm.MATCH_DTYPE)
+        cnt = rng.integers(0, 40, B).astype(np.int32)
+        cnt[3] = 0
+        for i in range(B):
+            m = np.zeros(cnt[i], lm.MATCH_DTYPE)
+            m["x"] = rng.integers(0, 6, cnt[i]); m["y"] = rng.integers(0, 6, cnt[i])
+            m["similarity"] = rng.integers(80, 84, cnt[i]).astype(np.float32)
+            m["template_id"] = rng.integers(0, 5, cnt[i]); m["class_idx"] = 0
+            u = lm.merge_matches([m])                           # sorted + unique, as a detector returns it
+            cnt[i] = len(u)
+            rec[i, :cnt[i]] = u
+        return rec, cnt
+
+    shards = [shard_lists() for _ in range(R)]
+    packs = [lm.pack_matches(r, c) for r, c in shards]
+    for (r, c), p in zip(shards, packs):
+        assert len(p) == c.sum() and p[:c[0]].tobytes() == r[0, :c[0]].tobytes()
+    stride = max(len(p) for p in packs) + 7
+    allr = np.zeros((R, stride), lm.MATCH_DTYPE)
+    for k, p in enumerate(packs):
+        allr[k, :len(p)] = p
+    allc = np.stack([c for _, c in shards])
+    merged, mc = lm.merge_batch(allr, allc)
+    pos = 0
+    for i in range(B):
+        exp = lm.merge_matches([shards[k][0][i, :shards[k][1][i]] for k in range(R)])
+        assert mc[i] == len(exp) and merged[pos:pos + mc[i]].tobytes() == exp.tobytes()
+        pos += mc[i]
+    assert pos == len(merged)
