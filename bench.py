@@ -46,6 +46,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128, help="frames per step (resident in HBM)")
+    ap.add_argument("--lanes", type=int, default=0, choices=(0, 1, 2),
+                    help="2: the step's frames are split over the detector's two lanes (two HIP streams driven by one "
+                         "host thread through lm_match_begin / lm_match_end) so that the stages of one half overlap "
+                         "those of the other (the scan is L1/L2-bound, the preprocess passes VALU / fabric-bound); "
+                         "0 = 2 on one GPU, 1 with N > 1 (see the note on torch in main())")
     ap.add_argument("--templates", type=int, default=3000, help="templates per GPU")
     ap.add_argument("--threshold", type=float, default=80.0)
     ap.add_argument("--byte-responses", action="store_true", help="LM_FLAG_BYTE_RESPONSES: byte scan kernel (A/B)")
@@ -62,11 +67,17 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
-    import torch
-    import torch.distributed as dist
-    if args.functional_gloo:
-        local_rank = 0
+    # One GPU needs no torch at all (lm_match_end synchronises its stream; inputs and results are numpy), and it is
+    # kept out on purpose: with torch loaded into the process the detector's two HIP streams no longer overlap
+    # (measured on the MI355X box, 100 steps of 128 frames: 93.8 K detections/s without `import torch`, 76 K with
+    # it, whatever the initialisation order, thread counts or synchronisation calls; one lane is unaffected:
+    # 85 K both ways).  N > 1 needs torch.distributed, so there the default is one lane.
+    torch = dist = device = None
     if world > 1:
+        import torch
+        import torch.distributed as dist
+        if args.functional_gloo:
+            local_rank = 0
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -75,7 +86,8 @@ def main():
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
+        device = torch.device("cuda", local_rank)
+        torch.cuda.synchronize()
 
     lm = importlib.import_module("line-mod-pipeline_amd")
     synth = importlib.import_module("line-mod-pipeline_amd.synth")
@@ -97,49 +109,82 @@ def main():
         det.upload_frame(i, bgr, depth)
 
     cap = 4096
-    bufs = [(np.zeros((B, cap), lm.MATCH_DTYPE), np.zeros(B, np.int32)) for _ in range(2)]
-    out, counts = bufs[0]
+    NL = args.lanes if args.lanes else (2 if world == 1 else 1)
+    if B % 2 or B < 2:
+        NL = 1
+    Bl = B // NL                                         # frames per lane and launch
+    NBUF = 3                                             # result buffers in rotation
+    bufs = [(np.zeros((B, cap), lm.MATCH_DTYPE), np.zeros(B, np.int32)) for _ in range(NBUF)]
+    views = [[(o[l * Bl:(l + 1) * Bl], cn[l * Bl:(l + 1) * Bl]) for l in range(NL)] for o, cn in bufs]
     gather = None
     if world > 1:
-        from concurrent.futures import ThreadPoolExecutor
+        import queue
+        import threading
         gather = distmod.ShardGather(lm.merge_matches, cap=cap, pack_fn=lm.pack_matches, merge_batch_fn=lm.merge_batch,
                                      device=torch.device("cpu") if args.functional_gloo else device)
-        pool = ThreadPoolExecutor(1)
-    state = {"k": 0, "pending": None}
+    state = {"k": 0, "merged": None, "error": None}
 
-    def step():
-        # one pass of the hot path over the batch; with N > 1 the exchange + merge of a step (two small
-        # collectives + lm_merge_batch on the host) runs on a worker thread while the GPU does the next step
-        o, c = bufs[state["k"] & 1]
-        state["k"] += 1
-        det.match_batch(B, args.threshold, 0, cap_per_frame=cap, out=o, counts=c)
-        if gather is None:
-            return None
-        prev = state["pending"]
-        res = prev.result() if prev is not None else None      # double buffer: at most one exchange in flight
-        state["pending"] = pool.submit(gather.gather_merge, o, c)
-        return res
+    def run_steps(n):
+        """n passes of the hot path over the batch, driven by this one host thread: lane l works on the frames of
+        slots [l * Bl, (l + 1) * Bl); as soon as a lane's step is collected its next step is enqueued, so the two
+        streams always have work and their stages overlap.  With N > 1 an exchange thread gathers + merges step k
+        (two small collectives + lm_merge_batch) while the GPU already works on step k + 1."""
+        if n <= 0:
+            return
+        k0 = state["k"]
+        state["k"] += n
+        if gather is not None:
+            todo = queue.Queue()
+            free = threading.Semaphore(NBUF - 1)           # buffers the lanes may fill ahead of the exchange
 
-    def drain():
-        prev, state["pending"] = state["pending"], None
-        return prev.result() if prev is not None else None
+            def exchange():
+                while True:
+                    k = todo.get()
+                    if k is None:
+                        return
+                    try:
+                        if state["error"] is None:
+                            state["merged"] = gather.gather_merge(*bufs[k % NBUF])
+                    except Exception as e:                 # noqa: BLE001 - re-raised by the main thread
+                        state["error"] = e
+                    free.release()
+
+            th = threading.Thread(target=exchange)
+            th.start()
+        for l in range(NL):
+            det.match_begin(l, l * Bl, Bl, args.threshold, 0)
+        for k in range(k0, k0 + n):
+            if gather is not None:
+                free.acquire()
+            for l in range(NL):
+                o, cn = views[k % NBUF][l]
+                det.match_end(l, cap, out=o, counts=cn)
+                if k + 1 < k0 + n:
+                    det.match_begin(l, l * Bl, Bl, args.threshold, 0)
+            if gather is not None:
+                todo.put(k)
+        if gather is not None:
+            todo.put(None)
+            th.join()
+            if state["error"] is not None:
+                raise state["error"]
 
     def fence():
-        merged_last = drain()                                   # the last step's exchange belongs to the timed region
+        # N > 1: barrier + torch.cuda.synchronize().  N = 1: the same device-wide synchronisation without torch.
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
-        return merged_last
+            torch.cuda.synchronize()
+        else:
+            det.synchronize()                           # hipDeviceSynchronize: the torch-free torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     det.set_profiling(True)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    merged = fence()
+    run_steps(args.steps)
+    fence()
     dt = time.perf_counter() - t0
+    merged = state["merged"]
     prof = det.get_profile()
     det.set_profiling(False)
     if world > 1:
@@ -149,19 +194,19 @@ def main():
 
     frames_done = B * args.steps
     fps = frames_done / dt
-    n_matches0 = int(bufs[(state["k"] - 1) & 1][1][0]) if merged is None else len(merged[0])
+    n_matches0 = int(bufs[(state["k"] - 1) % NBUF][1][0]) if merged is None else len(merged[0])
 
     # ---- roofline of the dominant kernel (similarity scan): algorithmic bytes / HIP-event time
     scan_us = prof["stage_us"][1] / max(prof["launches"], 1)
     bytes_per_launch = prof["scan_bytes"] / max(prof["launches"], 1)
     achieved = bytes_per_launch / (scan_us * 1e-6) / 1e9 if scan_us > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(B)
-    l2_bytes = det.scan_load_bytes(0) * B          # bytes the scan's vector loads request per launch
+    traffic, traffic_src = pmc_traffic(Bl)
+    l2_bytes = det.scan_load_bytes(0) * Bl         # bytes the scan's vector loads request per launch
     l2_rate = l2_bytes / (scan_us * 1e-6) / 1e9 if scan_us > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "k_scan4" if not args.byte_responses else "k_scan", "avg_launch_us": round(scan_us, 2),
-                "algorithmic_bytes_per_launch": bytes_per_launch, "frames_per_launch": B,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "frames_per_launch": Bl,
                 "on_chip": {"bound": "l2", "load_bytes_per_launch": l2_bytes, "achieved": round(l2_rate, 1),
                             "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(l2_rate / L2_PEAK_GBS, 4)},
                 "note": "the scanned level's linear memories (0.6 MB/frame, nibble-packed) are L2-resident: the "
@@ -182,6 +227,7 @@ def main():
             "config": {"workload": "SURVEY 8d config 2: 640x480 RGB-D, ColorGradient+DepthNormal, T={5,8}, "
                                    "2-level pyramid, fixed-geometry 96x96 templates, threshold %g" % args.threshold,
                        "templates_per_gpu": args.templates, "templates_total": n_total, "frames_per_step": B,
+                       "lanes": NL,
                        "frames_per_sec": round(fps, 1), "matches_frame0": n_matches0,
                        "unit_definition": "one detection = one frame matched against one %d-template bank shard; "
                                           "N GPUs search N shards of the same frames" % args.templates,

@@ -140,6 +140,19 @@ int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm
 int lm_match_batch(lm_detector* det, int n_slots, float threshold, int class_idx, lm_match_t* out, size_t cap_per_frame,
                    int32_t* counts);
 
+/* Asynchronous halves of lm_match_batch on one of two LANES (lane 0 = the detector's stream, lane 1 = a second
+ * HIP stream with its own events and threshold table).  lm_match_begin enqueues a3-a15 for the resident frames
+ * of slots [first_slot, first_slot + n_slots) and returns; lm_match_end waits for that lane and delivers the
+ * lists exactly like lm_match_batch (out + i * cap_per_frame, counts[i]; i counts from first_slot).  Two lanes
+ * working on disjoint slot ranges overlap each other's stages on the GPU (the scan is L1/L2-bound, the
+ * preprocess passes VALU / fabric-bound) from ONE host thread:
+ *     begin(0, A); begin(1, B);  loop { end(0); begin(0, A');  end(1); begin(1, B'); }
+ * A lane's slots must not be uploaded to while it is busy; the synchronous entry points refuse to run then. */
+int lm_match_begin(lm_detector* det, int lane, int first_slot, int n_slots, float threshold, int class_idx);
+/* hipDeviceSynchronize() on the detector's device (what torch.cuda.synchronize() is for a torch program). */
+int lm_synchronize(lm_detector* det);
+int lm_match_end(lm_detector* det, int lane, lm_match_t* out, size_t cap_per_frame, int32_t* counts);
+
 /* R-way merge of per-shard sorted lists + adjacent-unique: the step after the all-gather (8e).  Host-side. */
 int lm_merge_matches(const lm_match_t* lists, const int32_t* counts, int n_lists, size_t stride, lm_match_t* out,
                      size_t cap, size_t* n_out);

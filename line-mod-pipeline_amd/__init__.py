@@ -57,6 +57,7 @@ EXPORTS = [
     "lm_prepare_slot", "lm_debug_read", "lm_stage_scan", "lm_time_scan", "lm_time_stages", "lm_set_scan_variant",
     "lm_last_counts", "lm_set_profiling", "lm_get_profile", "lm_scan_load_bytes",
     "lm_save_yaml", "lm_load_yaml", "lm_yaml_numbers", "lm_yaml_string", "lm_pack_matches", "lm_merge_batch",
+    "lm_match_begin", "lm_match_end", "lm_synchronize",
 ]
 
 _lib = None
@@ -98,6 +99,10 @@ def load_library(path=None):
     lib.lm_upload_frame.argtypes = [vp, i, vp, sz, vp, sz]
     lib.lm_match_slot.argtypes = [vp, i, f, i, vp, sz, C.POINTER(sz)]
     lib.lm_match_batch.argtypes = [vp, i, f, i, vp, sz, vp]
+    lib.lm_match_begin.argtypes = [vp, i, i, i, f, i]
+    lib.lm_match_end.argtypes = [vp, i, vp, sz, vp]
+    lib.lm_pack_matches.argtypes = [vp, sz, vp, i, vp, sz, C.POINTER(sz)]
+    lib.lm_merge_batch.argtypes = [vp, sz, vp, i, i, vp, sz, vp, C.POINTER(sz)]
     lib.lm_merge_matches.argtypes = [vp, vp, i, sz, vp, sz, C.POINTER(sz)]
     lib.lm_save_bank.argtypes = [vp, C.c_char_p]
     lib.lm_load_bank.argtypes = [vp, C.c_char_p]
@@ -171,8 +176,7 @@ def pack_matches(records, counts):
     counts = _c(counts, np.int32)
     out = np.zeros(int(counts.sum()), MATCH_DTYPE)
     n = C.c_size_t()
-    rc = lib.lm_pack_matches(_ptr(records), C.c_size_t(records.shape[1]), _ptr(counts), len(counts), _ptr(out),
-                             C.c_size_t(out.size), C.byref(n))
+    rc = lib.lm_pack_matches(_ptr(records), records.shape[1], _ptr(counts), len(counts), _ptr(out), out.size, C.byref(n))
     if rc:
         raise LinemodError(rc, lib.lm_last_error().decode())
     return out
@@ -188,8 +192,7 @@ def merge_batch(packed, counts):
     out = np.zeros(int(counts.sum()), MATCH_DTYPE)
     oc = np.zeros(B, np.int32)
     n = C.c_size_t()
-    rc = lib.lm_merge_batch(_ptr(packed), C.c_size_t(packed.shape[1]), _ptr(counts), R, B, _ptr(out),
-                            C.c_size_t(out.size), _ptr(oc), C.byref(n))
+    rc = lib.lm_merge_batch(_ptr(packed), packed.shape[1], _ptr(counts), R, B, _ptr(out), out.size, _ptr(oc), C.byref(n))
     if rc:
         raise LinemodError(rc, lib.lm_last_error().decode())
     return out[:n.value], oc
@@ -374,6 +377,23 @@ class Detector:
         if counts is None:
             counts = np.zeros(n_slots, np.int32)
         self._check(self.lib.lm_match_batch(self.h, n_slots, threshold, class_idx, _ptr(out), cap_per_frame, _ptr(counts)))
+        return out, counts
+
+    def synchronize(self):
+        """hipDeviceSynchronize on the detector's device."""
+        self._check(self.lib.lm_synchronize(self.h))
+
+    def match_begin(self, lane, first_slot, n_slots, threshold, class_idx=-1):
+        """Enqueue the match of the resident frames in slots [first_slot, first_slot + n_slots) on `lane` (0 or 1)."""
+        self._check(self.lib.lm_match_begin(self.h, lane, first_slot, n_slots, threshold, class_idx))
+
+    def match_end(self, lane, cap_per_frame=4096, out=None, counts=None, n_slots=None):
+        """Wait for `lane` and fetch its lists (same layout as match_batch)."""
+        if out is None:
+            out = np.zeros((n_slots, cap_per_frame), MATCH_DTYPE)
+        if counts is None:
+            counts = np.zeros(len(out), np.int32)
+        self._check(self.lib.lm_match_end(self.h, lane, _ptr(out), cap_per_frame, _ptr(counts)))
         return out, counts
 
     # ---- stage hooks ---------------------------------------------------------------------------

@@ -57,6 +57,19 @@ struct lm_detector {
 
     // ---- device state
     bool dev_ready = false;
+    // The fields stream / ev / d_raw_thr / h_raw_thr / raw_thr_for below always belong to the ACTIVE lane
+    // (activate_lane swaps them); lane 0 is active outside lm_match_begin / lm_match_end.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        int* d_raw_thr = nullptr;
+        int* h_raw_thr = nullptr;
+        float raw_thr_for = -1.0f;
+        bool created = false, busy = false, timed = false;
+        int first = 0, n = 0, class_idx = 0;
+    };
+    Lane lanes[2];
+    int active = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<Slot> slots;
@@ -438,6 +451,8 @@ int upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride
     if (bgr_stride == 0) bgr_stride = (size_t)c.width * 3;
     if (depth_stride == 0) depth_stride = (size_t)c.width * 2;
     if (bgr_stride < (size_t)c.width * 3 || depth_stride < (size_t)c.width * 2) return fail(LM_ERR_INVALID, "stride smaller than a row");
+    for (const lm_detector::Lane& ln : d->lanes)
+        if (ln.busy && slot >= ln.first && slot < ln.first + ln.n) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
     HIP_TRY(hipStreamSynchronize(d->stream));  // staging buffers are reused
     for (int y = 0; y < c.height; ++y) std::memcpy(s.h_bgr + (size_t)y * c.width * 3, bgr + y * bgr_stride, (size_t)c.width * 3);
     HIP_TRY(hipMemcpyAsync(d->bgr(slot, 0), s.h_bgr, (size_t)c.width * c.height * 3, hipMemcpyHostToDevice, d->stream));
@@ -468,27 +483,51 @@ int ensure_scratch(lm_detector* d, size_t bytes) {
     return LM_OK;
 }
 
+// ---- lanes: two HIP streams with their own events and threshold table ---------------------------
+void activate_lane(lm_detector* d, int l) {
+    if (d->active == l) return;
+    lm_detector::Lane& cur = d->lanes[d->active];
+    cur.stream = d->stream; cur.d_raw_thr = d->d_raw_thr; cur.h_raw_thr = d->h_raw_thr; cur.raw_thr_for = d->raw_thr_for;
+    for (int k = 0; k < 5; ++k) cur.ev[k] = d->ev[k];
+    const lm_detector::Lane& nx = d->lanes[l];
+    d->stream = nx.stream; d->d_raw_thr = nx.d_raw_thr; d->h_raw_thr = nx.h_raw_thr; d->raw_thr_for = nx.raw_thr_for;
+    for (int k = 0; k < 5; ++k) d->ev[k] = nx.ev[k];
+    d->active = l;
+}
+
+int ensure_lane(lm_detector* d, int l) {
+    lm_detector::Lane& ln = d->lanes[l];
+    if (ln.created || l == 0) { ln.created = true; return LM_OK; }   // lane 0 = the detector's own stream (ensure_device)
+    HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+    for (auto& e : ln.ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ln.d_raw_thr), 128 * sizeof(int)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ln.h_raw_thr), 128 * sizeof(int), hipHostMallocDefault));
+    ln.raw_thr_for = -1.0f;
+    ln.created = true;
+    return LM_OK;
+}
+
+void account_profile(lm_detector* d, int n, int class_idx) {
+    for (int k = 0; k < 4; ++k) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, d->ev[k], d->ev[k + 1]) == hipSuccess) d->prof_us[k] += (double)ms * 1000.0;
+    }
+    double b = 0;
+    if (class_idx < 0) for (double v : d->hb.class_alg_bytes) b += v;
+    else if (class_idx < (int)d->hb.class_alg_bytes.size()) b = d->hb.class_alg_bytes[class_idx];
+    d->prof_scan_bytes += b * n;
+    d->prof_launches += 1;
+    d->prof_frames += n;
+}
+
 int run_match(lm_detector* d, int first, int n, float threshold, int class_idx) {
+    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     for (int i = 0; i < n; ++i)
         if (!d->slots[first + i].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot " + std::to_string(first + i));
     int rc;
     if ((rc = enqueue_match(d, first, n, threshold, class_idx, d->profiling))) return rc;
     HIP_TRY(hipStreamSynchronize(d->stream));
-    if (d->profiling) {  // HIP events on the launch stream bracket every stage (ev[0..4])
-        for (int k = 0; k < 4; ++k) {
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, d->ev[k], d->ev[k + 1]));
-            d->prof_us[k] += (double)ms * 1000.0;
-        }
-        ItemRange r;
-        if ((rc = item_range(d, class_idx, &r))) return rc;
-        double b = 0;
-        if (class_idx < 0) for (double v : d->hb.class_alg_bytes) b += v;
-        else b = d->hb.class_alg_bytes[class_idx];
-        d->prof_scan_bytes += b * n;
-        d->prof_launches += 1;
-        d->prof_frames += n;
-    }
+    if (d->profiling) account_profile(d, n, class_idx);   // HIP events on the launch stream bracket every stage
     return LM_OK;
 }
 
@@ -575,8 +614,16 @@ void lm_destroy(lm_detector* d) {
         for (Slot& s : d->slots) { hipHostFree(s.h_bgr); hipHostFree(s.h_depth); }
         hipFree(d->frame_arena); hipFree(d->aux_arena); hipHostFree(d->host_blocks);
         hipFree(d->d_raw_thr); hipHostFree(d->h_raw_thr);
+        activate_lane(d, 0);
         for (auto& ev : d->ev) if (ev) hipEventDestroy(ev);
         if (d->stream) hipStreamDestroy(d->stream);
+        lm_detector::Lane& l1 = d->lanes[1];
+        if (l1.created) {
+            hipStreamSynchronize(l1.stream);
+            for (auto& ev : l1.ev) if (ev) hipEventDestroy(ev);
+            hipStreamDestroy(l1.stream);
+            hipFree(l1.d_raw_thr); hipHostFree(l1.h_raw_thr);
+        }
         free_device_bank(d);
         hipFree(d->d_resp_tab); hipFree(d->d_sim_lut); hipFree(d->d_normal_lut); hipFree(d->d_scratch);
     }
@@ -743,6 +790,59 @@ int lm_match_batch(lm_detector* d, int n_slots, float threshold, int class_idx, 
     for (int i = 0; i < n_slots; ++i) {
         size_t n = 0;
         rc = collect_slot(d, i, out ? out + (size_t)i * cap_per_frame : nullptr, cap_per_frame, &n);
+        if (counts) counts[i] = (int32_t)n;
+        if (rc && !first_err) { first_err = rc; first_msg = g_err; }
+    }
+    if (first_err) return fail(first_err, first_msg);
+    return LM_OK;
+}
+
+int lm_synchronize(lm_detector* d) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return LM_OK;
+}
+
+int lm_match_begin(lm_detector* d, int lane, int first_slot, int n_slots, float threshold, int class_idx) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if (lane < 0 || lane > 1) return fail(LM_ERR_INVALID, "lane must be 0 or 1");
+    if ((rc = ensure_bank(d))) return rc;
+    if ((rc = check_slots(d, first_slot, n_slots))) return rc;
+    if (n_slots <= 0) return fail(LM_ERR_INVALID, "no slots");
+    lm_detector::Lane& ln = d->lanes[lane];
+    if (ln.busy) return fail(LM_ERR_INVALID, "lane is busy: call lm_match_end first");
+    const lm_detector::Lane& other = d->lanes[lane ^ 1];
+    if (other.busy && first_slot < other.first + other.n && other.first < first_slot + n_slots)
+        return fail(LM_ERR_INVALID, "slot range overlaps the range the other lane is working on");
+    for (int i = 0; i < n_slots; ++i)
+        if (!d->slots[first_slot + i].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot " + std::to_string(first_slot + i));
+    if ((rc = ensure_lane(d, lane))) return rc;
+    activate_lane(d, lane);
+    rc = enqueue_match(d, first_slot, n_slots, threshold, class_idx, d->profiling);
+    if (!rc) { ln.busy = true; ln.first = first_slot; ln.n = n_slots; ln.class_idx = class_idx; ln.timed = d->profiling; }
+    activate_lane(d, 0);
+    return rc;
+}
+
+int lm_match_end(lm_detector* d, int lane, lm_match_t* out, size_t cap_per_frame, int32_t* counts) {
+    if (!d) return fail(LM_ERR_INVALID, "null detector");
+    if (lane < 0 || lane > 1) return fail(LM_ERR_INVALID, "lane must be 0 or 1");
+    lm_detector::Lane& ln = d->lanes[lane];
+    if (!ln.busy) return fail(LM_ERR_INVALID, "lane has no match in flight");
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    activate_lane(d, lane);
+    hipError_t e = hipStreamSynchronize(d->stream);
+    if (e == hipSuccess && ln.timed) account_profile(d, ln.n, ln.class_idx);
+    activate_lane(d, 0);
+    ln.busy = false;
+    if (e != hipSuccess) return fail(LM_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    int first_err = LM_OK;
+    std::string first_msg;
+    for (int i = 0; i < ln.n; ++i) {
+        size_t n = 0;
+        int rc = collect_slot(d, ln.first + i, out ? out + (size_t)i * cap_per_frame : nullptr, cap_per_frame, &n);
         if (counts) counts[i] = (int32_t)n;
         if (rc && !first_err) { first_err = rc; first_msg = g_err; }
     }

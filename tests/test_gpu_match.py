@@ -241,3 +241,46 @@ def test_other_pyramids(lm, orc, synth):
         assert len(exp) > 0
         assert_matches_equal(d.match(bgr, depth, 60.0), exp)
         d.close()
+
+
+def test_two_lanes_equal_batch(lm, orc, synth):
+    """lm_match_begin / lm_match_end: two lanes (two HIP streams) on disjoint slot ranges deliver exactly what
+    lm_match_batch delivers, in any interleaving; misuse is refused."""
+    d, o = _pair(lm, orc, False, frame_slots=8)
+    frames = [synth.make_frame(640, 480, seed=300 + i) for i in range(8)]
+    q = _quantized(o, frames[0][0], frames[0][1], False)
+    descs, feats, _ = synth.make_bank(120, 2, 2, seed=3, quantized=q, crop_fraction=0.3, T0=d.get_T(0))
+    d.add_class("c", descs, feats)
+    for i, (b, dp) in enumerate(frames):
+        d.upload_frame(i, b, dp)
+    ref, rc = d.match_batch(8, 70.0)
+    ref = [ref[i, :rc[i]].copy() for i in range(8)]
+    assert sum(len(r) for r in ref) > 0
+    for rounds in range(2):
+        d.match_begin(0, 0, 3, 70.0)
+        d.match_begin(1, 3, 5, 70.0)
+        with pytest.raises(lm.LinemodError):
+            d.match_begin(1, 0, 2, 70.0)                      # lane busy
+        with pytest.raises(lm.LinemodError):
+            d.match_batch(8, 70.0)                            # synchronous call while lanes are busy
+        with pytest.raises(lm.LinemodError):
+            d.upload_frame(4, *frames[4])                     # slot in flight
+        o1, c1 = d.match_end(1, n_slots=5)
+        d.match_begin(1, 6, 2, 70.0)                          # lane 1 again while lane 0 is still busy
+        with pytest.raises(lm.LinemodError):
+            d.match_begin(0, 2, 2, 70.0)                      # lane 0 busy
+        o0, c0 = d.match_end(0, n_slots=3)
+        o2, c2 = d.match_end(1, n_slots=2)
+        for i in range(3):
+            assert o0[i, :c0[i]].tobytes() == ref[i].tobytes()
+        for i in range(5):
+            assert o1[i, :c1[i]].tobytes() == ref[3 + i].tobytes()
+        for i in range(2):
+            assert o2[i, :c2[i]].tobytes() == ref[6 + i].tobytes()
+    with pytest.raises(lm.LinemodError):
+        d.match_end(0, n_slots=1)                             # nothing in flight
+    d.match_begin(0, 0, 4, 70.0)
+    with pytest.raises(lm.LinemodError):
+        d.match_begin(1, 3, 2, 70.0)                          # overlapping slot ranges
+    d.match_end(0, n_slots=4)
+    d.close()

@@ -1,0 +1,33 @@
+"""Scratch: one detector, two lanes (lm_match_begin / lm_match_end) from one host thread."""
+import importlib, sys, os, time
+import numpy as np
+if os.environ.get("TORCH"):
+    import torch
+    torch.cuda.set_device(0); torch.cuda.synchronize()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+lm = importlib.import_module("line-mod-pipeline_amd")
+synth = importlib.import_module("line-mod-pipeline_amd.synth")
+from tools_probe import quantized_from_gpu
+W, H, M = 640, 480, 2
+NL = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+BT = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+B = BT // NL
+frames = [synth.make_frame(W, H, seed=1234 + i) for i in range(BT)]
+d = lm.Detector(lm.default_config(color_only=False, width=W, height=H, frame_slots=BT))
+q = quantized_from_gpu(d, frames[0][0], frames[0][1], M)
+descs, feats, crops = synth.make_bank(3000, M, 2, seed=4321, fixed_l0_size=(96, 96), quantized=q, crop_fraction=0.1, frame_size=(W, H), T0=5)
+d.add_class("c", descs, feats)
+for i in range(BT):
+    d.upload_frame(i, *frames[i])
+outs = [(np.zeros((B, 4096), lm.MATCH_DTYPE), np.zeros(B, np.int32)) for _ in range(NL)]
+def run(n):
+    for l in range(NL):
+        d.match_begin(l, l * B, B, 80.0, 0)
+    for k in range(n):
+        for l in range(NL):
+            d.match_end(l, 4096, out=outs[l][0], counts=outs[l][1])
+            if k + 1 < n:
+                d.match_begin(l, l * B, B, 80.0, 0)
+run(10)
+t0 = time.perf_counter(); run(100); dt = time.perf_counter() - t0
+print("lanes %d, %d frames per step: %.1f detections/s  (%.2f us/frame)  matches0 %d" % (NL, BT, BT * 100 / dt, dt / 100 / BT * 1e6, outs[0][1][0]))
