@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=128, help="frames per step (resident in HBM)")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step (resident in HBM)")
     ap.add_argument("--lanes", type=int, default=0, choices=(0, 1, 2),
                     help="2: the step's frames are split over the detector's two lanes (two HIP streams driven by one "
                          "host thread through lm_match_begin / lm_match_end) so that the stages of one half overlap "
@@ -232,6 +232,9 @@ def main():
                        "unit_definition": "one detection = one frame matched against one %d-template bank shard; "
                                           "N GPUs search N shards of the same frames" % args.templates,
                        "stage_us_per_frame": dict(zip(["preprocess", "scan", "refine", "sort"], stage_us_per_frame)),
+                       "stage_note": "HIP-event spans on each lane's stream per frame of that lane; with two lanes the "
+                                     "spans of one lane contain kernels of the other, so they add up to more than the "
+                                     "wall time per frame",
                        "parallelism": "template-shard x%d" % world},
             "roofline": roofline,
             "cpu_baseline": cpu,
