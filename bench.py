@@ -5,8 +5,9 @@
 A "step" = one pass of the hot path (Detector::match, a3-a15) over one batch of `--batch` synthetic
 frames that are already resident in HBM.  One process per GPU; with N > 1 the template bank is
 sharded over the ranks (3000 templates per GPU, weak scaling), every rank matches the same frames
-against its shard and the per-shard match lists are exchanged with one RCCL all-gather per step
-and merged on every rank.
+against its shard and the per-shard match lists are exchanged with two small RCCL all-gathers per
+step and merged on every rank (the rank process does the exchange, a torch-free worker process the
+matching; see main()).
 
 value = n_gpus * frames / time: one detection = one frame searched against one 3000-template shard
 (frames/sec of the whole job is reported separately in config.frames_per_sec).
@@ -19,6 +20,7 @@ import argparse
 import importlib
 import json
 import os
+import struct
 import sys
 import time
 
@@ -40,6 +42,160 @@ def quantized_from_gpu(det, bgr, depth, M, L=2):
             for l in range(L) for m in range(M)}
 
 
+CAP = 4096       # match records per frame in the result buffers (a shard's list must fit: SURVEY.md 8e)
+NBUF = 3         # result buffers in rotation: the matcher may run ahead of the exchange
+
+
+class Runner:
+    """The matcher of one GPU: detector, resident synthetic workload, and the step loop over its two lanes.
+    Lives in the bench process on one GPU and in a torch-free worker process per rank when N > 1."""
+
+    def __init__(self, args, rank, world, local_rank):
+        self.lm = lm = importlib.import_module("line-mod-pipeline_amd")
+        synth = importlib.import_module("line-mod-pipeline_amd.synth")
+        self.args = args
+        W, H, M, B = 640, 480, 2, args.batch
+        self.B = B
+        self.n_total = args.templates * world
+        cfg = lm.default_config(color_only=False, width=W, height=H, device=local_rank, shard_rank=rank,
+                                shard_size=world, frame_slots=max(B, 1), flags=1 if args.byte_responses else 0)
+        self.det = det = lm.Detector(cfg)
+        # ---- workload: seeded synthetic frames + fixed-geometry bank (SURVEY.md 8d config 2)
+        self.frames = [synth.make_frame(W, H, seed=1234 + i) for i in range(B)]
+        q = quantized_from_gpu(det, self.frames[0][0], self.frames[0][1], M)
+        self.descs, self.feats, _ = synth.make_bank(self.n_total, M, 2, seed=4321, fixed_l0_size=(96, 96), quantized=q,
+                                                    crop_fraction=0.1, frame_size=(W, H), T0=det.get_T(0))
+        det.add_class("synthetic.ply", self.descs, self.feats)
+        for i, (bgr, depth) in enumerate(self.frames):
+            det.upload_frame(i, bgr, depth)
+        self.NL = args.lanes if args.lanes else 2
+        if B % 2 or B < 2:
+            self.NL = 1
+        self.Bl = B // self.NL                           # frames per lane and launch
+        self.bufs = result_buffers(lm, B)
+        self.views = [[(o[l * self.Bl:(l + 1) * self.Bl], cn[l * self.Bl:(l + 1) * self.Bl]) for l in range(self.NL)]
+                      for o, cn in self.bufs]
+        self.k = 0
+
+    def run_steps(self, n, before_step=None, after_step=None):
+        """n passes of the hot path over the batch, driven by this one host thread: lane l works on the frames of
+        slots [l * Bl, (l + 1) * Bl); as soon as a lane's step is collected its next step is enqueued, so the two
+        streams always have work and their stages overlap."""
+        if n <= 0:
+            return
+        det, thr, NL, Bl = self.det, self.args.threshold, self.NL, self.Bl
+        k0 = self.k
+        self.k += n
+        for l in range(NL):
+            det.match_begin(l, l * Bl, Bl, thr, 0)
+        for k in range(k0, k0 + n):
+            if before_step is not None:
+                before_step(k)                            # result buffer k % NBUF must be free
+            for l in range(NL):
+                o, cn = self.views[k % NBUF][l]
+                det.match_end(l, CAP, out=o, counts=cn)
+                if k + 1 < k0 + n:
+                    det.match_begin(l, l * Bl, Bl, thr, 0)
+            if after_step is not None:
+                after_step(k)
+
+    def report(self):
+        prof = self.det.get_profile()
+        return {"prof": prof, "scan_load_bytes": self.det.scan_load_bytes(0), "Bl": self.Bl, "NL": self.NL,
+                "matches0": int(self.bufs[(self.k - 1) % NBUF][1][0]) if self.k else 0}
+
+
+def result_buffers(lm, B):
+    """NBUF x ([B, CAP] records, [B] counts)."""
+    return [(np.zeros((B, CAP), lm.MATCH_DTYPE), np.zeros(B, np.int32)) for _ in range(NBUF)]
+
+
+def send_msg(f, tag, payload=b""):
+    f.write(tag + struct.pack("<I", len(payload)) + payload)
+    f.flush()
+
+
+def recv_msg(f, expect=None):
+    hdr = f.read(8)
+    if len(hdr) < 8:
+        raise RuntimeError("bench worker pipe closed while waiting for %r" % (expect,))
+    tag, n = hdr[:4], struct.unpack("<I", hdr[4:])[0]
+    payload = f.read(n) if n else b""
+    if len(payload) < n:
+        raise RuntimeError("bench worker pipe closed inside a %r message" % (tag,))
+    if expect is not None and tag != expect:
+        raise RuntimeError("bench worker protocol: expected %r, got %r" % (expect, tag))
+    return tag, payload
+
+
+def worker_main(args):
+    """Torch-free matcher of one rank (N > 1).  Framed messages (4-byte tag, u32 length, payload) on stdin / stdout:
+         -> REDY | <- RUN_ n : n x (-> DONE k, total, counts[B], packed records) then -> REND
+         <- PROF 0/1 -> OK__ | <- REPT -> REPT json | <- QUIT
+    The pipe is the only coupling (no shared memory: /dev/shm may be tiny in a container); a step's packed lists are a
+    few hundred KB and the pipe's back-pressure bounds how far the matcher runs ahead of the exchange."""
+    out = os.fdopen(os.dup(1), "wb")
+    os.dup2(2, 1)                                          # anything else that prints to stdout goes to stderr
+    inp = os.fdopen(os.dup(0), "rb")
+    r = Runner(args, args.worker_rank, args.worker_world, args.worker_local_rank)
+    lm = r.lm
+
+    def after(k):
+        o, cn = r.bufs[k % NBUF]
+        packed = lm.pack_matches(o, cn)
+        send_msg(out, b"DONE", struct.pack("<ii", k, len(packed)) + cn.tobytes() + packed.tobytes())
+
+    send_msg(out, b"REDY")
+    while True:
+        tag, payload = recv_msg(inp)
+        if tag == b"RUN_":
+            r.run_steps(struct.unpack("<i", payload)[0], after_step=after)
+            send_msg(out, b"REND")
+        elif tag == b"PROF":
+            r.det.set_profiling(payload == b"1")
+            send_msg(out, b"OK__")
+        elif tag == b"REPT":
+            send_msg(out, b"REPT", json.dumps(r.report()).encode())
+        elif tag == b"QUIT":
+            break
+    r.det.close()
+
+
+class Worker:
+    """Parent side of worker_main."""
+
+    def __init__(self, args, rank, world, local_rank):
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--worker", "1", "--worker-rank", str(rank),
+               "--worker-world", str(world), "--worker-local-rank", str(local_rank), "--batch", str(args.batch),
+               "--templates", str(args.templates), "--threshold", repr(args.threshold), "--lanes", str(args.lanes)]
+        if args.byte_responses:
+            cmd.append("--byte-responses")
+        self.p = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+        self.B = args.batch
+
+    def send(self, tag, payload=b""):
+        send_msg(self.p.stdin, tag, payload)
+
+    def recv(self, expect):
+        return recv_msg(self.p.stdout, expect)[1]
+
+    def recv_step(self, dtype):
+        """-> (k, counts[B], packed records) of the next finished step."""
+        payload = self.recv(b"DONE")
+        k, total = struct.unpack("<ii", payload[:8])
+        counts = np.frombuffer(payload, np.int32, self.B, 8)
+        packed = np.frombuffer(payload, dtype, total, 8 + 4 * self.B)
+        return k, counts, packed
+
+    def close(self):
+        try:
+            self.send(b"QUIT")
+            self.p.wait(timeout=60)
+        except Exception:                                  # noqa: BLE001
+            self.p.kill()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -47,10 +203,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="frames per step (resident in HBM)")
     ap.add_argument("--lanes", type=int, default=0, choices=(0, 1, 2),
-                    help="2: the step's frames are split over the detector's two lanes (two HIP streams driven by one "
-                         "host thread through lm_match_begin / lm_match_end) so that the stages of one half overlap "
-                         "those of the other (the scan is L1/L2-bound, the preprocess passes VALU / fabric-bound); "
-                         "0 = 2 on one GPU, 1 with N > 1 (see the note on torch in main())")
+                    help="2 (= 0, the default): the step's frames are split over the detector's two lanes (two HIP "
+                         "streams driven by one host thread through lm_match_begin / lm_match_end) so that the stages "
+                         "of one half overlap those of the other (the scan is L1/L2-bound, the preprocess passes VALU "
+                         "/ fabric-bound)")
     ap.add_argument("--templates", type=int, default=3000, help="templates per GPU")
     ap.add_argument("--threshold", type=float, default=80.0)
     ap.add_argument("--byte-responses", action="store_true", help="LM_FLAG_BYTE_RESPONSES: byte scan kernel (A/B)")
@@ -59,149 +215,112 @@ def main():
                     help="functional check of the N > 1 path on a 1-GPU box: every rank uses cuda:0 and the exchange "
                          "goes through gloo on the host (never a measurement)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--worker", default=None, help=argparse.SUPPRESS)            # internal: matcher process of a rank
+    ap.add_argument("--worker-rank", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--worker-world", type=int, default=1, help=argparse.SUPPRESS)
+    ap.add_argument("--worker-local-rank", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.worker:
+        return worker_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.functional_gloo:
+        local_rank = 0
 
-    # One GPU needs no torch at all (lm_match_end synchronises its stream; inputs and results are numpy), and it is
-    # kept out on purpose: with torch loaded into the process the detector's two HIP streams no longer overlap
-    # (measured on the MI355X box, 100 steps of 128 frames: 93.8 K detections/s without `import torch`, 76 K with
-    # it, whatever the initialisation order, thread counts or synchronisation calls; one lane is unaffected:
-    # 85 K both ways).  N > 1 needs torch.distributed, so there the default is one lane.
-    torch = dist = device = None
-    if world > 1:
+    # The matcher never shares a process with torch: with torch loaded the detector's two HIP streams no longer
+    # overlap (measured on the MI355X box, 100 steps of 128 frames: 93.8 K detections/s without `import torch`,
+    # 76 K with it, whatever the initialisation order, thread counts or synchronisation calls; one lane is
+    # unaffected: 85 K both ways).  One GPU: no torch at all (inputs and results are numpy, lm_synchronize is the
+    # device-wide synchronisation).  N > 1: this process keeps torch.distributed (RCCL) for the exchange and a
+    # torch-free worker process, started before anything here touches the GPU, runs the matcher; the two talk over
+    # a pipe.
+    lm = importlib.import_module("line-mod-pipeline_amd")
+    runner = worker = gather = torch = dist = None
+    if world == 1:
+        runner = Runner(args, rank, world, local_rank)
+        det = runner.det
+    else:
+        worker = Worker(args, rank, world, local_rank)
         import torch
         import torch.distributed as dist
-        if args.functional_gloo:
-            local_rank = 0
+        distmod = importlib.import_module("line-mod-pipeline_amd.dist")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         if args.functional_gloo:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            device = torch.device("cpu")
         else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        device = torch.device("cuda", local_rank)
-        torch.cuda.synchronize()
-
-    lm = importlib.import_module("line-mod-pipeline_amd")
-    synth = importlib.import_module("line-mod-pipeline_amd.synth")
-    distmod = importlib.import_module("line-mod-pipeline_amd.dist")
-
-    W, H, M, B = 640, 480, 2, args.batch
-    n_total = args.templates * world
-    cfg = lm.default_config(color_only=False, width=W, height=H, device=local_rank, shard_rank=rank,
-                            shard_size=world, frame_slots=max(B, 1), flags=1 if args.byte_responses else 0)
-    det = lm.Detector(cfg)
-
-    # ---- workload: seeded synthetic frames + fixed-geometry bank
-    frames = [synth.make_frame(W, H, seed=1234 + i) for i in range(B)]
-    q = quantized_from_gpu(det, frames[0][0], frames[0][1], M)
-    descs, feats, crops = synth.make_bank(n_total, M, 2, seed=4321, fixed_l0_size=(96, 96), quantized=q,
-                                          crop_fraction=0.1, frame_size=(W, H), T0=det.get_T(0))
-    det.add_class("synthetic.ply", descs, feats)
-    for i, (bgr, depth) in enumerate(frames):
-        det.upload_frame(i, bgr, depth)
-
-    cap = 4096
-    NL = args.lanes if args.lanes else (2 if world == 1 else 1)
-    if B % 2 or B < 2:
-        NL = 1
-    Bl = B // NL                                         # frames per lane and launch
-    NBUF = 3                                             # result buffers in rotation
-    bufs = [(np.zeros((B, cap), lm.MATCH_DTYPE), np.zeros(B, np.int32)) for _ in range(NBUF)]
-    views = [[(o[l * Bl:(l + 1) * Bl], cn[l * Bl:(l + 1) * Bl]) for l in range(NL)] for o, cn in bufs]
-    gather = None
-    if world > 1:
-        import queue
-        import threading
-        gather = distmod.ShardGather(lm.merge_matches, cap=cap, pack_fn=lm.pack_matches, merge_batch_fn=lm.merge_batch,
-                                     device=torch.device("cpu") if args.functional_gloo else device)
-    state = {"k": 0, "merged": None, "error": None}
+            device = torch.device("cuda", local_rank)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        gather = distmod.ShardGather(lm.merge_matches, cap=CAP, pack_fn=lm.pack_matches, merge_batch_fn=lm.merge_batch,
+                                     device=device)
+        worker.recv(b"REDY")
+    state = {"merged": None}
 
     def run_steps(n):
-        """n passes of the hot path over the batch, driven by this one host thread: lane l works on the frames of
-        slots [l * Bl, (l + 1) * Bl); as soon as a lane's step is collected its next step is enqueued, so the two
-        streams always have work and their stages overlap.  With N > 1 an exchange thread gathers + merges step k
-        (two small collectives + lm_merge_batch) while the GPU already works on step k + 1."""
+        """One GPU: the matcher's own loop.  N > 1: the worker runs the steps; this process gathers + merges step k
+        (two small collectives + lm_merge_batch) as soon as the worker reports it, while the GPU already works on
+        step k + 1, and hands the result buffer back."""
         if n <= 0:
             return
-        k0 = state["k"]
-        state["k"] += n
-        if gather is not None:
-            todo = queue.Queue()
-            free = threading.Semaphore(NBUF - 1)           # buffers the lanes may fill ahead of the exchange
-
-            def exchange():
-                while True:
-                    k = todo.get()
-                    if k is None:
-                        return
-                    try:
-                        if state["error"] is None:
-                            state["merged"] = gather.gather_merge(*bufs[k % NBUF])
-                    except Exception as e:                 # noqa: BLE001 - re-raised by the main thread
-                        state["error"] = e
-                    free.release()
-
-            th = threading.Thread(target=exchange)
-            th.start()
-        for l in range(NL):
-            det.match_begin(l, l * Bl, Bl, args.threshold, 0)
-        for k in range(k0, k0 + n):
-            if gather is not None:
-                free.acquire()
-            for l in range(NL):
-                o, cn = views[k % NBUF][l]
-                det.match_end(l, cap, out=o, counts=cn)
-                if k + 1 < k0 + n:
-                    det.match_begin(l, l * Bl, Bl, args.threshold, 0)
-            if gather is not None:
-                todo.put(k)
-        if gather is not None:
-            todo.put(None)
-            th.join()
-            if state["error"] is not None:
-                raise state["error"]
+        if runner is not None:
+            return runner.run_steps(n)
+        worker.send(b"RUN_", struct.pack("<i", n))
+        for _ in range(n):
+            _, counts, packed = worker.recv_step(lm.MATCH_DTYPE)
+            state["merged"] = gather.gather_merge_packed(packed, counts)
+        worker.recv(b"REND")
 
     def fence():
-        # N > 1: barrier + torch.cuda.synchronize().  N = 1: the same device-wide synchronisation without torch.
+        # N > 1: barrier + torch.cuda.synchronize() (the worker's lm_match_end has synchronised its streams before
+        # it reported a step).  N = 1: the same device-wide synchronisation without torch.
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
         else:
-            det.synchronize()                           # hipDeviceSynchronize: the torch-free torch.cuda.synchronize()
+            det.synchronize()                           # hipDeviceSynchronize
 
     run_steps(args.warmup)
-    det.set_profiling(True)
+    if runner is not None:
+        det.set_profiling(True)
+    else:
+        worker.send(b"PROF", b"1")
+        worker.recv(b"OK__")
     fence()
     t0 = time.perf_counter()
     run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     merged = state["merged"]
-    prof = det.get_profile()
-    det.set_profiling(False)
+    if runner is not None:
+        rep = runner.report()
+        det.set_profiling(False)
+    else:
+        worker.send(b"REPT")
+        rep = json.loads(worker.recv(b"REPT").decode())
+    prof, Bl, NL = rep["prof"], rep["Bl"], rep["NL"]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if args.functional_gloo else device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    B = args.batch
+    n_total = args.templates * world
     frames_done = B * args.steps
     fps = frames_done / dt
-    n_matches0 = int(bufs[(state["k"] - 1) % NBUF][1][0]) if merged is None else len(merged[0])
+    n_matches0 = rep["matches0"] if merged is None else len(merged[0])
 
     # ---- roofline of the dominant kernel (similarity scan): algorithmic bytes / HIP-event time
     scan_us = prof["stage_us"][1] / max(prof["launches"], 1)
     bytes_per_launch = prof["scan_bytes"] / max(prof["launches"], 1)
     achieved = bytes_per_launch / (scan_us * 1e-6) / 1e9 if scan_us > 0 else 0.0
     traffic, traffic_src = pmc_traffic(Bl)
-    l2_bytes = det.scan_load_bytes(0) * Bl         # bytes the scan's vector loads request per launch
+    l2_bytes = rep["scan_load_bytes"] * Bl         # bytes the scan's vector loads request per launch
     l2_rate = l2_bytes / (scan_us * 1e-6) / 1e9 if scan_us > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -218,7 +337,7 @@ def main():
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args, frames, descs, feats, det, lm)
+            cpu = cpu_baseline(args, runner.frames, runner.descs, runner.feats, det, lm)
         result = {
             "metric": "detections/sec", "value": round(world * fps, 1), "unit": "detections/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -240,8 +359,10 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(result))
-    det.close()
-    if world > 1:
+    if runner is not None:
+        det.close()
+    else:
+        worker.close()
         dist.barrier()
         dist.destroy_process_group()
     return result

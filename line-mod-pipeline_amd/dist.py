@@ -78,6 +78,18 @@ class ShardGather:
                                 "(SURVEY.md 8e: K must cover all matches)" % (int(counts.max()), self.cap))
         if self.world == 1:
             return [records[i, :counts[i]].copy() for i in range(B)]
+        return self.gather_merge_packed(self._pack(records, counts), counts)
+
+    def gather_merge_packed(self, packed, counts):
+        """The same for lists that are already packed back to back (lm_pack_matches layout)."""
+        B = len(counts)
+        counts = np.array(counts, dtype=np.int32)            # writable copy (torch.from_numpy)
+        if int(counts.max(initial=0)) > self.cap:
+            raise OverflowError("shard produced %d matches for one frame, gather capacity %d "
+                                "(SURVEY.md 8e: K must cover all matches)" % (int(counts.max()), self.cap))
+        if self.world == 1:
+            ends = np.cumsum(counts)
+            return [packed[e - c:e].copy() for e, c in zip(ends, counts)]
         t = self.torch
         # 1. counts of every rank
         csend, crecv = self._count_buffers(B)
@@ -86,10 +98,9 @@ class ShardGather:
         allc = crecv.cpu().numpy()                                  # [R, B]
         totals = allc.sum(axis=1)
         # 2. packed records, padded to the largest rank total
-        packed = self._pack(records, counts)
         stride, rsend, rrecv = self._record_buffers(int(totals.max()))
         if len(packed):
-            rsend[:len(packed) * 5].copy_(t.from_numpy(packed.view(np.int32).reshape(-1)))
+            rsend[:len(packed) * 5].copy_(t.from_numpy(np.ascontiguousarray(packed).view(np.int32).reshape(-1).copy()))
         self.dist.all_gather_into_tensor(rrecv.view(-1), rsend, group=self.group)
         allr = rrecv.cpu().numpy().view(MATCH_DTYPE).reshape(self.world, stride)
         # 3. merge every frame
