@@ -1,5 +1,6 @@
 import sys, time, importlib, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import oracle as O
 synth = importlib.import_module("line-mod-pipeline_amd.synth")

@@ -5,6 +5,7 @@ if os.environ.get("TORCH"):
     import torch
     torch.cuda.set_device(0); torch.cuda.synchronize()
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lm = importlib.import_module("line-mod-pipeline_amd")
 synth = importlib.import_module("line-mod-pipeline_amd.synth")
 from tools_probe import quantized_from_gpu

@@ -1,4 +1,4 @@
-# usage: bash tools_profile_round.sh <tag>   (on the GPU box; writes under gpurun_out/<tag>_*)
+# usage (repo root, on the GPU box): bash tools/tools_profile_round.sh <tag>   -> gpurun_out/<tag>_*
 T=$1
 B="python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline"
 timeout 600 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
