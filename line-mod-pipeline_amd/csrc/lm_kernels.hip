@@ -1178,68 +1178,56 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
 // ------------------------------------------------------------------------------------------------
 // a11-a13, nibble form of the hot kernel (LmLevelGeom::nibble): responses are <= 4, so the lowest
 // level stores two positions per byte.  The vector L1 spends one cycle per 4 lanes of a load whatever
-// the width per lane, so every lane loads 16 bytes = 32 positions, and one wave carries TWO work
-// items (template, chunk of LM_SCAN4_CHUNK positions): lanes 0..31 the first, lanes 32..63 the second
-// (P is about 1000 for a 640x480 frame at T = 8: one item per template).  Bank offsets are in nibbles;
-// the per-half load address is rounded down to a dword and the 0..7 nibble shift is undone with
-// v_alignbit_b32, the 33rd.. nibble coming from the next lane by DPP -- lane 31 receives the other
-// item's dword there, which only reaches positions >= 1017 of the chunk, hence 1016 positions per item.
-// Three features are added nibble-wise (3 * 4 = 12 < 16), then split into even / odd positions and added
-// byte-wise (63 * 4 = 252).  Feature lists are padded to a multiple of 3.
+// the width per lane, so every lane loads 16 bytes = 32 positions, and one wave carries one work item
+// (template, chunk of LM_SCAN4_CHUNK positions) for TWO FRAMES: lanes 0..31 scan slot 2j, lanes 32..63
+// slot 2j + 1 (P is about 1000 for a 640x480 frame at T = 8: one item per template).  The template is the
+// same for both halves, so the feature offsets, the dword-aligned load address (buffer soffset) and the
+// 0..7 nibble shift are wave-uniform scalars: a feature costs no VALU instruction for addressing.  The
+// shift is undone with v_alignbit_b32, the 33rd.. nibble coming from the next lane by DPP -- lane 31
+// receives the other frame's dword there, which only reaches positions >= 1017 of the chunk, hence 1016
+// positions per item.  Three features are added nibble-wise (3 * 4 = 12 < 16), then split into even / odd
+// positions and added byte-wise (63 * 4 = 252).
 // ------------------------------------------------------------------------------------------------
 template <int FB, bool XCD_MAP>
 __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
     const int lane = threadIdx.x & 63;
-    u32 slot, wg;
-    if (XCD_MAP) {
-        const u32 G = (u32)a.wgs_per_slot, B = (u32)a.nslots;
-        const u32 b = blockIdx.x, x = b & 7u, k = b >> 3;
-        if ((B & 7u) == 0) { slot = x + 8u * (k / G); wg = k % G; }
-        else { const u32 r = 8u / B; slot = x % B; wg = k * r + x / B; }
-        if (wg >= G || slot >= B) return;
-    } else {
-        slot = blockIdx.z; wg = blockIdx.x;
-    }
+    const u32 npairs = ((u32)a.nslots + 1u) >> 1;
+    u32 pair, wg;
+    if (XCD_MAP) xcd_slot_tile((u32)a.wgs_per_slot, npairs, pair, wg);
+    else { pair = blockIdx.z; wg = blockIdx.x; }
+    if (pair >= npairs) return;
     const int wave = __builtin_amdgcn_readfirstlane((int)((wg * 256u + threadIdx.x) >> 6));
-    if (2 * wave >= a.n_items) return;
-    const bool hasB = 2 * wave + 1 < a.n_items;
-    const int itA = a.item_lo + 2 * wave, itB = hasB ? itA + 1 : itA;
-    const u32 tiA = a.item_t[itA], tiB = a.item_t[itB];
-    const u32 chA = a.item_chunk[itA], chB = a.item_chunk[itB];
-    const bool hi = lane >= 32;
-    const u32 ti = hi ? tiB : tiA;
-    const int P = hi ? (hasB ? a.scan_P[tiB] : 0) : a.scan_P[tiA];
-    const int cntA = a.scan_n[tiA], cntB = hasB ? a.scan_n[tiB] : 0;   // n | features of modality 0 << 8 | of 1 << 16
-    const int n = (hi ? a.scan_n[tiB] : cntA) & 0xFF;
+    if (wave >= a.n_items) return;
+    const u32 ti = a.item_t[a.item_lo + wave];
+    const u32 chunk = a.item_chunk[a.item_lo + wave];
+    const int cnt = a.scan_n[ti];                      // n | features of modality 0 << 8 | of 1 << 16
+    const int n = cnt & 0xFF;
     const int thr = a.raw_thr_by_n[n];
-    const u32 j0 = (hi ? chB : chA) * LM_SCAN4_CHUNK + (u32)(lane & 31) * 32u;   // first position of this lane
-    // one buffer descriptor for the slot's arena; voffset = the lane's 16 bytes inside its item's chunk + the
-    // feature's dword-aligned byte offset of its half
+    const bool hi = lane >= 32;
+    const u32 slot0 = 2u * pair;
+    const bool have = !hi || slot0 + 1u < (u32)a.nslots;            // an odd slot count leaves the last upper half idle
+    const u32 slot = slot0 + ((hi && have) ? 1u : 0u);
+    const int P = have ? a.scan_P[ti] : 0;
+    const u32 j0 = chunk * LM_SCAN4_CHUNK + (u32)(lane & 31) * 32u;  // first position of this lane
+    // buffer addressing: descriptor = arena of slot 2j, voffset = the lane's 16 bytes inside the chunk (+ one slot
+    // stride for the upper half), soffset = the feature's dword-aligned byte offset
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<u8*>(a.lm + (size_t)slot * a.lm_slot_stride), 0, 0x7FFFFFFF, 0x00020000);
-    const u32 lane_base = j0 >> 1;
-    const u32 half_sel = hi ? 0xFFFFFFFFu : 0u;
-    const u32 half_shift = hi ? 8u : 0u;
-    LmDevHeader* hdr = reinterpret_cast<LmDevHeader*>(reinterpret_cast<u8*>(a.hdr) + (size_t)slot * a.aux_slot_stride);
-    LmCand* cand = reinterpret_cast<LmCand*>(reinterpret_cast<u8*>(a.cand) + (size_t)slot * a.aux_slot_stride);
+        const_cast<u8*>(a.lm + (size_t)slot0 * a.lm_slot_stride), 0, 0x7FFFFFFF, 0x00020000);
+    const u32 lane_base = (j0 >> 1) + ((slot != slot0) ? (u32)a.lm_slot_stride : 0u);
 
     // u16 pairs: position 8k + i of the lane lives in t[k][i & 3], half i >> 2
     u32 t[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     for (int m = 0; m < a.M; ++m) {
-        const u32* offsA = a.scan_off + ((size_t)tiA * a.M + m) * a.fpad;
-        const u32* offsB = a.scan_off + ((size_t)tiB * a.M + m) * a.fpad;
+        const u32* offs = a.scan_off + ((size_t)ti * a.M + m) * a.fpad;
         u32 bl[4] = {0, 0, 0, 0}, bh[4] = {0, 0, 0, 0};   // byte lanes: even / odd positions of dword k
 #define LM_SCAN4_BLOCK(NF)                                                                       \
         {                                                                                        \
             u32x4 v[NF];                                                                         \
             u32 sh[NF];                                                                          \
             _Pragma("unroll") for (int k = 0; k < NF; ++k) {                                     \
-                const u32 oa = offsA[f + k], ob = offsB[f + k];                                  \
-                const u32 ba = (oa >> 3) << 2, bb = (ob >> 3) << 2;          /* scalar */        \
-                const u32 shp = ((oa & 7u) << 2) | ((ob & 7u) << 10);        /* scalar */        \
-                sh[k] = shp >> half_shift;                                   /* low 5 bits used */ \
-                const u32 vo = lane_base + ((ba & ~half_sel) | (bb & half_sel));                 \
-                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);                    \
+                const u32 o = offs[f + k];                                                       \
+                sh[k] = (o & 7u) << 2;                                                           \
+                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_base, (o >> 3) << 2, 0); \
             }                                                                                    \
             _Pragma("unroll") for (int g3 = 0; g3 < NF; g3 += 3) {                               \
                 u32 nb[4] = {0, 0, 0, 0};                                                        \
@@ -1255,9 +1243,7 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
                 }                                                                                \
             }                                                                                    \
         }
-        // features of this modality: the longer list of the pair (the shorter one is padded with zero-block offsets)
-        const int fa = (cntA >> (8 + 8 * m)) & 0xFF, fb = (cntB >> (8 + 8 * m)) & 0xFF;
-        const int F = fa > fb ? fa : fb;
+        const int F = (cnt >> (8 + 8 * m)) & 0xFF;        // in-bounds features of this modality
         int f = 0;
         for (; f + FB <= F; f += FB) LM_SCAN4_BLOCK(FB)
         if (FB > 6 && f + 6 <= F) { LM_SCAN4_BLOCK(6) f += 6; }
@@ -1280,11 +1266,13 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
             hit |= (sv > thr ? 1u : 0u) << (8 * k + i);
         }
     // positions of this item: [chunk * CHUNK, min(P, (chunk + 1) * CHUNK))
-    const int lim = min(P, (int)(((hi ? chB : chA) + 1u) * LM_SCAN4_CHUNK));
+    const int lim = min(P, (int)((chunk + 1u) * LM_SCAN4_CHUNK));
     const int valid = lim - (int)j0;
     if (valid <= 0) hit = 0;
     else if (valid < 32) hit &= (1u << valid) - 1u;
     if (!__any(hit != 0)) return;
+    LmDevHeader* hdr = reinterpret_cast<LmDevHeader*>(reinterpret_cast<u8*>(a.hdr) + (size_t)slot * a.aux_slot_stride);
+    LmCand* cand = reinterpret_cast<LmCand*>(reinterpret_cast<u8*>(a.cand) + (size_t)slot * a.aux_slot_stride);
     const int offset = a.T / 2 + (a.T % 2 - 1);
     while (hit) {
         const int b = __ffs(hit) - 1;
@@ -1692,23 +1680,24 @@ void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, 
 void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
     if (a_in.n_items <= 0) return;
     LmScanArgs a = a_in;
-    const int n_waves = a.nibble ? (a.n_items + 1) / 2 : a.n_items;   // k_scan4: two items per wave
-    const int G = (n_waves + 3) / 4;
-    a.wgs_per_slot = G; a.nslots = nslots;
-    // variant bits 0-1: feature-loop unroll (0: 8 loads in flight, 1: 4, 2: 2); bit 2: plain (slot = grid.z)
-    // mapping instead of the XCD-aware one
-    const bool xcd = !(variant & 4) && (nslots == 1 || nslots == 2 || nslots == 4 || (nslots % 8) == 0);
-    dim3 grid = xcd ? dim3(((nslots % 8) == 0) ? (unsigned)(G * nslots) : 8u * (unsigned)((G + 8 / nslots - 1) / (8 / nslots)))
-                    : dim3(G, 1, nslots);
+    a.nslots = nslots;
+    const int G = (a.n_items + 3) / 4;               // one wave per work item
+    a.wgs_per_slot = G;
     if (a.nibble) {
-#define SCAN4_LAUNCH(FB)                                                                        \
-    do { if (xcd) hipLaunchKernelGGL((k_scan4<FB, true>), grid, dim3(256), 0, s, a);            \
-         else hipLaunchKernelGGL((k_scan4<FB, false>), grid, dim3(256), 0, s, a); } while (0)
+        // k_scan4: a wave scans its item for a PAIR of slots; 1-D grid with XCD affinity per pair
+        const int npairs = (nslots + 1) / 2;
+        dim3 grid((unsigned)(G * npairs), 1, 1);
+#define SCAN4_LAUNCH(FB) hipLaunchKernelGGL((k_scan4<FB, true>), grid, dim3(256), 0, s, a)
         const int fb = variant & 3;
         if (fb == 1) SCAN4_LAUNCH(12); else if (fb == 2) SCAN4_LAUNCH(3); else SCAN4_LAUNCH(6);
 #undef SCAN4_LAUNCH
         return;
     }
+    // variant bits 0-1: feature-loop unroll (0: 8 loads in flight, 1: 4, 2: 2); bit 2: plain (slot = grid.z)
+    // mapping instead of the XCD-aware one
+    const bool xcd = !(variant & 4) && (nslots == 1 || nslots == 2 || nslots == 4 || (nslots % 8) == 0);
+    dim3 grid = xcd ? dim3(((nslots % 8) == 0) ? (unsigned)(G * nslots) : 8u * (unsigned)((G + 8 / nslots - 1) / (8 / nslots)))
+                    : dim3(G, 1, nslots);
     const int u = variant & 3;
 #define SCAN_LAUNCH(U)                                                                      \
     do { if (xcd) hipLaunchKernelGGL((k_scan<U, true>), grid, dim3(256), 0, s, a);  \
