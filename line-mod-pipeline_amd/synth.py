@@ -17,28 +17,34 @@ def make_frame(width=640, height=480, seed=1234, n_shapes=40, noise_sigma=2.0, h
     yy, xx = np.mgrid[0:height, 0:width].astype(np.float32)
     bgr = np.empty((height, width, 3), np.float32)
     bgr[:] = rng.integers(40, 216, 3)
-    depth = 900.0 + 0.15 * (xx - width / 2) + 0.1 * (yy - height / 2)
+    # float64 from here on: the planes below mix in float64 scalars
+    depth = (900.0 + 0.15 * (xx - width / 2) + 0.1 * (yy - height / 2)).astype(np.float64)
     for _ in range(n_shapes):
         kind = rng.integers(0, 3)
         cx, cy = rng.uniform(0, width), rng.uniform(0, height)
         sx, sy = rng.uniform(0.04, 0.22) * width, rng.uniform(0.04, 0.22) * height
+        # every shape lies inside this box, so only the box is evaluated (same pixels as the full image would give)
+        rad = float(np.hypot(sx, sy)) + 2.0
+        x0, x1 = max(int(cx - rad), 0), min(int(cx + rad) + 2, width)
+        y0, y1 = max(int(cy - rad), 0), min(int(cy + rad) + 2, height)
+        X, Y = xx[y0:y1, x0:x1], yy[y0:y1, x0:x1]
         if kind == 0:
-            m = ((xx - cx) / sx) ** 2 + ((yy - cy) / sy) ** 2 <= 1.0
+            m = ((X - cx) / sx) ** 2 + ((Y - cy) / sy) ** 2 <= 1.0
         elif kind == 1:
             a = rng.uniform(0, np.pi)
-            u = (xx - cx) * np.cos(a) + (yy - cy) * np.sin(a)
-            v = -(xx - cx) * np.sin(a) + (yy - cy) * np.cos(a)
+            u = (X - cx) * np.cos(a) + (Y - cy) * np.sin(a)
+            v = -(X - cx) * np.sin(a) + (Y - cy) * np.cos(a)
             m = (np.abs(u) <= sx) & (np.abs(v) <= sy)
         else:
             p = np.stack([rng.uniform(cx - sx, cx + sx, 3), rng.uniform(cy - sy, cy + sy, 3)], 1)
             def side(a, b):
-                return (xx - a[0]) * (b[1] - a[1]) - (yy - a[1]) * (b[0] - a[0])
+                return (X - a[0]) * (b[1] - a[1]) - (Y - a[1]) * (b[0] - a[0])
             s0, s1, s2 = side(p[0], p[1]), side(p[1], p[2]), side(p[2], p[0])
             m = ((s0 >= 0) & (s1 >= 0) & (s2 >= 0)) | ((s0 <= 0) & (s1 <= 0) & (s2 <= 0))
-        bgr[m] = rng.integers(0, 256, 3)
+        bgr[y0:y1, x0:x1][m] = rng.integers(0, 256, 3)
         gx, gy = rng.uniform(-0.6, 0.6, 2)
-        plane = rng.uniform(500, 1200) + gx * (xx - cx) + gy * (yy - cy)
-        depth = np.where(m, plane, depth)
+        plane = rng.uniform(500, 1200) + gx * (X - cx) + gy * (Y - cy)
+        depth[y0:y1, x0:x1] = np.where(m, plane, depth[y0:y1, x0:x1])
     bgr += rng.normal(0.0, noise_sigma, bgr.shape).astype(np.float32)
     bgr = np.clip(np.rint(bgr), 0, 255).astype(np.uint8)
     depth = np.clip(np.rint(depth), 300, 3000).astype(np.uint16)
