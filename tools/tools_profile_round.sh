@@ -1,6 +1,6 @@
 # usage (repo root, on the GPU box): bash tools/tools_profile_round.sh <tag>   -> gpurun_out/<tag>_*
 T=$1
-B="python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline"
+B="python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline"   # two lanes, 128 frames per launch
 timeout 600 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${T}_pmcF -- $B > /dev/null 2>&1
