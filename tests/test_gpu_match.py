@@ -284,3 +284,31 @@ def test_two_lanes_equal_batch(lm, orc, synth):
         d.match_begin(1, 3, 2, 70.0)                          # overlapping slot ranges
     d.match_end(0, n_slots=4)
     d.close()
+
+
+def test_config5_batch_1280x960_multi_object(lm, orc, synth):
+    """BASELINE.json config 5 (matching part): a batch of 1280x960 RGB-D frames against three models with odd
+    template counts (odd work-item counts, several 1016-position chunks per template at W x H = 80 x 60), per class
+    and all classes at once, through the two lanes."""
+    size = (1280, 960)
+    d, o = _pair(lm, orc, False, size, frame_slots=4)
+    frames = [synth.make_frame(size[0], size[1], seed=500 + i) for i in range(4)]
+    q = _quantized(o, frames[0][0], frames[0][1], False)
+    for k, (n, seed) in enumerate(((41, 5), (33, 6), (27, 7))):
+        descs, feats, _ = synth.make_bank(n, 2, 2, seed=seed, quantized=q, crop_fraction=0.4, frame_size=size,
+                                          T0=d.get_T(0))
+        assert d.add_class("model%d.ply" % k, descs, feats) == k
+        o.add_class("model%d.ply" % k, descs, feats)
+    for i, (b, dp) in enumerate(frames):
+        d.upload_frame(i, b, dp)
+    for ci in (-1, 1):
+        exp = [o.match(b, dp, 78.0, class_idx=ci, threads=8) for b, dp in frames]
+        assert sum(len(e) for e in exp) > 0
+        d.match_begin(0, 0, 1, 78.0, ci)
+        d.match_begin(1, 1, 3, 78.0, ci)
+        o0, c0 = d.match_end(0, n_slots=1)
+        o1, c1 = d.match_end(1, n_slots=3)
+        assert_matches_equal(o0[0, :c0[0]], exp[0])
+        for i in range(3):
+            assert_matches_equal(o1[i, :c1[i]], exp[1 + i])
+    d.close()

@@ -21,14 +21,21 @@ d.add_class("c", descs, feats)
 for i in range(BT):
     d.upload_frame(i, *frames[i])
 outs = [(np.zeros((B, 4096), lm.MATCH_DTYPE), np.zeros(B, np.int32)) for _ in range(NL)]
+tb = te = 0.0
 def run(n):
+    global tb, te
     for l in range(NL):
         d.match_begin(l, l * B, B, 80.0, 0)
     for k in range(n):
         for l in range(NL):
+            t = time.perf_counter()
             d.match_end(l, 4096, out=outs[l][0], counts=outs[l][1])
+            te += time.perf_counter() - t
             if k + 1 < n:
+                t = time.perf_counter()
                 d.match_begin(l, l * B, B, 80.0, 0)
+                tb += time.perf_counter() - t
 run(10)
 t0 = time.perf_counter(); run(100); dt = time.perf_counter() - t0
+print("host time per lane-step: begin %.1f us, end (wait + collect) %.1f us" % (tb / (110 * NL) * 1e6, te / (110 * NL) * 1e6))
 print("lanes %d, %d frames per step: %.1f detections/s  (%.2f us/frame)  matches0 %d" % (NL, BT, BT * 100 / dt, dt / 100 / BT * 1e6, outs[0][1][0]))
