@@ -112,3 +112,39 @@ def test_yaml_filestorage_lookups(lm, tmp_path):
         lm.yaml_numbers(m, "no such key")
     with pytest.raises(lm.LinemodError):
         lm.yaml_numbers(s, "model folder")
+
+
+def test_yaml_malformed_input_is_an_error_not_a_crash(lm, tmp_path):
+    """Truncated / garbled template files must come back as LM_ERR_IO (or load what is well-formed), never crash."""
+    text = open(os.path.join(GOLD, "opencv_style_templates.yml")).read()
+    rng = np.random.default_rng(3)
+    d = lm.Detector(color_only=False)
+    cuts = sorted(set(int(v) for v in rng.integers(40, len(text), 60)))
+    for k, cut in enumerate(cuts):
+        p = tmp_path / ("t%d.yml" % k)
+        p.write_text(text[:cut])
+        e = lm.Detector(color_only=False)
+        try:
+            e.load_yaml(p)
+        except lm.LinemodError:
+            pass
+        e.close()
+    for k in range(40):
+        b = bytearray(text.encode())
+        for pos in rng.integers(0, len(b), 8):
+            b[pos] = int(rng.integers(32, 127))
+        p = tmp_path / ("g%d.yml" % k)
+        p.write_bytes(bytes(b))
+        e = lm.Detector(color_only=False)
+        try:
+            e.load_yaml(p)
+        except lm.LinemodError:
+            pass
+        e.close()
+    (tmp_path / "empty.yml").write_text("")
+    with pytest.raises(lm.LinemodError):
+        d.load_yaml(tmp_path / "empty.yml")
+    (tmp_path / "notgz.yml.gz").write_bytes(b"\x1f\x8b\x08\x00garbage")
+    with pytest.raises(lm.LinemodError):
+        d.load_yaml(tmp_path / "notgz.yml.gz")
+    d.close()
