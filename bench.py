@@ -99,6 +99,18 @@ class Runner:
             if after_step is not None:
                 after_step(k)
 
+    def one_lane_profile(self, steps=10):
+        """The same launches (Bl frames each) on ONE lane, nothing running beside them: the clean per-stage and scan
+        times (outside the timed region; reported next to the numbers of the overlapped run)."""
+        det = self.det
+        det.set_profiling(True)
+        for _ in range(steps):
+            det.match_begin(0, 0, self.Bl, self.args.threshold, 0)
+            det.match_end(0, CAP, out=self.views[0][0][0], counts=self.views[0][0][1])
+        prof = det.get_profile()
+        det.set_profiling(False)
+        return prof
+
     def report(self):
         prof = self.det.get_profile()
         return {"prof": prof, "scan_load_bytes": self.det.scan_load_bytes(0), "Bl": self.Bl, "NL": self.NL,
@@ -297,9 +309,11 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     merged = state["merged"]
+    one_lane = None
     if runner is not None:
         rep = runner.report()
         det.set_profiling(False)
+        one_lane = runner.one_lane_profile()
     else:
         worker.send(b"REPT")
         rep = json.loads(worker.recv(b"REPT").decode())
@@ -332,6 +346,17 @@ def main():
                         "algorithmic bytes are served by the L2s (on_chip: what the vector loads really request vs "
                         "the guide's 34.5 TB/s aggregate L2 rate); HBM traffic is ~1% of them (see DESIGN.md)"}
     stage_us_per_frame = [round(v / max(prof["frames"], 1), 2) for v in prof["stage_us"]]
+    if one_lane is not None and one_lane["launches"]:
+        ol_us = one_lane["stage_us"][1] / one_lane["launches"]
+        ol_bytes = one_lane["scan_bytes"] / one_lane["launches"]
+        roofline["one_lane"] = {
+            "avg_launch_us": round(ol_us, 2), "achieved": round(ol_bytes / (ol_us * 1e-6) / 1e9, 1),
+            "frac": round(ol_bytes / (ol_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "on_chip_achieved": round(l2_bytes / (ol_us * 1e-6) / 1e9, 1),
+            "on_chip_frac": round(l2_bytes / (ol_us * 1e-6) / 1e9 / L2_PEAK_GBS, 4),
+            "stage_us_per_frame": dict(zip(["preprocess", "scan", "refine", "sort"],
+                                           [round(v / max(one_lane["frames"], 1), 2) for v in one_lane["stage_us"]])),
+            "note": "same launches on one lane with nothing running beside them, 10 steps after the timed region"}
 
     result = None
     if rank == 0:
