@@ -631,6 +631,7 @@ void lm_destroy(lm_detector* d) {
 }
 
 int lm_set_similarity_lut(lm_detector* d, const uint8_t lut[256]) {
+    if (d && (d->lanes[0].busy || d->lanes[1].busy)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (!d || !lut) return fail(LM_ERR_INVALID, "null argument");
     for (int i = 0; i < 256; ++i) if (lut[i] > 4) return fail(LM_ERR_INVALID, "similarity LUT entries must be <= 4 (63*4 must fit a byte)");
     // an empty spread value must score 0: reads past a linear memory land in zero padding (upstream: undefined)
@@ -638,6 +639,7 @@ int lm_set_similarity_lut(lm_detector* d, const uint8_t lut[256]) {
     std::memcpy(d->sim_lut, lut, 256); d->luts_dirty = true; return LM_OK;
 }
 int lm_set_normal_lut(lm_detector* d, const uint8_t lut[8000]) {
+    if (d && (d->lanes[0].busy || d->lanes[1].busy)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (!d || !lut) return fail(LM_ERR_INVALID, "null argument");
     std::memcpy(d->normal_lut, lut, 8000); d->luts_dirty = true; d->lut_onehot = -1; return LM_OK;
 }
@@ -666,6 +668,7 @@ int lm_pyramid_levels(const lm_detector* d) { return d ? d->cfg.pyramid_levels :
 
 int lm_add_class(lm_detector* d, const char* class_id, int n_templates, const lm_template_desc* descs,
                  const lm_feature* features, int* class_idx_out) {
+    if (d && (d->lanes[0].busy || d->lanes[1].busy)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (!d || !class_id || n_templates < 0 || (n_templates && (!descs || !features))) return fail(LM_ERR_INVALID, "null argument");
     std::string err;
     int ci = d->bank.add_class(class_id, n_templates, descs, features, d->cfg.pyramid_levels, d->cfg.num_modalities, err);
@@ -677,6 +680,7 @@ int lm_add_class(lm_detector* d, const char* class_id, int n_templates, const lm
 
 int lm_add_template(lm_detector* d, const char* class_id, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
                     size_t depth_stride, const uint8_t* mask, size_t mask_stride, int* template_id_out, lm_rect* bbox_out) {
+    if (d && (d->lanes[0].busy || d->lanes[1].busy)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (template_id_out) *template_id_out = -1;
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
@@ -952,6 +956,7 @@ int lm_save_bank(const lm_detector* d, const char* path) {
     return LM_OK;
 }
 int lm_load_bank(lm_detector* d, const char* path) {
+    if (d && (d->lanes[0].busy || d->lanes[1].busy)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (!d || !path) return fail(LM_ERR_INVALID, "null argument");
     std::string err;
     if (!lmh::load_bank(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
@@ -966,6 +971,7 @@ int lm_save_yaml(const lm_detector* d, const char* path) {
     return LM_OK;
 }
 int lm_load_yaml(lm_detector* d, const char* path) {
+    if (d && (d->lanes[0].busy || d->lanes[1].busy)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (!d || !path) return fail(LM_ERR_INVALID, "null argument");
     std::string err;
     if (!lmy::load_templates_yaml(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
