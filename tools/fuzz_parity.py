@@ -1,0 +1,81 @@
+"""Scratch fuzzer (not in the test-suite): stage kernels and whole matches against the oracle on random shapes and
+contents.  usage: python tools/fuzz_parity.py [seconds] [seed]"""
+import importlib, sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+lm = importlib.import_module("line-mod-pipeline_amd")
+synth = importlib.import_module("line-mod-pipeline_amd.synth")
+from oracle import oracle as orc
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+det = lm.Detector(color_only=False)
+t0 = time.time()
+n_stage = n_match = 0
+
+
+def rand_bgr(h, w):
+    k = rng.integers(0, 4)
+    if k == 0:
+        return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if k == 1:   # blocks with sharp edges
+        b = rng.integers(0, 256, ((h + 7) // 8, (w + 7) // 8, 3), dtype=np.uint8)
+        return np.ascontiguousarray(np.kron(b, np.ones((8, 8, 1), np.uint8))[:h, :w])
+    if k == 2:   # extremes
+        return (rng.integers(0, 2, (h, w, 3)) * 255).astype(np.uint8)
+    f, _ = synth.make_frame(max(w, 64), max(h, 64), seed=int(rng.integers(1 << 30)))
+    return np.ascontiguousarray(f[:h, :w])
+
+
+def rand_depth(h, w):
+    k = rng.integers(0, 3)
+    if k == 0:
+        return rng.integers(0, 2600, (h, w)).astype(np.uint16)
+    if k == 1:
+        return (600 + 49 * rng.integers(0, 3, (h, w))).astype(np.uint16)
+    _, d = synth.make_frame(max(w, 64), max(h, 64), seed=int(rng.integers(1 << 30)))
+    return np.ascontiguousarray(d[:h, :w])
+
+
+while time.time() - t0 < budget * 0.5:
+    w = int(rng.choice([16, 32, 48, 64, 80, 96, 160, 320, 640, 24, 40, 56, 37, 53, 70]))
+    h = int(rng.integers(8, 130))
+    bgr = rand_bgr(h, w)
+    thr = float(rng.choice([10.0, 0.0, 30.0, 200.0]))
+    assert np.array_equal(det.stage_color_quantize(bgr, thr), orc.color_quantize(bgr, thr)), ("colour", h, w, thr)
+    if h % 2 == 0 and w % 2 == 0 and h >= 4:
+        assert np.array_equal(det.stage_pyrdown(bgr), orc.pyrdown(bgr)), ("pyrdown", h, w)
+    dep = rand_depth(h, w)
+    assert np.array_equal(det.stage_depth_quantize(dep), orc.depth_quantize(dep)), ("depth", h, w)
+    n_stage += 1
+det.close()
+
+while time.time() - t0 < budget:
+    color_only = bool(rng.integers(0, 2))
+    T = [[5, 8], [2, 8], [4, 4], [8, 8]][int(rng.integers(0, 4))] if not color_only else [[2, 8], [4, 8], [2, 4]][int(rng.integers(0, 3))]
+    unit = int(np.lcm.reduce([T[0], 2 * T[1], 8]))
+    w, h = unit * int(rng.integers(1, 1 + 640 // unit)), unit * int(rng.integers(1, 1 + 480 // unit))
+    w, h = max(w, 4 * unit), max(h, 4 * unit)
+    try:
+        d = lm.Detector(lm.default_config(color_only=color_only, width=w, height=h, T=T, flags=int(rng.integers(0, 2))))
+    except lm.LinemodError:
+        continue
+    o = orc.Detector(color_only=color_only, T=T)
+    bgr, depth = synth.make_frame(w, h, seed=int(rng.integers(1 << 30)))
+    o.prepare(bgr, None if color_only else depth)
+    M = 1 if color_only else 2
+    q = {(l, m): o.stage(0, l, m).reshape(h >> l, w >> l) for l in range(2) for m in range(M)}
+    n = int(rng.integers(5, 120))
+    try:
+        descs, feats, _ = synth.make_bank(n, M, 2, seed=int(rng.integers(1 << 30)), quantized=q, crop_fraction=0.3,
+                                          frame_size=(w, h), T0=T[0])
+    except Exception:
+        d.close(); continue
+    d.add_class("c", descs, feats); o.add_class("c", descs, feats)
+    thr = float(rng.choice([60.0, 75.0, 85.0, 40.0]))
+    got = d.match(bgr, None if color_only else depth, thr, cap=1 << 18)
+    exp = o.match(bgr, None if color_only else depth, thr, threads=8, cap=1 << 18)
+    assert got.tobytes() == exp.tobytes(), ("match", color_only, T, w, h, n, thr, len(got), len(exp))
+    d.close()
+    n_match += 1
+print("fuzz ok: %d stage rounds, %d whole matches in %.0f s" % (n_stage, n_match, time.time() - t0))
