@@ -1,5 +1,5 @@
-"""Scratch fuzzer (not in the test-suite): stage kernels and whole matches against the oracle on random shapes and
-contents.  usage: python tools/fuzz_parity.py [seconds] [seed]"""
+"""Fuzzer (kept under tests/ because it drives the oracle; not collected by pytest): stage kernels and whole matches against the oracle on random shapes and
+contents.  usage: python tests/fuzz_parity.py [seconds] [seed]"""
 import importlib, sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

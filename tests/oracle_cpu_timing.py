@@ -1,3 +1,4 @@
+"""Stand-alone timing of the CPU oracle on the bench workload (kept under tests/: it drives the oracle; not collected by pytest)."""
 import sys, time, importlib, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
