@@ -88,6 +88,8 @@ struct lm_detector {
     int* d_raw_thr = nullptr;
     int* h_raw_thr = nullptr;
     float raw_thr_for = -1.0f;
+    u32* d_plan = nullptr;        // k_refine_plan output, one per lane: [8][plan_stride_cap] + [8]
+    int plan_stride_cap = 0;
     u64* d_resp_tab = nullptr;
     u32* d_sim_lut = nullptr;
     u8* d_normal_lut = nullptr;
@@ -178,6 +180,8 @@ int ensure_device(lm_detector* d) {
     std::memset(d->host_blocks, 0, d->host_stride * S);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_raw_thr), 128 * sizeof(int)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d->h_raw_thr), 128 * sizeof(int)));
+    d->plan_stride_cap = std::max(S / 8 * 2, 2);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_plan), 2 * (8 * (size_t)d->plan_stride_cap + 8) * sizeof(u32)));
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     for (auto& ev : d->ev) HIP_TRY(hipEventCreate(&ev));
     d->slots.assign(S, Slot());
@@ -335,6 +339,7 @@ LmRefineArgs make_refine_args(lm_detector* d, int first, int level, float thresh
     a.cand_cap = d->max_cand; a.match_cap = d->max_match;
     a.threshold = threshold;
     a.t_global = d->d_t_global; a.t_class = d->d_t_class;
+    a.plan = nullptr; a.plan_cap = 0;
     return a;
 }
 
@@ -370,7 +375,18 @@ int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, Item
     if (L == 1) {
         lmk_emit_unrefined(d->stream, make_refine_args(d, first, 0, threshold), n);
     } else {
-        for (int l = L - 2; l >= 0; --l) lmk_refine(d->stream, make_refine_args(d, first, l, threshold), l == 0, n);
+        // 8+ slots: balance the slots over the XCDs by their candidate counts (one plan per lane)
+        u32* plan = nullptr;
+        const int plan_cap = n / 8;          // every XCD gets exactly its share of slots, the heavy ones spread out
+        if ((n % 8) == 0 && n <= 1024 && d->d_plan) {
+            plan = d->d_plan + (size_t)d->active * (8 * (size_t)d->plan_stride_cap + 8);
+            lmk_refine_plan(d->stream, make_refine_args(d, first, L - 2, threshold), n, plan, plan_cap);
+        }
+        for (int l = L - 2; l >= 0; --l) {
+            LmRefineArgs ra = make_refine_args(d, first, l, threshold);
+            ra.plan = plan; ra.plan_cap = plan_cap;
+            lmk_refine(d->stream, ra, l == 0, n);
+        }
     }
     if (timed) HIP_TRY(hipEventRecord(d->ev[3], d->stream));
     lmk_sort_unique(d->stream, make_sort_args(d, first), n);
@@ -613,7 +629,7 @@ void lm_destroy(lm_detector* d) {
         hipDeviceSynchronize();
         for (Slot& s : d->slots) { hipHostFree(s.h_bgr); hipHostFree(s.h_depth); }
         hipFree(d->frame_arena); hipFree(d->aux_arena); hipHostFree(d->host_blocks);
-        hipFree(d->d_raw_thr); hipHostFree(d->h_raw_thr);
+        hipFree(d->d_raw_thr); hipHostFree(d->h_raw_thr); hipFree(d->d_plan);
         activate_lane(d, 0);
         for (auto& ev : d->ev) if (ev) hipEventDestroy(ev);
         if (d->stream) hipStreamDestroy(d->stream);

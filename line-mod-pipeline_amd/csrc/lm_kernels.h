@@ -71,8 +71,12 @@ struct LmRefineArgs {
     float threshold;
     const int* t_global;
     const int* t_class;
+    const u32* plan;         // slot -> XCD plan of k_refine_plan ([8][plan_cap] slots + [8] lengths), or nullptr
+    int plan_cap;
     int blocks_per_slot, nslots;  // filled by lmk_refine
 };
+// Balanced slot -> XCD lists for lmk_refine from the slots' candidate counts (nslots <= 1024, nslots % 8 == 0).
+void lmk_refine_plan(hipStream_t s, const LmRefineArgs& a, int nslots, u32* plan, int plan_cap);
 // a14: similarityLocal + argmax + rescore (+ threshold filter); last=true also emits sort keys.
 void lmk_refine(hipStream_t s, const LmRefineArgs& a, bool last, int nslots);
 // pyramid_levels == 1: candidates become matches unrefined.

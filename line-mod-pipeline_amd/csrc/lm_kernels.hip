@@ -1329,6 +1329,57 @@ __device__ __forceinline__ void emit_key(const LmRefineArgs& a, LmDevHeader* hdr
     }
 }
 
+// Slot -> XCD plan for k_refine.  Every slot must stay on ONE XCD (its spread memories live in that L2), but the
+// candidate counts differ a lot between frames (30 .. 1500), and the launch lasts as long as its busiest XCD
+// (fixed round-robin: max / mean = 1.35 on the bench workload).  One workgroup ranks the slots by candidate
+// count (rank sort in LDS); one thread then deals them, heaviest first, to the least loaded of the eight XCD
+// lists (cap = nslots / 8 slots each).  plan layout: [8][cap] slot numbers, then [8] list lengths.
+__global__ __launch_bounds__(1024) void k_refine_plan(const LmDevHeader* __restrict__ hdr0, size_t aux_slot_stride,
+                                                       int nslots, u32 cand_cap, int cap, u32* __restrict__ plan) {
+    __shared__ u32 cnt[1024];
+    __shared__ u32 sorted_cnt[1024], sorted_slot[1024];
+    __shared__ u32 pl[2048 + 8];
+    const int tid = threadIdx.x;
+    u32 c = 0;
+    if (tid < nslots) {
+        c = slot_ptr_s(hdr0, aux_slot_stride, (u32)tid)->cand_count;
+        if (c > cand_cap) c = cand_cap;
+        cnt[tid] = c;
+    }
+    __syncthreads();
+    if (tid < nslots) {
+        u32 rank = 0;
+#pragma unroll 8
+        for (int j = 0; j < nslots; ++j) {
+            const u32 cj = cnt[j];
+            rank += (cj > c || (cj == c && j < tid)) ? 1u : 0u;
+        }
+        sorted_cnt[rank] = c; sorted_slot[rank] = (u32)tid;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        u32 load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+        for (int r = 0; r < nslots; ++r) {
+            const u32 sc = sorted_cnt[r], ss = sorted_slot[r];   // independent of the carried state: loaded ahead
+            int best = 0;
+            u32 bl = 0xFFFFFFFFu;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const u32 lx = (int)len[x] < cap ? load[x] : 0xFFFFFFFFu;
+                if (lx < bl) { bl = lx; best = x; }
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x)
+                if (x == best) { pl[x * cap + len[x]] = ss; len[x] += 1; load[x] += sc + 8u; }   // + a little per slot
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) pl[8 * cap + x] = len[x];
+    }
+    __syncthreads();
+    for (int i = tid; i < 8 * cap + 8; i += 1024) plan[i] = pl[i];
+}
+
 template <bool LAST>
 __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
     // response of orientation o to spread byte v = max(LUT_lo[o][v & 15], LUT_hi[o][v >> 4]): 8 x 256 bytes in LDS,
@@ -1336,6 +1387,20 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
     // v_perm lookups and a byte max (the kernel was VALU-bound on those)
     __shared__ u8 resp[8][256];
     const int lane = threadIdx.x & 63;
+    u32 slot, tile;
+    if (a.plan) {   // block b runs on XCD b % 8 (see xcd_slot_tile): take the idx-th slot of that XCD's list
+        const u32 x = blockIdx.x & 7u, kk = blockIdx.x >> 3, idx = kk / (u32)a.blocks_per_slot;
+        if (idx >= a.plan[(size_t)8 * a.plan_cap + x]) return;
+        slot = a.plan[(size_t)x * a.plan_cap + idx];
+        tile = kk - idx * (u32)a.blocks_per_slot;
+    } else {
+        xcd_slot_tile((u32)a.blocks_per_slot, (u32)a.nslots, slot, tile);
+    }
+    {   // nothing to do for this workgroup: leave before building the table
+        u32 n0 = slot_ptr_s(a.hdr, a.aux_slot_stride, slot)->cand_count;
+        if (n0 > a.cand_cap) n0 = a.cand_cap;
+        if (tile * 4u >= n0) return;
+    }
     {
         const u8* sl = reinterpret_cast<const u8*>(a.sim_lut);   // [ori][lo 16 B | hi 16 B]
         const int v = threadIdx.x;
@@ -1346,8 +1411,6 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
         }
     }
     __syncthreads();
-    u32 slot, tile;
-    xcd_slot_tile((u32)a.blocks_per_slot, (u32)a.nslots, slot, tile);
     const u32 wave0 = (u32)__builtin_amdgcn_readfirstlane((int)((tile * 256u + threadIdx.x) >> 6));
     const u32 nwaves = (u32)a.blocks_per_slot * 4u;
     LmDevHeader* hdr = slot_ptr_s(a.hdr, a.aux_slot_stride, slot);
@@ -1725,12 +1788,17 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
 #undef SCAN_LAUNCH
 }
 
+void lmk_refine_plan(hipStream_t s, const LmRefineArgs& a, int nslots, u32* plan, int plan_cap) {
+    hipLaunchKernelGGL(k_refine_plan, dim3(1), dim3(1024), 0, s, a.hdr, a.aux_slot_stride, nslots, a.cand_cap, plan_cap, plan);
+}
+
 void lmk_refine(hipStream_t s, const LmRefineArgs& a_in, bool last, int nslots) {
     LmRefineArgs a = a_in;
     // persistent waves stride over the slot's candidate list; with the XCD-affine mapping one slot runs on one
     // XCD (32 CUs x 32 waves), so 256 blocks = 1024 waves per slot fill it
     a.blocks_per_slot = 256; a.nslots = nslots;
-    dim3 grid((unsigned)(a.blocks_per_slot * nslots), 1, 1);
+    // with a plan XCD x works through the plan_cap = nslots / 8 slots of its list
+    dim3 grid(a.plan ? (unsigned)(8 * a.plan_cap * a.blocks_per_slot) : (unsigned)(a.blocks_per_slot * nslots), 1, 1);
     if (last) hipLaunchKernelGGL(k_refine<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_refine<false>, grid, dim3(256), 0, s, a);
 }
