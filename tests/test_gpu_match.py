@@ -312,3 +312,26 @@ def test_config5_batch_1280x960_multi_object(lm, orc, synth):
         for i in range(3):
             assert_matches_equal(o1[i, :c1[i]], exp[1 + i])
     d.close()
+
+
+def test_batch_of_8_crowded_frames(lm, orc, synth):
+    """Eight slots = the XCD-affine paths (k_refine_plan included) with very uneven, large candidate lists:
+    a low threshold floods some frames, one slot holds a blank frame with no candidate at all."""
+    d, o = _pair(lm, orc, True, frame_slots=8)
+    frames = [synth.make_frame(640, 480, seed=900 + i)[0] for i in range(8)]
+    frames[5] = np.full((480, 640, 3), 127, np.uint8)
+    o.prepare(frames[0], None)
+    q = {(l, 0): o.stage(0, l, 0).reshape(480 >> l, 640 >> l) for l in range(2)}
+    descs, feats, _ = synth.make_bank(60, 1, 2, seed=77, quantized=q, crop_fraction=0.5, T0=d.get_T(0))
+    d.add_class("c", descs, feats); o.add_class("c", descs, feats)
+    for i, b in enumerate(frames):
+        d.upload_frame(i, b, None)
+    for thr in (35.0, 70.0):
+        out, counts = d.match_batch(8, thr, cap_per_frame=1 << 15)
+        cands = [d.last_counts(i)[0] for i in range(8)]
+        assert cands[5] == 0 and counts[5] == 0
+        assert max(cands) > 500 or thr > 50
+        for i in (0, 3, 5, 7):
+            exp = o.match(frames[i], None, thr, threads=8, cap=1 << 18)
+            assert_matches_equal(out[i, :counts[i]], exp)
+    d.close()
