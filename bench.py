@@ -275,9 +275,9 @@ def main():
     state = {"merged": None}
 
     def run_steps(n):
-        """One GPU: the matcher's own loop.  N > 1: the worker runs the steps; this process gathers + merges step k
-        (two small collectives + lm_merge_batch) as soon as the worker reports it, while the GPU already works on
-        step k + 1, and hands the result buffer back."""
+        """One GPU: the matcher's own loop.  N > 1: the worker runs the steps; this process gathers step k's lists of
+        every shard (two small collectives) as soon as the worker reports it and merges the frames it owns
+        (lm_merge_frames; the ranks share the merge by frame), while the GPU already works on step k + 1."""
         if n <= 0:
             return
         if runner is not None:
@@ -285,7 +285,7 @@ def main():
         worker.send(b"RUN_", struct.pack("<i", n))
         for _ in range(n):
             _, counts, packed = worker.recv_step(lm.MATCH_DTYPE)
-            state["merged"] = gather.gather_merge_packed(packed, counts)
+            state["merged"] = gather.gather_merge_packed(packed, counts, owned_only=True)
         worker.recv(b"REND")
 
     def fence():
@@ -327,7 +327,8 @@ def main():
     n_total = args.templates * world
     frames_done = B * args.steps
     fps = frames_done / dt
-    n_matches0 = rep["matches0"] if merged is None else len(merged[0])
+    # N > 1: merged = (first owned frame, merged lists of the frames this rank owns); frame 0 belongs to rank 0
+    n_matches0 = rep["matches0"] if merged is None else (len(merged[1][0]) if merged[1] else 0)
 
     # ---- roofline of the dominant kernel (similarity scan): algorithmic bytes / HIP-event time
     scan_us = prof["stage_us"][1] / max(prof["launches"], 1)

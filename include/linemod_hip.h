@@ -165,6 +165,10 @@ int lm_pack_matches(const lm_match_t* recs, size_t stride, const int32_t* counts
                     size_t cap, size_t* n_out);
 int lm_merge_batch(const lm_match_t* packed, size_t rank_stride, const int32_t* counts, int n_ranks, int n_frames,
                    lm_match_t* out, size_t cap, int32_t* out_counts, size_t* n_out);
+/* The same for the frames [frame_lo, frame_hi) only (out_counts: frame_hi - frame_lo entries): with R ranks each rank
+ * merges the frames it owns, so the host work of the exchange does not grow with R. */
+int lm_merge_frames(const lm_match_t* packed, size_t rank_stride, const int32_t* counts, int n_ranks, int n_frames,
+                    int frame_lo, int frame_hi, lm_match_t* out, size_t cap, int32_t* out_counts, size_t* n_out);
 
 /* Template-bank persistence (Detector::write/writeClass/read/readClass, HighLevelLinemod.cpp:260,267,294,299):
  * own compact binary format, see DESIGN.md. */

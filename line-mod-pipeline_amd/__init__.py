@@ -57,7 +57,7 @@ EXPORTS = [
     "lm_prepare_slot", "lm_debug_read", "lm_stage_scan", "lm_time_scan", "lm_time_stages", "lm_set_scan_variant",
     "lm_last_counts", "lm_set_profiling", "lm_get_profile", "lm_scan_load_bytes",
     "lm_save_yaml", "lm_load_yaml", "lm_yaml_numbers", "lm_yaml_string", "lm_pack_matches", "lm_merge_batch",
-    "lm_match_begin", "lm_match_end", "lm_synchronize",
+    "lm_match_begin", "lm_match_end", "lm_synchronize", "lm_merge_frames",
 ]
 
 _lib = None
@@ -103,6 +103,7 @@ def load_library(path=None):
     lib.lm_match_end.argtypes = [vp, i, vp, sz, vp]
     lib.lm_pack_matches.argtypes = [vp, sz, vp, i, vp, sz, C.POINTER(sz)]
     lib.lm_merge_batch.argtypes = [vp, sz, vp, i, i, vp, sz, vp, C.POINTER(sz)]
+    lib.lm_merge_frames.argtypes = [vp, sz, vp, i, i, i, i, vp, sz, vp, C.POINTER(sz)]
     lib.lm_merge_matches.argtypes = [vp, vp, i, sz, vp, sz, C.POINTER(sz)]
     lib.lm_save_bank.argtypes = [vp, C.c_char_p]
     lib.lm_load_bank.argtypes = [vp, C.c_char_p]
@@ -182,17 +183,19 @@ def pack_matches(records, counts):
     return out
 
 
-def merge_batch(packed, counts):
-    """packed: [R, stride] MATCH_DTYPE (rank r's frames back to back), counts: [R, B] -> (merged packed, counts[B])
-    (lm_merge_batch: per frame R-way merge + adjacent-unique)."""
+def merge_batch(packed, counts, frame_lo=0, frame_hi=None):
+    """packed: [R, stride] MATCH_DTYPE (rank r's frames back to back), counts: [R, B] -> (merged packed, counts) of the
+    frames [frame_lo, frame_hi) (default: all; lm_merge_frames: per frame R-way merge + adjacent-unique)."""
     lib = load_library()
     packed = np.ascontiguousarray(packed)
     counts = _c(counts, np.int32)
     R, B = counts.shape
-    out = np.zeros(int(counts.sum()), MATCH_DTYPE)
-    oc = np.zeros(B, np.int32)
+    frame_hi = B if frame_hi is None else frame_hi
+    out = np.zeros(int(counts[:, frame_lo:frame_hi].sum()), MATCH_DTYPE)
+    oc = np.zeros(frame_hi - frame_lo, np.int32)
     n = C.c_size_t()
-    rc = lib.lm_merge_batch(_ptr(packed), packed.shape[1], _ptr(counts), R, B, _ptr(out), out.size, _ptr(oc), C.byref(n))
+    rc = lib.lm_merge_frames(_ptr(packed), packed.shape[1], _ptr(counts), R, B, frame_lo, frame_hi, _ptr(out), out.size,
+                             _ptr(oc), C.byref(n))
     if rc:
         raise LinemodError(rc, lib.lm_last_error().decode())
     return out[:n.value], oc

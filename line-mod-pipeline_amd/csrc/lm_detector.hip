@@ -911,10 +911,19 @@ int lm_pack_matches(const lm_match_t* recs, size_t stride, const int32_t* counts
 // threads; output packed the same way with out_counts[i].
 int lm_merge_batch(const lm_match_t* packed, size_t rank_stride, const int32_t* counts, int n_ranks, int n_frames,
                    lm_match_t* out, size_t cap, int32_t* out_counts, size_t* n_out) {
+    return lm_merge_frames(packed, rank_stride, counts, n_ranks, n_frames, 0, n_frames, out, cap, out_counts, n_out);
+}
+
+// Only the frames [frame_lo, frame_hi) of the batch: the ranks share the merge work by frame (rank r merges the
+// frames it owns; every rank still holds the gathered lists of all frames).  out_counts has frame_hi - frame_lo entries.
+int lm_merge_frames(const lm_match_t* packed, size_t rank_stride, const int32_t* counts, int n_ranks, int n_frames,
+                    int frame_lo, int frame_hi, lm_match_t* out, size_t cap, int32_t* out_counts, size_t* n_out) {
     if (!packed || !counts || !out_counts || n_ranks <= 0 || n_frames < 0) return fail(LM_ERR_INVALID, "bad argument");
+    if (frame_lo < 0 || frame_hi < frame_lo || frame_hi > n_frames) return fail(LM_ERR_INVALID, "bad frame range");
     const size_t R = (size_t)n_ranks, F = (size_t)n_frames;
+    const size_t lo = (size_t)frame_lo, hi = (size_t)frame_hi, Fo = hi - lo;
     std::vector<size_t> start(R * F);      // start of (rank, frame) inside the rank's run
-    std::vector<size_t> bound(F + 1, 0);   // upper bound of the merged output before unique
+    std::vector<size_t> bound(Fo + 1, 0);  // upper bound of the merged output of the owned frames before unique
     for (size_t r = 0; r < R; ++r) {
         size_t pos = 0;
         for (size_t i = 0; i < F; ++i) {
@@ -922,15 +931,16 @@ int lm_merge_batch(const lm_match_t* packed, size_t rank_stride, const int32_t* 
             if (c < 0) return fail(LM_ERR_INVALID, "negative count");
             start[r * F + i] = pos;
             pos += (size_t)c;
-            bound[i + 1] += (size_t)c;
+            if (i >= lo && i < hi) bound[i - lo + 1] += (size_t)c;
         }
         if (pos > rank_stride) return fail(LM_ERR_INVALID, "counts exceed rank_stride");
     }
-    for (size_t i = 0; i < F; ++i) bound[i + 1] += bound[i];
-    std::vector<lm_match_t> tmp(bound[F]);
-    auto work = [&](size_t lo, size_t hi) {
+    for (size_t i = 0; i < Fo; ++i) bound[i + 1] += bound[i];
+    std::vector<lm_match_t> tmp(bound[Fo]);
+    auto work = [&](size_t a0, size_t a1) {
         std::vector<lm_match_t> a, b;
-        for (size_t i = lo; i < hi; ++i) {
+        for (size_t k = a0; k < a1; ++k) {
+            const size_t i = lo + k;
             a.clear();
             for (size_t r = 0; r < R; ++r) {
                 const lm_match_t* src = packed + r * rank_stride + start[r * F + i];
@@ -940,24 +950,24 @@ int lm_merge_batch(const lm_match_t* packed, size_t rank_stride, const int32_t* 
                 a.swap(b);
             }
             a.erase(std::unique(a.begin(), a.end(), lmh::match_eq), a.end());
-            std::copy(a.begin(), a.end(), tmp.begin() + (ptrdiff_t)bound[i]);
-            out_counts[i] = (int32_t)a.size();
+            std::copy(a.begin(), a.end(), tmp.begin() + (ptrdiff_t)bound[k]);
+            out_counts[k] = (int32_t)a.size();
         }
     };
-    const size_t nthreads = std::min<size_t>(F >= 16 ? 4 : 1, std::max(1u, std::thread::hardware_concurrency()));
-    if (nthreads <= 1) work(0, F);
+    const size_t nthreads = std::min<size_t>(bound[Fo] >= 50000 ? 4 : 1, std::max(1u, std::thread::hardware_concurrency()));
+    if (nthreads <= 1) work(0, Fo);
     else {
         std::vector<std::thread> th;
-        for (size_t t = 0; t < nthreads; ++t) th.emplace_back(work, F * t / nthreads, F * (t + 1) / nthreads);
+        for (size_t t = 0; t < nthreads; ++t) th.emplace_back(work, Fo * t / nthreads, Fo * (t + 1) / nthreads);
         for (auto& x : th) x.join();
     }
     size_t total = 0;
-    for (size_t i = 0; i < F; ++i) total += (size_t)out_counts[i];
+    for (size_t i = 0; i < Fo; ++i) total += (size_t)out_counts[i];
     if (n_out) *n_out = total;
     if (out) {
         if (total > cap) return fail(LM_ERR_OVERFLOW, "output buffer too small");
         size_t pos = 0;
-        for (size_t i = 0; i < F; ++i) {
+        for (size_t i = 0; i < Fo; ++i) {
             std::memcpy(out + pos, tmp.data() + bound[i], (size_t)out_counts[i] * sizeof(lm_match_t));
             pos += (size_t)out_counts[i];
         }

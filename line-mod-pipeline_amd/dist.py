@@ -80,8 +80,14 @@ class ShardGather:
             return [records[i, :counts[i]].copy() for i in range(B)]
         return self.gather_merge_packed(self._pack(records, counts), counts)
 
-    def gather_merge_packed(self, packed, counts):
-        """The same for lists that are already packed back to back (lm_pack_matches layout)."""
+    def owned_frames(self, B):
+        """Frames of a B-frame batch whose merge this rank does (contiguous ranges, like the template shards)."""
+        return B * self.rank // self.world, B * (self.rank + 1) // self.world
+
+    def gather_merge_packed(self, packed, counts, owned_only=False):
+        """The same for lists that are already packed back to back (lm_pack_matches layout).  owned_only: every
+        rank still receives all lists, but merges only the frames it owns (owned_frames) and returns
+        (first_frame, lists): the host work of the exchange then does not grow with the number of ranks."""
         B = len(counts)
         counts = np.array(counts, dtype=np.int32)            # writable copy (torch.from_numpy)
         if int(counts.max(initial=0)) > self.cap:
@@ -89,7 +95,9 @@ class ShardGather:
                                 "(SURVEY.md 8e: K must cover all matches)" % (int(counts.max()), self.cap))
         if self.world == 1:
             ends = np.cumsum(counts)
-            return [packed[e - c:e].copy() for e, c in zip(ends, counts)]
+            lists = [packed[e - c:e].copy() for e, c in zip(ends, counts)]
+            return (0, lists) if owned_only else lists
+        f0, f1 = self.owned_frames(B) if owned_only else (0, B)
         t = self.torch
         # 1. counts of every rank
         csend, crecv = self._count_buffers(B)
@@ -105,14 +113,15 @@ class ShardGather:
         allr = rrecv.cpu().numpy().view(MATCH_DTYPE).reshape(self.world, stride)
         # 3. merge every frame
         if self.merge_batch_fn is not None:
-            merged, mc = self.merge_batch_fn(allr, allc)
+            merged, mc = self.merge_batch_fn(allr, allc, f0, f1) if owned_only else self.merge_batch_fn(allr, allc)
             ends = np.cumsum(mc)
-            return [merged[e - c:e] for e, c in zip(ends, mc)]
-        starts = np.cumsum(allc, axis=1) - allc
-        out = []
-        for i in range(B):
-            out.append(self.merge_fn([allr[r, starts[r, i]:starts[r, i] + allc[r, i]] for r in range(self.world)]))
-        return out
+            out = [merged[e - c:e] for e, c in zip(ends, mc)]
+        else:
+            starts = np.cumsum(allc, axis=1) - allc
+            out = []
+            for i in range(f0, f1):
+                out.append(self.merge_fn([allr[r, starts[r, i]:starts[r, i] + allc[r, i]] for r in range(self.world)]))
+        return (f0, out) if owned_only else out
 
 
 class ShardedDetector:

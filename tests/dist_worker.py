@@ -44,10 +44,16 @@ def main():
     sd = distmod.ShardedDetector(local_match, lm.merge_matches, cap=cap, pack_fn=lm.pack_matches,
                                  merge_batch_fn=lm.merge_batch)
     merged = sd.match_batch(B, thr, 0)
+    # frame-partitioned merge (what bench.py uses): this rank merges only the frames it owns
+    rec, cnt = local_match(B, thr, 0)
+    f0, owned = sd.gather.gather_merge_packed(lm.pack_matches(rec, cnt), cnt, owned_only=True)
+    ok_owned = (f0, f0 + len(owned)) == sd.gather.owned_frames(B)
+    for k, lst in enumerate(owned):
+        ok_owned &= lst.tobytes() == merged[f0 + k].tobytes()
     # and the pure-Python fallback of the same exchange
     sd2 = distmod.ShardedDetector(local_match, lm.merge_matches, cap=cap)
     merged2 = sd2.match_batch(B, thr, 0)
-    ok = True
+    ok = ok_owned
     for i in range(B):
         full = o.match(frames[i][0], frames[i][1], thr, 0)
         ok &= len(full) > 0 and merged[i].tobytes() == full.tobytes() and merged2[i].tobytes() == full.tobytes()
