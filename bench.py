@@ -57,8 +57,13 @@ class Runner:
         W, H, M, B = 640, 480, 2, args.batch
         self.B = B
         self.n_total = args.templates * world
+        flags = (lm.FLAG_BYTE_RESPONSES if args.byte_responses else 0)
+        quota = cgroup_cpus()
+        if world > 1 and quota is not None and quota < 3 * world:
+            # two processes per GPU (matcher + exchange): with fewer CPUs than that, do not spin while waiting for the GPU
+            flags |= lm.FLAG_BLOCKING_SYNC
         cfg = lm.default_config(color_only=False, width=W, height=H, device=local_rank, shard_rank=rank,
-                                shard_size=world, frame_slots=max(B, 1), flags=1 if args.byte_responses else 0)
+                                shard_size=world, frame_slots=max(B, 1), flags=flags)
         self.det = det = lm.Detector(cfg)
         # ---- workload: seeded synthetic frames + fixed-geometry bank
         self.frames = [synth.make_frame(W, H, seed=1234 + i) for i in range(B)]

@@ -69,6 +69,10 @@ typedef struct lm_config {
 /* Keep the lowest pyramid level's response memories at one byte per position (upstream's layout) instead
  * of the default two positions per byte.  Results are identical; this only selects the scan kernel. */
 #define LM_FLAG_BYTE_RESPONSES 1
+/* lm_match* / lm_match_end sleep on a blocking HIP event instead of spinning in hipStreamSynchronize: for hosts
+ * that have fewer CPUs than busy processes (several GPUs' worth of matcher + exchange processes under a small
+ * cgroup CPU quota).  Costs some wake-up latency per wait. */
+#define LM_FLAG_BLOCKING_SYNC 2
 
 typedef struct lm_detector lm_detector;
 

@@ -34,6 +34,7 @@ class Config(C.Structure):
                 ("frame_slots", C.c_int32), ("flags", C.c_int32)]
 
 FLAG_BYTE_RESPONSES = 1
+FLAG_BLOCKING_SYNC = 2
 
 
 class Rect(C.Structure):

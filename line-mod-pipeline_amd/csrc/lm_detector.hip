@@ -70,6 +70,7 @@ struct lm_detector {
     };
     Lane lanes[2];
     int active = 0;
+    hipEvent_t blocking_ev[2] = {nullptr, nullptr};   // LM_FLAG_BLOCKING_SYNC: one per lane
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<Slot> slots;
@@ -536,13 +537,27 @@ void account_profile(lm_detector* d, int n, int class_idx) {
     d->prof_frames += n;
 }
 
+// Waits for everything enqueued on the active lane's stream.  LM_FLAG_BLOCKING_SYNC: sleep on an event created with
+// hipEventBlockingSync instead of spinning in hipStreamSynchronize (for hosts with fewer CPUs than busy processes).
+int wait_stream(lm_detector* d) {
+    if (d->cfg.flags & LM_FLAG_BLOCKING_SYNC) {
+        hipEvent_t& ev = d->blocking_ev[d->active];
+        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev, d->stream));
+        HIP_TRY(hipEventSynchronize(ev));
+        return LM_OK;
+    }
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return LM_OK;
+}
+
 int run_match(lm_detector* d, int first, int n, float threshold, int class_idx) {
     if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     for (int i = 0; i < n; ++i)
         if (!d->slots[first + i].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot " + std::to_string(first + i));
     int rc;
     if ((rc = enqueue_match(d, first, n, threshold, class_idx, d->profiling))) return rc;
-    HIP_TRY(hipStreamSynchronize(d->stream));
+    if ((rc = wait_stream(d))) return rc;
     if (d->profiling) account_profile(d, n, class_idx);   // HIP events on the launch stream bracket every stage
     return LM_OK;
 }
@@ -631,6 +646,7 @@ void lm_destroy(lm_detector* d) {
         hipFree(d->frame_arena); hipFree(d->aux_arena); hipHostFree(d->host_blocks);
         hipFree(d->d_raw_thr); hipHostFree(d->h_raw_thr); hipFree(d->d_plan);
         activate_lane(d, 0);
+        for (auto& ev : d->blocking_ev) if (ev) hipEventDestroy(ev);
         for (auto& ev : d->ev) if (ev) hipEventDestroy(ev);
         if (d->stream) hipStreamDestroy(d->stream);
         lm_detector::Lane& l1 = d->lanes[1];
@@ -853,11 +869,11 @@ int lm_match_end(lm_detector* d, int lane, lm_match_t* out, size_t cap_per_frame
     if (!ln.busy) return fail(LM_ERR_INVALID, "lane has no match in flight");
     HIP_TRY(hipSetDevice(d->cfg.device));
     activate_lane(d, lane);
-    hipError_t e = hipStreamSynchronize(d->stream);
-    if (e == hipSuccess && ln.timed) account_profile(d, ln.n, ln.class_idx);
+    const int wrc = wait_stream(d);
+    if (!wrc && ln.timed) account_profile(d, ln.n, ln.class_idx);
     activate_lane(d, 0);
     ln.busy = false;
-    if (e != hipSuccess) return fail(LM_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    if (wrc) return wrc;
     int first_err = LM_OK;
     std::string first_msg;
     for (int i = 0; i < ln.n; ++i) {

@@ -72,6 +72,7 @@ def test_known_answer_via_gpu_add_template(lm, orc, frame0, color_only):
     (True, (1280, 960), 200, 75.0, 0),
     (False, (640, 480), 300, 55.0, 1),     # LM_FLAG_BYTE_RESPONSES: byte scan kernel
     (True, (640, 480), 300, 70.0, 1),
+    (False, (640, 480), 300, 80.0, 2),     # LM_FLAG_BLOCKING_SYNC: sleeps on a blocking event while waiting
 ])
 def test_synthetic_bank_parity(lm, orc, synth, color_only, size, n, thr, flags):
     """Seeded synthetic frame + bank (10 % crops of the frame so real matches exist)."""
