@@ -339,11 +339,13 @@ __global__ __launch_bounds__(256) void k_color_quantize(const u8* __restrict__ b
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
-// a1+a2  GaussianBlur 7x7 -> S (the smoothed 8-bit image).  One lane = 16 bytes of a row x CB_ROWS rows.
-// Vertical taps first, on the raw bytes as u16 pairs (8 * 255 * 72.. sums <= 65280 fit 16 bits), then
-// the horizontal taps on the 16-bit column sums of the lane's 40-byte window (bytes -12 .. +27 around the
-// block: the taps of byte p are bytes p-9, p-6, ..., p+9 whatever the channel) with the final rounding.
-// The two separable passes are exact integer sums, so their order does not matter.
+// a1+a2  GaussianBlur 7x7 -> S (the smoothed 8-bit image).  One lane = 16 bytes of a row x 2 rows.
+// Vertical taps first, on the raw bytes: the 8 source rows of the two output rows form two groups of four; a 4x4
+// byte transpose (8 v_perm_b32 per 4 columns) puts the four rows of a column into one dword and v_dot4_u32_u8
+// applies four taps at once (weights {8,28,56,72,56,28,8} split over the two groups, shifted by one row for the
+// second output row).  Then the horizontal taps on the 16-bit column sums of the lane's 40-byte window (bytes
+// -12 .. +27 around the block: the taps of byte p are bytes p-9, p-6, ..., p+9 whatever the channel) with the final
+// rounding.  The two separable passes are exact integer sums, so their order does not matter.
 #define CB_ROWS 2
 __global__ __launch_bounds__(256) void k_cblur(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
                                                 size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
@@ -357,42 +359,51 @@ __global__ __launch_bounds__(256) void k_cblur(const u8* __restrict__ bgr0, int 
     const int y0 = band * CB_ROWS;
     if (y0 >= h) return;
     const size_t pitch = (size_t)w * 3;
-    const u32 K[7] = {8, 28, 56, 72, 56, 28, 8};
-    u32 ev[CB_ROWS][10], od[CB_ROWS][10];   // column sums of output row r: bytes {4d, 4d+2} / {4d+1, 4d+3} of window dword d
+    u32 W[8][10];                                          // source row y0 - 3 + i (BORDER_REPLICATE), window dwords
 #pragma unroll
-    for (int i = 0; i < CB_ROWS + 6; ++i) {               // source row y0 - 3 + i (BORDER_REPLICATE)
+    for (int i = 0; i < 8; ++i) {
         const u8* row = bgr + (size_t)clampi(y0 - 3 + i, 0, h - 1) * pitch;
         const u32x4 c = ld16(row + 16 * b);
-        u32 W[10];
         if (b > 0) {
             const u32x4 p = ld16(row + 16 * b - 16);
-            W[0] = p[1]; W[1] = p[2]; W[2] = p[3];
+            W[i][0] = p[1]; W[i][1] = p[2]; W[i][2] = p[3];
         } else {   // bytes -12..-1 replicate pixel 0 channel-wise: [B G R B][G R B G][R B G R]
-            W[0] = __builtin_amdgcn_perm(c[0], c[0], 0x00020100u);
-            W[1] = __builtin_amdgcn_perm(c[0], c[0], 0x01000201u);
-            W[2] = __builtin_amdgcn_perm(c[0], c[0], 0x02010002u);
+            W[i][0] = __builtin_amdgcn_perm(c[0], c[0], 0x00020100u);
+            W[i][1] = __builtin_amdgcn_perm(c[0], c[0], 0x01000201u);
+            W[i][2] = __builtin_amdgcn_perm(c[0], c[0], 0x02010002u);
         }
-        W[3] = c[0]; W[4] = c[1]; W[5] = c[2]; W[6] = c[3];
+        W[i][3] = c[0]; W[i][4] = c[1]; W[i][5] = c[2]; W[i][6] = c[3];
         if (b + 1 < nblk) {
             const u32x4 n = ld16(row + 16 * b + 16);
-            W[7] = n[0]; W[8] = n[1]; W[9] = n[2];
+            W[i][7] = n[0]; W[i][8] = n[1]; W[i][9] = n[2];
         } else {   // bytes 3w.. replicate the last pixel (bytes 1..3 of the last dword): [B G R B][G R B G][R B G R]
-            W[7] = __builtin_amdgcn_perm(c[3], c[3], 0x01030201u);
-            W[8] = __builtin_amdgcn_perm(c[3], c[3], 0x02010302u);
-            W[9] = __builtin_amdgcn_perm(c[3], c[3], 0x03020103u);
-        }
-#pragma unroll
-        for (int d = 0; d < 10; ++d) {
-            const u32 e = W[d] & 0x00FF00FFu, o = (W[d] >> 8) & 0x00FF00FFu;
-#pragma unroll
-            for (int r = 0; r < CB_ROWS; ++r) {
-                const int t = i - r;                      // tap of output row r
-                if (t < 0 || t > 6) continue;
-                if (t == 0) { ev[r][d] = K[0] * e; od[r][d] = K[0] * o; }
-                else { ev[r][d] += K[t] * e; od[r][d] += K[t] * o; }
-            }
+            W[i][7] = __builtin_amdgcn_perm(c[3], c[3], 0x01030201u);
+            W[i][8] = __builtin_amdgcn_perm(c[3], c[3], 0x02010302u);
+            W[i][9] = __builtin_amdgcn_perm(c[3], c[3], 0x03020103u);
         }
     }
+    // tap weights as bytes (byte i = row i of the group): output row 0 uses rows 0..6, output row 1 rows 1..7
+    const u32 wA0 = 8u | (28u << 8) | (56u << 16) | (72u << 24), wB0 = 56u | (28u << 8) | (8u << 16);
+    const u32 wA1 = (8u << 8) | (28u << 16) | (56u << 24), wB1 = 72u | (56u << 8) | (28u << 16) | (8u << 24);
+    u32 vb[CB_ROWS][40];                                   // column sums per window byte (<= 65280)
+#pragma unroll
+    for (int d = 0; d < 10; ++d) {
+        u32 T[2][4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {                      // 4 x 4 byte transpose of rows 4g .. 4g+3, columns 4d .. 4d+3
+            const u32 r0 = W[4 * g][d], r1 = W[4 * g + 1][d], r2 = W[4 * g + 2][d], r3 = W[4 * g + 3][d];
+            const u32 x0 = __builtin_amdgcn_perm(r1, r0, 0x05010400u), x1 = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+            const u32 z0 = __builtin_amdgcn_perm(r3, r2, 0x05010400u), z1 = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+            T[g][0] = __builtin_amdgcn_perm(z0, x0, 0x05040100u); T[g][1] = __builtin_amdgcn_perm(z0, x0, 0x07060302u);
+            T[g][2] = __builtin_amdgcn_perm(z1, x1, 0x05040100u); T[g][3] = __builtin_amdgcn_perm(z1, x1, 0x07060302u);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            vb[0][4 * d + c] = __builtin_amdgcn_udot4(T[0][c], wA0, __builtin_amdgcn_udot4(T[1][c], wB0, 0u, false), false);
+            vb[1][4 * d + c] = __builtin_amdgcn_udot4(T[0][c], wA1, __builtin_amdgcn_udot4(T[1][c], wB1, 0u, false), false);
+        }
+    }
+    const u32 K[7] = {8, 28, 56, 72, 56, 28, 8};
 #pragma unroll
     for (int r = 0; r < CB_ROWS; ++r) {
         const int y = y0 + r;
@@ -404,15 +415,10 @@ __global__ __launch_bounds__(256) void k_cblur(const u8* __restrict__ bgr0, int 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 // output byte 4j + q of the block = window byte 12 + 4j + q; taps at window bytes wb - 9 .. wb + 9
-                u32 acc = 0;
+                u32 acc = 32768u;
 #pragma unroll
-                for (int t = 0; t < 7; ++t) {
-                    const int wb = 12 + 4 * j + q + 3 * t - 9;
-                    const u32 dsum = (wb & 1) ? od[r][wb >> 2] : ev[r][wb >> 2];
-                    const u32 v = (wb & 2) ? (dsum >> 16) : (dsum & 0xFFFFu);
-                    acc += K[t] * v;
-                }
-                packed |= ((acc + 32768u) >> 16) << (8 * q);
+                for (int t = 0; t < 7; ++t) acc += K[t] * vb[r][12 + 4 * j + q + 3 * t - 9];
+                packed |= (acc >> 16) << (8 * q);
             }
             o4[j] = packed;
         }
