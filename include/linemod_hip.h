@@ -60,7 +60,7 @@ typedef struct lm_config {
     int32_t device;               /* HIP device ordinal                                                      */
     int32_t shard_rank;           /* template-bank shard held by this detector: templates of every class     */
     int32_t shard_size;           /*   are split into shard_size contiguous template_id ranges (8e)          */
-    int32_t max_candidates;       /* capacity of the device candidate buffer (0 = default 1<<20)             */
+    int32_t max_candidates;       /* capacity of the device candidate buffer (0 = default 1<<18)             */
     int32_t max_matches;          /* capacity of the device match buffer     (0 = default 1<<18)             */
     int32_t frame_slots;          /* resident-frame slots for lm_match_batch (0 = default 8)                 */
     int32_t flags;                /* LM_FLAG_* (0 = defaults)                                                */
@@ -135,9 +135,31 @@ int lm_get_template(const lm_detector* det, int class_idx, int template_id, int 
 int lm_match(lm_detector* det, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
              float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 
-/* Resident-frame path used by the benchmark and by batch-of-frames serving: upload once, match many. */
+/* Resident-frame path used by the benchmark and by batch-of-frames serving: upload once, match many.
+ *
+ * Streaming input (the reference's real call pattern is one fresh camera frame per detect() call,
+ * detector.cpp:17-42 -> PoseDetection.cpp:66): uploads are ASYNCHRONOUS.  lm_upload_frame packs the (pageable,
+ * strided) source into the slot's pinned staging buffer and enqueues the H2D copies on the detector's copy stream,
+ * behind which it records the slot's "uploaded" event; it returns without waiting for the copy and without touching
+ * any compute stream.  Every lm_match_slot / lm_match_batch / lm_match_begin makes its stream wait for the uploads
+ * of the slots it reads (hipStreamWaitEvent), so
+ *     begin(lane, A);  upload(B ...);  end(lane);  begin(lane, B);  upload(A ...);  ...
+ * overlaps the transfer of step k + 1 with the compute of step k.  A slot that belongs to a match in flight cannot
+ * be uploaded to (LM_ERR_INVALID).  The source buffer may be reused as soon as lm_upload_frame returns. */
 int lm_upload_frame(lm_detector* det, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
                     size_t depth_stride);
+/* The same for a source in PINNED host memory (lm_host_alloc, hipHostMalloc, hipHostRegister): no staging copy, the
+ * DMA engine reads the caller's buffer, which therefore must stay untouched until lm_upload_wait(det, slot) returns
+ * or a match that covers the slot has been collected.  This is the path that reaches the PCIe rate. */
+int lm_upload_frame_pinned(lm_detector* det, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
+                           size_t depth_stride);
+/* Host waits until the upload of `slot` (-1: of every slot) has landed in device memory. */
+int lm_upload_wait(lm_detector* det, int slot);
+/* Pinned host memory for frame sources (hipHostMalloc); needs a HIP device. */
+int  lm_host_alloc(size_t bytes, void** out);
+void lm_host_free(void* p);
+/* Pageable sources: number of pieces the staging memcpy is cut into so that it overlaps the DMA (default 2). */
+int lm_set_stage_chunks(lm_detector* det, int chunks);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 /* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame
  * records, counts n_slots entries. */
@@ -151,7 +173,9 @@ int lm_match_batch(lm_detector* det, int n_slots, float threshold, int class_idx
  * working on disjoint slot ranges overlap each other's stages on the GPU (the scan is L1/L2-bound, the
  * preprocess passes VALU / fabric-bound) from ONE host thread:
  *     begin(0, A); begin(1, B);  loop { end(0); begin(0, A');  end(1); begin(1, B'); }
- * A lane's slots must not be uploaded to while it is busy; the synchronous entry points refuse to run then. */
+ * A lane's slots must not be uploaded to while it is busy (lm_upload_frame* refuse); uploads to the OTHER slots
+ * may be issued at any time and are ordered against the lane that later reads them by per-slot events.  The
+ * synchronous entry points refuse to run while a lane is busy. */
 int lm_match_begin(lm_detector* det, int lane, int first_slot, int n_slots, float threshold, int class_idx);
 /* hipDeviceSynchronize() on the detector's device (what torch.cuda.synchronize() is for a torch program). */
 int lm_synchronize(lm_detector* det);

@@ -59,6 +59,7 @@ EXPORTS = [
     "lm_last_counts", "lm_set_profiling", "lm_get_profile", "lm_scan_load_bytes",
     "lm_save_yaml", "lm_load_yaml", "lm_yaml_numbers", "lm_yaml_string", "lm_pack_matches", "lm_merge_batch",
     "lm_match_begin", "lm_match_end", "lm_synchronize", "lm_merge_frames",
+    "lm_upload_frame_pinned", "lm_upload_wait", "lm_host_alloc", "lm_host_free", "lm_set_stage_chunks",
 ]
 
 _lib = None
@@ -122,6 +123,20 @@ def load_library(path=None):
     lib.lm_set_profiling.argtypes = [vp, i]
     lib.lm_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int64)]
+    lib.lm_last_error.argtypes = []
+    lib.lm_version.argtypes = []
+    lib.lm_save_yaml.argtypes = [vp, C.c_char_p]
+    lib.lm_load_yaml.argtypes = [vp, C.c_char_p]
+    lib.lm_yaml_numbers.argtypes = [C.c_char_p, C.c_char_p, vp, sz, C.POINTER(sz)]
+    lib.lm_yaml_string.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, sz]
+    lib.lm_scan_load_bytes.argtypes = [vp, i, C.POINTER(C.c_double)]
+    lib.lm_synchronize.argtypes = [vp]
+    lib.lm_upload_frame_pinned.argtypes = [vp, i, vp, sz, vp, sz]
+    lib.lm_upload_wait.argtypes = [vp, i]
+    lib.lm_host_alloc.argtypes = [sz, C.POINTER(vp)]
+    lib.lm_host_free.argtypes = [vp]
+    lib.lm_host_free.restype = None
+    lib.lm_set_stage_chunks.argtypes = [vp, i]
     if path is None:
         _lib = lib
     return lib
@@ -217,6 +232,28 @@ def merge_matches(lists):
     if rc:
         raise LinemodError(rc, lib.lm_last_error().decode())
     return out[:n.value].copy()
+
+
+class PinnedBuffer:
+    """Pinned host memory from lm_host_alloc, viewed as numpy arrays (sources of Detector.upload_frame_pinned)."""
+
+    def __init__(self, nbytes):
+        self.lib = load_library()
+        p = C.c_void_p()
+        rc = self.lib.lm_host_alloc(nbytes, C.byref(p))
+        if rc:
+            raise LinemodError(rc, self.lib.lm_last_error().decode())
+        self.ptr, self.nbytes = p, nbytes
+        self._raw = (C.c_uint8 * nbytes).from_address(p.value)
+
+    def view(self, dtype, shape, offset=0):
+        return np.frombuffer(self._raw, dtype=dtype, count=int(np.prod(shape)), offset=offset).reshape(shape)
+
+    def close(self):
+        if self.ptr:
+            self._raw = None
+            self.lib.lm_host_free(self.ptr)
+            self.ptr = None
 
 
 class Detector:
@@ -365,6 +402,21 @@ class Detector:
         if bgr.shape != (self.cfg.height, self.cfg.width, 3):
             raise ValueError("frame size does not match the detector")
         self._check(self.lib.lm_upload_frame(self.h, slot, _ptr(bgr), 0, _ptr(depth), 0))
+
+    def upload_frame_pinned(self, slot, bgr, depth=None):
+        """Source arrays must live in pinned host memory (PinnedBuffer) and stay untouched until upload_wait(slot)
+        or until a match that covers the slot has been collected."""
+        if bgr.dtype != np.uint8 or not bgr.flags.c_contiguous or bgr.shape != (self.cfg.height, self.cfg.width, 3):
+            raise ValueError("pinned colour frame must be a C-contiguous uint8 [h, w, 3] array of the detector's size")
+        if depth is not None and (depth.dtype != np.uint16 or not depth.flags.c_contiguous):
+            raise ValueError("pinned depth frame must be a C-contiguous uint16 array")
+        self._check(self.lib.lm_upload_frame_pinned(self.h, slot, _ptr(bgr), 0, _ptr(depth), 0))
+
+    def upload_wait(self, slot=-1):
+        self._check(self.lib.lm_upload_wait(self.h, slot))
+
+    def set_stage_chunks(self, chunks):
+        self._check(self.lib.lm_set_stage_chunks(self.h, chunks))
 
     def match_slot(self, slot, threshold, class_idx=-1, cap=1 << 16):
         out = np.zeros(cap, MATCH_DTYPE)

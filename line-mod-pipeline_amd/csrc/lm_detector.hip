@@ -42,6 +42,10 @@ struct Slot {
     u8* h_bgr = nullptr;     // pinned upload staging
     u16* h_depth = nullptr;
     bool has_frame = false;
+    // Uploads run on the detector's copy stream: ev_up is recorded behind the slot's H2D copies, up_seq is the
+    // upload's ticket (0 = never uploaded through the copy stream).  Copies complete in ticket order.
+    hipEvent_t ev_up = nullptr;
+    unsigned long long up_seq = 0;
 };
 
 }  // namespace
@@ -67,12 +71,19 @@ struct lm_detector {
         float raw_thr_for = -1.0f;
         bool created = false, busy = false, timed = false;
         int first = 0, n = 0, class_idx = 0;
+        unsigned long long waited_seq = 0;   // newest upload ticket this lane's stream has been told to wait for
     };
     Lane lanes[2];
     int active = 0;
     hipEvent_t blocking_ev[2] = {nullptr, nullptr};   // LM_FLAG_BLOCKING_SYNC: one per lane
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // H2D copies of lm_upload_frame* go through their own stream so that the frames of step k + 1 travel while
+    // the lanes compute step k; a lane's stream waits (hipStreamWaitEvent) for the newest upload among its slots.
+    hipStream_t copy_stream = nullptr;
+    unsigned long long up_seq_next = 1, up_seq_done = 0;   // next ticket / newest ticket known to have landed
+    unsigned long long waited_seq = 0;                     // ACTIVE lane's copy of Lane::waited_seq
+    int stage_chunks = 2;                                  // pageable source: staging memcpy pipelined with the DMA
     std::vector<Slot> slots;
     // frame arena: [slot][bgr[l] | depth | quant[l][m] | lm[l]]
     u8* frame_arena = nullptr;
@@ -184,12 +195,12 @@ int ensure_device(lm_detector* d) {
     d->plan_stride_cap = std::max(S / 8 * 2, 2);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_plan), 2 * (8 * (size_t)d->plan_stride_cap + 8) * sizeof(u32)));
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     for (auto& ev : d->ev) HIP_TRY(hipEventCreate(&ev));
     d->slots.assign(S, Slot());
-    for (Slot& s : d->slots) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.h_bgr), (size_t)c.width * c.height * 3));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.h_depth), (size_t)c.width * c.height * 2));
-    }
+    for (Slot& s : d->slots) HIP_TRY(hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
+    // pinned staging for pageable sources is allocated on a slot's first staged upload (ensure_staging): a
+    // streaming server that hands over pinned frames (lm_upload_frame_pinned) never needs it
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_resp_tab), 256 * sizeof(u64)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_sim_lut), 256));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_normal_lut), 8000));
@@ -261,6 +272,8 @@ void enqueue_depth_pyramid(lm_detector* d, int first, int n) {
         lmk_nn_half(d->stream, d->quant(first, l - 1, 1), d->lw[l - 1], d->quant(first, l, 1), d->lw[l], d->lh[l],
                     d->frame_stride, n);
 }
+
+int wait_uploads(lm_detector* d, hipStream_t stream, int first, int n, unsigned long long* seq);
 
 // a3-a10 on the frames resident in slots [first, first + n).
 void enqueue_preprocess(lm_detector* d, int first, int n) {
@@ -396,11 +409,21 @@ int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, Item
     return LM_OK;
 }
 
+// The active lane's stream waits for the copy-stream uploads of the slots it is about to read.
+int enqueue_upload_wait(lm_detector* d, int first, int n) {
+    unsigned long long seq = 0;
+    int rc;
+    if ((rc = wait_uploads(d, d->stream, first, n, &seq))) return rc;
+    if (seq > d->waited_seq) d->waited_seq = seq;
+    return LM_OK;
+}
+
 int enqueue_match(lm_detector* d, int first, int n, float threshold, int class_idx, bool timed = false) {
     ItemRange r;
     int rc;
     if ((rc = item_range(d, class_idx, &r))) return rc;
     if ((rc = enqueue_threshold(d, threshold))) return rc;
+    if ((rc = enqueue_upload_wait(d, first, n))) return rc;
     if (timed) HIP_TRY(hipEventRecord(d->ev[0], d->stream));
     enqueue_preprocess(d, first, n);
     return enqueue_match_stages(d, first, n, threshold, r, timed);
@@ -458,8 +481,63 @@ int collect_slot(lm_detector* d, int slot, lm_match_t* out, size_t cap, size_t* 
     return LM_OK;
 }
 
+int ensure_staging(lm_detector* d, Slot& s) {
+    const lm_config& c = d->cfg;
+    if (!s.h_bgr) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.h_bgr), (size_t)c.width * c.height * 3));
+    if (!s.h_depth && c.num_modalities == 2)
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.h_depth), (size_t)c.width * c.height * 2));
+    return LM_OK;
+}
+
+// Host waits until the slot's last copy-stream upload has landed (its staging buffer / the caller's pinned
+// source may then be reused).  Copies complete in ticket order, so this also retires every older ticket.
+int wait_slot_upload(lm_detector* d, Slot& s) {
+    if (s.up_seq > d->up_seq_done) {
+        HIP_TRY(hipEventSynchronize(s.ev_up));
+        d->up_seq_done = s.up_seq;
+    }
+    return LM_OK;
+}
+
+// Makes `stream` wait for the uploads of slots [first, first + n): one hipStreamWaitEvent on the newest ticket
+// among them (the copy stream is in order).  Returns that ticket in *seq (0: nothing pending).
+int wait_uploads(lm_detector* d, hipStream_t stream, int first, int n, unsigned long long* seq) {
+    unsigned long long best = 0;
+    int bi = -1;
+    for (int i = first; i < first + n; ++i)
+        if (d->slots[i].up_seq > d->up_seq_done && d->slots[i].up_seq > best) { best = d->slots[i].up_seq; bi = i; }
+    if (bi >= 0) HIP_TRY(hipStreamWaitEvent(stream, d->slots[bi].ev_up, 0));
+    if (seq) *seq = best;
+    return LM_OK;
+}
+
+// rows x row_bytes from a strided host image to dense device memory.  Pageable source: rows are packed into the
+// slot's pinned staging buffer in `chunks` pieces, each followed by its own async copy, so the host memcpy of
+// piece k + 1 overlaps the DMA of piece k.  pinned: the source goes straight to the DMA engine.
+int copy_image(hipStream_t st, u8* dst, u8* staging, const u8* src, size_t stride, size_t row_bytes, int rows,
+               bool pinned, int chunks) {
+    if (pinned) {
+        if (stride == row_bytes) HIP_TRY(hipMemcpyAsync(dst, src, row_bytes * rows, hipMemcpyHostToDevice, st));
+        else HIP_TRY(hipMemcpy2DAsync(dst, row_bytes, src, stride, row_bytes, rows, hipMemcpyHostToDevice, st));
+        return LM_OK;
+    }
+    if (chunks < 1) chunks = 1;
+    for (int k = 0; k < chunks; ++k) {
+        const int r0 = (int)((long long)rows * k / chunks), r1 = (int)((long long)rows * (k + 1) / chunks);
+        if (r1 <= r0) continue;
+        if (stride == row_bytes) std::memcpy(staging + (size_t)r0 * row_bytes, src + (size_t)r0 * stride, (size_t)(r1 - r0) * row_bytes);
+        else for (int y = r0; y < r1; ++y) std::memcpy(staging + (size_t)y * row_bytes, src + (size_t)y * stride, row_bytes);
+        HIP_TRY(hipMemcpyAsync(dst + (size_t)r0 * row_bytes, staging + (size_t)r0 * row_bytes, (size_t)(r1 - r0) * row_bytes,
+                               hipMemcpyHostToDevice, st));
+    }
+    return LM_OK;
+}
+
+// Frame -> slot.  inline_stream == nullptr: the copies go to the copy stream and the slot gets an upload ticket
+// (consumers call wait_uploads); otherwise they are issued on `inline_stream` itself, in order with the kernels
+// the caller enqueues behind them (single-frame calls: no cross-stream dependency on the latency path).
 int upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
-                 size_t depth_stride) {
+                 size_t depth_stride, bool pinned = false, hipStream_t inline_stream = nullptr) {
     const lm_config& c = d->cfg;
     Slot& s = d->slots[slot];
     if (!bgr) return fail(LM_ERR_INVALID, "sources.size() != modalities.size(): colour image missing");
@@ -470,13 +548,19 @@ int upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride
     if (bgr_stride < (size_t)c.width * 3 || depth_stride < (size_t)c.width * 2) return fail(LM_ERR_INVALID, "stride smaller than a row");
     for (const lm_detector::Lane& ln : d->lanes)
         if (ln.busy && slot >= ln.first && slot < ln.first + ln.n) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
-    HIP_TRY(hipStreamSynchronize(d->stream));  // staging buffers are reused
-    for (int y = 0; y < c.height; ++y) std::memcpy(s.h_bgr + (size_t)y * c.width * 3, bgr + y * bgr_stride, (size_t)c.width * 3);
-    HIP_TRY(hipMemcpyAsync(d->bgr(slot, 0), s.h_bgr, (size_t)c.width * c.height * 3, hipMemcpyHostToDevice, d->stream));
-    if (c.num_modalities == 2) {
-        for (int y = 0; y < c.height; ++y)
-            std::memcpy(s.h_depth + (size_t)y * c.width, reinterpret_cast<const u8*>(depth) + y * depth_stride, (size_t)c.width * 2);
-        HIP_TRY(hipMemcpyAsync(d->depth(slot), s.h_depth, (size_t)c.width * c.height * 2, hipMemcpyHostToDevice, d->stream));
+    int rc;
+    // the slot's previous upload may still be reading the staging buffer (and must land before this one anyway)
+    if ((rc = wait_slot_upload(d, s))) return rc;
+    if (!pinned && (rc = ensure_staging(d, s))) return rc;
+    hipStream_t st = inline_stream ? inline_stream : d->copy_stream;
+    if ((rc = copy_image(st, d->bgr(slot, 0), s.h_bgr, bgr, bgr_stride, (size_t)c.width * 3, c.height, pinned, d->stage_chunks))) return rc;
+    if (c.num_modalities == 2 &&
+        (rc = copy_image(st, reinterpret_cast<u8*>(d->depth(slot)), reinterpret_cast<u8*>(s.h_depth),
+                         reinterpret_cast<const u8*>(depth), depth_stride, (size_t)c.width * 2, c.height, pinned, d->stage_chunks)))
+        return rc;
+    if (!inline_stream) {
+        HIP_TRY(hipEventRecord(s.ev_up, d->copy_stream));
+        s.up_seq = d->up_seq_next++;
     }
     s.has_frame = true;
     return LM_OK;
@@ -505,9 +589,11 @@ void activate_lane(lm_detector* d, int l) {
     if (d->active == l) return;
     lm_detector::Lane& cur = d->lanes[d->active];
     cur.stream = d->stream; cur.d_raw_thr = d->d_raw_thr; cur.h_raw_thr = d->h_raw_thr; cur.raw_thr_for = d->raw_thr_for;
+    cur.waited_seq = d->waited_seq;
     for (int k = 0; k < 5; ++k) cur.ev[k] = d->ev[k];
     const lm_detector::Lane& nx = d->lanes[l];
     d->stream = nx.stream; d->d_raw_thr = nx.d_raw_thr; d->h_raw_thr = nx.h_raw_thr; d->raw_thr_for = nx.raw_thr_for;
+    d->waited_seq = nx.waited_seq;
     for (int k = 0; k < 5; ++k) d->ev[k] = nx.ev[k];
     d->active = l;
 }
@@ -545,9 +631,11 @@ int wait_stream(lm_detector* d) {
         if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ev, d->stream));
         HIP_TRY(hipEventSynchronize(ev));
-        return LM_OK;
+    } else {
+        HIP_TRY(hipStreamSynchronize(d->stream));
     }
-    HIP_TRY(hipStreamSynchronize(d->stream));
+    // everything this stream was told to wait for has landed
+    if (d->waited_seq > d->up_seq_done) d->up_seq_done = d->waited_seq;
     return LM_OK;
 }
 
@@ -642,7 +730,12 @@ void lm_destroy(lm_detector* d) {
     if (d->dev_ready) {
         hipSetDevice(d->cfg.device);
         hipDeviceSynchronize();
-        for (Slot& s : d->slots) { hipHostFree(s.h_bgr); hipHostFree(s.h_depth); }
+        for (Slot& s : d->slots) {
+            if (s.h_bgr) hipHostFree(s.h_bgr);
+            if (s.h_depth) hipHostFree(s.h_depth);
+            if (s.ev_up) hipEventDestroy(s.ev_up);
+        }
+        if (d->copy_stream) hipStreamDestroy(d->copy_stream);
         hipFree(d->frame_arena); hipFree(d->aux_arena); hipHostFree(d->host_blocks);
         hipFree(d->d_raw_thr); hipHostFree(d->h_raw_thr); hipFree(d->d_plan);
         activate_lane(d, 0);
@@ -719,7 +812,7 @@ int lm_add_template(lm_detector* d, const char* class_id, const uint8_t* bgr, si
     if (!class_id) return fail(LM_ERR_INVALID, "null class id");
     const lm_config& c = d->cfg;
     const int M = c.num_modalities, L = c.pyramid_levels;
-    if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride))) return rc;
+    if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride, false, d->stream))) return rc;
     d->slots[0].has_frame = false;  // slot 0 now holds a template image, not a scene frame
     // quantise every level on the GPU, keeping the gradient magnitude this time
     size_t mag_off[LM_MAX_LEVELS], total = 0;
@@ -794,6 +887,44 @@ int lm_upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_str
     return upload_frame(d, slot, bgr, bgr_stride, depth, depth_stride);
 }
 
+int lm_upload_frame_pinned(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
+                           size_t depth_stride) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if ((rc = check_slots(d, slot, 1))) return rc;
+    return upload_frame(d, slot, bgr, bgr_stride, depth, depth_stride, true);
+}
+
+int lm_upload_wait(lm_detector* d, int slot) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if (slot < 0) {
+        HIP_TRY(hipStreamSynchronize(d->copy_stream));
+        d->up_seq_done = d->up_seq_next - 1;
+        return LM_OK;
+    }
+    if ((rc = check_slots(d, slot, 1))) return rc;
+    return wait_slot_upload(d, d->slots[slot]);
+}
+
+int lm_host_alloc(size_t bytes, void** out) {
+    if (!out || !bytes) return fail(LM_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(LM_ERR_NO_DEVICE, "no HIP device available: pinned host memory needs the HIP runtime");
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return LM_OK;
+}
+
+void lm_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int lm_set_stage_chunks(lm_detector* d, int chunks) {
+    if (!d || chunks < 1 || chunks > 64) return fail(LM_ERR_INVALID, "bad argument");
+    d->stage_chunks = chunks;
+    return LM_OK;
+}
+
 int lm_match_slot(lm_detector* d, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
@@ -808,7 +939,9 @@ int lm_match(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
     if ((rc = ensure_bank(d))) return rc;
-    if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride))) return rc;
+    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    // the copies are issued on the compute stream itself, in order with the kernels: no cross-stream hop on the latency path
+    if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride, false, d->stream))) return rc;
     if ((rc = run_match(d, 0, 1, threshold, class_idx))) return rc;
     return collect_slot(d, 0, out, cap, n_out);
 }
@@ -1138,8 +1271,9 @@ int lm_prepare_slot(lm_detector* d, int slot) {
     if ((rc = ready_for_compute(d))) return rc;
     if ((rc = check_slots(d, slot, 1))) return rc;
     if (!d->slots[slot].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
+    if ((rc = enqueue_upload_wait(d, slot, 1))) return rc;
     enqueue_preprocess(d, slot, 1);
-    HIP_TRY(hipStreamSynchronize(d->stream));
+    if ((rc = wait_stream(d))) return rc;
     HIP_TRY(hipGetLastError());
     return LM_OK;
 }

@@ -177,16 +177,21 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
     return true;
 }
 
-// SIMILARITY_LUT default: linear max(0, 4 - |ori - bit|) (layout [ori][lo 16 | hi 16]).
+// SIMILARITY_LUT default = the table cv::linemod ships (layout [ori][lo nibble 16 | hi nibble 16],
+// entry = max over the nibble's set bits of the single-bit score).  Rows 3-7 are circular in the 8 orientation
+// bins, rows 0-2 are not (orientation 0 scores 0 against bits 5-7): an upstream quirk that is part of the
+// reference's behaviour, so it is the default here; lm_set_similarity_lut replaces it.
 void default_similarity_lut(u8 lut[256]) {
-    for (int ori = 0; ori < 8; ++ori)
-        for (int half = 0; half < 2; ++half)
-            for (int v = 0; v < 16; ++v) {
-                int best = 0;
-                for (int b = 0; b < 4; ++b)
-                    if (v & (1 << b)) best = std::max(best, std::max(0, 4 - std::abs(ori - (half * 4 + b))));
-                lut[32 * ori + 16 * half + v] = (u8)best;
-            }
+    static const u8 kUpstream[256] = {
+        0, 4, 3, 4, 2, 4, 3, 4, 1, 4, 3, 4, 2, 4, 3, 4,  0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+        0, 3, 4, 4, 3, 3, 4, 4, 2, 3, 4, 4, 3, 3, 4, 4,  0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1,
+        0, 2, 3, 3, 4, 4, 4, 4, 3, 3, 3, 3, 4, 4, 4, 4,  0, 2, 1, 2, 0, 2, 1, 2, 0, 2, 1, 2, 0, 2, 1, 2,
+        0, 1, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4,  0, 3, 2, 3, 1, 3, 2, 3, 0, 3, 2, 3, 1, 3, 2, 3,
+        0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3,  0, 4, 3, 4, 2, 4, 3, 4, 1, 4, 3, 4, 2, 4, 3, 4,
+        0, 1, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2,  0, 3, 4, 4, 3, 3, 4, 4, 2, 3, 4, 4, 3, 3, 4, 4,
+        0, 2, 1, 2, 0, 2, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2,  0, 2, 3, 3, 4, 4, 4, 4, 3, 3, 3, 3, 4, 4, 4, 4,
+        0, 3, 2, 3, 1, 3, 2, 3, 0, 3, 2, 3, 1, 3, 2, 3,  0, 1, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4};
+    std::memcpy(lut, kUpstream, 256);
 }
 
 // NORMAL_LUT default (our documented rule): azimuth of the cell centre, 8 bins.

@@ -103,8 +103,9 @@ void orc_default_config(orc_config* c, int color_only) {
 }
 
 // SIMILARITY_LUT layout (A.5): [ori 0..7][low nibble 16 | high nibble 16]; entry = max over the
-// set bits of the nibble of the single-bit score.  variant 0 (default) is the linear
-// max(0, 4-|i-j|) table; 1 the circular one; 2 the mixed table printed in SURVEY.md A.5.
+// set bits of the nibble of the single-bit score.  variant 2 (the DEFAULT of orc_create) is the table
+// printed in SURVEY.md A.5, which is the one upstream's linemod.cpp ships (rows 0-2 non-circular, rows
+// 3-7 circular: an upstream quirk, reproduced); 0 is the linear max(0, 4-|i-j|) table, 1 the circular one.
 void orc_default_similarity_lut(uint8_t lut[256], int variant) {
     for (int ori = 0; ori < 8; ++ori)
         for (int half = 0; half < 2; ++half)
@@ -561,7 +562,7 @@ orc_detector* orc_create(const orc_config* cfg) {
         cfg->pyramid_levels > ORC_MAX_LEVELS) { set_err("bad config"); return nullptr; }
     orc_detector* d = new orc_detector();
     d->cfg = *cfg;
-    orc_default_similarity_lut(d->sim_lut, 0);
+    orc_default_similarity_lut(d->sim_lut, 2);
     orc_default_normal_lut(d->normal_lut);
     return d;
 }

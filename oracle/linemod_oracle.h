@@ -59,7 +59,7 @@ typedef struct orc_detector orc_detector;
 
 /* ---- tables (data parameters) ---- */
 void orc_default_config(orc_config* cfg, int color_only);
-void orc_default_similarity_lut(uint8_t lut[256], int variant);   /* 0 linear |i-j| (default), 1 circular, 2 SURVEY-recalled */
+void orc_default_similarity_lut(uint8_t lut[256], int variant);   /* 2 = upstream's table, SURVEY.md A.5 (the default of orc_create); 0 linear |i-j|, 1 circular */
 void orc_default_normal_lut(uint8_t lut[8000]);
 
 /* ---- stage functions (each one upstream helper; all buffers dense row-major) ---- */

@@ -119,7 +119,7 @@ def _c(a, dtype):
 # ---------------------------------------------------------------------------------------------
 # stage wrappers (numpy in, numpy out)
 # ---------------------------------------------------------------------------------------------
-def similarity_lut(variant=0, lib=None):
+def similarity_lut(variant=2, lib=None):
     lib = lib or load()
     out = np.zeros(256, np.uint8)
     lib.orc_default_similarity_lut(_ptr(out), variant)

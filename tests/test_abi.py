@@ -151,7 +151,7 @@ def test_add_class_validation(lm):
 
 def test_tables_agree_with_oracle_defaults(lm, orc):
     d = lm.Detector(color_only=False)
-    assert np.array_equal(d.similarity_lut(), orc.similarity_lut(0))
+    assert np.array_equal(d.similarity_lut(), orc.similarity_lut())   # both default to upstream's table
     assert np.array_equal(d.normal_lut(), orc.normal_lut())
     lut = orc.similarity_lut(1)
     d.set_similarity_lut(lut)

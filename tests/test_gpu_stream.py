@@ -1,0 +1,123 @@
+"""Streaming input path (the reference's real call pattern: a fresh camera frame per detect(), detector.cpp:17-42):
+asynchronous uploads on the detector's copy stream, ordered against the lanes by per-slot events.  Every list is
+compared with the CPU oracle's on the same frame."""
+import numpy as np
+import pytest
+
+from conftest import assert_matches_equal
+
+pytestmark = pytest.mark.gpu
+
+W, H, THR = 640, 480, 75.0
+
+
+def _setup(lm, orc, synth, n_templates=120, slots=8, n_frames=6):
+    d = lm.Detector(color_only=False, width=W, height=H, frame_slots=slots)
+    o = orc.Detector(color_only=False)
+    frames = [synth.make_frame(W, H, seed=500 + i) for i in range(n_frames)]
+    o.prepare(*frames[0])
+    q = {(l, m): o.stage(0, l, m).reshape(H >> l, W >> l) for l in range(2) for m in range(2)}
+    descs, feats, _ = synth.make_bank(n_templates, 2, 2, seed=99, quantized=q, crop_fraction=0.3, frame_size=(W, H),
+                                      T0=d.get_T(0))
+    d.add_class("c", descs, feats)
+    o.add_class("c", descs, feats)
+    exp = [o.match(b, dp, THR, threads=8) for b, dp in frames]
+    assert sum(len(e) for e in exp) > 0
+    return d, frames, exp
+
+
+def test_upload_immediately_followed_by_begin_on_lane1(lm, orc, synth):
+    """an upload into lane 1's slots directly followed by lm_match_begin(1) used to race (the copy
+    ran on lane 0's stream, the kernels on lane 1's).  Changing frames every round: a stale or half-copied frame
+    shows up as a wrong list."""
+    d, frames, exp = _setup(lm, orc, synth)
+    nf = len(frames)
+    for rnd in range(12):
+        # lane 0 keeps its stream busy with slots 0..3 while lane 1's slots 4..7 are refilled and started at once
+        ids0 = [(rnd + k) % nf for k in range(4)]
+        ids1 = [(3 * rnd + 2 * k + 1) % nf for k in range(4)]
+        for k, f in enumerate(ids0):
+            d.upload_frame(k, *frames[f])
+        d.match_begin(0, 0, 4, THR, 0)
+        for k, f in enumerate(ids1):
+            d.upload_frame(4 + k, *frames[f])
+        d.match_begin(1, 4, 4, THR, 0)
+        out0, c0 = d.match_end(0, n_slots=4)
+        out1, c1 = d.match_end(1, n_slots=4)
+        for k, f in enumerate(ids0):
+            assert_matches_equal(out0[k, :c0[k]], exp[f])
+        for k, f in enumerate(ids1):
+            assert_matches_equal(out1[k, :c1[k]], exp[f])
+    d.close()
+
+
+def test_upload_refused_for_busy_lane_and_allowed_elsewhere(lm, orc, synth):
+    d, frames, exp = _setup(lm, orc, synth, n_frames=3)
+    for k in range(8):
+        d.upload_frame(k, *frames[k % 3])
+    d.match_begin(0, 0, 4, THR, 0)
+    with pytest.raises(lm.LinemodError):
+        d.upload_frame(2, *frames[1])            # slot of the lane in flight
+    d.upload_frame(6, *frames[2])                # another slot: allowed while lane 0 computes
+    out0, c0 = d.match_end(0, n_slots=4)
+    for k in range(4):
+        assert_matches_equal(out0[k, :c0[k]], exp[k % 3])
+    got = d.match_slot(6, THR, 0)
+    assert_matches_equal(got, exp[2])
+    d.close()
+
+
+def test_double_buffered_streaming_pinned(lm, orc, synth):
+    """The serving loop of include/linemod_hip.h: while a lane computes slot range A the next frames are uploaded
+    into range B from PINNED host memory (no staging copy), then the roles swap.  Frames change every step."""
+    d, frames, exp = _setup(lm, orc, synth)
+    nf, B = len(frames), 4
+    pb = lm.PinnedBuffer(2 * B * (W * H * 3 + W * H * 2))
+    hb = [[pb.view(np.uint8, (H, W, 3), offset=(r * B + k) * W * H * 5) for k in range(B)] for r in range(2)]
+    hd = [[pb.view(np.uint16, (H, W), offset=(r * B + k) * W * H * 5 + W * H * 3) for k in range(B)] for r in range(2)]
+
+    def fill(r, step):
+        ids = [(step * B + k) % nf for k in range(B)]
+        for k, f in enumerate(ids):
+            hb[r][k][...] = frames[f][0]
+            hd[r][k][...] = frames[f][1]
+            d.upload_frame_pinned(r * B + k, hb[r][k], hd[r][k])
+        return ids
+
+    ids = {0: fill(0, 0)}
+    d.match_begin(0, 0, B, THR, 0)
+    for step in range(1, 9):
+        r = step & 1
+        ids[r] = fill(r, step)                   # overlaps the compute of the other range
+        out, cnt = d.match_end(0, n_slots=B)
+        for k, f in enumerate(ids[r ^ 1]):
+            assert_matches_equal(out[k, :cnt[k]], exp[f])
+        d.match_begin(0, r * B, B, THR, 0)
+    out, cnt = d.match_end(0, n_slots=B)
+    for k, f in enumerate(ids[8 & 1]):
+        assert_matches_equal(out[k, :cnt[k]], exp[f])
+    d.close()
+    pb.close()
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 5])
+def test_single_frame_calls_with_staging_chunks(lm, orc, synth, chunks):
+    """lm_match (host frame in, the drop-in call): the staging memcpy is cut into pieces that overlap the DMA."""
+    d, frames, exp = _setup(lm, orc, synth, n_frames=3)
+    d.set_stage_chunks(chunks)
+    for rnd in range(3):
+        for f in range(3):
+            assert_matches_equal(d.match(frames[f][0], frames[f][1], THR, 0), exp[f])
+    # strided sources (a cv::Mat ROI): row pitch larger than the row
+    big = np.zeros((H, W + 16, 3), np.uint8)
+    bigd = np.zeros((H, W + 8), np.uint16)
+    big[:, :W] = frames[1][0]
+    bigd[:, :W] = frames[1][1]
+    out = np.zeros(4096, lm.MATCH_DTYPE)
+    import ctypes as C
+    n = C.c_size_t()
+    rc = d.lib.lm_match(d.h, big.ctypes.data_as(C.c_void_p), big.strides[0], bigd.ctypes.data_as(C.c_void_p),
+                        bigd.strides[0], THR, 0, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
+    assert rc == 0
+    assert_matches_equal(out[:n.value], exp[1])
+    d.close()

@@ -204,7 +204,30 @@ def test_similarity_lut_consistency(orc, variant):
         assert lut[32 * ori + 16 * (ori // 4) + (1 << (ori % 4))] == 4   # own orientation scores 4
 
 
-def test_default_lut_is_linear(orc):
+# SIMILARITY_LUT as cv::linemod ships it, typed out independently of the oracle's rule
+UPSTREAM_SIMILARITY_LUT = """
+0 4 3 4 2 4 3 4 1 4 3 4 2 4 3 4 | 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0 0
+0 3 4 4 3 3 4 4 2 3 4 4 3 3 4 4 | 0 1 0 1 0 1 0 1 0 1 0 1 0 1 0 1
+0 2 3 3 4 4 4 4 3 3 3 3 4 4 4 4 | 0 2 1 2 0 2 1 2 0 2 1 2 0 2 1 2
+0 1 2 2 3 3 3 3 4 4 4 4 4 4 4 4 | 0 3 2 3 1 3 2 3 0 3 2 3 1 3 2 3
+0 0 1 1 2 2 2 2 3 3 3 3 3 3 3 3 | 0 4 3 4 2 4 3 4 1 4 3 4 2 4 3 4
+0 1 0 1 1 1 1 1 2 2 2 2 2 2 2 2 | 0 3 4 4 3 3 4 4 2 3 4 4 3 3 4 4
+0 2 1 2 0 2 1 2 1 2 1 2 1 2 1 2 | 0 2 3 3 4 4 4 4 3 3 3 3 4 4 4 4
+0 3 2 3 1 3 2 3 0 3 2 3 1 3 2 3 | 0 1 2 2 3 3 3 3 4 4 4 4 4 4 4 4
+"""
+
+
+def test_default_lut_is_upstreams(orc):
+    exp = np.array([int(t) for t in UPSTREAM_SIMILARITY_LUT.replace("|", " ").split()], np.uint8)
+    assert exp.size == 256
+    assert np.array_equal(orc.similarity_lut(), exp)
+    det = orc.Detector(color_only=True)          # what orc_create installs
+    spr = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    assert np.array_equal(orc.response_maps(spr), orc.response_maps(spr, exp))
+    det.close()
+
+
+def test_linear_lut_variant(orc):
     lut = orc.similarity_lut(0)
     for ori in range(8):
         for bit in range(8):
