@@ -451,9 +451,9 @@ inline bool match_eq(const orc_match& a, const orc_match& b) {
     return a.x == b.x && a.y == b.y && a.similarity == b.similarity && a.class_idx == b.class_idx;
 }
 
-// a13 + a14: matchClass for one template.
-void match_template(const orc_detector* d, int class_idx, int template_id, const TemplatePyramid& tp,
-                    float threshold, std::vector<orc_match>& out) {
+// a11 + a12 + a13: matchClass, first half -- similarity maps of the lowest level, their sum and the threshold scan.
+void scan_template(const orc_detector* d, int class_idx, int template_id, const TemplatePyramid& tp, float threshold,
+                   std::vector<orc_match>& cand) {
     const orc_config& c = d->cfg;
     int M = c.num_modalities, Lc = c.pyramid_levels;
     const LevelData& low = d->levels[Lc - 1];
@@ -478,7 +478,6 @@ void match_template(const orc_detector* d, int class_idx, int template_id, const
     // A.7 raw threshold, float arithmetic
     int raw_threshold = (int)(2 * num_features + (threshold / 100.f) * (2 * num_features) + 0.5f);
 
-    std::vector<orc_match> cand;
     for (int r = 0; r < H; ++r)
         for (int cc = 0; cc < W; ++cc) {
             int raw = total[(size_t)r * W + cc];
@@ -493,6 +492,15 @@ void match_template(const orc_detector* d, int class_idx, int template_id, const
                 cand.push_back(mm);
             }
         }
+}
+
+// a13 + a14: matchClass for one template.
+void match_template(const orc_detector* d, int class_idx, int template_id, const TemplatePyramid& tp,
+                    float threshold, std::vector<orc_match>& out) {
+    const orc_config& c = d->cfg;
+    int M = c.num_modalities, Lc = c.pyramid_levels;
+    std::vector<orc_match> cand;
+    scan_template(d, class_idx, template_id, tp, threshold, cand);
 
     for (int l = Lc - 2; l >= 0; --l) {
         const LevelData& L = d->levels[l];
@@ -707,6 +715,34 @@ int orc_match_prepared(orc_detector* d, float threshold, int class_idx, int tid_
     matches.erase(std::unique(matches.begin(), matches.end(), match_eq), matches.end());
     int n = (int)matches.size();
     if (out) std::memcpy(out, matches.data(), sizeof(orc_match) * (size_t)std::min(n, cap));
+    return n;
+}
+
+// a11-a13 only: the candidates of the global scan of the prepared frame, before any refinement, as
+// (template_id, class_idx, x, y) int32 quadruples sorted by (class, template, y, x) -- what the HIP scan kernel must
+// hand to the refinement stage.  Returns the count (may exceed cap_records; only cap_records are written).
+int orc_scan_candidates(orc_detector* d, float threshold, int class_idx, int tid_lo, int tid_hi, int threads,
+                        int32_t* out, int cap_records) {
+    if (!d->prepared) { set_err("no frame prepared"); return -1; }
+    if (class_idx >= (int)d->classes.size()) { set_err("class index out of range"); return -1; }
+    std::vector<orc_match> all;
+    int c_lo = class_idx < 0 ? 0 : class_idx, c_hi = class_idx < 0 ? (int)d->classes.size() : class_idx + 1;
+    for (int ci = c_lo; ci < c_hi; ++ci) {
+        const ClassEntry& ce = d->classes[ci];
+        int lo = std::max(0, tid_lo), hi = std::min((int)ce.pyramids.size(), tid_hi);
+        std::vector<std::vector<orc_match>> per((size_t)std::max(hi - lo, 0));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads > 1 ? threads : 1)
+#endif
+        for (int t = lo; t < hi; ++t) scan_template(d, ci, t, ce.pyramids[t], threshold, per[(size_t)(t - lo)]);
+        for (const auto& v : per) all.insert(all.end(), v.begin(), v.end());   // already (class, template, y, x) ordered
+    }
+    int n = (int)all.size();
+    if (out)
+        for (int i = 0; i < std::min(n, cap_records); ++i) {
+            out[4 * i] = all[i].template_id; out[4 * i + 1] = all[i].class_idx;
+            out[4 * i + 2] = all[i].x; out[4 * i + 3] = all[i].y;
+        }
     return n;
 }
 

@@ -113,6 +113,11 @@ int orc_prepare_frame(orc_detector* d, const uint8_t* bgr, const uint16_t* depth
 int orc_match_prepared(orc_detector* d, float threshold, int class_idx, int tid_lo, int tid_hi,
                        int threads, orc_match* out, int cap);
 
+/* a11-a13 only: candidates of the global scan of the prepared frame before refinement, (template_id, class_idx,
+ * x, y) int32 quadruples sorted by (class, template, y, x).  Returns the count (may exceed cap_records). */
+int orc_scan_candidates(orc_detector* d, float threshold, int class_idx, int tid_lo, int tid_hi, int threads,
+                        int32_t* out, int cap_records);
+
 /* Access intermediate buffers of the last prepared frame (for stage-by-stage parity tests).
  * what: 0 quantized, 1 spread, 2 linear memories (8 * T*T * W*H bytes, [ori][memory][pos]).
  * Returns byte size, copies at most cap bytes. */

@@ -101,6 +101,7 @@ def load(path=None):
                                     vp, C.c_int]
     lib.orc_prepare_frame.argtypes = [vp, vp, vp, C.c_int, C.c_int]
     lib.orc_match_prepared.argtypes = [vp, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    lib.orc_scan_candidates.argtypes = [vp, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
     lib.orc_get_stage.restype = C.c_int64
     lib.orc_get_stage.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64]
     lib.orc_merge.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int]
@@ -291,6 +292,16 @@ class Detector:
             raise RuntimeError(self.lib.orc_last_error().decode())
         if n > cap:
             return self.match_prepared(threshold, class_idx, tid_lo, tid_hi, threads, cap=n)
+        return out[:n].copy()
+
+    def scan_candidates(self, threshold, class_idx=-1, tid_lo=0, tid_hi=INT32_MAX, threads=1, cap=1 << 18):
+        """a11-a13 of the prepared frame: [n, 4] int32 (template_id, class_idx, x, y), sorted."""
+        out = np.zeros((cap, 4), np.int32)
+        n = self.lib.orc_scan_candidates(self.h, threshold, class_idx, tid_lo, tid_hi, threads, _ptr(out), cap)
+        if n < 0:
+            raise RuntimeError(self.lib.orc_last_error().decode())
+        if n > cap:
+            return self.scan_candidates(threshold, class_idx, tid_lo, tid_hi, threads, cap=n)
         return out[:n].copy()
 
     def match(self, bgr, depth, threshold, class_idx=-1, tid_lo=0, tid_hi=INT32_MAX, threads=1, cap=1 << 16):

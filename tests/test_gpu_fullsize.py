@@ -1,0 +1,110 @@
+"""Every BASELINE.json configuration at its STATED size, HIP vs the CPU oracle (OpenMP over templates), through the
+C ABI: config 2 (640x480 RGB-D, 3000 templates, variable and fixed geometry), config 3 (1280x960 colour-only
+T = {2, 8}, 3000 templates), config 4 (24 300 templates = 162 viewpoints x 15 radii x 10 rotations, CameraViewPoints.cpp:
+84-124 x linemod_settings.yml:21-27, as 8 shards of 3 038 merged with lm_merge_matches).  Besides the final lists the
+a11-a13 candidate list of the scan kernel is compared record by record with the oracle's (orc_scan_candidates)."""
+import numpy as np
+import pytest
+
+from conftest import assert_matches_equal
+
+pytestmark = pytest.mark.gpu
+THREADS = 16
+
+
+def _oracle_quantized(o, bgr, depth, M):
+    o.prepare(bgr, depth if M == 2 else None)
+    return {(l, m): o.stage(0, l, m).reshape(bgr.shape[0] >> l, bgr.shape[1] >> l) for l in range(2) for m in range(M)}
+
+
+def _check_frames(d, o, frames, M, thr, class_idx=0, min_total=1):
+    total = 0
+    for i, (bgr, depth) in enumerate(frames):
+        dep = depth if M == 2 else None
+        exp = o.match(bgr, dep, thr, class_idx, threads=THREADS)
+        got = d.match(bgr, dep, thr, class_idx, cap=1 << 17)
+        assert_matches_equal(got, exp)
+        total += len(exp)
+        # a11-a13 in isolation: the scan kernel's candidate list, record by record
+        slot = 1 + (i % 3)
+        d.upload_frame(slot, bgr, dep)
+        d.prepare_slot(slot)
+        cands = d.stage_scan(slot, thr, class_idx)
+        o.prepare(bgr, dep)
+        assert np.array_equal(cands, o.scan_candidates(thr, class_idx, threads=THREADS))
+    assert total >= min_total
+    return total
+
+
+@pytest.mark.parametrize("fixed", [False, True])
+def test_config2_3000_templates(lm, orc, synth, fixed):
+    """BASELINE config 2: 1 GPU, 640x480 RGB-D, T = {5, 8}, 3000 templates; four distinct frames; variable geometry
+    (bbox 48..160) and the fixed 96x96 geometry the bench uses."""
+    W, H, M = 640, 480, 2
+    frames = [synth.make_frame(W, H, seed=1234 + i) for i in range(4)]
+    d = lm.Detector(color_only=False, width=W, height=H)
+    o = orc.Detector(color_only=False)
+    q = _oracle_quantized(o, frames[0][0], frames[0][1], M)
+    descs, feats, crops = synth.make_bank(3000, M, 2, seed=4321, fixed_l0_size=(96, 96) if fixed else None, quantized=q,
+                                          crop_fraction=0.1, frame_size=(W, H), T0=d.get_T(0))
+    d.add_class("synthetic.ply", descs, feats)
+    o.add_class("synthetic.ply", descs, feats)
+    assert d.num_templates() == 3000
+    _check_frames(d, o, frames, M, 80.0, min_total=len(crops) // 2)
+    # the same bank at a lower threshold: thousands of candidates per frame through refine + sort
+    _check_frames(d, o, frames[:2], M, 60.0)
+    d.close()
+
+
+@pytest.mark.parametrize("fixed", [False, True])
+def test_config3_1280x960_color_only_3000_templates(lm, orc, synth, fixed):
+    """BASELINE config 3: 1280x960, ColorGradient only, T = {2, 8} (the shipped modality, linemod_settings.yml:20,
+    HighLevelLinemod.cpp:36-43), 3000 templates; fixed geometry = level-1 bbox 96x96 (P = 3909)."""
+    W, H, M = 1280, 960, 1
+    frames = [synth.make_frame(W, H, seed=2234 + i) for i in range(4)]
+    d = lm.Detector(color_only=True, width=W, height=H)
+    o = orc.Detector(color_only=True)
+    q = _oracle_quantized(o, frames[0][0], None, M)
+    descs, feats, crops = synth.make_bank(3000, M, 2, seed=77, fixed_l0_size=(192, 192) if fixed else None,
+                                          size_range=(96, 320), quantized=q, crop_fraction=0.1, frame_size=(W, H),
+                                          T0=d.get_T(0))
+    d.add_class("shiny.ply", descs, feats)
+    o.add_class("shiny.ply", descs, feats)
+    _check_frames(d, o, frames, M, 80.0, min_total=len(crops) // 2)
+    _check_frames(d, o, frames[:1], M, 65.0)
+    d.close()
+
+
+def test_config4_24300_templates_8_shards_one_gpu(lm, orc, synth):
+    """BASELINE config 4 on one GPU: the 24 300-template bank split into R = 8 contiguous template_id ranges
+    (lm_config.shard_rank / shard_size, 3 037 or 3 038 templates each), one detector per shard created one after
+    another; lm_merge_matches of the eight lists must equal the oracle's list for the UNSHARDED bank.  Also run
+    unsharded on one detector (u32 offsets, work-item tables and capacities at 8 x the benched size)."""
+    W, H, M, N, R = 640, 480, 2, 24300, 8
+    frames = [synth.make_frame(W, H, seed=1234 + i) for i in range(2)]
+    o = orc.Detector(color_only=False)
+    q = _oracle_quantized(o, frames[0][0], frames[0][1], M)
+    descs, feats, crops = synth.make_bank(N, M, 2, seed=4321, quantized=q, crop_fraction=0.05, frame_size=(W, H), T0=5)
+    o.add_class("sphere.ply", descs, feats)
+    exp = [o.match(b, dp, 80.0, 0, threads=THREADS) for b, dp in frames]
+    assert len(exp[0]) > len(crops) // 4
+    lists = [[] for _ in frames]
+    sizes = []
+    for r in range(R):
+        d = lm.Detector(color_only=False, width=W, height=H, shard_rank=r, shard_size=R)
+        d.add_class("sphere.ply", descs, feats)          # every rank is handed the whole bank and keeps its range
+        for i, (b, dp) in enumerate(frames):
+            got = d.match(b, dp, 80.0, 0, cap=1 << 17)
+            lists[i].append(got)
+            lo, hi = N * r // R, N * (r + 1) // R
+            assert len(got) == 0 or (got["template_id"].min() >= lo and got["template_id"].max() < hi)
+            assert_matches_equal(got, o.match(b, dp, 80.0, 0, tid_lo=lo, tid_hi=hi, threads=THREADS))
+        sizes.append(N * (r + 1) // R - N * r // R)
+        d.close()
+    assert sorted(set(sizes)) == [3037, 3038]
+    for i in range(len(frames)):
+        assert_matches_equal(lm.merge_matches(lists[i]), exp[i])
+    d = lm.Detector(color_only=False, width=W, height=H, max_candidates=1 << 20)
+    d.add_class("sphere.ply", descs, feats)
+    _check_frames(d, o, frames, M, 80.0)
+    d.close()

@@ -93,7 +93,8 @@ def test_synthetic_bank_parity(lm, orc, synth, color_only, size, n, thr, flags):
     d.upload_frame(1, bgr, None if color_only else depth)
     d.prepare_slot(1)
     cands = d.stage_scan(1, thr)
-    assert len(cands) >= len(exp) // 4
+    o.prepare(bgr, None if color_only else depth)
+    assert np.array_equal(cands, o.scan_candidates(thr, threads=8))   # a11-a13 record by record
     d.close()
 
 
