@@ -158,8 +158,17 @@ int lm_upload_wait(lm_detector* det, int slot);
 /* Pinned host memory for frame sources (hipHostMalloc); needs a HIP device. */
 int  lm_host_alloc(size_t bytes, void** out);
 void lm_host_free(void* p);
-/* Pageable sources: number of pieces the staging memcpy is cut into so that it overlaps the DMA (default 2). */
+/* Pageable sources: number of pieces the staging memcpy is cut into so that it overlaps the DMA (default 1:
+ * on the MI355X host every extra hipMemcpyAsync call cost more than the overlap won). */
 int lm_set_stage_chunks(lm_detector* det, int chunks);
+/* Launch-shape knobs (results never depend on them; tools/ and the tests flip them for A/B runs).
+ * LM_TUNE_FORK_MAX_SLOTS: calls on at most this many frames run the three independent preprocess chains (colour
+ *   level 0 | pyrDown + colour of the levels above | depth) on three streams joined by events (default 0 = off: small calls are bound by the host's launch rate, measured r02);
+ * LM_TUNE_MATCH_UPLOAD_MODE: lm_match's copies 1 = on the copy stream with the depth chain alone waiting for the depth
+ *   image, 0 = inline on the compute stream (default). */
+#define LM_TUNE_FORK_MAX_SLOTS 1
+#define LM_TUNE_MATCH_UPLOAD_MODE 2
+int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 /* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame
  * records, counts n_slots entries. */

@@ -35,6 +35,8 @@ class Config(C.Structure):
 
 FLAG_BYTE_RESPONSES = 1
 FLAG_BLOCKING_SYNC = 2
+TUNE_FORK_MAX_SLOTS = 1
+TUNE_MATCH_UPLOAD_MODE = 2
 
 
 class Rect(C.Structure):
@@ -60,6 +62,7 @@ EXPORTS = [
     "lm_save_yaml", "lm_load_yaml", "lm_yaml_numbers", "lm_yaml_string", "lm_pack_matches", "lm_merge_batch",
     "lm_match_begin", "lm_match_end", "lm_synchronize", "lm_merge_frames",
     "lm_upload_frame_pinned", "lm_upload_wait", "lm_host_alloc", "lm_host_free", "lm_set_stage_chunks",
+    "lm_set_tuning",
 ]
 
 _lib = None
@@ -137,6 +140,7 @@ def load_library(path=None):
     lib.lm_host_free.argtypes = [vp]
     lib.lm_host_free.restype = None
     lib.lm_set_stage_chunks.argtypes = [vp, i]
+    lib.lm_set_tuning.argtypes = [vp, i, i]
     if path is None:
         _lib = lib
     return lib
@@ -417,6 +421,9 @@ class Detector:
 
     def set_stage_chunks(self, chunks):
         self._check(self.lib.lm_set_stage_chunks(self.h, chunks))
+
+    def set_tuning(self, key, value):
+        self._check(self.lib.lm_set_tuning(self.h, key, value))
 
     def match_slot(self, slot, threshold, class_idx=-1, cap=1 << 16):
         out = np.zeros(cap, MATCH_DTYPE)

@@ -45,6 +45,7 @@ struct Slot {
     // Uploads run on the detector's copy stream: ev_up is recorded behind the slot's H2D copies, up_seq is the
     // upload's ticket (0 = never uploaded through the copy stream).  Copies complete in ticket order.
     hipEvent_t ev_up = nullptr;
+    hipEvent_t ev_bgr = nullptr;     // recorded behind the colour image alone (RGB-D: the depth copy follows it)
     unsigned long long up_seq = 0;
 };
 
@@ -83,13 +84,24 @@ struct lm_detector {
     hipStream_t copy_stream = nullptr;
     unsigned long long up_seq_next = 1, up_seq_done = 0;   // next ticket / newest ticket known to have landed
     unsigned long long waited_seq = 0;                     // ACTIVE lane's copy of Lane::waited_seq
-    int stage_chunks = 2;                                  // pageable source: staging memcpy pipelined with the DMA
+    int stage_chunks = 1;                                  // pageable source: pieces of the staging memcpy (each piece is its own
+                                                           // async copy; measured: every extra hipMemcpyAsync costs more than the overlap wins)
     std::vector<Slot> slots;
     // frame arena: [slot][bgr[l] | depth | quant[l][m] | lm[l]]
     u8* frame_arena = nullptr;
     size_t frame_stride = 0;
     size_t off_bgr[LM_MAX_LEVELS] = {}, off_depth = 0, off_quant[LM_MAX_LEVELS][2] = {}, off_lm[LM_MAX_LEVELS] = {};
-    size_t off_cscratch = 0;   // colour-quantisation scratch (hb / vs / vd / qn), sized for level 0, reused per level
+    // colour-quantisation scratch S | qn: one region for level 0, one (sized for level 1) shared by the levels above,
+    // and the rank-code image of the depth passes -- disjoint, so the three chains may run concurrently (fork_streams)
+    size_t off_cscratch = 0, off_cscratch1 = 0, off_dscratch = 0;
+    // Small calls (n <= LM_FORK_MAX_SLOTS frames) are bound by the latency of 16 dependent launches, not by
+    // throughput: the colour chain of level 0, the pyrDown + colour chain of the levels above and the depth chain are
+    // independent until the scan, so they are forked onto two more streams of the lane and joined with events.
+    struct Fork { hipStream_t s[2] = {nullptr, nullptr}; hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr}; bool ok = false; };
+    Fork forks[2];   // per lane
+    int fork_max_slots = 0;          // measured r02: no gain (host launch rate, 3.4 us per launch, bounds small calls), so off by default
+    int fork_depth_wait_slot = -1;   // forked single-frame call: the depth chain's stream waits for this slot's whole upload
+    int match_upload_mode = 0;       // lm_match: 0 = copies inline on the compute stream (default, faster), 1 = copy stream + split events
     // aux arena: [slot][LmDevHeader | cand | keys | out]
     u8* aux_arena = nullptr;
     size_t aux_stride = 0;
@@ -128,7 +140,8 @@ struct lm_detector {
     u16* depth(int slot) const { return reinterpret_cast<u16*>(frame_arena + (size_t)slot * frame_stride + off_depth); }
     u8* quant(int slot, int l, int m) const { return frame_arena + (size_t)slot * frame_stride + off_quant[l][m]; }
     u8* lm(int slot, int l) const { return frame_arena + (size_t)slot * frame_stride + off_lm[l]; }
-    u8* cscratch(int slot) const { return frame_arena + (size_t)slot * frame_stride + off_cscratch; }
+    u8* cscratch(int slot, int l = 0) const { return frame_arena + (size_t)slot * frame_stride + (l == 0 ? off_cscratch : off_cscratch1); }
+    u8* dscratch(int slot) const { return frame_arena + (size_t)slot * frame_stride + off_dscratch; }
     u8* aux(int slot, size_t off) const { return aux_arena + (size_t)slot * aux_stride + off; }
     LmHostBlock* host_block(int slot) const { return reinterpret_cast<LmHostBlock*>(host_blocks + (size_t)slot * host_stride); }
 };
@@ -175,6 +188,8 @@ int ensure_device(lm_detector* d) {
         for (int m = 0; m < M; ++m) { d->off_quant[l][m] = off; off += align_up((size_t)d->lw[l] * d->lh[l], 256); }
     for (int l = 0; l < L; ++l) { d->off_lm[l] = off; off += align_up(d->geom[l].arena_bytes, 256); }
     d->off_cscratch = off; off += align_up(lmk_color_scratch_bytes(c.width, c.height), 256);
+    d->off_cscratch1 = off; off += align_up(lmk_color_scratch_bytes(d->lw[L > 1 ? 1 : 0], d->lh[L > 1 ? 1 : 0]), 256);
+    d->off_dscratch = off; off += align_up((size_t)c.width * c.height, 256);
     d->frame_stride = align_up(off, 4096);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->frame_arena), d->frame_stride * S));
     HIP_TRY(hipMemset(d->frame_arena, 0, d->frame_stride * S));  // linear-memory pads / zero blocks stay zero forever
@@ -198,7 +213,10 @@ int ensure_device(lm_detector* d) {
     HIP_TRY(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     for (auto& ev : d->ev) HIP_TRY(hipEventCreate(&ev));
     d->slots.assign(S, Slot());
-    for (Slot& s : d->slots) HIP_TRY(hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
+    for (Slot& s : d->slots) {
+        HIP_TRY(hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.ev_bgr, hipEventDisableTiming));
+    }
     // pinned staging for pageable sources is allocated on a slot's first staged upload (ensure_staging): a
     // streaming server that hands over pinned frames (lm_upload_frame_pinned) never needs it
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_resp_tab), 256 * sizeof(u64)));
@@ -274,37 +292,84 @@ void enqueue_depth_pyramid(lm_detector* d, int first, int n) {
 }
 
 int wait_uploads(lm_detector* d, hipStream_t stream, int first, int n, unsigned long long* seq);
+bool ensure_fork(lm_detector* d);
+
+// one modality's linear memories of level l (a6-a10)
+void enqueue_lm(lm_detector* d, hipStream_t st, int first, int n, int l, int m) {
+    const size_t fs = d->frame_stride;
+    const LmLevelGeom& g = d->geom[l];
+    const int sp = g.spread_only ? 1 : g.nibble ? 2 : 0;
+    u8* dst = d->lm(first, l) + (size_t)m * g.mod_stride;
+    if (m == 0 || l == 0)
+        lmk_linear_memories(st, d->quant(first, l, m), g.w, 0, sp, g.w, g.h, g.T, d->d_resp_tab, dst, g.ori_stride, fs, fs, n);
+    else   // level l of the depth modality reads the quantised image of level l-1 at (2y, 2x)
+        lmk_linear_memories(st, d->quant(first, l - 1, 1), d->lw[l - 1], 1, sp, g.w, g.h, g.T, d->d_resp_tab, dst,
+                            g.ori_stride, fs, fs, n);
+}
+
+bool ensure_fork(lm_detector* d) {
+    lm_detector::Fork& f = d->forks[d->active];
+    if (f.ok) return true;
+    for (auto& st : f.s) if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+    if (!f.fork && hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess) return false;
+    for (auto& e : f.join) if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+    f.ok = true;
+    return true;
+}
 
 // a3-a10 on the frames resident in slots [first, first + n).
 void enqueue_preprocess(lm_detector* d, int first, int n) {
     const lm_config& c = d->cfg;
     const int M = c.num_modalities, L = c.pyramid_levels;
     const size_t fs = d->frame_stride;
+    // ---- few frames: three concurrent chains (latency-bound regime)
+    if (n <= d->fork_max_slots && L >= 2 && ensure_fork(d)) {
+        lm_detector::Fork& f = d->forks[d->active];
+        hipStream_t s0 = d->stream, s1 = f.s[0], s2 = f.s[1];
+        (void)hipEventRecord(f.fork, s0);
+        (void)hipStreamWaitEvent(s1, f.fork, 0);
+        if (M == 2) (void)hipStreamWaitEvent(s2, f.fork, 0);
+        if (M == 2 && d->fork_depth_wait_slot == first) (void)hipStreamWaitEvent(s2, d->slots[first].ev_up, 0);
+        d->fork_depth_wait_slot = -1;
+        // s1: pyrDown + colour chain + linear memories of the levels above 0
+        for (int l = 1; l < L; ++l) {
+            lmk_pyrdown(s1, d->bgr(first, l - 1), d->lw[l - 1], d->lh[l - 1], d->bgr(first, l), fs, n);
+            lmk_color_quantize(s1, d->bgr(first, l), d->lw[l], d->lh[l], c.weak_threshold, d->quant(first, l, 0), nullptr,
+                               d->cscratch(first, 1), fs, n);
+            enqueue_lm(d, s1, first, n, l, 0);
+        }
+        (void)hipEventRecord(f.join[0], s1);
+        // s2: depth chain + the depth modality's linear memories of every level
+        if (M == 2) {
+            lmk_depth_quantize(s2, d->depth(first), d->lw[0], d->lh[0], c.distance_threshold, c.difference_threshold,
+                               d->d_normal_lut, normal_lut_onehot(d), d->quant(first, 0, 1), d->dscratch(first), fs, n);
+            if (L > 2) {
+                for (int l = 1; l < L; ++l)
+                    lmk_nn_half(s2, d->quant(first, l - 1, 1), d->lw[l - 1], d->quant(first, l, 1), d->lw[l], d->lh[l], fs, n);
+            }
+            for (int l = 0; l < L; ++l) enqueue_lm(d, s2, first, n, l, 1);
+            (void)hipEventRecord(f.join[1], s2);
+        }
+        // s0: colour chain + linear memories of level 0, then join
+        lmk_color_quantize(s0, d->bgr(first, 0), d->lw[0], d->lh[0], c.weak_threshold, d->quant(first, 0, 0), nullptr,
+                           d->cscratch(first, 0), fs, n);
+        enqueue_lm(d, s0, first, n, 0, 0);
+        (void)hipStreamWaitEvent(s0, f.join[0], 0);
+        if (M == 2) (void)hipStreamWaitEvent(s0, f.join[1], 0);
+        return;
+    }
     for (int l = 0; l < L; ++l) {
         if (l > 0) lmk_pyrdown(d->stream, d->bgr(first, l - 1), d->lw[l - 1], d->lh[l - 1], d->bgr(first, l), fs, n);
         lmk_color_quantize(d->stream, d->bgr(first, l), d->lw[l], d->lh[l], c.weak_threshold, d->quant(first, l, 0),
-                           nullptr, d->cscratch(first), fs, n);
+                           nullptr, d->cscratch(first, l), fs, n);
         if (M == 2 && l == 0)
             lmk_depth_quantize(d->stream, d->depth(first), d->lw[0], d->lh[0], c.distance_threshold,
                                c.difference_threshold, d->d_normal_lut, normal_lut_onehot(d), d->quant(first, 0, 1),
-                               d->cscratch(first), fs, n);
+                               d->dscratch(first), fs, n);
     }
     if (M == 2 && L > 2) enqueue_depth_pyramid(d, first, n);
-    for (int l = 0; l < L; ++l) {
-        const LmLevelGeom& g = d->geom[l];
-        const int sp = g.spread_only ? 1 : g.nibble ? 2 : 0;
-        lmk_linear_memories(d->stream, d->quant(first, l, 0), g.w, 0, sp, g.w, g.h, g.T, d->d_resp_tab, d->lm(first, l),
-                            g.ori_stride, fs, fs, n);
-        if (M == 2) {
-            // level l of the depth modality reads the quantised image of level l-1 at (2y, 2x)
-            if (l == 0)
-                lmk_linear_memories(d->stream, d->quant(first, 0, 1), g.w, 0, sp, g.w, g.h, g.T, d->d_resp_tab,
-                                    d->lm(first, l) + g.mod_stride, g.ori_stride, fs, fs, n);
-            else
-                lmk_linear_memories(d->stream, d->quant(first, l - 1, 1), d->lw[l - 1], 1, sp, g.w, g.h, g.T,
-                                    d->d_resp_tab, d->lm(first, l) + g.mod_stride, g.ori_stride, fs, fs, n);
-        }
-    }
+    for (int l = 0; l < L; ++l)
+        for (int m = 0; m < M; ++m) enqueue_lm(d, d->stream, first, n, l, m);
 }
 
 void fill_raw_thr(int* tab, float threshold) {
@@ -413,7 +478,18 @@ int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, Item
 int enqueue_upload_wait(lm_detector* d, int first, int n) {
     unsigned long long seq = 0;
     int rc;
-    if ((rc = wait_uploads(d, d->stream, first, n, &seq))) return rc;
+    d->fork_depth_wait_slot = -1;
+    Slot& s = d->slots[first];
+    if (n == 1 && d->cfg.num_modalities == 2 && d->cfg.pyramid_levels >= 2 && n <= d->fork_max_slots &&
+        s.up_seq > d->up_seq_done && ensure_fork(d)) {
+        // one RGB-D frame through the forked chains: the colour chains start behind the colour copy, only the depth
+        // chain waits for the depth copy (enqueue_preprocess makes its stream wait for ev_up)
+        HIP_TRY(hipStreamWaitEvent(d->stream, s.ev_bgr, 0));
+        d->fork_depth_wait_slot = first;
+        seq = s.up_seq;
+    } else if ((rc = wait_uploads(d, d->stream, first, n, &seq))) {
+        return rc;
+    }
     if (seq > d->waited_seq) d->waited_seq = seq;
     return LM_OK;
 }
@@ -554,6 +630,7 @@ int upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride
     if (!pinned && (rc = ensure_staging(d, s))) return rc;
     hipStream_t st = inline_stream ? inline_stream : d->copy_stream;
     if ((rc = copy_image(st, d->bgr(slot, 0), s.h_bgr, bgr, bgr_stride, (size_t)c.width * 3, c.height, pinned, d->stage_chunks))) return rc;
+    if (!inline_stream && c.num_modalities == 2) HIP_TRY(hipEventRecord(s.ev_bgr, d->copy_stream));
     if (c.num_modalities == 2 &&
         (rc = copy_image(st, reinterpret_cast<u8*>(d->depth(slot)), reinterpret_cast<u8*>(s.h_depth),
                          reinterpret_cast<const u8*>(depth), depth_stride, (size_t)c.width * 2, c.height, pinned, d->stage_chunks)))
@@ -734,8 +811,14 @@ void lm_destroy(lm_detector* d) {
             if (s.h_bgr) hipHostFree(s.h_bgr);
             if (s.h_depth) hipHostFree(s.h_depth);
             if (s.ev_up) hipEventDestroy(s.ev_up);
+            if (s.ev_bgr) hipEventDestroy(s.ev_bgr);
         }
         if (d->copy_stream) hipStreamDestroy(d->copy_stream);
+        for (auto& f : d->forks) {
+            for (auto& st : f.s) if (st) hipStreamDestroy(st);
+            if (f.fork) hipEventDestroy(f.fork);
+            for (auto& e : f.join) if (e) hipEventDestroy(e);
+        }
         hipFree(d->frame_arena); hipFree(d->aux_arena); hipHostFree(d->host_blocks);
         hipFree(d->d_raw_thr); hipHostFree(d->h_raw_thr); hipFree(d->d_plan);
         activate_lane(d, 0);
@@ -822,11 +905,11 @@ int lm_add_template(lm_detector* d, const char* class_id, const uint8_t* bgr, si
     for (int l = 0; l < L; ++l) {
         if (l > 0) lmk_pyrdown(d->stream, d->bgr(0, l - 1), d->lw[l - 1], d->lh[l - 1], d->bgr(0, l), 0, 1);
         lmk_color_quantize(d->stream, d->bgr(0, l), d->lw[l], d->lh[l], c.weak_threshold, d->quant(0, l, 0),
-                           reinterpret_cast<float*>(scratch + mag_off[l]), d->cscratch(0), 0, 1);
+                           reinterpret_cast<float*>(scratch + mag_off[l]), d->cscratch(0, l), 0, 1);
     }
     if (M == 2) {
         lmk_depth_quantize(d->stream, d->depth(0), d->lw[0], d->lh[0], c.distance_threshold, c.difference_threshold,
-                           d->d_normal_lut, normal_lut_onehot(d), d->quant(0, 0, 1), d->cscratch(0), 0, 1);
+                           d->d_normal_lut, normal_lut_onehot(d), d->quant(0, 0, 1), d->dscratch(0), 0, 1);
         enqueue_depth_pyramid(d, 0, 1);
     }
     std::vector<lmh::ExtractLevel> lv(L);
@@ -925,6 +1008,17 @@ int lm_set_stage_chunks(lm_detector* d, int chunks) {
     return LM_OK;
 }
 
+int lm_set_tuning(lm_detector* d, int key, int value) {
+    if (!d) return fail(LM_ERR_INVALID, "null detector");
+    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    switch (key) {
+        case LM_TUNE_FORK_MAX_SLOTS: if (value < 0) break; d->fork_max_slots = value; return LM_OK;
+        case LM_TUNE_MATCH_UPLOAD_MODE: if (value < 0 || value > 1) break; d->match_upload_mode = value; return LM_OK;
+        default: return fail(LM_ERR_INVALID, "unknown tuning key");
+    }
+    return fail(LM_ERR_INVALID, "tuning value out of range");
+}
+
 int lm_match_slot(lm_detector* d, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
@@ -940,8 +1034,9 @@ int lm_match(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16
     if ((rc = ready_for_compute(d))) return rc;
     if ((rc = ensure_bank(d))) return rc;
     if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    // the copies are issued on the compute stream itself, in order with the kernels: no cross-stream hop on the latency path
-    if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride, false, d->stream))) return rc;
+    // mode 1: copy stream; the colour chains wait for the colour copy only, the depth chain for the depth copy.
+    // mode 0: copies on the compute stream itself, in order with the kernels (no cross-stream hop)
+    if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride, false, d->match_upload_mode ? nullptr : d->stream))) return rc;
     if ((rc = run_match(d, 0, 1, threshold, class_idx))) return rc;
     return collect_slot(d, 0, out, cap, n_out);
 }

@@ -121,3 +121,30 @@ def test_single_frame_calls_with_staging_chunks(lm, orc, synth, chunks):
     assert rc == 0
     assert_matches_equal(out[:n.value], exp[1])
     d.close()
+
+
+@pytest.mark.parametrize("color_only", [False, True])
+@pytest.mark.parametrize("fork,mode", [(0, 0), (0, 1), (2, 0), (2, 1)])
+def test_single_frame_fork_and_upload_modes(lm, orc, synth, color_only, fork, mode):
+    """Single-frame calls run the three independent preprocess chains on three streams (LM_TUNE_FORK_MAX_SLOTS) and
+    lm_match may send its copies through the copy stream with the depth chain alone waiting for the depth image
+    (LM_TUNE_MATCH_UPLOAD_MODE): same lists whatever the launch shape, frames changing every call."""
+    d = lm.Detector(color_only=color_only, width=W, height=H, frame_slots=4)
+    o = orc.Detector(color_only=color_only)
+    M = 1 if color_only else 2
+    frames = [synth.make_frame(W, H, seed=900 + i) for i in range(4)]
+    o.prepare(frames[0][0], None if color_only else frames[0][1])
+    q = {(l, m): o.stage(0, l, m).reshape(H >> l, W >> l) for l in range(2) for m in range(M)}
+    descs, feats, _ = synth.make_bank(150, M, 2, seed=5, quantized=q, crop_fraction=0.3, frame_size=(W, H), T0=d.get_T(0))
+    d.add_class("c", descs, feats)
+    o.add_class("c", descs, feats)
+    d.set_tuning(lm.TUNE_FORK_MAX_SLOTS, fork)
+    d.set_tuning(lm.TUNE_MATCH_UPLOAD_MODE, mode)
+    exp = [o.match(b, None if color_only else dp, 70.0, threads=8) for b, dp in frames]
+    for rnd in range(5):
+        for f, (b, dp) in enumerate(frames):
+            assert_matches_equal(d.match(b, None if color_only else dp, 70.0), exp[f])
+        for f, (b, dp) in enumerate(frames):
+            d.upload_frame(f, b, None if color_only else dp)
+            assert_matches_equal(d.match_slot(f, 70.0), exp[f])       # upload immediately followed by the match
+    d.close()

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lm = importlib.import_module("line-mod-pipeline_amd")
 synth = importlib.import_module("line-mod-pipeline_amd.synth")
 W, H = 640, 480
+CONFIGS = eval(os.environ.get('LM_LAT_CONFIGS', '((0, 0, 1), (2, 0, 1), (2, 1, 1), (2, 1, 2))'))
 for color_only in (False, True):
     M = 1 if color_only else 2
     d = lm.Detector(lm.default_config(color_only=color_only, width=W, height=H, frame_slots=8))
@@ -16,19 +17,24 @@ for color_only in (False, True):
     d.add_class("c", descs, feats)
     for i, (b, dp) in enumerate(frames):
         d.upload_frame(i, b, None if color_only else dp)
-    for _ in range(20):
-        d.match_slot(1, 80.0, 0)
-    t = time.perf_counter()
-    for k in range(200):
-        d.match_slot(1 + k % 7, 80.0, 0)
-    t_slot = (time.perf_counter() - t) / 200
-    for _ in range(10):
-        d.match(frames[1][0], None if color_only else frames[1][1], 80.0, 0)
-    t = time.perf_counter()
-    for k in range(100):
-        b, dp = frames[1 + k % 7]
-        d.match(b, None if color_only else dp, 80.0, 0)
-    t_host = (time.perf_counter() - t) / 100
-    print("%s: resident frame %.0f us, host frame in (lm_match) %.0f us per detection, 3000 templates" % (
-        "colour-only" if color_only else "RGB-D", t_slot * 1e6, t_host * 1e6))
+    for fork, mode, chunks in CONFIGS:
+        d.set_tuning(lm.TUNE_FORK_MAX_SLOTS, fork)
+        d.set_tuning(lm.TUNE_MATCH_UPLOAD_MODE, mode)
+        d.set_stage_chunks(chunks)
+        for _ in range(20):
+            d.match_slot(1, 80.0, 0)
+        t = time.perf_counter()
+        for k in range(200):
+            d.match_slot(1 + k % 7, 80.0, 0)
+        t_slot = (time.perf_counter() - t) / 200
+        for _ in range(10):
+            d.match(frames[1][0], None if color_only else frames[1][1], 80.0, 0)
+        t = time.perf_counter()
+        for k in range(100):
+            b, dp = frames[1 + k % 7]
+            d.match(b, None if color_only else dp, 80.0, 0)
+        t_host = (time.perf_counter() - t) / 100
+        print("%s fork<=%d upload-mode %d chunks %d: resident frame %.0f us, host frame in (lm_match) %.0f us per "
+              "detection, 3000 templates" % ("colour-only" if color_only else "RGB-D", fork, mode, chunks,
+                                             t_slot * 1e6, t_host * 1e6))
     d.close()
