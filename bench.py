@@ -1,26 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- LINE-MOD hot path on MI355X (BASELINE.json metric: detections/sec at 640x480 RGB-D,
-~3000 templates, 2-level pyramid, ColorGradient+DepthNormal).
+"""bench.py -- LINE-MOD hot path on MI355X (BASELINE.json metric: detections/sec at 640x480 RGB-D, ~3000 templates,
+2-level pyramid, ColorGradient+DepthNormal = SURVEY.md 8d config 2; --config 3 = 1280x960 colour-only T = {2, 8}).
 
-A "step" = one pass of the hot path (Detector::match, a3-a15) over one batch of `--batch` synthetic
-frames that are already resident in HBM.  One process per GPU; with N > 1 the template bank is
-sharded over the ranks (3000 templates per GPU, weak scaling), every rank matches the same frames
-against its shard and the per-shard match lists are exchanged with two small RCCL all-gathers per
-step and merged on every rank (the rank process does the exchange, a torch-free worker process the
-matching; see main()).
+A "step" = one pass of the hot path (Detector::match, a3-a15) over one batch of `--batch` synthetic frames that are
+already resident in HBM.  One process per GPU, no torch anywhere: with N > 1 every rank holds one contiguous
+template_id shard of the bank (lm_config.shard_rank / shard_size), matches the same frames against it, and the per-shard
+lists are exchanged by two ncclAllGather calls per lane-step issued from the C++ library on the lane's own stream
+(lm_match_begin_gathered / lm_match_end_gathered); every rank merges the frames it owns.
 
-value = n_gpus * frames / time: one detection = one frame searched against one 3000-template shard
-(frames/sec of the whole job is reported separately in config.frames_per_sec).
+value = frames per second answered against the WHOLE bank (all N shards).  --scaling weak (default): 3000 templates
+per GPU, the bank grows with N (N = 8: 24 000 templates ~ BASELINE config 4); --scaling strong: the 3000-template bank
+of config 2 split N ways.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task description) carrying
-`roofline` (similarity-scan kernel, HIP events on its launch stream over the timed region) and
-`cpu_baseline` (the CPU oracle timed on this host, N=1 only).
+Prints ONE JSON line on rank 0 carrying `roofline` (similarity-scan kernel) and `cpu_baseline` (the CPU oracle timed
+on this host, N = 1 only) and, at N = 1, `config.h2d_inclusive`: the same path with fresh host frames uploaded every
+step (SURVEY.md 8d's "H2D of frame -> D2H of matches" definition).
 """
 import argparse
 import importlib
 import json
 import os
-import struct
 import sys
 import time
 
@@ -31,7 +30,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 L2_PEAK_GBS = 34500.0     # MI355X_MICROARCH.md, "L2 (per XCD)": ~34.5 TB/s aggregate
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PCIE_PEAK_GBS = 63.0      # MI355X_MICROARCH.md, "Host link": PCIe Gen5 x16, 63 GB/s (spec)
+
+CONFIGS = {
+    2: dict(name="SURVEY 8d config 2: 640x480 RGB-D, ColorGradient+DepthNormal, T={5,8}, 2-level pyramid, "
+                 "fixed-geometry 96x96 templates (level-1 bbox 48x48, P = 995)",
+            W=640, H=480, color_only=False, l0_size=(96, 96), seed_frames=1234, seed_bank=4321),
+    3: dict(name="SURVEY 8d config 3: 1280x960, ColorGradient only, T={2,8}, 2-level pyramid, fixed-geometry 192x192 "
+                 "templates (level-1 bbox 96x96, P = 3909)",
+            W=1280, H=960, color_only=True, l0_size=(192, 192), seed_frames=2234, seed_bank=77),
+}
 
 
 def quantized_from_gpu(det, bgr, depth, M, L=2):
@@ -43,70 +52,85 @@ def quantized_from_gpu(det, bgr, depth, M, L=2):
 
 
 CAP = 4096       # match records per frame in the result buffers (a shard's list must fit: SURVEY.md 8e)
-NBUF = 3         # result buffers in rotation: the matcher may run ahead of the exchange
+NBUF = 3         # result buffers in rotation
 
 
 class Runner:
-    """The matcher of one GPU: detector, resident synthetic workload, and the step loop over its two lanes.
-    Lives in the bench process on one GPU and in a torch-free worker process per rank when N > 1."""
+    """The matcher of one GPU: detector, resident synthetic workload, and the step loop over its two lanes."""
 
-    def __init__(self, args, rank, world, local_rank):
+    def __init__(self, args, rank, world, local_rank, exchange):
         self.lm = lm = importlib.import_module("line-mod-pipeline_amd")
         synth = importlib.import_module("line-mod-pipeline_amd.synth")
-        self.args = args
-        W, H, M, B = 640, 480, 2, args.batch
-        self.B = B
-        self.n_total = args.templates * world
+        self.args, self.rank, self.world, self.exchange = args, rank, world, exchange
+        wl = CONFIGS[args.config]
+        W, H, B = wl["W"], wl["H"], args.batch
+        self.M = M = 1 if wl["color_only"] else 2
+        self.B, self.W, self.H = B, W, H
+        self.n_total = args.templates * world if args.scaling == "weak" else args.templates
         flags = (lm.FLAG_BYTE_RESPONSES if args.byte_responses else 0)
         quota = cgroup_cpus()
-        if world > 1 and quota is not None and quota < 3 * world:
-            # two processes per GPU (matcher + exchange): with fewer CPUs than that, do not spin while waiting for the GPU
-            flags |= lm.FLAG_BLOCKING_SYNC
-        cfg = lm.default_config(color_only=False, width=W, height=H, device=local_rank, shard_rank=rank,
-                                shard_size=world, frame_slots=max(B, 1), flags=flags)
+        if world > 1 and quota is not None and quota < 2 * world:
+            flags |= lm.FLAG_BLOCKING_SYNC      # fewer CPUs than busy processes: do not spin while waiting for the GPU
+        self.stream_sets = 2 if (world == 1 and not args.no_h2d) else 1
+        cfg = lm.default_config(color_only=wl["color_only"], width=W, height=H, device=local_rank, shard_rank=rank,
+                                shard_size=world, frame_slots=max(B, 1) * self.stream_sets, flags=flags)
         self.det = det = lm.Detector(cfg)
-        # ---- workload: seeded synthetic frames + fixed-geometry bank (SURVEY.md 8d config 2)
-        self.frames = [synth.make_frame(W, H, seed=1234 + i) for i in range(B)]
+        # ---- workload: seeded synthetic frames + fixed-geometry bank (SURVEY.md 8d)
+        self.frames = [synth.make_frame(W, H, seed=wl["seed_frames"] + i) for i in range(B)]
         q = quantized_from_gpu(det, self.frames[0][0], self.frames[0][1], M)
-        self.descs, self.feats, _ = synth.make_bank(self.n_total, M, 2, seed=4321, fixed_l0_size=(96, 96), quantized=q,
-                                                    crop_fraction=0.1, frame_size=(W, H), T0=det.get_T(0))
+        self.descs, self.feats, _ = synth.make_bank(self.n_total, M, 2, seed=wl["seed_bank"], fixed_l0_size=wl["l0_size"],
+                                                    quantized=q, crop_fraction=0.1, frame_size=(W, H), T0=det.get_T(0))
         det.add_class("synthetic.ply", self.descs, self.feats)
         for i, (bgr, depth) in enumerate(self.frames):
-            det.upload_frame(i, bgr, depth)
+            det.upload_frame(i, bgr, depth if M == 2 else None)
+        det.upload_wait(-1)
         self.NL = args.lanes if args.lanes else 2
         if B % 2 or B < 2:
             self.NL = 1
         self.Bl = B // self.NL                           # frames per lane and launch
-        self.bufs = result_buffers(lm, B)
+        self.bufs = [(np.zeros((B, CAP), lm.MATCH_DTYPE), np.zeros(B, np.int32)) for _ in range(NBUF)]
         self.views = [[(o[l * self.Bl:(l + 1) * self.Bl], cn[l * self.Bl:(l + 1) * self.Bl]) for l in range(self.NL)]
                       for o, cn in self.bufs]
         self.k = 0
+        self.last_owned = None
+        if exchange == "rccl":
+            port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+            det.comm_init(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, args.gather_cap)
+            self.gbuf = [(np.zeros(self.Bl * CAP // 4, lm.MATCH_DTYPE), np.zeros(self.Bl, np.int32)) for _ in range(self.NL)]
 
-    def run_steps(self, n, before_step=None, after_step=None):
+    # ------------------------------------------------------------------------------------------
+    def run_steps(self, n, after_step=None):
         """n passes of the hot path over the batch, driven by this one host thread: lane l works on the frames of
         slots [l * Bl, (l + 1) * Bl); as soon as a lane's step is collected its next step is enqueued, so the two
-        streams always have work and their stages overlap."""
+        streams always have work and their stages overlap.  With the RCCL exchange the lane's all-gathers are part of
+        what lm_match_begin_gathered enqueues, and lm_match_end_gathered merges the frames this rank owns."""
         if n <= 0:
             return
         det, thr, NL, Bl = self.det, self.args.threshold, self.NL, self.Bl
+        rccl = self.exchange == "rccl"
+        begin = det.match_begin_gathered if rccl else det.match_begin
         k0 = self.k
         self.k += n
         for l in range(NL):
-            det.match_begin(l, l * Bl, Bl, thr, 0)
+            begin(l, l * Bl, Bl, thr, 0)
         for k in range(k0, k0 + n):
-            if before_step is not None:
-                before_step(k)                            # result buffer k % NBUF must be free
             for l in range(NL):
-                o, cn = self.views[k % NBUF][l]
-                det.match_end(l, CAP, out=o, counts=cn)
+                if rccl:
+                    o, cn = self.gbuf[l]
+                    f0, nf, tot = det.match_end_gathered(l, o, cn)
+                    if l == 0:
+                        self.last_owned = (f0, nf, int(cn[0]) if nf else 0)
+                else:
+                    o, cn = self.views[k % NBUF][l]
+                    det.match_end(l, CAP, out=o, counts=cn)
                 if k + 1 < k0 + n:
-                    det.match_begin(l, l * Bl, Bl, thr, 0)
+                    begin(l, l * Bl, Bl, thr, 0)
             if after_step is not None:
                 after_step(k)
 
     def one_lane_profile(self, steps=10):
-        """The same launches (Bl frames each) on ONE lane, nothing running beside them: the clean per-stage and scan
-        times (outside the timed region; reported next to the numbers of the overlapped run)."""
+        """The same launches (Bl frames each) on ONE lane, nothing running beside them and no exchange: the clean
+        per-stage and scan-kernel times (HIP events on the launch stream around every stage)."""
         det = self.det
         det.set_profiling(True)
         for _ in range(steps):
@@ -116,101 +140,69 @@ class Runner:
         det.set_profiling(False)
         return prof
 
+    def streaming(self, steps):
+        """SURVEY.md 8d's metric as defined: H2D of the frame -> D2H of the sorted matches.  Every step uploads all B
+        frames again from pinned host memory (the frame -> slot assignment rotates, so every step matches different
+        frames in every slot) into one of two slot sets while the lanes compute on the other (lm_upload_frame_pinned
+        on the copy stream, per-slot events).  Returns frames/s and the H2D rate."""
+        lm, det, B, NL, Bl, M = self.lm, self.det, self.B, self.NL, self.Bl, self.M
+        W, H, thr = self.W, self.H, self.args.threshold
+        fb = W * H * 3 + (W * H * 2 if M == 2 else 0)
+        pb = lm.PinnedBuffer(B * fb)
+        hb = [pb.view(np.uint8, (H, W, 3), offset=i * fb) for i in range(B)]
+        hd = [pb.view(np.uint16, (H, W), offset=i * fb + W * H * 3) if M == 2 else None for i in range(B)]
+        for i, (bgr, depth) in enumerate(self.frames):
+            hb[i][...] = bgr
+            if M == 2:
+                hd[i][...] = depth
+
+        def upload(s, k):
+            for i in range(B):
+                j = (i + 7 * k) % B
+                det.upload_frame_pinned(s * B + i, hb[j], hd[j])
+
+        def begin(s):
+            for l in range(NL):
+                det.match_begin(l, s * B + l * Bl, Bl, thr, 0)
+
+        def end(k):
+            for l in range(NL):
+                o, cn = self.views[k % NBUF][l]
+                det.match_end(l, CAP, out=o, counts=cn)
+
+        counts = []
+        for phase, n in (("warm", 3), ("timed", steps)):
+            upload(0, 0)
+            det.upload_wait(-1)
+            det.synchronize()
+            t0 = time.perf_counter()
+            begin(0)
+            for k in range(n):
+                if k + 1 < n:
+                    upload((k + 1) & 1, k + 1)          # travels while step k computes
+                end(k)
+                if phase == "timed" and k < 2:
+                    counts.append(int(self.bufs[k % NBUF][1].sum()))
+                if k + 1 < n:
+                    begin((k + 1) & 1)
+            det.synchronize()
+            dt = time.perf_counter() - t0
+        pb.close()
+        fps = B * steps / dt
+        gbs = fps * fb / 1e9
+        return {"value": round(fps, 1), "unit": "detections/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+                "h2d_bytes_per_frame": fb, "h2d_GBps": round(gbs, 2), "pcie_peak_GBps": PCIE_PEAK_GBS,
+                "frac_of_pcie_peak": round(gbs / PCIE_PEAK_GBS, 4),
+                "pcie_bound_detections_per_s": round(PCIE_PEAK_GBS * 1e9 / fb, 1),
+                "matches_step0_step1": counts,
+                "note": "every step uploads all %d frames from pinned host memory (rotating frame -> slot map) into one of "
+                        "two slot sets while the two lanes compute on the other; the upload of step 0 is inside the "
+                        "timed region; the link, not the GPU, bounds this mode" % B}
+
     def report(self):
         prof = self.det.get_profile()
         return {"prof": prof, "scan_load_bytes": self.det.scan_load_bytes(0), "Bl": self.Bl, "NL": self.NL,
                 "matches0": int(self.bufs[(self.k - 1) % NBUF][1][0]) if self.k else 0}
-
-
-def result_buffers(lm, B):
-    """NBUF x ([B, CAP] records, [B] counts)."""
-    return [(np.zeros((B, CAP), lm.MATCH_DTYPE), np.zeros(B, np.int32)) for _ in range(NBUF)]
-
-
-def send_msg(f, tag, payload=b""):
-    f.write(tag + struct.pack("<I", len(payload)) + payload)
-    f.flush()
-
-
-def recv_msg(f, expect=None):
-    hdr = f.read(8)
-    if len(hdr) < 8:
-        raise RuntimeError("bench worker pipe closed while waiting for %r" % (expect,))
-    tag, n = hdr[:4], struct.unpack("<I", hdr[4:])[0]
-    payload = f.read(n) if n else b""
-    if len(payload) < n:
-        raise RuntimeError("bench worker pipe closed inside a %r message" % (tag,))
-    if expect is not None and tag != expect:
-        raise RuntimeError("bench worker protocol: expected %r, got %r" % (expect, tag))
-    return tag, payload
-
-
-def worker_main(args):
-    """Torch-free matcher of one rank (N > 1).  Framed messages (4-byte tag, u32 length, payload) on stdin / stdout:
-         -> REDY | <- RUN_ n : n x (-> DONE k, total, counts[B], packed records) then -> REND
-         <- PROF 0/1 -> OK__ | <- REPT -> REPT json | <- QUIT
-    The pipe is the only coupling (no shared memory: /dev/shm may be tiny in a container); a step's packed lists are a
-    few hundred KB and the pipe's back-pressure bounds how far the matcher runs ahead of the exchange."""
-    out = os.fdopen(os.dup(1), "wb")
-    os.dup2(2, 1)                                          # anything else that prints to stdout goes to stderr
-    inp = os.fdopen(os.dup(0), "rb")
-    r = Runner(args, args.worker_rank, args.worker_world, args.worker_local_rank)
-    lm = r.lm
-
-    def after(k):
-        o, cn = r.bufs[k % NBUF]
-        packed = lm.pack_matches(o, cn)
-        send_msg(out, b"DONE", struct.pack("<ii", k, len(packed)) + cn.tobytes() + packed.tobytes())
-
-    send_msg(out, b"REDY")
-    while True:
-        tag, payload = recv_msg(inp)
-        if tag == b"RUN_":
-            r.run_steps(struct.unpack("<i", payload)[0], after_step=after)
-            send_msg(out, b"REND")
-        elif tag == b"PROF":
-            r.det.set_profiling(payload == b"1")
-            send_msg(out, b"OK__")
-        elif tag == b"REPT":
-            send_msg(out, b"REPT", json.dumps(r.report()).encode())
-        elif tag == b"QUIT":
-            break
-    r.det.close()
-
-
-class Worker:
-    """Parent side of worker_main."""
-
-    def __init__(self, args, rank, world, local_rank):
-        import subprocess
-        cmd = [sys.executable, os.path.abspath(__file__), "--worker", "1", "--worker-rank", str(rank),
-               "--worker-world", str(world), "--worker-local-rank", str(local_rank), "--batch", str(args.batch),
-               "--templates", str(args.templates), "--threshold", repr(args.threshold), "--lanes", str(args.lanes)]
-        if args.byte_responses:
-            cmd.append("--byte-responses")
-        self.p = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE)
-        self.B = args.batch
-
-    def send(self, tag, payload=b""):
-        send_msg(self.p.stdin, tag, payload)
-
-    def recv(self, expect):
-        return recv_msg(self.p.stdout, expect)[1]
-
-    def recv_step(self, dtype):
-        """-> (k, counts[B], packed records) of the next finished step."""
-        payload = self.recv(b"DONE")
-        k, total = struct.unpack("<ii", payload[:8])
-        counts = np.frombuffer(payload, np.int32, self.B, 8)
-        packed = np.frombuffer(payload, dtype, total, 8 + 4 * self.B)
-        return k, counts, packed
-
-    def close(self):
-        try:
-            self.send(b"QUIT")
-            self.p.wait(timeout=60)
-        except Exception:                                  # noqa: BLE001
-            self.p.kill()
 
 
 def main():
@@ -218,27 +210,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[] entry (2 or 3)")
     ap.add_argument("--batch", type=int, default=256, help="frames per step (resident in HBM)")
     ap.add_argument("--lanes", type=int, default=0, choices=(0, 1, 2),
                     help="2 (= 0, the default): the step's frames are split over the detector's two lanes (two HIP "
-                         "streams driven by one host thread through lm_match_begin / lm_match_end) so that the stages "
-                         "of one half overlap those of the other (the scan is L1/L2-bound, the preprocess passes VALU "
-                         "/ fabric-bound)")
-    ap.add_argument("--templates", type=int, default=3000, help="templates per GPU")
+                         "streams driven by one host thread) so that the stages of one half overlap those of the other")
+    ap.add_argument("--templates", type=int, default=3000, help="templates per GPU (weak) / in the whole bank (strong)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--threshold", type=float, default=80.0)
+    ap.add_argument("--gather-cap", type=int, default=0, help="lm_comm_init recs_per_frame_cap (0 = 256)")
     ap.add_argument("--byte-responses", action="store_true", help="LM_FLAG_BYTE_RESPONSES: byte scan kernel (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the h2d_inclusive (streaming) leg")
     ap.add_argument("--functional-gloo", action="store_true",
                     help="functional check of the N > 1 path on a 1-GPU box: every rank uses cuda:0 and the exchange "
-                         "goes through gloo on the host (never a measurement)")
+                         "goes through torch.distributed/gloo on the host (never a measurement; RCCL refuses two ranks "
+                         "on one device)")
+    ap.add_argument("--force-rccl", action="store_true",
+                    help="use the RCCL exchange even with one rank (single-rank communicator: exercises the whole "
+                         "gathered path on a 1-GPU box)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
-    ap.add_argument("--worker", default=None, help=argparse.SUPPRESS)            # internal: matcher process of a rank
-    ap.add_argument("--worker-rank", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--worker-world", type=int, default=1, help=argparse.SUPPRESS)
-    ap.add_argument("--worker-local-rank", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
-    if args.worker:
-        return worker_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -247,169 +239,156 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if args.functional_gloo:
         local_rank = 0
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-    # The matcher never shares a process with torch: with torch loaded the detector's two HIP streams no longer
-    # overlap (measured on the MI355X box, 100 steps of 128 frames: 93.8 K detections/s without `import torch`,
-    # 76 K with it, whatever the initialisation order, thread counts or synchronisation calls; one lane is
-    # unaffected: 85 K both ways).  One GPU: no torch at all (inputs and results are numpy, lm_synchronize is the
-    # device-wide synchronisation).  N > 1: this process keeps torch.distributed (RCCL) for the exchange and a
-    # torch-free worker process, started before anything here touches the GPU, runs the matcher; the two talk over
-    # a pipe.
+    # No torch in this process: torch's wheel bundles its own ROCm 7.0.2 libamdhip64 / libhsa-runtime64 with the same
+    # sonames as /opt/rocm's 7.2 ones; once it is imported the matcher runs on THAT runtime, under which the detector's
+    # two streams overlap far less (measured r02: 99.9 K detections/s without torch, 88.2 K with it; one lane 92.7 K
+    # either way).  The exchange is RCCL called from the C++ library.
     lm = importlib.import_module("line-mod-pipeline_amd")
-    runner = worker = gather = torch = dist = None
-    if world == 1:
-        runner = Runner(args, rank, world, local_rank)
-        det = runner.det
-    else:
-        worker = Worker(args, rank, world, local_rank)
-        import torch
+    exchange = "gloo" if (args.functional_gloo and world > 1) else ("rccl" if (world > 1 or args.force_rccl) else "none")
+    runner = Runner(args, rank, world, local_rank, exchange)
+    det = runner.det
+    gather = dist = None
+    state = {"merged": None}
+    if exchange == "gloo":
         import torch.distributed as dist
         distmod = importlib.import_module("line-mod-pipeline_amd.dist")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if args.functional_gloo:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            device = torch.device("cpu")
-        else:
-            device = torch.device("cuda", local_rank)
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
-        gather = distmod.ShardGather(lm.merge_matches, cap=CAP, pack_fn=lm.pack_matches, merge_batch_fn=lm.merge_batch,
-                                     device=device)
-        worker.recv(b"REDY")
-    state = {"merged": None}
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        gather = distmod.ShardGather(lm.merge_matches, cap=CAP, pack_fn=lm.pack_matches, merge_batch_fn=lm.merge_batch)
+
+    def after_step(k):
+        o, cn = runner.bufs[k % NBUF]
+        state["merged"] = gather.gather_merge_packed(lm.pack_matches(o, cn), cn, owned_only=True)
 
     def run_steps(n):
-        """One GPU: the matcher's own loop.  N > 1: the worker runs the steps; this process gathers step k's lists of
-        every shard (two small collectives) as soon as the worker reports it and merges the frames it owns
-        (lm_merge_frames; the ranks share the merge by frame), while the GPU already works on step k + 1."""
-        if n <= 0:
-            return
-        if runner is not None:
-            return runner.run_steps(n)
-        worker.send(b"RUN_", struct.pack("<i", n))
-        for _ in range(n):
-            _, counts, packed = worker.recv_step(lm.MATCH_DTYPE)
-            state["merged"] = gather.gather_merge_packed(packed, counts, owned_only=True)
-        worker.recv(b"REND")
+        runner.run_steps(n, after_step=after_step if exchange == "gloo" else None)
 
     def fence():
-        # N > 1: barrier + torch.cuda.synchronize() (the worker's lm_match_end has synchronised its streams before
-        # it reported a step).  N = 1: the same device-wide synchronisation without torch.
-        if world > 1:
+        # a barrier over the ranks + a device-wide synchronisation on both sides of the timed region
+        if exchange == "rccl":
+            det.comm_barrier()                          # hipDeviceSynchronize + ncclAllReduce + hipDeviceSynchronize
+        elif exchange == "gloo":
+            det.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
         else:
             det.synchronize()                           # hipDeviceSynchronize
 
     run_steps(args.warmup)
-    if runner is not None:
-        det.set_profiling(True)
-    else:
-        worker.send(b"PROF", b"1")
-        worker.recv(b"OK__")
+    det.set_profiling(True)
     fence()
     t0 = time.perf_counter()
     run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
-    merged = state["merged"]
-    one_lane = None
-    if runner is not None:
-        rep = runner.report()
-        det.set_profiling(False)
-        one_lane = runner.one_lane_profile()
-    else:
-        worker.send(b"REPT")
-        rep = json.loads(worker.recv(b"REPT").decode())
-    prof, Bl, NL = rep["prof"], rep["Bl"], rep["NL"]
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    rep = runner.report()
+    det.set_profiling(False)
+    one_lane = runner.one_lane_profile()
+    if exchange == "rccl":
+        dt = det.comm_max([dt])[0]
+    elif exchange == "gloo":
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    prof, Bl, NL = rep["prof"], rep["Bl"], rep["NL"]
     B = args.batch
-    n_total = args.templates * world
-    frames_done = B * args.steps
-    fps = frames_done / dt
-    # N > 1: merged = (first owned frame, merged lists of the frames this rank owns); frame 0 belongs to rank 0
-    n_matches0 = rep["matches0"] if merged is None else (len(merged[1][0]) if merged[1] else 0)
+    fps = B * args.steps / dt
+    if exchange == "rccl":
+        n_matches0 = runner.last_owned[2] if runner.last_owned else 0        # merged list of the first owned frame
+    elif exchange == "gloo":
+        merged = state["merged"]
+        n_matches0 = len(merged[1][0]) if merged and merged[1] else 0
+    else:
+        n_matches0 = rep["matches0"]
 
-    # ---- roofline of the dominant kernel (similarity scan): algorithmic bytes / HIP-event time
-    scan_us = prof["stage_us"][1] / max(prof["launches"], 1)
-    bytes_per_launch = prof["scan_bytes"] / max(prof["launches"], 1)
-    achieved = bytes_per_launch / (scan_us * 1e-6) / 1e9 if scan_us > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(Bl)
-    l2_bytes = rep["scan_load_bytes"] * Bl         # bytes the scan's vector loads request per launch
-    l2_rate = l2_bytes / (scan_us * 1e-6) / 1e9 if scan_us > 0 else 0.0
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "k_scan4" if not args.byte_responses else "k_scan", "avg_launch_us": round(scan_us, 2),
-                "algorithmic_bytes_per_launch": bytes_per_launch, "frames_per_launch": Bl,
-                "on_chip": {"bound": "l2", "load_bytes_per_launch": l2_bytes, "achieved": round(l2_rate, 1),
-                            "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(l2_rate / L2_PEAK_GBS, 4)},
-                "note": "the scanned level's linear memories (0.6 MB/frame, nibble-packed) are L2-resident: the "
-                        "algorithmic bytes are served by the L2s (on_chip: what the vector loads really request vs "
-                        "the guide's 34.5 TB/s aggregate L2 rate); HBM traffic is ~1% of them (see DESIGN.md)"}
-    stage_us_per_frame = [round(v / max(prof["frames"], 1), 2) for v in prof["stage_us"]]
-    if one_lane is not None and one_lane["launches"]:
-        ol_us = one_lane["stage_us"][1] / one_lane["launches"]
-        ol_bytes = one_lane["scan_bytes"] / one_lane["launches"]
-        roofline["one_lane"] = {
-            "avg_launch_us": round(ol_us, 2), "achieved": round(ol_bytes / (ol_us * 1e-6) / 1e9, 1),
-            "frac": round(ol_bytes / (ol_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-            "on_chip_achieved": round(l2_bytes / (ol_us * 1e-6) / 1e9, 1),
-            "on_chip_frac": round(l2_bytes / (ol_us * 1e-6) / 1e9 / L2_PEAK_GBS, 4),
-            "stage_us_per_frame": dict(zip(["preprocess", "scan", "refine", "sort"],
-                                           [round(v / max(one_lane["frames"], 1), 2) for v in one_lane["stage_us"]])),
-            "note": "same launches on one lane with nothing running beside them, 10 steps after the timed region"}
+    # ---- roofline of the dominant kernel (similarity scan)
+    kernel = "k_scan4" if not args.byte_responses else "k_scan"
+    l2_bytes = rep["scan_load_bytes"] * Bl             # bytes the scan's vector loads request per launch
+    span_us = prof["stage_us"][1] / max(prof["launches"], 1)
+    alg_bytes = prof["scan_bytes"] / max(prof["launches"], 1)
+    ol_us = one_lane["stage_us"][1] / max(one_lane["launches"], 1)
+    traffic, traffic_src = pmc_traffic(args.config, Bl)
+
+    def rate(nbytes, us):
+        return nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+
+    roofline = {
+        "bound": "l2", "achieved": round(rate(l2_bytes, ol_us), 1), "peak": L2_PEAK_GBS, "unit": "GB/s",
+        "frac": round(rate(l2_bytes, ol_us) / L2_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "kernel": kernel, "avg_launch_us": round(ol_us, 2), "frames_per_launch": Bl, "load_bytes_per_launch": l2_bytes,
+        "measured": "HIP events on the launch stream around every %s launch of %d launches (%d frames each) on one lane "
+                    "with nothing running beside them, in this process right after the timed region; rocprofv3 "
+                    "--kernel-trace --stats of `bench.py --lanes 1` agrees (profiles/)" % (kernel, one_lane["launches"], Bl),
+        "why_l2": "the scanned level's linear memories (nibble-packed, 0.6 MB per 640x480 frame) are L2-resident: the "
+                  "kernel is bound by what its vector loads request from the L2s (load_bytes_per_launch) against the "
+                  "guide's 34.5 TB/s aggregate L2 rate; HBM traffic (`traffic`, PMC) is ~0.4 % of the algorithmic bytes",
+        "hbm_algorithmic": {
+            "bound": "hbm", "achieved": round(rate(alg_bytes, ol_us), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(rate(alg_bytes, ol_us) / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg_bytes,
+            "note": "SURVEY.md 8d yard-stick: sum over templates and modalities of features x scanned positions, one "
+                    "byte each, divided by the same clean launch duration; > 1 because the bytes come from L2"},
+        "timed_region": {
+            "avg_span_us": round(span_us, 2), "lanes": NL,
+            "note": "HIP-event span around the scan launch inside the timed, two-lane run: it contains time in which "
+                    "the other lane's kernels hold the chip, so it is not a kernel duration"},
+        "stage_us_per_frame_one_lane": dict(zip(["preprocess", "scan", "refine", "sort"],
+                                                [round(v / max(one_lane["frames"], 1), 2) for v in one_lane["stage_us"]])),
+    }
 
     result = None
+    h2d = cpu = None
+    if world == 1 and not args.no_h2d:
+        try:
+            h2d = runner.streaming(max(args.steps // 4, 8))
+        except Exception as e:                          # the bench line must still be printed
+            h2d = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
-        cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args, runner.frames, runner.descs, runner.feats, det, lm)
+            cpu = cpu_baseline(args, runner, lm)
+        wl = CONFIGS[args.config]
         result = {
-            "metric": "detections/sec", "value": round(world * fps, 1), "unit": "detections/s",
+            "metric": "detections/sec", "value": round(fps, 1), "unit": "detections/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "SURVEY 8d config 2: 640x480 RGB-D, ColorGradient+DepthNormal, T={5,8}, "
-                                   "2-level pyramid, fixed-geometry 96x96 templates, threshold %g" % args.threshold,
-                       "templates_per_gpu": args.templates, "templates_total": n_total, "frames_per_step": B,
-                       "lanes": NL,
-                       "frames_per_sec": round(fps, 1), "matches_frame0": n_matches0,
-                       "unit_definition": "one detection = one frame matched against one %d-template bank shard; "
-                                          "N GPUs search N shards of the same frames" % args.templates,
-                       "stage_us_per_frame": dict(zip(["preprocess", "scan", "refine", "sort"], stage_us_per_frame)),
-                       "stage_note": "HIP-event spans on each lane's stream per frame of that lane; with two lanes the "
-                                     "spans of one lane contain kernels of the other, so they add up to more than the "
-                                     "wall time per frame",
+            "config": {"workload": wl["name"] + ", threshold %g" % args.threshold,
+                       "baseline_config": args.config,
+                       "templates_per_gpu": runner.n_total // world, "templates_total": runner.n_total,
+                       "frames_per_step": B, "lanes": NL, "frames_per_sec": round(fps, 1), "matches_frame0": n_matches0,
+                       "unit_definition": "one detection = one frame answered against the whole %d-template bank "
+                                          "(input frames resident in HBM)" % runner.n_total,
+                       "template_frames_per_sec": round(fps * runner.n_total, 1),
+                       "exchange": {"none": "single GPU", "gloo": "torch.distributed gloo (functional check only)",
+                                    "rccl": "2 x ncclAllGather per lane-step from liblinemod_hip.so on the lane's stream; "
+                                            "each rank merges the frames it owns"}[exchange],
+                       "h2d_inclusive": h2d,
                        "parallelism": "template-shard x%d" % world},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         print(json.dumps(result))
-    if runner is not None:
-        det.close()
-    else:
-        worker.close()
+        sys.stdout.flush()
+    if exchange == "gloo":
         dist.barrier()
         dist.destroy_process_group()
+    det.close()
     return result
 
 
-def pmc_traffic(frames_per_launch):
-    """HBM bytes per k_scan launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/summarize_pmc.py: 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes).  PMC counters cannot be read
-    from inside the process, so this is null unless a committed pass matches frames_per_launch."""
+def pmc_traffic(config, frames_per_launch):
+    """HBM bytes per scan launch from the committed rocprofv3 PMC passes of this same command (profiles/summarize_pmc.py:
+    2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes).  PMC counters cannot be read from inside the process, so this is null
+    unless a committed pass matches the config and frames_per_launch."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_batch*.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_*.json")), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
-        if d.get("frames_per_launch") != frames_per_launch:
+        if d.get("frames_per_launch") != frames_per_launch or d.get("baseline_config", 2) != config:
             continue
         for k, v in d.get("kernels", {}).items():
             if k.startswith("k_scan"):
@@ -426,20 +405,27 @@ def cgroup_cpus():
         return None
 
 
-def cpu_baseline(args, frames, descs, feats, det, lm):
-    """The CPU oracle (kind "port": a restatement, the reference itself cannot be built here) on this
-    host's cores, bounded sample, same frames and bank; its match list must equal the GPU's first."""
+def cpu_baseline(args, runner, lm):
+    """The CPU oracle (kind "port": a restatement, the reference itself cannot be built here) on this host's cores,
+    bounded sample, same frames and bank; the GPU's match lists of the first four frames must equal the oracle's
+    before the timing is accepted."""
     try:
         from oracle import oracle as O
         lib = O.build(arch="-march=native")
         cores = os.cpu_count() or 1
-        orc = O.Detector(color_only=False, lib_path=lib)
-        orc.add_class("synthetic.ply", descs, feats)
+        color_only = runner.M == 1
+        orc = O.Detector(color_only=color_only, lib_path=lib)
+        orc.add_class("synthetic.ply", runner.descs, runner.feats)
+        det, frames, thr = runner.det, runner.frames, args.threshold
+        for i in range(min(4, len(frames))):
+            bgr, depth = frames[i]
+            det.upload_frame(i, bgr, None if color_only else depth)
+            gpu = det.match_slot(i, thr, 0)
+            exp = orc.match(bgr, None if color_only else depth, thr, 0, threads=min(cores, 16))
+            if gpu.tobytes() != exp.tobytes():
+                return {"error": "GPU match list of frame %d differs from the oracle: timing not accepted" % i}
         bgr, depth = frames[0]
-        gpu = det.match_slot(0, args.threshold, 0)
-        exp = orc.match(bgr, depth, args.threshold, 0, threads=min(cores, 16))
-        if gpu.tobytes() != exp.tobytes():
-            return {"error": "GPU match list differs from the oracle: timing not accepted"}
+        depth = None if color_only else depth
         # all logical CPUs is not always fastest (SMT / cgroup CPU quota): take the best of a few team sizes
         cand = {cores, max(cores // 2, 1), max(cores // 4, 1)}
         quota = cgroup_cpus()
@@ -448,7 +434,7 @@ def cpu_baseline(args, frames, descs, feats, det, lm):
         best_t, threads = None, cores
         for th in sorted(cand):
             t1 = time.perf_counter()
-            orc.match(bgr, depth, args.threshold, 0, threads=th)
+            orc.match(bgr, depth, thr, 0, threads=th)
             t = time.perf_counter() - t1
             if best_t is None or t < best_t:
                 best_t, threads = t, th
@@ -456,19 +442,19 @@ def cpu_baseline(args, frames, descs, feats, det, lm):
         n = 0
         while True:
             b, d = frames[n % len(frames)]
-            orc.match(b, d, args.threshold, 0, threads=threads)
+            orc.match(b, None if color_only else d, thr, 0, threads=threads)
             n += 1
             if time.perf_counter() - t0 >= args.cpu_seconds or n >= 5000:
                 break
         dt = time.perf_counter() - t0
         t1 = time.perf_counter()
-        orc.match(bgr, depth, args.threshold, 0, threads=1)
+        orc.match(bgr, depth, thr, 0, threads=1)
         single = time.perf_counter() - t1
         return {"value": round(n / dt, 3), "unit": "detections/s", "cores": threads, "kind": "port",
                 "sample": "%d full frames (a3-a15, same bank of %d templates) in %.1f s; OpenMP over templates and "
                           "over image rows, %d threads (fastest of {1/4, 1/2, all} of %d logical CPUs and {1, 2} x the "
                           "cgroup CPU quota of %s); upstream-faithful single-thread run: %.3f s/frame; GPU and CPU "
-                          "match lists identical" % (n, args.templates, dt, threads, cores, quota or "none", single)}
+                          "match lists of 4 frames identical" % (n, runner.n_total, dt, threads, cores, quota or "none", single)}
     except Exception as e:  # the bench line must still be printed
         return {"error": "%s: %s" % (type(e).__name__, e)}
 

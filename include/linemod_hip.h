@@ -139,7 +139,7 @@ int lm_match(lm_detector* det, const uint8_t* bgr, size_t bgr_stride, const uint
  *
  * Streaming input (the reference's real call pattern is one fresh camera frame per detect() call,
  * detector.cpp:17-42 -> PoseDetection.cpp:66): uploads are ASYNCHRONOUS.  lm_upload_frame packs the (pageable,
- * strided) source into the slot's pinned staging buffer and enqueues the H2D copies on the detector's copy stream,
+ * strided) source into the slot's pinned staging buffer and enqueues the H2D copies on one of the detector's copy streams,
  * behind which it records the slot's "uploaded" event; it returns without waiting for the copy and without touching
  * any compute stream.  Every lm_match_slot / lm_match_batch / lm_match_begin makes its stream wait for the uploads
  * of the slots it reads (hipStreamWaitEvent), so
@@ -153,6 +153,10 @@ int lm_upload_frame(lm_detector* det, int slot, const uint8_t* bgr, size_t bgr_s
  * or a match that covers the slot has been collected.  This is the path that reaches the PCIe rate. */
 int lm_upload_frame_pinned(lm_detector* det, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
                            size_t depth_stride);
+/* A run of frames in ONE strided transfer: host frame i = [colour dense | depth dense] (colour only for a colour-only
+ * detector) at frames + i * frame_stride (0 = densely packed), pinned, into slots [first_slot, first_slot + n_slots).
+ * lm_upload_frame_pinned makes the same single copy per frame when it is handed such a contiguous pair. */
+int lm_upload_frames_pinned(lm_detector* det, int first_slot, int n_slots, const uint8_t* frames, size_t frame_stride);
 /* Host waits until the upload of `slot` (-1: of every slot) has landed in device memory. */
 int lm_upload_wait(lm_detector* det, int slot);
 /* Pinned host memory for frame sources (hipHostMalloc); needs a HIP device. */
@@ -168,6 +172,9 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
  *   image, 0 = inline on the compute stream (default). */
 #define LM_TUNE_FORK_MAX_SLOTS 1
 #define LM_TUNE_MATCH_UPLOAD_MODE 2
+/* LM_TUNE_COPY_STREAMS: copy streams the uploads are dealt to, slot -> stream round-robin (1..4, default 4: one
+ *   in-order stream moved 0.6-0.9 MB images at 25.6 GB/s, several keep several DMA engines busy). */
+#define LM_TUNE_COPY_STREAMS 3
 int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 /* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame
@@ -189,6 +196,32 @@ int lm_match_begin(lm_detector* det, int lane, int first_slot, int n_slots, floa
 /* hipDeviceSynchronize() on the detector's device (what torch.cuda.synchronize() is for a torch program). */
 int lm_synchronize(lm_detector* det);
 int lm_match_end(lm_detector* det, int lane, lm_match_t* out, size_t cap_per_frame, int32_t* counts);
+
+/* ---- multi-GPU: template-bank shards + the ONE exchange step of the path ------------------------
+ * One process per GPU; every rank creates its detector with lm_config.shard_rank / shard_size (contiguous template_id
+ * ranges, global ids preserved), uploads the SAME frames and calls the same sequence of lm_match_begin_gathered /
+ * lm_match_end_gathered.  lm_comm_init creates the RCCL communicators (librccl is loaded then, not before; one
+ * communicator per lane so that the lanes' collectives never wait for each other); the ncclUniqueId goes from rank 0
+ * to the others over TCP addr:port (one node: "127.0.0.1", e.g. MASTER_PORT + 1) -- no torch, no MPI, no second
+ * process.  recs_per_frame_cap (0 = 256): average records per frame a rank may contribute to one gather; the gather
+ * buffers have a fixed size of n_frames * recs_per_frame_cap records per rank so that no host round trip sits between
+ * the two collectives.  More records than that is LM_ERR_OVERFLOW, never a silent truncation (the reference consumes
+ * ALL matches: HighLevelLinemod.cpp:206-253). */
+int lm_comm_init(lm_detector* det, int rank, int world, const char* addr, int port, int recs_per_frame_cap);
+int lm_comm_destroy(lm_detector* det);
+int lm_comm_info(const lm_detector* det, int* rank, int* world);
+/* lm_match_begin + behind the sort kernel, on the lane's stream: k_pack_lists (the lane's sorted lists back to back +
+ * their lengths, device buffers), ncclAllGather of the lengths, ncclAllGather of the packed records, D2H of both. */
+int lm_match_begin_gathered(lm_detector* det, int lane, int first_slot, int n_slots, float threshold, int class_idx);
+/* Waits for the lane, then merges (R-way merge + adjacent-unique, lm_merge_frames) the frames THIS RANK OWNS: frames
+ * [n * rank / R, n * (rank + 1) / R) of the lane's n frames (*first_frame, *n_frames), so the host work per rank does
+ * not grow with R.  out: the owned frames' merged lists back to back (cap records), counts[i] their lengths. */
+int lm_match_end_gathered(lm_detector* det, int lane, lm_match_t* out, size_t cap, int32_t* counts, int* first_frame,
+                          int* n_frames, size_t* n_out);
+/* Every rank has reached this call and every rank's device is idle (ncclAllReduce + hipDeviceSynchronize): the
+ * "barrier + synchronize" that brackets a timed region.  lm_comm_max: element-wise maximum of n <= 32 doubles. */
+int lm_comm_barrier(lm_detector* det);
+int lm_comm_max(lm_detector* det, double* values, int n);
 
 /* R-way merge of per-shard sorted lists + adjacent-unique: the step after the all-gather (8e).  Host-side. */
 int lm_merge_matches(const lm_match_t* lists, const int32_t* counts, int n_lists, size_t stride, lm_match_t* out,

@@ -37,6 +37,7 @@ FLAG_BYTE_RESPONSES = 1
 FLAG_BLOCKING_SYNC = 2
 TUNE_FORK_MAX_SLOTS = 1
 TUNE_MATCH_UPLOAD_MODE = 2
+TUNE_COPY_STREAMS = 3
 
 
 class Rect(C.Structure):
@@ -62,7 +63,8 @@ EXPORTS = [
     "lm_save_yaml", "lm_load_yaml", "lm_yaml_numbers", "lm_yaml_string", "lm_pack_matches", "lm_merge_batch",
     "lm_match_begin", "lm_match_end", "lm_synchronize", "lm_merge_frames",
     "lm_upload_frame_pinned", "lm_upload_wait", "lm_host_alloc", "lm_host_free", "lm_set_stage_chunks",
-    "lm_set_tuning",
+    "lm_set_tuning", "lm_comm_init", "lm_comm_destroy", "lm_comm_info", "lm_match_begin_gathered",
+    "lm_match_end_gathered", "lm_comm_barrier", "lm_comm_max", "lm_upload_frames_pinned",
 ]
 
 _lib = None
@@ -136,11 +138,19 @@ def load_library(path=None):
     lib.lm_synchronize.argtypes = [vp]
     lib.lm_upload_frame_pinned.argtypes = [vp, i, vp, sz, vp, sz]
     lib.lm_upload_wait.argtypes = [vp, i]
+    lib.lm_upload_frames_pinned.argtypes = [vp, i, i, vp, sz]
     lib.lm_host_alloc.argtypes = [sz, C.POINTER(vp)]
     lib.lm_host_free.argtypes = [vp]
     lib.lm_host_free.restype = None
     lib.lm_set_stage_chunks.argtypes = [vp, i]
     lib.lm_set_tuning.argtypes = [vp, i, i]
+    lib.lm_comm_init.argtypes = [vp, i, i, C.c_char_p, i, i]
+    lib.lm_comm_destroy.argtypes = [vp]
+    lib.lm_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+    lib.lm_match_begin_gathered.argtypes = [vp, i, i, i, f, i]
+    lib.lm_match_end_gathered.argtypes = [vp, i, vp, sz, vp, C.POINTER(i), C.POINTER(i), C.POINTER(sz)]
+    lib.lm_comm_barrier.argtypes = [vp]
+    lib.lm_comm_max.argtypes = [vp, C.POINTER(C.c_double), i]
     if path is None:
         _lib = lib
     return lib
@@ -416,6 +426,10 @@ class Detector:
             raise ValueError("pinned depth frame must be a C-contiguous uint16 array")
         self._check(self.lib.lm_upload_frame_pinned(self.h, slot, _ptr(bgr), 0, _ptr(depth), 0))
 
+    def upload_frames_pinned(self, first_slot, n_slots, frames_ptr, frame_stride=0):
+        """frames_ptr: address (int / c_void_p) of n_slots pinned host frames, each [colour | depth] dense."""
+        self._check(self.lib.lm_upload_frames_pinned(self.h, first_slot, n_slots, C.c_void_p(frames_ptr), frame_stride))
+
     def upload_wait(self, slot=-1):
         self._check(self.lib.lm_upload_wait(self.h, slot))
 
@@ -449,6 +463,32 @@ class Detector:
     def match_begin(self, lane, first_slot, n_slots, threshold, class_idx=-1):
         """Enqueue the match of the resident frames in slots [first_slot, first_slot + n_slots) on `lane` (0 or 1)."""
         self._check(self.lib.lm_match_begin(self.h, lane, first_slot, n_slots, threshold, class_idx))
+
+    # ---- multi-GPU exchange (RCCL, include/linemod_hip.h "multi-GPU") ---------------------------
+    def comm_init(self, rank, world, addr="127.0.0.1", port=29511, recs_per_frame_cap=0):
+        self._check(self.lib.lm_comm_init(self.h, rank, world, addr.encode(), port, recs_per_frame_cap))
+
+    def comm_destroy(self):
+        self._check(self.lib.lm_comm_destroy(self.h))
+
+    def comm_barrier(self):
+        self._check(self.lib.lm_comm_barrier(self.h))
+
+    def comm_max(self, values):
+        v = (C.c_double * len(values))(*values)
+        self._check(self.lib.lm_comm_max(self.h, v, len(values)))
+        return list(v)
+
+    def match_begin_gathered(self, lane, first_slot, n_slots, threshold, class_idx=-1):
+        self._check(self.lib.lm_match_begin_gathered(self.h, lane, first_slot, n_slots, threshold, class_idx))
+
+    def match_end_gathered(self, lane, out, counts):
+        """-> (first owned frame, n owned frames, total records): merged lists of the frames this rank owns, back to
+        back in `out`, lengths in counts[:n]."""
+        f0, nf, n = C.c_int(), C.c_int(), C.c_size_t()
+        self._check(self.lib.lm_match_end_gathered(self.h, lane, _ptr(out), out.size, _ptr(counts), C.byref(f0),
+                                                   C.byref(nf), C.byref(n)))
+        return f0.value, nf.value, n.value
 
     def match_end(self, lane, cap_per_frame=4096, out=None, counts=None, n_slots=None):
         """Wait for `lane` and fetch its lists (same layout as match_batch)."""

@@ -11,9 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "liblinemod_hip.so")
-HIP_SOURCES = ["lm_kernels.hip", "lm_detector.hip"]
+HIP_SOURCES = ["lm_kernels.hip", "lm_detector.hip", "lm_comm.hip"]
 CXX_SOURCES = ["lm_host.cpp", "lm_extract.cpp", "lm_yaml.cpp"]
-HEADERS = ["lm_common.h", "lm_kernels.h", "lm_host.h", "lm_extract.h", "lm_median25.h", os.path.join("..", "..", "include", "linemod_hip.h")]
+HEADERS = ["lm_common.h", "lm_kernels.h", "lm_host.h", "lm_extract.h", "lm_median25.h", "lm_yaml.h", "lm_comm.h",
+           os.path.join("..", "..", "include", "linemod_hip.h")]
 # -ffp-contract=off: the two float islands (fastAtan2 polynomial, normal normalisation, raw threshold)
 # must round exactly like the oracle, which is built the same way.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
@@ -33,11 +34,14 @@ def build(force=False, verbose=False):
     obj_dir = os.path.join(HERE, "build")
     os.makedirs(obj_dir, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in HEADERS]
+    for h in headers:
+        if not os.path.exists(h):
+            raise FileNotFoundError("header missing from the checkout: " + h)
     objs = []
     for src in HIP_SOURCES + CXX_SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
-            continue
+            raise FileNotFoundError("source file missing from the checkout: " + sp)
         obj = os.path.join(obj_dir, src + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + headers + [os.path.abspath(__file__)]):
@@ -51,7 +55,7 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-lz"]
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-lz", "-ldl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

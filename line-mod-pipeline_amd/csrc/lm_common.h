@@ -71,7 +71,8 @@ struct LmRefMeta {
 struct LmDevHeader {
     u32 cand_count;      // candidates produced by the scan (may exceed capacity)
     u32 match_count;     // refined matches that passed the threshold (may exceed capacity)
-    u32 pad[2];
+    u32 pad[2];          // pad[0]: length of the sorted unique list k_sort_unique left in `out` (0xFFFFFFFF: none, the
+                         //         host sorts), read by k_pack_lists
 };
 
 // Same layout as lm_match_t of the C ABI.

@@ -93,3 +93,15 @@ struct LmSortArgs {
 };
 // a15: sort + adjacent-unique of up to LM_SORT_CAP keys, one workgroup per slot.
 void lmk_sort_unique(hipStream_t s, const LmSortArgs& a, int nslots);
+
+struct LmPackArgs {
+    const LmDevHeader* hdr;  // slot 0 of the range; aux_slot_stride apart (pad[0] = length of the sorted list)
+    const LmOutMatch* out;   // sorted lists, LM_SORT_CAP records per slot
+    size_t aux_slot_stride;
+    int nslots;
+    u32 cap_total;           // records `rec` can hold
+    int* cnt;                // [nslots + 1]: list lengths, then the status word
+    LmOutMatch* rec;         // packed lists
+};
+// 8e: the sorted lists of nslots frames back to back + their lengths (a rank's contribution to the all-gather).
+void lmk_pack_lists(hipStream_t s, const LmPackArgs& a);

@@ -1537,6 +1537,7 @@ __global__ __launch_bounds__(1024) void k_sort_unique(LmSortArgs a) {
         if (tid == 0) {
             hb->hdr.cand_count = cand_count; hb->hdr.match_count = match_count;
             hb->hdr.out_count = 0; hb->hdr.sorted_on_device = 0;
+            hdr->pad[0] = 0xFFFFFFFFu;   // no device-side list for k_pack_lists
         }
         return;
     }
@@ -1632,7 +1633,35 @@ __global__ __launch_bounds__(1024) void k_sort_unique(LmSortArgs a) {
     if (tid == 0) {
         hb->hdr.cand_count = cand_count; hb->hdr.match_count = match_count;
         hb->hdr.out_count = base; hb->hdr.sorted_on_device = 1;
+        hdr->pad[0] = base;              // length of the sorted list in `out` (k_pack_lists)
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 8e  Packs the sorted lists of `nslots` frames back to back (what a rank contributes to the all-gather): workgroup i
+// adds up the lengths of the lists before its own and copies list i behind them.  cnt[i] = length of list i,
+// cnt[nslots] = status (0 ok, bit 0: the lists do not fit cap_total records, bit 1: a list was left to the host sort).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_lists(LmPackArgs a) {
+    __shared__ u32 part[4];
+    const int tid = threadIdx.x, slot = blockIdx.x;
+    u32 s = 0;
+    for (int j = tid; j < slot; j += 256) {
+        const u32 c = slot_ptr_s(a.hdr, a.aux_slot_stride, (u32)j)->pad[0];
+        s += c == 0xFFFFFFFFu ? 0u : c;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += (u32)__shfl_xor((int)s, o, 64);
+    if ((tid & 63) == 0) part[tid >> 6] = s;
+    __syncthreads();
+    const u32 prefix = part[0] + part[1] + part[2] + part[3];
+    u32 mine = slot_ptr_s(a.hdr, a.aux_slot_stride, (u32)slot)->pad[0];
+    if (mine == 0xFFFFFFFFu) { mine = 0; if (tid == 0) atomicOr(reinterpret_cast<u32*>(a.cnt + a.nslots), 2u); }
+    if (tid == 0) a.cnt[slot] = (int)mine;
+    if (prefix + mine > a.cap_total) { if (tid == 0) atomicOr(reinterpret_cast<u32*>(a.cnt + a.nslots), 1u); return; }
+    const u32* src = reinterpret_cast<const u32*>(slot_ptr_s(a.out, a.aux_slot_stride, (u32)slot));
+    u32* dst = reinterpret_cast<u32*>(a.rec) + (size_t)prefix * 5;
+    for (u32 i = tid; i < mine * 5u; i += 256) dst[i] = src[i];
 }
 
 // materialises the NN pyramid of the depth modality's quantised image (levels >= 2, stage hooks)
@@ -1811,6 +1840,11 @@ void lmk_refine(hipStream_t s, const LmRefineArgs& a_in, bool last, int nslots) 
 
 void lmk_emit_unrefined(hipStream_t s, const LmRefineArgs& a, int nslots) {
     hipLaunchKernelGGL(k_emit_unrefined, dim3(64, 1, nslots), dim3(256), 0, s, a);
+}
+
+void lmk_pack_lists(hipStream_t s, const LmPackArgs& a) {
+    (void)hipMemsetAsync(a.cnt + a.nslots, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_pack_lists, dim3((unsigned)a.nslots), dim3(256), 0, s, a);
 }
 
 void lmk_sort_unique(hipStream_t s, const LmSortArgs& a, int nslots) {

@@ -3,7 +3,7 @@ bench.py command, as MI355X_MICROARCH.md section 'HBM' prescribes) to per-kernel
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dirF> -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <dirW> -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline
-  python profiles/summarize_pmc.py <dirF> <dirW> <frames_per_launch> <out.json>
+  python profiles/summarize_pmc.py <dirF> <dirW> <frames_per_launch> <out.json> [<BASELINE config: 2 | 3>]
 
 Units/corrections (guide): both counters are in KB (x1024); on gfx950 FETCH_SIZE reports exactly 1/2 of
 the bytes of a wide coalesced streaming read (16 B/lane), so it is doubled; WRITE_SIZE is exact for
@@ -30,8 +30,9 @@ def agg(path, cname):
 
 def main():
     dir_f, dir_w, frames, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    config = int(sys.argv[5]) if len(sys.argv) > 5 else 2
     fe, wr = agg(dir_f, "FETCH_SIZE"), agg(dir_w, "WRITE_SIZE")
-    res = {"frames_per_launch": frames, "kernels": {}}
+    res = {"frames_per_launch": frames, "baseline_config": config, "kernels": {}}
     for k in fe:
         v = [x for x, _ in fe[k]][2:]           # skip the warm-up launches
         w = [x for x, _ in wr.get(k, [])][2:]

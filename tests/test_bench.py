@@ -1,5 +1,6 @@
-"""bench.py end to end on the GPU box: the one-GPU line (two lanes, torch-free) and the whole N = 2 path (rank
-processes with torch.distributed + torch-free matcher workers, exchange over gloo because the box has one GPU)."""
+"""bench.py end to end on the GPU box: the one-GPU line (two lanes, torch-free, both BASELINE configs, the streaming
+leg), the RCCL exchange on a single-rank communicator, and the N = 2 path with the exchange over gloo (the box has one
+GPU and RCCL refuses two ranks on one device)."""
 import json
 import os
 import subprocess
@@ -26,9 +27,37 @@ def test_bench_one_gpu_line():
     assert d["metric"] == "detections/sec" and d["n_gpus"] == 1 and d["steps"] == 6 and d["value"] > 0
     assert d["config"]["lanes"] == 2 and d["config"]["frames_per_step"] == 16
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["achieved"] > 0 and rf["frames_per_launch"] == 8
+    assert rf["bound"] == "l2" and rf["achieved"] > 0 and rf["frames_per_launch"] == 8
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert rf["on_chip"]["load_bytes_per_launch"] > 0
+    assert rf["load_bytes_per_launch"] > 0 and rf["hbm_algorithmic"]["algorithmic_bytes_per_launch"] > 0
+    h = d["config"]["h2d_inclusive"]
+    assert h["value"] > 0 and h["h2d_GBps"] > 0 and h["matches_step0_step1"][0] > 0
+    # the streaming leg matches different frames per slot every step
+    assert d["config"]["baseline_config"] == 2
+
+
+@pytest.mark.gpu
+def test_bench_config3_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--no-h2d"] + SMALL,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["config"]["baseline_config"] == 3 and "1280x960" in d["config"]["workload"] and d["value"] > 0
+    # fixed geometry of SURVEY.md 8d config 3: 31 features x P = 3909 positions per template
+    assert d["roofline"]["hbm_algorithmic"]["algorithmic_bytes_per_launch"] == 300 * 31 * 3909 * 8
+
+
+@pytest.mark.gpu
+def test_bench_rccl_single_rank_communicator():
+    """The whole gathered path (k_pack_lists, 2 x ncclAllGather per lane-step, merge of the owned frames) through a
+    single-rank RCCL communicator: what a 1-GPU box can run of the N > 1 path."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-rccl", "--no-h2d"] + SMALL,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["matches_frame0"] > 0
+    assert "ncclAllGather" in d["config"]["exchange"]
 
 
 @pytest.mark.gpu

@@ -148,3 +148,35 @@ def test_single_frame_fork_and_upload_modes(lm, orc, synth, color_only, fork, mo
             d.upload_frame(f, b, None if color_only else dp)
             assert_matches_equal(d.match_slot(f, 70.0), exp[f])       # upload immediately followed by the match
     d.close()
+
+
+@pytest.mark.parametrize("color_only", [False, True])
+def test_batch_upload_one_strided_transfer(lm, orc, synth, color_only):
+    """lm_upload_frames_pinned: a run of [colour | depth] host frames into consecutive slots with one hipMemcpy2DAsync,
+    immediately followed by the match (per-slot events order it); host frame stride larger than a frame."""
+    M = 1 if color_only else 2
+    d = lm.Detector(color_only=color_only, width=W, height=H, frame_slots=8)
+    o = orc.Detector(color_only=color_only)
+    frames = [synth.make_frame(W, H, seed=700 + i) for i in range(5)]
+    o.prepare(frames[0][0], None if color_only else frames[0][1])
+    q = {(l, m): o.stage(0, l, m).reshape(H >> l, W >> l) for l in range(2) for m in range(M)}
+    descs, feats, _ = synth.make_bank(100, M, 2, seed=6, quantized=q, crop_fraction=0.3, frame_size=(W, H), T0=d.get_T(0))
+    d.add_class("c", descs, feats)
+    o.add_class("c", descs, feats)
+    exp = [o.match(b, None if color_only else dp, THR, threads=8) for b, dp in frames]
+    fb = W * H * (3 if color_only else 5)
+    stride = fb + 4096
+    pb = lm.PinnedBuffer(5 * stride)
+    for rnd in range(3):
+        order = [(rnd + 2 * k) % 5 for k in range(5)]
+        for k, f in enumerate(order):
+            pb.view(np.uint8, (H, W, 3), offset=k * stride)[...] = frames[f][0]
+            if not color_only:
+                pb.view(np.uint16, (H, W), offset=k * stride + W * H * 3)[...] = frames[f][1]
+        d.upload_frames_pinned(2, 5, pb.ptr.value, stride)
+        d.match_begin(1, 2, 5, THR, -1)
+        out, cnt = d.match_end(1, n_slots=5)
+        for k, f in enumerate(order):
+            assert_matches_equal(out[k, :cnt[k]], exp[f])
+    d.close()
+    pb.close()

@@ -1,6 +1,10 @@
 """Scratch: one detector, two lanes (lm_match_begin / lm_match_end) from one host thread."""
 import importlib, sys, os, time
 import numpy as np
+import ctypes
+if os.environ.get("PRELOAD"):   # bind the process to the system ROCm runtime before torch can load its bundled copy
+    for lib in ("libhsa-runtime64.so.1", "libamdhip64.so.7"):
+        ctypes.CDLL("/opt/rocm/lib/" + lib, mode=ctypes.RTLD_GLOBAL)
 if os.environ.get("TORCH"):
     import torch
     torch.cuda.set_device(0); torch.cuda.synchronize()
@@ -39,3 +43,7 @@ run(10)
 t0 = time.perf_counter(); run(100); dt = time.perf_counter() - t0
 print("host time per lane-step: begin %.1f us, end (wait + collect) %.1f us" % (tb / (110 * NL) * 1e6, te / (110 * NL) * 1e6))
 print("lanes %d, %d frames per step: %.1f detections/s  (%.2f us/frame)  matches0 %d" % (NL, BT, BT * 100 / dt, dt / 100 / BT * 1e6, outs[0][1][0]))
+
+v = ctypes.c_int()
+ctypes.CDLL("libamdhip64.so.7").hipRuntimeGetVersion(ctypes.byref(v))
+print("HIP runtime version", v.value, "| mapped:", sorted({l.split()[-1] for l in open("/proc/self/maps") if "amdhip64" in l or "hsa-runtime" in l}))
