@@ -93,6 +93,11 @@ int lm_set_similarity_lut(lm_detector* det, const uint8_t lut[256]);
 int lm_set_normal_lut(lm_detector* det, const uint8_t lut[8000]);
 int lm_get_similarity_lut(const lm_detector* det, uint8_t lut[256]);
 int lm_get_normal_lut(const lm_detector* det, uint8_t lut[8000]);
+/* 1 while the built-in NORMAL_LUT is active.  It is a documented SUBSTITUTE (azimuth of the cell centre, 8 bins), not
+ * OpenCV's normal_lut.i, which could not be restated: DepthNormal labels then differ from cv::linemod's,
+ * so a DepthNormal bank written by OpenCV must not be matched with it (lm_load_yaml warns on stderr).  Banks generated
+ * through this library are self-consistent.  lm_set_normal_lut(det, <the 8000 bytes of normal_lut.i>) clears the flag. */
+int lm_normal_lut_is_substitute(const lm_detector* det);
 
 /* Detector::numClasses()  HighLevelLinemod.cpp:60,527 ; numTemplates() :65 ; classIds() :55,145,262,526 */
 int         lm_num_classes(const lm_detector* det);
@@ -206,8 +211,11 @@ int lm_match_end(lm_detector* det, int lane, lm_match_t* out, size_t cap_per_fra
  * process.  recs_per_frame_cap (0 = 256): average records per frame a rank may contribute to one gather; the gather
  * buffers have a fixed size of n_frames * recs_per_frame_cap records per rank so that no host round trip sits between
  * the two collectives.  More records than that is LM_ERR_OVERFLOW, never a silent truncation (the reference consumes
- * ALL matches: HighLevelLinemod.cpp:206-253). */
+ * ALL matches: HighLevelLinemod.cpp:206-253).
+ * The two lanes' communicators rendezvous on `port` and `port + 1`. */
 int lm_comm_init(lm_detector* det, int rank, int world, const char* addr, int port, int recs_per_frame_cap);
+/* The rendezvous lm_comm_init uses, on its own (host only, no GPU): n bytes from rank 0's buf into every rank's buf. */
+int lm_rendezvous_broadcast(int rank, int world, const char* addr, int port, void* buf, size_t n, int timeout_s);
 int lm_comm_destroy(lm_detector* det);
 int lm_comm_info(const lm_detector* det, int* rank, int* world);
 /* lm_match_begin + behind the sort kernel, on the lane's stream: k_pack_lists (the lane's sorted lists back to back +

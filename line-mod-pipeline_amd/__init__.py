@@ -65,6 +65,7 @@ EXPORTS = [
     "lm_upload_frame_pinned", "lm_upload_wait", "lm_host_alloc", "lm_host_free", "lm_set_stage_chunks",
     "lm_set_tuning", "lm_comm_init", "lm_comm_destroy", "lm_comm_info", "lm_match_begin_gathered",
     "lm_match_end_gathered", "lm_comm_barrier", "lm_comm_max", "lm_upload_frames_pinned",
+    "lm_rendezvous_broadcast", "lm_normal_lut_is_substitute",
 ]
 
 _lib = None
@@ -90,6 +91,7 @@ def load_library(path=None):
     lib.lm_destroy.restype = None
     for name in ("lm_set_similarity_lut", "lm_set_normal_lut", "lm_get_similarity_lut", "lm_get_normal_lut"):
         getattr(lib, name).argtypes = [vp, vp]
+    lib.lm_normal_lut_is_substitute.argtypes = [vp]
     lib.lm_num_classes.argtypes = [vp]
     lib.lm_num_templates.argtypes = [vp]
     lib.lm_class_num_templates.argtypes = [vp, i]
@@ -146,6 +148,7 @@ def load_library(path=None):
     lib.lm_set_tuning.argtypes = [vp, i, i]
     lib.lm_comm_init.argtypes = [vp, i, i, C.c_char_p, i, i]
     lib.lm_comm_destroy.argtypes = [vp]
+    lib.lm_rendezvous_broadcast.argtypes = [i, i, C.c_char_p, i, vp, sz, i]
     lib.lm_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     lib.lm_match_begin_gathered.argtypes = [vp, i, i, i, f, i]
     lib.lm_match_end_gathered.argtypes = [vp, i, vp, sz, vp, C.POINTER(i), C.POINTER(i), C.POINTER(sz)]
@@ -198,6 +201,16 @@ def yaml_string(path, key):
     if rc:
         raise LinemodError(rc, lib.lm_last_error().decode())
     return buf.value.decode()
+
+
+def rendezvous_broadcast(rank, world, payload, addr="127.0.0.1", port=29511, timeout_s=60):
+    """rank 0's `payload` (bytes) to every rank over TCP (what lm_comm_init uses for the ncclUniqueId)."""
+    lib = load_library()
+    buf = C.create_string_buffer(payload, len(payload))
+    rc = lib.lm_rendezvous_broadcast(rank, world, addr.encode(), port, buf, len(payload), timeout_s)
+    if rc:
+        raise LinemodError(rc, lib.lm_last_error().decode())
+    return buf.raw
 
 
 def pack_matches(records, counts):
@@ -345,6 +358,9 @@ class Detector:
         out = np.zeros(256, np.uint8)
         self._check(self.lib.lm_get_similarity_lut(self.h, _ptr(out)))
         return out
+
+    def normal_lut_is_substitute(self):
+        return bool(self.lib.lm_normal_lut_is_substitute(self.h))
 
     def normal_lut(self):
         out = np.zeros(8000, np.uint8)

@@ -23,3 +23,6 @@ struct LmComm {
     bool all_reduce_max_f64(const void* send, void* recv, size_t n, hipStream_t st, std::string& err);
     ~LmComm() { destroy(); }
 };
+
+// rank 0 -> every rank: n bytes over TCP (the rendezvous LmComm::init uses for the ncclUniqueId); host only.
+bool lm_tcp_broadcast(int rank, int world, const char* addr, int port, int timeout_s, void* buf, size_t n, std::string& err);

@@ -103,6 +103,10 @@ bool tcp_broadcast(int rank, int world, const char* addr, int port, int timeout_
 
 }  // namespace
 
+bool lm_tcp_broadcast(int rank, int world, const char* addr, int port, int timeout_s, void* buf, size_t n, std::string& err) {
+    return tcp_broadcast(rank, world, addr, port, timeout_s, buf, n, err);
+}
+
 bool LmComm::init(int rank_, int world_, const char* addr, int port, int timeout_s, std::string& err) {
     destroy();
     if (world_ < 1 || rank_ < 0 || rank_ >= world_) { err = "bad rank / world size"; return false; }

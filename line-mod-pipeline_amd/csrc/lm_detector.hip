@@ -62,6 +62,7 @@ struct lm_detector {
     u8 sim_lut[256];
     u8 normal_lut[8000];
     int lut_onehot = -1;          // cached: every NORMAL_LUT entry is 0 or one-hot (-1 = not evaluated)
+    bool normal_lut_substitute = true;   // the built-in table (NOT OpenCV's normal_lut.i) is active: lm_set_normal_lut clears it
     lmh::Bank bank;
 
     // ---- device state
@@ -900,9 +901,10 @@ int lm_set_similarity_lut(lm_detector* d, const uint8_t lut[256]) {
 int lm_set_normal_lut(lm_detector* d, const uint8_t lut[8000]) {
     if (d && (d->lanes[0].busy || d->lanes[1].busy)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (!d || !lut) return fail(LM_ERR_INVALID, "null argument");
-    std::memcpy(d->normal_lut, lut, 8000); d->luts_dirty = true; d->lut_onehot = -1; return LM_OK;
+    std::memcpy(d->normal_lut, lut, 8000); d->luts_dirty = true; d->lut_onehot = -1; d->normal_lut_substitute = false; return LM_OK;
 }
 int lm_get_similarity_lut(const lm_detector* d, uint8_t lut[256]) { if (!d || !lut) return fail(LM_ERR_INVALID, "null argument"); std::memcpy(lut, d->sim_lut, 256); return LM_OK; }
+int lm_normal_lut_is_substitute(const lm_detector* d) { return (d && d->normal_lut_substitute) ? 1 : 0; }
 int lm_get_normal_lut(const lm_detector* d, uint8_t lut[8000]) { if (!d || !lut) return fail(LM_ERR_INVALID, "null argument"); std::memcpy(lut, d->normal_lut, 8000); return LM_OK; }
 
 int lm_num_classes(const lm_detector* d) { return d ? (int)d->bank.classes.size() : -1; }
@@ -1231,7 +1233,7 @@ int lm_comm_init(lm_detector* d, int rank, int world, const char* addr, int port
     for (int l = 0; l < 2; ++l) {
         LmComm* c = new LmComm();
         std::string err;
-        if (!c->init(rank, world, addr, port, 120, err)) {
+        if (!c->init(rank, world, addr, port + l, 120, err)) {   // lane l's rendezvous on port + l
             delete c;
             if (d->comm[0]) { delete d->comm[0]; d->comm[0] = nullptr; }
             return fail(LM_ERR_HIP, err);
@@ -1249,6 +1251,13 @@ int lm_comm_init(lm_detector* d, int rank, int world, const char* addr, int port
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g.h_all_rec), R * cap * sizeof(LmOutMatch)));
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_red), 64 * sizeof(double)));   // [0, 32) send | [32, 64) receive
+    return LM_OK;
+}
+
+int lm_rendezvous_broadcast(int rank, int world, const char* addr, int port, void* buf, size_t n, int timeout_s) {
+    if (!buf || world < 1 || rank < 0 || rank >= world) return fail(LM_ERR_INVALID, "bad argument");
+    std::string err;
+    if (!lm_tcp_broadcast(rank, world, addr ? addr : "127.0.0.1", port, timeout_s > 0 ? timeout_s : 60, buf, n, err)) return fail(LM_ERR_IO, err);
     return LM_OK;
 }
 
@@ -1488,24 +1497,38 @@ int lm_load_yaml(lm_detector* d, const char* path) {
     std::string err;
     if (!lmy::load_templates_yaml(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
     d->bank_dirty = true;
+    if (d->cfg.num_modalities == 2 && d->normal_lut_substitute) {
+        static bool warned = false;
+        if (!warned) {
+            warned = true;
+            std::fprintf(stderr, "liblinemod_hip: warning: %s holds DepthNormal templates, but the built-in NORMAL_LUT is a "
+                                 "substitute for OpenCV's normal_lut.i (SURVEY.md A.4): a bank WRITTEN BY OpenCV will be scored "
+                                 "against differently quantised normals.  Install the real table with lm_set_normal_lut, or "
+                                 "regenerate the bank with this library.\n", path);
+        }
+    }
     return LM_OK;
 }
 
 // Top-level scalars / number lists of a cv::FileStorage YAML file (linemod_settings.yml, models/<name>.yml,
 // benchmark/pose0.yml): the host glue reads its settings through these.
-static const lmy::Node* yaml_top(const char* path, const char* key, lmy::Node& root) {
+// Returns the status code (LM_ERR_IO: unreadable / unparsable file; LM_ERR_INVALID: no such key) and the node.
+static int yaml_top(const char* path, const char* key, lmy::Node& root, const lmy::Node** out) {
     std::string text, err;
-    if (!lmy::read_text_file(path, text, err)) { fail(LM_ERR_IO, err); return nullptr; }
-    if (!lmy::parse(text, root, err)) { fail(LM_ERR_IO, std::string(path) + ": " + err); return nullptr; }
+    *out = nullptr;
+    if (!lmy::read_text_file(path, text, err)) return fail(LM_ERR_IO, err);
+    if (!lmy::parse(text, root, err)) return fail(LM_ERR_IO, std::string(path) + ": " + err);
     const lmy::Node* n = root.get(key);
-    if (!n) fail(LM_ERR_INVALID, std::string("no key '") + key + "' in " + path);
-    return n;
+    if (!n) return fail(LM_ERR_INVALID, std::string("no key '") + key + "' in " + path);
+    *out = n;
+    return LM_OK;
 }
 int lm_yaml_numbers(const char* path, const char* key, double* out, size_t cap, size_t* n_out) {
     if (!path || !key) return fail(LM_ERR_INVALID, "null argument");
     lmy::Node root;
-    const lmy::Node* n = yaml_top(path, key, root);
-    if (!n) return LM_ERR_IO;
+    const lmy::Node* n = nullptr;
+    int rc;
+    if ((rc = yaml_top(path, key, root, &n))) return rc;
     if (n->kind == lmy::Node::Map && n->get("data")) n = n->get("data");   // !!opencv-matrix
     std::vector<double> v;
     double d;
@@ -1522,8 +1545,9 @@ int lm_yaml_numbers(const char* path, const char* key, double* out, size_t cap, 
 int lm_yaml_string(const char* path, const char* key, char* out, size_t cap) {
     if (!path || !key || !out || !cap) return fail(LM_ERR_INVALID, "null argument");
     lmy::Node root;
-    const lmy::Node* n = yaml_top(path, key, root);
-    if (!n) return LM_ERR_IO;
+    const lmy::Node* n = nullptr;
+    int rc;
+    if ((rc = yaml_top(path, key, root, &n))) return rc;
     if (n->kind != lmy::Node::Scalar) return fail(LM_ERR_INVALID, std::string("'") + key + "' is not a scalar");
     if (n->scalar.size() + 1 > cap) return fail(LM_ERR_INVALID, "buffer too small");
     std::memcpy(out, n->scalar.c_str(), n->scalar.size() + 1);

@@ -54,94 +54,101 @@ bool load_ply_ascii(const std::string& path, Mesh& mesh, std::string* err) {
 }
 
 // ==================================================================================================
-// CameraViewPoints (restated from /root/reference/src/CameraViewPoints.cpp)
+// Viewpoint sampling.  DERIVED FROM /root/reference/src/CameraViewPoints.cpp:11-225 in WHAT it produces -- the same
+// viewpoints in the same order, because the order of getVertices() decides the template ids of a bank
+// (TemplateGenerator.cpp:41-62) and the ids are what linemod_tempPosFile.bin indexes -- but built its own way: the
+// sphere is an edge-keyed midpoint refinement (one map lookup per edge instead of the reference's linear duplicate
+// search over all earlier vertices), the arc and the symmetry filter are small free functions.  Only the two public
+// entry points keep the reference's names (the API TemplateGenerator calls).  The sequences are pinned by
+// tests/test_viewpoints.py (tests/golden/viewpoints.txt).
 // ==================================================================================================
-void CameraViewPoints::createCameraViewPoints(float in_radius, uint8_t in_subdivions) {
-    vertices.clear();
-    indices.clear();
-    radius = in_radius;
-    numSubdivisions = in_subdivions;
-    if (modProps.rotationallySymmetrical) {
-        createVerticesForRotSym();
-    } else {
-        icosahedronPointsFromRadius();
-        createIcosahedron();
-        subdivide();
+namespace {
+
+// the icosahedron of the reference (CameraViewPoints.cpp:84-124): vertex i = signs/axes below with
+// a = r / sqrt(phi^2 + 1), b = a * phi; faces in the reference's order (both are data: the order is the contract)
+const int8_t kIcoVertex[12][3] = {{-1, 0, 2}, {1, 0, 2}, {-1, 0, -2}, {1, 0, -2}, {0, 2, 1}, {0, 2, -1},
+                                  {0, -2, 1}, {0, -2, -1}, {2, 1, 0}, {-2, 1, 0}, {2, -1, 0}, {-2, -1, 0}};   // 1 = a, 2 = b
+const uint8_t kIcoFace[20][3] = {{0, 4, 1}, {0, 9, 4}, {9, 5, 4}, {4, 5, 8}, {4, 8, 1}, {8, 10, 1}, {8, 3, 10},
+                                 {5, 3, 8}, {5, 2, 3}, {2, 7, 3}, {7, 10, 3}, {7, 6, 10}, {7, 11, 6}, {11, 0, 6},
+                                 {0, 1, 6}, {6, 1, 10}, {9, 0, 11}, {9, 11, 2}, {9, 2, 5}, {7, 2, 11}};
+
+struct Tri { uint32_t v[3]; };
+
+// Midpoint of an edge pushed out to the sphere, created once per undirected edge.  (p + q) / 2 is commutative in
+// floating point, so keying by the edge finds exactly the vertices the reference finds by comparing coordinates.
+struct Refiner {
+    std::vector<Vec3>& pts;
+    float radius;
+    uint32_t midpoint(uint32_t p, uint32_t q) {
+        const uint64_t key = p < q ? ((uint64_t)p << 32) | q : ((uint64_t)q << 32) | p;
+        for (const auto& e : cache_bucket(key)) if (e.first == key) return e.second;
+        Vec3 m{(pts[p].x + pts[q].x) / 2, (pts[p].y + pts[q].y) / 2, (pts[p].z + pts[q].z) / 2};
+        const float k = std::sqrt(m.x * m.x + m.y * m.y + m.z * m.z) / radius;   // CameraViewPoints.cpp:216-225: divide, not multiply
+        m.x /= k; m.y /= k; m.z /= k;
+        pts.push_back(m);
+        const uint32_t id = (uint32_t)pts.size() - 1;
+        cache_bucket(key).push_back({key, id});
+        return id;
     }
-    removeSuperfluousVertices();
-}
+    std::vector<std::vector<std::pair<uint64_t, uint32_t>>> buckets = std::vector<std::vector<std::pair<uint64_t, uint32_t>>>(1024);
+    std::vector<std::pair<uint64_t, uint32_t>>& cache_bucket(uint64_t key) { return buckets[(key * 0x9E3779B97F4A7C15ull) >> 54]; }
+};
 
-void CameraViewPoints::removeSuperfluousVertices() {   // keep the octant(s) the symmetry planes leave
-    std::vector<Vec3> keep;
-    for (const Vec3& v : vertices) {
-        Vec3 t{v.x * modProps.planesOfSymmetry.x, v.y * modProps.planesOfSymmetry.y, v.z * modProps.planesOfSymmetry.z};
-        if (!(t.x < 0 || t.y < 0 || t.z < 0)) keep.push_back(v);
+void sphere_points(float radius, int subdivisions, std::vector<Vec3>& pts) {
+    const float phi = 1.61803398875f;
+    const float a = std::sqrt((radius * radius) / (phi * phi + 1)), b = a * phi;
+    const float mag[3] = {0.0f, a, b};
+    pts.clear();
+    for (const auto& v : kIcoVertex) {
+        Vec3 p;
+        p.x = (v[0] < 0 ? -1.0f : 1.0f) * mag[v[0] < 0 ? -v[0] : v[0]];
+        p.y = (v[1] < 0 ? -1.0f : 1.0f) * mag[v[1] < 0 ? -v[1] : v[1]];
+        p.z = (v[2] < 0 ? -1.0f : 1.0f) * mag[v[2] < 0 ? -v[2] : v[2]];
+        pts.push_back(p);
     }
-    vertices.swap(keep);
-}
-
-void CameraViewPoints::icosahedronPointsFromRadius() {
-    const float goldenRatio = 1.61803398875f;
-    icosahedronPointA = std::sqrt((radius * radius) / (goldenRatio * goldenRatio + 1));
-    icosahedronPointB = icosahedronPointA * goldenRatio;
-}
-
-void CameraViewPoints::createVerticesForRotSym() {
-    // `uint16_t i = i + 60/pow(2, n)`: the double sum is truncated back into the uint16 counter (7.5 -> step 7)
-    for (uint16_t i = 0; i < 360; i = (uint16_t)(i + (60 / std::pow(2, numSubdivisions)))) {
-        const double PI = 3.1415926535897932384626433832795;
-        vertices.push_back(Vec3{0.0f, (float)(std::sin(i * PI / 180.0f) * radius), (float)(std::cos(i * PI / 180.0f) * radius)});
-        if (60 / std::pow(2, numSubdivisions) < 1.0) break;   // the reference would loop forever here
-    }
-}
-
-void CameraViewPoints::createIcosahedron() {
-    const float A = icosahedronPointA, B = icosahedronPointB;
-    const Vec3 v[12] = {{-A, 0, B}, {A, 0, B}, {-A, 0, -B}, {A, 0, -B}, {0, B, A}, {0, B, -A},
-                        {0, -B, A}, {0, -B, -A}, {B, A, 0}, {-B, A, 0}, {B, -A, 0}, {-B, -A, 0}};
-    vertices.assign(v, v + 12);
-    const Index idx[20] = {{0, 4, 1}, {0, 9, 4}, {9, 5, 4}, {4, 5, 8}, {4, 8, 1}, {8, 10, 1}, {8, 3, 10}, {5, 3, 8},
-                           {5, 2, 3}, {2, 7, 3}, {7, 10, 3}, {7, 6, 10}, {7, 11, 6}, {11, 0, 6}, {0, 1, 6}, {6, 1, 10},
-                           {9, 0, 11}, {9, 11, 2}, {9, 2, 5}, {7, 2, 11}};
-    indices.assign(idx, idx + 20);
-}
-
-int32_t CameraViewPoints::checkForDuplicate(uint32_t vertSize) {
-    int32_t index = -1;
-    for (uint32_t i = 0; i < vertSize; ++i)
-        if (vertices[vertSize].x == vertices[i].x && vertices[vertSize].y == vertices[i].y && vertices[vertSize].z == vertices[i].z)
-            index = (int32_t)i;
-    return index;
-}
-
-void CameraViewPoints::adjustVecToRadius(uint32_t index) {
-    Vec3& v = vertices[index];
-    float adjust = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z) / radius;
-    v.x /= adjust; v.y /= adjust; v.z /= adjust;
-}
-
-void CameraViewPoints::subdivide() {
-    for (uint8_t j = 0; j < numSubdivisions; ++j) {
-        const uint32_t numFaces = (uint32_t)indices.size();
-        uint32_t cur = (uint32_t)vertices.size();
-        auto midpoint = [&](uint32_t p, uint32_t q) -> uint32_t {
-            vertices.push_back(Vec3{(vertices[p].x + vertices[q].x) / 2, (vertices[p].y + vertices[q].y) / 2, (vertices[p].z + vertices[q].z) / 2});
-            adjustVecToRadius(cur);
-            int32_t dup = checkForDuplicate(cur);
-            if (dup != -1) { vertices.pop_back(); return (uint32_t)dup; }
-            return cur++;
-        };
-        for (uint32_t i = 0; i < numFaces; ++i) {
-            const Index f = indices[i];
-            uint32_t ab = midpoint(f.a, f.b);
-            uint32_t bc = midpoint(f.c, f.b);
-            uint32_t ac = midpoint(f.a, f.c);
-            indices.push_back(Index{f.a, ab, ac});
-            indices.push_back(Index{f.b, ab, bc});
-            indices.push_back(Index{f.c, bc, ac});
-            indices[i] = Index{ab, bc, ac};
+    std::vector<Tri> tris;
+    for (const auto& f : kIcoFace) tris.push_back(Tri{{f[0], f[1], f[2]}});
+    Refiner ref{pts, radius};
+    for (int level = 0; level < subdivisions; ++level) {
+        const size_t n = tris.size();
+        for (size_t i = 0; i < n; ++i) {
+            const Tri t = tris[i];
+            // the reference visits the edges as (a,b), (c,b), (a,c): that order numbers the new vertices
+            const uint32_t ab = ref.midpoint(t.v[0], t.v[1]);
+            const uint32_t cb = ref.midpoint(t.v[2], t.v[1]);
+            const uint32_t ac = ref.midpoint(t.v[0], t.v[2]);
+            tris.push_back(Tri{{t.v[0], ab, ac}});
+            tris.push_back(Tri{{t.v[1], ab, cb}});
+            tris.push_back(Tri{{t.v[2], cb, ac}});
+            tris[i] = Tri{{ab, cb, ac}};
         }
     }
+}
+
+// rotationally symmetric parts: one meridian in the y/z plane, every `60 / 2^n` degrees with the step truncated to
+// whole degrees by the reference's uint16_t loop counter (CameraViewPoints.cpp:75-82: 7.5 -> 7)
+void arc_points(float radius, int subdivisions, std::vector<Vec3>& pts) {
+    pts.clear();
+    const double step = 60 / std::pow(2, subdivisions);
+    const double PI = 3.1415926535897932384626433832795;
+    for (uint16_t deg = 0; deg < 360; deg = (uint16_t)(deg + step)) {
+        pts.push_back(Vec3{0.0f, (float)(std::sin(deg * PI / 180.0f) * radius), (float)(std::cos(deg * PI / 180.0f) * radius)});
+        if (step < 1.0) break;   // the reference's counter would never advance here
+    }
+}
+
+}  // namespace
+
+void CameraViewPoints::createCameraViewPoints(float in_radius, uint8_t in_subdivions) {
+    std::vector<Vec3> all;
+    if (modProps.rotationallySymmetrical) arc_points(in_radius, in_subdivions, all);
+    else sphere_points(in_radius, in_subdivions, all);
+    // symmetry planes (models/<name>.yml "planes of symmetry", CameraViewPoints.cpp:34-52): a viewpoint survives
+    // unless one of its coordinates, multiplied by the plane flag, is negative
+    vertices.clear();
+    const Vec3 s = modProps.planesOfSymmetry;
+    for (const Vec3& v : all)
+        if (!(v.x * s.x < 0 || v.y * s.y < 0 || v.z * s.z < 0)) vertices.push_back(v);
 }
 
 // ==================================================================================================

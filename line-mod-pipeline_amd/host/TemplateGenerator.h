@@ -29,26 +29,18 @@ struct SymmetryProperties {
     Vec3 planesOfSymmetry{0, 0, 0};
 };
 
+// Viewpoints around the model: an icosphere (12 * 4^n-ish vertices) or, for rotationally symmetric parts, one meridian
+// arc; symmetry planes prune it.  Same viewpoints in the same order as the reference's CameraViewPoints (the order
+// numbers the templates); the two entry points TemplateGenerator calls keep the reference's names.
 class CameraViewPoints {
 public:
     void setModelProperties(const SymmetryProperties& p) { modProps = p; }
-    void createCameraViewPoints(float in_radius, uint8_t in_subdivions);   // :11-32
+    void createCameraViewPoints(float in_radius, uint8_t in_subdivions);   // CameraViewPoints.cpp:11-32
     std::vector<Vec3>& getVertices() { return vertices; }
 
 private:
-    struct Index { uint32_t a, b, c; };
-    void createVerticesForRotSym();        // :75-82
-    void icosahedronPointsFromRadius();    // :69-73
-    void createIcosahedron();              // :84-124
-    void subdivide();                      // :143-214
-    int32_t checkForDuplicate(uint32_t vertSize);   // :126-141
-    void adjustVecToRadius(uint32_t index);          // :216-225
-    void removeSuperfluousVertices();      // :34-52
     std::vector<Vec3> vertices;
-    std::vector<Index> indices;
     SymmetryProperties modProps;
-    float radius = 0, icosahedronPointA = 0, icosahedronPointB = 0;
-    uint8_t numSubdivisions = 0;
 };
 
 // Software stand-in for OpenGLRender: perspective(fovy = 2 atan(h / 2fy), w/h, 100, 10000) * lookAt(cam, 0, +y),

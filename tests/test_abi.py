@@ -25,6 +25,9 @@ def test_library_exports_every_declared_symbol(lm):
         assert hasattr(lib, n), "liblinemod_hip.so does not export %s" % n
     assert sorted(lm.EXPORTS) == names
     assert b"gfx950" in lib.lm_version()
+    # the binding declares the C signature of every export (size_t / pointer arguments never ride on ctypes' int default)
+    for n in names:
+        assert getattr(lib, n).argtypes is not None, "no argtypes declared for %s" % n
 
 
 def test_default_config_matches_reference_constructions(lm):

@@ -86,3 +86,26 @@ def test_pack_and_merge_batch_equal_per_frame_merge(lm):
         assert mc[i] == len(exp) and merged[pos:pos + mc[i]].tobytes() == exp.tobytes()
         pos += mc[i]
     assert pos == len(merged)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rendezvous_broadcast_multiprocess(world, lm):
+    """The TCP rendezvous lm_comm_init uses for the ncclUniqueId (rank 0 -> all ranks), as `world` processes on the
+    CPU: every rank must end up with rank 0's 128 bytes; ranks start in arbitrary order (clients retry)."""
+    port = _free_port()
+    code = (
+        "import importlib, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "lm = importlib.import_module('line-mod-pipeline_amd')\n"
+        "rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])\n"
+        "time.sleep(0.3 * ((rank * 7) %% 3))\n"
+        "payload = bytes((i * 37 + 11) %% 256 for i in range(128)) if rank == 0 else bytes(128)\n"
+        "for rnd in range(2):\n"                      # two rounds on port, port + 1 like the two lanes' communicators
+        "    out = lm.rendezvous_broadcast(rank, world, payload, port=port + rnd, timeout_s=30)\n"
+        "    assert out == bytes((i * 37 + 11) %% 256 for i in range(128)), out[:8]\n"
+        "print('RANK %%d OK' %% rank)\n" % ROOT)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(world), str(port)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, cwd=ROOT) for r in range(world)]
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0 and "RANK %d OK" % r in out, err[-2000:]

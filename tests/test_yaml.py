@@ -110,6 +110,14 @@ def test_yaml_filestorage_lookups(lm, tmp_path):
     assert lm.yaml_numbers(m, "has rotational symmetry")[0] == 1
     with pytest.raises(lm.LinemodError):
         lm.yaml_numbers(m, "no such key")
+    try:
+        lm.yaml_numbers(m, "no such key")
+    except lm.LinemodError as e:
+        assert e.code == lm.LM_ERR_INVALID and "no key" in str(e)      # a missing key is not an I/O failure
+    try:
+        lm.yaml_numbers(str(tmp_path / "absent.yml"), "x")
+    except lm.LinemodError as e:
+        assert e.code == lm.LM_ERR_IO
     with pytest.raises(lm.LinemodError):
         lm.yaml_numbers(s, "model folder")
 
