@@ -81,6 +81,8 @@ class Runner:
         self.descs, self.feats, _ = synth.make_bank(self.n_total, M, 2, seed=wl["seed_bank"], fixed_l0_size=wl["l0_size"],
                                                     quantized=q, crop_fraction=0.1, frame_size=(W, H), T0=det.get_T(0))
         det.add_class("synthetic.ply", self.descs, self.feats)
+        if args.no_prune:
+            det.set_scan_variant(8)
         for i, (bgr, depth) in enumerate(self.frames):
             det.upload_frame(i, bgr, depth if M == 2 else None)
         det.upload_wait(-1)
@@ -138,6 +140,13 @@ class Runner:
             det.match_end(0, CAP, out=self.views[0][0][0], counts=self.views[0][0][1])
         prof = det.get_profile()
         det.set_profiling(False)
+        # one more launch with the scan's feature counters on: what fraction of the feature loads the pruning keeps
+        det.set_scan_stats(True)
+        det.match_begin(0, 0, self.Bl, self.args.threshold, 0)
+        det.match_end(0, CAP, out=self.views[0][0][0], counts=self.views[0][0][1])
+        loaded, total = det.get_scan_stats()
+        det.set_scan_stats(False)
+        prof["features_loaded_fraction"] = loaded / total if total else 1.0
         return prof
 
     def streaming(self, steps):
@@ -220,6 +229,9 @@ def main():
     ap.add_argument("--threshold", type=float, default=80.0)
     ap.add_argument("--gather-cap", type=int, default=0, help="lm_comm_init recs_per_frame_cap (0 = 256)")
     ap.add_argument("--byte-responses", action="store_true", help="LM_FLAG_BYTE_RESPONSES: byte scan kernel (A/B)")
+    ap.add_argument("--no-prune", action="store_true",
+                    help="exhaustive similarity scan: every feature of every template at every position, even where the "
+                         "threshold is already out of reach (scan variant bit 3; A/B of the exact pruning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the h2d_inclusive (streaming) leg")
     ap.add_argument("--functional-gloo", action="store_true",
@@ -306,7 +318,8 @@ def main():
 
     # ---- roofline of the dominant kernel (similarity scan)
     kernel = "k_scan4" if not args.byte_responses else "k_scan"
-    l2_bytes = rep["scan_load_bytes"] * Bl             # bytes the scan's vector loads request per launch
+    kept = one_lane.get("features_loaded_fraction", 1.0)
+    l2_bytes = rep["scan_load_bytes"] * Bl * kept      # bytes the scan's vector loads really request per launch
     span_us = prof["stage_us"][1] / max(prof["launches"], 1)
     alg_bytes = prof["scan_bytes"] / max(prof["launches"], 1)
     ol_us = one_lane["stage_us"][1] / max(one_lane["launches"], 1)
@@ -319,6 +332,10 @@ def main():
         "bound": "l2", "achieved": round(rate(l2_bytes, ol_us), 1), "peak": L2_PEAK_GBS, "unit": "GB/s",
         "frac": round(rate(l2_bytes, ol_us) / L2_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "kernel": kernel, "avg_launch_us": round(ol_us, 2), "frames_per_launch": Bl, "load_bytes_per_launch": l2_bytes,
+        "pruning": {"enabled": not args.no_prune and not args.byte_responses, "feature_loads_kept": round(kept, 4),
+                    "note": "exact: a work item stops loading features once partial sum + 4 x features to come cannot "
+                            "exceed the raw threshold at any of its positions (same candidate list; bench.py --no-prune "
+                            "runs the exhaustive scan); load_bytes_per_launch counts only the loads that were made"},
         "measured": "HIP events on the launch stream around every %s launch of %d launches (%d frames each) on one lane "
                     "with nothing running beside them, in this process right after the timed region; rocprofv3 "
                     "--kernel-trace --stats of `bench.py --lanes 1` agrees (profiles/)" % (kernel, one_lane["launches"], Bl),
@@ -329,7 +346,8 @@ def main():
             "bound": "hbm", "achieved": round(rate(alg_bytes, ol_us), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(rate(alg_bytes, ol_us) / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg_bytes,
             "note": "SURVEY.md 8d yard-stick: sum over templates and modalities of features x scanned positions, one "
-                    "byte each, divided by the same clean launch duration; > 1 because the bytes come from L2"},
+                    "byte each (ALL features, also those the pruning never loads), divided by the same clean launch "
+                    "duration; > 1 because the bytes come from L2 and because of the pruning"},
         "timed_region": {
             "avg_span_us": round(span_us, 2), "lanes": NL,
             "note": "HIP-event span around the scan launch inside the timed, two-lane run: it contains time in which "

@@ -309,7 +309,14 @@ int lm_get_profile(lm_detector* det, double stage_us[4], double* scan_algorithmi
 int lm_scan_load_bytes(lm_detector* det, int class_idx, double* bytes_per_frame);
 /* Counters of the last match on `slot`: scan candidates and refined matches before sort + unique. */
 int lm_last_counts(lm_detector* det, int slot, uint32_t* candidates, uint32_t* matches_before_unique);
-/* Selects the similarity-scan kernel variant used by lm_match* (0 = default; see lm_kernels.hip). */
+/* The nibble scan kernel stops loading a work item's features as soon as NO position it holds can still exceed the raw
+ * threshold (partial sum + 4 x features to come <= threshold: exact, the candidate list never changes).  With the
+ * statistics switched on every wave adds the (feature, work item) loads it made and the loads an exhaustive scan makes
+ * to device counters (per wave pair of frames; lm_set_scan_stats also zeroes them). */
+int lm_set_scan_stats(lm_detector* det, int enable);
+int lm_get_scan_stats(lm_detector* det, uint64_t* features_loaded, uint64_t* features_unpruned);
+/* Selects the similarity-scan kernel variant used by lm_match* (0 = default; bits 0-1: features per load block;
+ * bit 3 (value 8): no pruning, the plain exhaustive scan; see lm_kernels.hip). */
 int lm_set_scan_variant(lm_detector* det, int variant);
 
 #ifdef __cplusplus

@@ -66,6 +66,7 @@ EXPORTS = [
     "lm_set_tuning", "lm_comm_init", "lm_comm_destroy", "lm_comm_info", "lm_match_begin_gathered",
     "lm_match_end_gathered", "lm_comm_barrier", "lm_comm_max", "lm_upload_frames_pinned",
     "lm_rendezvous_broadcast", "lm_normal_lut_is_substitute",
+    "lm_set_scan_stats", "lm_get_scan_stats",
 ]
 
 _lib = None
@@ -126,6 +127,8 @@ def load_library(path=None):
     lib.lm_time_scan.argtypes = [vp, i, f, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.lm_time_stages.argtypes = [vp, i, f, i, i, C.POINTER(C.c_double)]
     lib.lm_set_scan_variant.argtypes = [vp, i]
+    lib.lm_set_scan_stats.argtypes = [vp, i]
+    lib.lm_get_scan_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.lm_last_counts.argtypes = [vp, i, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.lm_set_profiling.argtypes = [vp, i]
     lib.lm_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
@@ -596,6 +599,15 @@ class Detector:
         v = C.c_double()
         self._check(self.lib.lm_scan_load_bytes(self.h, class_idx, C.byref(v)))
         return v.value
+
+    def set_scan_stats(self, enable=True):
+        self._check(self.lib.lm_set_scan_stats(self.h, 1 if enable else 0))
+
+    def get_scan_stats(self):
+        """(feature loads made, feature loads of an exhaustive scan) since set_scan_stats()."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.lm_get_scan_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_scan_variant(self, variant):
         self._check(self.lib.lm_set_scan_variant(self.h, variant))

@@ -150,6 +150,8 @@ struct lm_detector {
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
     u32 max_cand = 0, max_match = 0;
     int scan_variant = 0;
+    bool scan_stats = false;                        // lm_set_scan_stats: the scan counts the features it loads
+    unsigned long long* d_scan_stat = nullptr;      // [1024][2]
     // live profile of lm_match* (lm_set_profiling): per-stage HIP-event time, scan launches and bytes
     bool profiling = false;
     double prof_us[4] = {0, 0, 0, 0};
@@ -249,6 +251,8 @@ int ensure_device(lm_detector* d) {
     // pinned staging for pageable sources is allocated on a slot's first staged upload (ensure_staging): a
     // streaming server that hands over pinned frames (lm_upload_frame_pinned) never needs it
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_resp_tab), 256 * sizeof(u64)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_scan_stat), 2048 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d->d_scan_stat, 0, 2048 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_sim_lut), 256));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_normal_lut), 8000));
     HIP_TRY(hipDeviceSynchronize());
@@ -425,6 +429,7 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r) {
     a.scan_off = d->d_scan_off; a.scan_P = d->d_scan_P; a.scan_n = d->d_scan_n;
     a.M = d->cfg.num_modalities; a.fpad = d->hb.fpad; a.nibble = g.nibble;
     a.raw_thr_by_n = d->d_raw_thr;
+    a.stat = d->scan_stats ? d->d_scan_stat : nullptr;
     a.W = g.W; a.T = g.T;
     a.hdr = reinterpret_cast<LmDevHeader*>(d->aux(first, d->off_hdr));
     a.cand = reinterpret_cast<LmCand*>(d->aux(first, d->off_cand));
@@ -885,6 +890,7 @@ void lm_destroy(lm_detector* d) {
         free_device_bank(d);
         for (auto& c : d->comm) { delete c; c = nullptr; }
         free_gather(d);
+        hipFree(d->d_scan_stat);
         hipFree(d->d_resp_tab); hipFree(d->d_sim_lut); hipFree(d->d_normal_lut); hipFree(d->d_scratch);
     }
     delete d;
@@ -1818,6 +1824,30 @@ int lm_scan_load_bytes(lm_detector* d, int class_idx, double* bytes_per_frame) {
     if (class_idx < 0) for (double v : d->hb.class_load_bytes) b += v;
     else b = d->hb.class_load_bytes[class_idx];
     *bytes_per_frame = b;
+    return LM_OK;
+}
+
+int lm_set_scan_stats(lm_detector* d, int enable) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(d->d_scan_stat, 0, 2048 * sizeof(unsigned long long)));
+    d->scan_stats = enable != 0;
+    return LM_OK;
+}
+
+int lm_get_scan_stats(lm_detector* d, uint64_t* features_loaded, uint64_t* features_unpruned) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    std::vector<unsigned long long> h(2048);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h.data(), d->d_scan_stat, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long a = 0, b = 0;
+    for (int i = 0; i < 1024; ++i) { a += h[2 * i]; b += h[2 * i + 1]; }
+    if (features_loaded) *features_loaded = a;
+    if (features_unpruned) *features_unpruned = b;
     return LM_OK;
 }
 

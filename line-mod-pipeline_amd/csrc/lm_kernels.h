@@ -48,6 +48,7 @@ struct LmScanArgs {
     LmCand* cand;
     size_t aux_slot_stride;
     u32 cand_cap;
+    unsigned long long* stat; // optional [1024][2] counters: features loaded / features an unpruned scan loads (k_scan4)
     int wgs_per_slot, nslots; // filled by lmk_scan
 };
 // a11+a12+a13: similarity scan over the lowest level fused with the threshold scan.

@@ -49,6 +49,13 @@ __device__ __forceinline__ u32 next_lane(u32 v) {
     return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true);
 }
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// v_pk_max_u16 on two u16 pairs
+__device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
+    const u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(u32, r);
+}
+
 template <typename T>
 __device__ __forceinline__ T* slot_ptr(T* p, size_t slot_stride) {
     return reinterpret_cast<T*>(reinterpret_cast<u8*>(const_cast<typename std::remove_const<T>::type*>(p)) +
@@ -1194,7 +1201,14 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
 // positions per item.  Three features are added nibble-wise (3 * 4 = 12 < 16), then split into even / odd
 // positions and added byte-wise (63 * 4 = 252).
 // ------------------------------------------------------------------------------------------------
-template <int FB, bool XCD_MAP>
+// Exact pruning (PRUNE): a position becomes a candidate only if its total exceeds the raw threshold, and a feature adds
+// at most 4.  So once, for EVERY position a wave holds (1016 positions of two frames), partial sum + 4 x (in-bounds
+// features still to come) <= threshold, none of them can become a candidate and the wave stops loading.  The test is
+// made in the middle and at the end of every modality's list: a packed-u16 max over the lane's 32 partial sums, one
+// compare, one ballot -- wave-uniform, so no lane ever diverges.  The candidate list is identical with and without
+// it (tests/test_gpu_match.py::test_scan_pruning_is_exact); at threshold 80 most templates stop after half their
+// features.  a.stat (optional): [0] += features loaded, [1] += features an unpruned scan would load, per wave.
+template <int FB, bool XCD_MAP, bool PRUNE>
 __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
     const int lane = threadIdx.x & 63;
     const u32 npairs = ((u32)a.nslots + 1u) >> 1;
@@ -1223,7 +1237,11 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
 
     // u16 pairs: position 8k + i of the lane lives in t[k][i & 3], half i >> 2
     u32 t[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int m = 0; m < a.M; ++m) {
+    int f_in_all = 0;                                      // in-bounds features of all modalities
+    for (int m = 0; m < a.M; ++m) f_in_all += (cnt >> (8 + 8 * m)) & 0xFF;
+    int f_done = 0;                                        // features loaded so far (all modalities)
+    bool pruned = false;
+    for (int m = 0; m < a.M && !pruned; ++m) {
         const u32* offs = a.scan_off + ((size_t)ti * a.M + m) * a.fpad;
         u32 bl[4] = {0, 0, 0, 0}, bh[4] = {0, 0, 0, 0};   // byte lanes: even / odd positions of dword k
 #define LM_SCAN4_BLOCK(NF)                                                                       \
@@ -1250,19 +1268,49 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
             }                                                                                    \
         }
         const int F = (cnt >> (8 + 8 * m)) & 0xFF;        // in-bounds features of this modality
+        // first block boundary at or past the middle of the list: the mid-list test
+        const int half = PRUNE ? ((F / 2 + FB - 1) / FB) * FB : -1;
         int f = 0;
-        for (; f + FB <= F; f += FB) LM_SCAN4_BLOCK(FB)
+        for (; f + FB <= F; f += FB) {
+            LM_SCAN4_BLOCK(FB)
+            if (PRUNE && f + FB == half && half < F) {
+                // largest partial sum of the lane: t (earlier modalities) + this modality's byte lanes
+                u32 mx = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u32 s0 = t[k][0] + (bl[k] & 0x00FF00FFu), s2 = t[k][2] + ((bl[k] >> 8) & 0x00FF00FFu);
+                    const u32 s1 = t[k][1] + (bh[k] & 0x00FF00FFu), s3 = t[k][3] + ((bh[k] >> 8) & 0x00FF00FFu);
+                    mx = pk_max_u16(mx, pk_max_u16(pk_max_u16(s0, s1), pk_max_u16(s2, s3)));
+                }
+                const int best = (int)max(mx & 0xFFFFu, mx >> 16);
+                if (!__any(best + 4 * (f_in_all - f_done - half) > thr)) { f_done += half; pruned = true; break; }
+            }
+        }
+        if (pruned) break;
         if (FB > 6 && f + 6 <= F) { LM_SCAN4_BLOCK(6) f += 6; }
         if (FB > 3 && f + 3 <= F) { LM_SCAN4_BLOCK(3) f += 3; }
         if (F - f == 2) LM_SCAN4_BLOCK(2)
         else if (F - f == 1) LM_SCAN4_BLOCK(1)
 #undef LM_SCAN4_BLOCK
+        f_done += F;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             t[k][0] += bl[k] & 0x00FF00FFu; t[k][2] += (bl[k] >> 8) & 0x00FF00FFu;
             t[k][1] += bh[k] & 0x00FF00FFu; t[k][3] += (bh[k] >> 8) & 0x00FF00FFu;
         }
+        if (PRUNE && m + 1 < a.M) {                        // end of a modality's list, more modalities to come
+            u32 mx = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mx = pk_max_u16(mx, pk_max_u16(pk_max_u16(t[k][0], t[k][1]), pk_max_u16(t[k][2], t[k][3])));
+            const int best = (int)max(mx & 0xFFFFu, mx >> 16);
+            if (!__any(best + 4 * (f_in_all - f_done) > thr)) pruned = true;
+        }
     }
+    if (a.stat && lane == 0) {
+        atomicAdd(&a.stat[2 * (blockIdx.x & 1023u)], (unsigned long long)f_done);
+        atomicAdd(&a.stat[2 * (blockIdx.x & 1023u) + 1], (unsigned long long)f_in_all);
+    }
+    if (pruned) return;
     u32 hit = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -1804,7 +1852,10 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
         // k_scan4: a wave scans its item for a PAIR of slots; 1-D grid with XCD affinity per pair
         const int npairs = (nslots + 1) / 2;
         dim3 grid((unsigned)(G * npairs), 1, 1);
-#define SCAN4_LAUNCH(FB) hipLaunchKernelGGL((k_scan4<FB, true>), grid, dim3(256), 0, s, a)
+#define SCAN4_LAUNCH(FB)                                                                              \
+    do { if (variant & 8) hipLaunchKernelGGL((k_scan4<FB, true, false>), grid, dim3(256), 0, s, a);   \
+         else hipLaunchKernelGGL((k_scan4<FB, true, true>), grid, dim3(256), 0, s, a); } while (0)
+        // variant bits 0-1: features per load block (0: 6, 1: 12, 2: 3); bit 3: no pruning (the plain exhaustive scan)
         const int fb = variant & 3;
         if (fb == 1) SCAN4_LAUNCH(12); else if (fb == 2) SCAN4_LAUNCH(3); else SCAN4_LAUNCH(6);
 #undef SCAN4_LAUNCH

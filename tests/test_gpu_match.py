@@ -337,3 +337,40 @@ def test_batch_of_8_crowded_frames(lm, orc, synth):
             exp = o.match(frames[i], None, thr, threads=8, cap=1 << 18)
             assert_matches_equal(out[i, :counts[i]], exp)
     d.close()
+
+
+@pytest.mark.parametrize("color_only,thr", [(False, 80.0), (False, 55.0), (False, 0.0), (True, 85.0), (True, 40.0)])
+def test_scan_pruning_is_exact(lm, orc, synth, color_only, thr):
+    """k_scan4 stops loading a work item's features once no position it holds can still exceed the raw threshold
+    (partial sum + 4 x features to come).  Candidate list with pruning == without (scan variant bit 3) == oracle's,
+    record by record, and the pruned scan really loads fewer features at a high threshold."""
+    bgr, depth = synth.make_frame(640, 480, seed=77)
+    d, o = _pair(lm, orc, color_only, frame_slots=4)
+    dep = None if color_only else depth
+    q = _quantized(o, bgr, depth, color_only)
+    M = 1 if color_only else 2
+    descs, feats, crops = synth.make_bank(400, M, 2, seed=12, quantized=q, crop_fraction=0.15, frame_size=(640, 480), T0=d.get_T(0))
+    d.add_class("c", descs, feats)
+    o.add_class("c", descs, feats)
+    d.upload_frame(0, bgr, dep)
+    d.upload_frame(1, synth.make_frame(640, 480, seed=78)[0], None if color_only else synth.make_frame(640, 480, seed=78)[1])
+    d.prepare_slot(0)
+    o.prepare(bgr, dep)
+    exp = o.scan_candidates(thr, threads=8)
+    stats = {}
+    for variant in (0, 8):
+        d.set_scan_variant(variant)
+        d.set_scan_stats(True)
+        assert np.array_equal(d.stage_scan(0, thr), exp)
+        stats[variant] = d.get_scan_stats()
+        d.set_scan_stats(False)
+        assert_matches_equal(d.match_slot(0, thr, cap=1 << 16), o.match(bgr, dep, thr, threads=8))
+        got, cnt = d.match_batch(2, thr, cap_per_frame=1 << 15)  # two frames per wave: the pair must agree to stop
+        assert_matches_equal(got[0, :cnt[0]], o.match(bgr, dep, thr, threads=8))
+    assert stats[8][0] == stats[8][1] == stats[0][1]            # the exhaustive scan loads every in-bounds feature
+    assert stats[0][0] <= stats[0][1]
+    if thr >= 80.0:
+        assert stats[0][0] < 0.8 * stats[0][1]
+    if thr == 0.0:
+        assert stats[0][0] == stats[0][1]                       # nothing can be pruned when every position qualifies
+    d.close()
