@@ -202,6 +202,17 @@ int lm_match_begin(lm_detector* det, int lane, int first_slot, int n_slots, floa
 int lm_synchronize(lm_detector* det);
 int lm_match_end(lm_detector* det, int lane, lm_match_t* out, size_t cap_per_frame, int32_t* counts);
 
+/* ---- f1: the colour check of the reference's match post-processing, batched on the GPU ----------
+ * For every match of the list (any class / template of the bank, e.g. a merged multi-GPU list): templateMask =
+ * fillPoly of the convex hull of the template's level-0 features moved to (match.x, match.y)
+ * (HighLevelLinemod.cpp:113-135), counted once alone and once AND-ed with the colour mask = inRange(cvtColor(frame,
+ * BGR2HSV), lower, upper) (:159-161): in_hull[i] and in_both[i] are the two countNonZero of colorCheck (:424-434),
+ * whose verdict is in_both * 100 / in_hull > percentToPassCheck.  The frame is the one resident in `slot`.  The
+ * reference builds a full-frame mask and counts the full frame once per tested match; here the colour mask is
+ * one bit per pixel, built once per call, and one wave rasterises one hull. */
+int lm_color_check_counts(lm_detector* det, int slot, const double lower_hsv[3], const double upper_hsv[3],
+                          const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both);
+
 /* ---- multi-GPU: template-bank shards + the ONE exchange step of the path ------------------------
  * One process per GPU; every rank creates its detector with lm_config.shard_rank / shard_size (contiguous template_id
  * ranges, global ids preserved), uploads the SAME frames and calls the same sequence of lm_match_begin_gathered /

@@ -66,7 +66,7 @@ EXPORTS = [
     "lm_set_tuning", "lm_comm_init", "lm_comm_destroy", "lm_comm_info", "lm_match_begin_gathered",
     "lm_match_end_gathered", "lm_comm_barrier", "lm_comm_max", "lm_upload_frames_pinned",
     "lm_rendezvous_broadcast", "lm_normal_lut_is_substitute",
-    "lm_set_scan_stats", "lm_get_scan_stats",
+    "lm_set_scan_stats", "lm_get_scan_stats", "lm_color_check_counts",
 ]
 
 _lib = None
@@ -127,6 +127,7 @@ def load_library(path=None):
     lib.lm_time_scan.argtypes = [vp, i, f, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.lm_time_stages.argtypes = [vp, i, f, i, i, C.POINTER(C.c_double)]
     lib.lm_set_scan_variant.argtypes = [vp, i]
+    lib.lm_color_check_counts.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, sz, vp, vp]
     lib.lm_set_scan_stats.argtypes = [vp, i]
     lib.lm_get_scan_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.lm_last_counts.argtypes = [vp, i, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -599,6 +600,14 @@ class Detector:
         v = C.c_double()
         self._check(self.lib.lm_scan_load_bytes(self.h, class_idx, C.byref(v)))
         return v.value
+
+    def color_check_counts(self, slot, lower_hsv, upper_hsv, matches):
+        """(in_hull, in_both) int64 arrays: the two countNonZero of the reference's colorCheck for every match."""
+        m = _c(matches, MATCH_DTYPE)
+        a, b = np.zeros(len(m), np.int64), np.zeros(len(m), np.int64)
+        lo, hi = (C.c_double * 3)(*lower_hsv), (C.c_double * 3)(*upper_hsv)
+        self._check(self.lib.lm_color_check_counts(self.h, slot, lo, hi, _ptr(m), len(m), _ptr(a), _ptr(b)))
+        return a, b
 
     def set_scan_stats(self, enable=True):
         self._check(self.lib.lm_set_scan_stats(self.h, 1 if enable else 0))

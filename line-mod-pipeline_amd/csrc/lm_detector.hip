@@ -11,6 +11,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -115,6 +116,11 @@ struct lm_detector {
         bool active = false;                                        // the lane's match in flight ends with a gather
         u32 cap_lane = 0;
     };
+    // ---- f1 colour check on the GPU: hulls of every template, HSV division tables, per-slot colour bit mask
+    bool hulls_dirty = true;
+    u32* d_hull_class_base = nullptr; u32* d_hull_off = nullptr; int16_t* d_hull_xy = nullptr;
+    int* d_hsv_div = nullptr;
+    size_t off_cmask = 0; int cmask_wpr = 0;
     LmComm* comm[2] = {nullptr, nullptr};   // one communicator per lane: the lanes' collectives never wait for each other
     int comm_recs_per_frame = 0;
     Gather gather[2];
@@ -215,6 +221,8 @@ int ensure_device(lm_detector* d) {
     d->off_cscratch = off; off += align_up(lmk_color_scratch_bytes(c.width, c.height), 256);
     d->off_cscratch1 = off; off += align_up(lmk_color_scratch_bytes(d->lw[L > 1 ? 1 : 0], d->lh[L > 1 ? 1 : 0]), 256);
     d->off_dscratch = off; off += align_up((size_t)c.width * c.height, 256);
+    d->cmask_wpr = (c.width + 31) / 32;
+    d->off_cmask = off; off += align_up((size_t)d->cmask_wpr * c.height * 4, 256);
     d->frame_stride = align_up(off, 4096);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->frame_arena), d->frame_stride * S));
     HIP_TRY(hipMemset(d->frame_arena, 0, d->frame_stride * S));  // linear-memory pads / zero blocks stay zero forever
@@ -258,7 +266,7 @@ int ensure_device(lm_detector* d) {
     HIP_TRY(hipDeviceSynchronize());
     d->dev_ready = true;
     d->luts_dirty = true;
-    d->bank_dirty = true;
+    d->bank_dirty = true; d->hulls_dirty = true;
     return LM_OK;
 }
 
@@ -891,6 +899,7 @@ void lm_destroy(lm_detector* d) {
         for (auto& c : d->comm) { delete c; c = nullptr; }
         free_gather(d);
         hipFree(d->d_scan_stat);
+        hipFree(d->d_hull_class_base); hipFree(d->d_hull_off); hipFree(d->d_hull_xy); hipFree(d->d_hsv_div);
         hipFree(d->d_resp_tab); hipFree(d->d_sim_lut); hipFree(d->d_normal_lut); hipFree(d->d_scratch);
     }
     delete d;
@@ -941,7 +950,7 @@ int lm_add_class(lm_detector* d, const char* class_id, int n_templates, const lm
     int ci = d->bank.add_class(class_id, n_templates, descs, features, d->cfg.pyramid_levels, d->cfg.num_modalities, err);
     if (ci < 0) return fail(LM_ERR_INVALID, err);
     if (class_idx_out) *class_idx_out = ci;
-    d->bank_dirty = true;
+    d->bank_dirty = true; d->hulls_dirty = true;
     return LM_OK;
 }
 
@@ -1001,7 +1010,7 @@ int lm_add_template(lm_detector* d, const char* class_id, const uint8_t* bgr, si
     if (bbox_out) *bbox_out = bb;
     int tid = d->bank.add_pyramid(class_id, std::move(tp));
     if (template_id_out) *template_id_out = tid;
-    d->bank_dirty = true;
+    d->bank_dirty = true; d->hulls_dirty = true;
     return LM_OK;
 }
 
@@ -1215,6 +1224,72 @@ int lm_match_end(lm_detector* d, int lane, lm_match_t* out, size_t cap_per_frame
         if (rc && !first_err) { first_err = rc; first_msg = g_err; }
     }
     if (first_err) return fail(first_err, first_msg);
+    return LM_OK;
+}
+
+// ---- f1: colour check of many matches of one resident frame (HighLevelLinemod.cpp:113-135,159-161,424-434) ------
+static int ensure_hulls(lm_detector* d) {
+    if (!d->hulls_dirty) return LM_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    hipFree(d->d_hull_class_base); hipFree(d->d_hull_off); hipFree(d->d_hull_xy);
+    d->d_hull_class_base = d->d_hull_off = nullptr; d->d_hull_xy = nullptr;
+    lmh::HullTable ht;
+    lmh::build_hull_table(d->bank, d->cfg.num_modalities, ht);
+    for (size_t t = 0; t + 1 < ht.hull_off.size(); ++t)
+        if (ht.hull_off[t + 1] - ht.hull_off[t] > LM_HULL_MAX) return fail(LM_ERR_INVALID, "template hull with more than 128 vertices");
+    int rc;
+    if ((rc = upload_vec(&d->d_hull_class_base, ht.class_base))) return rc;
+    if ((rc = upload_vec(&d->d_hull_off, ht.hull_off))) return rc;
+    if ((rc = upload_vec(&d->d_hull_xy, ht.hull_xy))) return rc;
+    if (!d->d_hsv_div) {
+        // cv::cvtColor's 8-bit RGB2HSV tables: sdiv_table[i] = round((255 << 12) / i), hdiv_table180[i] = round((180 << 12) / (6 i))
+        std::vector<int> tab(512, 0);
+        for (int i = 1; i < 256; ++i) {
+            tab[(size_t)i] = (int)std::lrint((255 << 12) / (1.0 * i));
+            tab[256 + (size_t)i] = (int)std::lrint((180 << 12) / (6.0 * i));
+        }
+        if ((rc = upload_vec(&d->d_hsv_div, tab))) return rc;
+    }
+    d->hulls_dirty = false;
+    return LM_OK;
+}
+
+int lm_color_check_counts(lm_detector* d, int slot, const double lower_hsv[3], const double upper_hsv[3],
+                          const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if ((rc = check_slots(d, slot, 1))) return rc;
+    if (!lower_hsv || !upper_hsv || (n && (!matches || !in_hull || !in_both))) return fail(LM_ERR_INVALID, "null argument");
+    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (!d->slots[slot].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
+    if (n == 0) return LM_OK;
+    if ((rc = ensure_hulls(d))) return rc;
+    const int nc = (int)d->bank.classes.size();
+    for (size_t i = 0; i < n; ++i) {
+        const lm_match_t& m = matches[i];
+        if (m.class_idx < 0 || m.class_idx >= nc || m.template_id < 0 || m.template_id >= (int)d->bank.classes[(size_t)m.class_idx].pyramids.size())
+            return fail(LM_ERR_INVALID, "match " + std::to_string(i) + " names a template the bank does not hold");
+    }
+    const size_t mb = align_up(n * sizeof(lm_match_t), 256);
+    if ((rc = ensure_scratch(d, mb + n * 2 * sizeof(long long)))) return rc;
+    u8* base = static_cast<u8*>(d->d_scratch);
+    if ((rc = enqueue_upload_wait(d, slot, 1))) return rc;
+    LmHsvRange rg;
+    for (int k = 0; k < 3; ++k) { rg.lo[k] = (int)std::lrint(lower_hsv[k]); rg.hi[k] = (int)std::lrint(upper_hsv[k]); }
+    u32* mask = reinterpret_cast<u32*>(d->frame_arena + (size_t)slot * d->frame_stride + d->off_cmask);
+    lmk_hsv_mask(d->stream, d->bgr(slot, 0), d->cfg.width, d->cfg.height, rg, d->d_hsv_div, mask, d->cmask_wpr, 0, 0, 1);
+    HIP_TRY(hipMemcpyAsync(base, matches, n * sizeof(lm_match_t), hipMemcpyHostToDevice, d->stream));
+    LmHullArgs a;
+    a.matches = reinterpret_cast<const LmOutMatch*>(base); a.n = (u32)n;
+    a.class_base = d->d_hull_class_base; a.hull_off = d->d_hull_off; a.hull_xy = d->d_hull_xy;
+    a.mask = mask; a.wpr = d->cmask_wpr; a.w = d->cfg.width; a.h = d->cfg.height;
+    a.out = reinterpret_cast<long long*>(base + mb);
+    lmk_hull_counts(d->stream, a);
+    std::vector<long long> out(2 * n);
+    HIP_TRY(hipMemcpyAsync(out.data(), a.out, out.size() * sizeof(long long), hipMemcpyDeviceToHost, d->stream));
+    if ((rc = wait_stream(d))) return rc;
+    HIP_TRY(hipGetLastError());
+    for (size_t i = 0; i < n; ++i) { in_hull[i] = out[2 * i]; in_both[i] = out[2 * i + 1]; }
     return LM_OK;
 }
 
@@ -1487,7 +1562,7 @@ int lm_load_bank(lm_detector* d, const char* path) {
     if (!d || !path) return fail(LM_ERR_INVALID, "null argument");
     std::string err;
     if (!lmh::load_bank(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
-    d->bank_dirty = true;
+    d->bank_dirty = true; d->hulls_dirty = true;
     return LM_OK;
 }
 
@@ -1502,7 +1577,7 @@ int lm_load_yaml(lm_detector* d, const char* path) {
     if (!d || !path) return fail(LM_ERR_INVALID, "null argument");
     std::string err;
     if (!lmy::load_templates_yaml(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
-    d->bank_dirty = true;
+    d->bank_dirty = true; d->hulls_dirty = true;
     if (d->cfg.num_modalities == 2 && d->normal_lut_substitute) {
         static bool warned = false;
         if (!warned) {

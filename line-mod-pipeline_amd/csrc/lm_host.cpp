@@ -177,6 +177,42 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
     return true;
 }
 
+void build_hull_table(const Bank& bank, int M, HullTable& out) {
+    out = HullTable();
+    struct P { int x, y; };
+    std::vector<P> p, hull;
+    for (const ClassEntry& c : bank.classes) {
+        out.class_base.push_back((u32)out.hull_off.size());
+        for (const TemplatePyramid& tp : c.pyramids) {
+            out.hull_off.push_back((u32)(out.hull_xy.size() / 2));
+            p.clear();
+            for (int m = 0; m < M && m < (int)tp.size(); ++m)          // tp[m], m < M: the level-0 templates
+                for (const lm_feature& f : tp[(size_t)m].features) p.push_back(P{f.x, f.y});
+            std::sort(p.begin(), p.end(), [](const P& a, const P& b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
+            p.erase(std::unique(p.begin(), p.end(), [](const P& a, const P& b) { return a.x == b.x && a.y == b.y; }), p.end());
+            if (p.size() >= 3) {
+                auto crs = [](const P& o, const P& a, const P& b) { return (long long)(a.x - o.x) * (b.y - o.y) - (long long)(a.y - o.y) * (b.x - o.x); };
+                hull.assign(2 * p.size(), P{0, 0});
+                size_t k = 0;
+                for (size_t i = 0; i < p.size(); ++i) {
+                    while (k >= 2 && crs(hull[k - 2], hull[k - 1], p[i]) <= 0) --k;
+                    hull[k++] = p[i];
+                }
+                for (size_t i = p.size() - 1, t = k + 1; i > 0; --i) {
+                    while (k >= t && crs(hull[k - 2], hull[k - 1], p[i - 1]) <= 0) --k;
+                    hull[k++] = p[i - 1];
+                }
+                hull.resize(k - 1);
+            } else {
+                hull = p;
+            }
+            for (const P& q : hull) { out.hull_xy.push_back((int16_t)q.x); out.hull_xy.push_back((int16_t)q.y); }
+        }
+    }
+    out.hull_off.push_back((u32)(out.hull_xy.size() / 2));
+    if (out.class_base.empty()) out.class_base.push_back(0);
+}
+
 // SIMILARITY_LUT default = the table cv::linemod ships (layout [ori][lo nibble 16 | hi nibble 16],
 // entry = max over the nibble's set bits of the single-bit score).  Rows 3-7 are circular in the 8 orientation
 // bins, rows 0-2 are not (orientation 0 scores 0 against bits 5-7): an upstream quirk that is part of the

@@ -55,6 +55,17 @@ inline void shard_range(int n, int rank, int size, int* lo, int* hi) {
 bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom* geom, DeviceBankHost& out,
                        std::string& err);
 
+// Convex hulls of the level-0 features (all modalities) of EVERY template of the bank, not only this shard's: the
+// colour check runs on merged match lists (host/PostProcess.cpp color_check; HighLevelLinemod.cpp:113-135).
+// Monotone chain: points sorted by (x, y), duplicates and collinear points dropped, counter-clockwise from the
+// leftmost-lowest point -- the vertex ORDER matters, the outline is drawn edge by edge in that direction.
+struct HullTable {
+    std::vector<u32> class_base;   // [n_classes] index of the class's first template in hull_off
+    std::vector<u32> hull_off;     // [n_templates + 1]
+    std::vector<int16_t> hull_xy;  // x, y per vertex
+};
+void build_hull_table(const Bank& bank, int modalities, HullTable& out);
+
 void default_similarity_lut(u8 lut[256]);
 void default_normal_lut(u8 lut[8000]);
 

@@ -106,3 +106,20 @@ struct LmPackArgs {
 };
 // 8e: the sorted lists of nslots frames back to back + their lengths (a rank's contribution to the all-gather).
 void lmk_pack_lists(hipStream_t s, const LmPackArgs& a);
+
+// ---- f1: batched colour check (HighLevelLinemod.cpp:113-135,159-161,424-434) -------------------------------------
+#define LM_HULL_MAX 128      // hull vertices per template (two modalities x 63 features at most = 126 points)
+struct LmHsvRange { int lo[3], hi[3]; };
+// one bit per pixel: 8-bit HSV of the BGR image inside [lo, hi]; divtab = sdiv_table[256] | hdiv_table180[256]
+void lmk_hsv_mask(hipStream_t s, const u8* bgr, int w, int h, const LmHsvRange& rg, const int* divtab, u32* mask, int wpr,
+                  size_t in_stride, size_t mask_stride, int nslots);
+struct LmHullArgs {
+    const LmOutMatch* matches; u32 n;
+    const u32* class_base;       // [n_classes] first hull of the class in hull_off
+    const u32* hull_off;         // [n_templates + 1] first vertex of every template's hull
+    const int16_t* hull_xy;      // vertices (x, y) relative to the template origin
+    const u32* mask; int wpr;    // colour bit mask of the frame
+    int w, h;
+    long long* out;              // [n][2]: pixels in the hull, pixels in the hull with the colour bit set
+};
+void lmk_hull_counts(hipStream_t s, const LmHullArgs& a);

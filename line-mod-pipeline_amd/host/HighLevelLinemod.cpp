@@ -67,24 +67,75 @@ bool HighLevelLineMOD::detectTemplate(std::vector<Image>& in_imgs, uint16_t in_c
     }
     matches.resize(n);
     if (matches.empty()) return false;  // :157,187-189
-    // :157-175 post-processing, when this class has template poses (built by addTemplate or read back)
-    if (in_classNumber < modelTemplates->size() && !(*modelTemplates)[in_classNumber].empty()) {
-        PostProcessSettings ps;
-        ps.onlyColorModality = onlyColorModality;
-        ps.videoWidth = videoWidth; ps.videoHeight = videoHeight; ps.fy = fy;
-        ps.stepSize = settings.stepSize; ps.percentToPassCheck = settings.percentToPassCheck;
-        ps.numberWantedPoses = settings.numberWantedPoses;
-        ps.radiusThresholdNewObject = settings.radiusThresholdNewObject;
-        ps.discardGroupRatio = settings.discardGroupRatio;
-        ps.useDepthImprovement = settings.useDepthImprovement; ps.depthOffset = settings.depthOffset;
-        ModelProperties props;
-        if (in_classNumber < modProps->size()) props = (*modProps)[in_classNumber];
-        PostProcessor pp(detector, ps);
-        posesMultipleObj = pp.run(matches, static_cast<const uint8_t*>(color.data), color.stride,
-                                  depth_img ? static_cast<const uint16_t*>(depth_img->data) : nullptr,
-                                  depth_img ? depth_img->stride : 0, (*modelTemplates)[in_classNumber], props);
-    }
+    // the frame lm_match uploaded is still resident in slot 0: the colour checks can run there
+    posesMultipleObj = postProcess(matches, color, depth_img, in_classNumber, gpuColorCheck ? 0 : -1);
     return true;
+}
+
+// :157-175 post-processing, when this class has template poses (built by addTemplate or read back)
+std::vector<std::vector<ObjectPose>> HighLevelLineMOD::postProcess(const std::vector<lm_match_t>& in_matches, const Image& color,
+                                                                   const Image* depth_img, uint16_t in_classNumber, int gpu_slot) {
+    std::vector<std::vector<ObjectPose>> out;
+    if (!(in_classNumber < modelTemplates->size()) || (*modelTemplates)[in_classNumber].empty()) return out;
+    PostProcessSettings ps;
+    ps.onlyColorModality = onlyColorModality;
+    ps.videoWidth = videoWidth; ps.videoHeight = videoHeight; ps.fy = fy;
+    ps.stepSize = settings.stepSize; ps.percentToPassCheck = settings.percentToPassCheck;
+    ps.numberWantedPoses = settings.numberWantedPoses;
+    ps.radiusThresholdNewObject = settings.radiusThresholdNewObject;
+    ps.discardGroupRatio = settings.discardGroupRatio;
+    ps.useDepthImprovement = settings.useDepthImprovement; ps.depthOffset = settings.depthOffset;
+    ModelProperties props;
+    if (in_classNumber < modProps->size()) props = (*modProps)[in_classNumber];
+    PostProcessor pp(detector, ps);
+    out = pp.run(in_matches, static_cast<const uint8_t*>(color.data), color.stride,
+                 depth_img ? static_cast<const uint16_t*>(depth_img->data) : nullptr, depth_img ? depth_img->stride : 0,
+                 (*modelTemplates)[in_classNumber], props, gpu_slot);
+    if (!pp.lastError().empty()) error = pp.lastError();
+    return out;
+}
+
+// A batch of frames against one class (BASELINE config 5): the frames go to the detector's slots [0, n) (asynchronous
+// uploads), ONE lm_match_batch matches them all, then every frame is post-processed like detectTemplate does, with its
+// colour checks on the GPU slot the frame is resident in.  in_frames[i] = {colour} or {colour, depth}.
+bool HighLevelLineMOD::detectTemplateBatch(std::vector<std::vector<Image>>& in_frames, uint16_t in_classNumber,
+                                           std::vector<std::vector<lm_match_t>>& out_matches,
+                                           std::vector<std::vector<std::vector<ObjectPose>>>& out_poses) {
+    const int n = (int)in_frames.size();
+    out_matches.assign((size_t)n, {});
+    out_poses.assign((size_t)n, {});
+    if (n == 0) return false;
+    for (int i = 0; i < n; ++i) {
+        if (in_frames[(size_t)i].empty()) { error = "no images"; return false; }
+        const Image& color = in_frames[(size_t)i][0];
+        const Image* depth_img = in_frames[(size_t)i].size() >= 2 ? &in_frames[(size_t)i][1] : nullptr;
+        const Image* match_depth = onlyColorModality ? nullptr : depth_img;
+        if (color.width != videoWidth || color.height != videoHeight) { error = "frame size differs from the detector's"; return false; }
+        if (lm_upload_frame(detector, i, static_cast<const uint8_t*>(color.data), color.stride,
+                            match_depth ? static_cast<const uint16_t*>(match_depth->data) : nullptr,
+                            match_depth ? match_depth->stride : 0) != LM_OK) { error = lm_last_error(); return false; }
+    }
+    size_t cap = 4096;
+    std::vector<lm_match_t> buf;
+    std::vector<int32_t> counts((size_t)n);
+    for (;;) {
+        buf.resize(cap * (size_t)n);
+        int rc = lm_match_batch(detector, n, detectorThreshold, in_classNumber, buf.data(), cap, counts.data());
+        size_t need = 0;
+        for (int32_t c : counts) need = std::max(need, (size_t)c);
+        if (rc == LM_ERR_OVERFLOW && need > cap) { cap = need; continue; }   // the reference consumes ALL matches
+        if (rc != LM_OK) { error = lm_last_error(); return false; }
+        break;
+    }
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        out_matches[(size_t)i].assign(buf.begin() + (ptrdiff_t)(cap * (size_t)i), buf.begin() + (ptrdiff_t)(cap * (size_t)i + (size_t)counts[(size_t)i]));
+        if (out_matches[(size_t)i].empty()) continue;
+        any = true;
+        const Image* depth_img = in_frames[(size_t)i].size() >= 2 ? &in_frames[(size_t)i][1] : nullptr;
+        out_poses[(size_t)i] = postProcess(out_matches[(size_t)i], in_frames[(size_t)i][0], depth_img, in_classNumber, gpuColorCheck ? i : -1);
+    }
+    return any;
 }
 
 void HighLevelLineMOD::writeLinemod() {

@@ -85,6 +85,16 @@ public:
     // poses) when template poses are known for the class.  Returns true iff the raw match list is non-empty.
     bool detectTemplate(std::vector<Image>& in_imgs, uint16_t in_classNumber);
 
+    // The same for a batch of frames in one lm_match_batch (not in the reference, which sees one camera frame at a
+    // time; BASELINE config 5): per frame the raw match list and the pose groups detectTemplate would produce.
+    bool detectTemplateBatch(std::vector<std::vector<Image>>& in_frames, uint16_t in_classNumber,
+                             std::vector<std::vector<lm_match_t>>& out_matches,
+                             std::vector<std::vector<std::vector<ObjectPose>>>& out_poses);
+    // colour checks of the post-processing on the GPU (default) or on the host (the reference's one-match-at-a-time way)
+    void setGpuColorCheck(bool on) { gpuColorCheck = on; }
+    // detector frame slots needed by detectTemplateBatch: lm_config.frame_slots (default 8)
+    static constexpr int kBatchSlots = 8;
+
     // The raw, sorted, unique match list of the last detectTemplate (the reference's private `matches`).
     const std::vector<lm_match_t>& getMatches() const { return matches; }
     std::vector<std::vector<ObjectPose>> getObjectPoses() { return posesMultipleObj; }   // :322-325
@@ -119,7 +129,10 @@ private:
     std::vector<std::vector<TemplatePose>>* modelTemplates;   // :165
     std::vector<ModelProperties>* modProps;                   // :169
     std::string error;
+    bool gpuColorCheck = true;
     void readColorRanges();
+    std::vector<std::vector<ObjectPose>> postProcess(const std::vector<lm_match_t>& in_matches, const Image& color,
+                                                     const Image* depth_img, uint16_t in_classNumber, int gpu_slot);
 };
 
 // utility.cpp: linemod_settings.yml -> the two settings structs (keys as in the reference's file).

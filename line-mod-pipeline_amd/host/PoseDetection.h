@@ -1,0 +1,52 @@
+// PoseDetection.h -- headless equivalent of the reference's online pipeline class
+//     class PoseDetection            /root/reference/include/PoseDetection.h:18-106, src/PoseDetection.cpp
+// over the HighLevelLineMOD facade: class name -> index (:49), principal-point shift of both images (:54-59,192-197),
+// detectTemplate (:66), first pose of every group until in_numberOfObjects (:86-92).  What the reference does besides
+// (OpenGL renderer, ICP refinement :72-84 -- off in the shipped settings --, Hodan error :96-104, drawing and imshow
+// :105-123) needs a display / OpenGL / OpenCV and is out of scope.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "HighLevelLinemod.h"
+
+namespace lmamd {
+
+class PoseDetection {
+public:
+    // The reference's constructor reads linemod_settings.yml and the template files itself (:3-18); here the settings
+    // are handed in (readSettings() fills them from the same file) and loadTemplates() is readLinemodFromFile (:142-160).
+    PoseDetection(CameraParameters const& in_camParams, TemplateGenerationSettings const& in_templateSettings);
+    ~PoseDetection();
+    PoseDetection(const PoseDetection&) = delete;
+    PoseDetection& operator=(const PoseDetection&) = delete;
+
+    void loadTemplates();                                   // readLinemodFromFile: line->readLinemod(), class ids
+    HighLevelLineMOD* lineMod() { return line; }            // to add templates in-process instead of reading files
+    void refreshClassIds();                                 // after templates were added through lineMod()
+
+    // :45-126.  in_imgs = {colour, depth}.  Like the reference, the poses are appended to in_objPose only when
+    // in_displayResults is set (:105-112: the push_back sits inside `if (in_displayResults)`); nothing is drawn here.
+    // getFinalObjectPoses() returns them either way.
+    void detect(std::vector<Image>& in_imgs, std::string const& in_className, uint16_t const& in_numberOfObjects,
+                std::vector<ObjectPose>& in_objPose, bool in_displayResults);
+    // The same for a batch of frames in one pass over the GPU (BASELINE config 5): out[i] = final poses of frame i.
+    void detectBatch(std::vector<std::vector<Image>>& in_frames, std::string const& in_className,
+                     uint16_t const& in_numberOfObjects, std::vector<std::vector<ObjectPose>>& out_objPoses);
+    const std::vector<ObjectPose>& getFinalObjectPoses() const { return finalObjectPoses; }
+
+private:
+    uint16_t findIndexInVector(std::string const& in_stringToFind, std::vector<std::string>& in_vectorToLookIn);   // :134-140
+    HighLevelLineMOD* line;
+    CameraParameters camParams;
+    TemplateGenerationSettings templateSettings;
+    std::vector<std::string> ids;
+    std::vector<std::vector<ObjectPose>> detectedPoses;
+    std::vector<ObjectPose> finalObjectPoses;
+    // shifted copies of one frame (translateImg works in place on clones, :54-59)
+    struct Shifted { std::vector<uint8_t> color; std::vector<uint16_t> depth; };
+    void shiftFrame(const std::vector<Image>& in_imgs, Shifted& buf, std::vector<Image>& out);
+    void pickFinal(const std::vector<std::vector<ObjectPose>>& groups, uint16_t nObjects, std::vector<ObjectPose>& out);
+};
+
+}  // namespace lmamd

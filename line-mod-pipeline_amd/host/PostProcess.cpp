@@ -292,9 +292,10 @@ void calculate_template_pose(Vec3 cam, int16_t inplaneRot, float t[3], float q[4
 // ==================================================================================================
 // PostProcessor
 // ==================================================================================================
-bool PostProcessor::color_check(const lm_match_t& m, const std::vector<uint8_t>& color_mask) {
+bool PostProcessor::color_counts(const lm_match_t& m, const std::vector<uint8_t>& color_mask, long* in_hull, long* in_both) {
     std::vector<Pt> pts;
     const int M = lm_num_modalities(det);
+    *in_hull = 0; *in_both = 0;
     for (int mod = 0; mod < M; ++mod) {   // templates[m].features for m < num_modalities = the level-0 templates (:120-126)
         int n = 0, tw = 0, th = 0;
         if (lm_get_template(det, m.class_idx, m.template_id, 0, mod, &tw, &th, nullptr, &n) != LM_OK) return false;
@@ -302,11 +303,20 @@ bool PostProcessor::color_check(const lm_match_t& m, const std::vector<uint8_t>&
         lm_get_template(det, m.class_idx, m.template_id, 0, mod, &tw, &th, f.data(), &n);
         for (const lm_feature& ft : f) pts.push_back(Pt{ft.x + m.x, ft.y + m.y});
     }
+    hull_counts(convex_hull(pts), color_mask.data(), st.videoWidth, st.videoHeight, in_hull, in_both);
+    return true;
+}
+
+static bool color_verdict(long in_hull, long in_both, uint16_t percentToPassCheck) {
+    if (in_hull == 0) return false;                         // the reference would divide by zero
+    float nonZer = (float)(in_both * 100 / in_hull);         // integer division first (:432)
+    return nonZer > (float)percentToPassCheck;
+}
+
+bool PostProcessor::color_check(const lm_match_t& m, const std::vector<uint8_t>& color_mask) {
     long in_hull = 0, in_both = 0;
-    hull_counts(convex_hull(pts), color_mask.data(), st.videoWidth, st.videoHeight, &in_hull, &in_both);
-    if (in_hull == 0) return false;                        // the reference would divide by zero
-    float nonZer = (float)(in_both * 100 / in_hull);        // integer division first (:432)
-    return nonZer > (float)st.percentToPassCheck;
+    if (!color_counts(m, color_mask, &in_hull, &in_both)) return false;
+    return color_verdict(in_hull, in_both, st.percentToPassCheck);
 }
 
 bool PostProcessor::depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth) {
@@ -346,12 +356,11 @@ ObjectPose PostProcessor::make_pose(const lm_match_t& m, const std::vector<Templ
 
 std::vector<std::vector<ObjectPose>> PostProcessor::run(const std::vector<lm_match_t>& matches, const uint8_t* bgr,
                                                         size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
-                                                        const std::vector<TemplatePose>& templates, const ModelProperties& props) {
+                                                        const std::vector<TemplatePose>& templates, const ModelProperties& props,
+                                                        int gpu_slot) {
     std::vector<std::vector<ObjectPose>> poses;
     if (matches.empty()) return poses;
     const int w = st.videoWidth, h = st.videoHeight;
-    std::vector<uint8_t> color_mask;
-    bgr2hsv_inrange(bgr, w, h, bgr_stride, props.lowerColorRange, props.upperColorRange, color_mask);   // :159-161
     std::vector<uint16_t> dense_depth;
     if (depth) {
         if (depth_stride == 0) depth_stride = (size_t)w * 2;
@@ -360,13 +369,33 @@ std::vector<std::vector<ObjectPose>> PostProcessor::run(const std::vector<lm_mat
             std::memcpy(&dense_depth[(size_t)y * w], reinterpret_cast<const uint8_t*>(depth) + y * depth_stride, (size_t)w * 2);
     }
     std::vector<MatchGroup> groups = discard_small_groups(group_similar_matches(matches, st.radiusThresholdNewObject), st.discardGroupRatio);
+    // colour check: on the host one match at a time as the reference does (:424-434), or every match of every surviving
+    // group in one GPU batch up front -- the sequential accept / break logic below then only looks the verdicts up
+    std::vector<uint8_t> color_mask;
+    std::vector<int64_t> gin, gboth;
+    std::vector<size_t> gpos(matches.size(), (size_t)-1);
+    if (gpu_slot >= 0) {
+        std::vector<lm_match_t> todo;
+        for (const MatchGroup& g : groups)
+            for (uint32_t idx : g.matchIndices)
+                if ((size_t)matches[idx].template_id < templates.size()) { gpos[idx] = todo.size(); todo.push_back(matches[idx]); }
+        gin.resize(todo.size()); gboth.resize(todo.size());
+        if (lm_color_check_counts(det, gpu_slot, props.lowerColorRange, props.upperColorRange, todo.data(), todo.size(),
+                                  gin.data(), gboth.data()) != LM_OK) {
+            error = lm_last_error();
+            return poses;
+        }
+    } else {
+        bgr2hsv_inrange(bgr, w, h, bgr_stride, props.lowerColorRange, props.upperColorRange, color_mask);   // :159-161
+    }
     for (const MatchGroup& g : groups) {   // :165-174, applyPostProcessing (:382-421)
         std::vector<ObjectPose> objPoses;
         for (uint32_t idx : g.matchIndices) {
             const lm_match_t& m = matches[idx];
             if ((size_t)m.template_id >= templates.size()) continue;
             int32_t tempDepth = (int32_t)templates[(size_t)m.template_id].translation[2];
-            bool ok = color_check(m, color_mask);
+            bool ok = gpu_slot >= 0 ? color_verdict((long)gin[gpos[idx]], (long)gboth[gpos[idx]], st.percentToPassCheck)
+                                    : color_check(m, color_mask);
             if (ok && depth) ok = depth_check(m, dense_depth.data(), templates, &tempDepth);   // && short-circuit like the reference
             if (ok) objPoses.push_back(make_pose(m, templates, tempDepth));
             if (objPoses.size() == st.numberWantedPoses) break;

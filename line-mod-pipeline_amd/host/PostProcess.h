@@ -86,12 +86,20 @@ class PostProcessor {
 public:
     PostProcessor(lm_detector* det, const PostProcessSettings& s) : det(det), st(s) {}
     // detectTemplate's tail (:157-175): colour mask, grouping, per-group colour/depth checks, poses.
+    // gpu_slot >= 0: the (same) frame is resident in that slot of the detector and the colour checks of ALL matches of
+    // the surviving groups are computed there in one batch (lm_color_check_counts: colour mask once per frame, one
+    // wave per hull) instead of one full-frame fillPoly + two countNonZero per tested match; -1: on the host.
     std::vector<std::vector<ObjectPose>> run(const std::vector<lm_match_t>& matches, const uint8_t* bgr, size_t bgr_stride,
                                              const uint16_t* depth, size_t depth_stride,
-                                             const std::vector<TemplatePose>& templates, const ModelProperties& props);
+                                             const std::vector<TemplatePose>& templates, const ModelProperties& props,
+                                             int gpu_slot = -1);
+    // the two counts of colorCheck for one match, on the host (also the checker of the GPU path)
+    bool color_counts(const lm_match_t& m, const std::vector<uint8_t>& color_mask, long* in_hull, long* in_both);
+    const std::string& lastError() const { return error; }
 
 private:
     bool color_check(const lm_match_t& m, const std::vector<uint8_t>& color_mask);                          // :424-434
+    std::string error;
     bool depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth);  // :437-457
     ObjectPose make_pose(const lm_match_t& m, const std::vector<TemplatePose>& t, int32_t tempDepth);       // :459-515
     lm_detector* det;

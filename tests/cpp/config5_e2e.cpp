@@ -1,0 +1,145 @@
+// BASELINE config 5 end to end on one GPU, headless: a batch of 8 frames of 1280x960 RGB-D with three objects each,
+// three classes (.ply models), lmamd::PoseDetection::detectBatch = principal-point shift -> upload -> ONE
+// lm_match_batch per class -> the reference's post-processing (grouping, colour check, depth check, poses), with the
+// colour checks batched on the GPU (lm_color_check_counts).  Prints, for pytest to compare:
+//   - "counts <n> <mismatches>": GPU in_hull / in_both of EVERY match of frame 0 against the host's hull_counts
+//   - the final poses with the colour check on the GPU and on the host (must be identical), and where each object was put
+// usage: config5_e2e <mesh.bin>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <vector>
+
+#include "../../line-mod-pipeline_amd/host/HighLevelLinemod.h"
+#include "../../line-mod-pipeline_amd/host/PoseDetection.h"
+#include "../../line-mod-pipeline_amd/host/PostProcess.h"
+#include "../../line-mod-pipeline_amd/host/TemplateGenerator.h"
+
+using namespace lmamd;
+
+static const int W = 1280, H = 960, NF = 8;
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    std::ifstream f(argv[1], std::ios::binary);
+    std::vector<char> mb((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(mb.data());
+    const uint32_t nv = hdr[0], nf = hdr[1];
+    const float* v = reinterpret_cast<const float*>(mb.data() + 8);
+    const int32_t* fi = reinterpret_cast<const int32_t*>(mb.data() + 8 + (size_t)nv * 12);
+    // three "models": the reference's part and two anisotropically scaled variants of it
+    const float scale[3][3] = {{1.f, 1.f, 1.f}, {1.35f, 1.f, 0.8f}, {0.75f, 1.25f, 1.1f}};
+    const char* names[3] = {"lagergehaeuse.ply", "wide.ply", "tall.ply"};
+    Mesh mesh[3];
+    for (int c = 0; c < 3; ++c) {
+        mesh[c].vertices.resize(nv);
+        for (uint32_t i = 0; i < nv; ++i) mesh[c].vertices[i] = Vec3{v[3 * i] * scale[c][0], v[3 * i + 1] * scale[c][1], v[3 * i + 2] * scale[c][2]};
+        mesh[c].indices.assign(fi, fi + (size_t)nf * 3);
+    }
+    CameraParameters cam;   // the shipped camera scaled to 1280x960, principal point off centre: the shift is (-12, +10)
+    cam.fx = 2089.74f; cam.fy = 2091.38282f; cam.cx = 652; cam.cy = 470; cam.videoWidth = W; cam.videoHeight = H;
+    TemplateGenerationSettings ts;
+    ts.onlyUseColorModality = false;
+    ts.detectorThreshold = 85.f;
+    ts.angleStart = -30; ts.angleStop = 30; ts.angleStep = 30;
+    PoseDetection pd(cam, ts);
+    HighLevelLineMOD& line = *pd.lineMod();
+    // templates are rendered with the principal point at the image centre (the reference's renderer, OpenglRender.cpp:9-11)
+    CameraParameters rcam = cam; rcam.cx = W / 2; rcam.cy = H / 2;
+    SoftRender render(rcam);
+    SymmetryProperties sym; sym.rotationallySymmetrical = true; sym.planesOfSymmetry = Vec3{1, 1, 1};
+    GeneratorSettings gs; gs.startDistance = 600; gs.endDistance = 700; gs.stepSize = 50; gs.subdivisions = 3;
+    for (int c = 0; c < 3; ++c) {
+        int n = generate_templates(line, render, mesh[c], names[c], sym, gs);
+        std::printf("class %d templates %d\n", c, n);
+        double lo[3] = {0, 0, 50}, hi[3] = {255, 150, 255};   // V >= 50: the black background fails the colour test
+        line.setColorRange((uint16_t)c, lo, hi);
+    }
+    pd.refreshClassIds();
+
+    // ---- scenes: per frame one rendered view of every class, pasted at its own place (in the SHIFTED frame the
+    // detector sees; the camera frame is that moved back by (+12, -10))
+    CameraViewPoints cams; cams.setModelProperties(sym);
+    std::vector<std::vector<uint8_t>> fb(NF, std::vector<uint8_t>((size_t)W * H * 3, 0));
+    std::vector<std::vector<uint16_t>> fd(NF, std::vector<uint16_t>((size_t)W * H, 0));
+    int placed[NF][3][2];
+    for (int i = 0; i < NF; ++i)
+        for (int c = 0; c < 3; ++c) {
+            const float radius = 600.f + 50.f * (float)((i + c) % 3);
+            cams.createCameraViewPoints(radius, 3);
+            const Vec3 vp = cams.getVertices()[(size_t)((3 * i + 5 * c) % (int)cams.getVertices().size())];
+            std::vector<uint8_t> bgr, rot; std::vector<uint16_t> depth, drot;
+            render.render(mesh[c], vp, bgr, depth);
+            const float ang = (float)(-30 + 30 * ((i + 2 * c) % 3));
+            warp_rotate_u8(bgr.data(), W, H, 3, ang, rot);
+            warp_rotate_u16(depth.data(), W, H, ang, drot);
+            const int ox = -380 + 380 * c + 12 * (i % 3), oy = -200 + 55 * i - 30 * c;     // object centre away from the image centre
+            placed[i][c][0] = ox; placed[i][c][1] = oy;
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    const int sx = x - ox - 12, sy = y - oy + 10;                             // camera frame = shifted frame moved by (+12, -10)
+                    if (sx < 0 || sy < 0 || sx >= W || sy >= H) continue;
+                    const uint16_t d = drot[(size_t)sy * W + sx];
+                    if (d > 1) {
+                        fd[i][(size_t)y * W + x] = d;
+                        std::memcpy(&fb[i][((size_t)y * W + x) * 3], &rot[((size_t)sy * W + sx) * 3], 3);
+                    }
+                }
+        }
+    std::vector<std::vector<Image>> frames(NF, std::vector<Image>(2));
+    for (int i = 0; i < NF; ++i) {
+        frames[i][0].data = fb[i].data(); frames[i][0].width = W; frames[i][0].height = H; frames[i][0].type = 0;
+        frames[i][1].data = fd[i].data(); frames[i][1].width = W; frames[i][1].height = H; frames[i][1].type = 1;
+    }
+
+    // ---- the two counts of colorCheck, GPU batch vs host, for every raw match of every frame and class (the frames
+    // as they are, unshifted: after detectTemplateBatch frame i is resident in slot i)
+    {
+        PostProcessSettings ps; ps.videoWidth = W; ps.videoHeight = H;
+        PostProcessor pp(line.handle(), ps);
+        const double lo[3] = {0, 0, 50}, hi[3] = {255, 150, 255};
+        size_t total = 0, bad = 0;
+        long sum_hull = 0, sum_both = 0;
+        std::vector<std::vector<uint8_t>> cmask(NF);
+        for (int i = 0; i < NF; ++i) bgr2hsv_inrange(fb[i].data(), W, H, 0, lo, hi, cmask[i]);
+        for (int c = 0; c < 3; ++c) {
+            std::vector<std::vector<lm_match_t>> m;
+            std::vector<std::vector<std::vector<ObjectPose>>> groups;
+            line.detectTemplateBatch(frames, (uint16_t)c, m, groups);
+            for (int i = 0; i < NF; ++i) {
+                std::vector<int64_t> gi(m[i].size()), gb(m[i].size());
+                if (lm_color_check_counts(line.handle(), i, lo, hi, m[i].data(), m[i].size(), gi.data(), gb.data()) != LM_OK) {
+                    std::printf("lm_color_check_counts failed: %s\n", lm_last_error());
+                    return 1;
+                }
+                for (size_t k = 0; k < m[i].size(); ++k) {
+                    long a = 0, b = 0;
+                    pp.color_counts(m[i][k], cmask[i], &a, &b);
+                    if (a != (long)gi[k] || b != (long)gb[k]) ++bad;
+                    sum_hull += a; sum_both += b; ++total;
+                }
+            }
+        }
+        std::printf("counts %zu %zu hull %ld both %ld\n", total, bad, sum_hull, sum_both);
+    }
+
+    // ---- the whole path, colour checks on the GPU and on the host
+    for (int mode = 0; mode < 2; ++mode) {
+        line.setGpuColorCheck(mode == 0);
+        for (int c = 0; c < 3; ++c) {
+            std::vector<std::vector<ObjectPose>> poses;
+            pd.detectBatch(frames, names[c], 1, poses);
+            for (int i = 0; i < NF; ++i) {
+                std::printf("%s frame %d class %d placed %d %d poses %zu", mode == 0 ? "gpu" : "host", i, c, placed[i][c][0], placed[i][c][1], poses[i].size());
+                for (const ObjectPose& p : poses[i])
+                    std::printf(" t %.9g %.9g %.9g q %.9g %.9g %.9g %.9g bb %d %d %d %d", p.translation.x, p.translation.y, p.translation.z,
+                                p.quaternions.w, p.quaternions.x, p.quaternions.y, p.quaternions.z, p.boundingBox.x, p.boundingBox.y,
+                                p.boundingBox.width, p.boundingBox.height);
+                std::printf("\n");
+            }
+        }
+    }
+    if (!line.lastError().empty()) std::printf("last error: %s\n", line.lastError().c_str());
+    return 0;
+}

@@ -374,3 +374,37 @@ def test_scan_pruning_is_exact(lm, orc, synth, color_only, thr):
     if thr == 0.0:
         assert stats[0][0] == stats[0][1]                       # nothing can be pruned when every position qualifies
     d.close()
+
+
+def test_color_check_counts_against_numpy_fill(lm, synth):
+    """lm_color_check_counts (f1: fillPoly of the template's feature hull + the two countNonZero of colorCheck) on
+    hulls whose fill is known in closed form: axis-aligned rectangles (corner features) and a single point, partly
+    outside the frame, against a numpy colour mask built with the same HSV rule on a two-colour image."""
+    W, H = 640, 480
+    d = lm.Detector(color_only=True, width=W, height=H)
+    # templates: rectangle 40 x 24 (corners + interior points), 1-point template, horizontal segment
+    shapes = [[(0, 0), (40, 0), (40, 24), (0, 24), (7, 9)], [(5, 5)], [(0, 3), (30, 3), (12, 3)]]
+    descs = np.zeros(len(shapes) * 2, synth.DESC_DTYPE)
+    feats = []
+    for t, pts in enumerate(shapes):
+        for l in range(2):
+            f = np.zeros(len(pts), synth.FEATURE_DTYPE)
+            f["x"] = [p[0] >> l for p in pts]; f["y"] = [p[1] >> l for p in pts]
+            descs[t * 2 + l] = (48 >> l, 32 >> l, l, len(pts))
+            feats.append(f)
+    d.add_class("shapes", descs, np.concatenate(feats))
+    bgr = np.zeros((H, W, 3), np.uint8)
+    bgr[:, 300:] = (40, 200, 90)                          # right part: V = 200 passes V >= 100, left part black fails
+    d.upload_frame(0, bgr)
+    mask = np.zeros((H, W), bool); mask[:, 300:] = True
+    m = np.zeros(6, lm.MATCH_DTYPE)
+    m["x"] = [280, 10, 620, 0, 290, -20]; m["y"] = [100, 10, 470, 0, 50, -2]; m["template_id"] = [0, 0, 0, 1, 2, 2]
+    a, b = d.color_check_counts(0, [0, 0, 100], [180, 255, 255], m)
+    for k in range(6):
+        pts = np.array(shapes[m["template_id"][k]])
+        x0, x1 = pts[:, 0].min() + m["x"][k], pts[:, 0].max() + m["x"][k]
+        y0, y1 = pts[:, 1].min() + m["y"][k], pts[:, 1].max() + m["y"][k]
+        xs = slice(max(x0, 0), min(x1, W - 1) + 1); ys = slice(max(y0, 0), min(y1, H - 1) + 1)
+        region = np.zeros((H, W), bool); region[ys, xs] = True
+        assert a[k] == region.sum() and b[k] == (region & mask).sum(), (k, a[k], b[k])
+    d.close()
