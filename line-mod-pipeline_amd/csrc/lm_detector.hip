@@ -138,7 +138,7 @@ struct lm_detector {
     int* d_raw_thr = nullptr;
     int* h_raw_thr = nullptr;
     float raw_thr_for = -1.0f;
-    u32* d_plan = nullptr;        // k_refine_plan output, one per lane: [8][plan_stride_cap] + [8]
+    u32* d_plan = nullptr;        // k_refine_plan output, one per lane: [8][cap] slots + [8] lengths + [8][cap + 1] running sums
     int plan_stride_cap = 0;
     u64* d_resp_tab = nullptr;
     u32* d_sim_lut = nullptr;
@@ -241,7 +241,7 @@ int ensure_device(lm_detector* d) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_raw_thr), 128 * sizeof(int)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d->h_raw_thr), 128 * sizeof(int)));
     d->plan_stride_cap = std::max(S / 8 * 2, 2);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_plan), 2 * (8 * (size_t)d->plan_stride_cap + 8) * sizeof(u32)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_plan), 2 * (16 * (size_t)d->plan_stride_cap + 16) * sizeof(u32)));
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     // lane 1's stream right behind lane 0's: the runtime deals streams to its hardware queues in creation order, and
     // two lanes that land on one queue run strictly one after the other (measured r02: 87 K instead of 102 K det/s)
@@ -500,7 +500,7 @@ int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, Item
         u32* plan = nullptr;
         const int plan_cap = n / 8;          // every XCD gets exactly its share of slots, the heavy ones spread out
         if ((n % 8) == 0 && n <= 1024 && d->d_plan) {
-            plan = d->d_plan + (size_t)d->active * (8 * (size_t)d->plan_stride_cap + 8);
+            plan = d->d_plan + (size_t)d->active * (16 * (size_t)d->plan_stride_cap + 16);
             lmk_refine_plan(d->stream, make_refine_args(d, first, L - 2, threshold), n, plan, plan_cap);
         }
         for (int l = L - 2; l >= 0; --l) {

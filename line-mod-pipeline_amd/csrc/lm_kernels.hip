@@ -1393,7 +1393,7 @@ __global__ __launch_bounds__(1024) void k_refine_plan(const LmDevHeader* __restr
                                                        int nslots, u32 cand_cap, int cap, u32* __restrict__ plan) {
     __shared__ u32 cnt[1024];
     __shared__ u32 sorted_cnt[1024], sorted_slot[1024];
-    __shared__ u32 pl[2048 + 8];
+    __shared__ u32 pl[2 * 1024 + 16 + 8];   // [8][cap] slots | [8] lengths | [8][cap + 1] running sums, cap <= 128
     const int tid = threadIdx.x;
     u32 c = 0;
     if (tid < nslots) {
@@ -1432,9 +1432,102 @@ __global__ __launch_bounds__(1024) void k_refine_plan(const LmDevHeader* __restr
         for (int x = 0; x < 8; ++x) pl[8 * cap + x] = len[x];
     }
     __syncthreads();
-    for (int i = tid; i < 8 * cap + 8; i += 1024) plan[i] = pl[i];
+    // running sums of the candidate counts along every XCD's list (k_refine's queue): [8][cap + 1] behind the lengths
+    if (tid < 8) {
+        u32 acc = 0;
+        u32* pre = pl + 8 * cap + 8 + tid * (cap + 1);
+        const u32 n = pl[8 * cap + tid];
+        for (u32 k = 0; k < n; ++k) { pre[k] = acc; acc += cnt[pl[tid * cap + k]]; }
+        for (u32 k = n; k <= (u32)cap; ++k) pre[k] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < 8 * cap + 8 + 8 * (cap + 1); i += 1024) plan[i] = pl[i];
 }
 
+// One candidate of one slot: similarityLocal over the 16 x 16 patch, first-max argmax, rescore, threshold filter.
+template <bool LAST>
+__device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 i, const u8 (*resp)[256], int lane) {
+    LmDevHeader* hdr = slot_ptr_s(a.hdr, a.aux_slot_stride, slot);
+    LmCand* cand = slot_ptr_s(a.cand, a.aux_slot_stride, slot);
+    u64* keys = slot_ptr_s(a.keys, a.aux_slot_stride, slot);
+    const u8* lm = a.lm + (size_t)slot * a.lm_slot_stride;
+    const int T = a.g.T, W = a.g.W;
+    const int border = 8 * T;
+    const int offset = T / 2 + (T % 2 - 1);
+    const u32 lane_off = (u32)((lane >> 2) * W + (lane & 3) * 4);
+    LmCand c = cand[i];
+    u32 ti = (u32)__builtin_amdgcn_readfirstlane((int)c.ti);
+    if (ti == LM_DROPPED) return;
+    int cx = __builtin_amdgcn_readfirstlane(c.x), cy = __builtin_amdgcn_readfirstlane(c.y);
+    const LmRefMeta mt = a.meta[ti];
+    int max_x = a.g.w - mt.width - border, max_y = a.g.h - mt.height - border;
+    int x = cx * 2 + 1, y = cy * 2 + 1;
+    x = x > border ? x : border; y = y > border ? y : border;
+    x = x < max_x ? x : max_x;  y = y < max_y ? y : max_y;
+    int bx = x / T - 8, by = y / T - 8;
+    int off_x = bx * T, off_y = by * T;
+    const u32 shift = (u32)(by * W + bx);   // two's complement: feature offset + shift >= 0 for kept features
+    u32 s01 = 0, s23 = 0;   // u16 pairs: patch positions {0, 1} and {2, 3} of this lane (sums <= 126 * 4)
+    for (int m = 0; m < a.M; ++m) {
+        const int cnt = (int)mt.count[m];
+        LmRefFeat ft;
+        ft.off = 0; ft.x = 0; ft.y = 0;
+        if (lane < cnt) ft = a.feats[mt.start[m] + lane];
+        int fx = ft.x + off_x, fy = ft.y + off_y;
+        bool ok = (lane < cnt) && fx >= 0 && fy >= 0 && fx < a.g.w && fy < a.g.h;
+        const u32 eff = ok ? (ft.off & 0x1FFFFFFFu) + shift : a.g.zero_off;
+        const u32 lab = ft.off >> 29;
+        for (int f = 0; f < cnt; f += 8) {
+            u32 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                // dword-aligned 8-byte load + v_alignbyte instead of a byte-misaligned dword load
+                const u32 t = (u32)__builtin_amdgcn_readlane((int)eff, f + k) + lane_off;
+                const u32x2 d = ld8a4(lm + (t & ~3u));
+                v[k] = __builtin_amdgcn_alignbyte(d[1], d[0], t & 3u);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const u32 lb = (u32)__builtin_amdgcn_readlane((int)lab, f + k);
+                const u8* tab = resp[lb];
+                const u32 r0 = tab[v[k] & 0xFFu], r1 = tab[(v[k] >> 8) & 0xFFu];
+                const u32 r2 = tab[(v[k] >> 16) & 0xFFu], r3 = tab[v[k] >> 24];
+                s01 += r0 | (r1 << 16);
+                s23 += r2 | (r3 << 16);
+            }
+        }
+    }
+    // first maximum in row-major order: key = score << 8 | (255 - index)
+    u32 idx0 = (u32)lane * 4u;
+    u32 k0 = ((s01 & 0xFFFF) << 8) | (255u - idx0);
+    u32 k1 = ((s01 >> 16) << 8) | (254u - idx0);
+    u32 k2 = ((s23 & 0xFFFF) << 8) | (253u - idx0);
+    u32 k3 = ((s23 >> 16) << 8) | (252u - idx0);
+    u32 k01 = k0 > k1 ? k0 : k1, k23 = k2 > k3 ? k2 : k3;
+    u32 key = wave_max_u32(k01 > k23 ? k01 : k23);
+    int best = (int)(key >> 8);
+    int best_r = -1, best_c = -1;
+    if (best > 0) { int idx = 255 - (int)(key & 255u); best_r = idx >> 4; best_c = idx & 15; }
+    int nx = (bx + best_c) * T + offset, ny = (by + best_r) * T + offset;
+    float sim = __fdiv_rn(__fmul_rn((float)best, 100.f), (float)(4 * mt.nfeat_total));
+    if (lane == 0) {
+        if (sim < a.threshold) {
+            cand[i].ti = LM_DROPPED;
+        } else if (LAST) {
+            emit_key(a, hdr, keys, ti, nx, ny, sim);
+        } else {
+            LmCand o; o.ti = ti; o.x = nx; o.y = ny; o.sim = sim;
+            cand[i] = o;
+        }
+    }
+}
+
+// Work distribution.  Every slot must stay on ONE XCD (its spread memories live in that L2), and candidate counts
+// differ a lot between frames (30 .. 1500).  With a plan (k_refine_plan: eight balanced slot lists + the running sums of
+// their candidate counts) an XCD's workgroups form ONE queue over all candidates of the XCD's slots: wave w takes the
+// candidates w, w + waves, ... of the concatenated lists, so no wave idles while another slot of the XCD still has
+// work.  (Measured r02: the same 1.9 us per frame as a fixed share of workgroups per slot -- the kernel is bound by the
+// L2 lines a 16 x 16 patch pulls, 16 lines for 256 useful bytes, not by idle waves; kept because it cannot lose.)
 template <bool LAST>
 __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
     // response of orientation o to spread byte v = max(LUT_lo[o][v & 15], LUT_hi[o][v >> 4]): 8 x 256 bytes in LDS,
@@ -1442,19 +1535,22 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
     // v_perm lookups and a byte max (the kernel was VALU-bound on those)
     __shared__ u8 resp[8][256];
     const int lane = threadIdx.x & 63;
-    u32 slot, tile;
-    if (a.plan) {   // block b runs on XCD b % 8 (see xcd_slot_tile): take the idx-th slot of that XCD's list
-        const u32 x = blockIdx.x & 7u, kk = blockIdx.x >> 3, idx = kk / (u32)a.blocks_per_slot;
-        if (idx >= a.plan[(size_t)8 * a.plan_cap + x]) return;
-        slot = a.plan[(size_t)x * a.plan_cap + idx];
-        tile = kk - idx * (u32)a.blocks_per_slot;
+    u32 slot = 0, tile = 0, total = 0;
+    const u32* xs = nullptr; const u32* xpre = nullptr;
+    u32 xlen = 0;
+    if (a.plan) {   // block b runs on XCD b % 8 (see xcd_slot_tile)
+        const u32 x = blockIdx.x & 7u;
+        tile = blockIdx.x >> 3;
+        xs = a.plan + (size_t)x * a.plan_cap;
+        xlen = a.plan[(size_t)8 * a.plan_cap + x];
+        xpre = a.plan + (size_t)8 * a.plan_cap + 8 + (size_t)x * (a.plan_cap + 1);
+        total = xpre[xlen];
+        if (tile * 4u >= total) return;
     } else {
         xcd_slot_tile((u32)a.blocks_per_slot, (u32)a.nslots, slot, tile);
-    }
-    {   // nothing to do for this workgroup: leave before building the table
-        u32 n0 = slot_ptr_s(a.hdr, a.aux_slot_stride, slot)->cand_count;
-        if (n0 > a.cand_cap) n0 = a.cand_cap;
-        if (tile * 4u >= n0) return;
+        total = slot_ptr_s(a.hdr, a.aux_slot_stride, slot)->cand_count;
+        if (total > a.cand_cap) total = a.cand_cap;
+        if (tile * 4u >= total) return;   // nothing to do for this workgroup: leave before building the table
     }
     {
         const u8* sl = reinterpret_cast<const u8*>(a.sim_lut);   // [ori][lo 16 B | hi 16 B]
@@ -1468,82 +1564,14 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
     __syncthreads();
     const u32 wave0 = (u32)__builtin_amdgcn_readfirstlane((int)((tile * 256u + threadIdx.x) >> 6));
     const u32 nwaves = (u32)a.blocks_per_slot * 4u;
-    LmDevHeader* hdr = slot_ptr_s(a.hdr, a.aux_slot_stride, slot);
-    LmCand* cand = slot_ptr_s(a.cand, a.aux_slot_stride, slot);
-    u64* keys = slot_ptr_s(a.keys, a.aux_slot_stride, slot);
-    const u8* lm = a.lm + (size_t)slot * a.lm_slot_stride;
-    u32 n = hdr->cand_count;
-    if (n > a.cand_cap) n = a.cand_cap;
-    const int T = a.g.T, W = a.g.W;
-    const int border = 8 * T;
-    const int offset = T / 2 + (T % 2 - 1);
-    const u32 lane_off = (u32)((lane >> 2) * W + (lane & 3) * 4);
-    for (u32 i = wave0; i < n; i += nwaves) {
-        LmCand c = cand[i];
-        u32 ti = (u32)__builtin_amdgcn_readfirstlane((int)c.ti);
-        if (ti == LM_DROPPED) continue;
-        int cx = __builtin_amdgcn_readfirstlane(c.x), cy = __builtin_amdgcn_readfirstlane(c.y);
-        const LmRefMeta mt = a.meta[ti];
-        int max_x = a.g.w - mt.width - border, max_y = a.g.h - mt.height - border;
-        int x = cx * 2 + 1, y = cy * 2 + 1;
-        x = x > border ? x : border; y = y > border ? y : border;
-        x = x < max_x ? x : max_x;  y = y < max_y ? y : max_y;
-        int bx = x / T - 8, by = y / T - 8;
-        int off_x = bx * T, off_y = by * T;
-        const u32 shift = (u32)(by * W + bx);   // two's complement: feature offset + shift >= 0 for kept features
-        u32 s01 = 0, s23 = 0;   // u16 pairs: patch positions {0, 1} and {2, 3} of this lane (sums <= 126 * 4)
-        for (int m = 0; m < a.M; ++m) {
-            const int cnt = (int)mt.count[m];
-            LmRefFeat ft;
-            ft.off = 0; ft.x = 0; ft.y = 0;
-            if (lane < cnt) ft = a.feats[mt.start[m] + lane];
-            int fx = ft.x + off_x, fy = ft.y + off_y;
-            bool ok = (lane < cnt) && fx >= 0 && fy >= 0 && fx < a.g.w && fy < a.g.h;
-            const u32 eff = ok ? (ft.off & 0x1FFFFFFFu) + shift : a.g.zero_off;
-            const u32 lab = ft.off >> 29;
-            for (int f = 0; f < cnt; f += 8) {
-                u32 v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    // dword-aligned 8-byte load + v_alignbyte instead of a byte-misaligned dword load
-                    const u32 t = (u32)__builtin_amdgcn_readlane((int)eff, f + k) + lane_off;
-                    const u32x2 d = ld8a4(lm + (t & ~3u));
-                    v[k] = __builtin_amdgcn_alignbyte(d[1], d[0], t & 3u);
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const u32 lb = (u32)__builtin_amdgcn_readlane((int)lab, f + k);
-                    const u8* tab = resp[lb];
-                    const u32 r0 = tab[v[k] & 0xFFu], r1 = tab[(v[k] >> 8) & 0xFFu];
-                    const u32 r2 = tab[(v[k] >> 16) & 0xFFu], r3 = tab[v[k] >> 24];
-                    s01 += r0 | (r1 << 16);
-                    s23 += r2 | (r3 << 16);
-                }
-            }
+    if (a.plan) {
+        u32 idx = 0;
+        for (u32 g = wave0; g < total; g += nwaves) {
+            while (idx + 1 < xlen && xpre[idx + 1] <= g) ++idx;      // g only grows: the list position moves forward
+            refine_one<LAST>(a, xs[idx], g - xpre[idx], resp, lane);
         }
-        // first maximum in row-major order: key = score << 8 | (255 - index)
-        u32 idx0 = (u32)lane * 4u;
-        u32 k0 = ((s01 & 0xFFFF) << 8) | (255u - idx0);
-        u32 k1 = ((s01 >> 16) << 8) | (254u - idx0);
-        u32 k2 = ((s23 & 0xFFFF) << 8) | (253u - idx0);
-        u32 k3 = ((s23 >> 16) << 8) | (252u - idx0);
-        u32 k01 = k0 > k1 ? k0 : k1, k23 = k2 > k3 ? k2 : k3;
-        u32 key = wave_max_u32(k01 > k23 ? k01 : k23);
-        int best = (int)(key >> 8);
-        int best_r = -1, best_c = -1;
-        if (best > 0) { int idx = 255 - (int)(key & 255u); best_r = idx >> 4; best_c = idx & 15; }
-        int nx = (bx + best_c) * T + offset, ny = (by + best_r) * T + offset;
-        float sim = __fdiv_rn(__fmul_rn((float)best, 100.f), (float)(4 * mt.nfeat_total));
-        if (lane == 0) {
-            if (sim < a.threshold) {
-                cand[i].ti = LM_DROPPED;
-            } else if (LAST) {
-                emit_key(a, hdr, keys, ti, nx, ny, sim);
-            } else {
-                LmCand o; o.ti = ti; o.x = nx; o.y = ny; o.sim = sim;
-                cand[i] = o;
-            }
-        }
+    } else {
+        for (u32 i = wave0; i < total; i += nwaves) refine_one<LAST>(a, slot, i, resp, lane);
     }
 }
 
@@ -2016,8 +2044,8 @@ void lmk_refine(hipStream_t s, const LmRefineArgs& a_in, bool last, int nslots) 
     // persistent waves stride over the slot's candidate list; with the XCD-affine mapping one slot runs on one
     // XCD (32 CUs x 32 waves), so 256 blocks = 1024 waves per slot fill it
     a.blocks_per_slot = 256; a.nslots = nslots;
-    // with a plan XCD x works through the plan_cap = nslots / 8 slots of its list
-    dim3 grid(a.plan ? (unsigned)(8 * a.plan_cap * a.blocks_per_slot) : (unsigned)(a.blocks_per_slot * nslots), 1, 1);
+    // with a plan the 256 workgroups of XCD x (8 per CU) are one queue over the candidates of the slots on its list
+    dim3 grid(a.plan ? (unsigned)(8 * a.blocks_per_slot) : (unsigned)(a.blocks_per_slot * nslots), 1, 1);
     if (last) hipLaunchKernelGGL(k_refine<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_refine<false>, grid, dim3(256), 0, s, a);
 }
