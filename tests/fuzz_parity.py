@@ -11,7 +11,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 det = lm.Detector(color_only=False)
 t0 = time.time()
-n_stage = n_match = 0
+n_stage = n_match = n_scan = 0
 
 
 def rand_bgr(h, w):
@@ -73,9 +73,17 @@ while time.time() - t0 < budget:
         d.close(); continue
     d.add_class("c", descs, feats); o.add_class("c", descs, feats)
     thr = float(rng.choice([60.0, 75.0, 85.0, 40.0]))
+    variant = int(rng.choice([0, 0, 8, 1, 2, 9]))          # load-block sizes, with (default) and without (bit 3) pruning
+    d.set_scan_variant(variant)
     got = d.match(bgr, None if color_only else depth, thr, cap=1 << 18)
     exp = o.match(bgr, None if color_only else depth, thr, threads=8, cap=1 << 18)
-    assert got.tobytes() == exp.tobytes(), ("match", color_only, T, w, h, n, thr, len(got), len(exp))
+    assert got.tobytes() == exp.tobytes(), ("match", color_only, T, w, h, n, thr, variant, len(got), len(exp))
+    # a11-a13 alone: the scan kernel's candidate list, record by record
+    d.upload_frame(1, bgr, None if color_only else depth)
+    d.prepare_slot(1)
+    assert np.array_equal(d.stage_scan(1, thr), o.scan_candidates(thr, threads=8)), ("scan", color_only, T, w, h, n, thr, variant)
     d.close()
     n_match += 1
-print("fuzz ok: %d stage rounds, %d whole matches in %.0f s" % (n_stage, n_match, time.time() - t0))
+    n_scan += 1
+print("fuzz ok: %d stage rounds, %d whole matches, %d scan candidate lists in %.0f s (seed %s)" % (
+    n_stage, n_match, n_scan, time.time() - t0, sys.argv[2] if len(sys.argv) > 2 else "1"))
