@@ -38,6 +38,7 @@ FLAG_BLOCKING_SYNC = 2
 TUNE_FORK_MAX_SLOTS = 1
 TUNE_MATCH_UPLOAD_MODE = 2
 TUNE_COPY_STREAMS = 3
+TUNE_CBLUR_VARIANT = 4
 
 
 class Rect(C.Structure):

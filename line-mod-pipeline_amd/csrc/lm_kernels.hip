@@ -50,6 +50,20 @@ __device__ __forceinline__ u32 next_lane(u32 v) {
     return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true);
 }
 
+// a + b * K for a 24-bit unsigned b and a small constant K (v_mad_u32_u24: full rate; a plain 32-bit multiply is
+// v_mul_lo_u32, quarter rate, and __umul24 makes the compiler mask both operands first).  K is an inline constant of
+// the instruction (0..64); larger ones are split.
+template <int K>
+__device__ __forceinline__ u32 mad24(u32 b, u32 a) {
+    if constexpr (K > 64) {
+        return mad24<64>(b, mad24<K - 64>(b, a));
+    } else {
+        u32 r;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(b), "n"(K), "v"(a));
+        return r;
+    }
+}
+
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // v_pk_max_u16 on two u16 pairs
 __device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
@@ -191,16 +205,14 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float p7 = -0.04432655554792128f * (float)(180.0 / 3.14159265358979323846);
     const float eps = (float)2.2204460492503131e-16;
     float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
-        c2 = __fmul_rn(c, c);
-        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
-    } else {
-        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
-        c2 = __fmul_rn(c, c);
-        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
-    }
+    // c = min / (max + eps) and ONE polynomial: the two branches of the reference (ay / (ax + eps) when ax >= ay, else
+    // ax / (ay + eps)) are this same quotient, so the if-converted code need not carry two correctly rounded divisions
+    const bool steep = !(ax >= ay);
+    const float mn = steep ? ax : ay, mx = steep ? ay : ax;
+    const float c = __fdiv_rn(mn, __fadd_rn(mx, eps));
+    const float c2 = __fmul_rn(c, c);
+    float a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    if (steep) a = __fsub_rn(90.f, a);
     if (x < 0) a = __fsub_rn(180.f, a);
     if (y < 0) a = __fsub_rn(360.f, a);
     return a;
@@ -432,6 +444,162 @@ __global__ __launch_bounds__(256) void k_cblur(const u8* __restrict__ bgr0, int 
         }
         st16(S + (size_t)y * pitch + 16 * b, u32x4{o4[0], o4[1], o4[2], o4[3]});
     }
+}
+
+// a1+a2, sliding-window form of k_cblur (the default).  Same arithmetic; what changes is how the rows reach the
+// registers.  k_cblur loads 8 source rows x 3 blocks for every 2 output rows (each source row is fetched by four
+// different lanes: 24 wave-loads per 2 KiB of output, 12 x read amplification through the L1) and every wave is one
+// load -> compute -> store shot, so at 4 waves per SIMD most of its time is memory latency.  Here a lane owns a column
+// block for a STRIP of CBS_STRIP rows and slides an 8-row window down it two rows at a time: the ring keeps the six
+// rows the next step re-uses, the two new rows are requested one step ahead (6 wave-loads per step, in flight while the
+// current step computes) -- a quarter of the L1 lookups, and the latency hides inside the wave.  The loop is unrolled
+// over the four ring phases so every register index is static (no moves: the ring rotates by renaming).
+#define CBS_STRIP 16
+__device__ __forceinline__ void cbs_request(const u8* bgr, int y, int h, u32 pitch, int b, int nblk, u32x4& c, u32x4& p, u32x4& n) {
+    // always three loads from valid addresses (the neighbour block is clamped at the row ends, where cbs_window does
+    // not use it): no exec-mask branches around loads; 32-bit offsets from the slot's base pointer
+    const u32 ro = (u32)clampi(y, 0, h - 1) * pitch;
+    c = ld16(bgr + (ro + 16u * (u32)b));
+    p = ld16(bgr + (ro + 16u * (u32)max(b - 1, 0)));
+    n = ld16(bgr + (ro + 16u * (u32)min(b + 1, nblk - 1)));
+}
+// window dwords of one row (bytes -12 .. +27 around the block), BORDER_REPLICATE at the row ends
+__device__ __forceinline__ void cbs_window(u32 (&w)[10], const u32x4& c, const u32x4& p, const u32x4& n, int b, int nblk) {
+    if (b > 0) { w[0] = p[1]; w[1] = p[2]; w[2] = p[3]; }
+    else {   // bytes -12..-1 replicate pixel 0 channel-wise: [B G R B][G R B G][R B G R]
+        w[0] = __builtin_amdgcn_perm(c[0], c[0], 0x00020100u);
+        w[1] = __builtin_amdgcn_perm(c[0], c[0], 0x01000201u);
+        w[2] = __builtin_amdgcn_perm(c[0], c[0], 0x02010002u);
+    }
+    w[3] = c[0]; w[4] = c[1]; w[5] = c[2]; w[6] = c[3];
+    if (b + 1 < nblk) { w[7] = n[0]; w[8] = n[1]; w[9] = n[2]; }
+    else {   // bytes 3w.. replicate the last pixel (bytes 1..3 of the last dword)
+        w[7] = __builtin_amdgcn_perm(c[3], c[3], 0x01030201u);
+        w[8] = __builtin_amdgcn_perm(c[3], c[3], 0x02010302u);
+        w[9] = __builtin_amdgcn_perm(c[3], c[3], 0x03020103u);
+    }
+}
+// The ring holds row PAIRS already interleaved (the first stage of the 4 x 4 byte transpose): pair k = source rows
+// (2k, 2k + 1) of the window as x0 = bytes {r0.0 r1.0 r0.1 r1.1}, x1 = {r0.2 r1.2 r0.3 r1.3} per window dword, so a
+// step only interleaves its NEW pair; logical pair i (source rows y - 3 + 2i, + 1) = ring[(i + P) & 3].
+__device__ __forceinline__ void cbs_pair(u32 (&pr)[10][2], const u32 (&r0)[10], const u32 (&r1)[10]) {
+#pragma unroll
+    for (int d = 0; d < 10; ++d) {
+        pr[d][0] = __builtin_amdgcn_perm(r1[d], r0[d], 0x05010400u);
+        pr[d][1] = __builtin_amdgcn_perm(r1[d], r0[d], 0x07030602u);
+    }
+}
+// two output rows (y, y + 1) from the four ring pairs
+template <int P>
+__device__ __forceinline__ void cbs_step(const u32 (&ring)[4][10][2], u32 (&o4)[2][4]) {
+    const u32 wA0 = 8u | (28u << 8) | (56u << 16) | (72u << 24), wB0 = 56u | (28u << 8) | (8u << 16);
+    const u32 wA1 = (8u << 8) | (28u << 16) | (56u << 24), wB1 = 72u | (56u << 8) | (28u << 16) | (8u << 24);
+    // Column sums are produced window dword by window dword; output dword j needs window dwords j .. j + 6 (taps at
+    // bytes -9 .. +9), so it is emitted as soon as dword j + 6 is done: at most 7 dwords of column sums are alive.
+    u32 vb[2][40];                                         // column sums per window byte (<= 65280)
+#pragma unroll
+    for (int d = 0; d < 10; ++d) {
+        u32 T[2][4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {                      // second stage: rows 4g .. 4g+3 of one byte column per dword
+            const u32 x0 = ring[(2 * g + P) & 3][d][0], x1 = ring[(2 * g + P) & 3][d][1];
+            const u32 z0 = ring[(2 * g + 1 + P) & 3][d][0], z1 = ring[(2 * g + 1 + P) & 3][d][1];
+            T[g][0] = __builtin_amdgcn_perm(z0, x0, 0x05040100u); T[g][1] = __builtin_amdgcn_perm(z0, x0, 0x07060302u);
+            T[g][2] = __builtin_amdgcn_perm(z1, x1, 0x05040100u); T[g][3] = __builtin_amdgcn_perm(z1, x1, 0x07060302u);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            vb[0][4 * d + c] = __builtin_amdgcn_udot4(T[0][c], wA0, __builtin_amdgcn_udot4(T[1][c], wB0, 0u, false), false);
+            vb[1][4 * d + c] = __builtin_amdgcn_udot4(T[0][c], wA1, __builtin_amdgcn_udot4(T[1][c], wB1, 0u, false), false);
+        }
+        if (d >= 6) {
+            const int j = d - 6;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                u32 packed = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i0 = 12 + 4 * j + q - 9;   // taps at window bytes i0, i0 + 3, ..., i0 + 18; sums < 2^16
+                    u32 acc = mad24<8>(vb[r][i0] + vb[r][i0 + 18], 32768u);
+                    acc = mad24<28>(vb[r][i0 + 3] + vb[r][i0 + 15], acc);
+                    acc = mad24<56>(vb[r][i0 + 6] + vb[r][i0 + 12], acc);
+                    acc = mad24<72>(vb[r][i0 + 9], acc);
+                    packed |= (acc >> 16) << (8 * q);
+                }
+                o4[r][j] = packed;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_cblur_sw(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
+                                                   size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    const u8* bgr = slot_ptr_s(bgr0, in_stride, slot);
+    u8* S = slot_ptr_s(s0, tmp_stride, slot);
+    const int nblk = (w * 3) >> 4;
+    const int gid = (int)(tile * 256u) + (int)threadIdx.x;
+    const int strip = gid / nblk, b = gid - strip * nblk;
+    const int y0 = strip * CBS_STRIP;
+    if (y0 >= h) return;
+    const u32 pitch = (u32)w * 3u;
+    u32 ring[4][10][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // the first window (source rows y0 - 3 .. y0 + 4), one pair at a time
+        u32x4 c[2], p[2], n[2];
+        cbs_request(bgr, y0 - 3 + 2 * k, h, pitch, b, nblk, c[0], p[0], n[0]);
+        cbs_request(bgr, y0 - 2 + 2 * k, h, pitch, b, nblk, c[1], p[1], n[1]);
+        u32 w0[10], w1[10];
+        cbs_window(w0, c[0], p[0], n[0], b, nblk); cbs_window(w1, c[1], p[1], n[1], b, nblk);
+        cbs_pair(ring[k], w0, w1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int y1 = min(y0 + CBS_STRIP, h);
+    const u32 bo = 16u * (u32)b, po = 16u * (u32)max(b - 1, 0), no = 16u * (u32)min(b + 1, nblk - 1);
+    // Requests run TWO steps ahead (a step is about 1.3 us of arithmetic at two waves per SIMD, a miss under load takes
+    // longer): set A holds the rows of the next step, set B those of the step after; the loop body is written twice so
+    // that the two sets swap roles by name.  Rows past the strip are requested too (clamped, never used): no branches
+    // around loads; all addresses first, then the six loads back to back.
+#define CBS_REQUEST(Y, C0, P0, N0, C1, P1, N1)                                                              \
+    {                                                                                                       \
+        const u32 r0 = (u32)clampi((Y), 0, h - 1) * pitch, r1 = (u32)clampi((Y) + 1, 0, h - 1) * pitch;     \
+        const u32 a0 = r0 + bo, a1 = r0 + po, a2 = r0 + no, a3 = r1 + bo, a4 = r1 + po, a5 = r1 + no;       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        C0 = ld16(bgr + a0); P0 = ld16(bgr + a1); N0 = ld16(bgr + a2);                                      \
+        C1 = ld16(bgr + a3); P1 = ld16(bgr + a4); N1 = ld16(bgr + a5);                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }
+    // one step: request the pair of step + 2 into the set that was consumed last, compute, THEN consume the set of step
+    // + 1 (the empty asm keeps the window assembly -- and with it the s_waitcnt -- behind the arithmetic), then store
+#define CBS_STEP(RC0, RP0, RN0, RC1, RP1, RN1, UC0, UP0, UN0, UC1, UP1, UN1)                                \
+    {                                                                                                       \
+        const bool more = y + 2 < y1;                                                                       \
+        CBS_REQUEST(y + 7, RC0, RP0, RN0, RC1, RP1, RN1)                                                    \
+        u32 o4[2][4];                                                                                       \
+        cbs_step<0>(ring, o4);                                                                              \
+        asm volatile("" : "+v"(UC0), "+v"(UP0), "+v"(UN0), "+v"(UC1), "+v"(UP1), "+v"(UN1), "+v"(o4[0][0]), "+v"(o4[1][3]) : : "memory"); \
+        if (more) {                                                                                         \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k)                                                   \
+                _Pragma("unroll") for (int d = 0; d < 10; ++d) { ring[k][d][0] = ring[k + 1][d][0]; ring[k][d][1] = ring[k + 1][d][1]; } \
+            u32 w0[10], w1[10];                                                                             \
+            cbs_window(w0, UC0, UP0, UN0, b, nblk); cbs_window(w1, UC1, UP1, UN1, b, nblk);                 \
+            cbs_pair(ring[3], w0, w1);                                                                      \
+        }                                                                                                   \
+        _Pragma("unroll") for (int r = 0; r < 2; ++r)                                                       \
+            if (y + r < h) st16(S + ((u32)(y + r) * pitch + bo), u32x4{o4[r][0], o4[r][1], o4[r][2], o4[r][3]}); \
+        if (!more) return;                                                                                  \
+        y += 2;                                                                                             \
+    }
+    u32x4 ac0, ap0, an0, ac1, ap1, an1, bc0, bp0, bn0, bc1, bp1, bn1;
+    int y = y0;
+    CBS_REQUEST(y + 5, ac0, ap0, an0, ac1, ap1, an1)         // the pair of step 1
+    for (;;) {
+        CBS_STEP(bc0, bp0, bn0, bc1, bp1, bn1, ac0, ap0, an0, ac1, ap1, an1)
+        CBS_STEP(ac0, ap0, an0, ac1, ap1, an1, bc0, bp0, bn0, bc1, bp1, bn1)
+    }
+#undef CBS_STEP
+#undef CBS_REQUEST
 }
 
 // a2+a3  Sobel(S, BORDER_REPLICATE) + strongest channel + fastAtan2 + 16 -> 8 bins + magnitude flag.
@@ -745,14 +913,16 @@ __global__ __launch_bounds__(256) void k_dnormal(const u16* __restrict__ depth0,
                         A0 += fi * di; A1 += fi * dj; A3 += fj * dj;
                         b0 += fi * delta; b1 += fj * delta;
                     }
-                const int det = A0 * A3 - A1 * A1;
-                const int ddx = A3 * b0 - A1 * b1;
-                const int ddy = -A1 * b0 + A0 * b1;
+                // A* <= 150 and |b*| <= 6 * 5 * 65535 < 2^23: every factor fits 24 bits, so v_mul_i32_i24 / v_mad_i32_i24
+                // (full rate) give the exact 32-bit products a v_mul_lo_u32 (quarter rate) would
+                const int det = __mul24(A0, A3) - __mul24(A1, A1);
+                const int ddx = __mul24(A3, b0) - __mul24(A1, b1);
+                const int ddy = __mul24(A0, b1) - __mul24(A1, b0);
                 // same values as upstream's 64-bit integer products rounded once to float: |ddx| < 2^30 so the
                 // double product is exact; |det * d| <= 22500 * 65535 < 2^31
                 float nx = (float)((double)ddx * 1150.0);
                 float ny = (float)((double)ddy * 1150.0);
-                float nz = (float)(-(det * d));
+                float nz = (float)(-__mul24(det, d));
                 const float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
                 if (len > 0) {
                     const float inv = __fdiv_rn(1.0f, len);
@@ -815,8 +985,10 @@ __global__ __launch_bounds__(256) void k_dmedian(const u8* __restrict__ code0, i
                 u32 o[2] = {0, 0};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const u32 PE = sumE[k] * 0x01010101u;                       // prefix sums of ranks 0..3
-                    const u32 PO = sumO[k] * 0x01010101u + (PE >> 24) * 0x01010101u;
+                    // x * 0x01010101 (byte prefix sums) as two shift-adds: a 32-bit multiply is quarter rate
+                    const u32 e1 = sumE[k] + (sumE[k] << 8), PE = e1 + (e1 << 16);      // prefix sums of ranks 0..3
+                    const u32 o0 = sumO[k] + (PE >> 24);                                 // carry the total of ranks 0..3 into byte 0 ...
+                    const u32 o1 = o0 + (o0 << 8), PO = o1 + (o1 << 16);                 // ... and it propagates to every byte
                     const u32 mE = (PE + 0x73737373u) & 0x80808080u;            // byte >= 13
                     const u32 mO = (PO + 0x73737373u) & 0x80808080u;
                     u32 res;
@@ -1903,6 +2075,9 @@ void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, i
     hipLaunchKernelGGL(k_nn_half, grid, dim3(256), 0, s, src, src_pitch, dst, dw, dh, slot_stride);
 }
 
+static int g_cblur_variant = 0;   // 0: sliding-window blur (k_cblur_sw), 1: one-shot blur (k_cblur); A/B knob of tools/ and tests
+void lmk_set_cblur_variant(int v) { g_cblur_variant = v; }
+
 size_t lmk_color_scratch_bytes(int w, int h) {
     // S u8 [h][3w] | qn u8 [h][w], each 256-B aligned (also the rank-code image of the depth passes)
     size_t px = (size_t)w * h;
@@ -1920,7 +2095,12 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
         const int n_b = (w * 3 / 16) * ((h + CB_ROWS - 1) / CB_ROWS);         // 16-byte blocks x row bands
         const int n_o = (w / 16) * h;                                         // 16-pixel groups
         const int n_t = (w / 16) * ((h + CVT_ROWS - 1) / CVT_ROWS);           // 16-pixel groups x bands
-        hipLaunchKernelGGL(k_cblur, dim3((unsigned)(((n_b + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_b + 255) / 256, nslots);
+        if (g_cblur_variant == 1) {
+            hipLaunchKernelGGL(k_cblur, dim3((unsigned)(((n_b + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_b + 255) / 256, nslots);
+        } else {
+            const int n_s = (w * 3 / 16) * ((h + CBS_STRIP - 1) / CBS_STRIP);   // 16-byte blocks x row strips
+            hipLaunchKernelGGL(k_cblur_sw, dim3((unsigned)(((n_s + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_s + 255) / 256, nslots);
+        }
         hipLaunchKernelGGL(k_corient, dim3((unsigned)(((n_o + 255) / 256) * nslots)), dim3(256), 0, s, S, w, h, thr2, qn, mag, slot_stride, slot_stride, (n_o + 255) / 256, nslots);
         hipLaunchKernelGGL(k_cvote, dim3((unsigned)(((n_t + 255) / 256) * nslots)), dim3(256), 0, s, qn, w, h, quant, slot_stride, slot_stride, (n_t + 255) / 256, nslots);
         return;
