@@ -64,6 +64,14 @@ __device__ __forceinline__ u32 mad24(u32 b, u32 a) {
     }
 }
 
+// a * b for factors that fit 24 signed bits: v_mul_i32_i24, full rate (v_mul_lo_u32 is quarter rate, and __mul24 goes
+// through sign-extending shifts the compiler does not always fold)
+__device__ __forceinline__ int mul_i24(int a, int b) {
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // v_pk_max_u16 on two u16 pairs
 __device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
@@ -895,47 +903,52 @@ __global__ __launch_bounds__(256) void k_dnormal(const u16* __restrict__ depth0,
         }
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
+            // BRANCHLESS: every pixel runs the whole computation and the result is selected at the end (most pixels
+            // are valid); with a branch per pixel the eight pixels' chains cannot be interleaved by the scheduler
             const int x = 8 * g + p;
-            u32 e = 0;
             const int d = (int)hw_u16(R[1], 8 + p);
-            if (x >= 5 && x < w - 6 && d < dist_thr) {
-                int A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
+            const bool valid = x >= 5 && x < w - 6 && d < dist_thr;
+            // sums over the neighbours that pass the bilateral gate |delta| < diff_thr (f = 1):
+            //   ci / cj = how many with i != 0 / j != 0, cx = f(+,+) + f(-,-) - f(+,-) - f(-,+),
+            //   sx / sy = sum of f delta over i = +5 minus over i = -5 / the same for j
+            // so that A0 = 25 ci, A3 = 25 cj, A1 = 25 cx, b0 = 5 sx, b1 = 5 sy (the accumulators of upstream's loop)
+            int ci = 0, cj = 0, cx = 0, sx = 0, sy = 0;
 #pragma unroll
-                for (int jj = -1; jj <= 1; ++jj)
+            for (int jj = -1; jj <= 1; ++jj)
 #pragma unroll
-                    for (int ii = -1; ii <= 1; ++ii) {
-                        if (ii == 0 && jj == 0) continue;
-                        const int di = ii * 5, dj = jj * 5;
-                        const int delta = (int)hw_u16(R[jj + 1], 8 + p + di) - d;
-                        const int ad = delta < 0 ? -delta : delta;
-                        const int f = ad < diff_thr ? 1 : 0;
-                        const int fi = f * di, fj = f * dj;
-                        A0 += fi * di; A1 += fi * dj; A3 += fj * dj;
-                        b0 += fi * delta; b1 += fj * delta;
-                    }
-                // A* <= 150 and |b*| <= 6 * 5 * 65535 < 2^23: every factor fits 24 bits, so v_mul_i32_i24 / v_mad_i32_i24
-                // (full rate) give the exact 32-bit products a v_mul_lo_u32 (quarter rate) would
-                const int det = __mul24(A0, A3) - __mul24(A1, A1);
-                const int ddx = __mul24(A3, b0) - __mul24(A1, b1);
-                const int ddy = __mul24(A0, b1) - __mul24(A1, b0);
-                // same values as upstream's 64-bit integer products rounded once to float: |ddx| < 2^30 so the
-                // double product is exact; |det * d| <= 22500 * 65535 < 2^31
-                float nx = (float)((double)ddx * 1150.0);
-                float ny = (float)((double)ddy * 1150.0);
-                float nz = (float)(-__mul24(det, d));
-                const float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
-                if (len > 0) {
-                    const float inv = __fdiv_rn(1.0f, len);
-                    nx = __fmul_rn(nx, inv); ny = __fmul_rn(ny, inv); nz = __fmul_rn(nz, inv);
-                    const int v1 = (int)__fadd_rn(__fmul_rn(nx, 10.f), 10.f);
-                    const int v2 = (int)__fadd_rn(__fmul_rn(ny, 10.f), 10.f);
-                    const int v3 = (int)__fadd_rn(__fmul_rn(nz, 20.f), 20.f);
-                    const int flat = v3 * 400 + v2 * 20 + v1;
-                    const u32 v = (flat >= 0 && flat < 8000) ? lut[flat] : 0u;
-                    const u32 rank = (u32)__ffs((int)v);                         // 0 for none, 1 + label otherwise
-                    e = rank < 4 ? 8 * rank : (rank < 8 ? 8 * (rank - 4) + 4 : 32u);
+                for (int ii = -1; ii <= 1; ++ii) {
+                    if (ii == 0 && jj == 0) continue;
+                    const int delta = (int)hw_u16(R[jj + 1], 8 + p + 5 * ii) - d;
+                    const int ad = delta < 0 ? -delta : delta;
+                    const int f = ad < diff_thr ? 1 : 0;
+                    const int fd = ad < diff_thr ? delta : 0;
+                    if (ii != 0) { ci += f; sx += ii * fd; }
+                    if (jj != 0) { cj += f; sy += jj * fd; }
+                    if (ii != 0 && jj != 0) cx += ii * jj * f;
                 }
-            }
+            const int A0 = 25 * ci, A3 = 25 * cj, A1 = 25 * cx, b0 = 5 * sx, b1 = 5 * sy;
+            // A* <= 150 and |b*| <= 6 * 5 * 65535 < 2^23: every factor fits 24 bits, so v_mul_i32_i24 / v_mad_i32_i24
+            // (full rate) give the exact 32-bit products a v_mul_lo_u32 (quarter rate) would
+            const int det = mul_i24(A0, A3) - mul_i24(A1, A1);
+            const int ddx = mul_i24(A3, b0) - mul_i24(A1, b1);
+            const int ddy = mul_i24(A0, b1) - mul_i24(A1, b0);
+            // same values as upstream's 64-bit integer products rounded once to float: |ddx| < 2^30 so the
+            // double product is exact; |det * d| <= 22500 * 65535 < 2^31
+            float nx = (float)((double)ddx * 1150.0);
+            float ny = (float)((double)ddy * 1150.0);
+            float nz = (float)(-mul_i24(det, d));
+            const float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+            const float inv = __fdiv_rn(1.0f, len > 0 ? len : 1.0f);
+            nx = __fmul_rn(nx, inv); ny = __fmul_rn(ny, inv); nz = __fmul_rn(nz, inv);
+            const int v1 = (int)__fadd_rn(__fmul_rn(nx, 10.f), 10.f);
+            const int v2 = (int)__fadd_rn(__fmul_rn(ny, 10.f), 10.f);
+            const int v3 = (int)__fadd_rn(__fmul_rn(nz, 20.f), 20.f);
+            const int flat = mul_i24(v3, 400) + mul_i24(v2, 20) + v1;   // |v| small: exact
+            const bool in_lut = flat >= 0 && flat < 8000;
+            const u32 v = lut[in_lut ? flat : 0];
+            const u32 rank = (u32)__ffs((int)v);                         // 0 for none, 1 + label otherwise
+            const u32 ecode = rank < 4 ? 8 * rank : (rank < 8 ? 8 * (rank - 4) + 4 : 32u);
+            const u32 e = (valid && len > 0 && in_lut) ? ecode : 0u;
             out[p >> 2] |= e << (8 * (p & 3));
         }
     }
@@ -1559,8 +1572,12 @@ __device__ __forceinline__ void emit_key(const LmRefineArgs& a, LmDevHeader* hdr
 // Slot -> XCD plan for k_refine.  Every slot must stay on ONE XCD (its spread memories live in that L2), but the
 // candidate counts differ a lot between frames (30 .. 1500), and the launch lasts as long as its busiest XCD
 // (fixed round-robin: max / mean = 1.35 on the bench workload).  One workgroup ranks the slots by candidate
-// count (rank sort in LDS); one thread then deals them, heaviest first, to the least loaded of the eight XCD
-// lists (cap = nslots / 8 slots each).  plan layout: [8][cap] slot numbers, then [8] list lengths.
+// count (rank sort in LDS) and deals them, heaviest first, to the least loaded of the eight XCD lists (cap = nslots / 8
+// slots each).  The dealing is sequential by nature; it runs on eight lanes of one wave, lane x holding list x's load
+// and length, the least loaded list found by a three-step butterfly minimum over (load, list) keys -- about 6 us
+// instead of the 30 us of round 1's single thread, which sat on the critical path of every lane-step.  (Dealing in snake
+// order of the rank is fully parallel but balances the skewed counts worse: k_refine 254 instead of 215 us.)
+// plan layout: [8][cap] slot numbers, [8] list lengths, [8][cap + 1] running sums of the candidate counts along every list.
 __global__ __launch_bounds__(1024) void k_refine_plan(const LmDevHeader* __restrict__ hdr0, size_t aux_slot_stride,
                                                        int nslots, u32 cand_cap, int cap, u32* __restrict__ plan) {
     __shared__ u32 cnt[1024];
@@ -1584,24 +1601,33 @@ __global__ __launch_bounds__(1024) void k_refine_plan(const LmDevHeader* __restr
         sorted_cnt[rank] = c; sorted_slot[rank] = (u32)tid;
     }
     __syncthreads();
-    if (tid == 0) {
-        u32 load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
+    if (tid < 64) {   // one wave; lanes 8.. mirror lanes 0..7 (x = lane & 7) so that the butterfly needs no masking
+        const u32 x = (u32)tid & 7u;
+        u32 load = 0, len = 0;
+        // the ranked list in registers (lane l holds ranks l, l + 64, ...): an iteration reads its entry with
+        // v_readlane instead of waiting for LDS, and the minimum goes through DPP, not through the LDS crossbar
+        u32 rc[2], rs[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { rc[q] = sorted_cnt[(tid + 64 * q) & 1023]; rs[q] = sorted_slot[(tid + 64 * q) & 1023]; }
         for (int r = 0; r < nslots; ++r) {
-            const u32 sc = sorted_cnt[r], ss = sorted_slot[r];   // independent of the carried state: loaded ahead
-            int best = 0;
-            u32 bl = 0xFFFFFFFFu;
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const u32 lx = (int)len[x] < cap ? load[x] : 0xFFFFFFFFu;
-                if (lx < bl) { bl = lx; best = x; }
+            u32 sc, ss;
+            if (r < 128) {
+                const int src = r & 63;
+                sc = (u32)__builtin_amdgcn_readlane((int)(r < 64 ? rc[0] : rc[1]), src);
+                ss = (u32)__builtin_amdgcn_readlane((int)(r < 64 ? rs[0] : rs[1]), src);
+            } else {
+                sc = sorted_cnt[r]; ss = sorted_slot[r];
             }
-#pragma unroll
-            for (int x = 0; x < 8; ++x)
-                if (x == best) { pl[x * cap + len[x]] = ss; len[x] += 1; load[x] += sc + 8u; }   // + a little per slot
+            u32 key = (int)len < cap ? ((load << 3) | x) : 0xFFFFFFFFu;      // loads stay below 2^29
+            key = min(key, (u32)__builtin_amdgcn_mov_dpp((int)key, 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+            key = min(key, (u32)__builtin_amdgcn_mov_dpp((int)key, 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+            key = min(key, (u32)__builtin_amdgcn_mov_dpp((int)key, 0x141, 0xf, 0xf, true));   // row_half_mirror: lane i <-> 7 - i
+            if ((key & 7u) == x) {
+                if (tid < 8) pl[x * cap + len] = ss;
+                len += 1; load += sc + 8u;                                   // + a little per slot
+            }
         }
-#pragma unroll
-        for (int x = 0; x < 8; ++x) pl[8 * cap + x] = len[x];
+        if (tid < 8) pl[8 * cap + x] = len;
     }
     __syncthreads();
     // running sums of the candidate counts along every XCD's list (k_refine's queue): [8][cap + 1] behind the lengths
