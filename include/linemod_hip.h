@@ -180,7 +180,8 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
 /* LM_TUNE_COPY_STREAMS: copy streams the uploads are dealt to, slot -> stream round-robin (1..4, default 4: one
  *   in-order stream moved 0.6-0.9 MB images at 25.6 GB/s, several keep several DMA engines busy). */
 #define LM_TUNE_COPY_STREAMS 3
-/* LM_TUNE_CBLUR_VARIANT (process-wide): 0 = sliding-window Gaussian blur (default), 1 = the one-shot kernel of round 1. */
+/* LM_TUNE_CBLUR_VARIANT (process-wide): Gaussian blur kernel 0 = by batch size (default: one-shot below 16 frames, sliding
+ *   window from there), 1 = one-shot, 2 = sliding window. */
 #define LM_TUNE_CBLUR_VARIANT 4
 int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);

@@ -2101,7 +2101,8 @@ void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, i
     hipLaunchKernelGGL(k_nn_half, grid, dim3(256), 0, s, src, src_pitch, dst, dw, dh, slot_stride);
 }
 
-static int g_cblur_variant = 0;   // 0: sliding-window blur (k_cblur_sw), 1: one-shot blur (k_cblur); A/B knob of tools/ and tests
+static int g_cblur_variant = 0;   // 0: by batch size (one-shot below 16 frames, sliding window from there), 1: one-shot blur
+                                  // (k_cblur), 2: sliding-window blur (k_cblur_sw); A/B knob of tools/ and tests
 void lmk_set_cblur_variant(int v) { g_cblur_variant = v; }
 
 size_t lmk_color_scratch_bytes(int w, int h) {
@@ -2121,7 +2122,9 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
         const int n_b = (w * 3 / 16) * ((h + CB_ROWS - 1) / CB_ROWS);         // 16-byte blocks x row bands
         const int n_o = (w / 16) * h;                                         // 16-pixel groups
         const int n_t = (w / 16) * ((h + CVT_ROWS - 1) / CVT_ROWS);           // 16-pixel groups x bands
-        if (g_cblur_variant == 1) {
+        // few frames: the one-shot kernel's many short waves finish sooner (a single frame is 57 sliding-window waves of
+        // eight dependent steps: 166 instead of 150 us per resident single-frame match); batches: the sliding window
+        if (g_cblur_variant == 1 || (g_cblur_variant == 0 && nslots < 16)) {
             hipLaunchKernelGGL(k_cblur, dim3((unsigned)(((n_b + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_b + 255) / 256, nslots);
         } else {
             const int n_s = (w * 3 / 16) * ((h + CBS_STRIP - 1) / CBS_STRIP);   // 16-byte blocks x row strips

@@ -408,3 +408,31 @@ def test_color_check_counts_against_numpy_fill(lm, synth):
         region = np.zeros((H, W), bool); region[ys, xs] = True
         assert a[k] == region.sum() and b[k] == (region & mask).sum(), (k, a[k], b[k])
     d.close()
+
+
+def test_batch_of_32_frames_takes_the_batch_kernels(lm, orc, synth):
+    """From 16 frames per launch on the preprocess uses its batch kernels (sliding-window blur): 32 distinct frames in one
+    lm_match_batch and as two lanes of 16, every list against the oracle."""
+    W, H = 640, 480
+    d = lm.Detector(color_only=False, width=W, height=H, frame_slots=32)
+    o = orc.Detector(color_only=False)
+    frames = [synth.make_frame(W, H, seed=3000 + i) for i in range(32)]
+    o.prepare(*frames[0])
+    q = {(l, m): o.stage(0, l, m).reshape(H >> l, W >> l) for l in range(2) for m in range(2)}
+    descs, feats, _ = synth.make_bank(60, 2, 2, seed=31, quantized=q, crop_fraction=0.3, frame_size=(W, H), T0=5)
+    d.add_class("c", descs, feats)
+    o.add_class("c", descs, feats)
+    for i, (b, dp) in enumerate(frames):
+        d.upload_frame(i, b, dp)
+    exp = [o.match(b, dp, 70.0, threads=8) for b, dp in frames]
+    assert sum(len(e) for e in exp) > 0
+    out, cnt = d.match_batch(32, 70.0)
+    for i in range(32):
+        assert_matches_equal(out[i, :cnt[i]], exp[i])
+    d.match_begin(0, 0, 16, 70.0)
+    d.match_begin(1, 16, 16, 70.0)
+    for lane in (0, 1):
+        out, cnt = d.match_end(lane, n_slots=16)
+        for i in range(16):
+            assert_matches_equal(out[i, :cnt[i]], exp[16 * lane + i])
+    d.close()

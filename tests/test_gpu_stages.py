@@ -33,6 +33,22 @@ def test_color_quantize_parity(det, orc, shape):
         assert np.array_equal(mag, emag)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+def test_color_quantize_both_blur_kernels(lm, det, orc, frame0, variant):
+    """The Gaussian blur has two kernels -- one shot (few frames) and sliding window (batches), chosen by batch size:
+    force each (LM_TUNE_CBLUR_VARIANT) on shapes that hit strip ends, row ends and both pyramid levels' widths."""
+    det.set_tuning(lm.TUNE_CBLUR_VARIANT, variant)
+    try:
+        rng = np.random.default_rng(variant)
+        for shape in [(480, 640), (240, 320), (960, 1280), (16, 64), (17, 64), (50, 16), (130, 160), (33, 48)]:
+            for smooth in (True, False):
+                bgr = _rand_bgr(rng, shape[0], shape[1], smooth)
+                assert np.array_equal(det.stage_color_quantize(bgr), orc.color_quantize(bgr)), (variant, shape, smooth)
+        assert np.array_equal(det.stage_color_quantize(frame0[0]), orc.color_quantize(frame0[0]))
+    finally:
+        det.set_tuning(lm.TUNE_CBLUR_VARIANT, 0)
+
+
 def test_color_quantize_frame0_and_thresholds(det, orc, frame0):
     bgr, _ = frame0
     assert np.array_equal(det.stage_color_quantize(bgr), orc.color_quantize(bgr))
