@@ -36,10 +36,10 @@ PCIE_PEAK_GBS = 63.0      # MI355X_MICROARCH.md, "Host link": PCIe Gen5 x16, 63 
 CONFIGS = {
     2: dict(name="SURVEY 8d config 2: 640x480 RGB-D, ColorGradient+DepthNormal, T={5,8}, 2-level pyramid, "
                  "fixed-geometry 96x96 templates (level-1 bbox 48x48, P = 995)",
-            W=640, H=480, color_only=False, l0_size=(96, 96), seed_frames=1234, seed_bank=4321),
+            W=640, H=480, color_only=False, l0_size=(96, 96), seed_frames=1234, seed_bank=4321, lanes=3, batch=288),
     3: dict(name="SURVEY 8d config 3: 1280x960, ColorGradient only, T={2,8}, 2-level pyramid, fixed-geometry 192x192 "
                  "templates (level-1 bbox 96x96, P = 3909)",
-            W=1280, H=960, color_only=True, l0_size=(192, 192), seed_frames=2234, seed_bank=77),
+            W=1280, H=960, color_only=True, l0_size=(192, 192), seed_frames=2234, seed_bank=77, lanes=2, batch=256),
 }
 
 
@@ -56,7 +56,7 @@ NBUF = 3         # result buffers in rotation
 
 
 class Runner:
-    """The matcher of one GPU: detector, resident synthetic workload, and the step loop over its two lanes."""
+    """The matcher of one GPU: detector, resident synthetic workload, and the step loop over its lanes."""
 
     def __init__(self, args, rank, world, local_rank, exchange):
         self.lm = lm = importlib.import_module("line-mod-pipeline_amd")
@@ -86,8 +86,8 @@ class Runner:
         for i, (bgr, depth) in enumerate(self.frames):
             det.upload_frame(i, bgr, depth if M == 2 else None)
         det.upload_wait(-1)
-        self.NL = args.lanes if args.lanes else 2
-        if B % 2 or B < 2:
+        self.NL = args.lanes
+        if B % self.NL or B < self.NL:
             self.NL = 1
         self.Bl = B // self.NL                           # frames per lane and launch
         self.bufs = [(np.zeros((B, CAP), lm.MATCH_DTYPE), np.zeros(B, np.int32)) for _ in range(NBUF)]
@@ -103,7 +103,7 @@ class Runner:
     # ------------------------------------------------------------------------------------------
     def run_steps(self, n, after_step=None):
         """n passes of the hot path over the batch, driven by this one host thread: lane l works on the frames of
-        slots [l * Bl, (l + 1) * Bl); as soon as a lane's step is collected its next step is enqueued, so the two
+        slots [l * Bl, (l + 1) * Bl); as soon as a lane's step is collected its next step is enqueued, so the
         streams always have work and their stages overlap.  With the RCCL exchange the lane's all-gathers are part of
         what lm_match_begin_gathered enqueues, and lm_match_end_gathered merges the frames this rank owns."""
         if n <= 0:
@@ -205,7 +205,7 @@ class Runner:
                 "pcie_bound_detections_per_s": round(PCIE_PEAK_GBS * 1e9 / fb, 1),
                 "matches_step0_step1": counts,
                 "note": "every step uploads all %d frames from pinned host memory (rotating frame -> slot map) into one of "
-                        "two slot sets while the two lanes compute on the other; the upload of step 0 is inside the "
+                        "two slot sets while the lanes compute on the other; the upload of step 0 is inside the "
                         "timed region; the link, not the GPU, bounds this mode" % B}
 
     def report(self):
@@ -220,10 +220,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[] entry (2 or 3)")
-    ap.add_argument("--batch", type=int, default=256, help="frames per step (resident in HBM)")
-    ap.add_argument("--lanes", type=int, default=0, choices=(0, 1, 2),
-                    help="2 (= 0, the default): the step's frames are split over the detector's two lanes (two HIP "
-                         "streams driven by one host thread) so that the stages of one half overlap those of the other")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames per step (resident in HBM); 0 = the config's default (config 2: 288 = 3 lanes x 96, "
+                         "config 3: 256 = 2 lanes x 128: the launch shapes measured fastest, DESIGN.md section 6)")
+    ap.add_argument("--lanes", type=int, default=0, choices=(0, 1, 2, 3, 4),
+                    help="the step's frames are split over this many of the detector's lanes (HIP streams driven by one "
+                         "host thread) so that the stages of one part overlap those of the others; 0 = the config's default")
     ap.add_argument("--templates", type=int, default=3000, help="templates per GPU (weak) / in the whole bank (strong)")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--threshold", type=float, default=80.0)
@@ -244,6 +246,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     args = ap.parse_args()
 
+    if not args.batch:
+        args.batch = CONFIGS[args.config]["batch"] if not args.lanes else 128 * args.lanes
+    if not args.lanes:
+        args.lanes = CONFIGS[args.config]["lanes"]
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -350,7 +356,7 @@ def main():
                     "duration; > 1 because the bytes come from L2 and because of the pruning"},
         "timed_region": {
             "avg_span_us": round(span_us, 2), "lanes": NL,
-            "note": "HIP-event span around the scan launch inside the timed, two-lane run: it contains time in which "
+            "note": "HIP-event span around the scan launch inside the timed, multi-lane run: it contains time in which "
                     "the other lane's kernels hold the chip, so it is not a kernel duration"},
         "stage_us_per_frame_one_lane": dict(zip(["preprocess", "scan", "refine", "sort"],
                                                 [round(v / max(one_lane["frames"], 1), 2) for v in one_lane["stage_us"]])),

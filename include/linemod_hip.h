@@ -190,8 +190,8 @@ int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm
 int lm_match_batch(lm_detector* det, int n_slots, float threshold, int class_idx, lm_match_t* out, size_t cap_per_frame,
                    int32_t* counts);
 
-/* Asynchronous halves of lm_match_batch on one of two LANES (lane 0 = the detector's stream, lane 1 = a second
- * HIP stream with its own events and threshold table).  lm_match_begin enqueues a3-a15 for the resident frames
+/* Asynchronous halves of lm_match_batch on one of four LANES (lane 0 = the detector's stream, lanes 1-3 = further
+ * HIP streams with their own events and threshold tables; two lanes are what bench.py drives).  lm_match_begin enqueues a3-a15 for the resident frames
  * of slots [first_slot, first_slot + n_slots) and returns; lm_match_end waits for that lane and delivers the
  * lists exactly like lm_match_batch (out + i * cap_per_frame, counts[i]; i counts from first_slot).  Two lanes
  * working on disjoint slot ranges overlap each other's stages on the GPU (the scan is L1/L2-bound, the
@@ -226,7 +226,7 @@ int lm_color_check_counts(lm_detector* det, int slot, const double lower_hsv[3],
  * buffers have a fixed size of n_frames * recs_per_frame_cap records per rank so that no host round trip sits between
  * the two collectives.  More records than that is LM_ERR_OVERFLOW, never a silent truncation (the reference consumes
  * ALL matches: HighLevelLinemod.cpp:206-253).
- * The two lanes' communicators rendezvous on `port` and `port + 1`. */
+ * The lanes' communicators (one per lane) rendezvous on `port` .. `port + 3`. */
 int lm_comm_init(lm_detector* det, int rank, int world, const char* addr, int port, int recs_per_frame_cap);
 /* The rendezvous lm_comm_init uses, on its own (host only, no GPU): n bytes from rank 0's buf into every rank's buf. */
 int lm_rendezvous_broadcast(int rank, int world, const char* addr, int port, void* buf, size_t n, int timeout_s);

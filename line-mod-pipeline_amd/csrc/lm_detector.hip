@@ -41,6 +41,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 #define LM_NCOPY 4
+#define LM_NLANES 4      // lanes per detector (lm_match_begin / lm_match_end): HIP streams whose stages overlap
 
 struct Slot {
     u8* h_bgr = nullptr;     // pinned upload staging
@@ -80,9 +81,9 @@ struct lm_detector {
         int first = 0, n = 0, class_idx = 0;
         unsigned long long waited_seq[LM_NCOPY] = {};   // newest upload ticket per copy stream this lane's stream waits for
     };
-    Lane lanes[2];
+    Lane lanes[LM_NLANES];
     int active = 0;
-    hipEvent_t blocking_ev[2] = {nullptr, nullptr};   // LM_FLAG_BLOCKING_SYNC: one per lane
+    hipEvent_t blocking_ev[LM_NLANES] = {};           // LM_FLAG_BLOCKING_SYNC: one per lane
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // H2D copies of lm_upload_frame* go through their own stream so that the frames of step k + 1 travel while
@@ -107,7 +108,7 @@ struct lm_detector {
     // throughput: the colour chain of level 0, the pyrDown + colour chain of the levels above and the depth chain are
     // independent until the scan, so they are forked onto two more streams of the lane and joined with events.
     struct Fork { hipStream_t s[2] = {nullptr, nullptr}; hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr}; bool ok = false; };
-    Fork forks[2];   // per lane
+    Fork forks[LM_NLANES];   // per lane
     // ---- multi-GPU exchange: RCCL communicator + per-lane gather buffers
     struct Gather {
         int* d_cnt = nullptr; LmOutMatch* d_rec = nullptr;          // this rank's packed lists (k_pack_lists)
@@ -121,9 +122,9 @@ struct lm_detector {
     u32* d_hull_class_base = nullptr; u32* d_hull_off = nullptr; int16_t* d_hull_xy = nullptr;
     int* d_hsv_div = nullptr;
     size_t off_cmask = 0; int cmask_wpr = 0;
-    LmComm* comm[2] = {nullptr, nullptr};   // one communicator per lane: the lanes' collectives never wait for each other
+    LmComm* comm[LM_NLANES] = {};   // one communicator per lane: the lanes' collectives never wait for each other
     int comm_recs_per_frame = 0;
-    Gather gather[2];
+    Gather gather[LM_NLANES];
     double* d_red = nullptr;   // small device buffer of lm_comm_max / lm_comm_barrier
     int fork_max_slots = 0;          // measured r02: no gain (host launch rate, 3.4 us per launch, bounds small calls), so off by default
     int fork_depth_wait_slot = -1;   // forked single-frame call: the depth chain's stream waits for this slot's whole upload
@@ -175,6 +176,11 @@ struct lm_detector {
 };
 
 namespace {
+
+bool any_lane_busy(const lm_detector* d) {
+    for (const lm_detector::Lane& ln : d->lanes) if (ln.busy) return true;
+    return false;
+}
 
 void free_device_bank(lm_detector* d) {
     hipFree(d->d_item_t); hipFree(d->d_item_chunk); hipFree(d->d_scan_off); hipFree(d->d_scan_P);
@@ -241,11 +247,11 @@ int ensure_device(lm_detector* d) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_raw_thr), 128 * sizeof(int)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d->h_raw_thr), 128 * sizeof(int)));
     d->plan_stride_cap = std::max(S / 8 * 2, 2);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_plan), 2 * (16 * (size_t)d->plan_stride_cap + 16) * sizeof(u32)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_plan), LM_NLANES * (16 * (size_t)d->plan_stride_cap + 16) * sizeof(u32)));
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     // lane 1's stream right behind lane 0's: the runtime deals streams to its hardware queues in creation order, and
     // two lanes that land on one queue run strictly one after the other (measured r02: 87 K instead of 102 K det/s)
-    HIP_TRY(hipStreamCreateWithFlags(&d->lanes[1].stream, hipStreamNonBlocking));
+    for (int l = 1; l < LM_NLANES; ++l) HIP_TRY(hipStreamCreateWithFlags(&d->lanes[l].stream, hipStreamNonBlocking));
     for (int k = 0; k < LM_NCOPY; ++k) {
         HIP_TRY(hipStreamCreateWithFlags(&d->copy_stream[k], hipStreamNonBlocking));
         d->up_seq_next[k] = 1; d->up_seq_done[k] = 0;
@@ -778,7 +784,7 @@ int wait_stream(lm_detector* d) {
 }
 
 int run_match(lm_detector* d, int first, int n, float threshold, int class_idx) {
-    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     for (int i = 0; i < n; ++i)
         if (!d->slots[first + i].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot " + std::to_string(first + i));
     int rc;
@@ -888,13 +894,15 @@ void lm_destroy(lm_detector* d) {
         for (auto& ev : d->blocking_ev) if (ev) hipEventDestroy(ev);
         for (auto& ev : d->ev) if (ev) hipEventDestroy(ev);
         if (d->stream) hipStreamDestroy(d->stream);
-        lm_detector::Lane& l1 = d->lanes[1];
-        if (l1.created) {
-            hipStreamSynchronize(l1.stream);
-            for (auto& ev : l1.ev) if (ev) hipEventDestroy(ev);
-            hipFree(l1.d_raw_thr); hipHostFree(l1.h_raw_thr);
+        for (int l = 1; l < LM_NLANES; ++l) {
+            lm_detector::Lane& ln = d->lanes[l];
+            if (ln.created) {
+                hipStreamSynchronize(ln.stream);
+                for (auto& ev : ln.ev) if (ev) hipEventDestroy(ev);
+                hipFree(ln.d_raw_thr); hipHostFree(ln.h_raw_thr);
+            }
+            if (ln.stream) hipStreamDestroy(ln.stream);
         }
-        if (l1.stream) hipStreamDestroy(l1.stream);
         free_device_bank(d);
         for (auto& c : d->comm) { delete c; c = nullptr; }
         free_gather(d);
@@ -906,7 +914,7 @@ void lm_destroy(lm_detector* d) {
 }
 
 int lm_set_similarity_lut(lm_detector* d, const uint8_t lut[256]) {
-    if (d && (d->lanes[0].busy || d->lanes[1].busy)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (d && any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (!d || !lut) return fail(LM_ERR_INVALID, "null argument");
     for (int i = 0; i < 256; ++i) if (lut[i] > 4) return fail(LM_ERR_INVALID, "similarity LUT entries must be <= 4 (63*4 must fit a byte)");
     // an empty spread value must score 0: reads past a linear memory land in zero padding (upstream: undefined)
@@ -914,7 +922,7 @@ int lm_set_similarity_lut(lm_detector* d, const uint8_t lut[256]) {
     std::memcpy(d->sim_lut, lut, 256); d->luts_dirty = true; return LM_OK;
 }
 int lm_set_normal_lut(lm_detector* d, const uint8_t lut[8000]) {
-    if (d && (d->lanes[0].busy || d->lanes[1].busy)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (d && any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (!d || !lut) return fail(LM_ERR_INVALID, "null argument");
     std::memcpy(d->normal_lut, lut, 8000); d->luts_dirty = true; d->lut_onehot = -1; d->normal_lut_substitute = false; return LM_OK;
 }
@@ -944,7 +952,7 @@ int lm_pyramid_levels(const lm_detector* d) { return d ? d->cfg.pyramid_levels :
 
 int lm_add_class(lm_detector* d, const char* class_id, int n_templates, const lm_template_desc* descs,
                  const lm_feature* features, int* class_idx_out) {
-    if (d && (d->lanes[0].busy || d->lanes[1].busy)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (d && any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (!d || !class_id || n_templates < 0 || (n_templates && (!descs || !features))) return fail(LM_ERR_INVALID, "null argument");
     std::string err;
     int ci = d->bank.add_class(class_id, n_templates, descs, features, d->cfg.pyramid_levels, d->cfg.num_modalities, err);
@@ -956,7 +964,7 @@ int lm_add_class(lm_detector* d, const char* class_id, int n_templates, const lm
 
 int lm_add_template(lm_detector* d, const char* class_id, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
                     size_t depth_stride, const uint8_t* mask, size_t mask_stride, int* template_id_out, lm_rect* bbox_out) {
-    if (d && (d->lanes[0].busy || d->lanes[1].busy)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (d && any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (template_id_out) *template_id_out = -1;
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
@@ -1106,7 +1114,7 @@ int lm_set_stage_chunks(lm_detector* d, int chunks) {
 
 int lm_set_tuning(lm_detector* d, int key, int value) {
     if (!d) return fail(LM_ERR_INVALID, "null detector");
-    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     switch (key) {
         case LM_TUNE_FORK_MAX_SLOTS: if (value < 0) break; d->fork_max_slots = value; return LM_OK;
         case LM_TUNE_MATCH_UPLOAD_MODE: if (value < 0 || value > 1) break; d->match_upload_mode = value; return LM_OK;
@@ -1131,7 +1139,7 @@ int lm_match(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
     if ((rc = ensure_bank(d))) return rc;
-    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     // mode 1: copy stream; the colour chains wait for the colour copy only, the depth chain for the depth copy.
     // mode 0: copies on the compute stream itself, in order with the kernels (no cross-stream hop)
     if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride, false, d->match_upload_mode ? nullptr : d->stream))) return rc;
@@ -1171,16 +1179,18 @@ static int enqueue_gather(lm_detector* d, int lane, int first, int n);
 static int begin_lane(lm_detector* d, int lane, int first_slot, int n_slots, float threshold, int class_idx, bool gathered) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
-    if (lane < 0 || lane > 1) return fail(LM_ERR_INVALID, "lane must be 0 or 1");
+    if (lane < 0 || lane >= LM_NLANES) return fail(LM_ERR_INVALID, "lane out of range (0 .. 3)");
     if (gathered && !d->comm[0]) return fail(LM_ERR_INVALID, "no communicator: call lm_comm_init first");
     if ((rc = ensure_bank(d))) return rc;
     if ((rc = check_slots(d, first_slot, n_slots))) return rc;
     if (n_slots <= 0) return fail(LM_ERR_INVALID, "no slots");
     lm_detector::Lane& ln = d->lanes[lane];
     if (ln.busy) return fail(LM_ERR_INVALID, "lane is busy: call lm_match_end first");
-    const lm_detector::Lane& other = d->lanes[lane ^ 1];
-    if (other.busy && first_slot < other.first + other.n && other.first < first_slot + n_slots)
-        return fail(LM_ERR_INVALID, "slot range overlaps the range the other lane is working on");
+    for (int o = 0; o < LM_NLANES; ++o) {
+        const lm_detector::Lane& other = d->lanes[o];
+        if (o != lane && other.busy && first_slot < other.first + other.n && other.first < first_slot + n_slots)
+            return fail(LM_ERR_INVALID, "slot range overlaps the range another lane is working on");
+    }
     for (int i = 0; i < n_slots; ++i)
         if (!d->slots[first_slot + i].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot " + std::to_string(first_slot + i));
     if ((rc = ensure_lane(d, lane))) return rc;
@@ -1205,7 +1215,7 @@ int lm_match_begin_gathered(lm_detector* d, int lane, int first_slot, int n_slot
 
 int lm_match_end(lm_detector* d, int lane, lm_match_t* out, size_t cap_per_frame, int32_t* counts) {
     if (!d) return fail(LM_ERR_INVALID, "null detector");
-    if (lane < 0 || lane > 1) return fail(LM_ERR_INVALID, "lane must be 0 or 1");
+    if (lane < 0 || lane >= LM_NLANES) return fail(LM_ERR_INVALID, "lane out of range (0 .. 3)");
     lm_detector::Lane& ln = d->lanes[lane];
     if (!ln.busy) return fail(LM_ERR_INVALID, "lane has no match in flight");
     if (d->gather[lane].active) return fail(LM_ERR_INVALID, "the lane's match was begun with lm_match_begin_gathered: collect it with lm_match_end_gathered");
@@ -1261,7 +1271,7 @@ int lm_color_check_counts(lm_detector* d, int slot, const double lower_hsv[3], c
     if ((rc = ready_for_compute(d))) return rc;
     if ((rc = check_slots(d, slot, 1))) return rc;
     if (!lower_hsv || !upper_hsv || (n && (!matches || !in_hull || !in_both))) return fail(LM_ERR_INVALID, "null argument");
-    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (!d->slots[slot].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
     if (n == 0) return LM_OK;
     if ((rc = ensure_hulls(d))) return rc;
@@ -1308,16 +1318,16 @@ static void free_gather(lm_detector* d) {
 int lm_comm_init(lm_detector* d, int rank, int world, const char* addr, int port, int recs_per_frame_cap) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
-    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (d->comm[0]) return fail(LM_ERR_INVALID, "communicator already initialised");
     if (recs_per_frame_cap <= 0) recs_per_frame_cap = 256;
     if (recs_per_frame_cap > LM_SORT_CAP) recs_per_frame_cap = LM_SORT_CAP;
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < LM_NLANES; ++l) {
         LmComm* c = new LmComm();
         std::string err;
         if (!c->init(rank, world, addr, port + l, 120, err)) {   // lane l's rendezvous on port + l
             delete c;
-            if (d->comm[0]) { delete d->comm[0]; d->comm[0] = nullptr; }
+            for (auto& cc : d->comm) { delete cc; cc = nullptr; }
             return fail(LM_ERR_HIP, err);
         }
         d->comm[l] = c;
@@ -1345,7 +1355,7 @@ int lm_rendezvous_broadcast(int rank, int world, const char* addr, int port, voi
 
 int lm_comm_destroy(lm_detector* d) {
     if (!d) return fail(LM_ERR_INVALID, "null detector");
-    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (d->comm[0]) {
         hipSetDevice(d->cfg.device);
         hipDeviceSynchronize();
@@ -1365,7 +1375,7 @@ int lm_comm_info(const lm_detector* d, int* rank, int* world) {
 // element-wise maximum over the ranks of n <= 32 doubles; returns when every rank's value has arrived
 int lm_comm_max(lm_detector* d, double* v, int n) {
     if (!d || !d->comm[0] || !v || n < 1 || n > 32) return fail(LM_ERR_INVALID, "bad argument");
-    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     HIP_TRY(hipSetDevice(d->cfg.device));
     std::string err;
     HIP_TRY(hipMemcpyAsync(d->d_red, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, d->stream));
@@ -1378,7 +1388,7 @@ int lm_comm_max(lm_detector* d, double* v, int n) {
 // every rank's device is idle and every rank has reached this call
 int lm_comm_barrier(lm_detector* d) {
     if (!d || !d->comm[0]) return fail(LM_ERR_INVALID, "no communicator");
-    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     HIP_TRY(hipSetDevice(d->cfg.device));
     HIP_TRY(hipDeviceSynchronize());
     double one = 1.0;
@@ -1415,7 +1425,7 @@ static int enqueue_gather(lm_detector* d, int lane, int first, int n) {
 int lm_match_end_gathered(lm_detector* d, int lane, lm_match_t* out, size_t cap, int32_t* counts, int* first_frame,
                           int* n_frames, size_t* n_out) {
     if (!d) return fail(LM_ERR_INVALID, "null detector");
-    if (lane < 0 || lane > 1) return fail(LM_ERR_INVALID, "lane must be 0 or 1");
+    if (lane < 0 || lane >= LM_NLANES) return fail(LM_ERR_INVALID, "lane out of range (0 .. 3)");
     lm_detector::Lane& ln = d->lanes[lane];
     lm_detector::Gather& g = d->gather[lane];
     if (!ln.busy || !g.active) return fail(LM_ERR_INVALID, "lane has no gathered match in flight");
@@ -1559,7 +1569,7 @@ int lm_save_bank(const lm_detector* d, const char* path) {
     return LM_OK;
 }
 int lm_load_bank(lm_detector* d, const char* path) {
-    if (d && (d->lanes[0].busy || d->lanes[1].busy)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (d && any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (!d || !path) return fail(LM_ERR_INVALID, "null argument");
     std::string err;
     if (!lmh::load_bank(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
@@ -1574,7 +1584,7 @@ int lm_save_yaml(const lm_detector* d, const char* path) {
     return LM_OK;
 }
 int lm_load_yaml(lm_detector* d, const char* path) {
-    if (d && (d->lanes[0].busy || d->lanes[1].busy)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (d && any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (!d || !path) return fail(LM_ERR_INVALID, "null argument");
     std::string err;
     if (!lmy::load_templates_yaml(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
@@ -1906,7 +1916,7 @@ int lm_scan_load_bytes(lm_detector* d, int class_idx, double* bytes_per_frame) {
 int lm_set_scan_stats(lm_detector* d, int enable) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
-    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(d->d_scan_stat, 0, 2048 * sizeof(unsigned long long)));
     d->scan_stats = enable != 0;
@@ -1916,7 +1926,7 @@ int lm_set_scan_stats(lm_detector* d, int enable) {
 int lm_get_scan_stats(lm_detector* d, uint64_t* features_loaded, uint64_t* features_unpruned) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
-    if (d->lanes[0].busy || d->lanes[1].busy) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     std::vector<unsigned long long> h(2048);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h.data(), d->d_scan_stat, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -9,7 +9,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--steps", "6", "--warmup", "2", "--batch", "16", "--templates", "300", "--no-cpu-baseline"]
+SMALL = ["--steps", "6", "--warmup", "2", "--batch", "16", "--lanes", "2", "--templates", "300", "--no-cpu-baseline"]
 
 
 def _json_line(out):
