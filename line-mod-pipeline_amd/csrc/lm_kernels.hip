@@ -1514,7 +1514,11 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
     LmDevHeader* hdr = reinterpret_cast<LmDevHeader*>(reinterpret_cast<u8*>(a.hdr) + (size_t)slot * a.aux_slot_stride);
     LmCand* cand = reinterpret_cast<LmCand*>(reinterpret_cast<u8*>(a.cand) + (size_t)slot * a.aux_slot_stride);
     const int offset = a.T / 2 + (a.T % 2 - 1);
-    while (hit) {
+    // one reservation per lane: its hits go into the list back to back, in position order, so neighbouring lattice
+    // positions of one template -- which refine onto overlapping patches -- sit next to each other in the list (and
+    // are refined by waves of one workgroup at the same time: their patch lines are then L1 hits)
+    u32 pos = hit ? atomicAdd(&hdr->cand_count, (u32)__popc(hit)) : 0u;
+    for (; hit; ++pos) {
         const int b = __ffs(hit) - 1;
         hit &= hit - 1;
         u32 tv = 0;
@@ -1525,7 +1529,6 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
         const int raw = (b & 4) ? (int)(tv >> 16) : (int)(tv & 0xFFFF);
         const int j = (int)j0 + b;
         const int r = j / a.W, c = j - r * a.W;
-        const u32 pos = atomicAdd(&hdr->cand_count, 1u);
         if (pos < a.cand_cap) {
             LmCand cd;
             cd.ti = ti;
@@ -1642,6 +1645,7 @@ __global__ __launch_bounds__(1024) void k_refine_plan(const LmDevHeader* __restr
     for (int i = tid; i < 8 * cap + 8 + 8 * (cap + 1); i += 1024) plan[i] = pl[i];
 }
 
+#define PRUNE_REFINE true
 // One candidate of one slot: similarityLocal over the 16 x 16 patch, first-max argmax, rescore, threshold filter.
 template <bool LAST>
 __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 i, const u8 (*resp)[256], int lane) {
@@ -1666,7 +1670,15 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
     int off_x = bx * T, off_y = by * T;
     const u32 shift = (u32)(by * W + bx);   // two's complement: feature offset + shift >= 0 for kept features
     u32 s01 = 0, s23 = 0;   // u16 pairs: patch positions {0, 1} and {2, 3} of this lane (sums <= 126 * 4)
-    for (int m = 0; m < a.M; ++m) {
+    // Exact pruning, as in the scan: the candidate survives only if its best patch position reaches `threshold`, and a
+    // feature adds at most 4.  Every 16 features the wave takes the maximum partial sum of the patch; once even
+    // (maximum + 4 x features to come) * 100 / (4 n) < threshold -- the very float expression of the final test, which
+    // is monotone in the score -- the candidate is dropped without loading the rest.  Most candidates that chance
+    // produced on the coarse level die here after a quarter of their features.
+    int f_left = mt.nfeat_total;
+    const float denom = (float)(4 * mt.nfeat_total);
+    bool dead = false;
+    for (int m = 0; m < a.M && !dead; ++m) {
         const int cnt = (int)mt.count[m];
         LmRefFeat ft;
         ft.off = 0; ft.x = 0; ft.y = 0;
@@ -1693,7 +1705,18 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
                 s01 += r0 | (r1 << 16);
                 s23 += r2 | (r3 << 16);
             }
+            f_left -= min(8, cnt - f);
+            if (PRUNE_REFINE && (f & 8) && f_left > 0) {       // every second batch of eight
+                const u32 mx = pk_max_u16(s01, s23);
+                const u32 best_now = wave_max_u32(max(mx & 0xFFFFu, mx >> 16));
+                const float reach = __fdiv_rn(__fmul_rn((float)(int)(best_now + 4u * (u32)f_left), 100.f), denom);
+                if (reach < a.threshold) { dead = true; break; }
+            }
         }
+    }
+    if (dead) {
+        if (lane == 0) cand[i].ti = LM_DROPPED;
+        return;
     }
     // first maximum in row-major order: key = score << 8 | (255 - index)
     u32 idx0 = (u32)lane * 4u;
