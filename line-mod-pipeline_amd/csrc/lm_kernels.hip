@@ -1743,6 +1743,107 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
     }
 }
 
+// Two neighbouring list entries in lock step.  The scan leaves a lane's hits -- neighbouring lattice positions of one
+// template -- next to each other in the list; their 16 x 16 patches overlap by about 80 %, i.e. they pull the SAME
+// lines.  When both entries name the same template the wave issues the two patch loads of every feature back to back,
+// so the second one hits the line the first has just requested: one L2 request instead of two (the kernel is bound by
+// the L2 lines a patch pulls).  Different templates (or a dropped entry): one after the other, as before.
+template <bool LAST>
+__device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32 i, const u8 (*resp)[256], int lane) {
+    LmCand* cand = slot_ptr_s(a.cand, a.aux_slot_stride, slot);
+    const u32 tiA = (u32)__builtin_amdgcn_readfirstlane((int)cand[i].ti);
+    const u32 tiB = (u32)__builtin_amdgcn_readfirstlane((int)cand[i + 1].ti);
+    if (tiA != tiB || tiA == LM_DROPPED) {
+        refine_one<LAST>(a, slot, i, resp, lane);
+        refine_one<LAST>(a, slot, i + 1, resp, lane);
+        return;
+    }
+    LmDevHeader* hdr = slot_ptr_s(a.hdr, a.aux_slot_stride, slot);
+    u64* keys = slot_ptr_s(a.keys, a.aux_slot_stride, slot);
+    const u8* lm = a.lm + (size_t)slot * a.lm_slot_stride;
+    const int T = a.g.T, W = a.g.W;
+    const int border = 8 * T;
+    const int offset = T / 2 + (T % 2 - 1);
+    const u32 lane_off = (u32)((lane >> 2) * W + (lane & 3) * 4);
+    const u32 ti = tiA;
+    const LmRefMeta mt = a.meta[ti];
+    const int max_x = a.g.w - mt.width - border, max_y = a.g.h - mt.height - border;
+    int bx[2], by[2], off_x[2], off_y[2];
+    u32 shift[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const LmCand cd = cand[i + c];
+        const int cx = __builtin_amdgcn_readfirstlane(cd.x), cy = __builtin_amdgcn_readfirstlane(cd.y);
+        int x = cx * 2 + 1, y = cy * 2 + 1;
+        x = x > border ? x : border; y = y > border ? y : border;
+        x = x < max_x ? x : max_x;  y = y < max_y ? y : max_y;
+        bx[c] = x / T - 8; by[c] = y / T - 8;
+        off_x[c] = bx[c] * T; off_y[c] = by[c] * T;
+        shift[c] = (u32)(by[c] * W + bx[c]);
+    }
+    u32 s01[2] = {0, 0}, s23[2] = {0, 0};
+    for (int m = 0; m < a.M; ++m) {
+        const int cnt = (int)mt.count[m];
+        LmRefFeat ft;
+        ft.off = 0; ft.x = 0; ft.y = 0;
+        if (lane < cnt) ft = a.feats[mt.start[m] + lane];
+        u32 eff[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int fx = ft.x + off_x[c], fy = ft.y + off_y[c];
+            const bool ok = (lane < cnt) && fx >= 0 && fy >= 0 && fx < a.g.w && fy < a.g.h;
+            eff[c] = ok ? (ft.off & 0x1FFFFFFFu) + shift[c] : a.g.zero_off;
+        }
+        const u32 lab = ft.off >> 29;
+        for (int f = 0; f < cnt; f += 4) {
+            u32 v[2][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const u32 t = (u32)__builtin_amdgcn_readlane((int)eff[c], f + k) + lane_off;
+                    const u32x2 d = ld8a4(lm + (t & ~3u));
+                    v[c][k] = __builtin_amdgcn_alignbyte(d[1], d[0], t & 3u);
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32 lb = (u32)__builtin_amdgcn_readlane((int)lab, f + k);
+                const u8* tab = resp[lb];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const u32 r0 = tab[v[c][k] & 0xFFu], r1 = tab[(v[c][k] >> 8) & 0xFFu];
+                    const u32 r2 = tab[(v[c][k] >> 16) & 0xFFu], r3 = tab[v[c][k] >> 24];
+                    s01[c] += r0 | (r1 << 16);
+                    s23[c] += r2 | (r3 << 16);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const u32 idx0 = (u32)lane * 4u;
+        const u32 k0 = ((s01[c] & 0xFFFF) << 8) | (255u - idx0), k1 = ((s01[c] >> 16) << 8) | (254u - idx0);
+        const u32 k2 = ((s23[c] & 0xFFFF) << 8) | (253u - idx0), k3 = ((s23[c] >> 16) << 8) | (252u - idx0);
+        const u32 k01 = k0 > k1 ? k0 : k1, k23 = k2 > k3 ? k2 : k3;
+        const u32 key = wave_max_u32(k01 > k23 ? k01 : k23);
+        const int best = (int)(key >> 8);
+        int best_r = -1, best_c = -1;
+        if (best > 0) { const int idx = 255 - (int)(key & 255u); best_r = idx >> 4; best_c = idx & 15; }
+        const int nx = (bx[c] + best_c) * T + offset, ny = (by[c] + best_r) * T + offset;
+        const float sim = __fdiv_rn(__fmul_rn((float)best, 100.f), (float)(4 * mt.nfeat_total));
+        if (lane == 0) {
+            if (sim < a.threshold) {
+                cand[i + c].ti = LM_DROPPED;
+            } else if (LAST) {
+                emit_key(a, hdr, keys, ti, nx, ny, sim);
+            } else {
+                LmCand o; o.ti = ti; o.x = nx; o.y = ny; o.sim = sim;
+                cand[i + c] = o;
+            }
+        }
+    }
+}
+
 // Work distribution.  Every slot must stay on ONE XCD (its spread memories live in that L2), and candidate counts
 // differ a lot between frames (30 .. 1500).  With a plan (k_refine_plan: eight balanced slot lists + the running sums of
 // their candidate counts) an XCD's workgroups form ONE queue over all candidates of the XCD's slots: wave w takes the
@@ -1766,12 +1867,12 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
         xlen = a.plan[(size_t)8 * a.plan_cap + x];
         xpre = a.plan + (size_t)8 * a.plan_cap + 8 + (size_t)x * (a.plan_cap + 1);
         total = xpre[xlen];
-        if (tile * 4u >= total) return;
+        if (tile * 8u >= total) return;
     } else {
         xcd_slot_tile((u32)a.blocks_per_slot, (u32)a.nslots, slot, tile);
         total = slot_ptr_s(a.hdr, a.aux_slot_stride, slot)->cand_count;
         if (total > a.cand_cap) total = a.cand_cap;
-        if (tile * 4u >= total) return;   // nothing to do for this workgroup: leave before building the table
+        if (tile * 8u >= total) return;   // nothing to do for this workgroup (a wave takes two entries): leave before building the table
     }
     {
         const u8* sl = reinterpret_cast<const u8*>(a.sim_lut);   // [ori][lo 16 B | hi 16 B]
@@ -1785,14 +1886,28 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
     __syncthreads();
     const u32 wave0 = (u32)__builtin_amdgcn_readfirstlane((int)((tile * 256u + threadIdx.x) >> 6));
     const u32 nwaves = (u32)a.blocks_per_slot * 4u;
+    // a wave takes list entries two at a time (refine_pair); an odd entry at the end of a slot's list goes alone
     if (a.plan) {
         u32 idx = 0;
-        for (u32 g = wave0; g < total; g += nwaves) {
+        for (u32 g = 2u * wave0; g < total; g += 2u * nwaves) {
             while (idx + 1 < xlen && xpre[idx + 1] <= g) ++idx;      // g only grows: the list position moves forward
-            refine_one<LAST>(a, xs[idx], g - xpre[idx], resp, lane);
+            const u32 i = g - xpre[idx];
+            if (g + 1 < xpre[idx + 1]) {
+                refine_pair<LAST>(a, xs[idx], i, resp, lane);
+            } else {
+                refine_one<LAST>(a, xs[idx], i, resp, lane);
+                if (g + 1 < total) {                                  // the second entry opens the next slot's list
+                    u32 idx2 = idx;
+                    while (idx2 + 1 < xlen && xpre[idx2 + 1] <= g + 1) ++idx2;
+                    refine_one<LAST>(a, xs[idx2], g + 1 - xpre[idx2], resp, lane);
+                }
+            }
         }
     } else {
-        for (u32 i = wave0; i < total; i += nwaves) refine_one<LAST>(a, slot, i, resp, lane);
+        for (u32 i = 2u * wave0; i < total; i += 2u * nwaves) {
+            if (i + 1 < total) refine_pair<LAST>(a, slot, i, resp, lane);
+            else refine_one<LAST>(a, slot, i, resp, lane);
+        }
     }
 }
 
