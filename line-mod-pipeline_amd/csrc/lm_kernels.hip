@@ -540,6 +540,7 @@ __device__ __forceinline__ void cbs_step(const u32 (&ring)[4][10][2], u32 (&o4)[
     }
 }
 
+template <int STRIP>
 __global__ __launch_bounds__(256, 2) void k_cblur_sw(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
                                                    size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
     u32 slot, tile;
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void k_cblur_sw(const u8* __restrict__ bgr0
     const int nblk = (w * 3) >> 4;
     const int gid = (int)(tile * 256u) + (int)threadIdx.x;
     const int strip = gid / nblk, b = gid - strip * nblk;
-    const int y0 = strip * CBS_STRIP;
+    const int y0 = strip * STRIP;
     if (y0 >= h) return;
     const u32 pitch = (u32)w * 3u;
     u32 ring[4][10][2];
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void k_cblur_sw(const u8* __restrict__ bgr0
         cbs_pair(ring[k], w0, w1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    const int y1 = min(y0 + CBS_STRIP, h);
+    const int y1 = min(y0 + STRIP, h);
     const u32 bo = 16u * (u32)b, po = 16u * (u32)max(b - 1, 0), no = 16u * (u32)min(b + 1, nblk - 1);
     // Requests run TWO steps ahead (a step is about 1.3 us of arithmetic at two waves per SIMD, a miss under load takes
     // longer): set A holds the rows of the next step, set B those of the step after; the loop body is written twice so
@@ -2265,8 +2266,15 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
         if (g_cblur_variant == 1 || (g_cblur_variant == 0 && nslots < 16)) {
             hipLaunchKernelGGL(k_cblur, dim3((unsigned)(((n_b + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_b + 255) / 256, nslots);
         } else {
-            const int n_s = (w * 3 / 16) * ((h + CBS_STRIP - 1) / CBS_STRIP);   // 16-byte blocks x row strips
-            hipLaunchKernelGGL(k_cblur_sw, dim3((unsigned)(((n_s + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_s + 255) / 256, nslots);
+            // rows per strip: 16, or 32 for tall images (fewer re-read window rows per strip; a 480-row image would
+            // not give enough waves at 32)
+            if (h > 640) {
+                const int n_s = (w * 3 / 16) * ((h + 31) / 32);                 // 16-byte blocks x row strips
+                hipLaunchKernelGGL(k_cblur_sw<32>, dim3((unsigned)(((n_s + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_s + 255) / 256, nslots);
+            } else {
+                const int n_s = (w * 3 / 16) * ((h + CBS_STRIP - 1) / CBS_STRIP);
+                hipLaunchKernelGGL(k_cblur_sw<CBS_STRIP>, dim3((unsigned)(((n_s + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_s + 255) / 256, nslots);
+            }
         }
         hipLaunchKernelGGL(k_corient, dim3((unsigned)(((n_o + 255) / 256) * nslots)), dim3(256), 0, s, S, w, h, thr2, qn, mag, slot_stride, slot_stride, (n_o + 255) / 256, nslots);
         hipLaunchKernelGGL(k_cvote, dim3((unsigned)(((n_t + 255) / 256) * nslots)), dim3(256), 0, s, qn, w, h, quant, slot_stride, slot_stride, (n_t + 255) / 256, nslots);
