@@ -1272,6 +1272,60 @@ __global__ __launch_bounds__(256) void k_lm_fast(const u8* __restrict__ q0, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// a6-a10 for T = 2, spread memory only (level 0 of the colour-only configuration, T = {2, 8}): a streaming pass.
+// spread(y, x) = OR of the 2 x 2 block at (y, x); memory g = (y % 2) * 2 + x % 2 holds it at (y / 2) * W + x / 2.
+// One lane = 32 pixels of two rows: three source rows (32 B + one dword of halo each) give 2 x 32 spread bytes, split
+// into even / odd x (v_perm) = one 16-byte store per row and memory.  The tiled k_lm_fast<2, ..> needs 2400 tiny
+// workgroups with three barriers each per 1280 x 960 frame (224 us per 128 frames); this moves the same 2.4 MB in
+// a fraction of that.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lm_spread2(const u8* __restrict__ q0, int qpitch, int w, int h, u8* __restrict__ lm0,
+                                                     size_t q_slot_stride, size_t lm_slot_stride, int gblocks, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    const u8* q = slot_ptr_s(q0, q_slot_stride, slot);
+    u8* lm = slot_ptr_s(lm0, lm_slot_stride, slot);
+    const int ng = w >> 5, W = w >> 1;
+    const u32 wh = (u32)W * (u32)(h >> 1);
+    const int gid = (int)(tile * 256u) + (int)threadIdx.x;
+    const int yp = gid / ng, g = gid - yp * ng;       // row pair, 32-pixel group
+    const int y = 2 * yp;
+    if (y >= h) return;
+    u32 R[3][9];                                      // rows y, y + 1, y + 2: 32 bytes + the next dword
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const bool in = y + j < h;                    // below the image: zeros (the OR is one-sided, in-bounds only)
+        const u8* row = q + (size_t)min(y + j, h - 1) * qpitch + 32 * g;
+        const u32x4 a = ld16(row), b = ld16(row + 16);
+        const u32 nx = g + 1 < ng ? *reinterpret_cast<const u32*>(row + 32) : 0u;
+        R[j][0] = in ? a[0] : 0u; R[j][1] = in ? a[1] : 0u; R[j][2] = in ? a[2] : 0u; R[j][3] = in ? a[3] : 0u;
+        R[j][4] = in ? b[0] : 0u; R[j][5] = in ? b[1] : 0u; R[j][6] = in ? b[2] : 0u; R[j][7] = in ? b[3] : 0u;
+        R[j][8] = in ? nx : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        u32 sp[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const u32 v0 = R[r][d] | R[r + 1][d], v1 = R[r][d + 1] | R[r + 1][d + 1];
+            sp[d] = v0 | __builtin_amdgcn_alignbyte(v1, v0, 1u);        // x and x + 1
+        }
+        // even / odd x of 8 dwords -> 4 + 4 dwords
+        u32 ev[4], od[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ev[k] = __builtin_amdgcn_perm(sp[2 * k + 1], sp[2 * k], 0x06040200u);
+            od[k] = __builtin_amdgcn_perm(sp[2 * k + 1], sp[2 * k], 0x07050301u);
+        }
+        if (y + r < h) {
+            u8* base = lm + (size_t)(2 * r) * wh + (size_t)yp * W + 16 * g;   // memory (r, 0); (r, 1) is wh further
+            st16(base, u32x4{ev[0], ev[1], ev[2], ev[3]});
+            st16(base + wh, u32x4{od[0], od[1], od[2], od[3]});
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // a11-a13  HOT KERNEL.  One wave per (template, chunk of 1008 positions): lane l < 63 owns positions
 // [16 l, 16 l + 16) of the chunk.  For every feature the wave reads 1 KiB contiguous from the
 // feature's linear memory at a wave-uniform byte offset (scalar-loaded from the bank), rounded down
@@ -2331,7 +2385,15 @@ void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, 
     if (aligned) {
 #define LMF_ARGS s, q, qpitch, src_shift, mode, w, h, resp_tab, lm, ori_stride, q_slot_stride, lm_slot_stride, nslots
         switch (T) {
-            case 2: lm_fast_launch<2, 128>(LMF_ARGS); return;
+            case 2:
+                if (mode == 1 && !src_shift && (w % 32) == 0 && (h % 2) == 0 && (qpitch % 16) == 0 && (((uintptr_t)q & 15) == 0) &&
+                    (((uintptr_t)lm & 15) == 0) && (q_slot_stride % 16) == 0 && (lm_slot_stride % 16) == 0 && (((size_t)W * (h / 2)) % 16) == 0) {
+                    const int n_l = (w / 32) * (h / 2);
+                    hipLaunchKernelGGL(k_lm_spread2, dim3((unsigned)(((n_l + 255) / 256) * nslots)), dim3(256), 0, s, q, qpitch, w, h, lm,
+                                       q_slot_stride, lm_slot_stride, (n_l + 255) / 256, nslots);
+                    return;
+                }
+                lm_fast_launch<2, 128>(LMF_ARGS); return;
             case 4: lm_fast_launch<4, 64>(LMF_ARGS); return;
             case 5: lm_fast_launch<5, 128>(LMF_ARGS); return;
             case 8: lm_fast_launch<8, 40>(LMF_ARGS); return;
