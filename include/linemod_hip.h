@@ -183,6 +183,9 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
 /* LM_TUNE_CBLUR_VARIANT (process-wide): Gaussian blur kernel 0 = by batch size (default: one-shot below 16 frames, sliding
  *   window from there), 1 = one-shot, 2 = sliding window. */
 #define LM_TUNE_CBLUR_VARIANT 4
+/* LM_TUNE_CGRAD_VARIANT (process-wide): gradient orientation + 3x3 vote 0 = by batch size (default: two kernels below 16
+ *   frames, the fused strip kernel from there), 1 = two kernels, 2 = fused. */
+#define LM_TUNE_CGRAD_VARIANT 5
 int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 /* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame

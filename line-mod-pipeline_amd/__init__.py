@@ -39,6 +39,7 @@ TUNE_FORK_MAX_SLOTS = 1
 TUNE_MATCH_UPLOAD_MODE = 2
 TUNE_COPY_STREAMS = 3
 TUNE_CBLUR_VARIANT = 4
+TUNE_CGRAD_VARIANT = 5
 
 
 class Rect(C.Structure):

@@ -754,6 +754,183 @@ __global__ __launch_bounds__(256) void k_cvote(const u8* __restrict__ qn0, int w
     }
 }
 
+// a2+a3 in one pass: k_corient + k_cvote for batches (S -> quant, no qn image in between).
+//
+// Arithmetic.  Both kernels above are bound by the vector ALU (95 + 21 instructions per pixel), not by memory, so
+// this one is built around the instruction count:
+//   * the three rows of S are unpacked once into even / odd byte pairs (u16 x 2 per dword) and everything up to the
+//     gradient runs as packed 16-bit arithmetic on them.  The Sobel taps are +-3 BYTES apart whatever the channel, and
+//     a 3-byte shift of an (even, odd) pair of registers is a register rename plus one v_alignbit;
+//   * the squared magnitude of a byte position is one v_dot2_i32_i16 of its (dx, dy) pair with itself;
+//   * the orientation label needs no arctangent.  For |dx|, |dy| <= 1020 (all a Sobel of 8-bit data can give) the
+//     label of cv::fastAtan2 -> x 16/360 -> rint -> & 7 depends on the signs, on |dy| > |dx| and on which of three
+//     intervals min / max falls into, and the interval bounds are the same in every octant: with
+//         s = (1282 min > 255 max) + (1384 min > 925 max)          (255/1282 and 925/1384: the mediants of the
+//         q = |dy| > |dx| ? 4 - s : s,   label = (sign(dx) != sign(dy) ? -q : q) & 7     neighbouring realised ratios)
+//     the label is bit-identical to the float path for ALL 2041 x 2041 inputs (tests/test_orientation_rule.py checks
+//     every pair against the oracle's float code).  The threshold flag (float)m > thr^2 is m > floor(thr^2).
+// Shape.  A lane owns 16 pixels x a strip of STRIP rows and walks down one row at a time: S rows r-1, r stay unpacked
+// in registers, row r+1 was requested one step earlier.  Each step yields the labels of row r as one-hot nibbles,
+// their horizontal 3-sums (the two neighbour pixels come from the adjacent lanes with v_mov_b32_dpp wave_shr / wave_shl)
+// and, from the 3-sums of rows r-2 .. r, the voted output row r-1.  Lanes 0 and 63 of a wave only feed their
+// neighbours: a wave covers 62 consecutive (strip, segment) pairs, and the pairs are numbered strip-major, so a wave
+// is always full (a neighbour from another strip only ever feeds column 0 or w-1, which is zero anyway).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 pk_sub_i16(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ u32 pk_add_i16(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ u32 pk_max_i16(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ int dot2_self(u32 p) {   // lo * lo + hi * hi of an i16 pair
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(r) : "v"(p));
+    return r;
+}
+// window dwords of one S row for a 16-pixel segment: bytes 48g - 4 .. 48g + 51 (14 dwords), unpacked
+struct CgRow { u32 E[14], O[14]; };    // E[d] = bytes (4d, 4d + 2), O[d] = bytes (4d + 1, 4d + 3) of the window, as u16 pairs
+struct CgRaw { u32x4 a, b, c; u32 l, r; };
+__device__ __forceinline__ void cg_request(CgRaw& q, const u8* S, int y, int h, u32 pitch, u32 so, u32 lo, u32 ro) {
+    const u32 row = (u32)clampi(y, 0, h - 1) * pitch;
+    q.a = ld16(S + (row + so)); q.b = ld16(S + (row + so + 16u)); q.c = ld16(S + (row + so + 32u));
+    q.l = *reinterpret_cast<const u32*>(S + (row + lo)); q.r = *reinterpret_cast<const u32*>(S + (row + ro));
+}
+__device__ __forceinline__ void cg_unpack(CgRow& u, const CgRaw& q) {
+    const u32 R[14] = {q.l, q.a[0], q.a[1], q.a[2], q.a[3], q.b[0], q.b[1], q.b[2], q.b[3], q.c[0], q.c[1], q.c[2], q.c[3], q.r};
+#pragma unroll
+    for (int d = 0; d < 14; ++d) {
+        u.E[d] = __builtin_amdgcn_perm(R[d], R[d], 0x0c020c00u);
+        u.O[d] = __builtin_amdgcn_perm(R[d], R[d], 0x0c030c01u);
+    }
+}
+// labels of one row: one-hot nibbles oh[p] = 1 << 4 label, flag word (bit 15 - p = magnitude of pixel p above the
+// threshold).  lmask = 28, or 0 on the first / last image row (labels forced to 0 there); first / last: segment at
+// the left / right image edge.
+__device__ __forceinline__ void cg_labels(const CgRow& A, const CgRow& B, const CgRow& N, u32 lmask, bool first, bool last,
+                                          int ithr, u32 (&oh)[16], u32& fw) {
+    u32 vse[14], vso[14], vde[14], vdo[14];
+#pragma unroll
+    for (int d = 0; d < 14; ++d) {
+        vse[d] = A.E[d] + N.E[d] + 2u * B.E[d]; vso[d] = A.O[d] + N.O[d] + 2u * B.O[d];      // <= 1020 per half
+        vde[d] = pk_sub_i16(N.E[d], A.E[d]); vdo[d] = pk_sub_i16(N.O[d], A.O[d]);
+    }
+    // byte position wb = 4d + k of the window: dx = VS[wb + 3] - VS[wb - 3], dy = VD[wb - 3] + 2 VD[wb] + VD[wb + 3];
+    // three bytes further / back from an even pair is (O[d].hi, O[d+1].lo) / O[d-1], from an odd pair E[d+1] / (E[d-1].hi, E[d].lo)
+    u32 P[56];   // (dx, dy) i16 pair per byte position, window bytes 4 .. 51
+    int M[56];
+#pragma unroll
+    for (int d = 1; d <= 12; ++d) {
+        const u32 dxe = pk_sub_i16(__builtin_amdgcn_alignbit(vso[d + 1], vso[d], 16), vso[d - 1]);
+        const u32 dxo = pk_sub_i16(vse[d + 1], __builtin_amdgcn_alignbit(vse[d], vse[d - 1], 16));
+        const u32 dye = pk_add_i16(pk_add_i16(vdo[d - 1], __builtin_amdgcn_alignbit(vdo[d + 1], vdo[d], 16)), pk_add_i16(vde[d], vde[d]));
+        const u32 dyo = pk_add_i16(pk_add_i16(__builtin_amdgcn_alignbit(vde[d], vde[d - 1], 16), vde[d + 1]), pk_add_i16(vdo[d], vdo[d]));
+        P[4 * d + 0] = __builtin_amdgcn_perm(dye, dxe, 0x05040100u); P[4 * d + 1] = __builtin_amdgcn_perm(dyo, dxo, 0x05040100u);
+        P[4 * d + 2] = __builtin_amdgcn_perm(dye, dxe, 0x07060302u); P[4 * d + 3] = __builtin_amdgcn_perm(dyo, dxo, 0x07060302u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) M[4 * d + k] = dot2_self(P[4 * d + k]);
+    }
+    fw = 0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const int wb = 4 + 3 * p;
+        const int m0 = M[wb], m1 = M[wb + 1], m2 = M[wb + 2];
+        const int bm = max(max(m0, m1), m2);
+        const u32 p0 = P[wb], p1 = P[wb + 1], p2 = P[wb + 2];  // (values first: a ?: on the array elements selects addresses)
+        u32 W = m1 >= m2 ? p1 : p2;
+        W = m0 == bm ? p0 : W;                                 // first maximum wins ties = upstream's >= cascade
+        const u32 Aa = pk_max_i16(W, pk_sub_i16(0u, W));       // (|dx|, |dy|)
+        const u32 ax = Aa & 0xFFFFu, ay = Aa >> 16;
+        const u32 mn = min(ax, ay), mx = max(ax, ay);
+        const int t1 = (int)(mn * 1282u) - (int)(mx * 255u), t2 = (int)(mn * 1384u) - (int)(mx * 925u);
+        const int s = (t1 > 0) + (t2 > 0);
+        int q = ay > ax ? 4 - s : s;
+        q = ((W ^ (W >> 16)) & 0x8000u) ? -q : q;
+        u32 sh = ((u32)q << 2) & lmask;
+        if (p == 0) sh = first ? 0u : sh;
+        if (p == 15) sh = last ? 0u : sh;
+        oh[p] = 1u << sh;
+        fw = __builtin_amdgcn_alignbit(fw, (u32)(ithr - bm), 31);   // fw = fw << 1 | (bm > ithr)
+    }
+}
+
+#define CG_STRIP 16
+template <int STRIP>
+__global__ __launch_bounds__(256, 2) void k_cgrad(const u8* __restrict__ s0, int w, int h, int ithr, u8* __restrict__ quant0,
+                                                  size_t tmp_stride, size_t out_stride, int gblocks, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    const u8* S = slot_ptr_s(s0, tmp_stride, slot);
+    u8* quant = slot_ptr_s(quant0, out_stride, slot);
+    const int ns = w >> 4, total = ns * ((h + STRIP - 1) / STRIP);
+    const int lane = (int)(threadIdx.x & 63u);
+    const int f0 = ((int)tile * 4 + (int)(threadIdx.x >> 6)) * 62 - 1;   // pair of lane 0 (a feeder)
+    if (f0 + 1 >= total) return;                                          // whole wave past the end
+    const bool writer = lane >= 1 && lane <= 62 && f0 + lane < total;
+    const int f = clampi(f0 + lane, 0, total - 1);
+    const int strip = f / ns, g = f - strip * ns;
+    const int y0 = strip * STRIP;
+    const u32 pitch = (u32)w * 3u;
+    const u32 so = 48u * (u32)g;
+    const u32 lo = g > 0 ? so - 4u : so, ro = g + 1 < ns ? so + 48u : so + 44u;   // at the row ends: any valid dword (column 0 / w-1 is zero)
+    const bool first = g == 0, last = g == ns - 1;
+    // Rings of three: S rows (r-1, r, r+1), 3-sum rows (r-2, r-1, r), flag words.  The loop body is written three times
+    // with the roles rotated by name, so that nothing is moved between steps.
+    CgRow R[3];
+    {
+        CgRaw q0, q1;
+        cg_request(q0, S, y0 - 2, h, pitch, so, lo, ro);
+        cg_request(q1, S, y0 - 1, h, pitch, so, lo, ro);
+        cg_unpack(R[0], q0); cg_unpack(R[1], q1);
+    }
+    CgRaw nx;
+    cg_request(nx, S, y0, h, pitch, so, lo, ro);
+    u32 H[3][16], F[3] = {0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 16; ++p) { H[0][p] = 0; H[1][p] = 0; H[2][p] = 0; }
+    const u32 emask = 0xFFFFu & ~((first ? 0x8000u : 0u) | (last ? 1u : 0u));   // columns 0 and w-1 never vote
+#define CG_STEP(K)                                                                                          \
+    {                                                                                                       \
+        const int r = y0 - 1 + t + (K);                        /* label row of this step */                 \
+        cg_unpack(R[((K) + 2) % 3], nx);                                                                    \
+        cg_request(nx, S, r + 2, h, pitch, so, lo, ro);        /* S row of the next step */                 \
+        u32 oh[16];                                                                                         \
+        cg_labels(R[(K) % 3], R[((K) + 1) % 3], R[((K) + 2) % 3], (r <= 0 || r >= h - 1) ? 0u : 28u, first, last, ithr, oh, F[((K) + 2) % 3]); \
+        const u32 ohl = (u32)__builtin_amdgcn_update_dpp(0, (int)oh[15], 0x138, 0xf, 0xf, false);   /* lane - 1's pixel 15 */ \
+        const u32 ohr = (u32)__builtin_amdgcn_update_dpp(0, (int)oh[0], 0x130, 0xf, 0xf, false);    /* lane + 1's pixel 0 */  \
+        _Pragma("unroll") for (int p = 0; p < 16; ++p)                                                      \
+            H[((K) + 2) % 3][p] = (p == 0 ? ohl : oh[p - 1]) + oh[p] + (p == 15 ? ohr : oh[p + 1]);         \
+        const int y = r - 1;                                   /* output row: centre of label rows r-2, r-1, r */ \
+        if (t + (K) >= 2 && y < h) {                                                                        \
+            const u32 keep = (y >= 1 && y <= h - 2) ? (F[((K) + 1) % 3] & emask) : 0u;                      \
+            u32 res[16];                                                                                    \
+            _Pragma("unroll") for (int p = 0; p < 16; ++p) {                                                \
+                const u32 cnt = H[0][p] + H[1][p] + H[2][p];                                                \
+                const u32 m = (cnt + 0x33333333u) & 0x88888888u;   /* at most one nibble reaches 5 of 9 votes */ \
+                /* no winner: ffs - 1 = -1 -> 1 << 31, whose byte 0 (all the packing below takes) is 0 */   \
+                const u32 one = 1u << (((u32)(__ffs((int)m) - 1) >> 2) & 31u);                              \
+                res[p] = one & (u32)__builtin_amdgcn_sbfe((int)keep, 15 - p, 1);                            \
+            }                                                                                               \
+            u32 o[4];                                                                                       \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                   \
+                o[k] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(res[4 * k + 3], res[4 * k + 2], 0x0c0c0400u), \
+                                             __builtin_amdgcn_perm(res[4 * k + 1], res[4 * k], 0x0c0c0400u), 0x05040100u); \
+            if (writer) st16(quant + ((u32)y * (u32)w + 16u * (u32)g), u32x4{o[0], o[1], o[2], o[3]});      \
+        }                                                                                                   \
+    }
+#pragma unroll 1
+    for (int t = 0; t < STRIP + 2; t += 3) {
+        CG_STEP(0)
+        if (t + 1 >= STRIP + 2) break;
+        CG_STEP(1)
+        if (t + 2 >= STRIP + 2) break;
+        CG_STEP(2)
+    }
+#undef CG_STEP
+}
+
 // ------------------------------------------------------------------------------------------------
 // a5  DepthNormal::process -> quantizedNormals + medianBlur(5).  64x8 outputs per workgroup; the
 // depth tile (+-7) and the raw normals (+-2) live in LDS.
@@ -2297,6 +2474,8 @@ void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, i
 static int g_cblur_variant = 0;   // 0: by batch size (one-shot below 16 frames, sliding window from there), 1: one-shot blur
                                   // (k_cblur), 2: sliding-window blur (k_cblur_sw); A/B knob of tools/ and tests
 void lmk_set_cblur_variant(int v) { g_cblur_variant = v; }
+static int g_cgrad_variant = 0;   // 0: by batch size (fused k_cgrad from 16 frames), 1: k_corient + k_cvote, 2: k_cgrad
+void lmk_set_cgrad_variant(int v) { g_cgrad_variant = v; }
 
 size_t lmk_color_scratch_bytes(int w, int h) {
     // S u8 [h][3w] | qn u8 [h][w], each 256-B aligned (also the rank-code image of the depth passes)
@@ -2329,6 +2508,22 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
                 const int n_s = (w * 3 / 16) * ((h + CBS_STRIP - 1) / CBS_STRIP);
                 hipLaunchKernelGGL(k_cblur_sw<CBS_STRIP>, dim3((unsigned)(((n_s + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_s + 255) / 256, nslots);
             }
+        }
+        // orientation + vote: fused for batches (k_cgrad), two kernels for few frames (many short waves) and whenever the
+        // caller wants the magnitude image
+        if (!mag && (g_cgrad_variant == 2 || (g_cgrad_variant == 0 && nslots >= 16))) {
+            const int ithr = thr2 >= 2147483648.f ? INT_MAX : (int)floorf(thr2);    // (float)m > thr2 <=> m > floor(thr2)
+            // rows per strip: 16 (2 of 18 label rows are recomputed by the neighbouring strips), 8 when that would leave
+            // SIMDs without a wave (a 320 x 240 level is 5 waves per frame at 16)
+            auto waves = [&](int strip) { return ((w / 16) * ((h + strip - 1) / strip) + 61) / 62; };
+            if ((long)waves(CG_STRIP) * nslots >= 1536) {
+                const int n_w = waves(CG_STRIP);
+                hipLaunchKernelGGL(k_cgrad<CG_STRIP>, dim3((unsigned)(((n_w + 3) / 4) * nslots)), dim3(256), 0, s, S, w, h, ithr, quant, slot_stride, slot_stride, (n_w + 3) / 4, nslots);
+            } else {
+                const int n_w = waves(8);
+                hipLaunchKernelGGL(k_cgrad<8>, dim3((unsigned)(((n_w + 3) / 4) * nslots)), dim3(256), 0, s, S, w, h, ithr, quant, slot_stride, slot_stride, (n_w + 3) / 4, nslots);
+            }
+            return;
         }
         hipLaunchKernelGGL(k_corient, dim3((unsigned)(((n_o + 255) / 256) * nslots)), dim3(256), 0, s, S, w, h, thr2, qn, mag, slot_stride, slot_stride, (n_o + 255) / 256, nslots);
         hipLaunchKernelGGL(k_cvote, dim3((unsigned)(((n_t + 255) / 256) * nslots)), dim3(256), 0, s, qn, w, h, quant, slot_stride, slot_stride, (n_t + 255) / 256, nslots);

@@ -266,6 +266,15 @@ void orc_color_quantize(const uint8_t* bgr, int w, int h, float weak_threshold, 
     if (magnitude) std::memcpy(magnitude, mag.data(), n * sizeof(float));
 }
 
+// The orientation label of orc_color_quantize for a batch of gradient vectors (steps 4-5: fastAtan2, x 16/360, rint,
+// & 7), so a test can sweep every (dx, dy) a Sobel of 8-bit data can produce.
+void orc_orientation_labels(const int32_t* dx, const int32_t* dy, size_t n, uint8_t* label) {
+    const float scale = (float)(16.0 / 360.0);
+    ORC_PAR_FOR
+    for (size_t i = 0; i < n; ++i)
+        label[i] = (u8)(sat_u8_rint(fast_atan2_deg((float)dy[i], (float)dx[i]) * scale + 0.0f) & 7);
+}
+
 // a4: cv::pyrDown on CV_8UC3: 5x5 [1 4 6 4 1]^2/256, BORDER_REFLECT_101, (sum+128)>>8 (A.2 pyrDown).
 void orc_pyrdown_u8c3(const uint8_t* src, int w, int h, uint8_t* dst) {
     static const int K[5] = {1, 4, 6, 4, 1};

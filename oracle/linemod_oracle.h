@@ -67,6 +67,7 @@ void orc_gaussian7_u8c3(const uint8_t* src, int w, int h, uint8_t* dst);        
 void orc_sobel3_s16c3(const uint8_t* src, int w, int h, int16_t* dx, int16_t* dy);             /* a3 Sobel CV_16S            */
 void orc_color_quantize(const uint8_t* bgr, int w, int h, float weak_threshold,
                         uint8_t* quantized, float* magnitude /* may be NULL */);              /* a3 quantizedOrientations   */
+void orc_orientation_labels(const int32_t* dx, const int32_t* dy, size_t n, uint8_t* label);  /* a3 steps 4-5 on given gradients */
 void orc_pyrdown_u8c3(const uint8_t* src, int w, int h, uint8_t* dst);                         /* a4 cv::pyrDown             */
 void orc_depth_quantize(const uint16_t* depth, int w, int h, int distance_threshold,
                         int difference_threshold, const uint8_t* normal_lut, uint8_t* quantized); /* a5 quantizedNormals  */

@@ -80,6 +80,7 @@ def load(path=None):
     lib.orc_sobel3_s16c3.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     lib.orc_color_quantize.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.orc_pyrdown_u8c3.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.orc_orientation_labels.argtypes = [vp, vp, C.c_size_t, vp]
     lib.orc_depth_quantize.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.orc_resize_nn_half.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.orc_spread.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
@@ -151,6 +152,12 @@ def color_quantize(bgr, weak_threshold=10.0, want_magnitude=False):
     mag = np.empty((h, w), np.float32) if want_magnitude else None
     lib.orc_color_quantize(_ptr(bgr), w, h, weak_threshold, _ptr(q), _ptr(mag))
     return (q, mag) if want_magnitude else q
+
+
+def orientation_labels(dx, dy):
+    """Orientation label (0..7) of the float path (fastAtan2 -> x 16/360 -> rint -> & 7) for int32 gradient arrays."""
+    lib = load(); dx = _c(dx, np.int32); dy = _c(dy, np.int32)
+    out = np.empty(dx.shape, np.uint8); lib.orc_orientation_labels(_ptr(dx), _ptr(dy), dx.size, _ptr(out)); return out
 
 
 def pyrdown(bgr):

@@ -49,6 +49,23 @@ def test_color_quantize_both_blur_kernels(lm, det, orc, frame0, variant):
         det.set_tuning(lm.TUNE_CBLUR_VARIANT, 0)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+def test_color_quantize_both_gradient_kernels(lm, det, orc, frame0, variant):
+    """Orientation + vote run as two kernels (few frames) or as the fused strip kernel with the integer orientation rule
+    (batches): force each (LM_TUNE_CGRAD_VARIANT) on shapes that hit strip ends, wave ends (62 segments) and thresholds."""
+    det.set_tuning(lm.TUNE_CGRAD_VARIANT, variant)
+    try:
+        rng = np.random.default_rng(10 + variant)
+        for shape in [(480, 640), (240, 320), (960, 1280), (16, 64), (17, 64), (50, 16), (130, 160), (33, 48), (35, 1008)]:
+            for smooth in (True, False):
+                bgr = _rand_bgr(rng, shape[0], shape[1], smooth)
+                assert np.array_equal(det.stage_color_quantize(bgr), orc.color_quantize(bgr)), (variant, shape, smooth)
+        for thr in (0.0, 3.5, 10.0, 30.0, 200.0, 1e6):
+            assert np.array_equal(det.stage_color_quantize(frame0[0], weak_threshold=thr), orc.color_quantize(frame0[0], thr)), thr
+    finally:
+        det.set_tuning(lm.TUNE_CGRAD_VARIANT, 0)
+
+
 def test_color_quantize_frame0_and_thresholds(det, orc, frame0):
     bgr, _ = frame0
     assert np.array_equal(det.stage_color_quantize(bgr), orc.color_quantize(bgr))

@@ -1,0 +1,41 @@
+"""The fused gradient kernel (k_cgrad, lm_kernels.hip) replaces fastAtan2 + rint by an integer rule:
+
+    s = (1282 min > 255 max) + (1384 min > 925 max),  q = |dy| > |dx| ? 4 - s : s,  label = (sign(dx) != sign(dy) ? -q : q) & 7
+
+with min / max of (|dx|, |dy|).  A 3x3 Sobel of 8-bit data gives |dx|, |dy| <= 1020; this test sweeps ALL of those
+(2041 x 2041 pairs) against the oracle's float code (cv::phase -> convertTo(CV_8U, 16/360) -> & 7).
+"""
+import numpy as np
+import pytest
+
+
+def integer_rule(dx, dy):
+    ax, ay = np.abs(dx), np.abs(dy)
+    mn, mx = np.minimum(ax, ay), np.maximum(ax, ay)
+    s = (mn * 1282 > mx * 255).astype(np.int32) + (mn * 1384 > mx * 925)
+    q = np.where(ay > ax, 4 - s, s)
+    q = np.where((dx < 0) ^ (dy < 0), -q, q)
+    return (q & 7).astype(np.uint8)
+
+
+def test_integer_orientation_rule_matches_float_path_everywhere():
+    from oracle import oracle as orc
+    r = 1020
+    dx, dy = np.meshgrid(np.arange(-r, r + 1, dtype=np.int32), np.arange(-r, r + 1, dtype=np.int32))
+    want = orc.orientation_labels(dx, dy)
+    got = integer_rule(dx, dy)
+    assert want.shape == got.shape == (2 * r + 1, 2 * r + 1)
+    assert np.array_equal(got, want)
+    assert set(np.unique(want).tolist()) == set(range(8))
+
+
+def test_rule_thresholds_are_strictly_between_realised_ratios():
+    """255/1282 and 925/1384 are mediants of neighbouring fractions with denominators <= 1020, so no realisable
+    min/max equals them: the strict compare never sees equality except at (0, 0), where the label is 0."""
+    from fractions import Fraction
+    for lo, hi, mid in ((Fraction(182, 915), Fraction(73, 367), Fraction(255, 1282)),
+                        (Fraction(661, 989), Fraction(264, 395), Fraction(925, 1384))):
+        assert lo < mid < hi
+        assert hi.numerator * lo.denominator - lo.numerator * hi.denominator == 1   # neighbours in the Farey sequence
+        assert mid.denominator > 1020
+    assert integer_rule(np.array([0]), np.array([0]))[0] == 0
