@@ -186,6 +186,10 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
 /* LM_TUNE_CGRAD_VARIANT (process-wide): gradient orientation + 3x3 vote 0 = by batch size (default: two kernels below 16
  *   frames, the fused strip kernel from there), 1 = two kernels, 2 = fused. */
 #define LM_TUNE_CGRAD_VARIANT 5
+/* LM_TUNE_PHASE_MAX_SLOTS: calls of at most this many frames run the pre-processing (a3-a10) as five launches, each
+ *   holding the independent kernels of one dependency level on ranges of the block index, instead of fourteen dependent
+ *   ones (default 15: from 16 frames the batch kernels take over; 0 = off; two-level T = {5, 8} pyramids only, anything else takes the plain sequence). */
+#define LM_TUNE_PHASE_MAX_SLOTS 6
 int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 /* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame

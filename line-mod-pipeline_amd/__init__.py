@@ -40,6 +40,7 @@ TUNE_MATCH_UPLOAD_MODE = 2
 TUNE_COPY_STREAMS = 3
 TUNE_CBLUR_VARIANT = 4
 TUNE_CGRAD_VARIANT = 5
+TUNE_PHASE_MAX_SLOTS = 6
 
 
 class Rect(C.Structure):

@@ -126,6 +126,7 @@ struct lm_detector {
     int comm_recs_per_frame = 0;
     Gather gather[LM_NLANES];
     double* d_red = nullptr;   // small device buffer of lm_comm_max / lm_comm_barrier
+    int phase_max_slots = 15;        // calls of up to this many frames run a3-a10 as one launch per dependency level (LmPhaseArgs)
     int fork_max_slots = 0;          // measured r02: no gain (host launch rate, 3.4 us per launch, bounds small calls), so off by default
     int fork_depth_wait_slot = -1;   // forked single-frame call: the depth chain's stream waits for this slot's whole upload
     int match_upload_mode = 0;       // lm_match: 0 = copies inline on the compute stream (default, faster), 1 = copy stream + split events
@@ -369,7 +370,26 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
     const lm_config& c = d->cfg;
     const int M = c.num_modalities, L = c.pyramid_levels;
     const size_t fs = d->frame_stride;
-    // ---- few frames: three concurrent chains (latency-bound regime)
+    // ---- few frames: one launch per dependency level (lm_kernels.h LmPhaseArgs): 5 launches instead of 14
+    if (n <= d->phase_max_slots && n > d->fork_max_slots && L == 2) {     // (the fork experiment, when switched on, wins)
+        LmPhaseArgs pa{};
+        pa.bgr0 = d->bgr(first, 0); pa.bgr1 = d->bgr(first, 1); pa.depth = M == 2 ? d->depth(first) : nullptr;
+        pa.cs0 = d->cscratch(first, 0); pa.cs1 = d->cscratch(first, 1); pa.ds = d->dscratch(first);
+        pa.qc0 = d->quant(first, 0, 0); pa.qc1 = d->quant(first, 1, 0); pa.qd0 = M == 2 ? d->quant(first, 0, 1) : nullptr;
+        pa.lm_c0 = d->lm(first, 0); pa.lm_c1 = d->lm(first, 1);
+        pa.lm_d0 = d->lm(first, 0) + d->geom[0].mod_stride; pa.lm_d1 = d->lm(first, 1) + d->geom[1].mod_stride;
+        pa.w = d->lw[0]; pa.h = d->lh[0];
+        pa.weak_threshold = c.weak_threshold; pa.dist_thr = c.distance_threshold; pa.diff_thr = c.difference_threshold;
+        pa.normal_lut = d->d_normal_lut; pa.resp_tab = d->d_resp_tab; pa.ori_stride1 = d->geom[1].ori_stride;
+        pa.slot_stride = fs; pa.nslots = n;
+        auto mode = [&](int l) { return d->geom[l].spread_only ? 1 : d->geom[l].nibble ? 2 : 0; };
+        if (M <= 2 && d->lw[1] * 2 == d->lw[0] && d->lh[1] * 2 == d->lh[0] &&
+            lmk_phases_supported(pa, d->geom[0].T, d->geom[1].T, mode(0), mode(1), M == 2 ? normal_lut_onehot(d) : true)) {
+            lmk_preprocess_phases(d->stream, pa);
+            return;
+        }
+    }
+    // ---- few frames: three concurrent chains (latency-bound regime; measured no gain, off by default)
     if (n <= d->fork_max_slots && L >= 2 && ensure_fork(d)) {
         lm_detector::Fork& f = d->forks[d->active];
         hipStream_t s0 = d->stream, s1 = f.s[0], s2 = f.s[1];
@@ -1119,6 +1139,7 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
         case LM_TUNE_FORK_MAX_SLOTS: if (value < 0) break; d->fork_max_slots = value; return LM_OK;
         case LM_TUNE_MATCH_UPLOAD_MODE: if (value < 0 || value > 1) break; d->match_upload_mode = value; return LM_OK;
         case LM_TUNE_CBLUR_VARIANT: if (value < 0 || value > 2) break; lmk_set_cblur_variant(value); return LM_OK;
+        case LM_TUNE_PHASE_MAX_SLOTS: if (value < 0) break; d->phase_max_slots = value; return LM_OK;
         case LM_TUNE_CGRAD_VARIANT: if (value < 0 || value > 2) break; lmk_set_cgrad_variant(value); return LM_OK;
         case LM_TUNE_COPY_STREAMS: if (value < 1 || value > LM_NCOPY) break; d->n_copy_streams = value; return LM_OK;
         default: return fail(LM_ERR_INVALID, "unknown tuning key");

@@ -115,6 +115,28 @@ struct LmHsvRange { int lo[3], hi[3]; };
 // one bit per pixel: 8-bit HSV of the BGR image inside [lo, hi]; divtab = sdiv_table[256] | hdiv_table180[256]
 void lmk_hsv_mask(hipStream_t s, const u8* bgr, int w, int h, const LmHsvRange& rg, const int* divtab, u32* mask, int wpr,
                   size_t in_stride, size_t mask_stride, int nslots);
+// a3-a10 of FEW frames as five launches instead of fourteen (single-frame latency; the default two-level RGB-D / colour
+// pyramid with T = {5, 8} only).  Every launch runs the independent kernels of one dependency level side by side, each
+// on its own range of the block index:
+//   1  blur(level 0)            | depth normals          | pyrDown(level 0 -> 1)
+//   2  median of the normals    | blur(level 1)          | orientation(level 0)
+//   3  vote(level 0)            | orientation(level 1)   | depth linear memories of levels 0 and 1
+//   4  vote(level 1)            | colour linear memories of level 0
+//   5  colour linear memories of level 1
+struct LmPhaseArgs {
+    const u8* bgr0; u8* bgr1; const u16* depth;      // level-0 colour image, level-1 colour image (written by launch 1), depth (or null)
+    u8 *cs0, *cs1, *ds;                              // scratch: colour level 0 / 1 (lmk_color_scratch_bytes each), depth (w * h)
+    u8 *qc0, *qc1, *qd0;                             // quantised images
+    u8 *lm_c0, *lm_c1, *lm_d0, *lm_d1;               // linear memories: modality base pointers of levels 0 and 1
+    int w, h;                                        // level 0; level 1 is w / 2 x h / 2
+    float weak_threshold; int dist_thr, diff_thr;
+    const u8* normal_lut; const u64* resp_tab;
+    u32 ori_stride1;                                 // bytes between the response memories of level 1 (nibble packed)
+    size_t slot_stride; int nslots;
+};
+bool lmk_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0, int mode1, bool lut_onehot);
+void lmk_preprocess_phases(hipStream_t s, const LmPhaseArgs& a);
+
 struct LmHullArgs {
     const LmOutMatch* matches; u32 n;
     const u32* class_base;       // [n_classes] first hull of the class in hull_off

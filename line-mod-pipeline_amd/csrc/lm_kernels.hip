@@ -93,11 +93,11 @@ __device__ __forceinline__ T* slot_ptr_s(T* p, size_t slot_stride, u32 slot) {
 // 1-D grids of G tiles x B slots with XCD affinity: block b is assumed to run on XCD b % 8 (observed round-robin
 // dispatch; only speed depends on it), so with B % 8 == 0 every tile of a slot runs on the same XCD and the
 // slot's working set (linear memories, partially written lines) lives in ONE 4 MB L2 instead of eight.
-__device__ __forceinline__ void xcd_slot_tile(u32 G, u32 B, u32& slot, u32& tile) {
-    const u32 b = blockIdx.x;
+__device__ __forceinline__ void xcd_slot_tile_b(u32 b, u32 G, u32 B, u32& slot, u32& tile) {
     if ((B & 7u) == 0) { const u32 x = b & 7u, k = b >> 3; slot = x + 8u * (k / G); tile = k - (k / G) * G; }
     else { slot = b / G; tile = b - slot * G; }
 }
+__device__ __forceinline__ void xcd_slot_tile(u32 G, u32 B, u32& slot, u32& tile) { xcd_slot_tile_b(blockIdx.x, G, B, slot, tile); }
 
 // ------------------------------------------------------------------------------------------------
 // a4  cv::pyrDown, CV_8UC3: 5x5 [1 4 6 4 1]^2, BORDER_REFLECT_101, (sum + 128) >> 8
@@ -132,10 +132,10 @@ __global__ __launch_bounds__(256) void k_pyrdown(const u8* __restrict__ src0, in
 // cv::pyrDown, one lane = 8 output pixels (sw % 16 == 0): the 20 source pixels 16g-2 .. 16g+17 are 60 bytes
 // at byte 10 of five aligned 16-byte blocks starting at 48 g - 16.  Vertical 1 4 6 4 1 first, on packed
 // bytes (u16 pairs, sums <= 4080), then the horizontal taps on the extracted 16-bit sums.
-__global__ __launch_bounds__(256) void k_pyrdown8(const u8* __restrict__ src0, int sw, int sh, u8* __restrict__ dst0,
+__device__ __forceinline__ void d_pyrdown8(const u32 vblock, const u8* __restrict__ src0, int sw, int sh, u8* __restrict__ dst0,
                                                    int dw, int dh, size_t slot_stride, int gblocks, int nslots) {
     u32 slot, tile;
-    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
     const u8* src = slot_ptr_s(src0, slot_stride, slot);
     u8* dst = slot_ptr_s(dst0, slot_stride, slot);
     const int ng = dw >> 3;
@@ -188,6 +188,10 @@ __global__ __launch_bounds__(256) void k_pyrdown8(const u8* __restrict__ src0, i
         }
     u32x2* out = reinterpret_cast<u32x2*>(dst + ((size_t)y * dw + 8 * g) * 3);
     out[0] = u32x2{o[0], o[1]}; out[1] = u32x2{o[2], o[3]}; out[2] = u32x2{o[4], o[5]};
+}
+__global__ __launch_bounds__(256) void k_pyrdown8(const u8* __restrict__ src0, int sw, int sh, u8* __restrict__ dst0,
+                                                   int dw, int dh, size_t slot_stride, int gblocks, int nslots) {
+    d_pyrdown8(blockIdx.x, src0, sw, sh, dst0, dw, dh, slot_stride, gblocks, nslots);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -375,10 +379,10 @@ __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4
 // -12 .. +27 around the block: the taps of byte p are bytes p-9, p-6, ..., p+9 whatever the channel) with the final
 // rounding.  The two separable passes are exact integer sums, so their order does not matter.
 #define CB_ROWS 2
-__global__ __launch_bounds__(256) void k_cblur(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
+__device__ __forceinline__ void d_cblur(const u32 vblock, const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
                                                 size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
     u32 slot, tile;
-    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
     const u8* bgr = slot_ptr_s(bgr0, in_stride, slot);
     u8* S = slot_ptr_s(s0, tmp_stride, slot);
     const int nblk = (w * 3) >> 4;
@@ -452,6 +456,10 @@ __global__ __launch_bounds__(256) void k_cblur(const u8* __restrict__ bgr0, int 
         }
         st16(S + (size_t)y * pitch + 16 * b, u32x4{o4[0], o4[1], o4[2], o4[3]});
     }
+}
+__global__ __launch_bounds__(256) void k_cblur(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
+                                                size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
+    d_cblur(blockIdx.x, bgr0, w, h, s0, in_stride, tmp_stride, gblocks, nslots);
 }
 
 // a1+a2, sliding-window form of k_cblur (the default).  Same arithmetic; what changes is how the rows reach the
@@ -615,11 +623,11 @@ __global__ __launch_bounds__(256, 2) void k_cblur_sw(const u8* __restrict__ bgr0
 // One lane = 16 pixels of a row (w % 16 == 0): rows y-1, y, y+1 of S, 48 bytes each plus the dword before
 // and after.  The vertical halves VS = S(y-1) + 2 S(y) + S(y+1) and VD + 256 = S(y+1) + 256 - S(y-1) are
 // formed on u16 pairs; window byte of pixel i (image x = 16g - 1 + i), channel c is 1 + 3i + c.
-__global__ __launch_bounds__(256) void k_corient(const u8* __restrict__ s0, int w, int h, float thr2,
+__device__ __forceinline__ void d_corient(const u32 vblock, const u8* __restrict__ s0, int w, int h, float thr2,
                                                   u8* __restrict__ qn0, float* __restrict__ mag0, size_t tmp_stride,
                                                   size_t mag_stride, int gblocks, int nslots) {
     u32 slot, tile;
-    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
     const u8* S = slot_ptr_s(s0, tmp_stride, slot);
     u8* qn = slot_ptr_s(qn0, tmp_stride, slot);
     float* mag = mag0 ? slot_ptr_s(mag0, mag_stride, slot) : nullptr;
@@ -699,15 +707,20 @@ __global__ __launch_bounds__(256) void k_corient(const u8* __restrict__ s0, int 
         for (int p = 0; p < 16; ++p) mo[p] = fmv[p];
     }
 }
+__global__ __launch_bounds__(256) void k_corient(const u8* __restrict__ s0, int w, int h, float thr2,
+                                                  u8* __restrict__ qn0, float* __restrict__ mag0, size_t tmp_stride,
+                                                  size_t mag_stride, int gblocks, int nslots) {
+    d_corient(blockIdx.x, s0, w, h, thr2, qn0, mag0, tmp_stride, mag_stride, gblocks, nslots);
+}
 
 #define CVT_ROWS 4   // output rows per lane of k_cvote
 // one lane = 16 pixels x CVT_ROWS rows (w % 16 == 0).  A pixel's label becomes a one-hot nibble counter
 // (1 << 4 label); horizontal then vertical 3-sums give the eight 4-bit counts of the 3x3 window, and
 // since at most one label can reach 5 of 9 votes, (cnt + 0x33333333) & 0x88888888 has at most one bit.
-__global__ __launch_bounds__(256) void k_cvote(const u8* __restrict__ qn0, int w, int h, u8* __restrict__ quant0,
+__device__ __forceinline__ void d_cvote(const u32 vblock, const u8* __restrict__ qn0, int w, int h, u8* __restrict__ quant0,
                                                 size_t tmp_stride, size_t out_stride, int gblocks, int nslots) {
     u32 slot, tile;
-    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
     const u8* qn = slot_ptr_s(qn0, tmp_stride, slot);
     u8* quant = slot_ptr_s(quant0, out_stride, slot);
     const int ng = w >> 4;
@@ -752,6 +765,10 @@ __global__ __launch_bounds__(256) void k_cvote(const u8* __restrict__ qn0, int w
             }
         }
     }
+}
+__global__ __launch_bounds__(256) void k_cvote(const u8* __restrict__ qn0, int w, int h, u8* __restrict__ quant0,
+                                                size_t tmp_stride, size_t out_stride, int gblocks, int nslots) {
+    d_cvote(blockIdx.x, qn0, w, h, quant0, tmp_stride, out_stride, gblocks, nslots);
 }
 
 // a2+a3 in one pass: k_corient + k_cvote for batches (S -> quant, no qn image in between).
@@ -1056,11 +1073,11 @@ __device__ __forceinline__ u32 hw_u16(const u32x4* A, int hw) {
     return (hw & 1) ? (d >> 16) : (d & 0xFFFFu);
 }
 
-__global__ __launch_bounds__(256) void k_dnormal(const u16* __restrict__ depth0, int w, int h, int dist_thr, int diff_thr,
+__device__ __forceinline__ void d_dnormal(const u32 vblock, const u16* __restrict__ depth0, int w, int h, int dist_thr, int diff_thr,
                                                   const u8* __restrict__ lut, u8* __restrict__ code0, size_t in_stride,
                                                   size_t tmp_stride, int gblocks, int nslots) {
     u32 slot, tile;
-    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
     const u16* depth = slot_ptr_s(depth0, in_stride, slot);
     u8* code = slot_ptr_s(code0, tmp_stride, slot);
     const int ng = w >> 3;
@@ -1132,12 +1149,17 @@ __global__ __launch_bounds__(256) void k_dnormal(const u16* __restrict__ depth0,
     }
     *reinterpret_cast<u32x2*>(code + (size_t)y * w + 8 * g) = u32x2{out[0], out[1]};
 }
+__global__ __launch_bounds__(256) void k_dnormal(const u16* __restrict__ depth0, int w, int h, int dist_thr, int diff_thr,
+                                                  const u8* __restrict__ lut, u8* __restrict__ code0, size_t in_stride,
+                                                  size_t tmp_stride, int gblocks, int nslots) {
+    d_dnormal(blockIdx.x, depth0, w, h, dist_thr, diff_thr, lut, code0, in_stride, tmp_stride, gblocks, nslots);
+}
 
 #define DM_ROWS 4   // output rows per lane of k_dmedian
-__global__ __launch_bounds__(256) void k_dmedian(const u8* __restrict__ code0, int w, int h, u8* __restrict__ quant0,
+__device__ __forceinline__ void d_dmedian(const u32 vblock, const u8* __restrict__ code0, int w, int h, u8* __restrict__ quant0,
                                                   size_t tmp_stride, size_t out_stride, int gblocks, int nslots) {
     u32 slot, tile;
-    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
     const u8* code = slot_ptr_s(code0, tmp_stride, slot);
     u8* quant = slot_ptr_s(quant0, out_stride, slot);
     const int ng = w >> 3;
@@ -1192,6 +1214,10 @@ __global__ __launch_bounds__(256) void k_dmedian(const u8* __restrict__ code0, i
             }
         }
     }
+}
+__global__ __launch_bounds__(256) void k_dmedian(const u8* __restrict__ code0, int w, int h, u8* __restrict__ quant0,
+                                                  size_t tmp_stride, size_t out_stride, int gblocks, int nslots) {
+    d_dmedian(blockIdx.x, code0, w, h, quant0, tmp_stride, out_stride, gblocks, nslots);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1314,7 +1340,7 @@ __global__ __launch_bounds__(256) void k_linear_memories(const u8* __restrict__ 
 // MODE 0: 8 response memories, one byte per position; 1: one spread memory; 2: 8 response memories packed
 // two positions per byte (responses are <= 4; position 2k in the low nibble of byte k) for k_scan4.
 template <int T, int SEG, int SRC_SHIFT, int MODE>
-__global__ __launch_bounds__(256) void k_lm_fast(const u8* __restrict__ q0, int qpitch, int w, int h,
+__device__ __forceinline__ void d_lm_fast(const u32 vblock, const u8* __restrict__ q0, int qpitch, int w, int h,
                                                   const u64* __restrict__ resp_tab, u8* __restrict__ lm0,
                                                   u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
                                                   int nseg, int nslots) {
@@ -1329,7 +1355,7 @@ __global__ __launch_bounds__(256) void k_lm_fast(const u8* __restrict__ q0, int 
     __shared__ u32 ho[ROWS][PD];
     __shared__ u32 sp[T][PD];
     u32 slot, tile;
-    xcd_slot_tile((u32)(nseg * (h / T)), (u32)nslots, slot, tile);
+    xcd_slot_tile_b(vblock, (u32)(nseg * (h / T)), (u32)nslots, slot, tile);
     const u8* q = slot_ptr_s(q0, q_slot_stride, slot);
     u8* lm = slot_ptr_s(lm0, lm_slot_stride, slot);
     const int tid = threadIdx.x;
@@ -1447,6 +1473,13 @@ __global__ __launch_bounds__(256) void k_lm_fast(const u8* __restrict__ q0, int 
         }
     }
 }
+template <int T, int SEG, int SRC_SHIFT, int MODE>
+__global__ __launch_bounds__(256) void k_lm_fast(const u8* __restrict__ q0, int qpitch, int w, int h,
+                                                  const u64* __restrict__ resp_tab, u8* __restrict__ lm0,
+                                                  u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
+                                                  int nseg, int nslots) {
+    d_lm_fast<T, SEG, SRC_SHIFT, MODE>(blockIdx.x, q0, qpitch, w, h, resp_tab, lm0, ori_stride, q_slot_stride, lm_slot_stride, nseg, nslots);
+}
 
 // ------------------------------------------------------------------------------------------------
 // a6-a10 for T = 2, spread memory only (level 0 of the colour-only configuration, T = {2, 8}): a streaming pass.
@@ -1517,6 +1550,38 @@ __global__ __launch_bounds__(256) void k_lm_spread2(const u8* __restrict__ q0, i
 // Workgroup -> (slot, items) mapping.  XCD_MAP: a 1-D grid whose block b is assumed to run on XCD b % 8
 // (observed round-robin dispatch; only speed depends on it): each XCD then works on one frame slot at a
 // time, so its 4 MB L2 holds that frame's 1.2 MB of linear memories + the bank instead of all slots'.
+// ------------------------------------------------------------------------------------------------
+// a3-a10 of few frames: the kernels of one dependency level in ONE launch, each on its own range of the block index
+// (LmPhaseArgs in lm_kernels.h).  A single frame is 14 dependent launches of 3-12 us otherwise, each with its own
+// dispatch and drain; here the independent ones overlap and the chain is five launches long.
+// ------------------------------------------------------------------------------------------------
+struct LmPhaseGrid { u32 nb[4]; int g[4]; };   // blocks / blocks-per-slot (or segments per band for the linear memories) of the parts
+template <int PH>
+__global__ __launch_bounds__(256) void k_phase(LmPhaseArgs a, LmPhaseGrid pg) {
+    const u32 b = blockIdx.x, e0 = pg.nb[0], e1 = e0 + pg.nb[1], e2 = e1 + pg.nb[2];
+    const size_t fs = a.slot_stride;
+    const int w1 = a.w >> 1, h1 = a.h >> 1;
+    const size_t a3_0 = ((size_t)a.w * a.h * 3 + 255) / 256 * 256, a3_1 = ((size_t)w1 * h1 * 3 + 255) / 256 * 256;   // qn behind S
+    const float thr2 = a.weak_threshold * a.weak_threshold;
+    if (PH == 1) {
+        if (b < e0) d_cblur(b, a.bgr0, a.w, a.h, a.cs0, fs, fs, pg.g[0], a.nslots);
+        else if (b < e1) d_dnormal(b - e0, a.depth, a.w, a.h, a.dist_thr, a.diff_thr, a.normal_lut, a.ds, fs, fs, pg.g[1], a.nslots);
+        else d_pyrdown8(b - e1, a.bgr0, a.w, a.h, a.bgr1, w1, h1, fs, pg.g[2], a.nslots);
+    } else if (PH == 2) {
+        if (b < e0) d_dmedian(b, a.ds, a.w, a.h, a.qd0, fs, fs, pg.g[0], a.nslots);
+        else if (b < e1) d_cblur(b - e0, a.bgr1, w1, h1, a.cs1, fs, fs, pg.g[1], a.nslots);
+        else d_corient(b - e1, a.cs0, a.w, a.h, thr2, a.cs0 + a3_0, nullptr, fs, fs, pg.g[2], a.nslots);
+    } else if (PH == 3) {
+        if (b < e0) d_cvote(b, a.cs0 + a3_0, a.w, a.h, a.qc0, fs, fs, pg.g[0], a.nslots);
+        else if (b < e1) d_corient(b - e0, a.cs1, w1, h1, thr2, a.cs1 + a3_1, nullptr, fs, fs, pg.g[1], a.nslots);
+        else if (b < e2) d_lm_fast<5, 128, 0, 1>(b - e1, a.qd0, a.w, a.w, a.h, a.resp_tab, a.lm_d0, 0u, fs, fs, pg.g[2], a.nslots);
+        else d_lm_fast<8, 40, 1, 2>(b - e2, a.qd0, a.w, w1, h1, a.resp_tab, a.lm_d1, a.ori_stride1, fs, fs, pg.g[3], a.nslots);
+    } else {
+        if (b < e0) d_cvote(b, a.cs1 + a3_1, w1, h1, a.qc1, fs, fs, pg.g[0], a.nslots);
+        else d_lm_fast<5, 128, 0, 1>(b - e0, a.qc0, a.w, a.w, a.h, a.resp_tab, a.lm_c0, 0u, fs, fs, pg.g[1], a.nslots);
+    }
+}
+
 template <int UNROLL, bool XCD_MAP>
 __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
     const int lane = threadIdx.x & 63;
@@ -2104,7 +2169,7 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
         xcd_slot_tile((u32)a.blocks_per_slot, (u32)a.nslots, slot, tile);
         total = slot_ptr_s(a.hdr, a.aux_slot_stride, slot)->cand_count;
         if (total > a.cand_cap) total = a.cand_cap;
-        if (tile * 8u >= total) return;   // nothing to do for this workgroup (a wave takes two entries): leave before building the table
+        if (tile * (total <= (u32)a.blocks_per_slot * 4u ? 4u : 8u) >= total) return;   // nothing to do for this workgroup (a wave takes one or two entries): leave before building the table
     }
     {
         const u8* sl = reinterpret_cast<const u8*>(a.sim_lut);   // [ori][lo 16 B | hi 16 B]
@@ -2135,6 +2200,9 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
                 }
             }
         }
+    } else if (total <= nwaves) {
+        // few frames: the list fits one round of waves, an entry per wave finishes sooner than pairs on half of them
+        if (wave0 < total) refine_one<LAST>(a, slot, wave0, resp, lane);
     } else {
         for (u32 i = 2u * wave0; i < total; i += 2u * nwaves) {
             if (i + 1 < total) refine_pair<LAST>(a, slot, i, resp, lane);
@@ -2613,6 +2681,44 @@ void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, 
     if (src_shift) { if (spread_only) LMK_LAUNCH(1, true); else LMK_LAUNCH(1, false); }
     else           { if (spread_only) LMK_LAUNCH(0, true); else LMK_LAUNCH(0, false); }
 #undef LMK_LAUNCH
+}
+
+bool lmk_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0, int mode1, bool lut_onehot) {
+    // exactly the shapes the streaming kernels and k_lm_fast<5, 128, ., 1> / <8, 40, ., 2> take
+    if (T0 != 5 || T1 != 8 || mode0 != 1 || mode1 != 2) return false;
+    if ((a.w % 32) != 0 || (a.h % 2) != 0 || (a.slot_stride % 16) != 0 || a.nslots < 1) return false;
+    const int w1 = a.w / 2, h1 = a.h / 2;
+    if ((a.w / 5) % 4 != 0 || !lmk_nibble_supported(w1, h1, 8) || (w1 / 8) % 4 != 0) return false;
+    auto al = [](const void* p, uintptr_t m) { return ((uintptr_t)p & (m - 1)) == 0; };
+    if (!al(a.bgr0, 16) || !al(a.bgr1, 16) || !al(a.cs0, 16) || !al(a.cs1, 16) || !al(a.qc0, 16) || !al(a.qc1, 16)) return false;
+    if (a.depth && (!lut_onehot || !al(a.depth, 16) || !al(a.ds, 8) || !al(a.qd0, 8))) return false;
+    return true;
+}
+
+void lmk_preprocess_phases(hipStream_t s, const LmPhaseArgs& a) {
+    const int w = a.w, h = a.h, w1 = w / 2, h1 = h / 2, n = a.nslots;
+    const bool dep = a.depth != nullptr;
+    auto per = [](int lanes) { return (lanes + 255) / 256; };
+    const int g_blur0 = per((w * 3 / 16) * ((h + CB_ROWS - 1) / CB_ROWS)), g_blur1 = per((w1 * 3 / 16) * ((h1 + CB_ROWS - 1) / CB_ROWS));
+    const int g_ori0 = per((w / 16) * h), g_ori1 = per((w1 / 16) * h1);
+    const int g_vote0 = per((w / 16) * ((h + CVT_ROWS - 1) / CVT_ROWS)), g_vote1 = per((w1 / 16) * ((h1 + CVT_ROWS - 1) / CVT_ROWS));
+    const int g_pyr = per((w1 / 8) * h1), g_nrm = per((w / 8) * h), g_med = per((w / 8) * ((h + DM_ROWS - 1) / DM_ROWS));
+    const int seg0 = (w / 5 + 127) / 128, seg1 = (w1 / 8 + 39) / 40;                 // segments per band of the linear memories
+    const u32 b_lm0 = (u32)(seg0 * (h / 5) * n), b_lm1 = (u32)(seg1 * (h1 / 8) * n);
+    auto launch = [&](auto kern, const LmPhaseGrid& pg) {
+        const u32 nb = pg.nb[0] + pg.nb[1] + pg.nb[2] + pg.nb[3];
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s, a, pg);
+    };
+    LmPhaseGrid p1 = {{(u32)(g_blur0 * n), dep ? (u32)(g_nrm * n) : 0u, (u32)(g_pyr * n), 0u}, {g_blur0, g_nrm, g_pyr, 0}};
+    launch(k_phase<1>, p1);
+    LmPhaseGrid p2 = {{dep ? (u32)(g_med * n) : 0u, (u32)(g_blur1 * n), (u32)(g_ori0 * n), 0u}, {g_med, g_blur1, g_ori0, 0}};
+    launch(k_phase<2>, p2);
+    LmPhaseGrid p3 = {{(u32)(g_vote0 * n), (u32)(g_ori1 * n), dep ? b_lm0 : 0u, dep ? b_lm1 : 0u}, {g_vote0, g_ori1, seg0, seg1}};
+    launch(k_phase<3>, p3);
+    LmPhaseGrid p4 = {{(u32)(g_vote1 * n), b_lm0, 0u, 0u}, {g_vote1, seg0, 0, 0}};
+    launch(k_phase<4>, p4);
+    hipLaunchKernelGGL((k_lm_fast<8, 40, 0, 2>), dim3(b_lm1), dim3(256), 0, s, a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1,
+                       a.slot_stride, a.slot_stride, seg1, n);
 }
 
 void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
