@@ -385,7 +385,7 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
         auto mode = [&](int l) { return d->geom[l].spread_only ? 1 : d->geom[l].nibble ? 2 : 0; };
         if (M <= 2 && d->lw[1] * 2 == d->lw[0] && d->lh[1] * 2 == d->lh[0] &&
             lmk_phases_supported(pa, d->geom[0].T, d->geom[1].T, mode(0), mode(1), M == 2 ? normal_lut_onehot(d) : true)) {
-            lmk_preprocess_phases(d->stream, pa);
+            lmk_preprocess_phases(d->stream, pa, d->geom[0].T);
             return;
         }
     }

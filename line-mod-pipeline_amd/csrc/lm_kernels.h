@@ -116,7 +116,7 @@ struct LmHsvRange { int lo[3], hi[3]; };
 void lmk_hsv_mask(hipStream_t s, const u8* bgr, int w, int h, const LmHsvRange& rg, const int* divtab, u32* mask, int wpr,
                   size_t in_stride, size_t mask_stride, int nslots);
 // a3-a10 of FEW frames as five launches instead of fourteen (single-frame latency; the default two-level RGB-D / colour
-// pyramid with T = {5, 8} only).  Every launch runs the independent kernels of one dependency level side by side, each
+// pyramid with T = {5, 8}, or {2, 8} without depth, only).  Every launch runs the independent kernels of one dependency level side by side, each
 // on its own range of the block index:
 //   1  blur(level 0)            | depth normals          | pyrDown(level 0 -> 1)
 //   2  median of the normals    | blur(level 1)          | orientation(level 0)
@@ -135,7 +135,7 @@ struct LmPhaseArgs {
     size_t slot_stride; int nslots;
 };
 bool lmk_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0, int mode1, bool lut_onehot);
-void lmk_preprocess_phases(hipStream_t s, const LmPhaseArgs& a);
+void lmk_preprocess_phases(hipStream_t s, const LmPhaseArgs& a, int T0);
 
 struct LmHullArgs {
     const LmOutMatch* matches; u32 n;

@@ -1489,10 +1489,10 @@ __global__ __launch_bounds__(256) void k_lm_fast(const u8* __restrict__ q0, int 
 // workgroups with three barriers each per 1280 x 960 frame (224 us per 128 frames); this moves the same 2.4 MB in
 // a fraction of that.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lm_spread2(const u8* __restrict__ q0, int qpitch, int w, int h, u8* __restrict__ lm0,
+__device__ __forceinline__ void d_lm_spread2(const u32 vblock, const u8* __restrict__ q0, int qpitch, int w, int h, u8* __restrict__ lm0,
                                                      size_t q_slot_stride, size_t lm_slot_stride, int gblocks, int nslots) {
     u32 slot, tile;
-    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
     const u8* q = slot_ptr_s(q0, q_slot_stride, slot);
     u8* lm = slot_ptr_s(lm0, lm_slot_stride, slot);
     const int ng = w >> 5, W = w >> 1;
@@ -1534,6 +1534,10 @@ __global__ __launch_bounds__(256) void k_lm_spread2(const u8* __restrict__ q0, i
         }
     }
 }
+__global__ __launch_bounds__(256) void k_lm_spread2(const u8* __restrict__ q0, int qpitch, int w, int h, u8* __restrict__ lm0,
+                                                     size_t q_slot_stride, size_t lm_slot_stride, int gblocks, int nslots) {
+    d_lm_spread2(blockIdx.x, q0, qpitch, w, h, lm0, q_slot_stride, lm_slot_stride, gblocks, nslots);
+}
 
 // ------------------------------------------------------------------------------------------------
 // a11-a13  HOT KERNEL.  One wave per (template, chunk of 1008 positions): lane l < 63 owns positions
@@ -1556,7 +1560,7 @@ __global__ __launch_bounds__(256) void k_lm_spread2(const u8* __restrict__ q0, i
 // dispatch and drain; here the independent ones overlap and the chain is five launches long.
 // ------------------------------------------------------------------------------------------------
 struct LmPhaseGrid { u32 nb[4]; int g[4]; };   // blocks / blocks-per-slot (or segments per band for the linear memories) of the parts
-template <int PH>
+template <int PH, int T0>
 __global__ __launch_bounds__(256) void k_phase(LmPhaseArgs a, LmPhaseGrid pg) {
     const u32 b = blockIdx.x, e0 = pg.nb[0], e1 = e0 + pg.nb[1], e2 = e1 + pg.nb[2];
     const size_t fs = a.slot_stride;
@@ -1578,7 +1582,8 @@ __global__ __launch_bounds__(256) void k_phase(LmPhaseArgs a, LmPhaseGrid pg) {
         else d_lm_fast<8, 40, 1, 2>(b - e2, a.qd0, a.w, w1, h1, a.resp_tab, a.lm_d1, a.ori_stride1, fs, fs, pg.g[3], a.nslots);
     } else {
         if (b < e0) d_cvote(b, a.cs1 + a3_1, w1, h1, a.qc1, fs, fs, pg.g[0], a.nslots);
-        else d_lm_fast<5, 128, 0, 1>(b - e0, a.qc0, a.w, a.w, a.h, a.resp_tab, a.lm_c0, 0u, fs, fs, pg.g[1], a.nslots);
+        else if (T0 == 5) d_lm_fast<5, 128, 0, 1>(b - e0, a.qc0, a.w, a.w, a.h, a.resp_tab, a.lm_c0, 0u, fs, fs, pg.g[1], a.nslots);
+        else d_lm_spread2(b - e0, a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, pg.g[1], a.nslots);     // T0 == 2 (colour only)
     }
 }
 
@@ -2684,18 +2689,20 @@ void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, 
 }
 
 bool lmk_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0, int mode1, bool lut_onehot) {
-    // exactly the shapes the streaming kernels and k_lm_fast<5, 128, ., 1> / <8, 40, ., 2> take
-    if (T0 != 5 || T1 != 8 || mode0 != 1 || mode1 != 2) return false;
+    // exactly the shapes the streaming kernels and k_lm_fast<5, 128, ., 1> (or k_lm_spread2) / <8, 40, ., 2> take
+    if ((T0 != 5 && !(T0 == 2 && !a.depth)) || T1 != 8 || mode0 != 1 || mode1 != 2) return false;
     if ((a.w % 32) != 0 || (a.h % 2) != 0 || (a.slot_stride % 16) != 0 || a.nslots < 1) return false;
     const int w1 = a.w / 2, h1 = a.h / 2;
-    if ((a.w / 5) % 4 != 0 || !lmk_nibble_supported(w1, h1, 8) || (w1 / 8) % 4 != 0) return false;
+    if (!lmk_nibble_supported(w1, h1, 8) || (w1 / 8) % 4 != 0) return false;
     auto al = [](const void* p, uintptr_t m) { return ((uintptr_t)p & (m - 1)) == 0; };
+    if (T0 == 5 && (a.w / 5) % 4 != 0) return false;
+    if (T0 == 2 && (!al(a.lm_c0, 16) || (((size_t)(a.w / 2) * (a.h / 2)) % 16) != 0)) return false;
     if (!al(a.bgr0, 16) || !al(a.bgr1, 16) || !al(a.cs0, 16) || !al(a.cs1, 16) || !al(a.qc0, 16) || !al(a.qc1, 16)) return false;
     if (a.depth && (!lut_onehot || !al(a.depth, 16) || !al(a.ds, 8) || !al(a.qd0, 8))) return false;
     return true;
 }
 
-void lmk_preprocess_phases(hipStream_t s, const LmPhaseArgs& a) {
+void lmk_preprocess_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
     const int w = a.w, h = a.h, w1 = w / 2, h1 = h / 2, n = a.nslots;
     const bool dep = a.depth != nullptr;
     auto per = [](int lanes) { return (lanes + 255) / 256; };
@@ -2703,20 +2710,21 @@ void lmk_preprocess_phases(hipStream_t s, const LmPhaseArgs& a) {
     const int g_ori0 = per((w / 16) * h), g_ori1 = per((w1 / 16) * h1);
     const int g_vote0 = per((w / 16) * ((h + CVT_ROWS - 1) / CVT_ROWS)), g_vote1 = per((w1 / 16) * ((h1 + CVT_ROWS - 1) / CVT_ROWS));
     const int g_pyr = per((w1 / 8) * h1), g_nrm = per((w / 8) * h), g_med = per((w / 8) * ((h + DM_ROWS - 1) / DM_ROWS));
-    const int seg0 = (w / 5 + 127) / 128, seg1 = (w1 / 8 + 39) / 40;                 // segments per band of the linear memories
-    const u32 b_lm0 = (u32)(seg0 * (h / 5) * n), b_lm1 = (u32)(seg1 * (h1 / 8) * n);
+    // linear memories: segments per band (k_lm_fast); for T0 = 2 the streaming kernel's blocks per slot instead
+    const int seg0 = T0 == 5 ? (w / 5 + 127) / 128 : per((w / 32) * (h / 2)), seg1 = (w1 / 8 + 39) / 40;
+    const u32 b_lm0 = T0 == 5 ? (u32)(seg0 * (h / 5) * n) : (u32)(seg0 * n), b_lm1 = (u32)(seg1 * (h1 / 8) * n);
     auto launch = [&](auto kern, const LmPhaseGrid& pg) {
         const u32 nb = pg.nb[0] + pg.nb[1] + pg.nb[2] + pg.nb[3];
         hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s, a, pg);
     };
     LmPhaseGrid p1 = {{(u32)(g_blur0 * n), dep ? (u32)(g_nrm * n) : 0u, (u32)(g_pyr * n), 0u}, {g_blur0, g_nrm, g_pyr, 0}};
-    launch(k_phase<1>, p1);
+    launch(k_phase<1, 5>, p1);
     LmPhaseGrid p2 = {{dep ? (u32)(g_med * n) : 0u, (u32)(g_blur1 * n), (u32)(g_ori0 * n), 0u}, {g_med, g_blur1, g_ori0, 0}};
-    launch(k_phase<2>, p2);
+    launch(k_phase<2, 5>, p2);
     LmPhaseGrid p3 = {{(u32)(g_vote0 * n), (u32)(g_ori1 * n), dep ? b_lm0 : 0u, dep ? b_lm1 : 0u}, {g_vote0, g_ori1, seg0, seg1}};
-    launch(k_phase<3>, p3);
+    launch(k_phase<3, 5>, p3);
     LmPhaseGrid p4 = {{(u32)(g_vote1 * n), b_lm0, 0u, 0u}, {g_vote1, seg0, 0, 0}};
-    launch(k_phase<4>, p4);
+    if (T0 == 5) launch(k_phase<4, 5>, p4); else launch(k_phase<4, 2>, p4);
     hipLaunchKernelGGL((k_lm_fast<8, 40, 0, 2>), dim3(b_lm1), dim3(256), 0, s, a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1,
                        a.slot_stride, a.slot_stride, seg1, n);
 }

@@ -180,3 +180,37 @@ def test_batch_upload_one_strided_transfer(lm, orc, synth, color_only):
             assert_matches_equal(out[k, :cnt[k]], exp[f])
     d.close()
     pb.close()
+
+
+@pytest.mark.parametrize("color_only", [False, True])
+def test_few_frames_take_one_launch_per_dependency_level(lm, orc, synth, color_only):
+    """Calls of fewer than 16 frames run a3-a10 as five launches, each holding the independent kernels of one dependency
+    level (LM_TUNE_PHASE_MAX_SLOTS, default 15), instead of the plain sequence: both must give the oracle's lists, for
+    the RGB-D pyramid T = {5, 8} and the colour-only one T = {2, 8}, at every batch size on either side of 8."""
+    M = 1 if color_only else 2
+    d = lm.Detector(color_only=color_only, width=W, height=H, frame_slots=12)
+    o = orc.Detector(color_only=color_only)
+    frames = [synth.make_frame(W, H, seed=700 + i) for i in range(5)]
+    o.prepare(frames[0][0], None if color_only else frames[0][1])
+    q = {(l, m): o.stage(0, l, m).reshape(H >> l, W >> l) for l in range(2) for m in range(M)}
+    descs, feats, _ = synth.make_bank(100, M, 2, seed=77, quantized=q, crop_fraction=0.3, frame_size=(W, H), T0=d.get_T(0))
+    d.add_class("c", descs, feats)
+    o.add_class("c", descs, feats)
+    exp = [o.match(b, None if color_only else dp, THR, threads=8) for b, dp in frames]
+    assert sum(len(e) for e in exp) > 0
+    for k in range(12):
+        b, dp = frames[(2 * k + 1) % 5]
+        d.upload_frame(k, b, None if color_only else dp)
+    for phases in (15, 0):
+        d.set_tuning(lm.TUNE_PHASE_MAX_SLOTS, phases)
+        for n in (1, 2, 3, 8, 12):
+            out, cnt = d.match_batch(n, THR, 0)
+            for k in range(n):
+                try:
+                    assert_matches_equal(out[k, :cnt[k]], exp[(2 * k + 1) % 5])
+                except AssertionError as e:
+                    raise AssertionError("phases %d, batch of %d, slot %d: %s" % (phases, n, k, str(e)[:80]))
+        b, dp = frames[4]
+        assert_matches_equal(d.match(b, None if color_only else dp, THR, 0), exp[4])     # (lm_match goes through slot 0)
+        d.upload_frame(0, frames[1][0], None if color_only else frames[1][1])
+    d.close()
