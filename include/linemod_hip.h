@@ -136,7 +136,9 @@ int lm_get_template(const lm_detector* det, int class_idx, int template_id, int 
  * Host frame in, sorted unique matches out (total order SURVEY.md A.9: similarity desc, template_id
  * asc, class asc, y asc, x asc; adjacent-unique on (x, y, similarity, class)).  *n_out receives the
  * number of matches found; if it exceeds `cap` only the first cap are written and LM_ERR_OVERFLOW
- * is returned.  With shard_size > 1 only this shard's templates are searched (ids stay global). */
+ * is returned.  With shard_size > 1 only this shard's templates are searched (ids stay global).
+ * Frames that lie inside a block from lm_host_alloc (pinned memory; e.g. a cv::Mat constructed over it) go to the
+ * device without the staging copy (one transfer when the depth image directly follows the colour image). */
 int lm_match(lm_detector* det, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
              float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 

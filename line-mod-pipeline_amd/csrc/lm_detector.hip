@@ -15,6 +15,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <mutex>
 
 #include "../../include/linemod_hip.h"
 #include "lm_common.h"
@@ -704,14 +705,16 @@ int upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride
     const int cs = slot % d->n_copy_streams;
     hipStream_t st = inline_stream ? inline_stream : d->copy_stream[cs];
     const size_t bgr_bytes = (size_t)c.width * c.height * 3;
-    if (pinned && !inline_stream && c.num_modalities == 2 && bgr_stride == (size_t)c.width * 3 && depth_stride == (size_t)c.width * 2 &&
+    if (pinned && c.num_modalities == 2 && bgr_stride == (size_t)c.width * 3 && depth_stride == (size_t)c.width * 2 &&
         reinterpret_cast<const u8*>(depth) == bgr + bgr_bytes) {
         // [colour | depth] contiguous on the host, as in the frame arena: one DMA transfer
         HIP_TRY(hipMemcpyAsync(d->bgr(slot, 0), bgr, bgr_bytes + (size_t)c.width * c.height * 2, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipEventRecord(s.ev_bgr, st));
-        HIP_TRY(hipEventRecord(s.ev_up, st));
-        s.up_stream = cs;
-        s.up_seq = d->up_seq_next[cs]++;
+        if (!inline_stream) {
+            HIP_TRY(hipEventRecord(s.ev_bgr, st));
+            HIP_TRY(hipEventRecord(s.ev_up, st));
+            s.up_stream = cs;
+            s.up_seq = d->up_seq_next[cs]++;
+        }
         s.has_frame = true;
         return LM_OK;
     }
@@ -1066,6 +1069,10 @@ int lm_upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_str
     return upload_frame(d, slot, bgr, bgr_stride, depth, depth_stride);
 }
 
+struct PinnedBlock { const u8* p; size_t bytes; };
+static std::mutex g_pinned_mu;
+static std::vector<PinnedBlock> g_pinned;      // blocks handed out by lm_host_alloc
+
 int lm_upload_frame_pinned(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
                            size_t depth_stride) {
     int rc;
@@ -1121,10 +1128,22 @@ int lm_host_alloc(size_t bytes, void** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(LM_ERR_NO_DEVICE, "no HIP device available: pinned host memory needs the HIP runtime");
     HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    {
+        std::lock_guard<std::mutex> g(g_pinned_mu);
+        g_pinned.push_back({reinterpret_cast<const u8*>(*out), bytes});
+    }
     return LM_OK;
 }
 
-void lm_host_free(void* p) { if (p) (void)hipHostFree(p); }
+void lm_host_free(void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_pinned_mu);
+        for (size_t i = 0; i < g_pinned.size(); ++i)
+            if (g_pinned[i].p == p) { g_pinned.erase(g_pinned.begin() + (long)i); break; }
+    }
+    (void)hipHostFree(p);
+}
 
 int lm_set_stage_chunks(lm_detector* d, int chunks) {
     if (!d || chunks < 1 || chunks > 64) return fail(LM_ERR_INVALID, "bad argument");
@@ -1156,6 +1175,15 @@ int lm_match_slot(lm_detector* d, int slot, float threshold, int class_idx, lm_m
     return collect_slot(d, slot, out, cap, n_out);
 }
 
+// [p, p + bytes) inside a block from lm_host_alloc?  (A table of our own: asking the runtime about a pageable pointer,
+// hipPointerGetAttributes, costs 10-20 us per call -- measured -- on the path this is meant to shorten.)
+static bool is_pinned_host(const void* p, size_t bytes) {
+    std::lock_guard<std::mutex> g(g_pinned_mu);
+    for (const PinnedBlock& b : g_pinned)
+        if (reinterpret_cast<const u8*>(p) >= b.p && reinterpret_cast<const u8*>(p) + bytes <= b.p + b.bytes) return true;
+    return false;
+}
+
 int lm_match(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
              float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out) {
     int rc;
@@ -1164,7 +1192,11 @@ int lm_match(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16
     if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     // mode 1: copy stream; the colour chains wait for the colour copy only, the depth chain for the depth copy.
     // mode 0: copies on the compute stream itself, in order with the kernels (no cross-stream hop)
-    if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride, false, d->match_upload_mode ? nullptr : d->stream))) return rc;
+    // frames that already live in pinned host memory (lm_host_alloc, hipHostMalloc, hipHostRegister) skip the staging copy
+    const size_t hh = (size_t)d->cfg.height;
+    const bool pinned = bgr && is_pinned_host(bgr, (bgr_stride ? bgr_stride : (size_t)d->cfg.width * 3) * hh) &&
+                        (d->cfg.num_modalities < 2 || (depth && is_pinned_host(depth, (depth_stride ? depth_stride : (size_t)d->cfg.width * 2) * hh)));
+    if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride, pinned, d->match_upload_mode ? nullptr : d->stream))) return rc;
     if ((rc = run_match(d, 0, 1, threshold, class_idx))) return rc;
     return collect_slot(d, 0, out, cap, n_out);
 }

@@ -214,3 +214,19 @@ def test_few_frames_take_one_launch_per_dependency_level(lm, orc, synth, color_o
         assert_matches_equal(d.match(b, None if color_only else dp, THR, 0), exp[4])     # (lm_match goes through slot 0)
         d.upload_frame(0, frames[1][0], None if color_only else frames[1][1])
     d.close()
+
+
+def test_lm_match_takes_pinned_frames_without_staging(lm, orc, synth):
+    """lm_match recognises frames inside blocks from lm_host_alloc: they go to the device in one DMA transfer without
+    the staging copy, pageable memory goes through the staging buffer -- same lists."""
+    d, frames, exp = _setup(lm, orc, synth, n_frames=3)
+    pb = lm.PinnedBuffer(3 * W * H * 5)
+    for k, (b, dp) in enumerate(frames):
+        pc = pb.view(np.uint8, (H, W, 3), offset=k * W * H * 5)
+        pd = pb.view(np.uint16, (H, W), offset=k * W * H * 5 + W * H * 3)
+        pc[...] = b; pd[...] = dp
+        assert_matches_equal(d.match(pc, pd, THR, 0), exp[k])              # contiguous [colour | depth]: one transfer
+        assert_matches_equal(d.match(b, dp, THR, 0), exp[k])               # pageable
+        assert_matches_equal(d.match(pc, dp, THR, 0), exp[k])              # mixed: staged
+    d.close()
+    pb.close()

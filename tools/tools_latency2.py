@@ -33,8 +33,21 @@ for color_only in (False, True):
             b, dp = frames[1 + k % 7]
             d.match(b, None if color_only else dp, 80.0, 0)
         t_host = (time.perf_counter() - t) / 150
-        line = "%s phases<=%d: resident frame %.0f us, host frame in (lm_match) %.0f us" % (
-            "colour-only" if color_only else "RGB-D", phase, t_slot * 1e6, t_host * 1e6)
+        pb = lm.PinnedBuffer(7 * W * H * 5)
+        pf = []
+        for k in range(7):
+            pc = pb.view(np.uint8, (H, W, 3), offset=k * W * H * 5); pd = pb.view(np.uint16, (H, W), offset=k * W * H * 5 + W * H * 3)
+            pc[...] = frames[1 + k][0]; pd[...] = frames[1 + k][1]
+            pf.append((pc, pd))
+        for _ in range(10):
+            d.match(pf[0][0], None if color_only else pf[0][1], 80.0, 0)
+        t = time.perf_counter()
+        for k in range(150):
+            b, dp = pf[k % 7]
+            d.match(b, None if color_only else dp, 80.0, 0)
+        t_pin = (time.perf_counter() - t) / 150
+        line = "%s phases<=%d: resident frame %.0f us, host frame in (lm_match) %.0f us, from pinned memory %.0f us" % (
+            "colour-only" if color_only else "RGB-D", phase, t_slot * 1e6, t_host * 1e6, t_pin * 1e6)
         for nb in (2, 4, 8, 12):
             for _ in range(5):
                 d.match_batch(nb, 80.0, 0)
