@@ -11,7 +11,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 det = lm.Detector(color_only=False)
 t0 = time.time()
-n_stage = n_match = n_scan = 0
+n_stage = n_match = n_scan = n_batch = 0
 
 
 def rand_bgr(h, w):
@@ -42,12 +42,15 @@ while time.time() - t0 < budget * 0.5:
     h = int(rng.integers(8, 130))
     bgr = rand_bgr(h, w)
     thr = float(rng.choice([10.0, 0.0, 30.0, 200.0]))
-    assert np.array_equal(det.stage_color_quantize(bgr, thr), orc.color_quantize(bgr, thr)), ("colour", h, w, thr)
+    kb, kg = int(rng.integers(0, 3)), int(rng.integers(0, 3))      # blur / gradient kernels: by batch size, few-frame, batch
+    det.set_tuning(lm.TUNE_CBLUR_VARIANT, kb); det.set_tuning(lm.TUNE_CGRAD_VARIANT, kg)
+    assert np.array_equal(det.stage_color_quantize(bgr, thr), orc.color_quantize(bgr, thr)), ("colour", h, w, thr, kb, kg)
     if h % 2 == 0 and w % 2 == 0 and h >= 4:
         assert np.array_equal(det.stage_pyrdown(bgr), orc.pyrdown(bgr)), ("pyrdown", h, w)
     dep = rand_depth(h, w)
     assert np.array_equal(det.stage_depth_quantize(dep), orc.depth_quantize(dep)), ("depth", h, w)
     n_stage += 1
+det.set_tuning(lm.TUNE_CBLUR_VARIANT, 0); det.set_tuning(lm.TUNE_CGRAD_VARIANT, 0)
 det.close()
 
 while time.time() - t0 < budget:
@@ -57,7 +60,9 @@ while time.time() - t0 < budget:
     w, h = unit * int(rng.integers(1, 1 + 640 // unit)), unit * int(rng.integers(1, 1 + 480 // unit))
     w, h = max(w, 4 * unit), max(h, 4 * unit)
     try:
-        d = lm.Detector(lm.default_config(color_only=color_only, width=w, height=h, T=T, flags=int(rng.integers(0, 2))))
+        nb = int(rng.choice([1, 1, 3, 8, 16, 19]))               # frames per call: phase launches below 16, batch kernels from 16
+        d = lm.Detector(lm.default_config(color_only=color_only, width=w, height=h, T=T, flags=int(rng.integers(0, 2)),
+                                          frame_slots=max(nb, 2)))
     except lm.LinemodError:
         continue
     o = orc.Detector(color_only=color_only, T=T)
@@ -78,6 +83,14 @@ while time.time() - t0 < budget:
     got = d.match(bgr, None if color_only else depth, thr, cap=1 << 18)
     exp = o.match(bgr, None if color_only else depth, thr, threads=8, cap=1 << 18)
     assert got.tobytes() == exp.tobytes(), ("match", color_only, T, w, h, n, thr, variant, len(got), len(exp))
+    if nb > 1:
+        d.set_tuning(lm.TUNE_PHASE_MAX_SLOTS, int(rng.choice([15, 0])))
+        for k in range(nb):
+            d.upload_frame(k, bgr, None if color_only else depth)
+        outb, cntb = d.match_batch(nb, thr, 0, cap_per_frame=max(len(exp), 1))
+        for k in range(nb):
+            assert cntb[k] == len(exp) and outb[k, :cntb[k]].tobytes() == exp.tobytes(), ("batch", color_only, T, w, h, n, thr, nb, k)
+        n_batch += 1
     # a11-a13 alone: the scan kernel's candidate list, record by record
     d.upload_frame(1, bgr, None if color_only else depth)
     d.prepare_slot(1)
@@ -85,5 +98,5 @@ while time.time() - t0 < budget:
     d.close()
     n_match += 1
     n_scan += 1
-print("fuzz ok: %d stage rounds, %d whole matches, %d scan candidate lists in %.0f s (seed %s)" % (
-    n_stage, n_match, n_scan, time.time() - t0, sys.argv[2] if len(sys.argv) > 2 else "1"))
+print("fuzz ok: %d stage rounds, %d whole matches, %d scan candidate lists, %d multi-frame calls in %.0f s (seed %s)" % (
+    n_stage, n_match, n_scan, n_batch, time.time() - t0, sys.argv[2] if len(sys.argv) > 2 else "1"))
