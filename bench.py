@@ -83,6 +83,8 @@ class Runner:
         det.add_class("synthetic.ply", self.descs, self.feats)
         if args.no_prune:
             det.set_scan_variant(8)
+        elif args.scan_variant:
+            det.set_scan_variant(args.scan_variant)
         for i, (bgr, depth) in enumerate(self.frames):
             det.upload_frame(i, bgr, depth if M == 2 else None)
         det.upload_wait(-1)
@@ -231,6 +233,7 @@ def main():
     ap.add_argument("--threshold", type=float, default=80.0)
     ap.add_argument("--gather-cap", type=int, default=0, help="lm_comm_init recs_per_frame_cap (0 = 256)")
     ap.add_argument("--byte-responses", action="store_true", help="LM_FLAG_BYTE_RESPONSES: byte scan kernel (A/B)")
+    ap.add_argument("--scan-variant", type=int, default=0, help="A/B knob: features per load block of the scan (0: 6, 1: 12, 2: 3)")
     ap.add_argument("--no-prune", action="store_true",
                     help="exhaustive similarity scan: every feature of every template at every position, even where the "
                          "threshold is already out of reach (scan variant bit 3; A/B of the exact pruning)")

@@ -1692,8 +1692,11 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
 // Exact pruning (PRUNE): a position becomes a candidate only if its total exceeds the raw threshold, and a feature adds
 // at most 4.  So once, for EVERY position a wave holds (1016 positions of two frames), partial sum + 4 x (in-bounds
 // features still to come) <= threshold, none of them can become a candidate and the wave stops loading.  The test is
-// made in the middle and at the end of every modality's list: a packed-u16 max over the lane's 32 partial sums, one
-// compare, one ballot -- wave-uniform, so no lane ever diverges.  The candidate list is identical with and without
+// made after every block of FB features, from the first block at which even a partial sum of 0 would be out of reach
+// (a scalar compare), and at the end of every modality's list: a packed-u16 max over the lane's 32 partial sums, one
+// compare, one ballot -- wave-uniform, so no lane ever diverges.  (The L1, not the vector ALU, bounds this kernel: the
+// tests ride in its shadow.  r02: tests only at the middle and the end of a list kept 54 % / 59 % of the loads of
+// configs 2 / 3, every block 50 % / 43 %.)  The candidate list is identical with and without
 // it (tests/test_gpu_match.py::test_scan_pruning_is_exact); at threshold 80 most templates stop after half their
 // features.  a.stat (optional): [0] += features loaded, [1] += features an unpruned scan would load, per wave.
 template <int FB, bool XCD_MAP, bool PRUNE>
@@ -1728,6 +1731,8 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
     int f_in_all = 0;                                      // in-bounds features of all modalities
     for (int m = 0; m < a.M; ++m) f_in_all += (cnt >> (8 + 8 * m)) & 0xFF;
     int f_done = 0;                                        // features loaded so far (all modalities)
+    // (Pruning the two frames of a wave separately -- the half whose frame is out of reach leaves the exec mask of the
+    // loads -- was measured in r02: 3-6 % fewer loads, 4-8 % MORE time; the test is per wave.)
     bool pruned = false;
     for (int m = 0; m < a.M && !pruned; ++m) {
         const u32* offs = a.scan_off + ((size_t)ti * a.M + m) * a.fpad;
@@ -1757,11 +1762,11 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
         }
         const int F = (cnt >> (8 + 8 * m)) & 0xFF;        // in-bounds features of this modality
         // first block boundary at or past the middle of the list: the mid-list test
-        const int half = PRUNE ? ((F / 2 + FB - 1) / FB) * FB : -1;
         int f = 0;
         for (; f + FB <= F; f += FB) {
             LM_SCAN4_BLOCK(FB)
-            if (PRUNE && f + FB == half && half < F) {
+            // (a scalar test first: while even a partial sum of 0 could still reach the threshold, nothing can be pruned)
+            if (PRUNE && f + FB < F && 4 * (f_in_all - f_done - (f + FB)) <= thr) {
                 // largest partial sum of the lane: t (earlier modalities) + this modality's byte lanes
                 u32 mx = 0;
 #pragma unroll
@@ -1771,7 +1776,7 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
                     mx = pk_max_u16(mx, pk_max_u16(pk_max_u16(s0, s1), pk_max_u16(s2, s3)));
                 }
                 const int best = (int)max(mx & 0xFFFFu, mx >> 16);
-                if (!__any(best + 4 * (f_in_all - f_done - half) > thr)) { f_done += half; pruned = true; break; }
+                if (!__any(best + 4 * (f_in_all - f_done - (f + FB)) > thr)) { f_done += f + FB; pruned = true; break; }
             }
         }
         if (pruned) break;
