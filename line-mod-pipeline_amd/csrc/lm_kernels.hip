@@ -1767,6 +1767,20 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
             LM_SCAN4_BLOCK(FB)
             // (a scalar test first: while even a partial sum of 0 could still reach the threshold, nothing can be pruned)
             if (PRUNE && f + FB < F && 4 * (f_in_all - f_done - (f + FB)) <= thr) {
+                const int rem = f_in_all - f_done - (f + FB);                                   // features still to come
+                if (m == 0 && F <= 31) {
+                    // first modality, byte sums <= 124: "some byte > B" for B = thr - 4 rem in 0 .. 127 is a carry into bit 7
+                    // of byte + (127 - B), no compare per position (B > 124: nothing can reach it; B < 0 was excluded above)
+                    const int B = thr - 4 * rem;
+                    bool any_left = false;
+                    if (B <= 124) {
+                        const u32 K = (u32)(127 - B) * 0x01010101u;
+                        const u32 y = (bl[0] + K) | (bl[1] + K) | (bl[2] + K) | (bl[3] + K) | (bh[0] + K) | (bh[1] + K) | (bh[2] + K) | (bh[3] + K);
+                        any_left = __any((y & 0x80808080u) != 0u);
+                    }
+                    if (!any_left) { f_done += f + FB; pruned = true; break; }
+                    continue;
+                }
                 // largest partial sum of the lane: t (earlier modalities) + this modality's byte lanes
                 u32 mx = 0;
 #pragma unroll
