@@ -1555,6 +1555,65 @@ __global__ __launch_bounds__(256) void k_lm_spread2(const u8* __restrict__ q0, i
 // (observed round-robin dispatch; only speed depends on it): each XCD then works on one frame slot at a
 // time, so its 4 MB L2 holds that frame's 1.2 MB of linear memories + the bank instead of all slots'.
 // ------------------------------------------------------------------------------------------------
+// a6-a10 for T = 5, spread memory only (level 0 of the RGB-D configuration), batches: a streaming pass in registers.
+// spread(y, x) = OR of the 5 x 5 block at (y, x); memory g = (y % 5) * 5 + x % 5 holds it at (y / 5) * W + x / 5.
+// One lane = (band of 5 output rows, 8 positions of every one of the 25 memories): nine source rows of 48 bytes
+// (40 pixels + 4 of halo, rounded up to dwords), horizontal OR-5 on dwords (v_alignbyte), vertical OR-5 over the last
+// five rows, then for every x phase the 8 bytes at stride 5 by v_perm.  The tiled k_lm_fast<5, ..> goes through LDS
+// with byte reads and index divisions: 26 vector instructions per pixel against about 5 here.
+// Needs W % 8 == 0 (so a row ends after 40 or 48 of a lane's source bytes) and dword-aligned rows.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 gather4_stride5(const u32 (&V)[11], int b0) {
+    // bytes b0, b0 + 5, b0 + 10, b0 + 15 of the 44-byte row V (v_perm selectors: 0..3 = second operand, 4..7 = first)
+    const int a0 = b0, a1 = b0 + 5, a2 = b0 + 10, a3 = b0 + 15;
+    const u32 lo = __builtin_amdgcn_perm(V[a1 >> 2], V[a0 >> 2], (u32)(a0 & 3) | ((u32)(4 + (a1 & 3)) << 8) | 0x0c0c0000u);
+    const u32 hi = __builtin_amdgcn_perm(V[a3 >> 2], V[a2 >> 2], (u32)(a2 & 3) | ((u32)(4 + (a3 & 3)) << 8) | 0x0c0c0000u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+__global__ __launch_bounds__(256) void k_lm_spread5(const u8* __restrict__ q0, int qpitch, int w, int h, u8* __restrict__ lm0,
+                                                     size_t q_slot_stride, size_t lm_slot_stride, int gblocks, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    const u8* q = slot_ptr_s(q0, q_slot_stride, slot);
+    u8* lm = slot_ptr_s(lm0, lm_slot_stride, slot);
+    const int W = w / 5, HB = h / 5, ng = W >> 3;
+    const u32 wh = (u32)W * (u32)HB;
+    const int gid = (int)(tile * 256u) + (int)threadIdx.x;
+    const int band = gid / ng, g = gid - band * ng;
+    if (band >= HB) return;
+    const int x0 = 40 * g, y0 = 5 * band;
+    const bool full = x0 + 48 <= w;                       // else the row ends after 40 of the lane's bytes
+    u32 Hr[9][11];                                        // horizontal OR-5 of source rows y0 .. y0 + 8 (static indices)
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        u32 R[12];
+#pragma unroll
+        for (int d = 0; d < 12; ++d) R[d] = 0;
+        if (y0 + r < h) {
+            const u8* row = q + (size_t)(y0 + r) * qpitch + x0;
+            const u32x4 a = ld16a4(row), b = ld16a4(row + 16);
+            R[0] = a[0]; R[1] = a[1]; R[2] = a[2]; R[3] = a[3]; R[4] = b[0]; R[5] = b[1]; R[6] = b[2]; R[7] = b[3];
+            if (full) { const u32x4 c = ld16a4(row + 32); R[8] = c[0]; R[9] = c[1]; R[10] = c[2]; R[11] = c[3]; }
+            else { const u32x2 c = ld8a4(row + 32); R[8] = c[0]; R[9] = c[1]; }
+        }
+#pragma unroll
+        for (int d = 0; d < 11; ++d)
+            Hr[r][d] = R[d] | __builtin_amdgcn_alignbyte(R[d + 1], R[d], 1u) | __builtin_amdgcn_alignbyte(R[d + 1], R[d], 2u) |
+                       __builtin_amdgcn_alignbyte(R[d + 1], R[d], 3u) | R[d + 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        u32 V[11];
+#pragma unroll
+        for (int d = 0; d < 11; ++d) V[d] = Hr[j][d] | Hr[j + 1][d] | Hr[j + 2][d] | Hr[j + 3][d] | Hr[j + 4][d];
+        u8* dst = lm + (size_t)(j * 5) * wh + (size_t)band * W + 8 * g;
+#pragma unroll
+        for (int c0 = 0; c0 < 5; ++c0)
+            *reinterpret_cast<u32x2*>(dst + (size_t)c0 * wh) = u32x2{gather4_stride5(V, c0), gather4_stride5(V, c0 + 20)};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // a3-a10 of few frames: the kernels of one dependency level in ONE launch, each on its own range of the block index
 // (LmPhaseArgs in lm_kernels.h).  A single frame is 14 dependent launches of 3-12 us otherwise, each with its own
 // dispatch and drain; here the independent ones overlap and the chain is five launches long.
@@ -2682,7 +2741,16 @@ void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, 
                 }
                 lm_fast_launch<2, 128>(LMF_ARGS); return;
             case 4: lm_fast_launch<4, 64>(LMF_ARGS); return;
-            case 5: lm_fast_launch<5, 128>(LMF_ARGS); return;
+            case 5:
+                // batches: the streaming kernel (one short wave per frame and band would not fill the chip for few frames)
+                if (mode == 1 && !src_shift && nslots >= 16 && (W % 8) == 0 && (h % 5) == 0 && (((uintptr_t)lm & 7) == 0) &&
+                    (lm_slot_stride % 8) == 0 && (((size_t)W * (h / 5)) % 8) == 0) {
+                    const int n_l = (W / 8) * (h / 5);
+                    hipLaunchKernelGGL(k_lm_spread5, dim3((unsigned)(((n_l + 255) / 256) * nslots)), dim3(256), 0, s, q, qpitch, w, h, lm,
+                                       q_slot_stride, lm_slot_stride, (n_l + 255) / 256, nslots);
+                    return;
+                }
+                lm_fast_launch<5, 128>(LMF_ARGS); return;
             case 8: lm_fast_launch<8, 40>(LMF_ARGS); return;
             default: break;
         }
