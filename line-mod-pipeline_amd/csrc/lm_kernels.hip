@@ -2059,10 +2059,12 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
     const float denom = (float)(4 * mt.nfeat_total);
     bool dead = false;
     for (int m = 0; m < a.M && !dead; ++m) {
-        const int cnt = (int)mt.count[m];
+        // (selects, not mt.count[m]: a runtime index into the struct copy would put it into scratch memory)
+        const int cnt = (int)(m == 0 ? mt.count[0] : mt.count[1]);
+        const u32 fstart = m == 0 ? mt.start[0] : mt.start[1];
         LmRefFeat ft;
         ft.off = 0; ft.x = 0; ft.y = 0;
-        if (lane < cnt) ft = a.feats[mt.start[m] + lane];
+        if (lane < cnt) ft = a.feats[fstart + lane];
         int fx = ft.x + off_x, fy = ft.y + off_y;
         bool ok = (lane < cnt) && fx >= 0 && fy >= 0 && fx < a.g.w && fy < a.g.h;
         const u32 eff = ok ? (ft.off & 0x1FFFFFFFu) + shift : a.g.zero_off;
@@ -2163,10 +2165,12 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
     }
     u32 s01[2] = {0, 0}, s23[2] = {0, 0};
     for (int m = 0; m < a.M; ++m) {
-        const int cnt = (int)mt.count[m];
+        // (selects, not mt.count[m]: a runtime index into the struct copy would put it into scratch memory)
+        const int cnt = (int)(m == 0 ? mt.count[0] : mt.count[1]);
+        const u32 fstart = m == 0 ? mt.start[0] : mt.start[1];
         LmRefFeat ft;
         ft.off = 0; ft.x = 0; ft.y = 0;
-        if (lane < cnt) ft = a.feats[mt.start[m] + lane];
+        if (lane < cnt) ft = a.feats[fstart + lane];
         u32 eff[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
