@@ -1183,7 +1183,7 @@ __device__ __forceinline__ void d_dmedian(const u32 vblock, const u8* __restrict
         else { e[10] = e[9]; e[11] = e[9]; }
         u32 oh[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) oh[k] = (e[k] & 32u) ? 0u : (1u << e[k]);
+        for (int k = 0; k < 12; ++k) oh[k] = (1u << (e[k] & 31u)) & ~(e[k] >> 5);   // code 32 (rank 8) counts nowhere: 1 << 0 cleared
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const u32 hs = oh[k] + oh[k + 1] + oh[k + 2] + oh[k + 3] + oh[k + 4];   // nibbles <= 5
@@ -1204,10 +1204,11 @@ __device__ __forceinline__ void d_dmedian(const u32 vblock, const u8* __restrict
                     const u32 o1 = o0 + (o0 << 8), PO = o1 + (o1 << 16);                 // ... and it propagates to every byte
                     const u32 mE = (PE + 0x73737373u) & 0x80808080u;            // byte >= 13
                     const u32 mO = (PO + 0x73737373u) & 0x80808080u;
-                    u32 res;
-                    if (mE) res = (1u << ((u32)(__ffs((int)mE) - 1) >> 3)) >> 1;   // ranks 0..3 -> 0, 1, 2, 4
-                    else if (mO) res = 8u << ((u32)(__ffs((int)mO) - 1) >> 3);     // ranks 4..7 -> 8 .. 64
-                    else res = 128u;
+                    // first byte that reached 13, ranks 0..3 in mE, 4..7 in mO, 8 if none: bit index 8 rank + 7 of the
+                    // 64-bit word mO:mE (ffs - 1 of an empty word is 0xFFFFFFFF: the min skips it).  No branches.
+                    const u32 fe = (u32)(__ffs((int)mE) - 1), fo = (u32)(__ffs((int)mO) - 1) | 32u;
+                    const u32 rank = min(min(fe, fo), 64u) >> 3;
+                    const u32 res = (1u << rank) >> 1;                             // ranks 0..8 -> 0, 1, 2, 4, ..., 128
                     o[k >> 2] |= res << (8 * (k & 3));
                 }
                 *reinterpret_cast<u32x2*>(quant + (size_t)y * w + 8 * g) = u32x2{o[0], o[1]};
