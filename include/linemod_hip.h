@@ -186,7 +186,8 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
  *   window from there), 1 = one-shot, 2 = sliding window. */
 #define LM_TUNE_CBLUR_VARIANT 4
 /* LM_TUNE_CGRAD_VARIANT (process-wide): gradient orientation + 3x3 vote 0 = by batch size (default: two kernels below 16
- *   frames, the fused strip kernel from there), 1 = two kernels, 2 = fused. */
+ *   frames, the fused strip kernel from there), 1 = two kernels, 2 = fused, 3 = fused with 32-row strips (what tall
+ *   images take in large batches). */
 #define LM_TUNE_CGRAD_VARIANT 5
 /* LM_TUNE_PHASE_MAX_SLOTS: calls of at most this many frames run the pre-processing (a3-a10) as five launches, each
  *   holding the independent kernels of one dependency level on ranges of the block index, instead of fourteen dependent

@@ -1159,7 +1159,7 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
         case LM_TUNE_MATCH_UPLOAD_MODE: if (value < 0 || value > 1) break; d->match_upload_mode = value; return LM_OK;
         case LM_TUNE_CBLUR_VARIANT: if (value < 0 || value > 2) break; lmk_set_cblur_variant(value); return LM_OK;
         case LM_TUNE_PHASE_MAX_SLOTS: if (value < 0) break; d->phase_max_slots = value; return LM_OK;
-        case LM_TUNE_CGRAD_VARIANT: if (value < 0 || value > 2) break; lmk_set_cgrad_variant(value); return LM_OK;
+        case LM_TUNE_CGRAD_VARIANT: if (value < 0 || value > 3) break; lmk_set_cgrad_variant(value); return LM_OK;
         case LM_TUNE_COPY_STREAMS: if (value < 1 || value > LM_NCOPY) break; d->n_copy_streams = value; return LM_OK;
         default: return fail(LM_ERR_INVALID, "unknown tuning key");
     }

@@ -13,7 +13,7 @@ void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, i
 // lmk_color_scratch_bytes(w, h), slot_stride apart like everything else) enables the 4-pass streaming
 // form when w % 4 == 0; without it (or for other widths) the fused LDS-tiled kernel runs.
 size_t lmk_color_scratch_bytes(int w, int h);
-void lmk_set_cgrad_variant(int v);   // 0: by batch size (default), 1: k_corient + k_cvote, 2: fused k_cgrad
+void lmk_set_cgrad_variant(int v);   // 0: by batch size (default), 1: k_corient + k_cvote, 2: fused k_cgrad, 3: fused, 32-row strips
 void lmk_set_cblur_variant(int v);   // 0: by batch size (default), 1: one-shot blur, 2: sliding-window blur
 void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_threshold, u8* quant, float* mag,
                         u8* scratch, size_t slot_stride, int nslots);

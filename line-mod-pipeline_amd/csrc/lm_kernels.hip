@@ -2630,7 +2630,7 @@ void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, i
 static int g_cblur_variant = 0;   // 0: by batch size (one-shot below 16 frames, sliding window from there), 1: one-shot blur
                                   // (k_cblur), 2: sliding-window blur (k_cblur_sw); A/B knob of tools/ and tests
 void lmk_set_cblur_variant(int v) { g_cblur_variant = v; }
-static int g_cgrad_variant = 0;   // 0: by batch size (fused k_cgrad from 16 frames), 1: k_corient + k_cvote, 2: k_cgrad
+static int g_cgrad_variant = 0;   // 0: by batch size (fused k_cgrad from 16 frames), 1: k_corient + k_cvote, 2: k_cgrad, 3: k_cgrad with 32-row strips
 void lmk_set_cgrad_variant(int v) { g_cgrad_variant = v; }
 
 size_t lmk_color_scratch_bytes(int w, int h) {
@@ -2667,12 +2667,15 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
         }
         // orientation + vote: fused for batches (k_cgrad), two kernels for few frames (many short waves) and whenever the
         // caller wants the magnitude image
-        if (!mag && (g_cgrad_variant == 2 || (g_cgrad_variant == 0 && nslots >= 16))) {
+        if (!mag && (g_cgrad_variant >= 2 || (g_cgrad_variant == 0 && nslots >= 16))) {
             const int ithr = thr2 >= 2147483648.f ? INT_MAX : (int)floorf(thr2);    // (float)m > thr2 <=> m > floor(thr2)
             // rows per strip: 16 (2 of 18 label rows are recomputed by the neighbouring strips), 8 when that would leave
             // SIMDs without a wave (a 320 x 240 level is 5 waves per frame at 16)
             auto waves = [&](int strip) { return ((w / 16) * ((h + strip - 1) / strip) + 61) / 62; };
-            if ((long)waves(CG_STRIP) * nslots >= 1536) {
+            if (g_cgrad_variant == 3 || (h > 640 && (long)waves(32) * nslots >= 3072)) {        // tall images: 2 of 34 label rows recomputed instead of 2 of 18
+                const int n_w = waves(32);
+                hipLaunchKernelGGL(k_cgrad<32>, dim3((unsigned)(((n_w + 3) / 4) * nslots)), dim3(256), 0, s, S, w, h, ithr, quant, slot_stride, slot_stride, (n_w + 3) / 4, nslots);
+            } else if ((long)waves(CG_STRIP) * nslots >= 1536) {
                 const int n_w = waves(CG_STRIP);
                 hipLaunchKernelGGL(k_cgrad<CG_STRIP>, dim3((unsigned)(((n_w + 3) / 4) * nslots)), dim3(256), 0, s, S, w, h, ithr, quant, slot_stride, slot_stride, (n_w + 3) / 4, nslots);
             } else {

@@ -49,7 +49,7 @@ def test_color_quantize_both_blur_kernels(lm, det, orc, frame0, variant):
         det.set_tuning(lm.TUNE_CBLUR_VARIANT, 0)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_color_quantize_both_gradient_kernels(lm, det, orc, frame0, variant):
     """Orientation + vote run as two kernels (few frames) or as the fused strip kernel with the integer orientation rule
     (batches): force each (LM_TUNE_CGRAD_VARIANT) on shapes that hit strip ends, wave ends (62 segments) and thresholds."""
