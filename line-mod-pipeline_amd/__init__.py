@@ -420,11 +420,16 @@ class Detector:
         self._check(self.lib.lm_load_yaml(self.h, str(path).encode()))
 
     # ---- matching ------------------------------------------------------------------------------
-    def match(self, bgr, depth, threshold, class_idx=-1, cap=1 << 16):
+    def match(self, bgr, depth, threshold, class_idx=-1, cap=1 << 16, out=None):
+        """out: a caller-owned MATCH_DTYPE array to fill (no allocation, the result is a view of it; overflow raises)."""
         bgr = _c(bgr, np.uint8)
         depth = None if depth is None else _c(depth, np.uint16)
         if bgr.shape != (self.cfg.height, self.cfg.width, 3):
             raise ValueError("frame size does not match the detector")
+        if out is not None:
+            n = C.c_size_t()
+            self._check(self.lib.lm_match(self.h, _ptr(bgr), 0, _ptr(depth), 0, threshold, class_idx, _ptr(out), out.size, C.byref(n)))
+            return out[:n.value]
         out = np.zeros(cap, MATCH_DTYPE)
         n = C.c_size_t()
         rc = self.lib.lm_match(self.h, _ptr(bgr), 0, _ptr(depth), 0, threshold, class_idx, _ptr(out), cap, C.byref(n))
@@ -462,7 +467,12 @@ class Detector:
     def set_tuning(self, key, value):
         self._check(self.lib.lm_set_tuning(self.h, key, value))
 
-    def match_slot(self, slot, threshold, class_idx=-1, cap=1 << 16):
+    def match_slot(self, slot, threshold, class_idx=-1, cap=1 << 16, out=None):
+        """out: a caller-owned MATCH_DTYPE array to fill (no allocation, the result is a view of it; overflow raises)."""
+        if out is not None:
+            n = C.c_size_t()
+            self._check(self.lib.lm_match_slot(self.h, slot, threshold, class_idx, _ptr(out), out.size, C.byref(n)))
+            return out[:n.value]
         out = np.zeros(cap, MATCH_DTYPE)
         n = C.c_size_t()
         rc = self.lib.lm_match_slot(self.h, slot, threshold, class_idx, _ptr(out), cap, C.byref(n))
