@@ -176,7 +176,8 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
  * LM_TUNE_FORK_MAX_SLOTS: calls on at most this many frames run the three independent preprocess chains (colour
  *   level 0 | pyrDown + colour of the levels above | depth) on three streams joined by events (default 0 = off: small calls are bound by the host's launch rate, measured r02);
  * LM_TUNE_MATCH_UPLOAD_MODE: lm_match's copies 1 = on the copy stream with the depth chain alone waiting for the depth
- *   image, 0 = inline on the compute stream (default). */
+ *   image, 2 = in pieces over all copy streams (measured r02: the four event pairs cost more than the parallel
+ *   transfers win, 133 -> 167 us), 0 = inline on the compute stream (default). */
 #define LM_TUNE_FORK_MAX_SLOTS 1
 #define LM_TUNE_MATCH_UPLOAD_MODE 2
 /* LM_TUNE_COPY_STREAMS: copy streams the uploads are dealt to, slot -> stream round-robin (1..4, default 4: one

@@ -130,6 +130,7 @@ struct lm_detector {
     int phase_max_slots = 15;        // calls of up to this many frames run a3-a10 as one launch per dependency level (LmPhaseArgs)
     int fork_max_slots = 0;          // measured r02: no gain (host launch rate, 3.4 us per launch, bounds small calls), so off by default
     int fork_depth_wait_slot = -1;   // forked single-frame call: the depth chain's stream waits for this slot's whole upload
+    hipEvent_t ev_split[LM_NCOPY] = {};   // lm_match upload mode 2: one per copy stream
     int match_upload_mode = 0;       // lm_match: 0 = copies inline on the compute stream (default, faster), 1 = copy stream + split events
     // aux arena: [slot][LmDevHeader | cand | keys | out]
     u8* aux_arena = nullptr;
@@ -915,6 +916,7 @@ void lm_destroy(lm_detector* d) {
         hipFree(d->d_raw_thr); hipHostFree(d->h_raw_thr); hipFree(d->d_plan);
         activate_lane(d, 0);
         for (auto& ev : d->blocking_ev) if (ev) hipEventDestroy(ev);
+        for (auto& ev : d->ev_split) if (ev) hipEventDestroy(ev);
         for (auto& ev : d->ev) if (ev) hipEventDestroy(ev);
         if (d->stream) hipStreamDestroy(d->stream);
         for (int l = 1; l < LM_NLANES; ++l) {
@@ -1156,7 +1158,7 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
     if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     switch (key) {
         case LM_TUNE_FORK_MAX_SLOTS: if (value < 0) break; d->fork_max_slots = value; return LM_OK;
-        case LM_TUNE_MATCH_UPLOAD_MODE: if (value < 0 || value > 1) break; d->match_upload_mode = value; return LM_OK;
+        case LM_TUNE_MATCH_UPLOAD_MODE: if (value < 0 || value > 2) break; d->match_upload_mode = value; return LM_OK;
         case LM_TUNE_CBLUR_VARIANT: if (value < 0 || value > 2) break; lmk_set_cblur_variant(value); return LM_OK;
         case LM_TUNE_PHASE_MAX_SLOTS: if (value < 0) break; d->phase_max_slots = value; return LM_OK;
         case LM_TUNE_CGRAD_VARIANT: if (value < 0 || value > 3) break; lmk_set_cgrad_variant(value); return LM_OK;
@@ -1184,6 +1186,44 @@ static bool is_pinned_host(const void* p, size_t bytes) {
     return false;
 }
 
+// lm_match upload mode 2: one frame in pieces over all copy streams (one in-order stream moves 1.5 MB at 25-32 GB/s, four
+// in parallel at 55); the compute stream waits for one event per copy stream.  Pageable sources go through the slot's
+// staging buffer piece by piece, so the memcpy of a piece overlaps the transfer of the previous one.
+static int upload_split(lm_detector* d, int slot, const uint8_t* bgr, const uint16_t* depth, bool pinned) {
+    const lm_config& c = d->cfg;
+    Slot& s = d->slots[slot];
+    int rc;
+    if ((rc = wait_slot_upload(d, s))) return rc;
+    if (!pinned && (rc = ensure_staging(d, s))) return rc;
+    const size_t nb = (size_t)c.width * c.height * 3, nd = c.num_modalities == 2 ? (size_t)c.width * c.height * 2 : 0;
+    const int K = d->n_copy_streams;
+    const size_t piece = align_up((nb + nd + K - 1) / K, 4096);
+    int j = 0;
+    bool used[LM_NCOPY] = {};
+    for (int part = 0; part < 2; ++part) {
+        const u8* src = part == 0 ? bgr : reinterpret_cast<const u8*>(depth);
+        u8* stage = part == 0 ? s.h_bgr : reinterpret_cast<u8*>(s.h_depth);
+        u8* dst = part == 0 ? d->bgr(slot, 0) : reinterpret_cast<u8*>(d->depth(slot));
+        const size_t n = part == 0 ? nb : nd;
+        for (size_t off = 0; off < n; off += piece) {
+            const size_t len = std::min(piece, n - off);
+            const u8* from = src + off;
+            if (!pinned) { std::memcpy(stage + off, src + off, len); from = stage + off; }
+            HIP_TRY(hipMemcpyAsync(dst + off, from, len, hipMemcpyHostToDevice, d->copy_stream[j]));
+            used[j] = true;
+            j = (j + 1) % K;
+        }
+    }
+    for (int k = 0; k < K; ++k) {
+        if (!used[k]) continue;
+        if (!d->ev_split[k]) HIP_TRY(hipEventCreateWithFlags(&d->ev_split[k], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(d->ev_split[k], d->copy_stream[k]));
+        HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_split[k], 0));
+    }
+    s.has_frame = true;
+    return LM_OK;
+}
+
 int lm_match(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
              float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out) {
     int rc;
@@ -1196,7 +1236,11 @@ int lm_match(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16
     const size_t hh = (size_t)d->cfg.height;
     const bool pinned = bgr && is_pinned_host(bgr, (bgr_stride ? bgr_stride : (size_t)d->cfg.width * 3) * hh) &&
                         (d->cfg.num_modalities < 2 || (depth && is_pinned_host(depth, (depth_stride ? depth_stride : (size_t)d->cfg.width * 2) * hh)));
-    if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride, pinned, d->match_upload_mode ? nullptr : d->stream))) return rc;
+    const bool dense = (bgr_stride == 0 || bgr_stride == (size_t)d->cfg.width * 3) &&
+                       (d->cfg.num_modalities < 2 || depth_stride == 0 || depth_stride == (size_t)d->cfg.width * 2);
+    if (d->match_upload_mode == 2 && dense && bgr && (d->cfg.num_modalities < 2 || depth)) {
+        if ((rc = upload_split(d, 0, bgr, depth, pinned))) return rc;
+    } else if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride, pinned, d->match_upload_mode == 1 ? nullptr : d->stream))) return rc;
     if ((rc = run_match(d, 0, 1, threshold, class_idx))) return rc;
     return collect_slot(d, 0, out, cap, n_out);
 }

@@ -124,11 +124,12 @@ def test_single_frame_calls_with_staging_chunks(lm, orc, synth, chunks):
 
 
 @pytest.mark.parametrize("color_only", [False, True])
-@pytest.mark.parametrize("fork,mode", [(0, 0), (0, 1), (2, 0), (2, 1)])
+@pytest.mark.parametrize("fork,mode", [(0, 0), (0, 1), (2, 0), (2, 1), (0, 2)])
 def test_single_frame_fork_and_upload_modes(lm, orc, synth, color_only, fork, mode):
     """Single-frame calls run the three independent preprocess chains on three streams (LM_TUNE_FORK_MAX_SLOTS) and
     lm_match may send its copies through the copy stream with the depth chain alone waiting for the depth image
-    (LM_TUNE_MATCH_UPLOAD_MODE): same lists whatever the launch shape, frames changing every call."""
+    (LM_TUNE_MATCH_UPLOAD_MODE 1) or in pieces over all copy streams (2): same lists whatever the launch shape, frames
+    changing every call."""
     d = lm.Detector(color_only=color_only, width=W, height=H, frame_slots=4)
     o = orc.Detector(color_only=color_only)
     M = 1 if color_only else 2

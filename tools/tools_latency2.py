@@ -19,8 +19,9 @@ for color_only in (False, True):
     for i in range(16):
         b, dp = frames[i % 8]
         d.upload_frame(i, b, None if color_only else dp)
-    for phase in (0, 16):
+    for phase, upmode in ((0, 0), (16, 0), (16, 2)):
         d.set_tuning(lm.TUNE_PHASE_MAX_SLOTS, phase)
+        d.set_tuning(lm.TUNE_MATCH_UPLOAD_MODE, upmode)
         for _ in range(20):
             d.match_slot(1, 80.0, 0, out=OUT)
         t = time.perf_counter()
@@ -47,7 +48,7 @@ for color_only in (False, True):
             b, dp = pf[k % 7]
             d.match(b, None if color_only else dp, 80.0, 0, out=OUT)
         t_pin = (time.perf_counter() - t) / 150
-        line = "%s phases<=%d: resident frame %.0f us, host frame in (lm_match) %.0f us, from pinned memory %.0f us" % (
+        line = ("%s phases<=%d upload-mode " + str(upmode) + ": resident frame %.0f us, host frame in (lm_match) %.0f us, from pinned memory %.0f us") % (
             "colour-only" if color_only else "RGB-D", phase, t_slot * 1e6, t_host * 1e6, t_pin * 1e6)
         for nb in (2, 4, 8, 12):
             for _ in range(5):
