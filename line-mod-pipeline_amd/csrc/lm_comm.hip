@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <netdb.h>
 #include <rccl/rccl.h>
 #include <sys/socket.h>
 #include <unistd.h>
@@ -51,7 +52,15 @@ bool tcp_broadcast(int rank, int world, const char* addr, int port, int timeout_
     std::memset(&sa, 0, sizeof(sa));
     sa.sin_family = AF_INET;
     sa.sin_port = htons((uint16_t)port);
-    if (inet_pton(AF_INET, addr, &sa.sin_addr) != 1) { err = std::string("bad rendezvous address: ") + addr; return false; }
+    if (inet_pton(AF_INET, addr, &sa.sin_addr) != 1) {
+        // not a dotted quad (e.g. MASTER_ADDR=localhost or a node name): resolve it
+        addrinfo hints, *res = nullptr;
+        std::memset(&hints, 0, sizeof(hints));
+        hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
+        if (getaddrinfo(addr, nullptr, &hints, &res) != 0 || !res) { err = std::string("bad rendezvous address: ") + addr; return false; }
+        sa.sin_addr = reinterpret_cast<sockaddr_in*>(res->ai_addr)->sin_addr;
+        freeaddrinfo(res);
+    }
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(timeout_s);
     if (rank == 0) {
         int ls = ::socket(AF_INET, SOCK_STREAM, 0);
