@@ -2131,6 +2131,9 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
 // lines.  When both entries name the same template the wave issues the two patch loads of every feature back to back,
 // so the second one hits the line the first has just requested: one L2 request instead of two (the kernel is bound by
 // the L2 lines a patch pulls).  Different templates (or a dropped entry): one after the other, as before.
+#ifndef RP_BATCH
+#define RP_BATCH 8   // features per load batch of refine_pair (x 2 candidates = loads in flight per wave)
+#endif
 template <bool LAST>
 __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32 i, const u8 (*resp)[256], int lane) {
     LmCand* cand = slot_ptr_s(a.cand, a.aux_slot_stride, slot);
@@ -2180,10 +2183,10 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
             eff[c] = ok ? (ft.off & 0x1FFFFFFFu) + shift[c] : a.g.zero_off;
         }
         const u32 lab = ft.off >> 29;
-        for (int f = 0; f < cnt; f += 4) {
-            u32 v[2][4];
+        for (int f = 0; f < cnt; f += RP_BATCH) {
+            u32 v[2][RP_BATCH];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < RP_BATCH; ++k)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const u32 t = (u32)__builtin_amdgcn_readlane((int)eff[c], f + k) + lane_off;
@@ -2191,7 +2194,7 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
                     v[c][k] = __builtin_amdgcn_alignbyte(d[1], d[0], t & 3u);
                 }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < RP_BATCH; ++k) {
                 const u32 lb = (u32)__builtin_amdgcn_readlane((int)lab, f + k);
                 const u8* tab = resp[lb];
 #pragma unroll
