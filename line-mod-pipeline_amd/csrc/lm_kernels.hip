@@ -1068,9 +1068,61 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const u16* __restrict__ 
 //              into byte counters (ranks 0..3 | 4..7), vertical 5-sums, prefix sums by one multiply, and
 //              the median is the first rank whose cumulative count reaches 13 (rank 8 if none does).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 pk_sub_u16_sat(u32 a, u32 b) {   // per half: max(a - b, 0)
+    u32 r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (asm, not the vector builtins: the compiler turns min(x, 1) and 0 - f on packed halves into per-half compares and
+// selects, three instructions for one)
+__device__ __forceinline__ u32 pk_min_u16(u32 a, u32 b) {
+    u32 r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ u32 pk_sub_i16_op(u32 a, u32 b) {
+    u32 r;
+    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ u32 pk_add_i16_op(u32 a, u32 b) {
+    u32 r;
+    asm("v_pk_add_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a.half * b.half + c for the low (HI = false) or high halves of two packed i16 pairs
+template <bool HI>
+__device__ __forceinline__ int mad_i16h(u32 a, u32 b, int c) {
+    int r;
+    if (HI) asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ u32 hw_u16(const u32x4* A, int hw) {
     const u32 d = A[hw >> 3][(hw >> 1) & 3];
     return (hw & 1) ? (d >> 16) : (d & 0xFFFFu);
+}
+
+// float tail of a5 for one pixel: normal (1150 ddx, 1150 ddy, -det d), normalised, quantised, looked up; returns the
+// label's rank code (see above), 0 for an invalid pixel.  Same operation order as the oracle.
+__device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool valid, const u8* __restrict__ lut) {
+    // same values as upstream's 64-bit integer products rounded once to float: |ddx| < 2^30 so the
+    // double product is exact; |det * d| <= 22500 * 65535 < 2^31
+    float nx = (float)((double)ddx * 1150.0);
+    float ny = (float)((double)ddy * 1150.0);
+    float nz = (float)(-mul_i24(det, d));
+    const float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+    const float inv = __fdiv_rn(1.0f, len > 0 ? len : 1.0f);
+    nx = __fmul_rn(nx, inv); ny = __fmul_rn(ny, inv); nz = __fmul_rn(nz, inv);
+    const int v1 = (int)__fadd_rn(__fmul_rn(nx, 10.f), 10.f);
+    const int v2 = (int)__fadd_rn(__fmul_rn(ny, 10.f), 10.f);
+    const int v3 = (int)__fadd_rn(__fmul_rn(nz, 20.f), 20.f);
+    const int flat = mul_i24(v3, 400) + mul_i24(v2, 20) + v1;   // |v| small: exact
+    const bool in_lut = flat >= 0 && flat < 8000;
+    const u32 v = lut[in_lut ? flat : 0];
+    const u32 rank = (u32)__ffs((int)v);                         // 0 for none, 1 + label otherwise
+    const u32 ecode = rank < 4 ? 8 * rank : (rank < 8 ? 8 * (rank - 4) + 4 : 32u);
+    return (valid && len > 0 && in_lut) ? ecode : 0u;
 }
 
 __device__ __forceinline__ void d_dnormal(const u32 vblock, const u16* __restrict__ depth0, int w, int h, int dist_thr, int diff_thr,
@@ -1096,6 +1148,59 @@ __device__ __forceinline__ void d_dnormal(const u32 vblock, const u16* __restric
                 R[j][k] = ok ? ld16(row + 16 * k) : u32x4{0, 0, 0, 0};
             }
         }
+        if (diff_thr <= 5461) {
+            // PACKED taps: two pixels per instruction.  A dword of a depth row is a pixel pair, the neighbours five pixels
+            // to the side are one v_alignbit away; |delta| by two saturating subtracts, the gate |delta| < diff_thr by a
+            // third, and ci / cj / cx / sx / sy accumulate as i16 pairs (|sx| <= 6 (diff_thr - 1) < 2^15 needs
+            // diff_thr <= 5461; larger thresholds take the per-pixel loop below).
+            u32 D[3][12];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int k = 0; k < 12; ++k) D[j][k] = R[j][k >> 2][k & 3];
+            const u32 THR = (u32)diff_thr * 0x00010001u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32 C = D[1][4 + k];
+                u32 ci = 0, cj = 0, cx = 0, sx = 0, sy = 0;
+#pragma unroll
+                for (int jj = -1; jj <= 1; ++jj)
+#pragma unroll
+                    for (int ii = -1; ii <= 1; ++ii) {
+                        if (ii == 0 && jj == 0) continue;
+                        const u32* Dr = D[jj + 1];
+                        const u32 N = ii == 0 ? Dr[4 + k]
+                                    : ii > 0 ? __builtin_amdgcn_alignbit(Dr[7 + k], Dr[6 + k], 16)
+                                             : __builtin_amdgcn_alignbit(Dr[2 + k], Dr[1 + k], 16);
+                        const u32 up = pk_sub_u16_sat(N, C), dn = pk_sub_u16_sat(C, N);      // one of them is 0
+                        const u32 f = pk_min_u16(pk_sub_u16_sat(THR, up | dn), 0x00010001u);  // |delta| < diff_thr ? 1 : 0
+                        const u32 fd = pk_sub_i16(up, dn) & pk_sub_i16_op(0u, f);                 // the gated delta
+                        if (ii != 0) { ci += f; sx = ii > 0 ? pk_add_i16(sx, fd) : pk_sub_i16(sx, fd); }
+                        if (jj != 0) { cj += f; sy = jj > 0 ? pk_add_i16(sy, fd) : pk_sub_i16(sy, fd); }
+                        if (ii != 0 && jj != 0) cx = ii * jj > 0 ? pk_add_i16(cx, f) : pk_sub_i16(cx, f);
+                    }
+                const u32 ncx = pk_sub_i16(0u, cx);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int p = 2 * k + hh;
+                    const int x = 8 * g + p;
+                    const int d = hh ? (int)(C >> 16) : (int)(C & 0xFFFFu);
+                    const bool valid = x >= 5 && x < w - 6 && d < dist_thr;
+                    int detq, ddxq, ddyq;                    // det / 625, ddx / 125, ddy / 125 of the per-pixel loop
+                    if (hh) {
+                        detq = mad_i16h<true>(ci, cj, mad_i16h<true>(ncx, cx, 0));
+                        ddxq = mad_i16h<true>(cj, sx, mad_i16h<true>(ncx, sy, 0));
+                        ddyq = mad_i16h<true>(ci, sy, mad_i16h<true>(ncx, sx, 0));
+                    } else {
+                        detq = mad_i16h<false>(ci, cj, mad_i16h<false>(ncx, cx, 0));
+                        ddxq = mad_i16h<false>(cj, sx, mad_i16h<false>(ncx, sy, 0));
+                        ddyq = mad_i16h<false>(ci, sy, mad_i16h<false>(ncx, sx, 0));
+                    }
+                    const u32 e = dn_label(mul_i24(detq, 625), mul_i24(ddxq, 125), mul_i24(ddyq, 125), d, valid, lut);
+                    out[p >> 2] |= e << (8 * (p & 3));
+                }
+            }
+        } else {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             // BRANCHLESS: every pixel runs the whole computation and the result is selected at the end (most pixels
@@ -1127,24 +1232,9 @@ __device__ __forceinline__ void d_dnormal(const u32 vblock, const u16* __restric
             const int det = mul_i24(A0, A3) - mul_i24(A1, A1);
             const int ddx = mul_i24(A3, b0) - mul_i24(A1, b1);
             const int ddy = mul_i24(A0, b1) - mul_i24(A1, b0);
-            // same values as upstream's 64-bit integer products rounded once to float: |ddx| < 2^30 so the
-            // double product is exact; |det * d| <= 22500 * 65535 < 2^31
-            float nx = (float)((double)ddx * 1150.0);
-            float ny = (float)((double)ddy * 1150.0);
-            float nz = (float)(-mul_i24(det, d));
-            const float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
-            const float inv = __fdiv_rn(1.0f, len > 0 ? len : 1.0f);
-            nx = __fmul_rn(nx, inv); ny = __fmul_rn(ny, inv); nz = __fmul_rn(nz, inv);
-            const int v1 = (int)__fadd_rn(__fmul_rn(nx, 10.f), 10.f);
-            const int v2 = (int)__fadd_rn(__fmul_rn(ny, 10.f), 10.f);
-            const int v3 = (int)__fadd_rn(__fmul_rn(nz, 20.f), 20.f);
-            const int flat = mul_i24(v3, 400) + mul_i24(v2, 20) + v1;   // |v| small: exact
-            const bool in_lut = flat >= 0 && flat < 8000;
-            const u32 v = lut[in_lut ? flat : 0];
-            const u32 rank = (u32)__ffs((int)v);                         // 0 for none, 1 + label otherwise
-            const u32 ecode = rank < 4 ? 8 * rank : (rank < 8 ? 8 * (rank - 4) + 4 : 32u);
-            const u32 e = (valid && len > 0 && in_lut) ? ecode : 0u;
+            const u32 e = dn_label(det, ddx, ddy, d, valid, lut);
             out[p >> 2] |= e << (8 * (p & 3));
+        }
         }
     }
     *reinterpret_cast<u32x2*>(code + (size_t)y * w + 8 * g) = u32x2{out[0], out[1]};

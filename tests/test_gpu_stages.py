@@ -108,6 +108,22 @@ def test_depth_quantize_parity(det, orc, synth, shape):
     assert np.array_equal(det.stage_depth_quantize(steps), orc.depth_quantize(steps))
 
 
+@pytest.mark.parametrize("diff_thr", [1, 50, 5461, 5462, 40000])
+def test_depth_quantize_thresholds_and_full_range(lm, orc, diff_thr):
+    """k_dnormal runs its eight taps on packed pixel pairs (saturating u16 subtracts, i16 sums) up to
+    difference_threshold 5461 and per pixel above: both sides of the switch, depths over the whole u16 range (deltas that
+    wrap as i16), and steps right at the gate."""
+    h, w = 96, 160
+    d = lm.Detector(color_only=False, width=w, height=h, T=[4, 8], difference_threshold=diff_thr, distance_threshold=70000)
+    rng = np.random.default_rng(diff_thr)
+    full = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+    near = (30000 + rng.integers(-diff_thr, diff_thr + 1, (h, w)).clip(-30000, 35535)).astype(np.uint16)
+    edge = (1000 + (diff_thr - 1) * rng.integers(0, 3, (h, w)) + rng.integers(0, 2, (h, w))).clip(0, 65535).astype(np.uint16)
+    for depth in (full, near, edge):
+        assert np.array_equal(d.stage_depth_quantize(depth), orc.depth_quantize(depth, 70000, diff_thr)), diff_thr
+    d.close()
+
+
 def test_depth_quantize_frame0_and_custom_lut(lm, orc, frame0):
     _, depth = frame0
     d = lm.Detector(color_only=False)
