@@ -99,7 +99,17 @@ class Runner:
         self.last_owned = None
         if exchange == "rccl":
             port = int(os.environ.get("MASTER_PORT", "29500")) + 1
-            det.comm_init(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, args.gather_cap)
+            # librccl prints a version banner on STDOUT when the first communicator comes up; stdout is for the one JSON
+            # line, so file descriptor 1 points at stderr while the communicators are created
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                det.comm_init(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, args.gather_cap)
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
             self.gbuf = [(np.zeros(self.Bl * CAP // 4, lm.MATCH_DTYPE), np.zeros(self.Bl, np.int32)) for _ in range(self.NL)]
 
     # ------------------------------------------------------------------------------------------
