@@ -20,6 +20,8 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -66,7 +68,7 @@ class Runner:
         W, H, B = wl["W"], wl["H"], args.batch
         self.M = M = 1 if wl["color_only"] else 2
         self.B, self.W, self.H = B, W, H
-        self.n_total = args.templates * world if args.scaling == "weak" else args.templates
+        self.n_total = args.templates_total
         flags = (lm.FLAG_BYTE_RESPONSES if args.byte_responses else 0)
         quota = cgroup_cpus()
         if world > 1 and quota is not None and quota < 2 * world:
@@ -226,6 +228,71 @@ class Runner:
                 "matches0": int(self.bufs[(self.k - 1) % NBUF][1][0]) if self.k else 0}
 
 
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` started as ONE plain process (no torchrun, WORLD_SIZE unset): this parent -- which imports
+    neither the package nor anything that touches HIP -- starts N fresh child processes of itself, one rank per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment), relays rank 0's one JSON line,
+    and fails if any rank fails: a child that dies takes the others with it (a rank that never arrives would leave
+    the rest waiting in the rendezvous), and the exit code is non-zero.  Never an os.exec*: the children are new
+    processes."""
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:     # a free port for this run (+1 is the ids' rendezvous)
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    import threading
+    procs = []
+    captured = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    reader = threading.Thread(target=lambda: captured.append(procs[0].stdout.read()), daemon=True)
+    reader.start()                                        # rank 0's stdout is drained while it runs (a full pipe would block it)
+    failed = None
+    pending = set(range(n))
+    while pending and failed is None:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        time.sleep(0.05)
+    if failed is not None:
+        for r in pending:
+            procs[r].kill()
+        for pr in procs:
+            try:
+                pr.wait(timeout=30)
+            except Exception:  # noqa: BLE001
+                pass
+        sys.stderr.write("bench.py: rank %d of %d exited with code %d; the run is void (no JSON line)\n" % (failed[0], n, failed[1]))
+        return failed[1] if failed[1] > 0 else 1
+    reader.join(timeout=30)
+    out = captured[0] if captured else ""
+    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: rank 0 printed %d JSON lines instead of 1\n" % len(lines))
+        return 1
+    d = json.loads(lines[0])
+    cfg = d.get("config", {})
+    if d.get("n_gpus") != n or not (cfg.get("rccl_ranks") == n or cfg.get("functional_gloo")):
+        sys.stderr.write("bench.py: asked for %d GPUs, the line reports n_gpus=%r rccl_ranks=%r\n"
+                         % (n, d.get("n_gpus"), cfg.get("rccl_ranks")))
+        return 1
+    print(lines[0])
+    sys.stdout.flush()
+    return 0
+
+
+CONFIG4_TEMPLATES = 24300    # BASELINE config 4: 162 viewpoints x 15 radii x 10 rotations, sharded over 8 GPUs (3037 / 3038 each)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,7 +305,10 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, choices=(0, 1, 2, 3, 4),
                     help="the step's frames are split over this many of the detector's lanes (HIP streams driven by one "
                          "host thread) so that the stages of one part overlap those of the others; 0 = the config's default")
-    ap.add_argument("--templates", type=int, default=3000, help="templates per GPU (weak) / in the whole bank (strong)")
+    ap.add_argument("--templates", type=int, default=0,
+                    help="templates per GPU (weak) / in the whole bank (strong); 0 = 3000 (config 2 / 3) on one GPU and, "
+                         "for N > 1 with weak scaling, BASELINE config 4's dense viewpoint sphere: 24 300 x N / 8 in the "
+                         "whole bank (N = 8: 24 300, 3037 / 3038 per GPU)")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--threshold", type=float, default=80.0)
     ap.add_argument("--gather-cap", type=int, default=0, help="lm_comm_init recs_per_frame_cap (0 = 256)")
@@ -263,11 +333,23 @@ def main():
         args.batch = CONFIGS[args.config]["batch"] if not args.lanes else 128 * args.lanes
     if not args.lanes:
         args.lanes = CONFIGS[args.config]["lanes"]
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (before anything touches HIP)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d: a run must have exactly one rank per GPU asked for"
+                         % (args.gpus, world))
+    if not 0 <= rank < world:
+        raise SystemExit("RANK %d outside WORLD_SIZE %d" % (rank, world))
+    if not args.templates:
+        args.templates_total = (CONFIG4_TEMPLATES * world + 4) // 8 if (world > 1 and args.scaling == "weak") else 3000
+    else:
+        args.templates_total = args.templates * world if args.scaling == "weak" else args.templates
     if args.functional_gloo:
         local_rank = 0
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -280,6 +362,19 @@ def main():
     exchange = "gloo" if (args.functional_gloo and world > 1) else ("rccl" if (world > 1 or args.force_rccl) else "none")
     runner = Runner(args, rank, world, local_rank, exchange)
     det = runner.det
+    rccl_ranks, bus_ids = None, [det.pci_bus_id()]
+    if exchange == "rccl":
+        # the communicator really has one rank per GPU asked for, and the ranks really sit on different GPUs
+        crank, cworld = det.comm_info()
+        if cworld != args.gpus or crank != rank:
+            raise SystemExit("RCCL communicator has rank %d of %d, the run was asked for rank %d of %d GPUs" % (crank, cworld, rank, args.gpus))
+        rccl_ranks = cworld
+        if world > 32:
+            raise SystemExit("more than 32 ranks on one node")
+        ids = det.comm_max([float(pci_bus_number(bus_ids[0])) if r == rank else -1.0 for r in range(world)])
+        bus_ids = ["%04x:%02x:%02x.%x" % ((int(v) >> 16) & 0xFFFF, (int(v) >> 8) & 0xFF, (int(v) >> 3) & 0x1F, int(v) & 7) for v in ids]
+        if len(set(ids)) != world or min(ids) < 0:
+            raise SystemExit("the %d ranks do not sit on %d different GPUs: PCI bus ids %s" % (world, world, bus_ids))
     gather = dist = None
     state = {"merged": None}
     if exchange == "gloo":
@@ -314,6 +409,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     rep = runner.report()
+    exch_us, exch_n = det.get_exchange_profile() if exchange == "rccl" else (0.0, 0)
     det.set_profiling(False)
     one_lane = runner.one_lane_profile()
     if exchange == "rccl":
@@ -401,6 +497,12 @@ def main():
                        "exchange": {"none": "single GPU", "gloo": "torch.distributed gloo (functional check only)",
                                     "rccl": "2 x ncclAllGather per lane-step from liblinemod_hip.so on the lane's stream; "
                                             "each rank merges the frames it owns"}[exchange],
+                       "rccl_ranks": rccl_ranks, "pci_bus_ids": bus_ids,
+                       "functional_gloo": bool(args.functional_gloo) or None,
+                       "exchange_span_us_per_lane_step": round(exch_us / exch_n, 2) if exch_n else None,
+                       "exchange_span_note": "HIP events on the lane's stream from behind k_sort_unique to behind the D2H of "
+                                             "the gathered lists: k_pack_lists + 2 x ncclAllGather + 2 copies, per lane-step "
+                                             "of %d frames (contains the wait for the slowest rank)" % Bl if exch_n else None,
                        "h2d_inclusive": h2d,
                        "parallelism": "template-shard x%d" % world},
             "roofline": roofline,
@@ -413,6 +515,13 @@ def main():
         dist.destroy_process_group()
     det.close()
     return result
+
+
+def pci_bus_number(s):
+    """'0000:c1:00.0' -> domain << 16 | bus << 8 | device << 3 | function (exact in a double)."""
+    dom, bus, rest = s.strip().split(":")
+    dev, fn = rest.split(".")
+    return (int(dom, 16) << 16) | (int(bus, 16) << 8) | (int(dev, 16) << 3) | int(fn, 16)
 
 
 def pmc_traffic(config, frames_per_launch):

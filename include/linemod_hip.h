@@ -200,6 +200,20 @@ int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm
  * records, counts n_slots entries. */
 int lm_match_batch(lm_detector* det, int n_slots, float threshold, int class_idx, lm_match_t* out, size_t cap_per_frame,
                    int32_t* counts);
+/* Detector::match(sources, threshold, matches, class_ids) with upstream's class LIST      HighLevelLinemod.cpp:145,152
+ * on the resident frames of slots [first_slot, first_slot + n_slots): a3-a10 run ONCE per frame, every named class is
+ * scanned against the same linear memories (one scan launch per run of neighbouring class indices), one refinement,
+ * one sort.  A list holds the matches of all named classes in the total order; lm_match_t.class_idx tells them apart.
+ * n_classes == 0 or {-1} = all classes; duplicates are ignored.  The per-class incremental cost is scan + refine only. */
+int lm_match_batch_classes(lm_detector* det, int first_slot, int n_slots, float threshold, const int32_t* class_idxs,
+                           int n_classes, lm_match_t* out, size_t cap_per_frame, int32_t* counts);
+/* a11-a15 ONLY, for slots whose a3-a10 results are current: a match or lm_prepare_slot has run on the frame the slot
+ * holds and neither an upload nor a LUT change has happened since (LM_ERR_INVALID otherwise -- never a silent
+ * re-use of stale memories).  This is the reference's call pattern for several objects in one camera frame
+ * (PoseDetection::detect per class name, PoseDetection.cpp:45-66 -> HighLevelLinemod.cpp:145-152): upload + prepare
+ * once, one lm_match_prepared per class. */
+int lm_match_prepared(lm_detector* det, int first_slot, int n_slots, float threshold, const int32_t* class_idxs,
+                      int n_classes, lm_match_t* out, size_t cap_per_frame, int32_t* counts);
 
 /* Asynchronous halves of lm_match_batch on one of four LANES (lane 0 = the detector's stream, lanes 1-3 = further
  * HIP streams with their own events and threshold tables; two lanes are what bench.py drives).  lm_match_begin enqueues a3-a15 for the resident frames
@@ -212,6 +226,9 @@ int lm_match_batch(lm_detector* det, int n_slots, float threshold, int class_idx
  * may be issued at any time and are ordered against the lane that later reads them by per-slot events.  The
  * synchronous entry points refuse to run while a lane is busy. */
 int lm_match_begin(lm_detector* det, int lane, int first_slot, int n_slots, float threshold, int class_idx);
+/* lm_match_begin with a class list (see lm_match_batch_classes); collected by lm_match_end. */
+int lm_match_begin_classes(lm_detector* det, int lane, int first_slot, int n_slots, float threshold,
+                           const int32_t* class_idxs, int n_classes);
 /* hipDeviceSynchronize() on the detector's device (what torch.cuda.synchronize() is for a torch program). */
 int lm_synchronize(lm_detector* det);
 int lm_match_end(lm_detector* det, int lane, lm_match_t* out, size_t cap_per_frame, int32_t* counts);
@@ -235,9 +252,13 @@ int lm_color_check_counts(lm_detector* det, int slot, const double lower_hsv[3],
  * to the others over TCP addr:port (one node: "127.0.0.1", e.g. MASTER_PORT + 1) -- no torch, no MPI, no second
  * process.  recs_per_frame_cap (0 = 256): average records per frame a rank may contribute to one gather; the gather
  * buffers have a fixed size of n_frames * recs_per_frame_cap records per rank so that no host round trip sits between
- * the two collectives.  More records than that is LM_ERR_OVERFLOW, never a silent truncation (the reference consumes
- * ALL matches: HighLevelLinemod.cpp:206-253).
- * The lanes' communicators (one per lane) rendezvous on `port` .. `port + 3`. */
+ * the two collectives.  More records than that -- or a frame with more than 4096 matches on some shard, which the
+ * single-GPU path hands to the host sort -- is NOT an error: lm_match_end_gathered then runs a second, exactly sized
+ * exchange (every rank sees the same status words, so all ranks take it together) and returns the same lists the
+ * single-GPU path returns (the reference consumes ALL matches: HighLevelLinemod.cpp:206-253).  Only a shard that
+ * overflows its own lm_config.max_candidates / max_matches fails (LM_ERR_OVERFLOW on every rank), as on one GPU.
+ * The ids of the lanes' communicators travel in ONE rendezvous on `port`; on any failure nothing is left behind and
+ * the call may be repeated. */
 int lm_comm_init(lm_detector* det, int rank, int world, const char* addr, int port, int recs_per_frame_cap);
 /* The rendezvous lm_comm_init uses, on its own (host only, no GPU): n bytes from rank 0's buf into every rank's buf. */
 int lm_rendezvous_broadcast(int rank, int world, const char* addr, int port, void* buf, size_t n, int timeout_s);
@@ -255,6 +276,9 @@ int lm_match_end_gathered(lm_detector* det, int lane, lm_match_t* out, size_t ca
  * "barrier + synchronize" that brackets a timed region.  lm_comm_max: element-wise maximum of n <= 32 doubles. */
 int lm_comm_barrier(lm_detector* det);
 int lm_comm_max(lm_detector* det, double* values, int n);
+/* "0000:c1:00.0"-style PCI bus id of the detector's device (hipDeviceGetPCIBusId): bench.py checks that the N ranks of
+ * a node really sit on N different GPUs. */
+int lm_device_pci_bus_id(lm_detector* det, char* out, size_t cap);
 
 /* R-way merge of per-shard sorted lists + adjacent-unique: the step after the all-gather (8e).  Host-side. */
 int lm_merge_matches(const lm_match_t* lists, const int32_t* counts, int n_lists, size_t stride, lm_match_t* out,
@@ -329,6 +353,12 @@ int lm_time_stages(lm_detector* det, int slot, float threshold, int class_idx, i
 int lm_set_profiling(lm_detector* det, int enable);
 int lm_get_profile(lm_detector* det, double stage_us[4], double* scan_algorithmic_bytes, int64_t* launches,
                    int64_t* frames);
+/* Accumulated with the profile above: HIP-event span of the exchange of lm_match_begin_gathered (behind the sort
+ * kernel: k_pack_lists, the two ncclAllGather, the two D2H copies) and the number of exchanges. */
+int lm_get_exchange_profile(lm_detector* det, double* exchange_us, int64_t* exchanges);
+/* Work counters since lm_set_profiling: out[0] frames that went through a3-a10, out[1] scan launches, out[2]
+ * refinement launches, out[3] sort launches (they count with profiling off too). */
+int lm_get_stage_counts(lm_detector* det, int64_t out[4]);
 /* Bytes the similarity scan's vector loads request per frame for `class_idx` (-1 = all classes): the on-chip
  * (L2 -> L1) traffic of the hot kernel, next to the algorithmic bytes lm_get_profile reports. */
 int lm_scan_load_bytes(lm_detector* det, int class_idx, double* bytes_per_frame);

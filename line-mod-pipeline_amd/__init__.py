@@ -70,6 +70,8 @@ EXPORTS = [
     "lm_match_end_gathered", "lm_comm_barrier", "lm_comm_max", "lm_upload_frames_pinned",
     "lm_rendezvous_broadcast", "lm_normal_lut_is_substitute",
     "lm_set_scan_stats", "lm_get_scan_stats", "lm_color_check_counts",
+    "lm_match_batch_classes", "lm_match_prepared", "lm_match_begin_classes", "lm_device_pci_bus_id",
+    "lm_get_exchange_profile", "lm_get_stage_counts",
 ]
 
 _lib = None
@@ -161,6 +163,12 @@ def load_library(path=None):
     lib.lm_match_end_gathered.argtypes = [vp, i, vp, sz, vp, C.POINTER(i), C.POINTER(i), C.POINTER(sz)]
     lib.lm_comm_barrier.argtypes = [vp]
     lib.lm_comm_max.argtypes = [vp, C.POINTER(C.c_double), i]
+    lib.lm_match_batch_classes.argtypes = [vp, i, i, f, vp, i, vp, sz, vp]
+    lib.lm_match_prepared.argtypes = [vp, i, i, f, vp, i, vp, sz, vp]
+    lib.lm_match_begin_classes.argtypes = [vp, i, i, i, f, vp, i]
+    lib.lm_device_pci_bus_id.argtypes = [vp, C.c_char_p, sz]
+    lib.lm_get_exchange_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.lm_get_stage_counts.argtypes = [vp, C.POINTER(C.c_int64)]
     if path is None:
         _lib = lib
     return lib
@@ -168,6 +176,20 @@ def load_library(path=None):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _check_out(out, ndim=1):
+    """A caller-owned result buffer goes to the library as (pointer, capacity): it must be what the library writes."""
+    if not isinstance(out, np.ndarray) or out.dtype != MATCH_DTYPE or not out.flags.c_contiguous or out.ndim != ndim \
+            or not out.flags.writeable:
+        raise ValueError("out must be a writable C-contiguous %d-d numpy array of MATCH_DTYPE" % ndim)
+    return out
+
+
+def _check_counts(counts, n):
+    if not isinstance(counts, np.ndarray) or counts.dtype != np.int32 or not counts.flags.c_contiguous or counts.size < n:
+        raise ValueError("counts must be a C-contiguous int32 array with one entry per frame")
+    return counts
 
 
 def _c(a, dtype):
@@ -281,13 +303,33 @@ class PinnedBuffer:
         self._raw = (C.c_uint8 * nbytes).from_address(p.value)
 
     def view(self, dtype, shape, offset=0):
+        """A numpy view of the block.  Views do NOT own the memory: they dangle after close()."""
+        if not self.ptr:
+            raise ValueError("PinnedBuffer is closed")
         return np.frombuffer(self._raw, dtype=dtype, count=int(np.prod(shape)), offset=offset).reshape(shape)
 
-    def close(self):
+    def close(self, detectors=()):
+        """Frees the block.  An upload that still reads it must have landed first: pass the detectors that were handed
+        views of it (their upload_wait(-1) runs here) or wait yourself."""
         if self.ptr:
+            for det in detectors:
+                det.upload_wait(-1)
             self._raw = None
             self.lib.lm_host_free(self.ptr)
             self.ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Detector:
@@ -427,6 +469,7 @@ class Detector:
         if bgr.shape != (self.cfg.height, self.cfg.width, 3):
             raise ValueError("frame size does not match the detector")
         if out is not None:
+            _check_out(out)
             n = C.c_size_t()
             self._check(self.lib.lm_match(self.h, _ptr(bgr), 0, _ptr(depth), 0, threshold, class_idx, _ptr(out), out.size, C.byref(n)))
             return out[:n.value]
@@ -470,6 +513,7 @@ class Detector:
     def match_slot(self, slot, threshold, class_idx=-1, cap=1 << 16, out=None):
         """out: a caller-owned MATCH_DTYPE array to fill (no allocation, the result is a view of it; overflow raises)."""
         if out is not None:
+            _check_out(out)
             n = C.c_size_t()
             self._check(self.lib.lm_match_slot(self.h, slot, threshold, class_idx, _ptr(out), out.size, C.byref(n)))
             return out[:n.value]
@@ -486,8 +530,60 @@ class Detector:
             out = np.zeros((n_slots, cap_per_frame), MATCH_DTYPE)
         if counts is None:
             counts = np.zeros(n_slots, np.int32)
+        _check_out(out, 2)
+        _check_counts(counts, n_slots)
+        if out.shape[0] < n_slots or out.shape[1] != cap_per_frame:
+            raise ValueError("out must be [n_slots, cap_per_frame]")
         self._check(self.lib.lm_match_batch(self.h, n_slots, threshold, class_idx, _ptr(out), cap_per_frame, _ptr(counts)))
         return out, counts
+
+    def _class_list(self, classes):
+        c = _c([] if classes is None else classes, np.int32).reshape(-1)
+        return c, _ptr(c) if c.size else None
+
+    def match_batch_classes(self, first_slot, n_slots, threshold, classes=None, cap_per_frame=4096):
+        """Detector::match with upstream's class list: one pre-processing per frame for all the named classes."""
+        out = np.zeros((n_slots, cap_per_frame), MATCH_DTYPE)
+        counts = np.zeros(n_slots, np.int32)
+        c, cp = self._class_list(classes)
+        self._check(self.lib.lm_match_batch_classes(self.h, first_slot, n_slots, threshold, cp, c.size, _ptr(out),
+                                                    cap_per_frame, _ptr(counts)))
+        return out, counts
+
+    def match_prepared(self, first_slot, n_slots, threshold, classes=None, cap_per_frame=4096):
+        """a11-a15 only on slots whose a3-a10 results are current (raises LinemodError otherwise)."""
+        out = np.zeros((n_slots, cap_per_frame), MATCH_DTYPE)
+        counts = np.zeros(n_slots, np.int32)
+        c, cp = self._class_list(classes)
+        self._check(self.lib.lm_match_prepared(self.h, first_slot, n_slots, threshold, cp, c.size, _ptr(out),
+                                               cap_per_frame, _ptr(counts)))
+        return out, counts
+
+    def match_begin_classes(self, lane, first_slot, n_slots, threshold, classes=None):
+        c, cp = self._class_list(classes)
+        self._check(self.lib.lm_match_begin_classes(self.h, lane, first_slot, n_slots, threshold, cp, c.size))
+
+    def pci_bus_id(self):
+        buf = C.create_string_buffer(64)
+        self._check(self.lib.lm_device_pci_bus_id(self.h, buf, 64))
+        return buf.value.decode()
+
+    def comm_info(self):
+        r, w = C.c_int(), C.c_int()
+        self._check(self.lib.lm_comm_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def get_exchange_profile(self):
+        """(accumulated HIP-event microseconds of the gathered path's exchange, number of exchanges)."""
+        us, n = C.c_double(), C.c_int64()
+        self._check(self.lib.lm_get_exchange_profile(self.h, C.byref(us), C.byref(n)))
+        return us.value, n.value
+
+    def get_stage_counts(self):
+        """dict(preprocess_frames, scan_launches, refine_launches, sort_launches) since set_profiling()."""
+        v = (C.c_int64 * 4)()
+        self._check(self.lib.lm_get_stage_counts(self.h, v))
+        return dict(zip(("preprocess_frames", "scan_launches", "refine_launches", "sort_launches"), list(v)))
 
     def synchronize(self):
         """hipDeviceSynchronize on the detector's device."""
@@ -518,6 +614,8 @@ class Detector:
     def match_end_gathered(self, lane, out, counts):
         """-> (first owned frame, n owned frames, total records): merged lists of the frames this rank owns, back to
         back in `out`, lengths in counts[:n]."""
+        _check_out(out)
+        _check_counts(counts, 0)
         f0, nf, n = C.c_int(), C.c_int(), C.c_size_t()
         self._check(self.lib.lm_match_end_gathered(self.h, lane, _ptr(out), out.size, _ptr(counts), C.byref(f0),
                                                    C.byref(nf), C.byref(n)))
@@ -529,6 +627,10 @@ class Detector:
             out = np.zeros((n_slots, cap_per_frame), MATCH_DTYPE)
         if counts is None:
             counts = np.zeros(len(out), np.int32)
+        _check_out(out, 2)
+        _check_counts(counts, 0)
+        if out.shape[1] != cap_per_frame:
+            raise ValueError("out must be [n_slots, cap_per_frame]")
         self._check(self.lib.lm_match_end(self.h, lane, _ptr(out), cap_per_frame, _ptr(counts)))
         return out, counts
 

@@ -2,6 +2,8 @@
 #include "lm_comm.h"
 
 #include <arpa/inet.h>
+#include <fcntl.h>
+#include <poll.h>
 #include <dlfcn.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -10,6 +12,7 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <chrono>
 #include <cstring>
@@ -45,7 +48,38 @@ bool recv_all(int fd, void* p, size_t n) {
     return true;
 }
 
-// rank 0 -> everyone: `n` bytes over TCP.  Every client first sends its rank (sanity), then receives the payload.
+#define LM_RDV_MAGIC 0x4C4D5256   // "LMRV": first word of a peer's handshake
+
+int ms_left(std::chrono::steady_clock::time_point deadline) {
+    const auto d = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+    return d < 0 ? 0 : (int)std::min<long long>(d, 1 << 30);
+}
+
+void set_io_timeout(int fd, int ms) {
+    if (ms < 1) ms = 1;
+    timeval tv; tv.tv_sec = ms / 1000; tv.tv_usec = (ms % 1000) * 1000;
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+}
+
+// connect() that gives up after `ms` milliseconds (non-blocking connect + poll)
+bool connect_timeout(int fd, const sockaddr_in& sa, int ms) {
+    const int fl = fcntl(fd, F_GETFL, 0);
+    fcntl(fd, F_SETFL, fl | O_NONBLOCK);
+    int rc = ::connect(fd, reinterpret_cast<const sockaddr*>(&sa), sizeof(sa));
+    if (rc != 0 && errno == EINPROGRESS) {
+        pollfd pf; pf.fd = fd; pf.events = POLLOUT; pf.revents = 0;
+        if (::poll(&pf, 1, ms) == 1) {
+            int soerr = 0; socklen_t sl = sizeof(soerr);
+            if (getsockopt(fd, SOL_SOCKET, SO_ERROR, &soerr, &sl) == 0 && soerr == 0) rc = 0;
+        }
+    }
+    fcntl(fd, F_SETFL, fl);
+    return rc == 0;
+}
+
+// rank 0 -> everyone: `n` bytes over TCP.  A peer first sends {magic, rank}, then receives the payload.  One overall
+// deadline on every rank; rank 0 drops connections that do not complete the handshake and keeps accepting.
 bool tcp_broadcast(int rank, int world, const char* addr, int port, int timeout_s, void* buf, size_t n, std::string& err) {
     if (world <= 1) return true;
     sockaddr_in sa;
@@ -67,43 +101,59 @@ bool tcp_broadcast(int rank, int world, const char* addr, int port, int timeout_
         if (ls < 0) { err = "socket() failed"; return false; }
         int one = 1;
         setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-        if (::bind(ls, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) != 0 || ::listen(ls, world) != 0) {
+        if (::bind(ls, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) != 0 || ::listen(ls, world + 8) != 0) {
             err = std::string("rendezvous: cannot listen on ") + addr + ":" + std::to_string(port) + ": " + std::strerror(errno);
             ::close(ls);
             return false;
         }
-        timeval tv; tv.tv_sec = timeout_s; tv.tv_usec = 0;
-        setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
         std::vector<bool> seen((size_t)world, false);
-        for (int k = 1; k < world; ++k) {
+        int served = 0, strays = 0;
+        while (served < world - 1) {
+            pollfd pf; pf.fd = ls; pf.events = POLLIN; pf.revents = 0;
+            const int left = ms_left(deadline);
+            const int pr = left > 0 ? ::poll(&pf, 1, left) : 0;
+            if (pr < 0 && errno == EINTR) continue;
+            if (pr <= 0) {
+                err = "rendezvous: timed out after " + std::to_string(timeout_s) + " s with " + std::to_string(served) + " of " +
+                      std::to_string(world - 1) + " peers served (" + std::to_string(strays) + " stray connections ignored)";
+                ::close(ls);
+                return false;
+            }
             int fd = ::accept(ls, nullptr, nullptr);
-            if (fd < 0) { err = "rendezvous: timed out waiting for the other ranks"; ::close(ls); return false; }
-            setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
-            int32_t r = -1;
-            bool ok = recv_all(fd, &r, 4) && r > 0 && r < world && !seen[(size_t)r] && send_all(fd, buf, n);
-            if (ok) seen[(size_t)r] = true;
+            if (fd < 0) continue;
+            // a peer that connects sends its 8 bytes at once: a short timeout keeps a silent stray from eating the deadline
+            set_io_timeout(fd, std::min(ms_left(deadline), 5000));
+            int32_t hs[2] = {0, -1};
+            const bool hello = recv_all(fd, hs, sizeof(hs)) && hs[0] == LM_RDV_MAGIC && hs[1] > 0 && hs[1] < world && !seen[(size_t)hs[1]];
+            if (hello) {
+                set_io_timeout(fd, std::max(ms_left(deadline), 1000));
+                if (send_all(fd, buf, n)) { seen[(size_t)hs[1]] = true; ++served; }
+                // a peer whose connection broke while the payload travelled reconnects (it retries until its deadline)
+            } else {
+                ++strays;
+            }
             ::close(fd);
-            if (!ok) { err = "rendezvous: bad handshake from a peer"; ::close(ls); return false; }
         }
         ::close(ls);
         return true;
     }
+    std::string last = "no attempt made";
     for (;;) {
         int fd = ::socket(AF_INET, SOCK_STREAM, 0);
         if (fd < 0) { err = "socket() failed"; return false; }
-        if (::connect(fd, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) == 0) {
-            timeval tv; tv.tv_sec = timeout_s; tv.tv_usec = 0;
-            setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
-            int32_t r = rank;
-            bool ok = send_all(fd, &r, 4) && recv_all(fd, buf, n);
+        if (connect_timeout(fd, sa, std::min(std::max(ms_left(deadline), 1), 2000))) {
+            set_io_timeout(fd, std::max(ms_left(deadline), 1000));
+            int32_t hs[2] = {LM_RDV_MAGIC, rank};
+            const bool ok = send_all(fd, hs, sizeof(hs)) && recv_all(fd, buf, n);
             ::close(fd);
             if (ok) return true;
-            err = "rendezvous: connection to rank 0 broke";
-            return false;
+            last = "connection to rank 0 broke";
+        } else {
+            ::close(fd);
+            last = "cannot reach rank 0";
         }
-        ::close(fd);
-        if (std::chrono::steady_clock::now() > deadline) {
-            err = std::string("rendezvous: cannot reach rank 0 at ") + addr + ":" + std::to_string(port);
+        if (ms_left(deadline) == 0) {
+            err = std::string("rendezvous: ") + last + " at " + addr + ":" + std::to_string(port) + " within " + std::to_string(timeout_s) + " s";
             return false;
         }
         std::this_thread::sleep_for(std::chrono::milliseconds(50));
@@ -116,9 +166,8 @@ bool lm_tcp_broadcast(int rank, int world, const char* addr, int port, int timeo
     return tcp_broadcast(rank, world, addr, port, timeout_s, buf, n, err);
 }
 
-bool LmComm::init(int rank_, int world_, const char* addr, int port, int timeout_s, std::string& err) {
-    destroy();
-    if (world_ < 1 || rank_ < 0 || rank_ >= world_) { err = "bad rank / world size"; return false; }
+bool LmComm::load(std::string& err) {
+    if (dl) return true;
     const char* names[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
     for (const char* nme : names) { dl = dlopen(nme, RTLD_NOW | RTLD_LOCAL); if (dl) break; }
     if (!dl) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
@@ -127,18 +176,42 @@ bool LmComm::init(int rank_, int world_, const char* addr, int port, int timeout
         fn[i] = dlsym(dl, syms[i]);
         if (!fn[i]) { err = std::string("librccl lacks ") + syms[i]; destroy(); return false; }
     }
-    rank = rank_; world = world_;
+    return true;
+}
+
+bool LmComm::unique_id(void* out, std::string& err) {
+    static_assert(sizeof(ncclUniqueId) == LM_NCCL_ID_BYTES, "ncclUniqueId size");
+    if (!load(err)) return false;
     ncclUniqueId id;
     std::memset(&id, 0, sizeof(id));
-    if (rank == 0) {
-        ncclResult_t r = reinterpret_cast<fn_get_unique_id>(fn[F_UID])(&id);
-        if (r != ncclSuccess) { err = std::string("ncclGetUniqueId: ") + reinterpret_cast<fn_get_error_string>(fn[F_ERRSTR])(r); destroy(); return false; }
-    }
-    if (!tcp_broadcast(rank, world, addr ? addr : "127.0.0.1", port, timeout_s, &id, sizeof(id), err)) { destroy(); return false; }
+    ncclResult_t r = reinterpret_cast<fn_get_unique_id>(fn[F_UID])(&id);
+    if (r != ncclSuccess) { err = std::string("ncclGetUniqueId: ") + reinterpret_cast<fn_get_error_string>(fn[F_ERRSTR])(r); return false; }
+    std::memcpy(out, &id, sizeof(id));
+    return true;
+}
+
+bool LmComm::init_rank(int rank_, int world_, const void* idp, std::string& err) {
+    if (world_ < 1 || rank_ < 0 || rank_ >= world_) { err = "bad rank / world size"; return false; }
+    if (!load(err)) return false;
+    if (comm) { err = "communicator already initialised"; return false; }
+    ncclUniqueId id;
+    std::memcpy(&id, idp, sizeof(id));
     ncclComm_t c = nullptr;
-    ncclResult_t r = reinterpret_cast<fn_comm_init_rank>(fn[F_INIT])(&c, world, id, rank);
-    if (r != ncclSuccess) { err = std::string("ncclCommInitRank: ") + reinterpret_cast<fn_get_error_string>(fn[F_ERRSTR])(r); destroy(); return false; }
+    ncclResult_t r = reinterpret_cast<fn_comm_init_rank>(fn[F_INIT])(&c, world_, id, rank_);
+    if (r != ncclSuccess) { err = std::string("ncclCommInitRank: ") + reinterpret_cast<fn_get_error_string>(fn[F_ERRSTR])(r); return false; }
+    rank = rank_; world = world_;
     comm = c;
+    return true;
+}
+
+bool LmComm::init(int rank_, int world_, const char* addr, int port, int timeout_s, std::string& err) {
+    destroy();
+    if (world_ < 1 || rank_ < 0 || rank_ >= world_) { err = "bad rank / world size"; return false; }
+    unsigned char id[LM_NCCL_ID_BYTES] = {};
+    if (!load(err)) return false;
+    if (rank_ == 0 && !unique_id(id, err)) { destroy(); return false; }
+    if (!tcp_broadcast(rank_, world_, addr ? addr : "127.0.0.1", port, timeout_s, id, sizeof(id), err)) { destroy(); return false; }
+    if (!init_rank(rank_, world_, id, err)) { destroy(); return false; }
     return true;
 }
 

@@ -48,6 +48,7 @@ struct Slot {
     u8* h_bgr = nullptr;     // pinned upload staging
     u16* h_depth = nullptr;
     bool has_frame = false;
+    bool prepared = false;   // a3-a10 have run on the frame the slot holds with the LUTs / thresholds now in force (lm_match_prepared)
     // Uploads run on the detector's copy stream: ev_up is recorded behind the slot's H2D copies, up_seq is the
     // upload's ticket (0 = never uploaded through the copy stream).  Copies complete in ticket order.
     hipEvent_t ev_up = nullptr;
@@ -74,19 +75,20 @@ struct lm_detector {
     // (activate_lane swaps them); lane 0 is active outside lm_match_begin / lm_match_end.
     struct Lane {
         hipStream_t stream = nullptr;
-        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         int* d_raw_thr = nullptr;
         int* h_raw_thr = nullptr;
         float raw_thr_for = -1.0f;
         bool created = false, busy = false, timed = false;
-        int first = 0, n = 0, class_idx = 0;
+        int first = 0, n = 0;
+        std::vector<int> classes;                       // class list of the match in flight ({-1} = all classes)
         unsigned long long waited_seq[LM_NCOPY] = {};   // newest upload ticket per copy stream this lane's stream waits for
     };
     Lane lanes[LM_NLANES];
     int active = 0;
     hipEvent_t blocking_ev[LM_NLANES] = {};           // LM_FLAG_BLOCKING_SYNC: one per lane
     hipStream_t stream = nullptr;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0..4] stage boundaries, [5] behind the exchange
     // H2D copies of lm_upload_frame* go through their own stream so that the frames of step k + 1 travel while
     // the lanes compute step k; a lane's stream waits (hipStreamWaitEvent) for the newest upload among its slots.
     // LM_NCOPY copy streams (slot -> stream round-robin): one in-order stream moved 0.6-0.9 MB copies at 25.6 GB/s
@@ -167,6 +169,8 @@ struct lm_detector {
     double prof_us[4] = {0, 0, 0, 0};
     double prof_scan_bytes = 0;
     long long prof_launches = 0, prof_frames = 0;
+    double prof_exch_us = 0; long long prof_exch_launches = 0;   // pack + 2 x all-gather + D2H of the gathered path (ev[4] -> ev[5])
+    long long cnt_preprocess_frames = 0, cnt_scan_launches = 0, cnt_refine_launches = 0, cnt_sort_launches = 0;   // lm_get_stage_counts
 
     u8* bgr(int slot, int l) const { return frame_arena + (size_t)slot * frame_stride + off_bgr[l]; }
     u16* depth(int slot) const { return reinterpret_cast<u16*>(frame_arena + (size_t)slot * frame_stride + off_depth); }
@@ -455,6 +459,30 @@ int item_range(lm_detector* d, int class_idx, ItemRange* r) {
     return LM_OK;
 }
 
+// Detector::match(..., class_ids): the work-item ranges of a LIST of classes (HighLevelLinemod.cpp:145,152).  {-1} or an
+// empty list = every class (upstream: an empty class_ids vector).  Duplicates are dropped (upstream would emit the
+// class twice and std::unique would remove the copies again); ranges of neighbouring classes are merged, so the usual
+// "all classes of the bank" list is ONE scan launch.  `classes` comes back normalised (sorted, unique).
+int item_ranges(lm_detector* d, std::vector<int>& classes, std::vector<ItemRange>& out) {
+    const int nc = (int)d->bank.classes.size();
+    out.clear();
+    for (int c : classes) if (c < -1 || c >= nc) return fail(LM_ERR_INVALID, "class index out of range");
+    std::sort(classes.begin(), classes.end());
+    classes.erase(std::unique(classes.begin(), classes.end()), classes.end());
+    if (classes.empty() || classes[0] < 0) {
+        if (classes.size() > 1) return fail(LM_ERR_INVALID, "class index -1 (all classes) cannot be combined with others");
+        classes.assign(1, -1);
+        out.push_back(ItemRange{0, (int)d->hb.item_t.size()});
+        return LM_OK;
+    }
+    for (int c : classes) {
+        const int lo = d->hb.class_item_lo[c], hi = d->hb.class_item_hi[c];
+        if (!out.empty() && out.back().lo + out.back().n == lo) out.back().n += hi - lo;
+        else out.push_back(ItemRange{lo, hi - lo});
+    }
+    return LM_OK;
+}
+
 LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r) {
     const int L = d->cfg.pyramid_levels;
     const LmLevelGeom& g = d->geom[L - 1];
@@ -516,10 +544,12 @@ int enqueue_threshold(lm_detector* d, float threshold) {
 }
 
 // a11-a15 on prepared linear memories; the sort kernel publishes the results to host-mapped memory.
-int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, ItemRange r, bool timed) {
+int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, const std::vector<ItemRange>& ranges, bool timed) {
     const int L = d->cfg.pyramid_levels;
     if (timed) HIP_TRY(hipEventRecord(d->ev[1], d->stream));
-    lmk_scan(d->stream, make_scan_args(d, first, r), d->scan_variant, n);
+    // one scan launch per run of neighbouring classes; the launches append to the same candidate lists
+    for (const ItemRange& r : ranges)
+        if (r.n > 0) { lmk_scan(d->stream, make_scan_args(d, first, r), d->scan_variant, n); d->cnt_scan_launches += 1; }
     if (timed) HIP_TRY(hipEventRecord(d->ev[2], d->stream));
     if (L == 1) {
         lmk_emit_unrefined(d->stream, make_refine_args(d, first, 0, threshold), n);
@@ -535,10 +565,12 @@ int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, Item
             LmRefineArgs ra = make_refine_args(d, first, l, threshold);
             ra.plan = plan; ra.plan_cap = plan_cap;
             lmk_refine(d->stream, ra, l == 0, n);
+            d->cnt_refine_launches += 1;
         }
     }
     if (timed) HIP_TRY(hipEventRecord(d->ev[3], d->stream));
     lmk_sort_unique(d->stream, make_sort_args(d, first), n);
+    d->cnt_sort_launches += 1;
     if (timed) HIP_TRY(hipEventRecord(d->ev[4], d->stream));
     HIP_TRY(hipGetLastError());
     return LM_OK;
@@ -564,15 +596,26 @@ int enqueue_upload_wait(lm_detector* d, int first, int n) {
     return LM_OK;
 }
 
-int enqueue_match(lm_detector* d, int first, int n, float threshold, int class_idx, bool timed = false) {
-    ItemRange r;
+// `classes` is normalised in place (item_ranges).  prepared: the slots' a3-a10 results are current (checked by the
+// caller): a11-a15 only.
+int enqueue_match(lm_detector* d, int first, int n, float threshold, std::vector<int>& classes, bool timed = false,
+                  bool prepared = false) {
+    std::vector<ItemRange> ranges;
     int rc;
-    if ((rc = item_range(d, class_idx, &r))) return rc;
+    if ((rc = item_ranges(d, classes, ranges))) return rc;
     if ((rc = enqueue_threshold(d, threshold))) return rc;
     if ((rc = enqueue_upload_wait(d, first, n))) return rc;
     if (timed) HIP_TRY(hipEventRecord(d->ev[0], d->stream));
-    enqueue_preprocess(d, first, n);
-    return enqueue_match_stages(d, first, n, threshold, r, timed);
+    if (!prepared) {
+        enqueue_preprocess(d, first, n);
+        d->cnt_preprocess_frames += n;
+        for (int i = 0; i < n; ++i) d->slots[first + i].prepared = true;
+    }
+    return enqueue_match_stages(d, first, n, threshold, ranges, timed);
+}
+int enqueue_match(lm_detector* d, int first, int n, float threshold, int class_idx, bool timed = false) {
+    std::vector<int> classes(1, class_idx);
+    return enqueue_match(d, first, n, threshold, classes, timed);
 }
 
 inline bool key_less(const u64* a, const u64* b) { return a[0] < b[0] || (a[0] == b[0] && a[1] < b[1]); }
@@ -700,6 +743,7 @@ int upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride
     for (const lm_detector::Lane& ln : d->lanes)
         if (ln.busy && slot >= ln.first && slot < ln.first + ln.n) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
     int rc;
+    s.prepared = false;
     // the slot's previous upload may still be reading the staging buffer (and must land before this one anyway)
     if ((rc = wait_slot_upload(d, s))) return rc;
     if (!pinned && (rc = ensure_staging(d, s))) return rc;
@@ -758,11 +802,11 @@ void activate_lane(lm_detector* d, int l) {
     lm_detector::Lane& cur = d->lanes[d->active];
     cur.stream = d->stream; cur.d_raw_thr = d->d_raw_thr; cur.h_raw_thr = d->h_raw_thr; cur.raw_thr_for = d->raw_thr_for;
     std::memcpy(cur.waited_seq, d->waited_seq, sizeof(cur.waited_seq));
-    for (int k = 0; k < 5; ++k) cur.ev[k] = d->ev[k];
+    for (int k = 0; k < 6; ++k) cur.ev[k] = d->ev[k];
     const lm_detector::Lane& nx = d->lanes[l];
     d->stream = nx.stream; d->d_raw_thr = nx.d_raw_thr; d->h_raw_thr = nx.h_raw_thr; d->raw_thr_for = nx.raw_thr_for;
     std::memcpy(d->waited_seq, nx.waited_seq, sizeof(d->waited_seq));
-    for (int k = 0; k < 5; ++k) d->ev[k] = nx.ev[k];
+    for (int k = 0; k < 6; ++k) d->ev[k] = nx.ev[k];
     d->active = l;
 }
 
@@ -778,14 +822,20 @@ int ensure_lane(lm_detector* d, int l) {
     return LM_OK;
 }
 
-void account_profile(lm_detector* d, int n, int class_idx) {
+void account_profile(lm_detector* d, int n, const std::vector<int>& classes, bool gathered = false) {
     for (int k = 0; k < 4; ++k) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, d->ev[k], d->ev[k + 1]) == hipSuccess) d->prof_us[k] += (double)ms * 1000.0;
     }
+    if (gathered) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, d->ev[4], d->ev[5]) == hipSuccess) { d->prof_exch_us += (double)ms * 1000.0; d->prof_exch_launches += 1; }
+    }
     double b = 0;
-    if (class_idx < 0) for (double v : d->hb.class_alg_bytes) b += v;
-    else if (class_idx < (int)d->hb.class_alg_bytes.size()) b = d->hb.class_alg_bytes[class_idx];
+    for (int c : classes) {
+        if (c < 0) for (double v : d->hb.class_alg_bytes) b += v;
+        else if (c < (int)d->hb.class_alg_bytes.size()) b += d->hb.class_alg_bytes[c];
+    }
     d->prof_scan_bytes += b * n;
     d->prof_launches += 1;
     d->prof_frames += n;
@@ -807,15 +857,21 @@ int wait_stream(lm_detector* d) {
     return LM_OK;
 }
 
-int run_match(lm_detector* d, int first, int n, float threshold, int class_idx) {
+int run_match(lm_detector* d, int first, int n, float threshold, std::vector<int> classes, bool prepared = false) {
     if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    for (int i = 0; i < n; ++i)
+    for (int i = 0; i < n; ++i) {
         if (!d->slots[first + i].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot " + std::to_string(first + i));
+        if (prepared && !d->slots[first + i].prepared)
+            return fail(LM_ERR_INVALID, "slot " + std::to_string(first + i) + " holds no current a3-a10 results: run lm_prepare_slot or a match on it first");
+    }
     int rc;
-    if ((rc = enqueue_match(d, first, n, threshold, class_idx, d->profiling))) return rc;
+    if ((rc = enqueue_match(d, first, n, threshold, classes, d->profiling, prepared))) return rc;
     if ((rc = wait_stream(d))) return rc;
-    if (d->profiling) account_profile(d, n, class_idx);   // HIP events on the launch stream bracket every stage
+    if (d->profiling) account_profile(d, n, classes);   // HIP events on the launch stream bracket every stage
     return LM_OK;
+}
+int run_match(lm_detector* d, int first, int n, float threshold, int class_idx) {
+    return run_match(d, first, n, threshold, std::vector<int>(1, class_idx));
 }
 
 }  // namespace
@@ -944,12 +1000,16 @@ int lm_set_similarity_lut(lm_detector* d, const uint8_t lut[256]) {
     for (int i = 0; i < 256; ++i) if (lut[i] > 4) return fail(LM_ERR_INVALID, "similarity LUT entries must be <= 4 (63*4 must fit a byte)");
     // an empty spread value must score 0: reads past a linear memory land in zero padding (upstream: undefined)
     for (int o = 0; o < 8; ++o) if (lut[32 * o] || lut[32 * o + 16]) return fail(LM_ERR_INVALID, "similarity LUT must map an empty nibble to 0");
-    std::memcpy(d->sim_lut, lut, 256); d->luts_dirty = true; return LM_OK;
+    std::memcpy(d->sim_lut, lut, 256); d->luts_dirty = true;
+    for (Slot& sl : d->slots) sl.prepared = false;
+    return LM_OK;
 }
 int lm_set_normal_lut(lm_detector* d, const uint8_t lut[8000]) {
     if (d && any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (!d || !lut) return fail(LM_ERR_INVALID, "null argument");
-    std::memcpy(d->normal_lut, lut, 8000); d->luts_dirty = true; d->lut_onehot = -1; d->normal_lut_substitute = false; return LM_OK;
+    std::memcpy(d->normal_lut, lut, 8000); d->luts_dirty = true; d->lut_onehot = -1; d->normal_lut_substitute = false;
+    for (Slot& sl : d->slots) sl.prepared = false;
+    return LM_OK;
 }
 int lm_get_similarity_lut(const lm_detector* d, uint8_t lut[256]) { if (!d || !lut) return fail(LM_ERR_INVALID, "null argument"); std::memcpy(lut, d->sim_lut, 256); return LM_OK; }
 int lm_normal_lut_is_substitute(const lm_detector* d) { return (d && d->normal_lut_substitute) ? 1 : 0; }
@@ -998,6 +1058,7 @@ int lm_add_template(lm_detector* d, const char* class_id, const uint8_t* bgr, si
     const int M = c.num_modalities, L = c.pyramid_levels;
     if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride, false, d->stream))) return rc;
     d->slots[0].has_frame = false;  // slot 0 now holds a template image, not a scene frame
+    d->slots[0].prepared = false;
     // quantise every level on the GPU, keeping the gradient magnitude this time
     size_t mag_off[LM_MAX_LEVELS], total = 0;
     for (int l = 0; l < L; ++l) { mag_off[l] = total; total += align_up((size_t)d->lw[l] * d->lh[l] * sizeof(float), 256); }
@@ -1104,7 +1165,7 @@ int lm_upload_frames_pinned(lm_detector* d, int first_slot, int n_slots, const u
         Slot& s = d->slots[first_slot + i];
         if (c.num_modalities == 2) HIP_TRY(hipEventRecord(s.ev_bgr, st));
         HIP_TRY(hipEventRecord(s.ev_up, st));
-        s.up_stream = cs; s.up_seq = seq; s.has_frame = true;
+        s.up_stream = cs; s.up_seq = seq; s.has_frame = true; s.prepared = false;
     }
     return LM_OK;
 }
@@ -1193,6 +1254,7 @@ static int upload_split(lm_detector* d, int slot, const uint8_t* bgr, const uint
     const lm_config& c = d->cfg;
     Slot& s = d->slots[slot];
     int rc;
+    s.prepared = false;
     if ((rc = wait_slot_upload(d, s))) return rc;
     if (!pinned && (rc = ensure_staging(d, s))) return rc;
     const size_t nb = (size_t)c.width * c.height * 3, nd = c.num_modalities == 2 ? (size_t)c.width * c.height * 2 : 0;
@@ -1265,6 +1327,49 @@ int lm_match_batch(lm_detector* d, int n_slots, float threshold, int class_idx, 
     return LM_OK;
 }
 
+// Detector::match(sources, threshold, matches, class_ids) with upstream's class LIST: a3-a10 once per frame, one
+// scan launch per run of neighbouring classes, one refinement, one sort; the lists hold the matches of all the named
+// classes in the total order (HighLevelLinemod.cpp:145,152).
+static int collect_range(lm_detector* d, int first, int n, lm_match_t* out, size_t cap_per_frame, int32_t* counts) {
+    int first_err = LM_OK;
+    std::string first_msg;
+    for (int i = 0; i < n; ++i) {
+        size_t k = 0;
+        int rc = collect_slot(d, first + i, out ? out + (size_t)i * cap_per_frame : nullptr, cap_per_frame, &k);
+        if (counts) counts[i] = (int32_t)k;
+        if (rc && !first_err) { first_err = rc; first_msg = g_err; }
+    }
+    if (first_err) return fail(first_err, first_msg);
+    return LM_OK;
+}
+
+int lm_match_batch_classes(lm_detector* d, int first_slot, int n_slots, float threshold, const int32_t* class_idxs, int n_classes,
+                           lm_match_t* out, size_t cap_per_frame, int32_t* counts) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if ((rc = ensure_bank(d))) return rc;
+    if ((rc = check_slots(d, first_slot, n_slots))) return rc;
+    if (n_classes < 0 || (n_classes && !class_idxs)) return fail(LM_ERR_INVALID, "bad class list");
+    if (n_slots == 0) return LM_OK;
+    if ((rc = run_match(d, first_slot, n_slots, threshold, std::vector<int>(class_idxs, class_idxs + n_classes)))) return rc;
+    return collect_range(d, first_slot, n_slots, out, cap_per_frame, counts);
+}
+
+// a11-a15 only, on slots whose a3-a10 results are current (a match or lm_prepare_slot has run on the frame the slot
+// holds, no upload and no LUT change since): the reference's per-class detect calls on ONE camera frame
+// (PoseDetection.cpp:45-66 per class name) pay the pre-processing once.
+int lm_match_prepared(lm_detector* d, int first_slot, int n_slots, float threshold, const int32_t* class_idxs, int n_classes,
+                      lm_match_t* out, size_t cap_per_frame, int32_t* counts) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if ((rc = ensure_bank(d))) return rc;
+    if ((rc = check_slots(d, first_slot, n_slots))) return rc;
+    if (n_classes < 0 || (n_classes && !class_idxs)) return fail(LM_ERR_INVALID, "bad class list");
+    if (n_slots == 0) return LM_OK;
+    if ((rc = run_match(d, first_slot, n_slots, threshold, std::vector<int>(class_idxs, class_idxs + n_classes), true))) return rc;
+    return collect_range(d, first_slot, n_slots, out, cap_per_frame, counts);
+}
+
 int lm_synchronize(lm_detector* d) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
@@ -1274,7 +1379,7 @@ int lm_synchronize(lm_detector* d) {
 
 static int enqueue_gather(lm_detector* d, int lane, int first, int n);
 
-static int begin_lane(lm_detector* d, int lane, int first_slot, int n_slots, float threshold, int class_idx, bool gathered) {
+static int begin_lane(lm_detector* d, int lane, int first_slot, int n_slots, float threshold, std::vector<int> classes, bool gathered) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
     if (lane < 0 || lane >= LM_NLANES) return fail(LM_ERR_INVALID, "lane out of range (0 .. 3)");
@@ -1293,10 +1398,10 @@ static int begin_lane(lm_detector* d, int lane, int first_slot, int n_slots, flo
         if (!d->slots[first_slot + i].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot " + std::to_string(first_slot + i));
     if ((rc = ensure_lane(d, lane))) return rc;
     activate_lane(d, lane);
-    rc = enqueue_match(d, first_slot, n_slots, threshold, class_idx, d->profiling);
+    rc = enqueue_match(d, first_slot, n_slots, threshold, classes, d->profiling);
     if (!rc && gathered) rc = enqueue_gather(d, lane, first_slot, n_slots);
     if (!rc) {
-        ln.busy = true; ln.first = first_slot; ln.n = n_slots; ln.class_idx = class_idx; ln.timed = d->profiling;
+        ln.busy = true; ln.first = first_slot; ln.n = n_slots; ln.classes = classes; ln.timed = d->profiling;
         d->gather[lane].active = gathered;
     }
     activate_lane(d, 0);
@@ -1304,11 +1409,17 @@ static int begin_lane(lm_detector* d, int lane, int first_slot, int n_slots, flo
 }
 
 int lm_match_begin(lm_detector* d, int lane, int first_slot, int n_slots, float threshold, int class_idx) {
-    return begin_lane(d, lane, first_slot, n_slots, threshold, class_idx, false);
+    return begin_lane(d, lane, first_slot, n_slots, threshold, std::vector<int>(1, class_idx), false);
+}
+
+int lm_match_begin_classes(lm_detector* d, int lane, int first_slot, int n_slots, float threshold, const int32_t* class_idxs,
+                           int n_classes) {
+    if (n_classes < 0 || (n_classes && !class_idxs)) return fail(LM_ERR_INVALID, "bad class list");
+    return begin_lane(d, lane, first_slot, n_slots, threshold, std::vector<int>(class_idxs, class_idxs + n_classes), false);
 }
 
 int lm_match_begin_gathered(lm_detector* d, int lane, int first_slot, int n_slots, float threshold, int class_idx) {
-    return begin_lane(d, lane, first_slot, n_slots, threshold, class_idx, true);
+    return begin_lane(d, lane, first_slot, n_slots, threshold, std::vector<int>(1, class_idx), true);
 }
 
 int lm_match_end(lm_detector* d, int lane, lm_match_t* out, size_t cap_per_frame, int32_t* counts) {
@@ -1320,7 +1431,7 @@ int lm_match_end(lm_detector* d, int lane, lm_match_t* out, size_t cap_per_frame
     HIP_TRY(hipSetDevice(d->cfg.device));
     activate_lane(d, lane);
     const int wrc = wait_stream(d);
-    if (!wrc && ln.timed) account_profile(d, ln.n, ln.class_idx);
+    if (!wrc && ln.timed) account_profile(d, ln.n, ln.classes);
     activate_lane(d, 0);
     ln.busy = false;
     if (wrc) return wrc;
@@ -1418,29 +1529,44 @@ int lm_comm_init(lm_detector* d, int rank, int world, const char* addr, int port
     if ((rc = ready_for_compute(d))) return rc;
     if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     if (d->comm[0]) return fail(LM_ERR_INVALID, "communicator already initialised");
+    if (world < 1 || rank < 0 || rank >= world) return fail(LM_ERR_INVALID, "bad rank / world size");
     if (recs_per_frame_cap <= 0) recs_per_frame_cap = 256;
     if (recs_per_frame_cap > LM_SORT_CAP) recs_per_frame_cap = LM_SORT_CAP;
-    for (int l = 0; l < LM_NLANES; ++l) {
-        LmComm* c = new LmComm();
-        std::string err;
-        if (!c->init(rank, world, addr, port + l, 120, err)) {   // lane l's rendezvous on port + l
-            delete c;
-            for (auto& cc : d->comm) { delete cc; cc = nullptr; }
-            return fail(LM_ERR_HIP, err);
-        }
-        d->comm[l] = c;
-    }
-    d->comm_recs_per_frame = recs_per_frame_cap;
+    // Buffers first, communicators last: a failure on the way leaves NOTHING behind (no communicator without its
+    // buffers -- lm_match_begin_gathered keys on comm[0] -- and the call can simply be repeated).
     const size_t S = d->slots.size(), R = (size_t)world, cap = (size_t)recs_per_frame_cap * S;
-    for (auto& g : d->gather) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_cnt), (S + 1) * sizeof(int)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_rec), cap * sizeof(LmOutMatch)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_all_cnt), R * (S + 1) * sizeof(int)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_all_rec), R * cap * sizeof(LmOutMatch)));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g.h_all_cnt), R * (S + 1) * sizeof(int)));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g.h_all_rec), R * cap * sizeof(LmOutMatch)));
+    auto alloc_all = [&]() -> int {
+        for (auto& g : d->gather) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_cnt), (S + 1) * sizeof(int)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_rec), cap * sizeof(LmOutMatch)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_all_cnt), R * (S + 1) * sizeof(int)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_all_rec), R * cap * sizeof(LmOutMatch)));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g.h_all_cnt), R * (S + 1) * sizeof(int)));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g.h_all_rec), R * cap * sizeof(LmOutMatch)));
+        }
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_red), 64 * sizeof(double)));   // [0, 32) send | [32, 64) receive
+        return LM_OK;
+    };
+    if ((rc = alloc_all())) { const std::string msg = g_err; free_gather(d); return fail(rc, msg); }
+    // ONE rendezvous for the ids of all lanes' communicators (rank 0 draws them), then the ncclCommInitRank calls in
+    // lane order on every rank.
+    LmComm* cs[LM_NLANES] = {};
+    unsigned char ids[LM_NLANES][LM_NCCL_ID_BYTES] = {};
+    std::string err;
+    bool ok = true;
+    for (int l = 0; l < LM_NLANES && ok; ++l) {
+        cs[l] = new LmComm();
+        ok = cs[l]->load(err) && (rank != 0 || cs[l]->unique_id(ids[l], err));
     }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_red), 64 * sizeof(double)));   // [0, 32) send | [32, 64) receive
+    if (ok) ok = lm_tcp_broadcast(rank, world, addr ? addr : "127.0.0.1", port, 120, ids, sizeof(ids), err);
+    for (int l = 0; l < LM_NLANES && ok; ++l) ok = cs[l]->init_rank(rank, world, ids[l], err);
+    if (!ok) {
+        for (auto& c : cs) delete c;
+        free_gather(d);
+        return fail(LM_ERR_HIP, err);
+    }
+    for (int l = 0; l < LM_NLANES; ++l) d->comm[l] = cs[l];
+    d->comm_recs_per_frame = recs_per_frame_cap;
     return LM_OK;
 }
 
@@ -1516,8 +1642,79 @@ static int enqueue_gather(lm_detector* d, int lane, int first, int n) {
     if (!comm->all_gather(g.d_rec, g.d_all_rec, rb, d->stream, err)) return fail(LM_ERR_HIP, err);
     HIP_TRY(hipMemcpyAsync(g.h_all_cnt, g.d_all_cnt, R * cb, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipMemcpyAsync(g.h_all_rec, g.d_all_rec, R * rb, hipMemcpyDeviceToHost, d->stream));
+    if (d->profiling) HIP_TRY(hipEventRecord(d->ev[5], d->stream));   // exchange span = ev[4] (behind the sort) -> ev[5]
     HIP_TRY(hipGetLastError());
     return LM_OK;
+}
+
+// The sized second exchange of the gathered path: some rank's lists did not fit the fixed-capacity gather, or a frame was
+// left to the host sort (> LM_SORT_CAP matches).  The single-GPU path returns such lists (collect_slot), so the sharded
+// one must too (the reference consumes ALL matches, HighLevelLinemod.cpp:206-253).  Every rank: collect its own lists
+// on the host (host sort where needed), all-gather the exact per-frame counts, all-gather the packed records in buffers
+// sized to the largest rank, merge the owned frames.  Synchronous, on the lane's own communicator and stream; this is
+// the slow path of low thresholds, not of the benchmark.
+static int gather_fallback(lm_detector* d, int lane, int first, int n, int f0, int f1, lm_match_t* out, size_t cap,
+                           int32_t* counts, size_t* n_out) {
+    lm_detector::Gather& g = d->gather[lane];
+    LmComm* comm = d->comm[lane];
+    const size_t R = (size_t)comm->world;
+    hipStream_t st = d->lanes[lane].stream ? d->lanes[lane].stream : d->stream;
+    if (lane == 0) st = d->stream;
+    // 1. this rank's lists, exact
+    std::vector<lm_match_t> mine;
+    std::vector<int32_t> my_cnt((size_t)n + 1, 0);
+    int local_rc = LM_OK;
+    std::string local_msg;
+    for (int i = 0; i < n; ++i) {
+        size_t k = 0;
+        int rc = collect_slot(d, first + i, nullptr, 0, &k);           // length (runs the host sort for host-sorted frames)
+        if (!rc) {
+            const size_t at = mine.size();
+            mine.resize(at + k);
+            rc = collect_slot(d, first + i, mine.data() + at, k, &k);
+        }
+        if (rc && !local_rc) { local_rc = rc; local_msg = g_err; }
+        my_cnt[(size_t)i] = (int32_t)k;
+    }
+    my_cnt[(size_t)n] = local_rc ? 4 : 0;                               // status travels with the counts: all ranks agree
+    // 2. exact counts of every rank
+    std::string err;
+    const size_t cb = (size_t)(n + 1) * sizeof(int);
+    HIP_TRY(hipMemcpyAsync(g.d_cnt, my_cnt.data(), cb, hipMemcpyHostToDevice, st));
+    if (!comm->all_gather(g.d_cnt, g.d_all_cnt, cb, st, err)) return fail(LM_ERR_HIP, err);
+    HIP_TRY(hipMemcpyAsync(g.h_all_cnt, g.d_all_cnt, R * cb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<int32_t> cnt(R * (size_t)n);
+    size_t max_total = 1;
+    for (size_t r = 0; r < R; ++r) {
+        const int* c = g.h_all_cnt + r * (size_t)(n + 1);
+        if (c[n]) {
+            if (local_rc) return fail(local_rc, local_msg);
+            return fail(LM_ERR_OVERFLOW, "rank " + std::to_string(r) + " could not deliver its match lists");
+        }
+        size_t tot = 0;
+        for (int i = 0; i < n; ++i) { cnt[r * (size_t)n + (size_t)i] = c[i]; tot += (size_t)c[i]; }
+        max_total = std::max(max_total, tot);
+    }
+    // 3. records, in buffers sized to the largest rank
+    LmOutMatch *d_send = nullptr, *d_recv = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_send), max_total * sizeof(LmOutMatch)));
+    if (hipMalloc(reinterpret_cast<void**>(&d_recv), R * max_total * sizeof(LmOutMatch)) != hipSuccess) {
+        hipFree(d_send);
+        return fail(LM_ERR_HIP, "hipMalloc of the sized exchange buffer failed");   // (every rank allocates the same size)
+    }
+    std::vector<lm_match_t> all(R * max_total);
+    bool ok = true;
+    hipError_t he = hipSuccess;
+    if (!mine.empty()) he = hipMemcpyAsync(d_send, mine.data(), mine.size() * sizeof(lm_match_t), hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) ok = comm->all_gather(d_send, d_recv, max_total * sizeof(LmOutMatch), st, err);
+    if (he == hipSuccess && ok) he = hipMemcpyAsync(all.data(), d_recv, all.size() * sizeof(lm_match_t), hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess && ok) he = hipStreamSynchronize(st);
+    hipFree(d_send); hipFree(d_recv);
+    if (!ok) return fail(LM_ERR_HIP, err);
+    if (he != hipSuccess) return fail(LM_ERR_HIP, std::string("sized exchange: ") + hipGetErrorString(he));
+    // 4. merge the frames this rank owns
+    return lm_merge_frames(all.data(), max_total, cnt.data(), (int)R, n, f0, f1, out, cap, counts, n_out);
 }
 
 int lm_match_end_gathered(lm_detector* d, int lane, lm_match_t* out, size_t cap, int32_t* counts, int* first_frame,
@@ -1530,29 +1727,37 @@ int lm_match_end_gathered(lm_detector* d, int lane, lm_match_t* out, size_t cap,
     HIP_TRY(hipSetDevice(d->cfg.device));
     activate_lane(d, lane);
     const int wrc = wait_stream(d);
-    if (!wrc && ln.timed) account_profile(d, ln.n, ln.class_idx);
+    if (!wrc && ln.timed) account_profile(d, ln.n, ln.classes, true);
     activate_lane(d, 0);
     ln.busy = false; g.active = false;
     if (wrc) return wrc;
     const int n = ln.n, R = d->comm[0]->world, rank = d->comm[0]->rank;
-    // this shard's own capacity overflows first (same messages as the ungathered path)
-    for (int i = 0; i < n; ++i) {
-        const LmHeader h = d->host_block(ln.first + i)->hdr;
-        if (h.cand_count > d->max_cand || h.match_count > d->max_match) { size_t dummy; return collect_slot(d, ln.first + i, nullptr, 0, &dummy); }
-    }
-    std::vector<int32_t> cnt((size_t)R * n);
-    for (int r = 0; r < R; ++r) {
-        const int* c = g.h_all_cnt + (size_t)r * (n + 1);
-        if (c[n] & 2) return fail(LM_ERR_OVERFLOW, "rank " + std::to_string(r) + ": a frame has more than " + std::to_string(LM_SORT_CAP) +
-                                                       " matches, too many for the device-side exchange");
-        if (c[n] & 1) return fail(LM_ERR_OVERFLOW, "rank " + std::to_string(r) + ": the lists of this batch exceed the gather capacity of " +
-                                                       std::to_string(d->comm_recs_per_frame) + " records per frame (lm_comm_init)");
-        std::memcpy(&cnt[(size_t)r * n], c, (size_t)n * sizeof(int32_t));
-    }
     const int f0 = (int)((long long)n * rank / R), f1 = (int)((long long)n * (rank + 1) / R);
     if (first_frame) *first_frame = f0;
     if (n_frames) *n_frames = f1 - f0;
-    return lm_merge_frames(reinterpret_cast<const lm_match_t*>(g.h_all_rec), g.cap_lane, cnt.data(), R, n, f0, f1, out, cap, counts, n_out);
+    // The status words every rank gathered are identical on all ranks, so all ranks take the same branch below (the
+    // fallback holds collectives).  bit 0: a rank's lists did not fit the fixed gather capacity; bit 1: a frame of a
+    // rank has more than LM_SORT_CAP matches (left to the host sort); bit 2: a rank overflowed its own candidate /
+    // match capacity (the single-GPU path fails on that too).
+    int status = 0, bad_rank = -1;
+    std::vector<int32_t> cnt((size_t)R * n);
+    for (int r = 0; r < R; ++r) {
+        const int* c = g.h_all_cnt + (size_t)r * (n + 1);
+        status |= c[n];
+        if ((c[n] & 4) && bad_rank < 0) bad_rank = r;
+        std::memcpy(&cnt[(size_t)r * n], c, (size_t)n * sizeof(int32_t));
+    }
+    if (status & 4) {
+        if (bad_rank == rank)      // this shard's own capacity overflow: same message as the ungathered path
+            for (int i = 0; i < n; ++i) {
+                const LmHeader h = d->host_block(ln.first + i)->hdr;
+                if (h.cand_count > d->max_cand || h.match_count > d->max_match) { size_t dummy; return collect_slot(d, ln.first + i, nullptr, 0, &dummy); }
+            }
+        return fail(LM_ERR_OVERFLOW, "rank " + std::to_string(bad_rank) + " overflowed its candidate / match capacity (raise lm_config.max_candidates / max_matches)");
+    }
+    if (status == 0)
+        return lm_merge_frames(reinterpret_cast<const lm_match_t*>(g.h_all_rec), g.cap_lane, cnt.data(), R, n, f0, f1, out, cap, counts, n_out);
+    return gather_fallback(d, lane, ln.first, n, f0, f1, out, cap, counts, n_out);
 }
 
 int lm_merge_matches(const lm_match_t* lists, const int32_t* counts, int n_lists, size_t stride, lm_match_t* out,
@@ -1824,8 +2029,10 @@ int lm_prepare_slot(lm_detector* d, int slot) {
     if (!d->slots[slot].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
     if ((rc = enqueue_upload_wait(d, slot, 1))) return rc;
     enqueue_preprocess(d, slot, 1);
+    d->cnt_preprocess_frames += 1;
     if ((rc = wait_stream(d))) return rc;
     HIP_TRY(hipGetLastError());
+    d->slots[slot].prepared = true;
     return LM_OK;
 }
 
@@ -1985,6 +2192,8 @@ int lm_set_profiling(lm_detector* d, int enable) {
     d->profiling = enable != 0;
     for (double& v : d->prof_us) v = 0;
     d->prof_scan_bytes = 0; d->prof_launches = 0; d->prof_frames = 0;
+    d->prof_exch_us = 0; d->prof_exch_launches = 0;
+    d->cnt_preprocess_frames = d->cnt_scan_launches = d->cnt_refine_launches = d->cnt_sort_launches = 0;
     return LM_OK;
 }
 
@@ -2032,6 +2241,27 @@ int lm_get_scan_stats(lm_detector* d, uint64_t* features_loaded, uint64_t* featu
     for (int i = 0; i < 1024; ++i) { a += h[2 * i]; b += h[2 * i + 1]; }
     if (features_loaded) *features_loaded = a;
     if (features_unpruned) *features_unpruned = b;
+    return LM_OK;
+}
+
+int lm_get_exchange_profile(lm_detector* d, double* exchange_us, int64_t* launches) {
+    if (!d) return fail(LM_ERR_INVALID, "null detector");
+    if (exchange_us) *exchange_us = d->prof_exch_us;
+    if (launches) *launches = d->prof_exch_launches;
+    return LM_OK;
+}
+
+int lm_get_stage_counts(lm_detector* d, int64_t out[4]) {
+    if (!d || !out) return fail(LM_ERR_INVALID, "null argument");
+    out[0] = d->cnt_preprocess_frames; out[1] = d->cnt_scan_launches; out[2] = d->cnt_refine_launches; out[3] = d->cnt_sort_launches;
+    return LM_OK;
+}
+
+int lm_device_pci_bus_id(lm_detector* d, char* out, size_t cap) {
+    int rc;
+    if (!out || cap < 16) return fail(LM_ERR_INVALID, "buffer too small");
+    if ((rc = ready_for_compute(d))) return rc;
+    HIP_TRY(hipDeviceGetPCIBusId(out, (int)cap, d->cfg.device));
     return LM_OK;
 }
 

@@ -2431,7 +2431,8 @@ __global__ __launch_bounds__(1024) void k_sort_unique(LmSortArgs a) {
         if (tid == 0) {
             hb->hdr.cand_count = cand_count; hb->hdr.match_count = match_count;
             hb->hdr.out_count = 0; hb->hdr.sorted_on_device = 0;
-            hdr->pad[0] = 0xFFFFFFFFu;   // no device-side list for k_pack_lists
+            // no device-side list for k_pack_lists: ...FF = left to the host sort, ...FE = capacity overflow of this shard
+            hdr->pad[0] = (cand_count > a.cand_cap || match_count > a.match_cap) ? 0xFFFFFFFEu : 0xFFFFFFFFu;
         }
         return;
     }
@@ -2534,7 +2535,8 @@ __global__ __launch_bounds__(1024) void k_sort_unique(LmSortArgs a) {
 // ------------------------------------------------------------------------------------------------
 // 8e  Packs the sorted lists of `nslots` frames back to back (what a rank contributes to the all-gather): workgroup i
 // adds up the lengths of the lists before its own and copies list i behind them.  cnt[i] = length of list i,
-// cnt[nslots] = status (0 ok, bit 0: the lists do not fit cap_total records, bit 1: a list was left to the host sort).
+// cnt[nslots] = status (0 ok, bit 0: the lists do not fit cap_total records, bit 1: a list was left to the host sort,
+// bit 2: a slot overflowed its candidate / match capacity).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_lists(LmPackArgs a) {
     __shared__ u32 part[4];
@@ -2542,7 +2544,7 @@ __global__ __launch_bounds__(256) void k_pack_lists(LmPackArgs a) {
     u32 s = 0;
     for (int j = tid; j < slot; j += 256) {
         const u32 c = slot_ptr_s(a.hdr, a.aux_slot_stride, (u32)j)->pad[0];
-        s += c == 0xFFFFFFFFu ? 0u : c;
+        s += c >= 0xFFFFFFFEu ? 0u : c;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += (u32)__shfl_xor((int)s, o, 64);
@@ -2550,7 +2552,7 @@ __global__ __launch_bounds__(256) void k_pack_lists(LmPackArgs a) {
     __syncthreads();
     const u32 prefix = part[0] + part[1] + part[2] + part[3];
     u32 mine = slot_ptr_s(a.hdr, a.aux_slot_stride, (u32)slot)->pad[0];
-    if (mine == 0xFFFFFFFFu) { mine = 0; if (tid == 0) atomicOr(reinterpret_cast<u32*>(a.cnt + a.nslots), 2u); }
+    if (mine >= 0xFFFFFFFEu) { if (tid == 0) atomicOr(reinterpret_cast<u32*>(a.cnt + a.nslots), mine == 0xFFFFFFFEu ? 4u : 2u); mine = 0; }
     if (tid == 0) a.cnt[slot] = (int)mine;
     if (prefix + mine > a.cap_total) { if (tid == 0) atomicOr(reinterpret_cast<u32*>(a.cnt + a.nslots), 1u); return; }
     const u32* src = reinterpret_cast<const u32*>(slot_ptr_s(a.out, a.aux_slot_stride, (u32)slot));

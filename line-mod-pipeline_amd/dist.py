@@ -30,7 +30,9 @@ class ShardGather:
     BATCH: the per-frame counts of every rank ([R, B] int32), then the packed records padded to the
     largest rank total of this batch (rounded up so the buffers are reused).  The merge of all frames is
     one call (`merge_batch_fn`, lm_merge_batch: threaded R-way merge + unique); with only the per-frame
-    `merge_fn` it falls back to a Python loop."""
+    `merge_fn` it falls back to a Python loop.  There is no per-frame capacity: the second collective is sized to the
+    largest rank total of the batch, so whatever the local matcher returns is exchanged (the reference consumes ALL
+    matches, HighLevelLinemod.cpp:206-253); `cap` is kept for callers that size their own buffers with it."""
 
     GRANULE = 4096      # records; gather buffers grow in these steps
 
@@ -73,9 +75,8 @@ class ShardGather:
         match arrays, identical on every rank."""
         B = len(counts)
         counts = np.ascontiguousarray(counts, dtype=np.int32)
-        if int(counts.max(initial=0)) > self.cap:
-            raise OverflowError("shard produced %d matches for one frame, gather capacity %d "
-                                "(SURVEY.md 8e: K must cover all matches)" % (int(counts.max()), self.cap))
+        if int(counts.max(initial=0)) > records.shape[1]:
+            raise ValueError("a count exceeds the record array's stride")
         if self.world == 1:
             return [records[i, :counts[i]].copy() for i in range(B)]
         return self.gather_merge_packed(self._pack(records, counts), counts)
@@ -90,9 +91,8 @@ class ShardGather:
         (first_frame, lists): the host work of the exchange then does not grow with the number of ranks."""
         B = len(counts)
         counts = np.array(counts, dtype=np.int32)            # writable copy (torch.from_numpy)
-        if int(counts.max(initial=0)) > self.cap:
-            raise OverflowError("shard produced %d matches for one frame, gather capacity %d "
-                                "(SURVEY.md 8e: K must cover all matches)" % (int(counts.max()), self.cap))
+        if int(counts.sum()) != len(packed):
+            raise ValueError("counts do not add up to the packed records")
         if self.world == 1:
             ends = np.cumsum(counts)
             lists = [packed[e - c:e].copy() for e, c in zip(ends, counts)]

@@ -138,6 +138,58 @@ bool HighLevelLineMOD::detectTemplateBatch(std::vector<std::vector<Image>>& in_f
     return any;
 }
 
+bool HighLevelLineMOD::detectTemplatesBatch(std::vector<std::vector<Image>>& in_frames, const std::vector<uint16_t>& in_classNumbers,
+                                            std::vector<std::vector<std::vector<lm_match_t>>>& out_matches,
+                                            std::vector<std::vector<std::vector<std::vector<ObjectPose>>>>& out_poses) {
+    const int n = (int)in_frames.size();
+    const size_t nc = in_classNumbers.size();
+    out_matches.assign(nc, std::vector<std::vector<lm_match_t>>((size_t)n));
+    out_poses.assign(nc, std::vector<std::vector<std::vector<ObjectPose>>>((size_t)n));
+    if (n == 0 || nc == 0) return false;
+    for (int i = 0; i < n; ++i) {
+        if (in_frames[(size_t)i].empty()) { error = "no images"; return false; }
+        const Image& color = in_frames[(size_t)i][0];
+        const Image* depth_img = in_frames[(size_t)i].size() >= 2 ? &in_frames[(size_t)i][1] : nullptr;
+        const Image* match_depth = onlyColorModality ? nullptr : depth_img;
+        if (color.width != videoWidth || color.height != videoHeight) { error = "frame size differs from the detector's"; return false; }
+        if (lm_upload_frame(detector, i, static_cast<const uint8_t*>(color.data), color.stride,
+                            match_depth ? static_cast<const uint16_t*>(match_depth->data) : nullptr,
+                            match_depth ? match_depth->stride : 0) != LM_OK) { error = lm_last_error(); return false; }
+    }
+    std::vector<int32_t> cls(in_classNumbers.begin(), in_classNumbers.end());
+    size_t cap = 4096;
+    std::vector<lm_match_t> buf;
+    std::vector<int32_t> counts((size_t)n);
+    for (;;) {
+        buf.resize(cap * (size_t)n);
+        int rc = lm_match_batch_classes(detector, 0, n, detectorThreshold, cls.data(), (int)cls.size(), buf.data(), cap, counts.data());
+        size_t need = 0;
+        for (int32_t c : counts) need = std::max(need, (size_t)c);
+        if (rc == LM_ERR_OVERFLOW && need > cap) {
+            // the frames are still resident and prepared: only a11-a15 run again (the reference consumes ALL matches)
+            cap = need;
+            buf.resize(cap * (size_t)n);
+            rc = lm_match_prepared(detector, 0, n, detectorThreshold, cls.data(), (int)cls.size(), buf.data(), cap, counts.data());
+        }
+        if (rc != LM_OK) { error = lm_last_error(); return false; }
+        break;
+    }
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        const lm_match_t* m = buf.data() + cap * (size_t)i;
+        // the mixed list is in the total order; a class's sub-list keeps it
+        for (size_t c = 0; c < nc; ++c) {
+            std::vector<lm_match_t>& dst = out_matches[c][(size_t)i];
+            for (int32_t k = 0; k < counts[(size_t)i]; ++k) if (m[k].class_idx == (int32_t)in_classNumbers[c]) dst.push_back(m[k]);
+            if (dst.empty()) continue;
+            any = true;
+            const Image* depth_img = in_frames[(size_t)i].size() >= 2 ? &in_frames[(size_t)i][1] : nullptr;
+            out_poses[c][(size_t)i] = postProcess(dst, in_frames[(size_t)i][0], depth_img, in_classNumbers[c], gpuColorCheck ? i : -1);
+        }
+    }
+    return any;
+}
+
 void HighLevelLineMOD::writeLinemod() {
     // cv::FileStorage fs("linemod_templates.yml.gz", WRITE); detector->write(fs); classes [ { writeClass } ]  (:256-270)
     if (lm_save_yaml(detector, "linemod_templates.yml.gz") != LM_OK) { error = lm_last_error(); std::printf("ERROR::%s\n", error.c_str()); }

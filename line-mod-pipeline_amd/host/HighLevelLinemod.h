@@ -90,6 +90,13 @@ public:
     bool detectTemplateBatch(std::vector<std::vector<Image>>& in_frames, uint16_t in_classNumber,
                              std::vector<std::vector<lm_match_t>>& out_matches,
                              std::vector<std::vector<std::vector<ObjectPose>>>& out_poses);
+    // Several classes against the same batch of frames: upstream's match(sources, threshold, matches, class_ids) takes a
+    // class LIST (:145,152) and builds the linear memories once.  ONE upload and ONE pre-processing (a3-a10) per frame for
+    // all the named classes (lm_match_batch_classes); the mixed lists are split by class and every (class, frame) is
+    // post-processed like detectTemplate does.  out_*[c][i]: class in_classNumbers[c], frame i.
+    bool detectTemplatesBatch(std::vector<std::vector<Image>>& in_frames, const std::vector<uint16_t>& in_classNumbers,
+                              std::vector<std::vector<std::vector<lm_match_t>>>& out_matches,
+                              std::vector<std::vector<std::vector<std::vector<ObjectPose>>>>& out_poses);
     // colour checks of the post-processing on the GPU (default) or on the host (the reference's one-match-at-a-time way)
     void setGpuColorCheck(bool on) { gpuColorCheck = on; }
     // detector frame slots needed by detectTemplateBatch: lm_config.frame_slots (default 8)

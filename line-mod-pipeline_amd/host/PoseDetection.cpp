@@ -92,4 +92,20 @@ void PoseDetection::detectBatch(std::vector<std::vector<Image>>& in_frames, std:
     finalObjectPoses = out.empty() ? std::vector<ObjectPose>() : out.back();
 }
 
+void PoseDetection::detectBatch(std::vector<std::vector<Image>>& in_frames, std::vector<std::string> const& in_classNames,
+                                uint16_t const& in_numberOfObjects, std::vector<std::vector<std::vector<ObjectPose>>>& out) {
+    std::vector<uint16_t> idx;
+    for (const std::string& nme : in_classNames) idx.push_back(findIndexInVector(nme, ids));
+    std::vector<Shifted> bufs(in_frames.size());
+    std::vector<std::vector<Image>> shifted(in_frames.size());
+    for (size_t i = 0; i < in_frames.size(); ++i) shiftFrame(in_frames[i], bufs[i], shifted[i]);
+    std::vector<std::vector<std::vector<lm_match_t>>> m;
+    std::vector<std::vector<std::vector<std::vector<ObjectPose>>>> groups;
+    line->detectTemplatesBatch(shifted, idx, m, groups);
+    out.assign(in_classNames.size(), std::vector<std::vector<ObjectPose>>(in_frames.size()));
+    for (size_t c = 0; c < in_classNames.size(); ++c)
+        for (size_t i = 0; i < in_frames.size(); ++i) pickFinal(groups[c][i], in_numberOfObjects, out[c][i]);
+    finalObjectPoses = (out.empty() || out.back().empty()) ? std::vector<ObjectPose>() : out.back().back();
+}
+
 }  // namespace lmamd

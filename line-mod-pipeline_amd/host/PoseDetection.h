@@ -33,6 +33,12 @@ public:
     // The same for a batch of frames in one pass over the GPU (BASELINE config 5): out[i] = final poses of frame i.
     void detectBatch(std::vector<std::vector<Image>>& in_frames, std::string const& in_className,
                      uint16_t const& in_numberOfObjects, std::vector<std::vector<ObjectPose>>& out_objPoses);
+    // Several objects in the same batch of frames (BASELINE config 5: >= 3 models): one upload and one pre-processing per
+    // frame for ALL the classes (the reference calls detect once per class name on the same camera frame and pays
+    // Detector::match's pyramid each time, PoseDetection.cpp:45-66).  out[c][i] = final poses of class in_classNames[c] in
+    // frame i.
+    void detectBatch(std::vector<std::vector<Image>>& in_frames, std::vector<std::string> const& in_classNames,
+                     uint16_t const& in_numberOfObjects, std::vector<std::vector<std::vector<ObjectPose>>>& out_objPoses);
     const std::vector<ObjectPose>& getFinalObjectPoses() const { return finalObjectPoses; }
 
 private:

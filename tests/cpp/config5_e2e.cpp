@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <string>
 #include <vector>
 
 #include "../../line-mod-pipeline_amd/host/HighLevelLinemod.h"
@@ -124,20 +125,41 @@ int main(int argc, char** argv) {
         std::printf("counts %zu %zu hull %ld both %ld\n", total, bad, sum_hull, sum_both);
     }
 
-    // ---- the whole path, colour checks on the GPU and on the host
+    // ---- the whole path, colour checks on the GPU and on the host: ALL THREE classes in one detectBatch = one upload and
+    // one pre-processing (a3-a10) per frame for the three classes (lm_match_batch_classes); "percls" = the older
+    // one-call-per-class path, whose poses must be the same
+    const std::vector<std::string> all_names = {names[0], names[1], names[2]};
     for (int mode = 0; mode < 2; ++mode) {
         line.setGpuColorCheck(mode == 0);
+        lm_set_profiling(line.handle(), 0);        // resets the stage counters
+        std::vector<std::vector<std::vector<ObjectPose>>> poses;
+        pd.detectBatch(frames, all_names, 1, poses);
+        int64_t sc[4];
+        lm_get_stage_counts(line.handle(), sc);
+        std::printf("stagecounts %s preprocess_frames %lld scan_launches %lld refine_launches %lld sort_launches %lld\n", mode == 0 ? "gpu" : "host",
+                    (long long)sc[0], (long long)sc[1], (long long)sc[2], (long long)sc[3]);
         for (int c = 0; c < 3; ++c) {
-            std::vector<std::vector<ObjectPose>> poses;
-            pd.detectBatch(frames, names[c], 1, poses);
             for (int i = 0; i < NF; ++i) {
-                std::printf("%s frame %d class %d placed %d %d poses %zu", mode == 0 ? "gpu" : "host", i, c, placed[i][c][0], placed[i][c][1], poses[i].size());
-                for (const ObjectPose& p : poses[i])
+                std::printf("%s frame %d class %d placed %d %d poses %zu", mode == 0 ? "gpu" : "host", i, c, placed[i][c][0], placed[i][c][1], poses[c][i].size());
+                for (const ObjectPose& p : poses[c][i])
                     std::printf(" t %.9g %.9g %.9g q %.9g %.9g %.9g %.9g bb %d %d %d %d", p.translation.x, p.translation.y, p.translation.z,
                                 p.quaternions.w, p.quaternions.x, p.quaternions.y, p.quaternions.z, p.boundingBox.x, p.boundingBox.y,
                                 p.boundingBox.width, p.boundingBox.height);
                 std::printf("\n");
             }
+        }
+    }
+    line.setGpuColorCheck(true);
+    for (int c = 0; c < 3; ++c) {
+        std::vector<std::vector<ObjectPose>> poses;
+        pd.detectBatch(frames, std::string(names[c]), 1, poses);
+        for (int i = 0; i < NF; ++i) {
+            std::printf("percls frame %d class %d placed %d %d poses %zu", i, c, placed[i][c][0], placed[i][c][1], poses[i].size());
+            for (const ObjectPose& p : poses[i])
+                std::printf(" t %.9g %.9g %.9g q %.9g %.9g %.9g %.9g bb %d %d %d %d", p.translation.x, p.translation.y, p.translation.z,
+                            p.quaternions.w, p.quaternions.x, p.quaternions.y, p.quaternions.z, p.boundingBox.x, p.boundingBox.y,
+                            p.boundingBox.width, p.boundingBox.height);
+            std::printf("\n");
         }
     }
     if (!line.lastError().empty()) std::printf("last error: %s\n", line.lastError().c_str());

@@ -57,13 +57,18 @@ def main():
     for i in range(B):
         full = o.match(frames[i][0], frames[i][1], thr, 0)
         ok &= len(full) > 0 and merged[i].tobytes() == full.tobytes() and merged2[i].tobytes() == full.tobytes()
-    # capacity overflow must be loud (K must cover all matches)
-    small = distmod.ShardGather(lm.merge_matches, cap=1)
-    try:
-        small.gather_merge(*local_match(B, thr, 0))
-        ok = False
-    except OverflowError:
-        pass
+    # a list longer than any fixed capacity (threshold 0: every template matches everywhere it was a candidate, far more
+    # than the 4096 records a device-sorted list holds) is exchanged like any other: the sharded path never refuses what
+    # the unsharded one returns (the reference consumes ALL matches, HighLevelLinemod.cpp:206-253)
+    big = 1 << 16
+    m0 = o.match(frames[0][0], frames[0][1], 0.0, 0, tid_lo=lo, tid_hi=hi)
+    full0 = o.match(frames[0][0], frames[0][1], 0.0, 0)
+    ok &= len(full0) > 4096 and len(m0) <= big
+    rec0 = np.zeros((1, big), lm.MATCH_DTYPE)
+    rec0[0, :len(m0)] = m0
+    small = distmod.ShardGather(lm.merge_matches, cap=1, pack_fn=lm.pack_matches, merge_batch_fn=lm.merge_batch)
+    got0 = small.gather_merge(rec0, np.array([len(m0)], np.int32))
+    ok &= got0[0].tobytes() == full0.tobytes()
     dist.barrier()
     dist.destroy_process_group()
     print("RANK %d %s" % (rank, "OK" if ok else "FAIL"), flush=True)

@@ -71,3 +71,70 @@ def test_bench_two_ranks_functional():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["templates_total"] == 600 and d["value"] > 0
     assert d["config"]["matches_frame0"] > 0          # merged list of both shards for frame 0
+
+
+@pytest.mark.gpu
+def test_bench_launcher_two_ranks_functional():
+    """Plain `python bench.py --gpus 2` (no torchrun, WORLD_SIZE unset): the parent starts the two ranks itself and relays
+    rank 0's line (here with the exchange over gloo, the box has one GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--functional-gloo"] + SMALL,
+                       capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["templates_total"] == 600 and d["config"]["functional_gloo"] is True
+    assert d["config"]["matches_frame0"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_launcher_refuses_two_ranks_on_one_gpu():
+    """On a 1-GPU box `bench.py --gpus 2` must fail loudly instead of printing a 1-GPU number labelled n_gpus: 2
+    (VERDICT r2 #1): rank 1 finds no second device, the launcher stops the other rank, exit code non-zero, no JSON."""
+    import importlib
+    lm = importlib.import_module("line-mod-pipeline_amd")
+    probe = lm.Detector(color_only=True, width=64, height=64, device=1)
+    try:
+        probe.prepare_slot(0)
+    except lm.LinemodError as e:
+        if "no frame" in str(e):
+            pytest.skip("this box has a second GPU")
+    finally:
+        probe.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL,
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert "rank" in r.stderr and "void" in r.stderr
+
+
+def test_bench_launcher_without_gpu_fails_loudly():
+    """CPU container: no HIP device -> every rank fails, the launcher reports it, no JSON line, non-zero exit."""
+    import importlib
+    lm = importlib.import_module("line-mod-pipeline_amd")
+    probe = lm.Detector(color_only=True, width=64, height=64)
+    try:
+        probe.prepare_slot(0)
+        pytest.skip("a HIP device is present")
+    except lm.LinemodError as e:
+        if e.code != lm.LM_ERR_NO_DEVICE:
+            pytest.skip("a HIP device is present")
+    finally:
+        probe.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL,
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert "void" in r.stderr
+
+
+def test_bench_rejects_mismatched_world_size():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"] + SMALL,
+                       capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL,       # --gpus defaults to 1
+                       capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr

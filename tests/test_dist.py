@@ -109,3 +109,54 @@ def test_rendezvous_broadcast_multiprocess(world, lm):
     for r, p in enumerate(procs):
         out, err = p.communicate(timeout=120)
         assert p.returncode == 0 and "RANK %d OK" % r in out, err[-2000:]
+
+
+def test_rendezvous_ignores_stray_connections(lm):
+    """rank 0 must not abort the rendezvous because something that is not a peer connects (port scanner, a
+    stale process of an earlier run): it drops the connection and keeps accepting under its one deadline."""
+    import time
+    port = _free_port()
+    code = (
+        "import importlib, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "lm = importlib.import_module('line-mod-pipeline_amd')\n"
+        "rank, port = int(sys.argv[1]), int(sys.argv[2])\n"
+        "payload = bytes(range(128)) if rank == 0 else bytes(128)\n"
+        "out = lm.rendezvous_broadcast(rank, 2, payload, port=port, timeout_s=30)\n"
+        "assert out == bytes(range(128))\n"
+        "print('RANK %%d OK' %% rank)\n" % ROOT)
+    p0 = subprocess.Popen([sys.executable, "-c", code, "0", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+    # strays: one that says nothing and hangs up, one that sends garbage, one that claims to be rank 0 / out of range
+    deadline = time.time() + 20
+    sent = 0
+    while sent < 3 and time.time() < deadline:
+        try:
+            s = socket.create_connection(("127.0.0.1", port), timeout=1)
+        except OSError:
+            time.sleep(0.1)
+            continue
+        if sent == 1:
+            s.sendall(b"GET / HTTP/1.0\r\n\r\n")
+        elif sent == 2:
+            s.sendall((0x4C4D5256).to_bytes(4, "little") + (7).to_bytes(4, "little"))
+        s.close()
+        sent += 1
+    assert sent == 3
+    p1 = subprocess.Popen([sys.executable, "-c", code, "1", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+    for r, p in enumerate((p0, p1)):
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0 and "RANK %d OK" % r in out, err[-2000:]
+
+
+def test_rendezvous_times_out_under_one_deadline(lm):
+    """A peer that never arrives: rank 0 gives up after timeout_s (one overall deadline), with a message that says how
+    many peers it served."""
+    import time
+    t0 = time.time()
+    with pytest.raises(lm.LinemodError) as e:
+        lm.rendezvous_broadcast(0, 3, bytes(128), port=_free_port(), timeout_s=2)
+    assert time.time() - t0 < 10 and "0 of 2 peers" in str(e.value)
+    t0 = time.time()
+    with pytest.raises(lm.LinemodError):
+        lm.rendezvous_broadcast(1, 2, bytes(128), port=_free_port(), timeout_s=2)     # nobody listens
+    assert time.time() - t0 < 10

@@ -189,6 +189,12 @@ def test_config5_pose_detection_batch_end_to_end(lm, tmp_path):
     gpu = [l[4:] for l in out if l.startswith("gpu frame")]
     hst = [l[5:] for l in out if l.startswith("host frame")]
     assert len(gpu) == 24 and gpu == hst                                 # identical poses, to the last printed digit
+    # three classes in ONE detectBatch: a3-a10 ran once per frame (8), not once per frame and class (24); one scan launch
+    # covers the three neighbouring classes; and the poses equal those of one call per class
+    sc = [l.split() for l in out if l.startswith("stagecounts gpu")][0]
+    assert int(sc[3]) == 8 and int(sc[5]) == 1 and int(sc[9]) == 1, sc
+    per = [l[7:] for l in out if l.startswith("percls frame")]
+    assert per == gpu
     found = 0
     for l in gpu:
         t = l.split()

@@ -67,17 +67,65 @@ def test_gathered_equals_batch_on_single_rank_communicator(lm, orc, synth):
     d.close()
 
 
-def test_gather_capacity_overflow_is_an_error(lm, orc, synth):
+def _gathered_lists(d, lm, lane, first, n, thr, cap=1 << 20):
+    out = np.zeros(cap, lm.MATCH_DTYPE)
+    cnt = np.zeros(n, np.int32)
+    d.match_begin_gathered(lane, first, n, thr, 0)
+    f0, nf, tot = d.match_end_gathered(lane, out, cnt)
+    assert (f0, nf) == (0, n) and tot == cnt.sum()
+    ends = np.cumsum(cnt)
+    return [out[e - c:e].copy() for e, c in zip(ends, cnt)]
+
+
+def test_gather_capacity_overflow_takes_the_sized_exchange(lm, orc, synth):
+    """More records than the fixed gather capacity: the gathered path runs its second, exactly sized exchange and returns
+    what lm_match_batch returns (the reference consumes ALL matches, HighLevelLinemod.cpp:206-253) -- never an error,
+    never a truncation."""
     d, o, frames = _detector(lm, orc, synth)
     thr = 30.0                                           # hundreds of matches per frame
     exp = [o.match(b, dp, thr, 0, threads=8) for b, dp in frames[:2]]
     assert len(exp[0]) + len(exp[1]) > 16
     d.comm_init(0, 1, "127.0.0.1", _free_port(), recs_per_frame_cap=8)
-    out = np.zeros(1 << 16, lm.MATCH_DTYPE)
-    cnt = np.zeros(8, np.int32)
-    d.match_begin_gathered(0, 0, 2, thr, 0)
-    with pytest.raises(lm.LinemodError) as e:
-        d.match_end_gathered(0, out, cnt)
-    assert e.value.code == lm.LM_ERR_OVERFLOW
+    for rnd in range(2):
+        got = _gathered_lists(d, lm, rnd, 0, 2, thr)
+        for g, e in zip(got, exp):
+            assert_matches_equal(g, e)
+    ref, c = d.match_batch(2, thr, 0, cap_per_frame=1 << 15)
+    for i in range(2):
+        assert_matches_equal(got[i], ref[i, :c[i]])
+    # the fast path still works afterwards on the same communicator
+    got = _gathered_lists(d, lm, 0, 0, 2, 95.0)
+    for i in range(2):
+        assert_matches_equal(got[i], o.match(*frames[i], 95.0, 0, threads=8))
+    d.comm_destroy()
+    d.close()
+
+
+def test_gathered_host_sorted_frames(lm, orc, synth):
+    """Threshold 0: far more than the 4096 matches the device sorts per frame; lm_match_batch hands such frames to the
+    host sort, and the gathered path must deliver the same lists (VERDICT r2 missing #5)."""
+    d, o, frames = _detector(lm, orc, synth, slots=8, n_templates=120)
+    ref, c = d.match_batch(3, 0.0, 0, cap_per_frame=1 << 17)
+    assert c.max() > 4096
+    exp = o.match(*frames[0], 0.0, 0, threads=8)
+    assert_matches_equal(ref[0, :c[0]], exp)
+    d.comm_init(0, 1, "127.0.0.1", _free_port())
+    got = _gathered_lists(d, lm, 1, 0, 3, 0.0, cap=1 << 19)
+    for i in range(3):
+        assert_matches_equal(got[i], ref[i, :c[i]])
+    d.comm_destroy()
+    d.close()
+
+
+def test_comm_init_failure_leaves_nothing_behind(lm, orc, synth):
+    """a failed lm_comm_init must be repeatable and must not leave a communicator without buffers."""
+    d, o, frames = _detector(lm, orc, synth, slots=8, n_templates=20)
+    with pytest.raises(lm.LinemodError):
+        d.comm_init(3, 2, "127.0.0.1", _free_port())      # rank outside the world
+    with pytest.raises(lm.LinemodError):
+        d.match_begin_gathered(0, 0, 2, 80.0, 0)          # no communicator: refused, nothing dereferenced
+    d.comm_init(0, 1, "127.0.0.1", _free_port())
+    assert d.comm_info() == (0, 1)
+    _gathered_lists(d, lm, 0, 0, 2, 80.0)
     d.comm_destroy()
     d.close()
