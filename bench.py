@@ -159,8 +159,10 @@ class Runner:
         det.match_begin(0, 0, self.Bl, self.args.threshold, 0)
         det.match_end(0, CAP, out=self.views[0][0][0], counts=self.views[0][0][1])
         loaded, total = det.get_scan_stats()
+        lane_issued, lane_total = det.get_scan_lane_stats()
         det.set_scan_stats(False)
         prof["features_loaded_fraction"] = loaded / total if total else 1.0
+        prof["lane_loads_fraction"] = lane_issued / lane_total if lane_total else 1.0
         return prof
 
     def streaming(self, steps):
@@ -434,7 +436,8 @@ def main():
     # ---- roofline of the dominant kernel (similarity scan)
     kernel = "k_scan4" if not args.byte_responses else "k_scan"
     kept = one_lane.get("features_loaded_fraction", 1.0)
-    l2_bytes = rep["scan_load_bytes"] * Bl * kept      # bytes the scan's vector loads really request per launch
+    kept_lanes = one_lane.get("lane_loads_fraction", kept)
+    l2_bytes = rep["scan_load_bytes"] * Bl * kept_lanes      # bytes the scan's vector loads really request per launch (16 B per active lane)
     span_us = prof["stage_us"][1] / max(prof["launches"], 1)
     alg_bytes = prof["scan_bytes"] / max(prof["launches"], 1)
     ol_us = one_lane["stage_us"][1] / max(one_lane["launches"], 1)
@@ -448,6 +451,7 @@ def main():
         "frac": round(rate(l2_bytes, ol_us) / L2_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "kernel": kernel, "avg_launch_us": round(ol_us, 2), "frames_per_launch": Bl, "load_bytes_per_launch": l2_bytes,
         "pruning": {"enabled": not args.no_prune and not args.byte_responses, "feature_loads_kept": round(kept, 4),
+                    "lane_loads_kept": round(kept_lanes, 4),
                     "note": "exact: a work item stops loading features once partial sum + 4 x features to come cannot "
                             "exceed the raw threshold at any of its positions (same candidate list; bench.py --no-prune "
                             "runs the exhaustive scan); load_bytes_per_launch counts only the loads that were made"},

@@ -370,8 +370,13 @@ int lm_last_counts(lm_detector* det, int slot, uint32_t* candidates, uint32_t* m
  * to device counters (per wave pair of frames; lm_set_scan_stats also zeroes them). */
 int lm_set_scan_stats(lm_detector* det, int enable);
 int lm_get_scan_stats(lm_detector* det, uint64_t* features_loaded, uint64_t* features_unpruned);
+/* The same at lane granularity (nibble kernel): with per-lane pruning a lane none of whose 32 positions can still reach
+ * the threshold leaves the exec mask of the loads that follow.  lane_loads_issued: 16-byte lane-loads really made (a live
+ * lane's right neighbour included); lane_loads_unpruned: 64 x the feature loads of an exhaustive scan. */
+int lm_get_scan_lane_stats(lm_detector* det, uint64_t* lane_loads_issued, uint64_t* lane_loads_unpruned);
 /* Selects the similarity-scan kernel variant used by lm_match* (0 = default; bits 0-1: features per load block;
- * bit 3 (value 8): no pruning, the plain exhaustive scan; see lm_kernels.hip). */
+ * bit 3 (value 8): no pruning, the plain exhaustive scan; bit 4 (value 16): wave-level pruning only, without the
+ * per-lane exec masking; see lm_kernels.hip). */
 int lm_set_scan_variant(lm_detector* det, int variant);
 
 #ifdef __cplusplus

@@ -71,7 +71,7 @@ EXPORTS = [
     "lm_rendezvous_broadcast", "lm_normal_lut_is_substitute",
     "lm_set_scan_stats", "lm_get_scan_stats", "lm_color_check_counts",
     "lm_match_batch_classes", "lm_match_prepared", "lm_match_begin_classes", "lm_device_pci_bus_id",
-    "lm_get_exchange_profile", "lm_get_stage_counts",
+    "lm_get_exchange_profile", "lm_get_stage_counts", "lm_get_scan_lane_stats",
 ]
 
 _lib = None
@@ -169,6 +169,7 @@ def load_library(path=None):
     lib.lm_device_pci_bus_id.argtypes = [vp, C.c_char_p, sz]
     lib.lm_get_exchange_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.lm_get_stage_counts.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.lm_get_scan_lane_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     if path is None:
         _lib = lib
     return lib
@@ -731,6 +732,12 @@ class Detector:
         """(feature loads made, feature loads of an exhaustive scan) since set_scan_stats()."""
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self.lib.lm_get_scan_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def get_scan_lane_stats(self):
+        """(16-byte lane-loads issued, lane-loads of an exhaustive scan) since set_scan_stats()."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.lm_get_scan_lane_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def set_scan_variant(self, variant):

@@ -163,7 +163,7 @@ struct lm_detector {
     u32 max_cand = 0, max_match = 0;
     int scan_variant = 0;
     bool scan_stats = false;                        // lm_set_scan_stats: the scan counts the features it loads
-    unsigned long long* d_scan_stat = nullptr;      // [1024][2]
+    unsigned long long* d_scan_stat = nullptr;      // [1024][4]: features loaded per wave, features of an exhaustive scan, lane-loads issued
     // live profile of lm_match* (lm_set_profiling): per-stage HIP-event time, scan launches and bytes
     bool profiling = false;
     double prof_us[4] = {0, 0, 0, 0};
@@ -272,8 +272,8 @@ int ensure_device(lm_detector* d) {
     // pinned staging for pageable sources is allocated on a slot's first staged upload (ensure_staging): a
     // streaming server that hands over pinned frames (lm_upload_frame_pinned) never needs it
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_resp_tab), 256 * sizeof(u64)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_scan_stat), 2048 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(d->d_scan_stat, 0, 2048 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_scan_stat), 4096 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d->d_scan_stat, 0, 4096 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_sim_lut), 256));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_normal_lut), 8000));
     HIP_TRY(hipDeviceSynchronize());
@@ -2225,7 +2225,7 @@ int lm_set_scan_stats(lm_detector* d, int enable) {
     if ((rc = ready_for_compute(d))) return rc;
     if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(d->d_scan_stat, 0, 2048 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d->d_scan_stat, 0, 4096 * sizeof(unsigned long long)));
     d->scan_stats = enable != 0;
     return LM_OK;
 }
@@ -2234,13 +2234,27 @@ int lm_get_scan_stats(lm_detector* d, uint64_t* features_loaded, uint64_t* featu
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
     if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    std::vector<unsigned long long> h(2048);
+    std::vector<unsigned long long> h(4096);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h.data(), d->d_scan_stat, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long a = 0, b = 0;
-    for (int i = 0; i < 1024; ++i) { a += h[2 * i]; b += h[2 * i + 1]; }
+    for (int i = 0; i < 1024; ++i) { a += h[4 * i]; b += h[4 * i + 1]; }
     if (features_loaded) *features_loaded = a;
     if (features_unpruned) *features_unpruned = b;
+    return LM_OK;
+}
+
+int lm_get_scan_lane_stats(lm_detector* d, uint64_t* lane_loads_issued, uint64_t* lane_loads_unpruned) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    std::vector<unsigned long long> h(4096);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h.data(), d->d_scan_stat, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long a = 0, b = 0;
+    for (int i = 0; i < 1024; ++i) { a += h[4 * i + 2]; b += h[4 * i + 1]; }
+    if (lane_loads_issued) *lane_loads_issued = a;
+    if (lane_loads_unpruned) *lane_loads_unpruned = 64ull * b;
     return LM_OK;
 }
 

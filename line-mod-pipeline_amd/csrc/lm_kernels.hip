@@ -1849,7 +1849,15 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
 // configs 2 / 3, every block 50 % / 43 %.)  The candidate list is identical with and without
 // it (tests/test_gpu_match.py::test_scan_pruning_is_exact); at threshold 80 most templates stop after half their
 // features.  a.stat (optional): [0] += features loaded, [1] += features an unpruned scan would load, per wave.
-template <int FB, bool XCD_MAP, bool PRUNE>
+//
+// Per-lane pruning (PRUNE == 2, the default; r03).  The same test answers per LANE: a lane none of whose 32 positions can
+// still reach the threshold is dead for the rest of the item.  Dead lanes leave the exec mask of the feature blocks that
+// follow (the vector L1 spends its cycles per quad of ACTIVE lanes of a load, so a wave whose survivors are the few
+// lanes around a real match costs a fraction of a full wave-load); a live lane's right neighbour stays in (it supplies
+// the spill-over dword of the shift), dead lanes can never emit (their true totals are below the threshold whatever
+// their stale registers hold: the hit mask is cleared for them), and the wave stops once no lane is alive -- the
+// wave-level rule of PRUNE == 1 is the special case "all lanes dead".  a.stat[2] counts the lane-loads really issued.
+template <int FB, bool XCD_MAP, int PRUNE>
 __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
     const int lane = threadIdx.x & 63;
     const u32 npairs = ((u32)a.nslots + 1u) >> 1;
@@ -1884,11 +1892,15 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
     // (Pruning the two frames of a wave separately -- the half whose frame is out of reach leaves the exec mask of the
     // loads -- was measured in r02: 3-6 % fewer loads, 4-8 % MORE time; the test is per wave.)
     bool pruned = false;
+    unsigned long long alive = ~0ull;                      // PRUNE == 2: lanes with a position still in reach
+    bool act = true;                                       // this lane loads (alive, or the right neighbour of an alive lane)
+    unsigned long long lane_loads = 0;                     // statistics: lane-loads issued
     for (int m = 0; m < a.M && !pruned; ++m) {
         const u32* offs = a.scan_off + ((size_t)ti * a.M + m) * a.fpad;
         u32 bl[4] = {0, 0, 0, 0}, bh[4] = {0, 0, 0, 0};   // byte lanes: even / odd positions of dword k
 #define LM_SCAN4_BLOCK(NF)                                                                       \
-        {                                                                                        \
+        if (a.stat) lane_loads += (unsigned long long)(NF) * (unsigned long long)__popcll(PRUNE == 2 ? (alive | (alive << 1)) : ~0ull); \
+        if (PRUNE != 2 || act) {                                                                 \
             u32x4 v[NF];                                                                         \
             u32 sh[NF];                                                                          \
             _Pragma("unroll") for (int k = 0; k < NF; ++k) {                                     \
@@ -1922,13 +1934,14 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
                     // first modality, byte sums <= 124: "some byte > B" for B = thr - 4 rem in 0 .. 127 is a carry into bit 7
                     // of byte + (127 - B), no compare per position (B > 124: nothing can reach it; B < 0 was excluded above)
                     const int B = thr - 4 * rem;
-                    bool any_left = false;
+                    unsigned long long left = 0;
                     if (B <= 124) {
                         const u32 K = (u32)(127 - B) * 0x01010101u;
                         const u32 y = (bl[0] + K) | (bl[1] + K) | (bl[2] + K) | (bl[3] + K) | (bh[0] + K) | (bh[1] + K) | (bh[2] + K) | (bh[3] + K);
-                        any_left = __any((y & 0x80808080u) != 0u);
+                        left = __ballot((y & 0x80808080u) != 0u) & alive;
                     }
-                    if (!any_left) { f_done += f + FB; pruned = true; break; }
+                    if (!left) { f_done += f + FB; pruned = true; break; }
+                    if (PRUNE == 2) { alive = left; act = (((left | (left << 1)) >> lane) & 1ull) != 0; }
                     continue;
                 }
                 // largest partial sum of the lane: t (earlier modalities) + this modality's byte lanes
@@ -1940,7 +1953,9 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
                     mx = pk_max_u16(mx, pk_max_u16(pk_max_u16(s0, s1), pk_max_u16(s2, s3)));
                 }
                 const int best = (int)max(mx & 0xFFFFu, mx >> 16);
-                if (!__any(best + 4 * (f_in_all - f_done - (f + FB)) > thr)) { f_done += f + FB; pruned = true; break; }
+                const unsigned long long left = __ballot(best + 4 * (f_in_all - f_done - (f + FB)) > thr) & alive;
+                if (!left) { f_done += f + FB; pruned = true; break; }
+                if (PRUNE == 2) { alive = left; act = (((left | (left << 1)) >> lane) & 1ull) != 0; }
             }
         }
         if (pruned) break;
@@ -1960,12 +1975,15 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) mx = pk_max_u16(mx, pk_max_u16(pk_max_u16(t[k][0], t[k][1]), pk_max_u16(t[k][2], t[k][3])));
             const int best = (int)max(mx & 0xFFFFu, mx >> 16);
-            if (!__any(best + 4 * (f_in_all - f_done) > thr)) pruned = true;
+            const unsigned long long left = __ballot(best + 4 * (f_in_all - f_done) > thr) & alive;
+            if (!left) pruned = true;
+            else if (PRUNE == 2) { alive = left; act = (((left | (left << 1)) >> lane) & 1ull) != 0; }
         }
     }
     if (a.stat && lane == 0) {
-        atomicAdd(&a.stat[2 * (blockIdx.x & 1023u)], (unsigned long long)f_done);
-        atomicAdd(&a.stat[2 * (blockIdx.x & 1023u) + 1], (unsigned long long)f_in_all);
+        atomicAdd(&a.stat[4 * (blockIdx.x & 1023u)], (unsigned long long)f_done);
+        atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 1], (unsigned long long)f_in_all);
+        atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 2], lane_loads);
     }
     if (pruned) return;
     u32 hit = 0;
@@ -1981,6 +1999,7 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
     const int valid = lim - (int)j0;
     if (valid <= 0) hit = 0;
     else if (valid < 32) hit &= (1u << valid) - 1u;
+    if (PRUNE == 2 && !((alive >> lane) & 1ull)) hit = 0;   // a dead lane's registers are stale; its true totals cannot reach the threshold
     if (!__any(hit != 0)) return;
     LmDevHeader* hdr = reinterpret_cast<LmDevHeader*>(reinterpret_cast<u8*>(a.hdr) + (size_t)slot * a.aux_slot_stride);
     LmCand* cand = reinterpret_cast<LmCand*>(reinterpret_cast<u8*>(a.cand) + (size_t)slot * a.aux_slot_stride);
@@ -2930,9 +2949,11 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
         const int npairs = (nslots + 1) / 2;
         dim3 grid((unsigned)(G * npairs), 1, 1);
 #define SCAN4_LAUNCH(FB)                                                                              \
-    do { if (variant & 8) hipLaunchKernelGGL((k_scan4<FB, true, false>), grid, dim3(256), 0, s, a);   \
-         else hipLaunchKernelGGL((k_scan4<FB, true, true>), grid, dim3(256), 0, s, a); } while (0)
-        // variant bits 0-1: features per load block (0: 6, 1: 12, 2: 3); bit 3: no pruning (the plain exhaustive scan)
+    do { if (variant & 8) hipLaunchKernelGGL((k_scan4<FB, true, 0>), grid, dim3(256), 0, s, a);       \
+         else if (variant & 16) hipLaunchKernelGGL((k_scan4<FB, true, 1>), grid, dim3(256), 0, s, a); \
+         else hipLaunchKernelGGL((k_scan4<FB, true, 2>), grid, dim3(256), 0, s, a); } while (0)
+        // variant bits 0-1: features per load block (0: 6, 1: 12, 2: 3); bit 3: no pruning (the plain exhaustive scan);
+        // bit 4: wave-level pruning only (r02's rule; default: per-lane pruning)
         const int fb = variant & 3;
         if (fb == 1) SCAN4_LAUNCH(12); else if (fb == 2) SCAN4_LAUNCH(3); else SCAN4_LAUNCH(6);
 #undef SCAN4_LAUNCH

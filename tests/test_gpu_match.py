@@ -432,20 +432,25 @@ def test_scan_pruning_is_exact(lm, orc, synth, color_only, thr):
     d.prepare_slot(0)
     o.prepare(bgr, dep)
     exp = o.scan_candidates(thr, threads=8)
-    stats = {}
-    for variant in (0, 8):
+    stats, lanes = {}, {}
+    for variant in (0, 16, 8):                                  # per-lane pruning (default), wave-level pruning (r02), none
         d.set_scan_variant(variant)
         d.set_scan_stats(True)
         assert np.array_equal(d.stage_scan(0, thr), exp)
         stats[variant] = d.get_scan_stats()
+        lanes[variant] = d.get_scan_lane_stats()
         d.set_scan_stats(False)
         assert_matches_equal(d.match_slot(0, thr, cap=1 << 16), o.match(bgr, dep, thr, threads=8))
         got, cnt = d.match_batch(2, thr, cap_per_frame=1 << 15)  # two frames per wave: the pair must agree to stop
         assert_matches_equal(got[0, :cnt[0]], o.match(bgr, dep, thr, threads=8))
     assert stats[8][0] == stats[8][1] == stats[0][1]            # the exhaustive scan loads every in-bounds feature
     assert stats[0][0] <= stats[0][1]
+    assert stats[0][0] == stats[16][0]                          # a wave stops when its last lane dies: the same rule
+    assert lanes[8][0] == lanes[8][1] == 64 * stats[8][1] and lanes[16][0] == 64 * stats[16][0]
+    assert lanes[0][0] <= lanes[16][0]
     if thr >= 80.0:
         assert stats[0][0] < 0.8 * stats[0][1]
+        assert lanes[0][0] < 0.8 * lanes[16][0]                 # dead lanes leave the loads' exec mask
     if thr == 0.0:
         assert stats[0][0] == stats[0][1]                       # nothing can be pruned when every position qualifies
     d.close()
