@@ -1899,6 +1899,7 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
         const u32* offs = a.scan_off + ((size_t)ti * a.M + m) * a.fpad;
         u32 bl[4] = {0, 0, 0, 0}, bh[4] = {0, 0, 0, 0};   // byte lanes: even / odd positions of dword k
 #define LM_SCAN4_BLOCK(NF)                                                                       \
+        {                                                                                        \
         if (a.stat) lane_loads += (unsigned long long)(NF) * (unsigned long long)__popcll(PRUNE == 2 ? (alive | (alive << 1)) : ~0ull); \
         if (PRUNE != 2 || act) {                                                                 \
             u32x4 v[NF];                                                                         \
@@ -1921,6 +1922,7 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
                     bl[q] += nb[q] & 0x0F0F0F0Fu; bh[q] += (nb[q] >> 4) & 0x0F0F0F0Fu;           \
                 }                                                                                \
             }                                                                                    \
+        }                                                                                        \
         }
         const int F = (cnt >> (8 + 8 * m)) & 0xFF;        // in-bounds features of this modality
         // first block boundary at or past the middle of the list: the mid-list test

@@ -409,6 +409,16 @@ inline u8 lm_read(const std::vector<u8>& lm, int ori, size_t block, size_t idx) 
     return idx < block ? lm[(size_t)ori * block + idx] : 0;
 }
 
+// 0: every byte of the similarity sums goes through lm_read (one bounds check per byte: a scalar loop); 1 (default): the
+// bounds check is hoisted out of the inner loops -- the run [base, base + n) is split once into the part inside the
+// orientation's block and the zeros past it -- so the compiler vectorises the byte adds the way upstream's SSE path adds
+// 16 bytes per _mm_add_epi8.  Same sums either way (tests/test_oracle.py); bench.py's cpu_baseline reports both.
+int g_scan_mode = 1;
+}  // namespace
+extern "C" void orc_set_scan_mode(int mode) { g_scan_mode = mode ? 1 : 0; }
+extern "C" int orc_get_scan_mode(void) { return g_scan_mode; }
+namespace {
+
 // accessLinearMemory: returns flat index inside the orientation's block.
 inline size_t lm_index(const orc_feature& f, int T, int W, int H) {
     int grid = (f.y % T) * T + (f.x % T);
@@ -427,7 +437,14 @@ void similarity(const LevelData& L, int m, const Template& t, std::vector<u8>& d
     for (const orc_feature& f : t.features) {
         if (f.x < 0 || f.x >= L.w || f.y < 0 || f.y >= L.h) continue;
         size_t base = lm_index(f, T, W, H);
-        for (int j = 0; j < P; ++j) dst[j] = (u8)(dst[j] + lm_read(L.lm[m], f.label, block, base + j));
+        if (g_scan_mode == 0) {
+            for (int j = 0; j < P; ++j) dst[j] = (u8)(dst[j] + lm_read(L.lm[m], f.label, block, base + j));
+        } else {
+            const int n_in = base < block ? (int)std::min<size_t>((size_t)P, block - base) : 0;   // the rest reads 0
+            const u8* __restrict__ src = L.lm[m].data() + (size_t)f.label * block + base;
+            u8* __restrict__ out = dst.data();
+            for (int j = 0; j < n_in; ++j) out[j] = (u8)(out[j] + src[j]);
+        }
     }
 }
 
@@ -441,9 +458,15 @@ void similarity_local(const LevelData& L, int m, const Template& t, int cx, int 
         f.x += off_x; f.y += off_y;
         if (f.x < 0 || f.y < 0 || f.x >= L.w || f.y >= L.h) continue;
         size_t base = lm_index(f, T, W, H);
-        for (int r = 0; r < 16; ++r)
-            for (int c = 0; c < 16; ++c)
-                dst[r * 16 + c] = (u8)(dst[r * 16 + c] + lm_read(L.lm[m], f.label, block, base + (size_t)r * W + c));
+        if (g_scan_mode == 0 || base + 15 * (size_t)W + 16 > block) {
+            for (int r = 0; r < 16; ++r)
+                for (int c = 0; c < 16; ++c)
+                    dst[r * 16 + c] = (u8)(dst[r * 16 + c] + lm_read(L.lm[m], f.label, block, base + (size_t)r * W + c));
+        } else {   // the whole patch lies inside the block: sixteen 16-byte row adds
+            const u8* __restrict__ src = L.lm[m].data() + (size_t)f.label * block + base;
+            for (int r = 0; r < 16; ++r)
+                for (int c = 0; c < 16; ++c) dst[r * 16 + c] = (u8)(dst[r * 16 + c] + src[(size_t)r * W + c]);
+        }
     }
 }
 

@@ -127,6 +127,10 @@ int64_t orc_get_stage(const orc_detector* d, int what, int level, int modality, 
 /* R-way merge of per-shard sorted match lists + adjacent-unique. */
 int orc_merge(const orc_match* lists, const int32_t* counts, int n_lists, int stride, orc_match* out, int cap);
 
+/* Process-wide: 0 = one bounds check per byte of the similarity sums (scalar), 1 = hoisted bounds check, vectorisable byte
+ * adds (default).  Identical results. */
+void orc_set_scan_mode(int mode);
+int  orc_get_scan_mode(void);
 const char* orc_last_error(void);
 
 #ifdef __cplusplus

@@ -106,8 +106,16 @@ def load(path=None):
     lib.orc_get_stage.restype = C.c_int64
     lib.orc_get_stage.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64]
     lib.orc_merge.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int]
+    lib.orc_set_scan_mode.argtypes = [C.c_int]
+    lib.orc_set_scan_mode.restype = None
     _lib_cache[path] = lib
     return lib
+
+
+def set_scan_mode(mode, lib_path=None):
+    """0: scalar similarity sums, one bounds check per byte (upstream-faithful loop shape); 1 (default): the bounds check
+    hoisted, vectorisable byte adds.  Identical results; process-wide per loaded library."""
+    load(lib_path).orc_set_scan_mode(int(mode))
 
 
 def _ptr(a):

@@ -277,3 +277,27 @@ def test_no_templates_no_matches(orc, frame0):
     bgr, depth = frame0
     det = orc.Detector(color_only=False)
     assert len(det.match(bgr, depth, 80.0)) == 0
+
+
+def test_scan_modes_agree(orc, synth):
+    """The oracle's two shapes of the similarity sums -- one bounds check per byte (scalar) and the hoisted check with
+    vectorisable byte adds (what bench.py's cpu_baseline times beside it) -- give the same candidates and matches,
+    including templates whose scan runs past an orientation's block (reads of 0) and refinement patches at the border."""
+    bgr, depth = synth.make_frame(640, 480, seed=9)
+    o = orc.Detector(color_only=False)
+    o.prepare(bgr, depth)
+    q = {(l, m): o.stage(0, l, m).reshape(480 >> l, 640 >> l) for l in range(2) for m in range(2)}
+    descs, feats, _ = synth.make_bank(60, 2, 2, seed=3, quantized=q, crop_fraction=0.3)
+    o.add_class("c", descs, feats)
+    d2, f2, _ = synth.make_bank(6, 2, 2, seed=5, fixed_l0_size=(620, 470))     # span <= 0 / clamped templates
+    o.add_class("big", d2, f2)
+    res = {}
+    try:
+        for mode in (0, 1):
+            orc.set_scan_mode(mode)
+            res[mode] = (o.scan_candidates(40.0), o.match(bgr, depth, 40.0), o.match(bgr, depth, 0.0, class_idx=1))
+    finally:
+        orc.set_scan_mode(1)
+    assert len(res[0][1]) > 0
+    for a, b in zip(res[0], res[1]):
+        assert a.tobytes() == b.tobytes()
