@@ -909,6 +909,10 @@ int lm_create(const lm_config* cfg, lm_detector** out) {
     if (c.max_matches <= 0) c.max_matches = 1 << 18;
     if (c.frame_slots <= 0) c.frame_slots = 8;
     if (c.frame_slots > 1024) return fail(LM_ERR_INVALID, "frame_slots out of range");
+    {
+        std::string why;   // negative / non-finite thresholds would select kernel paths that were never meant to see them
+        if (!lmh::check_modality_params(c, why)) return fail(LM_ERR_INVALID, why);
+    }
     lm_detector* d = new lm_detector();
     d->cfg = c;
     d->max_cand = (u32)c.max_candidates;
@@ -1504,7 +1508,10 @@ int lm_color_check_counts(lm_detector* d, int slot, const double lower_hsv[3], c
     a.class_base = d->d_hull_class_base; a.hull_off = d->d_hull_off; a.hull_xy = d->d_hull_xy;
     a.mask = mask; a.wpr = d->cmask_wpr; a.w = d->cfg.width; a.h = d->cfg.height;
     a.out = reinterpret_cast<long long*>(base + mb);
-    lmk_hull_counts(d->stream, a);
+    if (!lmk_hull_counts(d->stream, a)) {
+        (void)wait_stream(d);
+        return fail(LM_ERR_INVALID, "frame too tall for the GPU colour check (more than 4992 rows): use the host colour check");
+    }
     std::vector<long long> out(2 * n);
     HIP_TRY(hipMemcpyAsync(out.data(), a.out, out.size() * sizeof(long long), hipMemcpyDeviceToHost, d->stream));
     if ((rc = wait_stream(d))) return rc;

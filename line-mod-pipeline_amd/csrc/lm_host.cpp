@@ -21,6 +21,38 @@ int Bank::add_pyramid(const std::string& id, TemplatePyramid&& tp) {
     return (int)classes[ci].pyramids.size() - 1;
 }
 
+bool check_template_pyramid(const TemplatePyramid& tp, int levels, int modalities, std::string& err) {
+    if (levels < 1 || modalities < 1 || tp.size() != (size_t)levels * (size_t)modalities) { err = "a pyramid needs levels x modalities templates"; return false; }
+    for (int l = 0; l < levels; ++l) {
+        size_t nf = 0;
+        for (int m = 0; m < modalities; ++m) {
+            const Template& t = tp[(size_t)l * modalities + m];
+            if (t.pyramid_level != l) { err = "templates must be ordered [level*M + modality]"; return false; }
+            if (t.width < 0 || t.height < 0 || t.width > 32767 || t.height > 32767) { err = "template size outside 0..32767"; return false; }
+            if (t.features.size() > LM_MAX_FEATURES) { err = "template with more than 63 features (upstream CV_Assert(features.size() <= 63))"; return false; }
+            for (const lm_feature& ft : t.features) {
+                if (ft.label < 0 || ft.label > 7) { err = "feature label outside 0..7"; return false; }
+                if (ft.x < 0 || ft.y < 0 || ft.x > 32767 || ft.y > 32767) { err = "feature coordinate outside 0..32767"; return false; }
+            }
+            nf += t.features.size();
+        }
+        if (nf == 0) { err = "template without features at a pyramid level (similarity would divide by zero)"; return false; }
+    }
+    return true;
+}
+
+bool check_modality_params(const lm_config& c, std::string& err) {
+    auto fin = [](float v) { return v == v && v >= 0.0f && v < 1e18f; };
+    if (!fin(c.weak_threshold) || !fin(c.strong_threshold)) { err = "ColorGradient thresholds must be finite and >= 0"; return false; }
+    if (c.num_features < 1 || c.num_features > LM_MAX_FEATURES) { err = "ColorGradient num_features must be in 1..63"; return false; }
+    if (c.num_modalities >= 2) {
+        if (c.distance_threshold < 0 || c.difference_threshold < 0) { err = "DepthNormal thresholds must be >= 0"; return false; }
+        if (c.depth_num_features < 1 || c.depth_num_features > LM_MAX_FEATURES) { err = "DepthNormal num_features must be in 1..63"; return false; }
+        if (c.extract_threshold < 0) { err = "DepthNormal extract_threshold must be >= 0"; return false; }
+    }
+    return true;
+}
+
 int Bank::add_class(const std::string& id, int n_templates, const lm_template_desc* descs, const lm_feature* features,
                     int levels, int modalities, std::string& err) {
     const int per = levels * modalities;
@@ -34,6 +66,7 @@ int Bank::add_class(const std::string& id, int n_templates, const lm_template_de
                 return -1;
             }
             if (ds.pyramid_level != k / modalities) { err = "template descs must be ordered [level*M + modality]"; return -1; }
+            if (ds.width < 0 || ds.height < 0 || ds.width > 32767 || ds.height > 32767) { err = "template size outside 0..32767"; return -1; }
             for (int f = 0; f < ds.num_features; ++f) {
                 const lm_feature& ft = features[fo + f];
                 if (ft.label < 0 || ft.label > 7) { err = "feature label outside 0..7"; return -1; }
@@ -115,10 +148,9 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
                 // modality's own value and require them equal.
                 if (t.width != t0.width || t.height != t0.height) { err = "modalities of one pyramid level must share width/height"; return false; }
                 int wf = (t.width - 1) / gl.T + 1, hf = (t.height - 1) / gl.T + 1;
-                int span_x = gl.W - wf, span_y = gl.H - hf;
-                P = span_y * gl.W + span_x + 1;
-                if (P > (int)gl.wh) P = (int)gl.wh;
-                if (P < 0) P = 0;
+                const int span_x = gl.W - wf, span_y = gl.H - hf;
+                const long long P64 = (long long)span_y * gl.W + span_x + 1;
+                P = (int)std::min<long long>(std::max<long long>(P64, 0), (long long)gl.wh);
                 int k = 0;
                 const size_t list_begin = out.scan_off.size();
                 for (const lm_feature& f : t.features) {
@@ -316,17 +348,23 @@ bool load_bank(Bank& bank, const lm_config& cfg, const char* path, std::string& 
     }
     u32 nc = 0;
     if (!rd(fh.f, &nc, 4)) { err = "truncated bank file"; return false; }
+    // counts read from the file size buffers below: none may promise more bytes than the file holds
+    long here = std::ftell(fh.f);
+    if (here < 0 || std::fseek(fh.f, 0, SEEK_END) != 0) { err = "cannot seek in bank file"; return false; }
+    const unsigned long long file_bytes = (unsigned long long)std::ftell(fh.f);
+    if (std::fseek(fh.f, here, SEEK_SET) != 0) { err = "cannot seek in bank file"; return false; }
     Bank nb;
     for (u32 c = 0; c < nc; ++c) {
         u32 len = 0, nt = 0, nf = 0;
         if (!rd(fh.f, &len, 4) || len > 4096) { err = "corrupt bank file"; return false; }
         std::string id(len, '\0');
         if (!rd(fh.f, &id[0], len) || !rd(fh.f, &nt, 4)) { err = "truncated bank file"; return false; }
+        if ((unsigned long long)nt * L * M * sizeof(lm_template_desc) > file_bytes) { err = "corrupt bank file (template count)"; return false; }
         std::vector<lm_template_desc> descs((size_t)nt * L * M);
         if (!rd(fh.f, descs.data(), descs.size() * sizeof(lm_template_desc)) || !rd(fh.f, &nf, 4)) { err = "truncated bank file"; return false; }
         unsigned long long want = 0;
         for (const auto& ds : descs) want += (unsigned)std::max(ds.num_features, 0);
-        if (want != nf) { err = "corrupt bank file (feature count)"; return false; }
+        if (want != nf || (unsigned long long)nf * sizeof(lm_feature) > file_bytes) { err = "corrupt bank file (feature count)"; return false; }
         std::vector<lm_feature> feats(nf);
         if (!rd(fh.f, feats.data(), feats.size() * sizeof(lm_feature))) { err = "truncated bank file"; return false; }
         if (nb.add_class(id, (int)nt, descs.data(), feats.data(), (int)L, (int)M, err) < 0) return false;

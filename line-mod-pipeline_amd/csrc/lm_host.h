@@ -31,6 +31,15 @@ struct Bank {
     int add_pyramid(const std::string& id, TemplatePyramid&& tp);  // returns template id
 };
 
+// What every template pyramid of the bank must satisfy, whoever built it (lm_add_class, lm_load_bank, lm_load_yaml --
+// the YAML reader parses files this library did not write): levels x modalities templates ordered [level * M + modality],
+// at most 63 features each (upstream CV_Assert), at least one feature per level (similarity divides by their number),
+// labels 0..7, coordinates and sizes in 0..32767 (16-bit fields of the device records).
+bool check_template_pyramid(const TemplatePyramid& tp, int levels, int modalities, std::string& err);
+// The modality parameters a detector can run with (lm_create, lm_load_yaml): finite non-negative thresholds, feature
+// counts in 1..63.
+bool check_modality_params(const lm_config& cfg, std::string& err);
+
 // Host image of the device bank of one shard (uploaded verbatim by lm_detector.hip).
 struct DeviceBankHost {
     int fpad = LM_SCAN_FPAD;

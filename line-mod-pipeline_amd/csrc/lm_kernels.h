@@ -146,4 +146,5 @@ struct LmHullArgs {
     int w, h;
     long long* out;              // [n][2]: pixels in the hull, pixels in the hull with the colour bit set
 };
-void lmk_hull_counts(hipStream_t s, const LmHullArgs& a);
+// false: the frame has more rows than the kernel's per-wave row table fits into LDS (nothing was launched)
+bool lmk_hull_counts(hipStream_t s, const LmHullArgs& a);

@@ -1148,7 +1148,7 @@ __device__ __forceinline__ void d_dnormal(const u32 vblock, const u16* __restric
                 R[j][k] = ok ? ld16(row + 16 * k) : u32x4{0, 0, 0, 0};
             }
         }
-        if (diff_thr <= 5461) {
+        if (diff_thr >= 0 && diff_thr <= 5461) {   // (a negative threshold gates every neighbour out: the per-pixel loop below gives f = 0 like the oracle)
             // PACKED taps: two pixels per instruction.  A dword of a depth row is a pixel pair, the neighbours five pixels
             // to the side are one v_alignbit away; |delta| by two saturating subtracts, the gate |delta| < diff_thr by a
             // third, and ci / cj / cx / sx / sy accumulate as i16 pairs (|sx| <= 6 (diff_thr - 1) < 2^15 needs
@@ -2999,10 +2999,24 @@ void lmk_hsv_mask(hipStream_t s, const u8* bgr, int w, int h, const LmHsvRange& 
                        mask, wpr, in_stride, mask_stride);
 }
 
-void lmk_hull_counts(hipStream_t s, const LmHullArgs& a) {
-    if (a.n == 0) return;
+bool lmk_hull_counts(hipStream_t s, const LmHullArgs& a) {
+    if (a.n == 0) return true;
+    // per wave: the hull's vertices + one (left, right) pair per image row
     const size_t shmem = 4 * (size_t)(2 * LM_HULL_MAX + 2 * a.h) * sizeof(int);
+    if (shmem > 160 * 1024) return false;          // more rows than a CU's LDS holds (h > 4992): the caller checks on the host
+    if (shmem > 64 * 1024) {
+        // frames taller than 1920 rows need more than the default 64 KB of dynamic LDS
+        static size_t raised = 0;
+        if (shmem > raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_hull_counts), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+            raised = shmem;
+        }
+    }
     hipLaunchKernelGGL(k_hull_counts, dim3((a.n + 3) / 4), dim3(256), shmem, s, a);
+    return true;
 }
 
 void lmk_pack_lists(hipStream_t s, const LmPackArgs& a) {

@@ -84,9 +84,20 @@ std::string trim(const std::string& s) {
     return s.substr(a, b - a);
 }
 
+// cv::FileStorage files nest a handful of levels (the template file: 9).  Collections nested deeper than this are
+// refused: the parser and the Node destructor recurse once per level, and a hostile or damaged file must not be able to
+// run them off the stack.
+#define LMY_MAX_DEPTH 64
+
 struct Parser {
     std::vector<Line> lines;
     std::string err;
+    int depth = 0;
+    struct Deeper {
+        int& d;
+        explicit Deeper(int& dd) : d(dd) { ++d; }
+        ~Deeper() { --d; }
+    };
 
     bool fail(size_t i, const char* what) {
         err = std::string(what) + " near: " + (i < lines.size() ? lines[i].text : std::string("<end of file>"));
@@ -95,6 +106,8 @@ struct Parser {
 
     // flow collection starting at s[pos] == '['; pos is left behind the closing bracket
     bool flow(const std::string& s, size_t& pos, Node& out) {
+        Deeper guard(depth);
+        if (depth > LMY_MAX_DEPTH) { err = "collections nested deeper than " + std::to_string(LMY_MAX_DEPTH) + " levels"; return false; }
         ++pos;
         std::vector<Node> items;
         bool all_num = true;
@@ -160,6 +173,8 @@ struct Parser {
     }
 
     bool block(size_t& i, int indent, Node& out) {
+        Deeper guard(depth);
+        if (depth > LMY_MAX_DEPTH) return fail(i, "collections nested too deeply");
         if (i >= lines.size()) { out.kind = Node::Null; return true; }
         if (lines[i].text[0] == '-' && (lines[i].text.size() == 1 || lines[i].text[1] == ' ')) {
             out.kind = Node::Seq;
@@ -216,6 +231,9 @@ bool parse(const std::string& text, Node& root, std::string& err) {
         std::string body = raw.substr(ind);
         if (body.empty() || body[0] == '%' || body == "---" || body == "...") continue;
         // a flow collection may wrap: join continuation lines until the brackets balance
+        // (the balance is kept incrementally: re-scanning the joined text per line is quadratic in the length of a
+        // collection that never closes; a quote left open across lines makes the count approximate, which only decides
+        // where joining stops -- flow() then reports the malformed collection)
         int bal = bracket_balance(body);
         while (bal > 0 && pos < text.size()) {
             size_t e2 = text.find('\n', pos);
@@ -223,8 +241,10 @@ bool parse(const std::string& text, Node& root, std::string& err) {
             std::string more = text.substr(pos, e2 - pos);
             pos = e2 + 1;
             strip_comment(more);
-            body += " " + trim(more);
-            bal = bracket_balance(body);
+            more = trim(more);
+            bal += bracket_balance(more);
+            body += " ";
+            body += more;
         }
         p.lines.push_back(Line{(int)ind, std::move(body)});
     }
@@ -249,17 +269,23 @@ std::string fs_float(float v) {
 
 const char* modality_name(int m) { return m == 0 ? "ColorGradient" : "DepthNormal"; }
 
+// a double that is an int32 (the cast of anything else is undefined behaviour)
+bool to_int(double d, int* out) {
+    if (!(d >= -2147483648.0 && d <= 2147483647.0)) return false;   // also rejects NaN
+    *out = (int)d;
+    return true;
+}
 bool get_int(const Node& n, const char* key, int* out) {
     const Node* v = n.get(key);
     double d;
     if (!v || !v->number(&d)) return false;
-    *out = (int)d;
-    return true;
+    return to_int(d, out);
 }
 bool get_float(const Node& n, const char* key, float* out) {
     const Node* v = n.get(key);
     double d;
     if (!v || !v->number(&d)) return false;
+    if (!(d >= -3.0e38 && d <= 3.0e38)) return false;
     *out = (float)d;
     return true;
 }
@@ -334,7 +360,7 @@ bool load_templates_yaml(lmh::Bank& bank, lm_config& cfg, const char* path, std:
     if (!T || T->kind != Node::Nums || (int)T->nums.size() != levels) { err = "T missing or not pyramid_levels long"; return false; }
     if (levels != L) { err = "file has " + std::to_string(levels) + " pyramid levels, the detector " + std::to_string(L); return false; }
     for (int l = 0; l < L; ++l)
-        if ((int)T->nums[l] != cfg.T[l]) { err = "T of the file differs from the detector's at level " + std::to_string(l); return false; }
+        if (T->nums[l] != (double)cfg.T[l]) { err = "T of the file differs from the detector's at level " + std::to_string(l); return false; }
     const Node* mods = root.get("modalities");
     if (!mods || mods->kind != Node::Seq || (int)mods->seq.size() != M) { err = "the file's modalities differ from the detector's"; return false; }
     lm_config nc = cfg;
@@ -349,6 +375,7 @@ bool load_templates_yaml(lmh::Bank& bank, lm_config& cfg, const char* path, std:
                   get_int(mn, "num_features", &nc.depth_num_features) && get_int(mn, "extract_threshold", &nc.extract_threshold);
         if (!ok) { err = std::string("incomplete parameters of modality ") + modality_name(m); return false; }
     }
+    if (!lmh::check_modality_params(nc, err)) { err = std::string(path) + ": " + err; return false; }
     // readClass per entry
     const Node* classes = root.get("classes");
     std::vector<lmh::ClassEntry> incoming;
@@ -387,12 +414,16 @@ bool load_templates_yaml(lmh::Bank& bank, lm_config& cfg, const char* path, std:
                             for (const Node& fn : fl->seq) {
                                 if (fn.kind != Node::Nums || fn.nums.size() != 3) { err = "class " + ce.id + ": a feature is [x, y, label]"; return false; }
                                 lm_feature ft;
-                                ft.x = (int)fn.nums[0]; ft.y = (int)fn.nums[1]; ft.label = (int)fn.nums[2];
-                                if (ft.label < 0 || ft.label > 7) { err = "class " + ce.id + ": feature label out of range"; return false; }
+                                if (!to_int(fn.nums[0], &ft.x) || !to_int(fn.nums[1], &ft.y) || !to_int(fn.nums[2], &ft.label)) {
+                                    err = "class " + ce.id + ": feature value is not an integer"; return false;
+                                }
+                                if (t.features.size() >= LM_MAX_FEATURES) { err = "class " + ce.id + ": template with more than 63 features"; return false; }
                                 t.features.push_back(ft);
                             }
                         }
                     }
+                    std::string why;
+                    if (!lmh::check_template_pyramid(tp, L, M, why)) { err = "class " + ce.id + ", template " + std::to_string(tid) + ": " + why; return false; }
                     ce.pyramids.push_back(std::move(tp));
                 }
             }

@@ -382,6 +382,8 @@ std::vector<std::vector<ObjectPose>> PostProcessor::run(const std::vector<lm_mat
         gin.resize(todo.size()); gboth.resize(todo.size());
         if (lm_color_check_counts(det, gpu_slot, props.lowerColorRange, props.upperColorRange, todo.data(), todo.size(),
                                   gin.data(), gboth.data()) != LM_OK) {
+            // loud, never a silent switch of implementation: frames of up to 4992 rows run on the GPU; beyond that the
+            // caller selects the host check (HighLevelLineMOD::setGpuColorCheck(false))
             error = lm_last_error();
             return poses;
         }

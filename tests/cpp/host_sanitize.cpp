@@ -1,0 +1,158 @@
+// Sanitizer driver for the host-only parts of liblinemod_hip.so (csrc/lm_yaml.cpp, lm_host.cpp, lm_extract.cpp): built by
+// tests/test_sanitize.py with g++ -fsanitize=address,undefined (CPU build only; GPU ASan is not available on the pool).
+// lm_load_yaml / lm_load_bank parse files this library did not write (HighLevelLinemod.cpp:292-303 reads whatever
+// linemod_templates.yml.gz is lying around), so valid files are mutated -- truncated, bytes flipped, spans deleted or
+// duplicated, numbers replaced by absurd ones -- and every mutant goes through the parser, the template loader, the
+// device-bank builder and the hull table.  A mutant may be rejected (false + message) or accepted; it must never crash,
+// read out of bounds, overflow, or hang.
+// usage: host_sanitize <opencv_style_templates.yml> <iterations> <seed> <scratch dir>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../line-mod-pipeline_amd/csrc/lm_extract.h"
+#include "../../line-mod-pipeline_amd/csrc/lm_host.h"
+#include "../../line-mod-pipeline_amd/csrc/lm_yaml.h"
+
+static lm_config make_cfg(int M) {
+    lm_config c;
+    std::memset(&c, 0, sizeof(c));
+    c.width = 640; c.height = 480; c.num_modalities = M; c.pyramid_levels = 2;
+    c.T[0] = M == 2 ? 5 : 2; c.T[1] = 8;
+    c.weak_threshold = 10.f; c.num_features = 63; c.strong_threshold = 55.f;
+    c.distance_threshold = 2000; c.difference_threshold = 50; c.depth_num_features = 63; c.extract_threshold = 2;
+    c.shard_rank = 0; c.shard_size = 1;
+    return c;
+}
+
+static void make_geom(const lm_config& c, LmLevelGeom* geom) {   // as lm_create does
+    int w = c.width, h = c.height;
+    for (int l = 0; l < c.pyramid_levels; ++l) {
+        if (l > 0) { w /= 2; h /= 2; }
+        LmLevelGeom& g = geom[l];
+        std::memset(&g, 0, sizeof(g));
+        g.w = w; g.h = h; g.T = c.T[l]; g.W = w / g.T; g.H = h / g.T; g.wh = (u32)g.W * (u32)g.H;
+        g.spread_only = l + 1 < c.pyramid_levels; g.nibble = g.spread_only ? 0 : 1;
+        const size_t pad = ((size_t)g.wh + 16 * (size_t)g.W + 2 * LM_SCAN_CHUNK + 64 + 255) / 256 * 256;
+        const size_t ori = ((((size_t)g.T * g.T * g.wh) >> g.nibble) + 255) / 256 * 256 + pad;
+        g.ori_stride = (u32)ori; g.mod_stride = (u32)(g.spread_only ? ori : 8 * ori);
+        g.zero_off = (u32)((size_t)c.num_modalities * g.mod_stride); g.arena_bytes = g.zero_off + (u32)pad;
+    }
+}
+
+static void digest(const lmh::Bank& bank, const lm_config& cfg) {
+    LmLevelGeom geom[LM_MAX_LEVELS];
+    make_geom(cfg, geom);
+    lmh::DeviceBankHost hb;
+    std::string err;
+    (void)lmh::build_device_bank(bank, cfg, geom, hb, err);
+    lmh::HullTable ht;
+    lmh::build_hull_table(bank, cfg.num_modalities, ht);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 5) return 2;
+    const std::string dir = argv[4];
+    const int iters = std::atoi(argv[2]);
+    std::mt19937 rng((unsigned)std::atoi(argv[3]));
+    std::string text, err;
+    if (!lmy::read_text_file(argv[1], text, err)) { std::printf("cannot read %s: %s\n", argv[1], err.c_str()); return 2; }
+    const lm_config cfg0 = make_cfg(2);
+    // ---- the valid file: parse, load, digest, write, re-load, bank file round trip
+    lmh::Bank good;
+    {
+        lm_config cfg = cfg0;
+        lmy::Node root;
+        if (!lmy::parse(text, root, err) || !lmy::load_templates_yaml(good, cfg, argv[1], err)) { std::printf("valid file rejected: %s\n", err.c_str()); return 1; }
+        digest(good, cfg);
+        const std::string y = dir + "/rt.yml.gz", b = dir + "/rt.bank";
+        lmh::Bank again, again2;
+        if (!lmy::save_templates_yaml(good, cfg, y.c_str(), err) || !lmy::load_templates_yaml(again, cfg, y.c_str(), err)) { std::printf("yaml round trip: %s\n", err.c_str()); return 1; }
+        if (!lmh::save_bank(good, cfg, b.c_str(), err) || !lmh::load_bank(again2, cfg, b.c_str(), err)) { std::printf("bank round trip: %s\n", err.c_str()); return 1; }
+        if (again.classes.size() != good.classes.size() || again2.classes.size() != good.classes.size()) { std::printf("round trip lost classes\n"); return 1; }
+    }
+    std::string bank_bytes;
+    { std::ifstream f(dir + "/rt.bank", std::ios::binary); bank_bytes.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>()); }
+    const char* absurd[] = {"4294967296", "-1", "99999999999999999999", "1e309", "nan", "0x7fffffff", "-2147483648", "[", "]", "{", ":", "- ", "!!opencv-matrix", "\"", "   ", "\t"};
+    auto mutate = [&](std::string s) {
+        const int n = 1 + (int)(rng() % 4);
+        for (int k = 0; k < n && !s.empty(); ++k) {
+            const size_t at = rng() % s.size();
+            switch (rng() % 7) {
+                case 0: s.resize(at); break;                                                     // truncate
+                case 1: s[at] = (char)(rng() & 0xFF); break;                                     // flip a byte
+                case 2: s.erase(at, std::min<size_t>(1 + rng() % 200, s.size() - at)); break;    // delete a span
+                case 3: s.insert(at, s.substr(at, std::min<size_t>(1 + rng() % 300, s.size() - at))); break;   // duplicate a span
+                case 4: { const char* a = absurd[rng() % (sizeof(absurd) / sizeof(*absurd))]; s.insert(at, a); break; }
+                case 5: { size_t e = at; while (e < s.size() && (std::isdigit((unsigned char)s[e]) || s[e] == '-')) ++e;   // replace a number
+                          if (e > at) s.replace(at, e - at, absurd[rng() % 7]); break; }
+                default: { size_t e = s.find('\n', at); if (e != std::string::npos) s.erase(at, e - at); break; }   // cut a line short
+            }
+        }
+        return s;
+    };
+    long accepted = 0, rejected = 0, bank_accepted = 0;
+    for (int it = 0; it < iters; ++it) {
+        // YAML mutant through the parser and the template loader
+        const std::string m = mutate(text), p = dir + "/m.yml";
+        { std::ofstream f(p, std::ios::binary); f.write(m.data(), (std::streamsize)m.size()); }
+        lmy::Node root;
+        std::string e;
+        (void)lmy::parse(m, root, e);
+        lmh::Bank bank;
+        lm_config cfg = cfg0;
+        if (lmy::load_templates_yaml(bank, cfg, p.c_str(), e)) { ++accepted; digest(bank, cfg0); } else ++rejected;
+        // bank-file mutant
+        if ((it & 3) == 0) {
+            const std::string bm = mutate(bank_bytes), bp = dir + "/m.bank";
+            { std::ofstream f(bp, std::ios::binary); f.write(bm.data(), (std::streamsize)bm.size()); }
+            lmh::Bank bb;
+            if (lmh::load_bank(bb, cfg0, bp.c_str(), e)) { ++bank_accepted; digest(bb, cfg0); }
+        }
+    }
+    // ---- pathological shapes: deep nesting (recursion depth), one enormous line, a sea of dashes
+    {
+        std::vector<std::string> evil;
+        evil.push_back("%YAML:1.0\n---\nT: " + std::string(200000, '[') + "\n");
+        evil.push_back("%YAML:1.0\n---\nT: [ " + std::string(200000, '1') + " ]\n");
+        std::string deep = "%YAML:1.0\n---\n";
+        for (int i = 0; i < 20000; ++i) deep += std::string((size_t)i, ' ') + "a:\n";
+        evil.push_back(deep);
+        std::string dashes = "%YAML:1.0\n---\nclasses:\n";
+        for (int i = 0; i < 20000; ++i) dashes += std::string((size_t)(3 * (i % 50 + 1)), ' ') + "-\n";
+        evil.push_back(dashes);
+        for (const std::string& m : evil) {
+            lmy::Node root;
+            std::string e;
+            (void)lmy::parse(m, root, e);
+        }
+    }
+    // ---- feature extraction on random quantised images (lm_extract.cpp)
+    for (int it = 0; it < 20; ++it) {
+        lm_config cfg = make_cfg(1 + (int)(rng() % 2));
+        cfg.width = 64 + 16 * (int)(rng() % 4); cfg.height = 48 + 16 * (int)(rng() % 4);
+        std::vector<lmh::ExtractLevel> lv(2);
+        for (int l = 0; l < 2; ++l) {
+            lv[l].w = cfg.width >> l; lv[l].h = cfg.height >> l;
+            const size_t px = (size_t)lv[l].w * lv[l].h;
+            lv[l].color_q.resize(px); lv[l].color_mag.resize(px);
+            if (cfg.num_modalities == 2) lv[l].depth_q.resize(px);
+            if (it & 1) lv[l].mask.assign(px, 0);
+            for (size_t i = 0; i < px; ++i) {
+                lv[l].color_q[i] = (rng() % 3) ? (u8)(1u << (rng() % 8)) : 0;
+                lv[l].color_mag[i] = (float)(rng() % 20000);
+                if (cfg.num_modalities == 2) lv[l].depth_q[i] = (rng() % 4) ? (u8)(1u << (rng() % 8)) : 0;
+                if (it & 1) lv[l].mask[i] = ((i % lv[l].w) > 5 && (i % lv[l].w) < (size_t)lv[l].w - 6 && i / lv[l].w > 4) ? 255 : 0;
+            }
+        }
+        lmh::TemplatePyramid tp;
+        if (lmh::extract_pyramid(lv, cfg, tp)) (void)lmh::crop_templates(tp);
+    }
+    std::printf("OK yaml mutants accepted %ld rejected %ld, bank mutants accepted %ld\n", accepted, rejected, bank_accepted);
+    return 0;
+}
