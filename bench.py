@@ -85,6 +85,8 @@ class Runner:
         det.add_class("synthetic.ply", self.descs, self.feats)
         if args.fork:
             det.set_tuning(lm.TUNE_FORK_MAX_SLOTS, 1 << 20)
+        if args.no_batch_phases:
+            det.set_tuning(lm.TUNE_BATCH_PHASES, 0)
         if args.no_prune:
             det.set_scan_variant(8)
         elif args.scan_variant:
@@ -324,6 +326,9 @@ def main():
     ap.add_argument("--fork", action="store_true",
                     help="A/B knob: run the three independent pre-processing chains of a lane-step (colour level 0 | pyrDown + "
                          "colour level 1 | depth) on three streams joined by events (LM_TUNE_FORK_MAX_SLOTS)")
+    ap.add_argument("--no-batch-phases", action="store_true",
+                    help="A/B knob: one launch per pre-processing kernel (eleven per lane-step) instead of the four launches of "
+                         "level-fused batch kernels (LM_TUNE_BATCH_PHASES = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the h2d_inclusive (streaming) leg")
     ap.add_argument("--functional-gloo", action="store_true",

@@ -41,6 +41,7 @@ TUNE_COPY_STREAMS = 3
 TUNE_CBLUR_VARIANT = 4
 TUNE_CGRAD_VARIANT = 5
 TUNE_PHASE_MAX_SLOTS = 6
+TUNE_BATCH_PHASES = 7
 
 
 class Rect(C.Structure):

@@ -129,6 +129,7 @@ struct lm_detector {
     int comm_recs_per_frame = 0;
     Gather gather[LM_NLANES];
     double* d_red = nullptr;   // small device buffer of lm_comm_max / lm_comm_barrier
+    int batch_phases = 1;            // calls of 16+ frames run a3-a10 as four launches of level-fused batch kernels (lmk_preprocess_batch_phases)
     int phase_max_slots = 15;        // calls of up to this many frames run a3-a10 as one launch per dependency level (LmPhaseArgs)
     int fork_max_slots = 0;          // measured r02: no gain (host launch rate, 3.4 us per launch, bounds small calls), so off by default
     int fork_depth_wait_slot = -1;   // forked single-frame call: the depth chain's stream waits for this slot's whole upload
@@ -376,8 +377,10 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
     const lm_config& c = d->cfg;
     const int M = c.num_modalities, L = c.pyramid_levels;
     const size_t fs = d->frame_stride;
-    // ---- few frames: one launch per dependency level (lm_kernels.h LmPhaseArgs): 5 launches instead of 14
-    if (n <= d->phase_max_slots && n > d->fork_max_slots && L == 2) {     // (the fork experiment, when switched on, wins)
+    // ---- few frames: one launch per dependency level (lm_kernels.h LmPhaseArgs): 5 launches instead of 14;
+    // ---- batches: the same with the batch kernels, 4 launches instead of 11 (LM_TUNE_BATCH_PHASES)
+    const bool few = n <= d->phase_max_slots;
+    if ((few || (d->batch_phases && n >= 16)) && n > d->fork_max_slots && L == 2) {     // (the fork experiment, when switched on, wins)
         LmPhaseArgs pa{};
         pa.bgr0 = d->bgr(first, 0); pa.bgr1 = d->bgr(first, 1); pa.depth = M == 2 ? d->depth(first) : nullptr;
         pa.cs0 = d->cscratch(first, 0); pa.cs1 = d->cscratch(first, 1); pa.ds = d->dscratch(first);
@@ -389,10 +392,16 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
         pa.normal_lut = d->d_normal_lut; pa.resp_tab = d->d_resp_tab; pa.ori_stride1 = d->geom[1].ori_stride;
         pa.slot_stride = fs; pa.nslots = n;
         auto mode = [&](int l) { return d->geom[l].spread_only ? 1 : d->geom[l].nibble ? 2 : 0; };
-        if (M <= 2 && d->lw[1] * 2 == d->lw[0] && d->lh[1] * 2 == d->lh[0] &&
-            lmk_phases_supported(pa, d->geom[0].T, d->geom[1].T, mode(0), mode(1), M == 2 ? normal_lut_onehot(d) : true)) {
-            lmk_preprocess_phases(d->stream, pa, d->geom[0].T);
-            return;
+        const bool onehot = M == 2 ? normal_lut_onehot(d) : true;
+        if (M <= 2 && d->lw[1] * 2 == d->lw[0] && d->lh[1] * 2 == d->lh[0]) {
+            if (few && lmk_phases_supported(pa, d->geom[0].T, d->geom[1].T, mode(0), mode(1), onehot)) {
+                lmk_preprocess_phases(d->stream, pa, d->geom[0].T);
+                return;
+            }
+            if (!few && lmk_batch_phases_supported(pa, d->geom[0].T, d->geom[1].T, mode(0), mode(1), onehot)) {
+                lmk_preprocess_batch_phases(d->stream, pa, d->geom[0].T);
+                return;
+            }
         }
     }
     // ---- few frames: three concurrent chains (latency-bound regime; measured no gain, off by default)
@@ -1228,6 +1237,7 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
         case LM_TUNE_PHASE_MAX_SLOTS: if (value < 0) break; d->phase_max_slots = value; return LM_OK;
         case LM_TUNE_CGRAD_VARIANT: if (value < 0 || value > 3) break; lmk_set_cgrad_variant(value); return LM_OK;
         case LM_TUNE_COPY_STREAMS: if (value < 1 || value > LM_NCOPY) break; d->n_copy_streams = value; return LM_OK;
+        case LM_TUNE_BATCH_PHASES: if (value < 0 || value > 1) break; d->batch_phases = value; return LM_OK;
         default: return fail(LM_ERR_INVALID, "unknown tuning key");
     }
     return fail(LM_ERR_INVALID, "tuning value out of range");

@@ -136,6 +136,11 @@ struct LmPhaseArgs {
 };
 bool lmk_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0, int mode1, bool lut_onehot);
 void lmk_preprocess_phases(hipStream_t s, const LmPhaseArgs& a, int T0);
+// The same idea for BATCHES (16+ frames, the batch kernels: sliding-window blur, fused gradient + vote, streaming spread
+// memories): the kernels of one dependency level share one grid, so the short level-1 launches fill the tail of the
+// long level-0 ones; four launches per lane-step instead of eleven.
+bool lmk_batch_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0, int mode1, bool lut_onehot);
+void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0);
 
 struct LmHullArgs {
     const LmOutMatch* matches; u32 n;

@@ -549,10 +549,10 @@ __device__ __forceinline__ void cbs_step(const u32 (&ring)[4][10][2], u32 (&o4)[
 }
 
 template <int STRIP>
-__global__ __launch_bounds__(256, 2) void k_cblur_sw(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
-                                                   size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
+__device__ __forceinline__ void d_cblur_sw(const u32 vblock, const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
+                                           size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
     u32 slot, tile;
-    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
     const u8* bgr = slot_ptr_s(bgr0, in_stride, slot);
     u8* S = slot_ptr_s(s0, tmp_stride, slot);
     const int nblk = (w * 3) >> 4;
@@ -617,6 +617,11 @@ __global__ __launch_bounds__(256, 2) void k_cblur_sw(const u8* __restrict__ bgr0
     }
 #undef CBS_STEP
 #undef CBS_REQUEST
+}
+template <int STRIP>
+__global__ __launch_bounds__(256, 2) void k_cblur_sw(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
+                                                   size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
+    d_cblur_sw<STRIP>(blockIdx.x, bgr0, w, h, s0, in_stride, tmp_stride, gblocks, nslots);
 }
 
 // a2+a3  Sobel(S, BORDER_REPLICATE) + strongest channel + fastAtan2 + 16 -> 8 bins + magnitude flag.
@@ -875,10 +880,10 @@ __device__ __forceinline__ void cg_labels(const CgRow& A, const CgRow& B, const 
 
 #define CG_STRIP 16
 template <int STRIP>
-__global__ __launch_bounds__(256, 2) void k_cgrad(const u8* __restrict__ s0, int w, int h, int ithr, u8* __restrict__ quant0,
-                                                  size_t tmp_stride, size_t out_stride, int gblocks, int nslots) {
+__device__ __forceinline__ void d_cgrad(const u32 vblock, const u8* __restrict__ s0, int w, int h, int ithr, u8* __restrict__ quant0,
+                                        size_t tmp_stride, size_t out_stride, int gblocks, int nslots) {
     u32 slot, tile;
-    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
     const u8* S = slot_ptr_s(s0, tmp_stride, slot);
     u8* quant = slot_ptr_s(quant0, out_stride, slot);
     const int ns = w >> 4, total = ns * ((h + STRIP - 1) / STRIP);
@@ -946,6 +951,11 @@ __global__ __launch_bounds__(256, 2) void k_cgrad(const u8* __restrict__ s0, int
         CG_STEP(2)
     }
 #undef CG_STEP
+}
+template <int STRIP>
+__global__ __launch_bounds__(256, 2) void k_cgrad(const u8* __restrict__ s0, int w, int h, int ithr, u8* __restrict__ quant0,
+                                                  size_t tmp_stride, size_t out_stride, int gblocks, int nslots) {
+    d_cgrad<STRIP>(blockIdx.x, s0, w, h, ithr, quant0, tmp_stride, out_stride, gblocks, nslots);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1661,10 +1671,10 @@ __device__ __forceinline__ u32 gather4_stride5(const u32 (&V)[11], int b0) {
     const u32 hi = __builtin_amdgcn_perm(V[a3 >> 2], V[a2 >> 2], (u32)(a2 & 3) | ((u32)(4 + (a3 & 3)) << 8) | 0x0c0c0000u);
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
-__global__ __launch_bounds__(256) void k_lm_spread5(const u8* __restrict__ q0, int qpitch, int w, int h, u8* __restrict__ lm0,
-                                                     size_t q_slot_stride, size_t lm_slot_stride, int gblocks, int nslots) {
+__device__ __forceinline__ void d_lm_spread5(const u32 vblock, const u8* __restrict__ q0, int qpitch, int w, int h, u8* __restrict__ lm0,
+                                             size_t q_slot_stride, size_t lm_slot_stride, int gblocks, int nslots) {
     u32 slot, tile;
-    xcd_slot_tile((u32)gblocks, (u32)nslots, slot, tile);
+    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
     const u8* q = slot_ptr_s(q0, q_slot_stride, slot);
     u8* lm = slot_ptr_s(lm0, lm_slot_stride, slot);
     const int W = w / 5, HB = h / 5, ng = W >> 3;
@@ -1703,6 +1713,10 @@ __global__ __launch_bounds__(256) void k_lm_spread5(const u8* __restrict__ q0, i
             *reinterpret_cast<u32x2*>(dst + (size_t)c0 * wh) = u32x2{gather4_stride5(V, c0), gather4_stride5(V, c0 + 20)};
     }
 }
+__global__ __launch_bounds__(256) void k_lm_spread5(const u8* __restrict__ q0, int qpitch, int w, int h, u8* __restrict__ lm0,
+                                                     size_t q_slot_stride, size_t lm_slot_stride, int gblocks, int nslots) {
+    d_lm_spread5(blockIdx.x, q0, qpitch, w, h, lm0, q_slot_stride, lm_slot_stride, gblocks, nslots);
+}
 
 // ------------------------------------------------------------------------------------------------
 // a3-a10 of few frames: the kernels of one dependency level in ONE launch, each on its own range of the block index
@@ -1734,6 +1748,46 @@ __global__ __launch_bounds__(256) void k_phase(LmPhaseArgs a, LmPhaseGrid pg) {
         if (b < e0) d_cvote(b, a.cs1 + a3_1, w1, h1, a.qc1, fs, fs, pg.g[0], a.nslots);
         else if (T0 == 5) d_lm_fast<5, 128, 0, 1>(b - e0, a.qc0, a.w, a.w, a.h, a.resp_tab, a.lm_c0, 0u, fs, fs, pg.g[1], a.nslots);
         else d_lm_spread2(b - e0, a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, pg.g[1], a.nslots);     // T0 == 2 (colour only)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a3-a10 of a BATCH as four launches (r03: "horizontal fusion of the pyramid levels").  The batch kernels of one dependency
+// level share ONE grid, each on its own range of the block index, the longest-running first: the level-1 kernels and the
+// other short ones (a 320 x 240 level is 10 waves per frame: 960 waves for 1024 SIMDs when launched alone, each walking
+// its strip serially) fill the chip's tail instead of holding a half-empty launch of their own, and a lane-step is 4 + 4
+// dependent launches instead of 11 + 4.
+//   1  depth normals          | blur(level 0)           | pyrDown(level 0 -> 1)
+//   2  gradient + vote(0)     | median of the normals   | blur(level 1)
+//   3  gradient + vote(1)     | colour spread memory(0) | depth spread memory(0) | depth response memories(1)
+//   4  colour response memories(1)                                             (plain k_lm_fast launch)
+// Same device functions, same results as the kernels launched one by one (LM_TUNE_BATCH_PHASES = 0).  Every part keeps
+// its XCD affinity: the parts' block counts are multiples of 8 whenever the slot count is.
+// SB / SG: rows per strip of the level-0 blur / gradient kernels (16, or 32 for tall images).
+// ------------------------------------------------------------------------------------------------
+template <int PH, int T0, int SB, int SG>
+__global__ __launch_bounds__(256, 2) void k_bphase(LmPhaseArgs a, LmPhaseGrid pg) {
+    const u32 b = blockIdx.x, e0 = pg.nb[0], e1 = e0 + pg.nb[1], e2 = e1 + pg.nb[2];
+    const size_t fs = a.slot_stride;
+    const int w1 = a.w >> 1, h1 = a.h >> 1, n = a.nslots;
+    const float thr2 = a.weak_threshold * a.weak_threshold;
+    const int ithr = thr2 >= 2147483648.f ? INT_MAX : (int)floorf(thr2);    // (float)m > thr2 <=> m > floor(thr2)
+    if (PH == 1) {
+        if (b < e0) d_dnormal(b, a.depth, a.w, a.h, a.dist_thr, a.diff_thr, a.normal_lut, a.ds, fs, fs, pg.g[0], n);
+        else if (b < e1) d_cblur_sw<SB>(b - e0, a.bgr0, a.w, a.h, a.cs0, fs, fs, pg.g[1], n);
+        else d_pyrdown8(b - e1, a.bgr0, a.w, a.h, a.bgr1, w1, h1, fs, pg.g[2], n);
+    } else if (PH == 2) {
+        if (b < e0) d_cgrad<SG>(b, a.cs0, a.w, a.h, ithr, a.qc0, fs, fs, pg.g[0], n);
+        else if (b < e1) d_dmedian(b - e0, a.ds, a.w, a.h, a.qd0, fs, fs, pg.g[1], n);
+        else d_cblur_sw<16>(b - e1, a.bgr1, w1, h1, a.cs1, fs, fs, pg.g[2], n);
+    } else {
+        if (b < e0) d_cgrad<16>(b, a.cs1, w1, h1, ithr, a.qc1, fs, fs, pg.g[0], n);
+        else if (b < e1) {
+            if (T0 == 5) d_lm_spread5(b - e0, a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, pg.g[1], n);
+            else d_lm_spread2(b - e0, a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, pg.g[1], n);
+        }
+        else if (b < e2) d_lm_spread5(b - e1, a.qd0, a.w, a.w, a.h, a.lm_d0, fs, fs, pg.g[2], n);
+        else d_lm_fast<8, 40, 1, 2>(b - e2, a.qd0, a.w, w1, h1, a.resp_tab, a.lm_d1, a.ori_stride1, fs, fs, pg.g[3], n);
     }
 }
 
@@ -2936,6 +2990,49 @@ void lmk_preprocess_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
     launch(k_phase<3, 5>, p3);
     LmPhaseGrid p4 = {{(u32)(g_vote1 * n), b_lm0, 0u, 0u}, {g_vote1, seg0, 0, 0}};
     if (T0 == 5) launch(k_phase<4, 5>, p4); else launch(k_phase<4, 2>, p4);
+    hipLaunchKernelGGL((k_lm_fast<8, 40, 0, 2>), dim3(b_lm1), dim3(256), 0, s, a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1,
+                       a.slot_stride, a.slot_stride, seg1, n);
+}
+
+bool lmk_batch_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0, int mode1, bool lut_onehot) {
+    if (!lmk_phases_supported(a, T0, T1, mode0, mode1, lut_onehot)) return false;
+    if (a.nslots < 16 || (a.w % 32) != 0 || (a.h % 2) != 0) return false;
+    auto al = [](const void* p, uintptr_t m) { return ((uintptr_t)p & (m - 1)) == 0; };
+    if (T0 == 5) {   // k_lm_spread5's shape
+        const int W = a.w / 5;
+        if ((a.w % 5) || (a.h % 5) || (W % 8) || (((size_t)W * (a.h / 5)) % 8) || !al(a.lm_c0, 8) || (a.depth && !al(a.lm_d0, 8)) || (a.slot_stride % 8)) return false;
+    } else if (a.depth) return false;     // T0 == 2 is the colour-only pyramid
+    return true;
+}
+
+void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
+    const int w = a.w, h = a.h, w1 = w / 2, h1 = h / 2, n = a.nslots;
+    const bool dep = a.depth != nullptr;
+    const bool tall = h > 640;                                     // 32-row strips at level 0 (fewer re-read window rows)
+    auto per = [](int lanes) { return (lanes + 255) / 256; };
+    auto strips = [](int rows, int strip) { return (rows + strip - 1) / strip; };
+    auto gwaves = [&](int ww, int hh, int strip) { return (((ww / 16) * strips(hh, strip) + 61) / 62 + 3) / 4; };   // k_cgrad: 62 useful lanes per wave, 4 waves per block
+    const int sb = tall ? 32 : 16, sg = tall ? 32 : 16;
+    const int g_nrm = per((w / 8) * h), g_blur0 = per((w * 3 / 16) * strips(h, sb)), g_pyr = per((w1 / 8) * h1);
+    const int g_grad0 = gwaves(w, h, sg), g_med = per((w / 8) * strips(h, DM_ROWS)), g_blur1 = per((w1 * 3 / 16) * strips(h1, 16));
+    const int g_grad1 = gwaves(w1, h1, 16);
+    const int g_sp = T0 == 5 ? per(((w / 5) / 8) * (h / 5)) : per((w / 32) * (h / 2));
+    const int seg1 = (w1 / 8 + 39) / 40;
+    const u32 b_lm1 = (u32)(seg1 * (h1 / 8) * n);
+    auto launch = [&](auto kern, const LmPhaseGrid& pg) {
+        const u32 nb = pg.nb[0] + pg.nb[1] + pg.nb[2] + pg.nb[3];
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s, a, pg);
+    };
+    const LmPhaseGrid p1 = {{dep ? (u32)(g_nrm * n) : 0u, (u32)(g_blur0 * n), (u32)(g_pyr * n), 0u}, {g_nrm, g_blur0, g_pyr, 0}};
+    const LmPhaseGrid p2 = {{(u32)(g_grad0 * n), dep ? (u32)(g_med * n) : 0u, (u32)(g_blur1 * n), 0u}, {g_grad0, g_med, g_blur1, 0}};
+    const LmPhaseGrid p3 = {{(u32)(g_grad1 * n), (u32)(g_sp * n), dep ? (u32)(g_sp * n) : 0u, dep ? b_lm1 : 0u}, {g_grad1, g_sp, g_sp, seg1}};
+    if (T0 == 5) {
+        if (tall) { launch(k_bphase<1, 5, 32, 32>, p1); launch(k_bphase<2, 5, 32, 32>, p2); launch(k_bphase<3, 5, 32, 32>, p3); }
+        else { launch(k_bphase<1, 5, 16, 16>, p1); launch(k_bphase<2, 5, 16, 16>, p2); launch(k_bphase<3, 5, 16, 16>, p3); }
+    } else {
+        if (tall) { launch(k_bphase<1, 2, 32, 32>, p1); launch(k_bphase<2, 2, 32, 32>, p2); launch(k_bphase<3, 2, 32, 32>, p3); }
+        else { launch(k_bphase<1, 2, 16, 16>, p1); launch(k_bphase<2, 2, 16, 16>, p2); launch(k_bphase<3, 2, 16, 16>, p3); }
+    }
     hipLaunchKernelGGL((k_lm_fast<8, 40, 0, 2>), dim3(b_lm1), dim3(256), 0, s, a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1,
                        a.slot_stride, a.slot_stride, seg1, n);
 }

@@ -440,7 +440,7 @@ void similarity(const LevelData& L, int m, const Template& t, std::vector<u8>& d
         if (g_scan_mode == 0) {
             for (int j = 0; j < P; ++j) dst[j] = (u8)(dst[j] + lm_read(L.lm[m], f.label, block, base + j));
         } else {
-            const int n_in = base < block ? (int)std::min<size_t>((size_t)P, block - base) : 0;   // the rest reads 0
+            const int n_in = (P > 0 && base < block) ? (int)std::min<size_t>((size_t)P, block - base) : 0;   // the rest reads 0
             const u8* __restrict__ src = L.lm[m].data() + (size_t)f.label * block + base;
             u8* __restrict__ out = dst.data();
             for (int j = 0; j < n_in; ++j) out[j] = (u8)(out[j] + src[j]);

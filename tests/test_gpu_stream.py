@@ -231,3 +231,45 @@ def test_lm_match_takes_pinned_frames_without_staging(lm, orc, synth):
         assert_matches_equal(d.match(pc, dp, THR, 0), exp[k])              # mixed: staged
     d.close()
     pb.close()
+
+
+@pytest.mark.parametrize("color_only,size", [(False, (640, 480)), (True, (640, 480)), (True, (1280, 960)), (False, (320, 240))])
+def test_batches_take_one_launch_per_dependency_level(lm, orc, synth, color_only, size):
+    """Calls of 16 or more frames run a3-a10 as four launches in which the batch kernels of one dependency level share a
+    grid (LM_TUNE_BATCH_PHASES, default on; r03: the level-1 kernels fill the tail of the level-0 ones).  Same buffers and
+    lists as one launch per kernel and as the oracle: quantised images and linear memories of every level and modality
+    are diffed for the first, a middle and the last slot of the batch, the lists for all."""
+    w, h = size
+    M = 1 if color_only else 2
+    n = 24 if w <= 640 else 16
+    d = lm.Detector(color_only=color_only, width=w, height=h, frame_slots=n)
+    o = orc.Detector(color_only=color_only)
+    frames = [synth.make_frame(w, h, seed=900 + i) for i in range(4)]
+    o.prepare(frames[0][0], None if color_only else frames[0][1])
+    q = {(l, m): o.stage(0, l, m).reshape(h >> l, w >> l) for l in range(2) for m in range(M)}
+    descs, feats, _ = synth.make_bank(60, M, 2, seed=78, size_range=(48, min(160, h // 2)), quantized=q, crop_fraction=0.3,
+                                      frame_size=(w, h), T0=d.get_T(0))
+    d.add_class("c", descs, feats)
+    o.add_class("c", descs, feats)
+    exp = [o.match(b, None if color_only else dp, THR, threads=8) for b, dp in frames]
+    assert sum(len(e) for e in exp) > 0
+    for k in range(n):
+        b, dp = frames[(3 * k + 1) % 4]
+        d.upload_frame(k, b, None if color_only else dp)
+    for phases in (1, 0):
+        d.set_tuning(lm.TUNE_BATCH_PHASES, phases)
+        for nb in (n, 16):
+            out, cnt = d.match_batch(nb, THR, 0)
+            for k in range(nb):
+                try:
+                    assert_matches_equal(out[k, :cnt[k]], exp[(3 * k + 1) % 4])
+                except AssertionError as e:
+                    raise AssertionError("batch phases %d, batch of %d, slot %d: %s" % (phases, nb, k, str(e)[:80]))
+        for k in (0, n // 2 + 1, n - 1):
+            b, dp = frames[(3 * k + 1) % 4]
+            o.prepare(b, None if color_only else dp)
+            for level in range(2):
+                for mod in range(M):
+                    assert np.array_equal(d.debug_read(k, 0, level, mod), o.stage(0, level, mod)), (phases, k, level, mod)
+                    assert np.array_equal(d.debug_read(k, 2, level, mod), o.stage(2, level, mod)), (phases, k, level, mod)
+    d.close()

@@ -291,11 +291,14 @@ def test_scan_modes_agree(orc, synth):
     o.add_class("c", descs, feats)
     d2, f2, _ = synth.make_bank(6, 2, 2, seed=5, fixed_l0_size=(620, 470))     # span <= 0 / clamped templates
     o.add_class("big", d2, f2)
+    d3, f3, _ = synth.make_bank(6, 2, 2, seed=6, fixed_l0_size=(700, 500))     # larger than the frame: negative spans
+    o.add_class("toobig", d3, f3)
     res = {}
     try:
         for mode in (0, 1):
             orc.set_scan_mode(mode)
-            res[mode] = (o.scan_candidates(40.0), o.match(bgr, depth, 40.0), o.match(bgr, depth, 0.0, class_idx=1))
+            res[mode] = (o.scan_candidates(40.0), o.match(bgr, depth, 40.0), o.match(bgr, depth, 0.0, class_idx=1),
+                         o.match(bgr, depth, 0.0, class_idx=2))
     finally:
         orc.set_scan_mode(1)
     assert len(res[0][1]) > 0
