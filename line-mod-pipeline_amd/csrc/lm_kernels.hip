@@ -1791,6 +1791,35 @@ __global__ __launch_bounds__(256, 2) void k_bphase(LmPhaseArgs a, LmPhaseGrid pg
     }
 }
 
+// The RGB-D form.  A fused kernel's waves all allocate the registers of its hungriest part: with the depth kernels
+// (k_dnormal: 61 VGPRs, 8 waves per SIMD when launched alone) inside the grids of the blur / gradient kernels (204 / 238
+// VGPRs, 2 waves per SIMD) the level-fused launches above LOSE (r03, config 2: pre-processing 4.82 -> 4.88 us per frame
+// on one lane, 145 K -> 131 K detections/s with three lanes -- the fat waves also keep the other lanes' scan waves off
+// the SIMDs).  So the RGB-D pyramid fuses only kernels of one register class:
+//   light  0: depth normals | pyrDown                      heavy  1: gradient + vote(0) | blur(level 1)
+//   light  2: colour spread memory(0) | depth spread memory(0) | depth response memories(1)
+// between the plain launches of blur(level 0), median, gradient + vote(1) and the colour response memories(1): seven
+// launches instead of eleven.
+template <int PART, int SG>
+__global__ __launch_bounds__(256, PART == 1 ? 2 : 1) void k_bsplit(LmPhaseArgs a, LmPhaseGrid pg) {
+    const u32 b = blockIdx.x, e0 = pg.nb[0], e1 = e0 + pg.nb[1];
+    const size_t fs = a.slot_stride;
+    const int w1 = a.w >> 1, h1 = a.h >> 1, n = a.nslots;
+    if (PART == 0) {
+        if (b < e0) d_dnormal(b, a.depth, a.w, a.h, a.dist_thr, a.diff_thr, a.normal_lut, a.ds, fs, fs, pg.g[0], n);
+        else d_pyrdown8(b - e0, a.bgr0, a.w, a.h, a.bgr1, w1, h1, fs, pg.g[1], n);
+    } else if (PART == 1) {
+        const float thr2 = a.weak_threshold * a.weak_threshold;
+        const int ithr = thr2 >= 2147483648.f ? INT_MAX : (int)floorf(thr2);
+        if (b < e0) d_cgrad<SG>(b, a.cs0, a.w, a.h, ithr, a.qc0, fs, fs, pg.g[0], n);
+        else d_cblur_sw<16>(b - e0, a.bgr1, w1, h1, a.cs1, fs, fs, pg.g[1], n);
+    } else {
+        if (b < e0) d_lm_spread5(b, a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, pg.g[0], n);
+        else if (b < e1) d_lm_spread5(b - e0, a.qd0, a.w, a.w, a.h, a.lm_d0, fs, fs, pg.g[1], n);
+        else d_lm_fast<8, 40, 1, 2>(b - e1, a.qd0, a.w, w1, h1, a.resp_tab, a.lm_d1, a.ori_stride1, fs, fs, pg.g[2], n);
+    }
+}
+
 template <int UNROLL, bool XCD_MAP>
 __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
     const int lane = threadIdx.x & 63;
@@ -3023,15 +3052,35 @@ void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
         const u32 nb = pg.nb[0] + pg.nb[1] + pg.nb[2] + pg.nb[3];
         hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s, a, pg);
     };
-    const LmPhaseGrid p1 = {{dep ? (u32)(g_nrm * n) : 0u, (u32)(g_blur0 * n), (u32)(g_pyr * n), 0u}, {g_nrm, g_blur0, g_pyr, 0}};
-    const LmPhaseGrid p2 = {{(u32)(g_grad0 * n), dep ? (u32)(g_med * n) : 0u, (u32)(g_blur1 * n), 0u}, {g_grad0, g_med, g_blur1, 0}};
-    const LmPhaseGrid p3 = {{(u32)(g_grad1 * n), (u32)(g_sp * n), dep ? (u32)(g_sp * n) : 0u, dep ? b_lm1 : 0u}, {g_grad1, g_sp, g_sp, seg1}};
-    if (T0 == 5) {
-        if (tall) { launch(k_bphase<1, 5, 32, 32>, p1); launch(k_bphase<2, 5, 32, 32>, p2); launch(k_bphase<3, 5, 32, 32>, p3); }
-        else { launch(k_bphase<1, 5, 16, 16>, p1); launch(k_bphase<2, 5, 16, 16>, p2); launch(k_bphase<3, 5, 16, 16>, p3); }
+    if (dep) {
+        // RGB-D: only kernels of one register class share a grid (see k_bsplit)
+        const float thr2 = a.weak_threshold * a.weak_threshold;
+        const int ithr = thr2 >= 2147483648.f ? INT_MAX : (int)floorf(thr2);
+        const size_t fs = a.slot_stride;
+        const LmPhaseGrid l0 = {{(u32)(g_nrm * n), (u32)(g_pyr * n), 0u, 0u}, {g_nrm, g_pyr, 0, 0}};
+        const LmPhaseGrid h1g = {{(u32)(g_grad0 * n), (u32)(g_blur1 * n), 0u, 0u}, {g_grad0, g_blur1, 0, 0}};
+        const LmPhaseGrid l2 = {{(u32)(g_sp * n), (u32)(g_sp * n), b_lm1, 0u}, {g_sp, g_sp, seg1, 0}};
+        launch(k_bsplit<0, 16>, l0);
+        if (tall) hipLaunchKernelGGL(k_cblur_sw<32>, dim3((unsigned)(g_blur0 * n)), dim3(256), 0, s, a.bgr0, w, h, a.cs0, fs, fs, g_blur0, n);
+        else hipLaunchKernelGGL(k_cblur_sw<16>, dim3((unsigned)(g_blur0 * n)), dim3(256), 0, s, a.bgr0, w, h, a.cs0, fs, fs, g_blur0, n);
+        if (tall) launch(k_bsplit<1, 32>, h1g); else launch(k_bsplit<1, 16>, h1g);
+        hipLaunchKernelGGL(k_dmedian, dim3((unsigned)(g_med * n)), dim3(256), 0, s, a.ds, w, h, a.qd0, fs, fs, g_med, n);
+        // level 1 alone: 8-row strips when 16-row ones would leave SIMDs without a wave (as lmk_color_quantize chooses)
+        const int waves16 = ((w1 / 16) * strips(h1, 16) + 61) / 62;
+        if ((long)waves16 * n >= 1536) hipLaunchKernelGGL(k_cgrad<16>, dim3((unsigned)(g_grad1 * n)), dim3(256), 0, s, a.cs1, w1, h1, ithr, a.qc1, fs, fs, g_grad1, n);
+        else { const int g8 = gwaves(w1, h1, 8); hipLaunchKernelGGL(k_cgrad<8>, dim3((unsigned)(g8 * n)), dim3(256), 0, s, a.cs1, w1, h1, ithr, a.qc1, fs, fs, g8, n); }
+        launch(k_bsplit<2, 16>, l2);
     } else {
-        if (tall) { launch(k_bphase<1, 2, 32, 32>, p1); launch(k_bphase<2, 2, 32, 32>, p2); launch(k_bphase<3, 2, 32, 32>, p3); }
-        else { launch(k_bphase<1, 2, 16, 16>, p1); launch(k_bphase<2, 2, 16, 16>, p2); launch(k_bphase<3, 2, 16, 16>, p3); }
+        const LmPhaseGrid p1 = {{0u, (u32)(g_blur0 * n), (u32)(g_pyr * n), 0u}, {g_nrm, g_blur0, g_pyr, 0}};
+        const LmPhaseGrid p2 = {{(u32)(g_grad0 * n), 0u, (u32)(g_blur1 * n), 0u}, {g_grad0, g_med, g_blur1, 0}};
+        const LmPhaseGrid p3 = {{(u32)(g_grad1 * n), (u32)(g_sp * n), 0u, 0u}, {g_grad1, g_sp, g_sp, seg1}};
+        if (T0 == 5) {
+            if (tall) { launch(k_bphase<1, 5, 32, 32>, p1); launch(k_bphase<2, 5, 32, 32>, p2); launch(k_bphase<3, 5, 32, 32>, p3); }
+            else { launch(k_bphase<1, 5, 16, 16>, p1); launch(k_bphase<2, 5, 16, 16>, p2); launch(k_bphase<3, 5, 16, 16>, p3); }
+        } else {
+            if (tall) { launch(k_bphase<1, 2, 32, 32>, p1); launch(k_bphase<2, 2, 32, 32>, p2); launch(k_bphase<3, 2, 32, 32>, p3); }
+            else { launch(k_bphase<1, 2, 16, 16>, p1); launch(k_bphase<2, 2, 16, 16>, p2); launch(k_bphase<3, 2, 16, 16>, p3); }
+        }
     }
     hipLaunchKernelGGL((k_lm_fast<8, 40, 0, 2>), dim3(b_lm1), dim3(256), 0, s, a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1,
                        a.slot_stride, a.slot_stride, seg1, n);
