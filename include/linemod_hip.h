@@ -194,10 +194,12 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
  *   holding the independent kernels of one dependency level on ranges of the block index, instead of fourteen dependent
  *   ones (default 15: from 16 frames the batch kernels take over; 0 = off; two-level T = {5, 8} pyramids only, anything else takes the plain sequence). */
 #define LM_TUNE_PHASE_MAX_SLOTS 6
-/* LM_TUNE_BATCH_PHASES: calls of 16 or more frames run the pre-processing as four launches in which the batch kernels of
- *   one dependency level share a grid (the level-1 kernels fill the tail of the level-0 ones) instead of eleven dependent
- *   launches (default 1; 0 = one launch per kernel; two-level T = {5, 8} / {2, 8} pyramids of 32-pixel-aligned frames only,
- *   anything else takes the plain sequence). */
+/* LM_TUNE_BATCH_PHASES: calls of 16 or more frames run the pre-processing as launches in which batch kernels of one
+ *   dependency level (and one register class) share a grid -- the level-1 kernels fill the tail of the level-0 ones: four
+ *   (colour only) or seven (RGB-D) dependent launches instead of eleven.  0 = never, 1 = always, 2 (default) = when no
+ *   other lane has a match in flight: measured r03, the fused launches win when a lane has the chip to itself and lose
+ *   beside other lanes, whose kernels fill the tails anyway.  Two-level T = {5, 8} / {2, 8} pyramids of 32-pixel-aligned
+ *   frames only; anything else takes the plain sequence.  Results never depend on it. */
 #define LM_TUNE_BATCH_PHASES 7
 int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);

@@ -129,7 +129,10 @@ struct lm_detector {
     int comm_recs_per_frame = 0;
     Gather gather[LM_NLANES];
     double* d_red = nullptr;   // small device buffer of lm_comm_max / lm_comm_barrier
-    int batch_phases = 1;            // calls of 16+ frames run a3-a10 as four launches of level-fused batch kernels (lmk_preprocess_batch_phases)
+    int batch_phases = 2;            // calls of 16+ frames run a3-a10 as launches of level-fused batch kernels (lmk_preprocess_batch_phases):
+                                     // 0 never, 1 always, 2 (default) when no other lane has work in flight -- measured r03: alone on the
+                                     // chip the fused launches win (config 2: 4.81 -> 4.66, config 3: 8.54 -> 8.06 us per frame), beside two
+                                     // other lanes the separate launches interleave better (config 2: 145 K against 140 K detections/s)
     int phase_max_slots = 15;        // calls of up to this many frames run a3-a10 as one launch per dependency level (LmPhaseArgs)
     int fork_max_slots = 0;          // measured r02: no gain (host launch rate, 3.4 us per launch, bounds small calls), so off by default
     int fork_depth_wait_slot = -1;   // forked single-frame call: the depth chain's stream waits for this slot's whole upload
@@ -380,7 +383,10 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
     // ---- few frames: one launch per dependency level (lm_kernels.h LmPhaseArgs): 5 launches instead of 14;
     // ---- batches: the same with the batch kernels, 4 launches instead of 11 (LM_TUNE_BATCH_PHASES)
     const bool few = n <= d->phase_max_slots;
-    if ((few || (d->batch_phases && n >= 16)) && n > d->fork_max_slots && L == 2) {     // (the fork experiment, when switched on, wins)
+    bool others_busy = false;
+    for (int o = 0; o < LM_NLANES; ++o) others_busy |= (o != d->active && d->lanes[o].busy);
+    const bool fuse_batch = d->batch_phases == 1 || (d->batch_phases == 2 && !others_busy);
+    if ((few || (fuse_batch && n >= 16)) && n > d->fork_max_slots && L == 2) {     // (the fork experiment, when switched on, wins)
         LmPhaseArgs pa{};
         pa.bgr0 = d->bgr(first, 0); pa.bgr1 = d->bgr(first, 1); pa.depth = M == 2 ? d->depth(first) : nullptr;
         pa.cs0 = d->cscratch(first, 0); pa.cs1 = d->cscratch(first, 1); pa.ds = d->dscratch(first);
@@ -1237,7 +1243,7 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
         case LM_TUNE_PHASE_MAX_SLOTS: if (value < 0) break; d->phase_max_slots = value; return LM_OK;
         case LM_TUNE_CGRAD_VARIANT: if (value < 0 || value > 3) break; lmk_set_cgrad_variant(value); return LM_OK;
         case LM_TUNE_COPY_STREAMS: if (value < 1 || value > LM_NCOPY) break; d->n_copy_streams = value; return LM_OK;
-        case LM_TUNE_BATCH_PHASES: if (value < 0 || value > 1) break; d->batch_phases = value; return LM_OK;
+        case LM_TUNE_BATCH_PHASES: if (value < 0 || value > 2) break; d->batch_phases = value; return LM_OK;
         default: return fail(LM_ERR_INVALID, "unknown tuning key");
     }
     return fail(LM_ERR_INVALID, "tuning value out of range");

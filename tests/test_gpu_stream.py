@@ -256,7 +256,7 @@ def test_batches_take_one_launch_per_dependency_level(lm, orc, synth, color_only
     for k in range(n):
         b, dp = frames[(3 * k + 1) % 4]
         d.upload_frame(k, b, None if color_only else dp)
-    for phases in (1, 0):
+    for phases in (1, 0, 2):
         d.set_tuning(lm.TUNE_BATCH_PHASES, phases)
         for nb in (n, 16):
             out, cnt = d.match_batch(nb, THR, 0)
