@@ -383,7 +383,8 @@ int lm_get_scan_stats(lm_detector* det, uint64_t* features_loaded, uint64_t* fea
 int lm_get_scan_lane_stats(lm_detector* det, uint64_t* lane_loads_issued, uint64_t* lane_loads_unpruned);
 /* Selects the similarity-scan kernel variant used by lm_match* (0 = default; bits 0-1: features per load block;
  * bit 3 (value 8): no pruning, the plain exhaustive scan; bit 4 (value 16): wave-level pruning only, without the
- * per-lane exec masking; see lm_kernels.hip). */
+ * per-lane exec masking; bit 5 (value 32): per-lane pruning also for one-modality detectors, which default to the
+ * wave-level rule; see lm_kernels.hip). */
 int lm_set_scan_variant(lm_detector* det, int variant);
 
 #ifdef __cplusplus

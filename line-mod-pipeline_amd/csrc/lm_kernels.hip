@@ -3098,10 +3098,14 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
         dim3 grid((unsigned)(G * npairs), 1, 1);
 #define SCAN4_LAUNCH(FB)                                                                              \
     do { if (variant & 8) hipLaunchKernelGGL((k_scan4<FB, true, 0>), grid, dim3(256), 0, s, a);       \
-         else if (variant & 16) hipLaunchKernelGGL((k_scan4<FB, true, 1>), grid, dim3(256), 0, s, a); \
+         else if ((variant & 16) || (a.M < 2 && !(variant & 32))) hipLaunchKernelGGL((k_scan4<FB, true, 1>), grid, dim3(256), 0, s, a); \
          else hipLaunchKernelGGL((k_scan4<FB, true, 2>), grid, dim3(256), 0, s, a); } while (0)
         // variant bits 0-1: features per load block (0: 6, 1: 12, 2: 3); bit 3: no pruning (the plain exhaustive scan);
-        // bit 4: wave-level pruning only (r02's rule; default: per-lane pruning)
+        // bit 4: wave-level pruning only (r02's rule); bit 5: per-lane pruning whatever the modality count.  Default:
+        // per-lane pruning for two modalities (r03, config 2: 181.6 -> 172.9 us per 96-frame launch, 35 % of the lane-loads
+        // instead of 50 %), wave-level for one (config 3: the per-lane form measured 455 against 413 us per 128-frame launch:
+        // with 31 features per template few lanes die long before their wave does, and the masked loads still pull the
+        // same lines)
         const int fb = variant & 3;
         if (fb == 1) SCAN4_LAUNCH(12); else if (fb == 2) SCAN4_LAUNCH(3); else SCAN4_LAUNCH(6);
 #undef SCAN4_LAUNCH

@@ -78,7 +78,7 @@ while time.time() - t0 < budget:
         d.close(); continue
     d.add_class("c", descs, feats); o.add_class("c", descs, feats)
     thr = float(rng.choice([60.0, 75.0, 85.0, 40.0]))
-    variant = int(rng.choice([0, 0, 0, 8, 1, 2, 9, 16, 17, 18]))   # load-block sizes; per-lane pruning (default), none (bit 3), wave-level (bit 4)
+    variant = int(rng.choice([0, 0, 32, 8, 1, 34, 9, 16, 17, 18]))   # load-block sizes; per-lane pruning (default), none (bit 3), wave-level (bit 4)
     d.set_scan_variant(variant)
     got = d.match(bgr, None if color_only else depth, thr, cap=1 << 18)
     exp = o.match(bgr, None if color_only else depth, thr, threads=8, cap=1 << 18)

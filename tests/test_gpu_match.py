@@ -433,7 +433,7 @@ def test_scan_pruning_is_exact(lm, orc, synth, color_only, thr):
     o.prepare(bgr, dep)
     exp = o.scan_candidates(thr, threads=8)
     stats, lanes = {}, {}
-    for variant in (0, 16, 8):                                  # per-lane pruning (default), wave-level pruning (r02), none
+    for variant in (32, 16, 8):                                 # per-lane pruning, wave-level pruning (r02), none
         d.set_scan_variant(variant)
         d.set_scan_stats(True)
         assert np.array_equal(d.stage_scan(0, thr), exp)
@@ -443,16 +443,18 @@ def test_scan_pruning_is_exact(lm, orc, synth, color_only, thr):
         assert_matches_equal(d.match_slot(0, thr, cap=1 << 16), o.match(bgr, dep, thr, threads=8))
         got, cnt = d.match_batch(2, thr, cap_per_frame=1 << 15)  # two frames per wave: the pair must agree to stop
         assert_matches_equal(got[0, :cnt[0]], o.match(bgr, dep, thr, threads=8))
-    assert stats[8][0] == stats[8][1] == stats[0][1]            # the exhaustive scan loads every in-bounds feature
-    assert stats[0][0] <= stats[0][1]
-    assert stats[0][0] == stats[16][0]                          # a wave stops when its last lane dies: the same rule
+    assert stats[8][0] == stats[8][1] == stats[32][1]           # the exhaustive scan loads every in-bounds feature
+    assert stats[32][0] <= stats[32][1]
+    assert stats[32][0] == stats[16][0]                         # a wave stops when its last lane dies: the same rule
     assert lanes[8][0] == lanes[8][1] == 64 * stats[8][1] and lanes[16][0] == 64 * stats[16][0]
-    assert lanes[0][0] <= lanes[16][0]
+    assert lanes[32][0] <= lanes[16][0]
     if thr >= 80.0:
-        assert stats[0][0] < 0.8 * stats[0][1]
-        assert lanes[0][0] < 0.8 * lanes[16][0]                 # dead lanes leave the loads' exec mask
+        assert stats[32][0] < 0.8 * stats[32][1]
+        assert lanes[32][0] < 0.8 * lanes[16][0]                # dead lanes leave the loads' exec mask
+    d.set_scan_variant(0)                                       # the default picks one of the two pruning rules by modality count
+    assert np.array_equal(d.stage_scan(0, thr), exp)
     if thr == 0.0:
-        assert stats[0][0] == stats[0][1]                       # nothing can be pruned when every position qualifies
+        assert stats[32][0] == stats[32][1]                     # nothing can be pruned when every position qualifies
     d.close()
 
 
