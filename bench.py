@@ -452,6 +452,7 @@ def main():
     alg_bytes = prof["scan_bytes"] / max(prof["launches"], 1)
     ol_us = one_lane["stage_us"][1] / max(one_lane["launches"], 1)
     traffic, traffic_src = pmc_traffic(args.config, Bl)
+    l2c = l2_counters(args.config, Bl)
 
     def rate(nbytes, us):
         return nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
@@ -484,6 +485,40 @@ def main():
         "stage_us_per_frame_one_lane": dict(zip(["preprocess", "scan", "refine", "sort"],
                                                 [round(v / max(one_lane["frames"], 1), 2) for v in one_lane["stage_us"]])),
     }
+    roofline_refine = None
+    if l2c:
+        bpr = l2c["bytes_per_request"]
+
+        def from_counters(prefix, us):
+            ks = [k for k in l2c["kernels"] if k.startswith(prefix)]
+            if not ks or us <= 0:
+                return None
+            c = l2c["kernels"][ks[0]]
+            req = c.get("TCP_TCC_READ_REQ_sum", 0.0)
+            hit, miss = c.get("TCC_HIT_sum", 0.0), c.get("TCC_MISS_sum", 0.0)
+            return {"kernel_in_counter_file": ks[0], "TCP_TCC_READ_REQ_per_launch": req, "bytes_per_request": bpr,
+                    "l2_to_l1_bytes_per_launch": req * bpr, "achieved_GBps": round(rate(req * bpr, us), 1),
+                    "frac_of_l2_peak": round(rate(req * bpr, us) / L2_PEAK_GBS, 4),
+                    "TCP_TOTAL_CACHE_ACCESSES_per_launch": c.get("TCP_TOTAL_CACHE_ACCESSES_sum"),
+                    "TCC_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None}
+
+        roofline["l2_counters"] = from_counters(kernel, ol_us)
+        if roofline["l2_counters"]:
+            roofline["l2_counters"].update({
+                "source": l2c["source"], "calibration": l2c.get("calibration"),
+                "note": "COUNTED L1 -> L2 read requests of the committed rocprofv3 --pmc pass of this command (one lane, %d frames per "
+                        "launch) x the calibrated request size, over this run's clean launch duration: the counter-based twin of "
+                        "`frac` (which prices the bytes the loads REQUEST, 16 B per active lane; a request moves a whole 128-B "
+                        "line)" % Bl})
+        ref_us = one_lane["stage_us"][2] / max(one_lane["launches"], 1)
+        rr = from_counters("k_refine<", ref_us)
+        if rr:
+            roofline_refine = {"bound": "l2", "achieved": rr["achieved_GBps"], "peak": L2_PEAK_GBS, "unit": "GB/s",
+                               "frac": rr["frac_of_l2_peak"], "kernel": "k_refine (+ k_refine_plan)", "avg_launch_us": round(ref_us, 2),
+                               "frames_per_launch": Bl, "counters": rr, "source": l2c["source"],
+                               "note": "similarityLocal + refinement (a14): one wave per candidate, a 16 x 16 patch per feature pulls "
+                                       "16-17 lines of 128 B for 256 useful bytes; by the counters neither the L2 (this fraction), nor the "
+                                       "L1 tag pipeline, nor the vector ALU is saturated on its own (DESIGN.md section 5)"}
 
     result = None
     h2d = cpu = None
@@ -520,6 +555,7 @@ def main():
                        "h2d_inclusive": h2d,
                        "parallelism": "template-shard x%d" % world},
             "roofline": roofline,
+            "roofline_refine": roofline_refine,
             "cpu_baseline": cpu,
         }
         print(json.dumps(result))
@@ -554,6 +590,22 @@ def pmc_traffic(config, frames_per_launch):
             if k.startswith("k_scan"):
                 return v["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
     return None, None
+
+
+def l2_counters(config, frames_per_launch):
+    """Per-kernel L1 / L2 counters per launch from the committed rocprofv3 --pmc passes (tools/collect_counters.sh,
+    profiles/summarize_l2.py): TCP_TCC_READ_REQ, TCP_TOTAL_CACHE_ACCESSES, TCC_REQ / HIT / MISS, and the calibrated size of a
+    TCP -> TCC read request.  None unless a committed file matches the config and the frames per launch."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*l2_counters_*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            continue
+        if d.get("frames_per_launch") == frames_per_launch and d.get("baseline_config") == config and d.get("kernels"):
+            d["source"] = os.path.relpath(path, ROOT)
+            return d
+    return None
 
 
 def cgroup_cpus():

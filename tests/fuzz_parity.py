@@ -85,16 +85,29 @@ while time.time() - t0 < budget:
     assert got.tobytes() == exp.tobytes(), ("match", color_only, T, w, h, n, thr, variant, len(got), len(exp))
     if nb > 1:
         d.set_tuning(lm.TUNE_PHASE_MAX_SLOTS, int(rng.choice([15, 0])))
+        d.set_tuning(lm.TUNE_BATCH_PHASES, int(rng.choice([0, 1, 2])))     # 16+ frames: level-fused batch launches or one per kernel
         for k in range(nb):
             d.upload_frame(k, bgr, None if color_only else depth)
         outb, cntb = d.match_batch(nb, thr, 0, cap_per_frame=max(len(exp), 1))
         for k in range(nb):
             assert cntb[k] == len(exp) and outb[k, :cntb[k]].tobytes() == exp.tobytes(), ("batch", color_only, T, w, h, n, thr, nb, k)
         n_batch += 1
+    if n_match % 4 == 0:
+        # a second class: Detector::match with a class list = the merged per-class lists, one pre-processing (lm_match_batch_classes),
+        # and the prepared slot again per class (lm_match_prepared)
+        d2, f2, _ = synth.make_bank(max(n // 2, 3), M, 2, seed=int(rng.integers(1 << 30)), quantized=q, crop_fraction=0.3, frame_size=(w, h), T0=T[0])
+        d.add_class("c2", d2, f2); o.add_class("c2", d2, f2)
+        d.upload_frame(0, bgr, None if color_only else depth)
+        exp2 = o.match(bgr, None if color_only else depth, thr, class_idx=-1, threads=8, cap=1 << 18)
+        outc, cntc = d.match_batch_classes(0, 1, thr, [1, 0], cap_per_frame=max(len(exp2), 1))
+        assert outc[0, :cntc[0]].tobytes() == exp2.tobytes(), ("class list", color_only, T, w, h, n, thr)
+        for c in (0, 1):
+            outp, cntp = d.match_prepared(0, 1, thr, [c], cap_per_frame=max(len(exp2), 1))
+            assert outp[0, :cntp[0]].tobytes() == exp2[exp2["class_idx"] == c].tobytes(), ("prepared", color_only, T, w, h, n, thr, c)
     # a11-a13 alone: the scan kernel's candidate list, record by record
     d.upload_frame(1, bgr, None if color_only else depth)
     d.prepare_slot(1)
-    assert np.array_equal(d.stage_scan(1, thr), o.scan_candidates(thr, threads=8)), ("scan", color_only, T, w, h, n, thr, variant)
+    assert np.array_equal(d.stage_scan(1, thr, 0), o.scan_candidates(thr, 0, threads=8)), ("scan", color_only, T, w, h, n, thr, variant)
     d.close()
     n_match += 1
     n_scan += 1
