@@ -111,7 +111,9 @@ class Runner:
             saved = os.dup(1)
             os.dup2(2, 1)
             try:
-                det.comm_init(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, args.gather_cap)
+                # fixed gather capacity: 1024 records per frame and rank on average over a lane-step (the bench bank yields
+                # about 530 per frame and 3000-template shard at threshold 80); lists beyond it take the sized second exchange
+                det.comm_init(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, args.gather_cap or 1024)
             finally:
                 sys.stdout.flush()
                 os.dup2(saved, 1)
@@ -317,7 +319,7 @@ def main():
                          "whole bank (N = 8: 24 300, 3037 / 3038 per GPU)")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--threshold", type=float, default=80.0)
-    ap.add_argument("--gather-cap", type=int, default=0, help="lm_comm_init recs_per_frame_cap (0 = 256)")
+    ap.add_argument("--gather-cap", type=int, default=0, help="lm_comm_init recs_per_frame_cap (0 = 1024)")
     ap.add_argument("--byte-responses", action="store_true", help="LM_FLAG_BYTE_RESPONSES: byte scan kernel (A/B)")
     ap.add_argument("--scan-variant", type=int, default=0, help="A/B knob: features per load block of the scan (0: 6, 1: 12, 2: 3)")
     ap.add_argument("--no-prune", action="store_true",
@@ -421,7 +423,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     rep = runner.report()
-    exch_us, exch_n = det.get_exchange_profile() if exchange == "rccl" else (0.0, 0)
+    exch_us, exch_n, exch_fb = det.get_exchange_profile() if exchange == "rccl" else (0.0, 0, 0)
     det.set_profiling(False)
     one_lane = runner.one_lane_profile()
     if exchange == "rccl":
@@ -549,6 +551,8 @@ def main():
                        "rccl_ranks": rccl_ranks, "pci_bus_ids": bus_ids,
                        "functional_gloo": bool(args.functional_gloo) or None,
                        "exchange_span_us_per_lane_step": round(exch_us / exch_n, 2) if exch_n else None,
+                       "exchange_sized_fallbacks": exch_fb if exchange == "rccl" else None,
+                       "gather_records_per_frame_cap": (args.gather_cap or 1024) if exchange == "rccl" else None,
                        "exchange_span_note": "HIP events on the lane's stream from behind k_sort_unique to behind the D2H of "
                                              "the gathered lists: k_pack_lists + 2 x ncclAllGather + 2 copies, per lane-step "
                                              "of %d frames (contains the wait for the slowest rank)" % Bl if exch_n else None,

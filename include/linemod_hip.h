@@ -361,8 +361,10 @@ int lm_set_profiling(lm_detector* det, int enable);
 int lm_get_profile(lm_detector* det, double stage_us[4], double* scan_algorithmic_bytes, int64_t* launches,
                    int64_t* frames);
 /* Accumulated with the profile above: HIP-event span of the exchange of lm_match_begin_gathered (behind the sort
- * kernel: k_pack_lists, the two ncclAllGather, the two D2H copies) and the number of exchanges. */
-int lm_get_exchange_profile(lm_detector* det, double* exchange_us, int64_t* exchanges);
+ * kernel: k_pack_lists, the two ncclAllGather, the two D2H copies), the number of exchanges, and (counted with
+ * profiling off too) how many lane-steps needed the sized second exchange because a rank's lists overflowed the
+ * fixed gather capacity or a frame was left to the host sort (raise recs_per_frame_cap if that is the common case). */
+int lm_get_exchange_profile(lm_detector* det, double* exchange_us, int64_t* exchanges, int64_t* fallbacks);
 /* Work counters since lm_set_profiling: out[0] frames that went through a3-a10, out[1] scan launches, out[2]
  * refinement launches, out[3] sort launches (they count with profiling off too). */
 int lm_get_stage_counts(lm_detector* det, int64_t out[4]);

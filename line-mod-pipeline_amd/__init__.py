@@ -168,7 +168,7 @@ def load_library(path=None):
     lib.lm_match_prepared.argtypes = [vp, i, i, f, vp, i, vp, sz, vp]
     lib.lm_match_begin_classes.argtypes = [vp, i, i, i, f, vp, i]
     lib.lm_device_pci_bus_id.argtypes = [vp, C.c_char_p, sz]
-    lib.lm_get_exchange_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.lm_get_exchange_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.lm_get_stage_counts.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.lm_get_scan_lane_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     if path is None:
@@ -576,10 +576,11 @@ class Detector:
         return r.value, w.value
 
     def get_exchange_profile(self):
-        """(accumulated HIP-event microseconds of the gathered path's exchange, number of exchanges)."""
-        us, n = C.c_double(), C.c_int64()
-        self._check(self.lib.lm_get_exchange_profile(self.h, C.byref(us), C.byref(n)))
-        return us.value, n.value
+        """(accumulated HIP-event microseconds of the gathered path's exchange, number of exchanges, lane-steps that needed
+        the sized second exchange)."""
+        us, n, fb = C.c_double(), C.c_int64(), C.c_int64()
+        self._check(self.lib.lm_get_exchange_profile(self.h, C.byref(us), C.byref(n), C.byref(fb)))
+        return us.value, n.value, fb.value
 
     def get_stage_counts(self):
         """dict(preprocess_frames, scan_launches, refine_launches, sort_launches) since set_profiling()."""

@@ -173,6 +173,7 @@ struct lm_detector {
     double prof_us[4] = {0, 0, 0, 0};
     double prof_scan_bytes = 0;
     long long prof_launches = 0, prof_frames = 0;
+    long long prof_exch_fallbacks = 0;                           // lane-steps that needed the sized second exchange
     double prof_exch_us = 0; long long prof_exch_launches = 0;   // pack + 2 x all-gather + D2H of the gathered path (ev[4] -> ev[5])
     long long cnt_preprocess_frames = 0, cnt_scan_launches = 0, cnt_refine_launches = 0, cnt_sort_launches = 0;   // lm_get_stage_counts
 
@@ -1780,6 +1781,7 @@ int lm_match_end_gathered(lm_detector* d, int lane, lm_match_t* out, size_t cap,
     }
     if (status == 0)
         return lm_merge_frames(reinterpret_cast<const lm_match_t*>(g.h_all_rec), g.cap_lane, cnt.data(), R, n, f0, f1, out, cap, counts, n_out);
+    d->prof_exch_fallbacks += 1;
     return gather_fallback(d, lane, ln.first, n, f0, f1, out, cap, counts, n_out);
 }
 
@@ -2215,7 +2217,7 @@ int lm_set_profiling(lm_detector* d, int enable) {
     d->profiling = enable != 0;
     for (double& v : d->prof_us) v = 0;
     d->prof_scan_bytes = 0; d->prof_launches = 0; d->prof_frames = 0;
-    d->prof_exch_us = 0; d->prof_exch_launches = 0;
+    d->prof_exch_us = 0; d->prof_exch_launches = 0; d->prof_exch_fallbacks = 0;
     d->cnt_preprocess_frames = d->cnt_scan_launches = d->cnt_refine_launches = d->cnt_sort_launches = 0;
     return LM_OK;
 }
@@ -2281,10 +2283,11 @@ int lm_get_scan_lane_stats(lm_detector* d, uint64_t* lane_loads_issued, uint64_t
     return LM_OK;
 }
 
-int lm_get_exchange_profile(lm_detector* d, double* exchange_us, int64_t* launches) {
+int lm_get_exchange_profile(lm_detector* d, double* exchange_us, int64_t* launches, int64_t* fallbacks) {
     if (!d) return fail(LM_ERR_INVALID, "null detector");
     if (exchange_us) *exchange_us = d->prof_exch_us;
     if (launches) *launches = d->prof_exch_launches;
+    if (fallbacks) *fallbacks = d->prof_exch_fallbacks;
     return LM_OK;
 }
 

@@ -180,7 +180,14 @@ bool HighLevelLineMOD::detectTemplatesBatch(std::vector<std::vector<Image>>& in_
         // the mixed list is in the total order; a class's sub-list keeps it
         for (size_t c = 0; c < nc; ++c) {
             std::vector<lm_match_t>& dst = out_matches[c][(size_t)i];
-            for (int32_t k = 0; k < counts[(size_t)i]; ++k) if (m[k].class_idx == (int32_t)in_classNumbers[c]) dst.push_back(m[k]);
+            // Match::operator== compares x, y, similarity and class; std::unique removed the ADJACENT duplicates of the mixed
+            // list, where a match of another class may sit between two equal ones of this class: filtering and removing
+            // adjacent duplicates once more gives exactly the list a one-class match() returns
+            for (int32_t k = 0; k < counts[(size_t)i]; ++k) {
+                if (m[k].class_idx != (int32_t)in_classNumbers[c]) continue;
+                if (!dst.empty() && dst.back().x == m[k].x && dst.back().y == m[k].y && dst.back().similarity == m[k].similarity) continue;
+                dst.push_back(m[k]);
+            }
             if (dst.empty()) continue;
             any = true;
             const Image* depth_img = in_frames[(size_t)i].size() >= 2 ? &in_frames[(size_t)i][1] : nullptr;

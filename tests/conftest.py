@@ -73,3 +73,16 @@ def assert_matches_equal(a, b, sim_tol=0.0):
         assert np.array_equal(a["similarity"], b["similarity"])
     else:
         assert np.allclose(a["similarity"], b["similarity"], atol=sim_tol, rtol=0)
+
+
+def class_sublist(mixed, class_idx):
+    """The list Detector::match returns for ONE class, from the list it returns for several (HighLevelLinemod.cpp:145,152):
+    filter by class, then adjacent-unique on (x, y, similarity) once more -- std::unique only removes ADJACENT duplicates,
+    and in the mixed order a match of another class may sit between two equal matches of this one."""
+    sub = mixed[mixed["class_idx"] == class_idx]
+    if len(sub) < 2:
+        return sub
+    same = (sub["x"][1:] == sub["x"][:-1]) & (sub["y"][1:] == sub["y"][:-1]) & (sub["similarity"][1:] == sub["similarity"][:-1])
+    keep = np.ones(len(sub), bool)
+    keep[1:] = ~same
+    return sub[keep]

@@ -6,7 +6,7 @@ a11-a13 candidate list of the scan kernel is compared record by record with the 
 import numpy as np
 import pytest
 
-from conftest import assert_matches_equal
+from conftest import assert_matches_equal, class_sublist
 
 pytestmark = pytest.mark.gpu
 THREADS = 16
@@ -154,5 +154,5 @@ def test_config5_three_classes_8100_templates_each_1280x960_rgbd(lm, orc, synth)
         mixed = got[i, :cnt[i]]
         for c in range(3):
             pc, pn = per[c]
-            assert_matches_equal(mixed[mixed["class_idx"] == c], pc[i, :pn[i]])
+            assert_matches_equal(class_sublist(mixed, c), pc[i, :pn[i]])
     d.close()

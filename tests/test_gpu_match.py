@@ -149,8 +149,16 @@ def test_class_list_matches_once_prepared(lm, orc, synth, frame0):
     per = {(i, c): o.match(b, dp, thr, class_idx=c) for i, (b, dp) in enumerate(frames) for c in range(4)}
     assert sum(len(v) for v in per.values()) > 20
 
+    mixed_all = [o.match(b, dp, thr, class_idx=-1) for b, dp in frames]
+
     def expect(i, classes):
+        # the reference's semantics for a class LIST: all the named classes' matches sorted together, then adjacent-unique
+        # (for this bank no two equal matches of one class have another class's match between them, so the merge of the
+        # per-class lists is that list; checked against the oracle's all-class list below)
         return lm.merge_matches([per[(i, c)] for c in classes])
+
+    for i in range(3):
+        assert_matches_equal(expect(i, [0, 1, 2, 3]), mixed_all[i])
 
     d.set_profiling(False)          # resets the stage counters
     for classes in ([0, 2], [1, 2, 3], [3], [2, 0, 2], [0, 1, 2, 3]):
