@@ -142,6 +142,12 @@ int lm_get_template(const lm_detector* det, int class_idx, int template_id, int 
 int lm_match(lm_detector* det, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
              float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 
+/* The same with upstream's class LIST (std::vector<String> class_ids; the reference builds a one-element list, :145):
+ * the linear memories are built once and every named class is scanned against them; the list holds the matches of all
+ * named classes in the total order (lm_match_t.class_idx tells them apart).  n_classes == 0 or {-1} = all classes. */
+int lm_match_classes(lm_detector* det, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
+                     float threshold, const int32_t* class_idxs, int n_classes, lm_match_t* out, size_t cap, size_t* n_out);
+
 /* Resident-frame path used by the benchmark and by batch-of-frames serving: upload once, match many.
  *
  * Streaming input (the reference's real call pattern is one fresh camera frame per detect() call,

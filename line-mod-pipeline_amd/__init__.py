@@ -72,7 +72,7 @@ EXPORTS = [
     "lm_rendezvous_broadcast", "lm_normal_lut_is_substitute",
     "lm_set_scan_stats", "lm_get_scan_stats", "lm_color_check_counts",
     "lm_match_batch_classes", "lm_match_prepared", "lm_match_begin_classes", "lm_device_pci_bus_id",
-    "lm_get_exchange_profile", "lm_get_stage_counts", "lm_get_scan_lane_stats",
+    "lm_get_exchange_profile", "lm_get_stage_counts", "lm_get_scan_lane_stats", "lm_match_classes",
 ]
 
 _lib = None
@@ -164,6 +164,7 @@ def load_library(path=None):
     lib.lm_match_end_gathered.argtypes = [vp, i, vp, sz, vp, C.POINTER(i), C.POINTER(i), C.POINTER(sz)]
     lib.lm_comm_barrier.argtypes = [vp]
     lib.lm_comm_max.argtypes = [vp, C.POINTER(C.c_double), i]
+    lib.lm_match_classes.argtypes = [vp, vp, sz, vp, sz, f, vp, i, vp, sz, C.POINTER(sz)]
     lib.lm_match_batch_classes.argtypes = [vp, i, i, f, vp, i, vp, sz, vp]
     lib.lm_match_prepared.argtypes = [vp, i, i, f, vp, i, vp, sz, vp]
     lib.lm_match_begin_classes.argtypes = [vp, i, i, i, f, vp, i]
@@ -542,6 +543,21 @@ class Detector:
     def _class_list(self, classes):
         c = _c([] if classes is None else classes, np.int32).reshape(-1)
         return c, _ptr(c) if c.size else None
+
+    def match_classes(self, bgr, depth, threshold, classes=None, cap=1 << 16):
+        """Detector::match(sources, threshold, matches, class_ids) on a host frame with a class list."""
+        bgr = _c(bgr, np.uint8)
+        depth = None if depth is None else _c(depth, np.uint16)
+        if bgr.shape != (self.cfg.height, self.cfg.width, 3):
+            raise ValueError("frame size does not match the detector")
+        c, cp = self._class_list(classes)
+        out = np.zeros(cap, MATCH_DTYPE)
+        n = C.c_size_t()
+        rc = self.lib.lm_match_classes(self.h, _ptr(bgr), 0, _ptr(depth), 0, threshold, cp, c.size, _ptr(out), cap, C.byref(n))
+        if rc == LM_ERR_OVERFLOW and n.value > cap:
+            return self.match_classes(bgr, depth, threshold, classes, cap=n.value)
+        self._check(rc)
+        return out[:n.value].copy()
 
     def match_batch_classes(self, first_slot, n_slots, threshold, classes=None, cap_per_frame=4096):
         """Detector::match with upstream's class list: one pre-processing per frame for all the named classes."""

@@ -1307,8 +1307,8 @@ static int upload_split(lm_detector* d, int slot, const uint8_t* bgr, const uint
     return LM_OK;
 }
 
-int lm_match(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
-             float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out) {
+static int match_host_frame(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
+                            float threshold, std::vector<int> classes, lm_match_t* out, size_t cap, size_t* n_out) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
     if ((rc = ensure_bank(d))) return rc;
@@ -1324,8 +1324,19 @@ int lm_match(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16
     if (d->match_upload_mode == 2 && dense && bgr && (d->cfg.num_modalities < 2 || depth)) {
         if ((rc = upload_split(d, 0, bgr, depth, pinned))) return rc;
     } else if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride, pinned, d->match_upload_mode == 1 ? nullptr : d->stream))) return rc;
-    if ((rc = run_match(d, 0, 1, threshold, class_idx))) return rc;
+    if ((rc = run_match(d, 0, 1, threshold, std::move(classes)))) return rc;
     return collect_slot(d, 0, out, cap, n_out);
+}
+
+int lm_match(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
+             float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out) {
+    return match_host_frame(d, bgr, bgr_stride, depth, depth_stride, threshold, std::vector<int>(1, class_idx), out, cap, n_out);
+}
+
+int lm_match_classes(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
+                     float threshold, const int32_t* class_idxs, int n_classes, lm_match_t* out, size_t cap, size_t* n_out) {
+    if (n_classes < 0 || (n_classes && !class_idxs)) return fail(LM_ERR_INVALID, "bad class list");
+    return match_host_frame(d, bgr, bgr_stride, depth, depth_stride, threshold, std::vector<int>(class_idxs, class_idxs + n_classes), out, cap, n_out);
 }
 
 int lm_match_batch(lm_detector* d, int n_slots, float threshold, int class_idx, lm_match_t* out, size_t cap_per_frame,

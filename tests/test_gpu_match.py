@@ -168,6 +168,9 @@ def test_class_list_matches_once_prepared(lm, orc, synth, frame0):
     sc = d.get_stage_counts()
     # [0, 2] is two runs of classes (two scan launches), the others one each
     assert sc["preprocess_frames"] == 15 and sc["scan_launches"] == 7 and sc["sort_launches"] == 5, sc
+    # a host frame with a class list (lm_match_classes), through slot 0
+    assert_matches_equal(d.match_classes(*frames[2], thr, [3, 1]), expect(2, [1, 3]))
+    d.upload_frame(0, *frames[0])
     # all classes: empty list, {-1}, and the classic class_idx = -1 agree
     ref, rc = d.match_batch(3, thr, -1)
     for classes in (None, [-1]):
