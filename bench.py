@@ -105,19 +105,9 @@ class Runner:
         self.last_owned = None
         if exchange == "rccl":
             port = int(os.environ.get("MASTER_PORT", "29500")) + 1
-            # librccl prints a version banner on STDOUT when the first communicator comes up; stdout is for the one JSON
-            # line, so file descriptor 1 points at stderr while the communicators are created
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                # fixed gather capacity: 1024 records per frame and rank on average over a lane-step (the bench bank yields
-                # about 530 per frame and 3000-template shard at threshold 80); lists beyond it take the sized second exchange
-                det.comm_init(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, args.gather_cap or 1024)
-            finally:
-                sys.stdout.flush()
-                os.dup2(saved, 1)
-                os.close(saved)
+            # fixed gather capacity: 1024 records per frame and rank on average over a lane-step (the bench bank yields
+            # about 530 per frame and 3000-template shard at threshold 80); lists beyond it take the sized second exchange
+            det.comm_init(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, args.gather_cap or 1024)
             self.gbuf = [(np.zeros(self.Bl * CAP // 4, lm.MATCH_DTYPE), np.zeros(self.Bl, np.int32)) for _ in range(self.NL)]
 
     # ------------------------------------------------------------------------------------------
@@ -373,6 +363,12 @@ def main():
     # two streams overlap far less (measured r02: 99.9 K detections/s without torch, 88.2 K with it; one lane 92.7 K
     # either way).  The exchange is RCCL called from the C++ library.
     lm = importlib.import_module("line-mod-pipeline_amd")
+    # librccl prints a version banner on STDOUT (from its own threads, when the first communicator / collective comes up);
+    # stdout carries exactly ONE JSON line, so file descriptor 1 points at stderr for the whole run and the line is written
+    # to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     exchange = "gloo" if (args.functional_gloo and world > 1) else ("rccl" if (world > 1 or args.force_rccl) else "none")
     runner = Runner(args, rank, world, local_rank, exchange)
     det = runner.det
@@ -562,8 +558,8 @@ def main():
             "roofline_refine": roofline_refine,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(result))
         sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if exchange == "gloo":
         dist.barrier()
         dist.destroy_process_group()

@@ -4,7 +4,11 @@
 // colour checks batched on the GPU (lm_color_check_counts).  Prints, for pytest to compare:
 //   - "counts <n> <mismatches>": GPU in_hull / in_both of EVERY match of frame 0 against the host's hull_counts
 //   - the final poses with the colour check on the GPU and on the host (must be identical), and where each object was put
-// usage: config5_e2e <mesh.bin>
+// usage: config5_e2e <mesh.bin> [full]
+//   full: the STATED bank size of BASELINE config 5 -- 162 viewpoints (subdivisions 2, no symmetry reduction) x 5 radii x
+//   10 in-plane rotations = 8 100 templates per class, 24 300 in the bank (CameraViewPoints.cpp:84-124 x
+//   linemod_settings.yml:21-27); takes minutes (24 300 renders / rotations / GPU quantisations), so pytest runs it only
+//   with LM_CONFIG5_FULL=1 (log: profiles/r03_config5_full.log)
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -23,6 +27,7 @@ static const int W = 1280, H = 960, NF = 8;
 
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
+    const bool full = argc >= 3 && std::string(argv[2]) == "full";
     std::ifstream f(argv[1], std::ios::binary);
     std::vector<char> mb((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     const uint32_t* hdr = reinterpret_cast<const uint32_t*>(mb.data());
@@ -44,6 +49,7 @@ int main(int argc, char** argv) {
     ts.onlyUseColorModality = false;
     ts.detectorThreshold = 85.f;
     ts.angleStart = -30; ts.angleStop = 30; ts.angleStep = 30;
+    if (full) { ts.angleStart = -45; ts.angleStop = 45; ts.angleStep = 10; }     // linemod_settings.yml:25-27
     PoseDetection pd(cam, ts);
     HighLevelLineMOD& line = *pd.lineMod();
     // templates are rendered with the principal point at the image centre (the reference's renderer, OpenglRender.cpp:9-11)
@@ -51,8 +57,13 @@ int main(int argc, char** argv) {
     SoftRender render(rcam);
     SymmetryProperties sym; sym.rotationallySymmetrical = true; sym.planesOfSymmetry = Vec3{1, 1, 1};
     GeneratorSettings gs; gs.startDistance = 600; gs.endDistance = 700; gs.stepSize = 50; gs.subdivisions = 3;
+    SymmetryProperties gen_sym = sym;
+    if (full) {   // every viewpoint of the subdivision-2 sphere, five radii
+        gen_sym.rotationallySymmetrical = false; gen_sym.planesOfSymmetry = Vec3{0, 0, 0};
+        gs.startDistance = 600; gs.endDistance = 800; gs.stepSize = 50; gs.subdivisions = 2;
+    }
     for (int c = 0; c < 3; ++c) {
-        int n = generate_templates(line, render, mesh[c], names[c], sym, gs);
+        int n = generate_templates(line, render, mesh[c], names[c], gen_sym, gs);
         std::printf("class %d templates %d\n", c, n);
         double lo[3] = {0, 0, 50}, hi[3] = {255, 150, 255};   // V >= 50: the black background fails the colour test
         line.setColorRange((uint16_t)c, lo, hi);
@@ -115,6 +126,7 @@ int main(int argc, char** argv) {
                     return 1;
                 }
                 for (size_t k = 0; k < m[i].size(); ++k) {
+                    if (full && k >= 100) break;           // the host check fills a full-frame mask per match: a sample is enough here
                     long a = 0, b = 0;
                     pp.color_counts(m[i][k], cmask[i], &a, &b);
                     if (a != (long)gi[k] || b != (long)gb[k]) ++bad;

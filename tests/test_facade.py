@@ -212,3 +212,39 @@ def test_config5_pose_detection_batch_end_to_end(lm, tmp_path):
         # the object's centre was put (ox, oy) pixels from the image centre of the shifted frame
         assert abs(tx - ox * tz / 2091.38282) < 25 and abs(ty - oy * tz / 2091.38282) < 25, l
     assert found >= 20, found                                            # 8 frames x 3 classes
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("LM_CONFIG5_FULL") != "1", reason="minutes of template generation: run with LM_CONFIG5_FULL=1 "
+                                                                      "(log of the r03 run: profiles/r03_config5_full.log)")
+def test_config5_full_bank_end_to_end(lm, tmp_path):
+    """BASELINE config 5 at its STATED size, end to end with poses: 8 frames of 1280x960 RGB-D, three classes
+    x 8 100 rendered templates (162 viewpoints x 5 radii x 10 rotations), all three classes in ONE detectBatch (one
+    pre-processing per frame), GPU colour check == host colour check, poses of the multi-class call == one call per class."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "lagergehaeuse.npz"))
+    with open(tmp_path / "mesh.bin", "wb") as fh:
+        fh.write(np.array([len(g["vertices"]), len(g["faces"])], np.uint32).tobytes())
+        fh.write(g["vertices"].astype(np.float32).tobytes())
+        fh.write(g["faces"].astype(np.int32).tobytes())
+    exe = str(tmp_path / "config5_e2e")
+    libdir = os.path.dirname(lm.LIB_PATH)
+    host = os.path.join(ROOT, "line-mod-pipeline_amd", "host")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(ROOT, "tests", "cpp", "config5_e2e.cpp")] +
+                          [os.path.join(host, f) for f in ("HighLevelLinemod.cpp", "PostProcess.cpp", "TemplateGenerator.cpp",
+                                                           "PoseDetection.cpp")] +
+                          ["-L" + libdir, "-llinemod_hip", "-Wl,-rpath," + libdir])
+    r = subprocess.run([exe, "mesh.bin", "full"], cwd=tmp_path, capture_output=True, text=True, timeout=5400)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = [l for l in r.stdout.splitlines() if not l.startswith("ERROR")]
+    print("\n".join(l for l in out if l.startswith(("class ", "counts ", "stagecounts "))))
+    tmpl = [int(l.split()[3]) for l in out if l.startswith("class ")]
+    assert tmpl == [8100, 8100, 8100], tmpl
+    counts = [l.split() for l in out if l.startswith("counts ")][0]
+    assert int(counts[1]) >= 40 and int(counts[2]) == 0, counts
+    gpu = [l[4:] for l in out if l.startswith("gpu frame")]
+    hst = [l[5:] for l in out if l.startswith("host frame")]
+    per = [l[7:] for l in out if l.startswith("percls frame")]
+    assert len(gpu) == 24 and gpu == hst and per == gpu
+    sc = [l.split() for l in out if l.startswith("stagecounts gpu")][0]
+    assert int(sc[3]) == 8 and int(sc[5]) == 1, sc
+    assert sum(1 for l in gpu if int(l.split()[8]) > 0) >= 20
