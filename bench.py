@@ -42,6 +42,15 @@ CONFIGS = {
     3: dict(name="SURVEY 8d config 3: 1280x960, ColorGradient only, T={2,8}, 2-level pyramid, fixed-geometry 192x192 "
                  "templates (level-1 bbox 96x96, P = 3909)",
             W=1280, H=960, color_only=True, l0_size=(192, 192), seed_frames=2234, seed_bank=77, lanes=2, batch=256),
+    # BASELINE configs[4] on the hot path: a batch of 8 frames of 1280x960 RGB-D against three classes x 8 100 templates
+    # (162 viewpoints x 5 radii x 10 rotations each) in ONE class-list match (Detector::match(..., class_ids)): one
+    # pre-processing per frame for the three classes.  The bank is fixed (24 300 templates; N ranks shard every class N
+    # ways), so this line is NOT a weak-scaling line.  The PoseDetection post-processing of config 5 is host C++
+    # (tests/test_facade.py), not part of the timed hot path.
+    5: dict(name="BASELINE configs[4] / SURVEY 8d config 5 (hot path): batches of 8 frames of 1280x960 RGB-D, T={5,8}, three classes x "
+                 "8100 templates (variable geometry, level-0 bbox 96..320) in one class-list match",
+            W=1280, H=960, color_only=False, l0_size=None, size_range=(96, 320), seed_frames=1234, seed_bank=500, lanes=2, batch=16,
+            classes=3, templates_per_class=8100),
 }
 
 
@@ -80,9 +89,20 @@ class Runner:
         # ---- workload: seeded synthetic frames + fixed-geometry bank
         self.frames = [synth.make_frame(W, H, seed=wl["seed_frames"] + i) for i in range(B)]
         q = quantized_from_gpu(det, self.frames[0][0], self.frames[0][1], M)
-        self.descs, self.feats, _ = synth.make_bank(self.n_total, M, 2, seed=wl["seed_bank"], fixed_l0_size=wl["l0_size"],
-                                                    quantized=q, crop_fraction=0.1, frame_size=(W, H), T0=det.get_T(0))
-        det.add_class("synthetic.ply", self.descs, self.feats)
+        self.banks = []
+        if wl.get("classes"):
+            self.n_total = wl["classes"] * wl["templates_per_class"]
+            for c in range(wl["classes"]):
+                descs, feats, _ = synth.make_bank(wl["templates_per_class"], M, 2, seed=wl["seed_bank"] + c, size_range=wl["size_range"],
+                                                  quantized=q, crop_fraction=0.02, frame_size=(W, H), T0=det.get_T(0))
+                self.banks.append(("model%d.ply" % c, descs, feats))
+        else:
+            descs, feats, _ = synth.make_bank(self.n_total, M, 2, seed=wl["seed_bank"], fixed_l0_size=wl["l0_size"],
+                                              quantized=q, crop_fraction=0.1, frame_size=(W, H), T0=det.get_T(0))
+            self.banks.append(("synthetic.ply", descs, feats))
+        for name, descs, feats in self.banks:
+            det.add_class(name, descs, feats)
+        self.cls = -1 if len(self.banks) > 1 else 0       # all classes of the bank = upstream's class list of all ids
         if args.fork:
             det.set_tuning(lm.TUNE_FORK_MAX_SLOTS, 1 << 20)
         if args.no_batch_phases:
@@ -124,7 +144,7 @@ class Runner:
         k0 = self.k
         self.k += n
         for l in range(NL):
-            begin(l, l * Bl, Bl, thr, 0)
+            begin(l, l * Bl, Bl, thr, self.cls)
         for k in range(k0, k0 + n):
             for l in range(NL):
                 if rccl:
@@ -136,7 +156,7 @@ class Runner:
                     o, cn = self.views[k % NBUF][l]
                     det.match_end(l, CAP, out=o, counts=cn)
                 if k + 1 < k0 + n:
-                    begin(l, l * Bl, Bl, thr, 0)
+                    begin(l, l * Bl, Bl, thr, self.cls)
             if after_step is not None:
                 after_step(k)
 
@@ -146,13 +166,13 @@ class Runner:
         det = self.det
         det.set_profiling(True)
         for _ in range(steps):
-            det.match_begin(0, 0, self.Bl, self.args.threshold, 0)
+            det.match_begin(0, 0, self.Bl, self.args.threshold, self.cls)
             det.match_end(0, CAP, out=self.views[0][0][0], counts=self.views[0][0][1])
         prof = det.get_profile()
         det.set_profiling(False)
         # one more launch with the scan's feature counters on: what fraction of the feature loads the pruning keeps
         det.set_scan_stats(True)
-        det.match_begin(0, 0, self.Bl, self.args.threshold, 0)
+        det.match_begin(0, 0, self.Bl, self.args.threshold, self.cls)
         det.match_end(0, CAP, out=self.views[0][0][0], counts=self.views[0][0][1])
         loaded, total = det.get_scan_stats()
         lane_issued, lane_total = det.get_scan_lane_stats()
@@ -184,7 +204,7 @@ class Runner:
 
         def begin(s):
             for l in range(NL):
-                det.match_begin(l, s * B + l * Bl, Bl, thr, 0)
+                det.match_begin(l, s * B + l * Bl, Bl, thr, self.cls)
 
         def end(k):
             for l in range(NL):
@@ -222,7 +242,7 @@ class Runner:
 
     def report(self):
         prof = self.det.get_profile()
-        return {"prof": prof, "scan_load_bytes": self.det.scan_load_bytes(0), "Bl": self.Bl, "NL": self.NL,
+        return {"prof": prof, "scan_load_bytes": self.det.scan_load_bytes(self.cls), "Bl": self.Bl, "NL": self.NL,
                 "matches0": int(self.bufs[(self.k - 1) % NBUF][1][0]) if self.k else 0}
 
 
@@ -296,7 +316,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[] entry (2 or 3)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="2 / 3: SURVEY 8d configs 2 / 3 (the headline is config 2); 5: the hot path of BASELINE configs[4] (8-frame "
+                         "batches of 1280x960 RGB-D, 3 classes x 8100 templates)")
     ap.add_argument("--batch", type=int, default=0,
                     help="frames per step (resident in HBM); 0 = the config's default (config 2: 288 = 3 lanes x 96, "
                          "config 3: 256 = 2 lanes x 128: the launch shapes measured fastest, DESIGN.md section 6)")
@@ -333,8 +355,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     args = ap.parse_args()
 
+    if CONFIGS[args.config].get("classes"):
+        args.scaling = "strong"            # config 5's bank is fixed (3 x 8100 templates): N ranks shard it, it does not grow with N
     if not args.batch:
-        args.batch = CONFIGS[args.config]["batch"] if not args.lanes else 128 * args.lanes
+        args.batch = CONFIGS[args.config]["batch"] if not args.lanes else (128 if args.config != 5 else 8) * args.lanes
     if not args.lanes:
         args.lanes = CONFIGS[args.config]["lanes"]
     if args.gpus < 1:
@@ -627,13 +651,15 @@ def cpu_baseline(args, runner, lm):
         cores = os.cpu_count() or 1
         color_only = runner.M == 1
         orc = O.Detector(color_only=color_only, lib_path=lib)
-        orc.add_class("synthetic.ply", runner.descs, runner.feats)
+        for name, descs, feats in runner.banks:
+            orc.add_class(name, descs, feats)
+        cls = runner.cls
         det, frames, thr = runner.det, runner.frames, args.threshold
         for i in range(min(4, len(frames))):
             bgr, depth = frames[i]
             det.upload_frame(i, bgr, None if color_only else depth)
-            gpu = det.match_slot(i, thr, 0)
-            exp = orc.match(bgr, None if color_only else depth, thr, 0, threads=min(cores, 16))
+            gpu = det.match_slot(i, thr, cls)
+            exp = orc.match(bgr, None if color_only else depth, thr, cls, threads=min(cores, 16))
             if gpu.tobytes() != exp.tobytes():
                 return {"error": "GPU match list of frame %d differs from the oracle: timing not accepted" % i}
         bgr, depth = frames[0]
@@ -646,7 +672,7 @@ def cpu_baseline(args, runner, lm):
         best_t, threads = None, cores
         for th in sorted(cand):
             t1 = time.perf_counter()
-            orc.match(bgr, depth, thr, 0, threads=th)
+            orc.match(bgr, depth, thr, cls, threads=th)
             t = time.perf_counter() - t1
             if best_t is None or t < best_t:
                 best_t, threads = t, th
@@ -654,13 +680,13 @@ def cpu_baseline(args, runner, lm):
         n = 0
         while True:
             b, d = frames[n % len(frames)]
-            orc.match(b, None if color_only else d, thr, 0, threads=threads)
+            orc.match(b, None if color_only else d, thr, cls, threads=threads)
             n += 1
             if time.perf_counter() - t0 >= args.cpu_seconds or n >= 5000:
                 break
         dt = time.perf_counter() - t0
         t1 = time.perf_counter()
-        orc.match(bgr, depth, thr, 0, threads=1)
+        orc.match(bgr, depth, thr, cls, threads=1)
         single = time.perf_counter() - t1
         # the same frames through the scalar loop shape (one bounds check per byte of the similarity sums): what r01 / r02
         # reported; the default above hoists the check so that the byte adds vectorise like upstream's SSE path
@@ -670,11 +696,11 @@ def cpu_baseline(args, runner, lm):
             k = 0
             while time.perf_counter() - t1 < max(args.cpu_seconds / 4, 2.0) and k < 1000:
                 b, d = frames[k % len(frames)]
-                ms = orc.match(b, None if color_only else d, thr, 0, threads=threads)
+                ms = orc.match(b, None if color_only else d, thr, cls, threads=threads)
                 k += 1
             scalar_rate = k / (time.perf_counter() - t1)
             t1 = time.perf_counter()
-            orc.match(bgr, depth, thr, 0, threads=1)
+            orc.match(bgr, depth, thr, cls, threads=1)
             scalar_single = time.perf_counter() - t1
         finally:
             O.set_scan_mode(1, lib)

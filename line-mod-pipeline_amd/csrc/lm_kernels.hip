@@ -1115,11 +1115,16 @@ __device__ __forceinline__ u32 hw_u16(const u32x4* A, int hw) {
 
 // float tail of a5 for one pixel: normal (1150 ddx, 1150 ddy, -det d), normalised, quantised, looked up; returns the
 // label's rank code (see above), 0 for an invalid pixel.  Same operation order as the oracle.
+// SMALL: |ddx * 1150| and |ddy * 1150| are known to stay below 2^31 (difference_threshold <= 249: |ddx| <= 125 * 60 *
+// (threshold - 1)), so the products are exact in 32-bit integers and ONE int -> float conversion rounds them exactly like
+// the double product rounded to float (both round the same exact integer to nearest even) -- two integer multiplies and
+// conversions instead of six double-precision instructions per pixel.
+template <bool SMALL>
 __device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool valid, const u8* __restrict__ lut) {
     // same values as upstream's 64-bit integer products rounded once to float: |ddx| < 2^30 so the
     // double product is exact; |det * d| <= 22500 * 65535 < 2^31
-    float nx = (float)((double)ddx * 1150.0);
-    float ny = (float)((double)ddy * 1150.0);
+    float nx = SMALL ? (float)(ddx * 1150) : (float)((double)ddx * 1150.0);
+    float ny = SMALL ? (float)(ddy * 1150) : (float)((double)ddy * 1150.0);
     float nz = (float)(-mul_i24(det, d));
     const float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
     const float inv = __fdiv_rn(1.0f, len > 0 ? len : 1.0f);
@@ -1135,7 +1140,8 @@ __device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool v
     return (valid && len > 0 && in_lut) ? ecode : 0u;
 }
 
-__device__ __forceinline__ void d_dnormal(const u32 vblock, const u16* __restrict__ depth0, int w, int h, int dist_thr, int diff_thr,
+template <bool SMALL>
+__device__ __forceinline__ void d_dnormal_t(const u32 vblock, const u16* __restrict__ depth0, int w, int h, int dist_thr, int diff_thr,
                                                   const u8* __restrict__ lut, u8* __restrict__ code0, size_t in_stride,
                                                   size_t tmp_stride, int gblocks, int nslots) {
     u32 slot, tile;
@@ -1206,7 +1212,7 @@ __device__ __forceinline__ void d_dnormal(const u32 vblock, const u16* __restric
                         ddxq = mad_i16h<false>(cj, sx, mad_i16h<false>(ncx, sy, 0));
                         ddyq = mad_i16h<false>(ci, sy, mad_i16h<false>(ncx, sx, 0));
                     }
-                    const u32 e = dn_label(mul_i24(detq, 625), mul_i24(ddxq, 125), mul_i24(ddyq, 125), d, valid, lut);
+                    const u32 e = dn_label<SMALL>(mul_i24(detq, 625), mul_i24(ddxq, 125), mul_i24(ddyq, 125), d, valid, lut);
                     out[p >> 2] |= e << (8 * (p & 3));
                 }
             }
@@ -1242,12 +1248,19 @@ __device__ __forceinline__ void d_dnormal(const u32 vblock, const u16* __restric
             const int det = mul_i24(A0, A3) - mul_i24(A1, A1);
             const int ddx = mul_i24(A3, b0) - mul_i24(A1, b1);
             const int ddy = mul_i24(A0, b1) - mul_i24(A1, b0);
-            const u32 e = dn_label(det, ddx, ddy, d, valid, lut);
+            const u32 e = dn_label<false>(det, ddx, ddy, d, valid, lut);
             out[p >> 2] |= e << (8 * (p & 3));
         }
         }
     }
     *reinterpret_cast<u32x2*>(code + (size_t)y * w + 8 * g) = u32x2{out[0], out[1]};
+}
+// (a wave-uniform branch once per wave: the two bodies differ in the float tail's first two conversions, see dn_label)
+__device__ __forceinline__ void d_dnormal(const u32 vblock, const u16* __restrict__ depth0, int w, int h, int dist_thr, int diff_thr,
+                                          const u8* __restrict__ lut, u8* __restrict__ code0, size_t in_stride,
+                                          size_t tmp_stride, int gblocks, int nslots) {
+    if (diff_thr >= 0 && diff_thr <= 249) d_dnormal_t<true>(vblock, depth0, w, h, dist_thr, diff_thr, lut, code0, in_stride, tmp_stride, gblocks, nslots);
+    else d_dnormal_t<false>(vblock, depth0, w, h, dist_thr, diff_thr, lut, code0, in_stride, tmp_stride, gblocks, nslots);
 }
 __global__ __launch_bounds__(256) void k_dnormal(const u16* __restrict__ depth0, int w, int h, int dist_thr, int diff_thr,
                                                   const u8* __restrict__ lut, u8* __restrict__ code0, size_t in_stride,

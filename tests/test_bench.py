@@ -138,3 +138,16 @@ def test_bench_rejects_mismatched_world_size():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL,       # --gpus defaults to 1
                        capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
     assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_config5_line():
+    """bench.py --config 5: the hot path of BASELINE configs[4] -- 8-frame batches of 1280x960 RGB-D against three classes x
+    8100 templates in one class-list match (bank fixed: reported as strong scaling)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--no-h2d", "--steps", "4", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["config"]["baseline_config"] == 5 and d["config"]["templates_total"] == 24300 and d["scaling"] == "strong"
+    assert d["config"]["frames_per_step"] == 16 and d["config"]["lanes"] == 2 and d["value"] > 0
+    assert d["config"]["matches_frame0"] > 0

@@ -108,7 +108,7 @@ def test_depth_quantize_parity(det, orc, synth, shape):
     assert np.array_equal(det.stage_depth_quantize(steps), orc.depth_quantize(steps))
 
 
-@pytest.mark.parametrize("diff_thr", [1, 50, 5461, 5462, 40000])
+@pytest.mark.parametrize("diff_thr", [1, 50, 249, 250, 5461, 5462, 40000])   # 249 / 250: integer vs double products of the normal; 5461 / 5462: packed vs per-pixel taps
 def test_depth_quantize_thresholds_and_full_range(lm, orc, diff_thr):
     """k_dnormal runs its eight taps on packed pixel pairs (saturating u16 subtracts, i16 sums) up to
     difference_threshold 5461 and per pixel above: both sides of the switch, depths over the whole u16 range (deltas that
