@@ -524,14 +524,22 @@ def main():
                     "TCP_TOTAL_CACHE_ACCESSES_per_launch": c.get("TCP_TOTAL_CACHE_ACCESSES_sum"),
                     "TCC_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None}
 
-        roofline["l2_counters"] = from_counters(kernel, ol_us)
-        if roofline["l2_counters"]:
-            roofline["l2_counters"].update({
-                "source": l2c["source"], "calibration": l2c.get("calibration"),
-                "note": "COUNTED L1 -> L2 read requests of the committed rocprofv3 --pmc pass of this command (one lane, %d frames per "
-                        "launch) x the calibrated request size, over this run's clean launch duration: the counter-based twin of "
-                        "`frac` (which prices the bytes the loads REQUEST, 16 B per active lane; a request moves a whole 128-B "
-                        "line)" % Bl})
+        lc = from_counters(kernel, ol_us)
+        if lc and not args.no_prune and not args.scan_variant:
+            # The line's headline fraction comes from COUNTERS when a committed pass of this very command exists: L1 -> L2 read
+            # requests x the calibrated request size (128 B: a request moves a whole line) over this run's clean launch
+            # duration.  The r02 model -- bytes the loads NAME, 16 B per active lane -- stays beside it as `load_model`.
+            roofline["load_model"] = {"achieved": roofline["achieved"], "frac": roofline["frac"], "unit": "GB/s",
+                                      "load_bytes_per_launch": l2_bytes,
+                                      "note": "bytes the scan's vector loads request (16 B per lane-load issued, lm_get_scan_lane_stats) over "
+                                              "the clean launch duration: the r02 figure; a 128-B line is moved per request, so the L2 -> L1 "
+                                              "traffic the counters see is larger"}
+            roofline["achieved"], roofline["frac"] = lc["achieved_GBps"], lc["frac_of_l2_peak"]
+            lc.update({"source": l2c["source"], "calibration": l2c.get("calibration"),
+                       "note": "TCP_TCC_READ_REQ_sum of the committed rocprofv3 --pmc pass of this command (one lane, %d frames per "
+                               "launch; tools/collect_counters.sh) x the calibrated request size, over THIS run's clean launch "
+                               "duration (HIP events)" % Bl})
+            roofline["l2_counters"] = lc
         ref_us = one_lane["stage_us"][2] / max(one_lane["launches"], 1)
         rr = from_counters("k_refine<", ref_us)
         if rr:

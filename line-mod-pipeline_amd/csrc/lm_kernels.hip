@@ -1990,13 +1990,13 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
     bool pruned = false;
     unsigned long long alive = ~0ull;                      // PRUNE == 2: lanes with a position still in reach
     bool act = true;                                       // this lane loads (alive, or the right neighbour of an alive lane)
-    unsigned long long lane_loads = 0;                     // statistics: lane-loads issued
+    u32 lane_loads = 0;                                    // statistics: lane-loads issued (PRUNE == 2; otherwise 64 per feature loaded)
     for (int m = 0; m < a.M && !pruned; ++m) {
         const u32* offs = a.scan_off + ((size_t)ti * a.M + m) * a.fpad;
         u32 bl[4] = {0, 0, 0, 0}, bh[4] = {0, 0, 0, 0};   // byte lanes: even / odd positions of dword k
 #define LM_SCAN4_BLOCK(NF)                                                                       \
         {                                                                                        \
-        if (a.stat) lane_loads += (unsigned long long)(NF) * (unsigned long long)__popcll(PRUNE == 2 ? (alive | (alive << 1)) : ~0ull); \
+        if (PRUNE == 2) lane_loads += (u32)(NF) * (u32)__popcll(alive | (alive << 1));   /* scalar, unconditional: no branch in front of the loads */ \
         if (PRUNE != 2 || act) {                                                                 \
             u32x4 v[NF];                                                                         \
             u32 sh[NF];                                                                          \
@@ -2081,7 +2081,7 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
     if (a.stat && lane == 0) {
         atomicAdd(&a.stat[4 * (blockIdx.x & 1023u)], (unsigned long long)f_done);
         atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 1], (unsigned long long)f_in_all);
-        atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 2], lane_loads);
+        atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 2], PRUNE == 2 ? (unsigned long long)lane_loads : 64ull * (unsigned long long)f_done);
     }
     if (pruned) return;
     u32 hit = 0;
