@@ -1140,7 +1140,7 @@ int lm_get_template(const lm_detector* d, int ci, int tid, int level, int modali
     if (width) *width = t.width;
     if (height) *height = t.height;
     if (num_features) *num_features = (int)t.features.size();
-    if (features) std::memcpy(features, t.features.data(), t.features.size() * sizeof(lm_feature));
+    if (features && !t.features.empty()) std::memcpy(features, t.features.data(), t.features.size() * sizeof(lm_feature));
     return LM_OK;
 }
 
@@ -1806,7 +1806,7 @@ int lm_merge_matches(const lm_match_t* lists, const int32_t* counts, int n_lists
     }
     lmh::sort_unique(all);
     if (n_out) *n_out = all.size();
-    if (out) std::memcpy(out, all.data(), std::min(all.size(), cap) * sizeof(lm_match_t));
+    if (out && !all.empty() && cap) std::memcpy(out, all.data(), std::min(all.size(), cap) * sizeof(lm_match_t));
     if (all.size() > cap && out) return fail(LM_ERR_OVERFLOW, "output buffer too small");
     return LM_OK;
 }

@@ -711,7 +711,7 @@ int64_t orc_get_stage(const orc_detector* d, int what, int level, int modality, 
     const LevelData& L = d->levels[level];
     const std::vector<u8>* v = what == 0 ? &L.quantized[modality] : what == 1 ? &L.spread[modality] : &L.lm[modality];
     int64_t n = (int64_t)v->size();
-    if (out) std::memcpy(out, v->data(), (size_t)std::min(n, cap));
+    if (out && n > 0 && cap > 0) std::memcpy(out, v->data(), (size_t)std::min(n, cap));
     return n;
 }
 
@@ -746,7 +746,7 @@ int orc_match_prepared(orc_detector* d, float threshold, int class_idx, int tid_
     std::sort(matches.begin(), matches.end(), match_less);
     matches.erase(std::unique(matches.begin(), matches.end(), match_eq), matches.end());
     int n = (int)matches.size();
-    if (out) std::memcpy(out, matches.data(), sizeof(orc_match) * (size_t)std::min(n, cap));
+    if (out && n > 0 && cap > 0) std::memcpy(out, matches.data(), sizeof(orc_match) * (size_t)std::min(n, cap));   // (memcpy from the null data() of an empty vector is undefined even for 0 bytes)
     return n;
 }
 
@@ -793,7 +793,7 @@ int orc_merge(const orc_match* lists, const int32_t* counts, int n_lists, int st
     std::sort(all.begin(), all.end(), match_less);  // inputs are sorted; a sort of the concatenation is the R-way merge
     all.erase(std::unique(all.begin(), all.end(), match_eq), all.end());
     int n = (int)all.size();
-    if (out) std::memcpy(out, all.data(), sizeof(orc_match) * (size_t)std::min(n, cap));
+    if (out && n > 0 && cap > 0) std::memcpy(out, all.data(), sizeof(orc_match) * (size_t)std::min(n, cap));
     return n;
 }
 
