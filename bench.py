@@ -506,6 +506,10 @@ def main():
                     "the other lane's kernels hold the chip, so it is not a kernel duration"},
         "stage_us_per_frame_one_lane": dict(zip(["preprocess", "scan", "refine", "sort"],
                                                 [round(v / max(one_lane["frames"], 1), 2) for v in one_lane["stage_us"]])),
+        "stage_note": "one lane alone on the chip: with LM_TUNE_BATCH_PHASES at its default (auto) the pre-processing of a lone "
+                      "lane of 16+ frames runs as level-fused launches, while lanes that run beside others -- the timed region "
+                      "with %d lanes -- take one launch per kernel (measured r03: fused wins alone, loses beside other lanes); "
+                      "--no-batch-phases forces one launch per kernel everywhere" % NL,
     }
     roofline_refine = None
     if l2c:
