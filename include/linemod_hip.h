@@ -355,6 +355,11 @@ int lm_stage_scan(lm_detector* det, int slot, float threshold, int class_idx, in
  * and the algorithmic bytes one launch reads (sum over templates/modalities of F*P). */
 int lm_time_scan(lm_detector* det, int slot, float threshold, int class_idx, int iters, int variant,
                  double* avg_us_out, double* algorithmic_bytes_out);
+/* The same over a batch of PREPARED slots (one launch = n_slots frames, what a lane-step launches); candidates are
+ * counted, not stored.  variant 8 | 64 runs the exhaustive scan WITHOUT its shift-undo instructions -- wrong sums, a
+ * timing experiment only (the upper bound of what pre-shifted copies of the linear memories could save). */
+int lm_time_scan_batch(lm_detector* det, int first_slot, int n_slots, float threshold, int class_idx, int iters, int variant,
+                       double* avg_us_out);
 /* Per-stage average microseconds of the last lm_match_slot-style pipeline, measured with HIP events
  * over `iters` runs: out[0]=preprocess (a3-a10), out[1]=scan, out[2]=refine, out[3]=sort+copy. */
 int lm_time_stages(lm_detector* det, int slot, float threshold, int class_idx, int iters, double out_us[4]);

@@ -73,6 +73,7 @@ EXPORTS = [
     "lm_set_scan_stats", "lm_get_scan_stats", "lm_color_check_counts",
     "lm_match_batch_classes", "lm_match_prepared", "lm_match_begin_classes", "lm_device_pci_bus_id",
     "lm_get_exchange_profile", "lm_get_stage_counts", "lm_get_scan_lane_stats", "lm_match_classes",
+    "lm_time_scan_batch",
 ]
 
 _lib = None
@@ -132,6 +133,7 @@ def load_library(path=None):
     lib.lm_stage_scan.argtypes = [vp, i, f, i, vp, sz, C.POINTER(sz)]
     lib.lm_time_scan.argtypes = [vp, i, f, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.lm_time_stages.argtypes = [vp, i, f, i, i, C.POINTER(C.c_double)]
+    lib.lm_time_scan_batch.argtypes = [vp, i, i, f, i, i, i, C.POINTER(C.c_double)]
     lib.lm_set_scan_variant.argtypes = [vp, i]
     lib.lm_color_check_counts.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, sz, vp, vp]
     lib.lm_set_scan_stats.argtypes = [vp, i]
@@ -706,6 +708,12 @@ class Detector:
         us, by = C.c_double(), C.c_double()
         self._check(self.lib.lm_time_scan(self.h, slot, threshold, class_idx, iters, variant, C.byref(us), C.byref(by)))
         return us.value, by.value
+
+    def time_scan_batch(self, first_slot, n_slots, threshold, class_idx=-1, iters=20, variant=0):
+        """Average microseconds of one scan launch over n_slots prepared slots (candidates counted, not stored)."""
+        us = C.c_double()
+        self._check(self.lib.lm_time_scan_batch(self.h, first_slot, n_slots, threshold, class_idx, iters, variant, C.byref(us)))
+        return us.value
 
     def time_stages(self, slot, threshold, class_idx=-1, iters=20):
         out = (C.c_double * 4)()

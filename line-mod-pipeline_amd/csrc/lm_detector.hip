@@ -1928,6 +1928,7 @@ int lm_load_yaml(lm_detector* d, const char* path) {
     std::string err;
     if (!lmy::load_templates_yaml(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
     d->bank_dirty = true; d->hulls_dirty = true;
+    for (Slot& sl : d->slots) sl.prepared = false;   // the file's modality parameters (thresholds) replaced the detector's: a3-a10 results are stale
     if (d->cfg.num_modalities == 2 && d->normal_lut_substitute) {
         static bool warned = false;
         if (!warned) {
@@ -2191,6 +2192,37 @@ int lm_time_scan(lm_detector* d, int slot, float threshold, int class_idx, int i
         else b = d->hb.class_alg_bytes[class_idx];
         *algorithmic_bytes_out = b;
     }
+    return LM_OK;
+}
+
+// The scan kernel alone over a BATCH of prepared slots (one launch = n_slots frames, as a lane-step launches it), candidates
+// counted but not stored.  `variant` as lm_set_scan_variant; 8 | 64 = exhaustive scan WITHOUT the shift-undo instructions
+// (wrong sums -- a timing experiment only).
+int lm_time_scan_batch(lm_detector* d, int first_slot, int n_slots, float threshold, int class_idx, int iters, int variant,
+                       double* avg_us_out) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if ((rc = check_slots(d, first_slot, n_slots))) return rc;
+    if ((rc = ensure_bank(d))) return rc;
+    if (iters <= 0 || n_slots <= 0) return fail(LM_ERR_INVALID, "iters and n_slots must be positive");
+    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    for (int i = 0; i < n_slots; ++i)
+        if (!d->slots[first_slot + i].prepared) return fail(LM_ERR_INVALID, "slot " + std::to_string(first_slot + i) + " is not prepared");
+    ItemRange r;
+    if ((rc = item_range(d, class_idx, &r))) return rc;
+    if ((rc = enqueue_threshold(d, threshold))) return rc;
+    LmScanArgs a = make_scan_args(d, first_slot, r);
+    a.cand_cap = 0;
+    for (int i = 0; i < 2; ++i) lmk_scan(d->stream, a, variant, n_slots);
+    HIP_TRY(hipEventRecord(d->ev[0], d->stream));
+    for (int i = 0; i < iters; ++i) lmk_scan(d->stream, a, variant, n_slots);
+    HIP_TRY(hipEventRecord(d->ev[1], d->stream));
+    for (int i = 0; i < n_slots; ++i) HIP_TRY(hipMemsetAsync(d->aux(first_slot + i, d->off_hdr), 0, sizeof(LmDevHeader), d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
+    if (avg_us_out) *avg_us_out = (double)ms * 1000.0 / iters;
     return LM_OK;
 }
 

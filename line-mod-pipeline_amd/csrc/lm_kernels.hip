@@ -1953,7 +1953,10 @@ __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
 // the spill-over dword of the shift), dead lanes can never emit (their true totals are below the threshold whatever
 // their stale registers hold: the hit mask is cleared for them), and the wave stops once no lane is alive -- the
 // wave-level rule of PRUNE == 1 is the special case "all lanes dead".  a.stat[2] counts the lane-loads really issued.
-template <int FB, bool XCD_MAP, int PRUNE>
+// NOSHIFT (measurement only, WRONG sums): the loaded dwords are added as they are, without the v_alignbit / DPP shift-undo --
+// the upper bound of what pre-shifted copies of the linear memories could save in vector instructions, at no cost in
+// footprint (lm_time_scan_batch, scan variant 8 | 64).
+template <int FB, bool XCD_MAP, int PRUNE, bool NOSHIFT = false>
 __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
     const int lane = threadIdx.x & 63;
     const u32 npairs = ((u32)a.nslots + 1u) >> 1;
@@ -2008,6 +2011,7 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
             _Pragma("unroll") for (int g3 = 0; g3 < NF; g3 += 3) {                               \
                 u32 nb[4] = {0, 0, 0, 0};                                                        \
                 _Pragma("unroll") for (int k = g3; k < (g3 + 3 < NF ? g3 + 3 : NF); ++k) {       \
+                    if (NOSHIFT) { nb[0] += v[k][0]; nb[1] += v[k][1]; nb[2] += v[k][2]; nb[3] += v[k][3]; continue; } \
                     const u32 nx = next_lane(v[k][0]);                                           \
                     nb[0] += __builtin_amdgcn_alignbit(v[k][1], v[k][0], sh[k]);                 \
                     nb[1] += __builtin_amdgcn_alignbit(v[k][2], v[k][1], sh[k]);                 \
@@ -3120,6 +3124,10 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
         // with 31 features per template few lanes die long before their wave does, and the masked loads still pull the
         // same lines)
         const int fb = variant & 3;
+        if ((variant & 64) && (variant & 8)) {   // measurement only (wrong sums): exhaustive scan without the shift-undo
+            hipLaunchKernelGGL((k_scan4<6, true, 0, true>), grid, dim3(256), 0, s, a);
+            return;
+        }
         if (fb == 1) SCAN4_LAUNCH(12); else if (fb == 2) SCAN4_LAUNCH(3); else SCAN4_LAUNCH(6);
 #undef SCAN4_LAUNCH
         return;
