@@ -38,10 +38,10 @@ PCIE_PEAK_GBS = 63.0      # MI355X_MICROARCH.md, "Host link": PCIe Gen5 x16, 63 
 CONFIGS = {
     2: dict(name="SURVEY 8d config 2: 640x480 RGB-D, ColorGradient+DepthNormal, T={5,8}, 2-level pyramid, "
                  "fixed-geometry 96x96 templates (level-1 bbox 48x48, P = 995)",
-            W=640, H=480, color_only=False, l0_size=(96, 96), seed_frames=1234, seed_bank=4321, lanes=3, batch=288),
+            W=640, H=480, color_only=False, l0_size=(96, 96), seed_frames=1234, seed_bank=4321, lanes=3, batch=288, h2d_group=24),
     3: dict(name="SURVEY 8d config 3: 1280x960, ColorGradient only, T={2,8}, 2-level pyramid, fixed-geometry 192x192 "
                  "templates (level-1 bbox 96x96, P = 3909)",
-            W=1280, H=960, color_only=True, l0_size=(192, 192), seed_frames=2234, seed_bank=77, lanes=2, batch=256),
+            W=1280, H=960, color_only=True, l0_size=(192, 192), seed_frames=2234, seed_bank=77, lanes=2, batch=256, h2d_group=16),
     # BASELINE configs[4] on the hot path: a batch of 8 frames of 1280x960 RGB-D against three classes x 8 100 templates
     # (162 viewpoints x 5 radii x 10 rotations each) in ONE class-list match (Detector::match(..., class_ids)): one
     # pre-processing per frame for the three classes.  The bank is fixed (24 300 templates; N ranks shard every class N
@@ -197,10 +197,21 @@ class Runner:
             if M == 2:
                 hd[i][...] = depth
 
+        G = max(1, int(self.args.h2d_group or CONFIGS[self.args.config].get("h2d_group", 1)))
+
         def upload(s, k):
-            for i in range(B):
+            # frame (i + 7 k) mod B goes to slot i of the set: runs of G consecutive slots take G consecutive host frames, which
+            # lie back to back in the pinned block -- one strided transfer per run (lm_upload_frames_pinned: the larger the DMA,
+            # the closer to the link rate), single frames otherwise
+            i = 0
+            while i < B:
                 j = (i + 7 * k) % B
-                det.upload_frame_pinned(s * B + i, hb[j], hd[j])
+                g = min(G, B - i, B - j)
+                if g > 1:
+                    det.upload_frames_pinned(s * B + i, g, pb.ptr.value + j * fb, fb)
+                else:
+                    det.upload_frame_pinned(s * B + i, hb[j], hd[j])
+                i += g
 
         def begin(s):
             for l in range(NL):
@@ -236,9 +247,10 @@ class Runner:
                 "frac_of_pcie_peak": round(gbs / PCIE_PEAK_GBS, 4),
                 "pcie_bound_detections_per_s": round(PCIE_PEAK_GBS * 1e9 / fb, 1),
                 "matches_step0_step1": counts,
-                "note": "every step uploads all %d frames from pinned host memory (rotating frame -> slot map) into one of "
-                        "two slot sets while the lanes compute on the other; the upload of step 0 is inside the "
-                        "timed region; the link, not the GPU, bounds this mode" % B}
+                "frames_per_transfer": G,
+                "note": "every step uploads all %d frames from pinned host memory (rotating frame -> slot map, runs of up to %d "
+                        "consecutive frames per strided transfer) into one of two slot sets while the lanes compute on the other; "
+                        "the upload of step 0 is inside the timed region; the link, not the GPU, bounds this mode" % (B, G)}
 
     def report(self):
         prof = self.det.get_profile()
@@ -345,6 +357,10 @@ def main():
                          "level-fused batch kernels (LM_TUNE_BATCH_PHASES = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the h2d_inclusive (streaming) leg")
+    ap.add_argument("--h2d-group", type=int, default=0,
+                    help="streaming leg: consecutive frames per H2D transfer (lm_upload_frames_pinned for runs, 1 = one transfer per "
+                         "frame; 0 = the config's default: 24 frames = 36.9 MB for config 2, 16 = 59 MB for config 3 -- measured r03: "
+                         "1.5 MB transfers reach 49.9 GB/s, 24-frame ones 54.3)")
     ap.add_argument("--functional-gloo", action="store_true",
                     help="functional check of the N > 1 path on a 1-GPU box: every rank uses cuda:0 and the exchange "
                          "goes through torch.distributed/gloo on the host (never a measurement; RCCL refuses two ranks "

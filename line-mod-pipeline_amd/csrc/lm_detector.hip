@@ -1177,7 +1177,7 @@ int lm_upload_frames_pinned(lm_detector* d, int first_slot, int n_slots, const u
         if (ln.busy && first_slot < ln.first + ln.n && ln.first < first_slot + n_slots) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
     for (int i = 0; i < n_slots; ++i) if ((rc = wait_slot_upload(d, d->slots[first_slot + i]))) return rc;
     // one strided transfer: row i = host frame i ([colour | depth] dense), destination pitch = the arena's slot stride
-    const int cs = first_slot % d->n_copy_streams;
+    const int cs = (first_slot / n_slots) % d->n_copy_streams;   // consecutive runs of n_slots slots take turns on the copy streams
     hipStream_t st = d->copy_stream[cs];
     HIP_TRY(hipMemcpy2DAsync(d->bgr(first_slot, 0), d->frame_stride, frames, frame_stride, fb, (size_t)n_slots, hipMemcpyHostToDevice, st));
     const unsigned long long seq = d->up_seq_next[cs]++;
