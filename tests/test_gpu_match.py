@@ -464,6 +464,12 @@ def test_scan_pruning_is_exact(lm, orc, synth, color_only, thr):
         assert lanes[32][0] < 0.8 * lanes[16][0]                # dead lanes leave the loads' exec mask
     d.set_scan_variant(0)                                       # the default picks one of the two pruning rules by modality count
     assert np.array_equal(d.stage_scan(0, thr), exp)
+    # the measurement hook over a batch of prepared slots (incl. the timing-only variant without the shift-undo)
+    d.prepare_slot(1)
+    assert d.time_scan_batch(0, 2, thr, iters=2) > 0 and d.time_scan_batch(0, 2, thr, iters=2, variant=8 | 64) > 0
+    with pytest.raises(lm.LinemodError):
+        d.time_scan_batch(0, 3, thr)                            # slot 2 holds no prepared frame
+    assert np.array_equal(d.stage_scan(0, thr), exp)            # (the timing runs leave no state behind)
     if thr == 0.0:
         assert stats[32][0] == stats[32][1]                     # nothing can be pruned when every position qualifies
     d.close()
