@@ -278,11 +278,12 @@ int lm_rendezvous_broadcast(int rank, int world, const char* addr, int port, voi
 int lm_comm_destroy(lm_detector* det);
 int lm_comm_info(const lm_detector* det, int* rank, int* world);
 /* lm_match_begin + behind the sort kernel, on the lane's stream: k_pack_lists (the lane's sorted lists back to back +
- * their lengths, device buffers), ncclAllGather of the lengths, ncclAllGather of the packed records, D2H of both. */
+ * their lengths, device buffers), ncclAllGather of the lengths, ncclAllGather of the packed records, D2H of the lengths. */
 int lm_match_begin_gathered(lm_detector* det, int lane, int first_slot, int n_slots, float threshold, int class_idx);
-/* Waits for the lane, then merges (R-way merge + adjacent-unique, lm_merge_frames) the frames THIS RANK OWNS: frames
- * [n * rank / R, n * (rank + 1) / R) of the lane's n frames (*first_frame, *n_frames), so the host work per rank does
- * not grow with R.  out: the owned frames' merged lists back to back (cap records), counts[i] their lengths. */
+/* Waits for the lane, fetches from every rank's gathered run exactly the records of the frames THIS RANK OWNS (one
+ * contiguous piece per rank: with R ranks 1 / R of the records crosses the PCIe link, not R x the gather capacity) and
+ * merges them (R-way merge + adjacent-unique, lm_merge_frames): frames [n * rank / R, n * (rank + 1) / R) of the lane's n
+ * frames (*first_frame, *n_frames), so neither the host work nor the D2H volume per rank grows with R.  out: the owned frames' merged lists back to back (cap records), counts[i] their lengths. */
 int lm_match_end_gathered(lm_detector* det, int lane, lm_match_t* out, size_t cap, int32_t* counts, int* first_frame,
                           int* n_frames, size_t* n_out);
 /* Every rank has reached this call and every rank's device is idle (ncclAllReduce + hipDeviceSynchronize): the

@@ -1675,8 +1675,10 @@ static int enqueue_gather(lm_detector* d, int lane, int first, int n) {
     const size_t cb = (size_t)(n + 1) * sizeof(int), rb = (size_t)g.cap_lane * sizeof(LmOutMatch);
     if (!comm->all_gather(g.d_cnt, g.d_all_cnt, cb, d->stream, err)) return fail(LM_ERR_HIP, err);
     if (!comm->all_gather(g.d_rec, g.d_all_rec, rb, d->stream, err)) return fail(LM_ERR_HIP, err);
+    // only the lengths come to the host here: lm_match_end_gathered then fetches, per rank, exactly the records of the frames
+    // THIS rank merges (a contiguous piece of every rank's packed run) -- with R ranks 1 / R of the real records instead of
+    // R x the gather capacity over the PCIe link every lane-step
     HIP_TRY(hipMemcpyAsync(g.h_all_cnt, g.d_all_cnt, R * cb, hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipMemcpyAsync(g.h_all_rec, g.d_all_rec, R * rb, hipMemcpyDeviceToHost, d->stream));
     if (d->profiling) HIP_TRY(hipEventRecord(d->ev[5], d->stream));   // exchange span = ev[4] (behind the sort) -> ev[5]
     HIP_TRY(hipGetLastError());
     return LM_OK;
@@ -1790,8 +1792,24 @@ int lm_match_end_gathered(lm_detector* d, int lane, lm_match_t* out, size_t cap,
             }
         return fail(LM_ERR_OVERFLOW, "rank " + std::to_string(bad_rank) + " overflowed its candidate / match capacity (raise lm_config.max_candidates / max_matches)");
     }
-    if (status == 0)
+    if (status == 0) {
+        // the owned frames' records of every rank: frames are packed in order, so they are ONE contiguous piece per rank
+        activate_lane(d, lane);
+        int crc = LM_OK;
+        for (int r = 0; r < R && !crc; ++r) {
+            size_t start = 0, len = 0;
+            for (int i = 0; i < f1; ++i) (i < f0 ? start : len) += (size_t)cnt[(size_t)r * n + i];
+            if (start + len > (size_t)g.cap_lane) { crc = fail(LM_ERR_INVALID, "gathered counts exceed the gather capacity"); break; }
+            if (!len) continue;
+            const size_t at = (size_t)r * g.cap_lane + start;
+            if (hipMemcpyAsync(g.h_all_rec + at, g.d_all_rec + at, len * sizeof(LmOutMatch), hipMemcpyDeviceToHost, d->stream) != hipSuccess)
+                crc = fail(LM_ERR_HIP, "D2H of the gathered records failed");
+        }
+        if (!crc) crc = wait_stream(d);
+        activate_lane(d, 0);
+        if (crc) return crc;
         return lm_merge_frames(reinterpret_cast<const lm_match_t*>(g.h_all_rec), g.cap_lane, cnt.data(), R, n, f0, f1, out, cap, counts, n_out);
+    }
     d->prof_exch_fallbacks += 1;
     return gather_fallback(d, lane, ln.first, n, f0, f1, out, cap, counts, n_out);
 }
