@@ -624,6 +624,129 @@ __global__ __launch_bounds__(256, 2) void k_cblur_sw(const u8* __restrict__ bgr0
     d_cblur_sw<STRIP>(blockIdx.x, bgr0, w, h, s0, in_stride, tmp_stride, gblocks, nslots);
 }
 
+// a1+a2, sliding window with the COLUMN SUMS SHARED between neighbouring lanes (r03).  k_cblur_sw gives every lane the
+// whole 40-byte window of its 16 output bytes: it loads three blocks per row and runs the vertical pass (4 x 4 byte
+// transposes + v_dot4) on ten window dwords for four output dwords -- 2.5 x the vertical work and 3 x the loads.  Here a
+// lane loads and sums ONLY its own block; the nine column sums to the left and to the right of it come from the adjacent
+// lanes by DPP (wave_shr / wave_shl), exactly like the neighbour labels of k_cgrad: lanes 0 and 63 of a wave only feed, a
+// wave covers 62 consecutive (strip, block) pairs numbered strip-major, and a lane at a row end takes the replicated
+// border bytes from its own sums instead (a wave-uniform branch: only waves that hold a row end pay the selects).
+// Same arithmetic, same rounding: vertical taps {8, 28, 56, 72, 56, 28, 8} on bytes, horizontal taps on the 16-bit sums, one
+// round-half-up at the end.  The ring is 4 pairs x 4 dwords (32 registers instead of 80).
+__device__ __forceinline__ void cbx_pair(u32 (&pr)[4][2], const u32x4& r0, const u32x4& r1) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        pr[d][0] = __builtin_amdgcn_perm(r1[d], r0[d], 0x05010400u);
+        pr[d][1] = __builtin_amdgcn_perm(r1[d], r0[d], 0x07030602u);
+    }
+}
+template <int STRIP>
+__device__ __forceinline__ void d_cblur_sh(const u32 vblock, const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
+                                           size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
+    const u8* bgr = slot_ptr_s(bgr0, in_stride, slot);
+    u8* S = slot_ptr_s(s0, tmp_stride, slot);
+    const int nblk = (w * 3) >> 4, total = nblk * ((h + STRIP - 1) / STRIP);
+    const int lane = (int)(threadIdx.x & 63u);
+    const int f0 = ((int)tile * 4 + (int)(threadIdx.x >> 6)) * 62 - 1;    // pair of lane 0 (a feeder)
+    if (f0 + 1 >= total) return;                                           // whole wave past the end
+    const bool writer = lane >= 1 && lane <= 62 && f0 + lane < total;
+    const int f = clampi(f0 + lane, 0, total - 1);
+    const int strip = f / nblk, b = f - strip * nblk;
+    const int y0 = strip * STRIP, y1 = min(y0 + STRIP, h);
+    const bool first = b == 0, last = b == nblk - 1;
+    const bool edge_wave = __any(first || last);
+    const u32 pitch = (u32)w * 3u, bo = 16u * (u32)b;
+    const u32 wA0 = 8u | (28u << 8) | (56u << 16) | (72u << 24), wB0 = 56u | (28u << 8) | (8u << 16);
+    const u32 wA1 = (8u << 8) | (28u << 16) | (56u << 24), wB1 = 72u | (56u << 8) | (28u << 16) | (8u << 24);
+    u32 ring[4][4][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // the first window: source rows y0 - 3 .. y0 + 4
+        const u32x4 r0 = ld16(bgr + ((u32)clampi(y0 - 3 + 2 * k, 0, h - 1) * pitch + bo));
+        const u32x4 r1 = ld16(bgr + ((u32)clampi(y0 - 2 + 2 * k, 0, h - 1) * pitch + bo));
+        cbx_pair(ring[k], r0, r1);
+    }
+    u32x4 n0 = ld16(bgr + ((u32)clampi(y0 + 5, 0, h - 1) * pitch + bo));   // the pair of the next step
+    u32x4 n1 = ld16(bgr + ((u32)clampi(y0 + 6, 0, h - 1) * pitch + bo));
+#pragma unroll 1
+    for (int y = y0;; y += 2) {
+        const bool more = y + 2 < y1;
+        // the pair of the step after next is requested before this step's arithmetic
+        const u32x4 m0 = ld16(bgr + ((u32)clampi(y + 7, 0, h - 1) * pitch + bo));
+        const u32x4 m1 = ld16(bgr + ((u32)clampi(y + 8, 0, h - 1) * pitch + bo));
+        // vertical pass on the lane's own 16 byte columns: rows 4g .. 4g + 3 of one byte column per dword, two v_dot4 per output row
+        u32 vb[2][16];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            u32 T[2][4];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const u32 x0 = ring[2 * g][d][0], x1 = ring[2 * g][d][1], z0 = ring[2 * g + 1][d][0], z1 = ring[2 * g + 1][d][1];
+                T[g][0] = __builtin_amdgcn_perm(z0, x0, 0x05040100u); T[g][1] = __builtin_amdgcn_perm(z0, x0, 0x07060302u);
+                T[g][2] = __builtin_amdgcn_perm(z1, x1, 0x05040100u); T[g][3] = __builtin_amdgcn_perm(z1, x1, 0x07060302u);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                vb[0][4 * d + c] = __builtin_amdgcn_udot4(T[0][c], wA0, __builtin_amdgcn_udot4(T[1][c], wB0, 0u, false), false);
+                vb[1][4 * d + c] = __builtin_amdgcn_udot4(T[0][c], wA1, __builtin_amdgcn_udot4(T[1][c], wB1, 0u, false), false);
+            }
+        }
+        u32 o4[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            // E[i + 9] = column sum of window byte i, i = -9 .. 24: nine from the left neighbour (its bytes 7 .. 15), the lane's
+            // own sixteen, nine from the right neighbour (its bytes 0 .. 8)
+            u32 E[34];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                E[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)vb[r][7 + k], 0x138, 0xf, 0xf, false);       // lane - 1
+                E[25 + k] = (u32)__builtin_amdgcn_update_dpp(0, (int)vb[r][k], 0x130, 0xf, 0xf, false);     // lane + 1
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) E[9 + i] = vb[r][i];
+            if (edge_wave) {
+                // BORDER_REPLICATE: byte -9 + k of the row is channel k % 3 of pixel 0 (own bytes 0 .. 2), byte 16 + k past the row
+                // end channel k % 3 of the last pixel (own bytes 13 .. 15)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    E[k] = first ? vb[r][k % 3] : E[k];
+                    E[25 + k] = last ? vb[r][13 + k % 3] : E[25 + k];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32 packed = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i0 = 4 * j + q;                 // output byte i0: taps at E[i0], E[i0 + 3], ..., E[i0 + 18]
+                    u32 acc = mad24<8>(E[i0] + E[i0 + 18], 32768u);
+                    acc = mad24<28>(E[i0 + 3] + E[i0 + 15], acc);
+                    acc = mad24<56>(E[i0 + 6] + E[i0 + 12], acc);
+                    acc = mad24<72>(E[i0 + 9], acc);
+                    packed |= (acc >> 16) << (8 * q);
+                }
+                o4[r][j] = packed;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (writer && y + r < h) st16(S + ((u32)(y + r) * pitch + bo), u32x4{o4[r][0], o4[r][1], o4[r][2], o4[r][3]});
+        if (!more) return;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { ring[k][d][0] = ring[k + 1][d][0]; ring[k][d][1] = ring[k + 1][d][1]; }
+        cbx_pair(ring[3], n0, n1);
+        n0 = m0; n1 = m1;
+    }
+}
+template <int STRIP>
+__global__ __launch_bounds__(256, 2) void k_cblur_sh(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
+                                                   size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
+    d_cblur_sh<STRIP>(blockIdx.x, bgr0, w, h, s0, in_stride, tmp_stride, gblocks, nslots);
+}
+
 // a2+a3  Sobel(S, BORDER_REPLICATE) + strongest channel + fastAtan2 + 16 -> 8 bins + magnitude flag.
 // One lane = 16 pixels of a row (w % 16 == 0): rows y-1, y, y+1 of S, 48 bytes each plus the dword before
 // and after.  The vertical halves VS = S(y-1) + 2 S(y) + S(y+1) and VD + 256 = S(y+1) + 256 - S(y-1) are
@@ -2844,7 +2967,8 @@ void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, i
 }
 
 static int g_cblur_variant = 0;   // 0: by batch size (one-shot below 16 frames, sliding window from there), 1: one-shot blur
-                                  // (k_cblur), 2: sliding-window blur (k_cblur_sw); A/B knob of tools/ and tests
+                                  // (k_cblur), 2: sliding-window blur (k_cblur_sw), 3: sliding window with the column sums shared
+                                  // between neighbouring lanes (k_cblur_sh); A/B knob of tools/ and tests
 void lmk_set_cblur_variant(int v) { g_cblur_variant = v; }
 static int g_cgrad_variant = 0;   // 0: by batch size (fused k_cgrad from 16 frames), 1: k_corient + k_cvote, 2: k_cgrad, 3: k_cgrad with 32-row strips
 void lmk_set_cgrad_variant(int v) { g_cgrad_variant = v; }
@@ -2870,6 +2994,15 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
         // eight dependent steps: 166 instead of 150 us per resident single-frame match); batches: the sliding window
         if (g_cblur_variant == 1 || (g_cblur_variant == 0 && nslots < 16)) {
             hipLaunchKernelGGL(k_cblur, dim3((unsigned)(((n_b + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_b + 255) / 256, nslots);
+        } else if (g_cblur_variant == 3) {
+            // column sums shared between neighbouring lanes: 62 (strip, block) pairs per wave, four waves per workgroup
+            if (h > 640) {
+                const int n_w = (((w * 3 / 16) * ((h + 31) / 32) + 61) / 62 + 3) / 4;
+                hipLaunchKernelGGL(k_cblur_sh<32>, dim3((unsigned)(n_w * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, n_w, nslots);
+            } else {
+                const int n_w = (((w * 3 / 16) * ((h + CBS_STRIP - 1) / CBS_STRIP) + 61) / 62 + 3) / 4;
+                hipLaunchKernelGGL(k_cblur_sh<CBS_STRIP>, dim3((unsigned)(n_w * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, n_w, nslots);
+            }
         } else {
             // rows per strip: 16, or 32 for tall images (fewer re-read window rows per strip; a 480-row image would
             // not give enough waves at 32)

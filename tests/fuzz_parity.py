@@ -42,7 +42,7 @@ while time.time() - t0 < budget * 0.5:
     h = int(rng.integers(8, 130))
     bgr = rand_bgr(h, w)
     thr = float(rng.choice([10.0, 0.0, 30.0, 200.0]))
-    kb, kg = int(rng.integers(0, 3)), int(rng.integers(0, 4))      # blur / gradient kernels: by batch size, few-frame, batch
+    kb, kg = int(rng.integers(0, 4)), int(rng.integers(0, 4))      # blur / gradient kernels: by batch size, few-frame, batch
     det.set_tuning(lm.TUNE_CBLUR_VARIANT, kb); det.set_tuning(lm.TUNE_CGRAD_VARIANT, kg)
     assert np.array_equal(det.stage_color_quantize(bgr, thr), orc.color_quantize(bgr, thr)), ("colour", h, w, thr, kb, kg)
     if h % 2 == 0 and w % 2 == 0 and h >= 4:

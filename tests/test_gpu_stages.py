@@ -33,9 +33,10 @@ def test_color_quantize_parity(det, orc, shape):
         assert np.array_equal(mag, emag)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_color_quantize_both_blur_kernels(lm, det, orc, frame0, variant):
-    """The Gaussian blur has two kernels -- one shot (few frames) and sliding window (batches), chosen by batch size:
+    """The Gaussian blur has three kernels -- one shot (few frames), sliding window (batches) and the sliding window whose
+    column sums travel between neighbouring lanes (r03) -- chosen by batch size:
     force each (LM_TUNE_CBLUR_VARIANT) on shapes that hit strip ends, row ends and both pyramid levels' widths."""
     det.set_tuning(lm.TUNE_CBLUR_VARIANT, variant)
     try:
