@@ -1910,12 +1910,12 @@ __global__ __launch_bounds__(256, 2) void k_bphase(LmPhaseArgs a, LmPhaseGrid pg
     const int ithr = thr2 >= 2147483648.f ? INT_MAX : (int)floorf(thr2);    // (float)m > thr2 <=> m > floor(thr2)
     if (PH == 1) {
         if (b < e0) d_dnormal(b, a.depth, a.w, a.h, a.dist_thr, a.diff_thr, a.normal_lut, a.ds, fs, fs, pg.g[0], n);
-        else if (b < e1) d_cblur_sw<SB>(b - e0, a.bgr0, a.w, a.h, a.cs0, fs, fs, pg.g[1], n);
+        else if (b < e1) d_cblur_sh<SB>(b - e0, a.bgr0, a.w, a.h, a.cs0, fs, fs, pg.g[1], n);
         else d_pyrdown8(b - e1, a.bgr0, a.w, a.h, a.bgr1, w1, h1, fs, pg.g[2], n);
     } else if (PH == 2) {
         if (b < e0) d_cgrad<SG>(b, a.cs0, a.w, a.h, ithr, a.qc0, fs, fs, pg.g[0], n);
         else if (b < e1) d_dmedian(b - e0, a.ds, a.w, a.h, a.qd0, fs, fs, pg.g[1], n);
-        else d_cblur_sw<16>(b - e1, a.bgr1, w1, h1, a.cs1, fs, fs, pg.g[2], n);
+        else d_cblur_sh<16>(b - e1, a.bgr1, w1, h1, a.cs1, fs, fs, pg.g[2], n);
     } else {
         if (b < e0) d_cgrad<16>(b, a.cs1, w1, h1, ithr, a.qc1, fs, fs, pg.g[0], n);
         else if (b < e1) {
@@ -1948,7 +1948,7 @@ __global__ __launch_bounds__(256, PART == 1 ? 2 : 1) void k_bsplit(LmPhaseArgs a
         const float thr2 = a.weak_threshold * a.weak_threshold;
         const int ithr = thr2 >= 2147483648.f ? INT_MAX : (int)floorf(thr2);
         if (b < e0) d_cgrad<SG>(b, a.cs0, a.w, a.h, ithr, a.qc0, fs, fs, pg.g[0], n);
-        else d_cblur_sw<16>(b - e0, a.bgr1, w1, h1, a.cs1, fs, fs, pg.g[1], n);
+        else d_cblur_sh<16>(b - e0, a.bgr1, w1, h1, a.cs1, fs, fs, pg.g[1], n);
     } else {
         if (b < e0) d_lm_spread5(b, a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, pg.g[0], n);
         else if (b < e1) d_lm_spread5(b - e0, a.qd0, a.w, a.w, a.h, a.lm_d0, fs, fs, pg.g[1], n);
@@ -2966,9 +2966,10 @@ void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, i
     hipLaunchKernelGGL(k_nn_half, grid, dim3(256), 0, s, src, src_pitch, dst, dw, dh, slot_stride);
 }
 
-static int g_cblur_variant = 0;   // 0: by batch size (one-shot below 16 frames, sliding window from there), 1: one-shot blur
-                                  // (k_cblur), 2: sliding-window blur (k_cblur_sw), 3: sliding window with the column sums shared
-                                  // between neighbouring lanes (k_cblur_sh); A/B knob of tools/ and tests
+static int g_cblur_variant = 0;   // 0: by batch size (one-shot below 16 frames, k_cblur_sh from there), 1: one-shot blur (k_cblur),
+                                  // 2: sliding-window blur (k_cblur_sw, r02's batch kernel), 3: sliding window with the column sums
+                                  // shared between neighbouring lanes (k_cblur_sh, r03: config 2 146.3 -> 150.7 K, config 3 81.9 -> 86.1 K
+                                  // detections/s); A/B knob of tools/ and tests
 void lmk_set_cblur_variant(int v) { g_cblur_variant = v; }
 static int g_cgrad_variant = 0;   // 0: by batch size (fused k_cgrad from 16 frames), 1: k_corient + k_cvote, 2: k_cgrad, 3: k_cgrad with 32-row strips
 void lmk_set_cgrad_variant(int v) { g_cgrad_variant = v; }
@@ -2994,7 +2995,7 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
         // eight dependent steps: 166 instead of 150 us per resident single-frame match); batches: the sliding window
         if (g_cblur_variant == 1 || (g_cblur_variant == 0 && nslots < 16)) {
             hipLaunchKernelGGL(k_cblur, dim3((unsigned)(((n_b + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_b + 255) / 256, nslots);
-        } else if (g_cblur_variant == 3) {
+        } else if (g_cblur_variant == 3 || g_cblur_variant == 0) {
             // column sums shared between neighbouring lanes: 62 (strip, block) pairs per wave, four waves per workgroup
             if (h > 640) {
                 const int n_w = (((w * 3 / 16) * ((h + 31) / 32) + 61) / 62 + 3) / 4;
@@ -3192,8 +3193,9 @@ void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
     auto strips = [](int rows, int strip) { return (rows + strip - 1) / strip; };
     auto gwaves = [&](int ww, int hh, int strip) { return (((ww / 16) * strips(hh, strip) + 61) / 62 + 3) / 4; };   // k_cgrad: 62 useful lanes per wave, 4 waves per block
     const int sb = tall ? 32 : 16, sg = tall ? 32 : 16;
-    const int g_nrm = per((w / 8) * h), g_blur0 = per((w * 3 / 16) * strips(h, sb)), g_pyr = per((w1 / 8) * h1);
-    const int g_grad0 = gwaves(w, h, sg), g_med = per((w / 8) * strips(h, DM_ROWS)), g_blur1 = per((w1 * 3 / 16) * strips(h1, 16));
+    auto bwaves = [&](int ww, int hh, int strip) { return (((ww * 3 / 16) * strips(hh, strip) + 61) / 62 + 3) / 4; };   // k_cblur_sh: 62 useful lanes per wave
+    const int g_nrm = per((w / 8) * h), g_blur0 = bwaves(w, h, sb), g_pyr = per((w1 / 8) * h1);
+    const int g_grad0 = gwaves(w, h, sg), g_med = per((w / 8) * strips(h, DM_ROWS)), g_blur1 = bwaves(w1, h1, 16);
     const int g_grad1 = gwaves(w1, h1, 16);
     const int g_sp = T0 == 5 ? per(((w / 5) / 8) * (h / 5)) : per((w / 32) * (h / 2));
     const int seg1 = (w1 / 8 + 39) / 40;
@@ -3211,8 +3213,8 @@ void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
         const LmPhaseGrid h1g = {{(u32)(g_grad0 * n), (u32)(g_blur1 * n), 0u, 0u}, {g_grad0, g_blur1, 0, 0}};
         const LmPhaseGrid l2 = {{(u32)(g_sp * n), (u32)(g_sp * n), b_lm1, 0u}, {g_sp, g_sp, seg1, 0}};
         launch(k_bsplit<0, 16>, l0);
-        if (tall) hipLaunchKernelGGL(k_cblur_sw<32>, dim3((unsigned)(g_blur0 * n)), dim3(256), 0, s, a.bgr0, w, h, a.cs0, fs, fs, g_blur0, n);
-        else hipLaunchKernelGGL(k_cblur_sw<16>, dim3((unsigned)(g_blur0 * n)), dim3(256), 0, s, a.bgr0, w, h, a.cs0, fs, fs, g_blur0, n);
+        if (tall) hipLaunchKernelGGL(k_cblur_sh<32>, dim3((unsigned)(g_blur0 * n)), dim3(256), 0, s, a.bgr0, w, h, a.cs0, fs, fs, g_blur0, n);
+        else hipLaunchKernelGGL(k_cblur_sh<16>, dim3((unsigned)(g_blur0 * n)), dim3(256), 0, s, a.bgr0, w, h, a.cs0, fs, fs, g_blur0, n);
         if (tall) launch(k_bsplit<1, 32>, h1g); else launch(k_bsplit<1, 16>, h1g);
         hipLaunchKernelGGL(k_dmedian, dim3((unsigned)(g_med * n)), dim3(256), 0, s, a.ds, w, h, a.qd0, fs, fs, g_med, n);
         // level 1 alone: 8-row strips when 16-row ones would leave SIMDs without a wave (as lmk_color_quantize chooses)
