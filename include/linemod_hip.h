@@ -208,6 +208,9 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
  *   beside other lanes, whose kernels fill the tails anyway.  Two-level T = {5, 8} / {2, 8} pyramids of 32-pixel-aligned
  *   frames only; anything else takes the plain sequence.  Results never depend on it. */
 #define LM_TUNE_BATCH_PHASES 7
+/* LM_TUNE_PYRDOWN_VARIANT (process-wide): cv::pyrDown kernel 0 = by batch size (default: one lane per 8 output pixels below 16
+ *   frames, the row-walking kernel whose column sums travel between lanes from there), 1 / 2 = force either. */
+#define LM_TUNE_PYRDOWN_VARIANT 8
 int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 /* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame

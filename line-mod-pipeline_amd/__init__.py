@@ -42,6 +42,7 @@ TUNE_CBLUR_VARIANT = 4
 TUNE_CGRAD_VARIANT = 5
 TUNE_PHASE_MAX_SLOTS = 6
 TUNE_BATCH_PHASES = 7
+TUNE_PYRDOWN_VARIANT = 8
 
 
 class Rect(C.Structure):

@@ -1245,6 +1245,7 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
         case LM_TUNE_CGRAD_VARIANT: if (value < 0 || value > 3) break; lmk_set_cgrad_variant(value); return LM_OK;
         case LM_TUNE_COPY_STREAMS: if (value < 1 || value > LM_NCOPY) break; d->n_copy_streams = value; return LM_OK;
         case LM_TUNE_BATCH_PHASES: if (value < 0 || value > 2) break; d->batch_phases = value; return LM_OK;
+        case LM_TUNE_PYRDOWN_VARIANT: if (value < 0 || value > 2) break; lmk_set_pyrdown_variant(value); return LM_OK;
         default: return fail(LM_ERR_INVALID, "unknown tuning key");
     }
     return fail(LM_ERR_INVALID, "tuning value out of range");

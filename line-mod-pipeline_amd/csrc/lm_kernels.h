@@ -7,6 +7,7 @@
 
 // a4: cv::pyrDown on dense BGR (sw x sh) -> (sw/2 x sh/2)
 void lmk_pyrdown(hipStream_t s, const u8* src, int sw, int sh, u8* dst, size_t slot_stride, int nslots);
+void lmk_set_pyrdown_variant(int v);   // 0: by batch size (default), 1: one lane per 8 output pixels (k_pyrdown8), 2: row-walking k_pyrdown16
 // DepthNormalPyramid::pyrDown: nearest-neighbour half-size copy of a quantised image
 void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, int dh, size_t slot_stride, int nslots);
 // a3: ColorGradient quantisation of a dense w x h BGR image; mag may be null.  `scratch` (per slot,

@@ -35,6 +35,9 @@ __device__ __forceinline__ int refl101(int p, int n) {
     return p;
 }
 __device__ __forceinline__ u32x4 ld16u(const u8* p) { return reinterpret_cast<const U32x4U*>(p)->v; }
+// 16-byte-aligned wide accesses
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 __device__ __forceinline__ u32 ld4u(const u8* p) { return reinterpret_cast<const U32U*>(p)->v; }
 // dword-aligned wide loads: byte-misaligned vector loads are split by the memory pipeline and run at
 // less than half rate on gfx950 (measured: 16.7 -> 7.6 us per frame for the scan), dword alignment is
@@ -192,6 +195,124 @@ __device__ __forceinline__ void d_pyrdown8(const u32 vblock, const u8* __restric
 __global__ __launch_bounds__(256) void k_pyrdown8(const u8* __restrict__ src0, int sw, int sh, u8* __restrict__ dst0,
                                                    int dw, int dh, size_t slot_stride, int gblocks, int nslots) {
     d_pyrdown8(blockIdx.x, src0, sw, sh, dst0, dw, dh, slot_stride, gblocks, nslots);
+}
+
+// cv::pyrDown for batches (r03): a lane owns 16 source pixels (48 bytes = three aligned blocks -> 8 output pixels = 24 bytes)
+// for a strip of PD_STRIP output rows and walks down one output row at a time.  k_pyrdown8 loads 5 rows x 5 blocks for every
+// 8 output pixels and unpacks all of it (29 vector instructions per output byte); here
+//   * the source rows live in a ring of interleaved row PAIRS (as in k_cblur_sh): output row y needs rows 2y-2 .. 2y+2 = two
+//     pairs and the first row of the third, output row y+1 re-uses two of the three, so a step loads two new rows;
+//   * the vertical taps 1 4 6 4 are ONE v_dot4 per byte column on the 4 x 4 byte transpose of the two pairs, the fifth row's
+//     byte is a second v_dot4 with a one-byte selector that accumulates onto it;
+//   * the two source pixels to the left and the one to the right that the horizontal taps need are column sums of the
+//     ADJACENT lanes (DPP wave_shr / wave_shl; lanes 0 and 63 of a wave only feed, 62 (strip, segment) pairs per wave,
+//     strip-major); a lane at a row end takes BORDER_REFLECT_101 from its own sums.
+// Same integers as k_pyrdown8 / k_pyrdown: vertical sums <= 4080, (sum + 128) >> 8.
+#define PD_STRIP 16
+template <int STRIP>
+__device__ __forceinline__ void d_pyrdown16(const u32 vblock, const u8* __restrict__ src0, int sw, int sh, u8* __restrict__ dst0,
+                                            int dw, int dh, size_t slot_stride, int gblocks, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
+    const u8* src = slot_ptr_s(src0, slot_stride, slot);
+    u8* dst = slot_ptr_s(dst0, slot_stride, slot);
+    const int ng = sw >> 4, total = ng * ((dh + STRIP - 1) / STRIP);
+    const int lane = (int)(threadIdx.x & 63u);
+    const int f0 = ((int)tile * 4 + (int)(threadIdx.x >> 6)) * 62 - 1;    // pair of lane 0 (a feeder)
+    if (f0 + 1 >= total) return;
+    const bool writer = lane >= 1 && lane <= 62 && f0 + lane < total;
+    const int f = clampi(f0 + lane, 0, total - 1);
+    const int strip = f / ng, g = f - strip * ng;
+    const int y0 = strip * STRIP, y1 = min(y0 + STRIP, dh);
+    const bool first = g == 0, last = g == ng - 1;
+    const bool edge_wave = __any(first || last);
+    const u32 pitch = (u32)sw * 3u, so = 48u * (u32)g;
+    const u32 W1464 = 1u | (4u << 8) | (6u << 16) | (4u << 24);
+    auto row_off = [&](int r) { return (u32)refl101(r, sh) * pitch + so; };
+    u32 A[12][2], B[12][2], C0[12];     // pairs (2y-2, 2y-1), (2y, 2y+1) interleaved; row 2y+2 raw
+    {
+        const u8* p0 = src + row_off(2 * y0 - 2); const u8* p1 = src + row_off(2 * y0 - 1);
+        const u8* p2 = src + row_off(2 * y0);     const u8* p3 = src + row_off(2 * y0 + 1);
+        const u8* p4 = src + row_off(2 * y0 + 2);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const u32x4 r0 = ld16(p0 + 16 * k), r1 = ld16(p1 + 16 * k), r2 = ld16(p2 + 16 * k), r3 = ld16(p3 + 16 * k), r4 = ld16(p4 + 16 * k);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                A[4 * k + q][0] = __builtin_amdgcn_perm(r1[q], r0[q], 0x05010400u); A[4 * k + q][1] = __builtin_amdgcn_perm(r1[q], r0[q], 0x07030602u);
+                B[4 * k + q][0] = __builtin_amdgcn_perm(r3[q], r2[q], 0x05010400u); B[4 * k + q][1] = __builtin_amdgcn_perm(r3[q], r2[q], 0x07030602u);
+                C0[4 * k + q] = r4[q];
+            }
+        }
+    }
+#pragma unroll 1
+    for (int y = y0;; ++y) {
+        const bool more = y + 1 < y1;
+        // the two rows the next step adds (2y+3, 2y+4) are requested before this step's arithmetic
+        u32x4 n3[3], n4[3];
+        {
+            const u8* p3 = src + row_off(2 * y + 3); const u8* p4 = src + row_off(2 * y + 4);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { n3[k] = ld16(p3 + 16 * k); n4[k] = ld16(p4 + 16 * k); }
+        }
+        // vertical 1 4 6 4 1 per byte column
+        u32 V[48];
+#pragma unroll
+        for (int d = 0; d < 12; ++d) {
+            const u32 T0 = __builtin_amdgcn_perm(B[d][0], A[d][0], 0x05040100u), T1 = __builtin_amdgcn_perm(B[d][0], A[d][0], 0x07060302u);
+            const u32 T2 = __builtin_amdgcn_perm(B[d][1], A[d][1], 0x05040100u), T3 = __builtin_amdgcn_perm(B[d][1], A[d][1], 0x07060302u);
+            V[4 * d + 0] = __builtin_amdgcn_udot4(C0[d], 0x00000001u, __builtin_amdgcn_udot4(T0, W1464, 0u, false), false);
+            V[4 * d + 1] = __builtin_amdgcn_udot4(C0[d], 0x00000100u, __builtin_amdgcn_udot4(T1, W1464, 0u, false), false);
+            V[4 * d + 2] = __builtin_amdgcn_udot4(C0[d], 0x00010000u, __builtin_amdgcn_udot4(T2, W1464, 0u, false), false);
+            V[4 * d + 3] = __builtin_amdgcn_udot4(C0[d], 0x01000000u, __builtin_amdgcn_udot4(T3, W1464, 0u, false), false);
+        }
+        // E[i + 6] = column sum of the lane's byte i, i = -6 .. 50: two pixels from the left neighbour, one from the right
+        u32 EL[6], ER[3];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) EL[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)V[42 + k], 0x138, 0xf, 0xf, false);   // lane - 1
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ER[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)V[k], 0x130, 0xf, 0xf, false);        // lane + 1
+        if (edge_wave) {
+            // BORDER_REFLECT_101: pixel -2 -> 2 (bytes 6 .. 8), -1 -> 1 (bytes 3 .. 5); pixel sw -> sw - 2 (the lane's pixel 14: bytes 42 .. 44)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                EL[c] = first ? V[6 + c] : EL[c];
+                EL[3 + c] = first ? V[3 + c] : EL[3 + c];
+                ER[c] = last ? V[42 + c] : ER[c];
+            }
+        }
+        u32 o[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int i = 6 * p + c;                                     // centre byte of output pixel p, channel c
+                const u32 a = i - 6 >= 0 ? V[i - 6] : EL[i], b = i - 3 >= 0 ? V[i - 3] : EL[i + 3];
+                const u32 e = i + 6 < 48 ? V[i + 6] : ER[i + 6 - 48], dd = V[i + 3];
+                const u32 sum = a + e + 4u * (b + dd) + 6u * V[i] + 128u;
+                const int bi = 3 * p + c;
+                o[bi >> 2] |= (sum >> 8) << (8 * (bi & 3));
+            }
+        if (writer) {
+            u32x2* out = reinterpret_cast<u32x2*>(dst + ((size_t)y * dw + 8 * g) * 3);
+            out[0] = u32x2{o[0], o[1]}; out[1] = u32x2{o[2], o[3]}; out[2] = u32x2{o[4], o[5]};
+        }
+        if (!more) return;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = 4 * k + q;
+                A[d][0] = B[d][0]; A[d][1] = B[d][1];
+                B[d][0] = __builtin_amdgcn_perm(n3[k][q], C0[d], 0x05010400u); B[d][1] = __builtin_amdgcn_perm(n3[k][q], C0[d], 0x07030602u);
+                C0[d] = n4[k][q];
+            }
+    }
+}
+template <int STRIP>
+__global__ __launch_bounds__(256, 2) void k_pyrdown16(const u8* __restrict__ src0, int sw, int sh, u8* __restrict__ dst0,
+                                                      int dw, int dh, size_t slot_stride, int gblocks, int nslots) {
+    d_pyrdown16<STRIP>(blockIdx.x, src0, sw, sh, dst0, dw, dh, slot_stride, gblocks, nslots);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -368,8 +489,6 @@ __global__ __launch_bounds__(256) void k_color_quantize(const u8* __restrict__ b
 // Intermediates are kept small on purpose (8-bit S instead of 16-bit partial sums): with 32+ frames in
 // flight they do not fit the L2s and every byte written here is fabric traffic.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
-__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
 // a1+a2  GaussianBlur 7x7 -> S (the smoothed 8-bit image).  One lane = 16 bytes of a row x 2 rows.
 // Vertical taps first, on the raw bytes: the 8 source rows of the two output rows form two groups of four; a 4x4
@@ -1911,7 +2030,7 @@ __global__ __launch_bounds__(256, 2) void k_bphase(LmPhaseArgs a, LmPhaseGrid pg
     if (PH == 1) {
         if (b < e0) d_dnormal(b, a.depth, a.w, a.h, a.dist_thr, a.diff_thr, a.normal_lut, a.ds, fs, fs, pg.g[0], n);
         else if (b < e1) d_cblur_sh<SB>(b - e0, a.bgr0, a.w, a.h, a.cs0, fs, fs, pg.g[1], n);
-        else d_pyrdown8(b - e1, a.bgr0, a.w, a.h, a.bgr1, w1, h1, fs, pg.g[2], n);
+        else d_pyrdown16<PD_STRIP>(b - e1, a.bgr0, a.w, a.h, a.bgr1, w1, h1, fs, pg.g[2], n);
     } else if (PH == 2) {
         if (b < e0) d_cgrad<SG>(b, a.cs0, a.w, a.h, ithr, a.qc0, fs, fs, pg.g[0], n);
         else if (b < e1) d_dmedian(b - e0, a.ds, a.w, a.h, a.qd0, fs, fs, pg.g[1], n);
@@ -1943,7 +2062,7 @@ __global__ __launch_bounds__(256, PART == 1 ? 2 : 1) void k_bsplit(LmPhaseArgs a
     const int w1 = a.w >> 1, h1 = a.h >> 1, n = a.nslots;
     if (PART == 0) {
         if (b < e0) d_dnormal(b, a.depth, a.w, a.h, a.dist_thr, a.diff_thr, a.normal_lut, a.ds, fs, fs, pg.g[0], n);
-        else d_pyrdown8(b - e0, a.bgr0, a.w, a.h, a.bgr1, w1, h1, fs, pg.g[1], n);
+        else d_pyrdown16<PD_STRIP>(b - e0, a.bgr0, a.w, a.h, a.bgr1, w1, h1, fs, pg.g[1], n);
     } else if (PART == 1) {
         const float thr2 = a.weak_threshold * a.weak_threshold;
         const int ithr = thr2 >= 2147483648.f ? INT_MAX : (int)floorf(thr2);
@@ -2950,8 +3069,16 @@ __global__ void k_nn_half(const u8* __restrict__ src0, int sp, u8* __restrict__ 
 // ================================================================================================
 // launchers
 // ================================================================================================
+static int g_pyrdown_variant = 0;   // 0: by batch size (k_pyrdown8 below 16 frames, the row-walking k_pyrdown16 from there), 1: k_pyrdown8, 2: k_pyrdown16
+void lmk_set_pyrdown_variant(int v) { g_pyrdown_variant = v; }
 void lmk_pyrdown(hipStream_t s, const u8* src, int sw, int sh, u8* dst, size_t slot_stride, int nslots) {
     int dw = sw / 2, dh = sh / 2;
+    if (g_pyrdown_variant != 1 && (g_pyrdown_variant == 2 || nslots >= 16) && (sw % 16) == 0 && (sh % 2) == 0 && sh >= 4 &&
+        ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0 && (slot_stride % 16) == 0) {
+        const int n_w = (((sw / 16) * ((dh + PD_STRIP - 1) / PD_STRIP) + 61) / 62 + 3) / 4;
+        hipLaunchKernelGGL(k_pyrdown16<PD_STRIP>, dim3((unsigned)(n_w * nslots)), dim3(256), 0, s, src, sw, sh, dst, dw, dh, slot_stride, n_w, nslots);
+        return;
+    }
     if ((sw % 16) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0 && (slot_stride % 16) == 0) {
         const int lanes = (dw / 8) * dh;
         hipLaunchKernelGGL(k_pyrdown8, dim3((unsigned)(((lanes + 255) / 256) * nslots)), dim3(256), 0, s, src, sw, sh, dst, dw, dh, slot_stride, (lanes + 255) / 256, nslots);
@@ -3194,7 +3321,7 @@ void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
     auto gwaves = [&](int ww, int hh, int strip) { return (((ww / 16) * strips(hh, strip) + 61) / 62 + 3) / 4; };   // k_cgrad: 62 useful lanes per wave, 4 waves per block
     const int sb = tall ? 32 : 16, sg = tall ? 32 : 16;
     auto bwaves = [&](int ww, int hh, int strip) { return (((ww * 3 / 16) * strips(hh, strip) + 61) / 62 + 3) / 4; };   // k_cblur_sh: 62 useful lanes per wave
-    const int g_nrm = per((w / 8) * h), g_blur0 = bwaves(w, h, sb), g_pyr = per((w1 / 8) * h1);
+    const int g_nrm = per((w / 8) * h), g_blur0 = bwaves(w, h, sb), g_pyr = (((w / 16) * strips(h1, PD_STRIP) + 61) / 62 + 3) / 4;   // k_pyrdown16
     const int g_grad0 = gwaves(w, h, sg), g_med = per((w / 8) * strips(h, DM_ROWS)), g_blur1 = bwaves(w1, h1, 16);
     const int g_grad1 = gwaves(w1, h1, 16);
     const int g_sp = T0 == 5 ? per(((w / 5) / 8) * (h / 5)) : per((w / 32) * (h / 2));

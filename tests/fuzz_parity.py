@@ -46,11 +46,13 @@ while time.time() - t0 < budget * 0.5:
     det.set_tuning(lm.TUNE_CBLUR_VARIANT, kb); det.set_tuning(lm.TUNE_CGRAD_VARIANT, kg)
     assert np.array_equal(det.stage_color_quantize(bgr, thr), orc.color_quantize(bgr, thr)), ("colour", h, w, thr, kb, kg)
     if h % 2 == 0 and w % 2 == 0 and h >= 4:
-        assert np.array_equal(det.stage_pyrdown(bgr), orc.pyrdown(bgr)), ("pyrdown", h, w)
+        kp = int(rng.integers(0, 3))
+        det.set_tuning(lm.TUNE_PYRDOWN_VARIANT, kp)
+        assert np.array_equal(det.stage_pyrdown(bgr), orc.pyrdown(bgr)), ("pyrdown", h, w, kp)
     dep = rand_depth(h, w)
     assert np.array_equal(det.stage_depth_quantize(dep), orc.depth_quantize(dep)), ("depth", h, w)
     n_stage += 1
-det.set_tuning(lm.TUNE_CBLUR_VARIANT, 0); det.set_tuning(lm.TUNE_CGRAD_VARIANT, 0)
+det.set_tuning(lm.TUNE_CBLUR_VARIANT, 0); det.set_tuning(lm.TUNE_CGRAD_VARIANT, 0); det.set_tuning(lm.TUNE_PYRDOWN_VARIANT, 0)
 det.close()
 
 while time.time() - t0 < budget:

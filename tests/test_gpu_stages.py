@@ -96,6 +96,28 @@ def test_pyrdown_parity(det, orc, shape):
     assert np.array_equal(det.stage_pyrdown(bgr), orc.pyrdown(bgr))
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+def test_pyrdown_both_kernels(lm, det, orc, frame0, variant):
+    """cv::pyrDown has a one-shot kernel (a lane per 8 output pixels) and, for batches, a row-walking one whose column sums
+    travel between neighbouring lanes (r03): force each (LM_TUNE_PYRDOWN_VARIANT) on shapes that hit strip ends, row ends,
+    the reflected borders and both pyramid levels' sizes, on random and on extreme contents."""
+    det.set_tuning(lm.TUNE_PYRDOWN_VARIANT, variant)
+    try:
+        rng = np.random.default_rng(variant)
+        for shape in [(480, 640), (240, 320), (960, 1280), (4, 16), (6, 32), (34, 48), (66, 160), (130, 1024), (32, 16)]:
+            for kind in range(3):
+                if kind == 0:
+                    bgr = rng.integers(0, 256, (shape[0], shape[1], 3), dtype=np.uint8)
+                elif kind == 1:
+                    bgr = (rng.integers(0, 2, (shape[0], shape[1], 3)) * 255).astype(np.uint8)
+                else:
+                    bgr = np.full((shape[0], shape[1], 3), 255, np.uint8)
+                assert np.array_equal(det.stage_pyrdown(bgr), orc.pyrdown(bgr)), (variant, shape, kind)
+        assert np.array_equal(det.stage_pyrdown(frame0[0]), orc.pyrdown(frame0[0]))
+    finally:
+        det.set_tuning(lm.TUNE_PYRDOWN_VARIANT, 0)
+
+
 @pytest.mark.parametrize("shape", [(480, 640), (960, 1280), (40, 48), (23, 91), (12, 12)])
 def test_depth_quantize_parity(det, orc, synth, shape):
     rng = np.random.default_rng(shape[0])
