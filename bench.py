@@ -111,6 +111,8 @@ class Runner:
             det.set_tuning(lm.TUNE_CBLUR_VARIANT, args.cblur_variant)
         if args.pyrdown_variant:
             det.set_tuning(lm.TUNE_PYRDOWN_VARIANT, args.pyrdown_variant)
+        if args.no_blur_pyr:
+            det.set_tuning(lm.TUNE_BLUR_PYR, 0)
         if args.no_prune:
             det.set_scan_variant(8)
         elif args.scan_variant:
@@ -361,6 +363,7 @@ def main():
                          "level-fused batch kernels (LM_TUNE_BATCH_PHASES = 0)")
     ap.add_argument("--cblur-variant", type=int, default=0, help="A/B knob: LM_TUNE_CBLUR_VARIANT (2: sliding window, 3: shared column sums)")
     ap.add_argument("--pyrdown-variant", type=int, default=0, help="A/B knob: LM_TUNE_PYRDOWN_VARIANT (1: k_pyrdown8, 2: row-walking k_pyrdown16)")
+    ap.add_argument("--no-blur-pyr", action="store_true", help="A/B knob: level-0 blur and pyrDown as two launches (LM_TUNE_BLUR_PYR = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the h2d_inclusive (streaming) leg")
     ap.add_argument("--h2d-group", type=int, default=0,

@@ -211,6 +211,9 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
 /* LM_TUNE_PYRDOWN_VARIANT (process-wide): cv::pyrDown kernel 0 = by batch size (default: one lane per 8 output pixels below 16
  *   frames, the row-walking kernel whose column sums travel between lanes from there), 1 / 2 = force either. */
 #define LM_TUNE_PYRDOWN_VARIANT 8
+/* LM_TUNE_BLUR_PYR (process-wide): batches run the level-0 Gaussian blur and cv::pyrDown level 0 -> 1 as ONE launch whose
+ *   blocks are interleaved per frame slot, so the raw image is read from HBM once (default 1; 0 = two launches). */
+#define LM_TUNE_BLUR_PYR 9
 int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 /* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame

@@ -43,6 +43,7 @@ TUNE_CGRAD_VARIANT = 5
 TUNE_PHASE_MAX_SLOTS = 6
 TUNE_BATCH_PHASES = 7
 TUNE_PYRDOWN_VARIANT = 8
+TUNE_BLUR_PYR = 9
 
 
 class Rect(C.Structure):

@@ -447,10 +447,13 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
         if (M == 2) (void)hipStreamWaitEvent(s0, f.join[1], 0);
         return;
     }
+    // batches: the level-0 blur and pyrDown 0 -> 1 share one slot-interleaved launch (the raw image comes from HBM once)
+    const bool blur_pyr = L >= 2 && lmk_blur_pyrdown(d->stream, d->bgr(first, 0), d->lw[0], d->lh[0], d->cscratch(first, 0), d->bgr(first, 1),
+                                                      d->quant(first, 0, 0), fs, n);
     for (int l = 0; l < L; ++l) {
-        if (l > 0) lmk_pyrdown(d->stream, d->bgr(first, l - 1), d->lw[l - 1], d->lh[l - 1], d->bgr(first, l), fs, n);
+        if (l > 0 && !(l == 1 && blur_pyr)) lmk_pyrdown(d->stream, d->bgr(first, l - 1), d->lw[l - 1], d->lh[l - 1], d->bgr(first, l), fs, n);
         lmk_color_quantize(d->stream, d->bgr(first, l), d->lw[l], d->lh[l], c.weak_threshold, d->quant(first, l, 0),
-                           nullptr, d->cscratch(first, l), fs, n);
+                           nullptr, d->cscratch(first, l), fs, n, l == 0 && blur_pyr);
         if (M == 2 && l == 0)
             lmk_depth_quantize(d->stream, d->depth(first), d->lw[0], d->lh[0], c.distance_threshold,
                                c.difference_threshold, d->d_normal_lut, normal_lut_onehot(d), d->quant(first, 0, 1),
@@ -1246,6 +1249,7 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
         case LM_TUNE_COPY_STREAMS: if (value < 1 || value > LM_NCOPY) break; d->n_copy_streams = value; return LM_OK;
         case LM_TUNE_BATCH_PHASES: if (value < 0 || value > 2) break; d->batch_phases = value; return LM_OK;
         case LM_TUNE_PYRDOWN_VARIANT: if (value < 0 || value > 2) break; lmk_set_pyrdown_variant(value); return LM_OK;
+        case LM_TUNE_BLUR_PYR: if (value < 0 || value > 1) break; lmk_set_blur_pyr(value); return LM_OK;
         default: return fail(LM_ERR_INVALID, "unknown tuning key");
     }
     return fail(LM_ERR_INVALID, "tuning value out of range");

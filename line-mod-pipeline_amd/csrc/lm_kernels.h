@@ -16,8 +16,14 @@ void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, i
 size_t lmk_color_scratch_bytes(int w, int h);
 void lmk_set_cgrad_variant(int v);   // 0: by batch size (default), 1: k_corient + k_cvote, 2: fused k_cgrad, 3: fused, 32-row strips
 void lmk_set_cblur_variant(int v);   // 0: by batch size (default), 1: one-shot blur, 2: sliding-window blur
+// blurred: the level's Gaussian-blurred image S is already in `scratch` (lmk_blur_pyrdown ran): orientation + vote only.
 void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_threshold, u8* quant, float* mag,
-                        u8* scratch, size_t slot_stride, int nslots);
+                        u8* scratch, size_t slot_stride, int nslots, bool blurred = false);
+// Batches: the level-0 blur (into scratch0, as lmk_color_quantize would) AND cv::pyrDown level 0 -> 1 in one slot-interleaved
+// launch, so that the raw image is read from HBM once.  false: shape not supported, nothing launched (the caller launches
+// the two kernels itself).
+bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0, u8* bgr1, u8* quant0, size_t slot_stride, int nslots);
+void lmk_set_blur_pyr(int v);
 // a5: DepthNormal quantisation (normals + LUT + 5x5 median)
 // scratch: w*h bytes per slot (rank codes between the two streaming passes), nullptr or a NORMAL_LUT that is
 // not 0 / one-hot selects the LDS-tiled fallback kernel.

@@ -210,10 +210,8 @@ __global__ __launch_bounds__(256) void k_pyrdown8(const u8* __restrict__ src0, i
 // Same integers as k_pyrdown8 / k_pyrdown: vertical sums <= 4080, (sum + 128) >> 8.
 #define PD_STRIP 16
 template <int STRIP>
-__device__ __forceinline__ void d_pyrdown16(const u32 vblock, const u8* __restrict__ src0, int sw, int sh, u8* __restrict__ dst0,
-                                            int dw, int dh, size_t slot_stride, int gblocks, int nslots) {
-    u32 slot, tile;
-    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
+__device__ __forceinline__ void d_pyrdown16_st(const u32 slot, const u32 tile, const u8* __restrict__ src0, int sw, int sh, u8* __restrict__ dst0,
+                                               int dw, int dh, size_t slot_stride) {
     const u8* src = slot_ptr_s(src0, slot_stride, slot);
     u8* dst = slot_ptr_s(dst0, slot_stride, slot);
     const int ng = sw >> 4, total = ng * ((dh + STRIP - 1) / STRIP);
@@ -308,6 +306,13 @@ __device__ __forceinline__ void d_pyrdown16(const u32 vblock, const u8* __restri
                 C0[d] = n4[k][q];
             }
     }
+}
+template <int STRIP>
+__device__ __forceinline__ void d_pyrdown16(const u32 vblock, const u8* __restrict__ src0, int sw, int sh, u8* __restrict__ dst0,
+                                            int dw, int dh, size_t slot_stride, int gblocks, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
+    d_pyrdown16_st<STRIP>(slot, tile, src0, sw, sh, dst0, dw, dh, slot_stride);
 }
 template <int STRIP>
 __global__ __launch_bounds__(256, 2) void k_pyrdown16(const u8* __restrict__ src0, int sw, int sh, u8* __restrict__ dst0,
@@ -760,10 +765,8 @@ __device__ __forceinline__ void cbx_pair(u32 (&pr)[4][2], const u32x4& r0, const
     }
 }
 template <int STRIP>
-__device__ __forceinline__ void d_cblur_sh(const u32 vblock, const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
-                                           size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
-    u32 slot, tile;
-    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
+__device__ __forceinline__ void d_cblur_sh_st(const u32 slot, const u32 tile, const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
+                                              size_t in_stride, size_t tmp_stride) {
     const u8* bgr = slot_ptr_s(bgr0, in_stride, slot);
     u8* S = slot_ptr_s(s0, tmp_stride, slot);
     const int nblk = (w * 3) >> 4, total = nblk * ((h + STRIP - 1) / STRIP);
@@ -861,9 +864,29 @@ __device__ __forceinline__ void d_cblur_sh(const u32 vblock, const u8* __restric
     }
 }
 template <int STRIP>
+__device__ __forceinline__ void d_cblur_sh(const u32 vblock, const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
+                                           size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
+    d_cblur_sh_st<STRIP>(slot, tile, bgr0, w, h, s0, in_stride, tmp_stride);
+}
+template <int STRIP>
 __global__ __launch_bounds__(256, 2) void k_cblur_sh(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
                                                    size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
     d_cblur_sh<STRIP>(blockIdx.x, bgr0, w, h, s0, in_stride, tmp_stride, gblocks, nslots);
+}
+// Level-0 blur AND cv::pyrDown of the same frames in ONE grid, interleaved per slot (r03; VERDICT r2 #2b "blur + pyrDown from
+// one pass over the raw image", as far as it pays): both read the raw level-0 image, and launched apart they read it from
+// HBM twice (k_pyrdown8: 110 MB per 96-frame launch of config 2, 590 MB per 128 frames of config 3 -- it runs at the HBM rate).
+// Here a slot's tiles are [blur tiles | pyrDown tiles] back to back in the order its XCD takes them (xcd_slot_tile_b over
+// the combined tile count), so the second reader finds the rows in that XCD's L2.  Both parts are of one register class.
+template <int SB>
+__global__ __launch_bounds__(256, 2) void k_blur_pyr(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0, u8* __restrict__ bgr1,
+                                                     size_t slot_stride, int g_blur, int g_pyr, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile_b(blockIdx.x, (u32)(g_blur + g_pyr), (u32)nslots, slot, tile);
+    if (tile < (u32)g_blur) d_cblur_sh_st<SB>(slot, tile, bgr0, w, h, s0, slot_stride, slot_stride);
+    else d_pyrdown16_st<PD_STRIP>(slot, tile - (u32)g_blur, bgr0, w, h, bgr1, w >> 1, h >> 1, slot_stride);
 }
 
 // a2+a3  Sobel(S, BORDER_REPLICATE) + strongest channel + fastAtan2 + 16 -> 8 bins + magnitude flag.
@@ -3107,8 +3130,28 @@ size_t lmk_color_scratch_bytes(int w, int h) {
     return (px * 3 + 255) / 256 * 256 + (px + 255) / 256 * 256;
 }
 
+static int g_blur_pyr = 1;   // level-0 blur and cv::pyrDown of a batch in one slot-interleaved launch (k_blur_pyr); 0: two launches
+void lmk_set_blur_pyr(int v) { g_blur_pyr = v; }
+bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0, u8* bgr1, u8* quant0, size_t slot_stride, int nslots) {
+    // exactly the shapes lmk_color_quantize's streaming path and k_pyrdown16 take, batches only
+    if (!g_blur_pyr || nslots < 16 || g_cblur_variant == 1 || g_cblur_variant == 2 || g_pyrdown_variant == 1) return false;
+    if (!scratch0 || (w % 16) != 0 || (h % 2) != 0 || h < 4 || (slot_stride % 16) != 0) return false;
+    if (((uintptr_t)bgr0 & 15) || ((uintptr_t)scratch0 & 15) || ((uintptr_t)quant0 & 15) || ((uintptr_t)bgr1 & 7)) return false;
+    const int dh = h / 2;
+    auto waves4 = [](int pairs) { return ((pairs + 61) / 62 + 3) / 4; };
+    const int g_pyr = waves4((w / 16) * ((dh + PD_STRIP - 1) / PD_STRIP));
+    if (h > 640) {
+        const int g_blur = waves4((w * 3 / 16) * ((h + 31) / 32));
+        hipLaunchKernelGGL(k_blur_pyr<32>, dim3((unsigned)((g_blur + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, g_blur, g_pyr, nslots);
+    } else {
+        const int g_blur = waves4((w * 3 / 16) * ((h + CBS_STRIP - 1) / CBS_STRIP));
+        hipLaunchKernelGGL(k_blur_pyr<CBS_STRIP>, dim3((unsigned)((g_blur + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, g_blur, g_pyr, nslots);
+    }
+    return true;
+}
+
 void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_threshold, u8* quant, float* mag,
-                        u8* scratch, size_t slot_stride, int nslots) {
+                        u8* scratch, size_t slot_stride, int nslots, bool blurred) {
     const float thr2 = weak_threshold * weak_threshold;
     if (scratch && (w % 16) == 0 && ((uintptr_t)bgr & 15) == 0 && ((uintptr_t)scratch & 15) == 0 &&
         ((uintptr_t)quant & 15) == 0 && (slot_stride % 16) == 0) {
@@ -3120,7 +3163,9 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
         const int n_t = (w / 16) * ((h + CVT_ROWS - 1) / CVT_ROWS);           // 16-pixel groups x bands
         // few frames: the one-shot kernel's many short waves finish sooner (a single frame is 57 sliding-window waves of
         // eight dependent steps: 166 instead of 150 us per resident single-frame match); batches: the sliding window
-        if (g_cblur_variant == 1 || (g_cblur_variant == 0 && nslots < 16)) {
+        if (blurred) {
+            // S is already in `scratch` (lmk_blur_pyrdown)
+        } else if (g_cblur_variant == 1 || (g_cblur_variant == 0 && nslots < 16)) {
             hipLaunchKernelGGL(k_cblur, dim3((unsigned)(((n_b + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_b + 255) / 256, nslots);
         } else if (g_cblur_variant == 3 || g_cblur_variant == 0) {
             // column sums shared between neighbouring lanes: 62 (strip, block) pairs per wave, four waves per workgroup
@@ -3339,9 +3384,14 @@ void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
         const LmPhaseGrid l0 = {{(u32)(g_nrm * n), (u32)(g_pyr * n), 0u, 0u}, {g_nrm, g_pyr, 0, 0}};
         const LmPhaseGrid h1g = {{(u32)(g_grad0 * n), (u32)(g_blur1 * n), 0u, 0u}, {g_grad0, g_blur1, 0, 0}};
         const LmPhaseGrid l2 = {{(u32)(g_sp * n), (u32)(g_sp * n), b_lm1, 0u}, {g_sp, g_sp, seg1, 0}};
-        launch(k_bsplit<0, 16>, l0);
-        if (tall) hipLaunchKernelGGL(k_cblur_sh<32>, dim3((unsigned)(g_blur0 * n)), dim3(256), 0, s, a.bgr0, w, h, a.cs0, fs, fs, g_blur0, n);
-        else hipLaunchKernelGGL(k_cblur_sh<16>, dim3((unsigned)(g_blur0 * n)), dim3(256), 0, s, a.bgr0, w, h, a.cs0, fs, fs, g_blur0, n);
+        if (lmk_blur_pyrdown(s, a.bgr0, w, h, a.cs0, a.bgr1, a.qc0, fs, n)) {
+            // blur(0) and pyrDown share the slot-interleaved launch (one read of the raw image); the normals go alone
+            hipLaunchKernelGGL(k_dnormal, dim3((unsigned)(g_nrm * n)), dim3(256), 0, s, a.depth, w, h, a.dist_thr, a.diff_thr, a.normal_lut, a.ds, fs, fs, g_nrm, n);
+        } else {
+            launch(k_bsplit<0, 16>, l0);
+            if (tall) hipLaunchKernelGGL(k_cblur_sh<32>, dim3((unsigned)(g_blur0 * n)), dim3(256), 0, s, a.bgr0, w, h, a.cs0, fs, fs, g_blur0, n);
+            else hipLaunchKernelGGL(k_cblur_sh<16>, dim3((unsigned)(g_blur0 * n)), dim3(256), 0, s, a.bgr0, w, h, a.cs0, fs, fs, g_blur0, n);
+        }
         if (tall) launch(k_bsplit<1, 32>, h1g); else launch(k_bsplit<1, 16>, h1g);
         hipLaunchKernelGGL(k_dmedian, dim3((unsigned)(g_med * n)), dim3(256), 0, s, a.ds, w, h, a.qd0, fs, fs, g_med, n);
         // level 1 alone: 8-row strips when 16-row ones would leave SIMDs without a wave (as lmk_color_quantize chooses)
@@ -3353,12 +3403,13 @@ void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
         const LmPhaseGrid p1 = {{0u, (u32)(g_blur0 * n), (u32)(g_pyr * n), 0u}, {g_nrm, g_blur0, g_pyr, 0}};
         const LmPhaseGrid p2 = {{(u32)(g_grad0 * n), 0u, (u32)(g_blur1 * n), 0u}, {g_grad0, g_med, g_blur1, 0}};
         const LmPhaseGrid p3 = {{(u32)(g_grad1 * n), (u32)(g_sp * n), 0u, 0u}, {g_grad1, g_sp, g_sp, seg1}};
+        const bool bp = lmk_blur_pyrdown(s, a.bgr0, w, h, a.cs0, a.bgr1, a.qc0, a.slot_stride, n);   // launch 1, slot-interleaved (one read of the raw image)
         if (T0 == 5) {
-            if (tall) { launch(k_bphase<1, 5, 32, 32>, p1); launch(k_bphase<2, 5, 32, 32>, p2); launch(k_bphase<3, 5, 32, 32>, p3); }
-            else { launch(k_bphase<1, 5, 16, 16>, p1); launch(k_bphase<2, 5, 16, 16>, p2); launch(k_bphase<3, 5, 16, 16>, p3); }
+            if (tall) { if (!bp) launch(k_bphase<1, 5, 32, 32>, p1); launch(k_bphase<2, 5, 32, 32>, p2); launch(k_bphase<3, 5, 32, 32>, p3); }
+            else { if (!bp) launch(k_bphase<1, 5, 16, 16>, p1); launch(k_bphase<2, 5, 16, 16>, p2); launch(k_bphase<3, 5, 16, 16>, p3); }
         } else {
-            if (tall) { launch(k_bphase<1, 2, 32, 32>, p1); launch(k_bphase<2, 2, 32, 32>, p2); launch(k_bphase<3, 2, 32, 32>, p3); }
-            else { launch(k_bphase<1, 2, 16, 16>, p1); launch(k_bphase<2, 2, 16, 16>, p2); launch(k_bphase<3, 2, 16, 16>, p3); }
+            if (tall) { if (!bp) launch(k_bphase<1, 2, 32, 32>, p1); launch(k_bphase<2, 2, 32, 32>, p2); launch(k_bphase<3, 2, 32, 32>, p3); }
+            else { if (!bp) launch(k_bphase<1, 2, 16, 16>, p1); launch(k_bphase<2, 2, 16, 16>, p2); launch(k_bphase<3, 2, 16, 16>, p3); }
         }
     }
     hipLaunchKernelGGL((k_lm_fast<8, 40, 0, 2>), dim3(b_lm1), dim3(256), 0, s, a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1,

@@ -256,8 +256,9 @@ def test_batches_take_one_launch_per_dependency_level(lm, orc, synth, color_only
     for k in range(n):
         b, dp = frames[(3 * k + 1) % 4]
         d.upload_frame(k, b, None if color_only else dp)
-    for phases in (1, 0, 2):
+    for phases, blur_pyr in ((1, 1), (0, 1), (2, 1), (0, 0), (1, 0)):
         d.set_tuning(lm.TUNE_BATCH_PHASES, phases)
+        d.set_tuning(lm.TUNE_BLUR_PYR, blur_pyr)     # level-0 blur + pyrDown in one slot-interleaved launch, or apart
         for nb in (n, 16):
             out, cnt = d.match_batch(nb, THR, 0)
             for k in range(nb):
@@ -272,4 +273,5 @@ def test_batches_take_one_launch_per_dependency_level(lm, orc, synth, color_only
                 for mod in range(M):
                     assert np.array_equal(d.debug_read(k, 0, level, mod), o.stage(0, level, mod)), (phases, k, level, mod)
                     assert np.array_equal(d.debug_read(k, 2, level, mod), o.stage(2, level, mod)), (phases, k, level, mod)
+    d.set_tuning(lm.TUNE_BLUR_PYR, 1)
     d.close()
