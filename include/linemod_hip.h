@@ -189,9 +189,9 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
 /* LM_TUNE_COPY_STREAMS: copy streams the uploads are dealt to, slot -> stream round-robin (1..4, default 4: one
  *   in-order stream moved 0.6-0.9 MB images at 25.6 GB/s, several keep several DMA engines busy). */
 #define LM_TUNE_COPY_STREAMS 3
-/* LM_TUNE_CBLUR_VARIANT (process-wide): Gaussian blur kernel 0 = by batch size (default: one-shot below 16 frames, sliding
- *   window from there), 1 = one-shot, 2 = sliding window, 3 = sliding window with the column sums shared between
- *   neighbouring lanes (r03). */
+/* LM_TUNE_CBLUR_VARIANT (process-wide): Gaussian blur kernel 0 = by batch size (default: one-shot below 16 frames, the row
+ *   walker with shared column sums from there), 1 = one-shot, 2 = r02's sliding window, 3 = row walker with the column sums
+ *   shared between neighbouring lanes (r03). */
 #define LM_TUNE_CBLUR_VARIANT 4
 /* LM_TUNE_CGRAD_VARIANT (process-wide): gradient orientation + 3x3 vote 0 = by batch size (default: two kernels below 16
  *   frames, the fused strip kernel from there), 1 = two kernels, 2 = fused, 3 = fused with 32-row strips (what tall
