@@ -49,7 +49,7 @@ CONFIGS = {
     # (tests/test_facade.py), not part of the timed hot path.
     5: dict(name="BASELINE configs[4] / SURVEY 8d config 5 (hot path): batches of 8 frames of 1280x960 RGB-D, T={5,8}, three classes x "
                  "8100 templates (variable geometry, level-0 bbox 96..320) in one class-list match",
-            W=1280, H=960, color_only=False, l0_size=None, size_range=(96, 320), seed_frames=1234, seed_bank=500, lanes=2, batch=16,
+            W=1280, H=960, color_only=False, l0_size=None, size_range=(96, 320), seed_frames=1234, seed_bank=500, lanes=3, batch=24,
             classes=3, templates_per_class=8100),
 }
 
@@ -113,6 +113,8 @@ class Runner:
             det.set_tuning(lm.TUNE_PYRDOWN_VARIANT, args.pyrdown_variant)
         if args.no_blur_pyr:
             det.set_tuning(lm.TUNE_BLUR_PYR, 0)
+        if args.no_level_pairs:
+            det.set_tuning(lm.TUNE_LEVEL_PAIRS, 0)
         if args.no_prune:
             det.set_scan_variant(8)
         elif args.scan_variant:
@@ -363,6 +365,7 @@ def main():
                          "level-fused batch kernels (LM_TUNE_BATCH_PHASES = 0)")
     ap.add_argument("--cblur-variant", type=int, default=0, help="A/B knob: LM_TUNE_CBLUR_VARIANT (2: sliding window, 3: shared column sums)")
     ap.add_argument("--pyrdown-variant", type=int, default=0, help="A/B knob: LM_TUNE_PYRDOWN_VARIANT (1: k_pyrdown8, 2: row-walking k_pyrdown16)")
+    ap.add_argument("--no-level-pairs", action="store_true", help="A/B knob: no slot-interleaved level pairs (LM_TUNE_LEVEL_PAIRS = 0)")
     ap.add_argument("--no-blur-pyr", action="store_true", help="A/B knob: level-0 blur and pyrDown as two launches (LM_TUNE_BLUR_PYR = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the h2d_inclusive (streaming) leg")

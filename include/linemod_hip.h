@@ -212,8 +212,13 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
  *   frames, the row-walking kernel whose column sums travel between lanes from there), 1 / 2 = force either. */
 #define LM_TUNE_PYRDOWN_VARIANT 8
 /* LM_TUNE_BLUR_PYR (process-wide): batches run the level-0 Gaussian blur and cv::pyrDown level 0 -> 1 as ONE launch whose
- *   blocks are interleaved per frame slot, so the raw image is read from HBM once (default 1; 0 = two launches). */
+ *   blocks are interleaved per frame slot (default 1; 0 = two launches). */
 #define LM_TUNE_BLUR_PYR 9
+/* LM_TUNE_LEVEL_PAIRS (process-wide): batches of 16+ frames run the level-1 kernels inside the level-0 grids of their own
+ *   register class, interleaved per frame slot (k_pair: median(0) | blur(1); gradient(0) | gradient(1); all four linear-memory
+ *   kernels) -- five launches per RGB-D batch instead of ten.  Default 1; 0 = the sequences LM_TUNE_BATCH_PHASES chooses.  Same
+ *   pyramids and frame shapes as LM_TUNE_BATCH_PHASES; results never depend on it. */
+#define LM_TUNE_LEVEL_PAIRS 10
 int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 /* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame
@@ -368,6 +373,10 @@ int lm_time_scan(lm_detector* det, int slot, float threshold, int class_idx, int
  * timing experiment only (the upper bound of what pre-shifted copies of the linear memories could save). */
 int lm_time_scan_batch(lm_detector* det, int first_slot, int n_slots, float threshold, int class_idx, int iters, int variant,
                        double* avg_us_out);
+/* Self-test (no upstream counterpart): the depth-normal kernel's float tail takes 1 / len and sqrt by sequences that drop the
+ * compiler's exponent-range handling; this runs every float of the tail's domain through both forms on the device.
+ * out[0] / out[1] = number of floats whose reciprocal / square root differ (0 / 0 expected). */
+int lm_selftest_float_tail(lm_detector* det, uint64_t out[2]);
 /* Per-stage average microseconds of the last lm_match_slot-style pipeline, measured with HIP events
  * over `iters` runs: out[0]=preprocess (a3-a10), out[1]=scan, out[2]=refine, out[3]=sort+copy. */
 int lm_time_stages(lm_detector* det, int slot, float threshold, int class_idx, int iters, double out_us[4]);

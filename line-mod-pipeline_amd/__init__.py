@@ -44,6 +44,7 @@ TUNE_PHASE_MAX_SLOTS = 6
 TUNE_BATCH_PHASES = 7
 TUNE_PYRDOWN_VARIANT = 8
 TUNE_BLUR_PYR = 9
+TUNE_LEVEL_PAIRS = 10
 
 
 class Rect(C.Structure):
@@ -76,6 +77,7 @@ EXPORTS = [
     "lm_match_batch_classes", "lm_match_prepared", "lm_match_begin_classes", "lm_device_pci_bus_id",
     "lm_get_exchange_profile", "lm_get_stage_counts", "lm_get_scan_lane_stats", "lm_match_classes",
     "lm_time_scan_batch",
+    "lm_selftest_float_tail",
 ]
 
 _lib = None
@@ -136,6 +138,7 @@ def load_library(path=None):
     lib.lm_time_scan.argtypes = [vp, i, f, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.lm_time_stages.argtypes = [vp, i, f, i, i, C.POINTER(C.c_double)]
     lib.lm_time_scan_batch.argtypes = [vp, i, i, f, i, i, i, C.POINTER(C.c_double)]
+    lib.lm_selftest_float_tail.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.lm_set_scan_variant.argtypes = [vp, i]
     lib.lm_color_check_counts.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, sz, vp, vp]
     lib.lm_set_scan_stats.argtypes = [vp, i]
@@ -716,6 +719,12 @@ class Detector:
         us = C.c_double()
         self._check(self.lib.lm_time_scan_batch(self.h, first_slot, n_slots, threshold, class_idx, iters, variant, C.byref(us)))
         return us.value
+
+    def selftest_float_tail(self):
+        """(reciprocals, square roots) of the depth-normal tail's float domain that differ from the correctly rounded forms."""
+        out = (C.c_uint64 * 2)()
+        self._check(self.lib.lm_selftest_float_tail(self.h, out))
+        return int(out[0]), int(out[1])
 
     def time_stages(self, slot, threshold, class_idx=-1, iters=20):
         out = (C.c_double * 4)()

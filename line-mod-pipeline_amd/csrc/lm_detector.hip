@@ -280,7 +280,7 @@ int ensure_device(lm_detector* d) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_scan_stat), 4096 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(d->d_scan_stat, 0, 4096 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_sim_lut), 256));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_normal_lut), 8000));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_normal_lut), 2 * 8000));    // the table, then its labels as rank codes (LMK_NORMAL_CODE_OFFSET)
     HIP_TRY(hipDeviceSynchronize());
     d->dev_ready = true;
     d->luts_dirty = true;
@@ -302,7 +302,17 @@ int ensure_luts(lm_detector* d) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(d->d_resp_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d->d_sim_lut, d->sim_lut, 256, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d->d_normal_lut, d->normal_lut, 8000, hipMemcpyHostToDevice));
+    {
+        // k_dnormal writes the label's RANK CODE (lm_kernels.hip, a5 streaming form): looked up directly from a second table
+        u8 both[2 * 8000];
+        std::memcpy(both, d->normal_lut, 8000);
+        for (int i = 0; i < 8000; ++i) {
+            const u8 v = d->normal_lut[i];
+            const unsigned rank = v ? (unsigned)__builtin_ffs((int)v) : 0u;        // 0 for none, 1 + label otherwise
+            both[LMK_NORMAL_CODE_OFFSET + i] = (u8)(rank < 4 ? 8 * rank : (rank < 8 ? 8 * (rank - 4) + 4 : 32u));
+        }
+        HIP_TRY(hipMemcpy(d->d_normal_lut, both, sizeof(both), hipMemcpyHostToDevice));
+    }
     d->luts_dirty = false;
     return LM_OK;
 }
@@ -387,7 +397,8 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
     bool others_busy = false;
     for (int o = 0; o < LM_NLANES; ++o) others_busy |= (o != d->active && d->lanes[o].busy);
     const bool fuse_batch = d->batch_phases == 1 || (d->batch_phases == 2 && !others_busy);
-    if ((few || (fuse_batch && n >= 16)) && n > d->fork_max_slots && L == 2) {     // (the fork experiment, when switched on, wins)
+    const bool pairs = lmk_level_pairs() != 0;      // slot-interleaved level pairs (k_pair), beside other lanes too
+    if ((few || ((fuse_batch || pairs) && n >= 16)) && n > d->fork_max_slots && L == 2) {     // (the fork experiment, when switched on, wins)
         LmPhaseArgs pa{};
         pa.bgr0 = d->bgr(first, 0); pa.bgr1 = d->bgr(first, 1); pa.depth = M == 2 ? d->depth(first) : nullptr;
         pa.cs0 = d->cscratch(first, 0); pa.cs1 = d->cscratch(first, 1); pa.ds = d->dscratch(first);
@@ -406,7 +417,7 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
                 return;
             }
             if (!few && lmk_batch_phases_supported(pa, d->geom[0].T, d->geom[1].T, mode(0), mode(1), onehot)) {
-                lmk_preprocess_batch_phases(d->stream, pa, d->geom[0].T);
+                lmk_preprocess_batch_phases(d->stream, pa, d->geom[0].T, pairs);
                 return;
             }
         }
@@ -1250,6 +1261,7 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
         case LM_TUNE_BATCH_PHASES: if (value < 0 || value > 2) break; d->batch_phases = value; return LM_OK;
         case LM_TUNE_PYRDOWN_VARIANT: if (value < 0 || value > 2) break; lmk_set_pyrdown_variant(value); return LM_OK;
         case LM_TUNE_BLUR_PYR: if (value < 0 || value > 1) break; lmk_set_blur_pyr(value); return LM_OK;
+        case LM_TUNE_LEVEL_PAIRS: if (value < 0 || value > 1) break; lmk_set_level_pairs(value); return LM_OK;
         default: return fail(LM_ERR_INVALID, "unknown tuning key");
     }
     return fail(LM_ERR_INVALID, "tuning value out of range");
@@ -2246,6 +2258,26 @@ int lm_time_scan_batch(lm_detector* d, int first_slot, int n_slots, float thresh
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
     if (avg_us_out) *avg_us_out = (double)ms * 1000.0 / iters;
+    return LM_OK;
+}
+
+// Self-test of k_dnormal's float tail (lm_kernels.hip dn_rcp / dn_sqrt): every float of the tail's domain through the short
+// sequences and through the compiler's correctly rounded 1.0f / x and sqrtf on this device; out[0] / out[1] = floats that differ.
+int lm_selftest_float_tail(lm_detector* d, uint64_t out[2]) {
+    int rc;
+    if (!out) return fail(LM_ERR_INVALID, "null argument");
+    if ((rc = ready_for_compute(d))) return rc;
+    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    unsigned long long* dev = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), 2 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(dev, 0, 2 * sizeof(unsigned long long), d->stream);
+    unsigned long long host[2] = {0, 0};
+    if (e == hipSuccess) { lmk_selftest_float_tail(d->stream, dev); e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, d->stream); }
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(LM_ERR_HIP, hipGetErrorString(e));
+    out[0] = host[0]; out[1] = host[1];
     return LM_OK;
 }
 

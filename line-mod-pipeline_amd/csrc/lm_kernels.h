@@ -130,6 +130,8 @@ void lmk_hsv_mask(hipStream_t s, const u8* bgr, int w, int h, const LmHsvRange& 
 //   3  vote(level 0)            | orientation(level 1)   | depth linear memories of levels 0 and 1
 //   4  vote(level 1)            | colour linear memories of level 0
 //   5  colour linear memories of level 1
+// the device NORMAL_LUT buffer holds the 8000-byte table and, behind it, the same table as the rank codes k_dnormal writes
+#define LMK_NORMAL_CODE_OFFSET 8000
 struct LmPhaseArgs {
     const u8* bgr0; u8* bgr1; const u16* depth;      // level-0 colour image, level-1 colour image (written by launch 1), depth (or null)
     u8 *cs0, *cs1, *ds;                              // scratch: colour level 0 / 1 (lmk_color_scratch_bytes each), depth (w * h)
@@ -147,7 +149,13 @@ void lmk_preprocess_phases(hipStream_t s, const LmPhaseArgs& a, int T0);
 // memories): the kernels of one dependency level share one grid, so the short level-1 launches fill the tail of the
 // long level-0 ones; four launches per lane-step instead of eleven.
 bool lmk_batch_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0, int mode1, bool lut_onehot);
-void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0);
+// pairs: the slot-interleaved level pairs (k_pair: five launches for an RGB-D batch) instead of the register-class fusion
+void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0, bool pairs = false);
+void lmk_set_level_pairs(int v);
+// out2[0] / out2[1] += floats of k_dnormal's tail domain on which its short reciprocal / square root differ from the compiler's
+// correctly rounded ones (device counters, zeroed by the caller)
+void lmk_selftest_float_tail(hipStream_t s, unsigned long long* out2);
+int lmk_level_pairs();
 
 struct LmHullArgs {
     const LmOutMatch* matches; u32 n;

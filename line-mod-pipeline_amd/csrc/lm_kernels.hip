@@ -101,6 +101,11 @@ __device__ __forceinline__ void xcd_slot_tile_b(u32 b, u32 G, u32 B, u32& slot, 
     else { slot = b / G; tile = b - slot * G; }
 }
 __device__ __forceinline__ void xcd_slot_tile(u32 G, u32 B, u32& slot, u32& tile) { xcd_slot_tile_b(blockIdx.x, G, B, slot, tile); }
+// the block index at which a grid of G tiles x B slots would hold (slot, tile): lets a kernel that interleaves several parts per
+// slot (k_pair) hand a part's tile to the part's device function, which decodes it with xcd_slot_tile_b again
+__device__ __forceinline__ u32 xcd_vblock(u32 slot, u32 tile, u32 G, u32 B) {
+    return (B & 7u) == 0 ? ((((slot >> 3) * G + tile) << 3) | (slot & 7u)) : slot * G + tile;
+}
 
 // ------------------------------------------------------------------------------------------------
 // a4  cv::pyrDown, CV_8UC3: 5x5 [1 4 6 4 1]^2, BORDER_REFLECT_101, (sum + 128) >> 8
@@ -1384,6 +1389,22 @@ __device__ __forceinline__ u32 hw_u16(const u32x4* A, int hw) {
 // (threshold - 1)), so the products are exact in 32-bit integers and ONE int -> float conversion rounds them exactly like
 // the double product rounded to float (both round the same exact integer to nearest even) -- two integer multiplies and
 // conversions instead of six double-precision instructions per pixel.
+// 1 / x and sqrt(x) of the float tail, for x = 0 or a NORMAL float whose reciprocal is normal too (here the squares' sum is 0
+// or in [1, 2^82) and 1 <= len < 2^41: nx, ny, nz are integers below 2^40 in magnitude):
+// the compiler's correctly rounded 1.0f / x is v_div_scale x 2, v_rcp, six fused steps, v_div_fmas, v_div_fixup -- scale
+// and fixup only act on operands near the ends of the exponent range -- and its sqrtf scales denormal inputs around a
+// v_sqrt_f32.  Without those: 7 + 1 instructions instead of 11 + 6, bit-identical on the domain (lm_selftest_float_tail
+// sweeps every float of the domain against __fdiv_rn / __fsqrt_rn on the device; tests/test_gpu_stages.py).
+__device__ __forceinline__ float dn_rcp(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e, r0, r0);
+    const float err0 = __builtin_fmaf(-d, r1, 1.0f);
+    const float q1 = __builtin_fmaf(err0, r1, r1);
+    const float err1 = __builtin_fmaf(-d, q1, 1.0f);
+    return __builtin_fmaf(err1, r1, q1);
+}
+__device__ __forceinline__ float dn_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 template <bool SMALL>
 __device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool valid, const u8* __restrict__ lut) {
     // same values as upstream's 64-bit integer products rounded once to float: |ddx| < 2^30 so the
@@ -1391,18 +1412,31 @@ __device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool v
     float nx = SMALL ? (float)(ddx * 1150) : (float)((double)ddx * 1150.0);
     float ny = SMALL ? (float)(ddy * 1150) : (float)((double)ddy * 1150.0);
     float nz = (float)(-mul_i24(det, d));
-    const float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
-    const float inv = __fdiv_rn(1.0f, len > 0 ? len : 1.0f);
+    const float len = dn_sqrt(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+    const float inv = dn_rcp(len > 0 ? len : 1.0f);
     nx = __fmul_rn(nx, inv); ny = __fmul_rn(ny, inv); nz = __fmul_rn(nz, inv);
     const int v1 = (int)__fadd_rn(__fmul_rn(nx, 10.f), 10.f);
     const int v2 = (int)__fadd_rn(__fmul_rn(ny, 10.f), 10.f);
     const int v3 = (int)__fadd_rn(__fmul_rn(nz, 20.f), 20.f);
     const int flat = mul_i24(v3, 400) + mul_i24(v2, 20) + v1;   // |v| small: exact
-    const bool in_lut = flat >= 0 && flat < 8000;
-    const u32 v = lut[in_lut ? flat : 0];
-    const u32 rank = (u32)__ffs((int)v);                         // 0 for none, 1 + label otherwise
-    const u32 ecode = rank < 4 ? 8 * rank : (rank < 8 ? 8 * (rank - 4) + 4 : 32u);
+    const bool in_lut = (u32)flat < 8000u;
+    // the label's rank code straight from the second table (ensure_luts: 8 rank / 8 (rank - 4) + 4 / 32)
+    const u32 ecode = lut[LMK_NORMAL_CODE_OFFSET + (in_lut ? flat : 0)];
     return (valid && len > 0 && in_lut) ? ecode : 0u;
+}
+
+// every float of the tail's domain through dn_rcp / dn_sqrt and through the compiler's correctly rounded forms
+__global__ __launch_bounds__(256) void k_selftest_float_tail(unsigned long long* __restrict__ out) {
+    const u32 lo = 0x3F800000u, hi_rcp = (127u + 42u) << 23, hi_sqrt = (127u + 84u) << 23;   // 1.0f .. 2^42 / 2^84
+    unsigned long long bad_rcp = 0, bad_sqrt = 0;
+    for (u32 b = lo + blockIdx.x * 256u + threadIdx.x; b <= hi_sqrt; b += gridDim.x * 256u) {
+        const float x = __builtin_bit_cast(float, b);
+        if (b <= hi_rcp) bad_rcp += __builtin_bit_cast(u32, dn_rcp(x)) != __builtin_bit_cast(u32, __fdiv_rn(1.0f, x));
+        bad_sqrt += __builtin_bit_cast(u32, dn_sqrt(x)) != __builtin_bit_cast(u32, __fsqrt_rn(x));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) bad_sqrt += __builtin_bit_cast(u32, dn_sqrt(0.0f)) != 0u;
+    if (bad_rcp) atomicAdd(&out[0], bad_rcp);
+    if (bad_sqrt) atomicAdd(&out[1], bad_sqrt);
 }
 
 template <bool SMALL>
@@ -2095,6 +2129,48 @@ __global__ __launch_bounds__(256, PART == 1 ? 2 : 1) void k_bsplit(LmPhaseArgs a
         if (b < e0) d_lm_spread5(b, a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, pg.g[0], n);
         else if (b < e1) d_lm_spread5(b - e0, a.qd0, a.w, a.w, a.h, a.lm_d0, fs, fs, pg.g[1], n);
         else d_lm_fast<8, 40, 1, 2>(b - e1, a.qd0, a.w, w1, h1, a.resp_tab, a.lm_d1, a.ori_stride1, fs, fs, pg.g[2], n);
+    }
+}
+
+// Level PAIRS (r03, VERDICT r2 #2a): the level-1 launches of a batch are small grids of long dependent row walks
+// (k_cgrad<8> of 320 x 240: 40 us for a quarter of the 73 us level-0 work; blur 23 us; the two response-memory launches 17
+// + 18 us).  Each rides in the grid of a kernel of ITS OWN register class, interleaved per frame slot the way k_blur_pyr
+// interleaves blur and pyrDown (a slot's tiles back to back on the slot's XCD):
+//   0: median(0) | blur(1)            (107 / 120 VGPRs)       1: gradient + vote(0) | gradient + vote(1)   (237)
+//   2: colour spread memory(0) | depth spread memory(0) | depth response memories(1) | colour response memories(1)
+//   3: colour only: spread memory(0) | response memories(1)
+// pg.g[i] = tiles per slot of part i.  Chain of an RGB-D batch: k_blur_pyr, k_dnormal, k_pair<0>, <1>, <2> -- five launches
+// instead of ten; colour only: k_blur_pyr, k_cblur_sh(1), k_pair<1>, <3> -- four instead of six.
+template <int KIND, int T0, int SG>
+__global__ __launch_bounds__(256, KIND >= 2 ? 1 : 2) void k_pair(LmPhaseArgs a, LmPhaseGrid pg) {
+    const size_t fs = a.slot_stride;
+    const int w1 = a.w >> 1, h1 = a.h >> 1;
+    const u32 n = (u32)a.nslots;
+    const u32 g0 = (u32)pg.g[0], g1 = (u32)pg.g[1], g2 = (u32)pg.g[2], g3 = (u32)pg.g[3];
+    u32 slot, tile;
+    xcd_slot_tile_b(blockIdx.x, g0 + g1 + g2 + g3, n, slot, tile);
+    if (KIND == 0) {
+        if (tile < g0) d_dmedian(xcd_vblock(slot, tile, g0, n), a.ds, a.w, a.h, a.qd0, fs, fs, (int)g0, (int)n);
+        else d_cblur_sh<16>(xcd_vblock(slot, tile - g0, g1, n), a.bgr1, w1, h1, a.cs1, fs, fs, (int)g1, (int)n);
+    } else if (KIND == 1) {
+        const float thr2 = a.weak_threshold * a.weak_threshold;
+        const int ithr = thr2 >= 2147483648.f ? INT_MAX : (int)floorf(thr2);
+        if (tile < g0) d_cgrad<SG>(xcd_vblock(slot, tile, g0, n), a.cs0, a.w, a.h, ithr, a.qc0, fs, fs, (int)g0, (int)n);
+        else d_cgrad<16>(xcd_vblock(slot, tile - g0, g1, n), a.cs1, w1, h1, ithr, a.qc1, fs, fs, (int)g1, (int)n);
+    } else if (KIND == 2) {
+        // g2 = g3 = segments per band x bands of the level-1 response memories; d_lm_fast takes the segments per band
+        const int seg1 = (w1 / 8 + 39) / 40;
+        if (tile < g0) d_lm_spread5(xcd_vblock(slot, tile, g0, n), a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, (int)g0, (int)n);
+        else if (tile < g0 + g1) d_lm_spread5(xcd_vblock(slot, tile - g0, g1, n), a.qd0, a.w, a.w, a.h, a.lm_d0, fs, fs, (int)g1, (int)n);
+        else if (tile < g0 + g1 + g2) d_lm_fast<8, 40, 1, 2>(xcd_vblock(slot, tile - g0 - g1, g2, n), a.qd0, a.w, w1, h1, a.resp_tab, a.lm_d1, a.ori_stride1, fs, fs, seg1, (int)n);
+        else d_lm_fast<8, 40, 0, 2>(xcd_vblock(slot, tile - g0 - g1 - g2, g3, n), a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1, fs, fs, seg1, (int)n);
+    } else {
+        const int seg1 = (w1 / 8 + 39) / 40;
+        if (tile < g0) {
+            if (T0 == 5) d_lm_spread5(xcd_vblock(slot, tile, g0, n), a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, (int)g0, (int)n);
+            else d_lm_spread2(xcd_vblock(slot, tile, g0, n), a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, (int)g0, (int)n);
+        }
+        else d_lm_fast<8, 40, 0, 2>(xcd_vblock(slot, tile - g0, g1, n), a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1, fs, fs, seg1, (int)n);
     }
 }
 
@@ -3357,7 +3433,15 @@ bool lmk_batch_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0,
     return true;
 }
 
-void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
+static int g_level_pairs = 0;   // 1: batches run the level-1 kernels inside the level-0 grids of their register class (k_pair).  Measured r03: no gain
+                                // (config 2 one lane 4.46 plain, 4.27 register-class fusion, 4.30 pairs us per frame; 152-153 K against 155-157 K
+                                // detections/s beside other lanes; config 3 7.28 against 6.81 us), so off; kept as a tested knob
+void lmk_selftest_float_tail(hipStream_t s, unsigned long long* out2) {
+    hipLaunchKernelGGL(k_selftest_float_tail, dim3(8192), dim3(256), 0, s, out2);
+}
+void lmk_set_level_pairs(int v) { g_level_pairs = v; }
+int lmk_level_pairs() { return g_level_pairs; }
+void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0, bool pairs) {
     const int w = a.w, h = a.h, w1 = w / 2, h1 = h / 2, n = a.nslots;
     const bool dep = a.depth != nullptr;
     const bool tall = h > 640;                                     // 32-row strips at level 0 (fewer re-read window rows)
@@ -3376,6 +3460,28 @@ void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
         const u32 nb = pg.nb[0] + pg.nb[1] + pg.nb[2] + pg.nb[3];
         hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s, a, pg);
     };
+    if (pairs) {
+        // slot-interleaved level pairs (k_pair); needs the blur + pyrDown launch's shapes, else the forms below
+        const size_t fs = a.slot_stride;
+        const int g_lm1 = seg1 * (h1 / 8);
+        if (lmk_blur_pyrdown(s, a.bgr0, w, h, a.cs0, a.bgr1, a.qc0, fs, n)) {
+            auto launch_pair = [&](auto kern, int p0, int p1, int p2, int p3) {
+                const LmPhaseGrid pg = {{0u, 0u, 0u, 0u}, {p0, p1, p2, p3}};
+                hipLaunchKernelGGL(kern, dim3((unsigned)((p0 + p1 + p2 + p3) * n)), dim3(256), 0, s, a, pg);
+            };
+            if (dep) {
+                hipLaunchKernelGGL(k_dnormal, dim3((unsigned)(g_nrm * n)), dim3(256), 0, s, a.depth, w, h, a.dist_thr, a.diff_thr, a.normal_lut, a.ds, fs, fs, g_nrm, n);
+                launch_pair(k_pair<0, 5, 16>, g_med, g_blur1, 0, 0);
+            } else {
+                hipLaunchKernelGGL(k_cblur_sh<16>, dim3((unsigned)(g_blur1 * n)), dim3(256), 0, s, a.bgr1, w1, h1, a.cs1, fs, fs, g_blur1, n);
+            }
+            if (tall) launch_pair(k_pair<1, 5, 32>, g_grad0, g_grad1, 0, 0); else launch_pair(k_pair<1, 5, 16>, g_grad0, g_grad1, 0, 0);
+            if (dep) launch_pair(k_pair<2, 5, 16>, g_sp, g_sp, g_lm1, g_lm1);
+            else if (T0 == 5) launch_pair(k_pair<3, 5, 16>, g_sp, g_lm1, 0, 0);
+            else launch_pair(k_pair<3, 2, 16>, g_sp, g_lm1, 0, 0);
+            return;
+        }
+    }
     if (dep) {
         // RGB-D: only kernels of one register class share a grid (see k_bsplit)
         const float thr2 = a.weak_threshold * a.weak_threshold;

@@ -147,6 +147,15 @@ def test_depth_quantize_thresholds_and_full_range(lm, orc, diff_thr):
     d.close()
 
 
+def test_depth_normal_float_tail_sequences_are_exact(lm):
+    """k_dnormal takes 1 / len and sqrt by sequences without the compiler's exponent-range handling (dn_rcp: v_rcp + six fused
+    steps, no v_div_scale / v_div_fixup; dn_sqrt: a bare v_sqrt_f32).  Every float of the tail's domain -- len in [1, 2^42],
+    squared lengths in [1, 2^84] and 0 -- goes through both forms on the device; none may differ."""
+    d = lm.Detector(color_only=False)
+    assert d.selftest_float_tail() == (0, 0)
+    d.close()
+
+
 def test_depth_quantize_frame0_and_custom_lut(lm, orc, frame0):
     _, depth = frame0
     d = lm.Detector(color_only=False)

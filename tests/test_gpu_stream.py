@@ -256,22 +256,24 @@ def test_batches_take_one_launch_per_dependency_level(lm, orc, synth, color_only
     for k in range(n):
         b, dp = frames[(3 * k + 1) % 4]
         d.upload_frame(k, b, None if color_only else dp)
-    for phases, blur_pyr in ((1, 1), (0, 1), (2, 1), (0, 0), (1, 0)):
+    for phases, blur_pyr, pairs in ((0, 1, 1), (1, 1, 0), (0, 1, 0), (2, 1, 0), (0, 0, 0), (1, 0, 0), (1, 0, 1)):
         d.set_tuning(lm.TUNE_BATCH_PHASES, phases)
         d.set_tuning(lm.TUNE_BLUR_PYR, blur_pyr)     # level-0 blur + pyrDown in one slot-interleaved launch, or apart
+        d.set_tuning(lm.TUNE_LEVEL_PAIRS, pairs)     # level-1 kernels inside the level-0 grids of their register class (k_pair)
         for nb in (n, 16):
             out, cnt = d.match_batch(nb, THR, 0)
             for k in range(nb):
                 try:
                     assert_matches_equal(out[k, :cnt[k]], exp[(3 * k + 1) % 4])
                 except AssertionError as e:
-                    raise AssertionError("batch phases %d, batch of %d, slot %d: %s" % (phases, nb, k, str(e)[:80]))
+                    raise AssertionError("batch phases %d, blur_pyr %d, pairs %d, batch of %d, slot %d: %s" % (phases, blur_pyr, pairs, nb, k, str(e)[:80]))
         for k in (0, n // 2 + 1, n - 1):
             b, dp = frames[(3 * k + 1) % 4]
             o.prepare(b, None if color_only else dp)
             for level in range(2):
                 for mod in range(M):
-                    assert np.array_equal(d.debug_read(k, 0, level, mod), o.stage(0, level, mod)), (phases, k, level, mod)
-                    assert np.array_equal(d.debug_read(k, 2, level, mod), o.stage(2, level, mod)), (phases, k, level, mod)
+                    assert np.array_equal(d.debug_read(k, 0, level, mod), o.stage(0, level, mod)), (phases, blur_pyr, pairs, k, level, mod)
+                    assert np.array_equal(d.debug_read(k, 2, level, mod), o.stage(2, level, mod)), (phases, blur_pyr, pairs, k, level, mod)
     d.set_tuning(lm.TUNE_BLUR_PYR, 1)
+    d.set_tuning(lm.TUNE_LEVEL_PAIRS, 1)
     d.close()
