@@ -216,9 +216,14 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
 #define LM_TUNE_BLUR_PYR 9
 /* LM_TUNE_LEVEL_PAIRS (process-wide): batches of 16+ frames run the level-1 kernels inside the level-0 grids of their own
  *   register class, interleaved per frame slot (k_pair: median(0) | blur(1); gradient(0) | gradient(1); all four linear-memory
- *   kernels) -- five launches per RGB-D batch instead of ten.  Default 1; 0 = the sequences LM_TUNE_BATCH_PHASES chooses.  Same
+ *   kernels) -- five launches per RGB-D batch instead of ten.  Default 0 (measured r03: no gain over what LM_TUNE_BATCH_PHASES
+ *   chooses); 1 = on.  Same
  *   pyramids and frame shapes as LM_TUNE_BATCH_PHASES; results never depend on it. */
 #define LM_TUNE_LEVEL_PAIRS 10
+/* LM_TUNE_DMEDIAN_VARIANT (process-wide): 5 x 5 median of the normals' labels, output rows per lane 0 = by batch size (default:
+ *   4 below 16 frames -- many short waves --, 16 from there: 20 rows of horizontal sums per 16 outputs instead of 8 per 4),
+ *   1 / 2 = force either. */
+#define LM_TUNE_DMEDIAN_VARIANT 11
 int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 /* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame

@@ -45,6 +45,7 @@ TUNE_BATCH_PHASES = 7
 TUNE_PYRDOWN_VARIANT = 8
 TUNE_BLUR_PYR = 9
 TUNE_LEVEL_PAIRS = 10
+TUNE_DMEDIAN_VARIANT = 11
 
 
 class Rect(C.Structure):

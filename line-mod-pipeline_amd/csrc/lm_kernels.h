@@ -152,6 +152,7 @@ bool lmk_batch_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0,
 // pairs: the slot-interleaved level pairs (k_pair: five launches for an RGB-D batch) instead of the register-class fusion
 void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0, bool pairs = false);
 void lmk_set_level_pairs(int v);
+void lmk_set_dmedian_variant(int v);
 // out2[0] / out2[1] += floats of k_dnormal's tail domain on which its short reciprocal / square root differ from the compiler's
 // correctly rounded ones (device counters, zeroed by the caller)
 void lmk_selftest_float_tail(hipStream_t s, unsigned long long* out2);

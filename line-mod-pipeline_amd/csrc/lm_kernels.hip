@@ -1567,7 +1567,11 @@ __global__ __launch_bounds__(256) void k_dnormal(const u16* __restrict__ depth0,
     d_dnormal(blockIdx.x, depth0, w, h, dist_thr, diff_thr, lut, code0, in_stride, tmp_stride, gblocks, nslots);
 }
 
-#define DM_ROWS 4   // output rows per lane of k_dmedian
+#define DM_ROWS 4          // output rows per lane of k_dmedian, few frames (many short waves)
+#ifndef DM_ROWS_BATCH
+#define DM_ROWS_BATCH 16   // batches: 20 rows of horizontal sums per 16 output rows instead of 8 per 4 (r03: 49.7 -> see DESIGN.md section 7)
+#endif
+template <int ROWS>
 __device__ __forceinline__ void d_dmedian(const u32 vblock, const u8* __restrict__ code0, int w, int h, u8* __restrict__ quant0,
                                                   size_t tmp_stride, size_t out_stride, int gblocks, int nslots) {
     u32 slot, tile;
@@ -1577,22 +1581,22 @@ __device__ __forceinline__ void d_dmedian(const u32 vblock, const u8* __restrict
     const int ng = w >> 3;
     const int gid = (int)(tile * 256u) + (int)threadIdx.x;
     const int band = gid / ng, g = gid - band * ng;
-    const int y0 = band * DM_ROWS;
+    const int y0 = band * ROWS;
     if (y0 >= h) return;
     u32 ringE[5][8], ringO[5][8];   // byte counters of the last five rows' horizontal sums: ranks 0..3 | 4..7
     u32 sumE[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sumO[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < DM_ROWS + 4; ++i) {               // image row y0 - 2 + i, replicated at the borders
+    for (int i = 0; i < ROWS + 4; ++i) {                  // image row y0 - 2 + i, replicated at the borders
         const int yy = clampi(y0 - 2 + i, 0, h - 1);
         const u8* row = code + (size_t)yy * w + 8 * g;
         const u32x2 c = *reinterpret_cast<const u32x2*>(row);
         u32 e[12];                                        // codes of pixels 8g-2 .. 8g+9
 #pragma unroll
         for (int k = 0; k < 8; ++k) e[2 + k] = (c[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-        if (g > 0) { const u32 l = *reinterpret_cast<const u32*>(row - 4); e[0] = (l >> 16) & 0xFFu; e[1] = l >> 24; }
-        else { e[0] = e[2]; e[1] = e[2]; }
-        if (g + 1 < ng) { const u32 r = *reinterpret_cast<const u32*>(row + 8); e[10] = r & 0xFFu; e[11] = (r >> 8) & 0xFFu; }
-        else { e[10] = e[9]; e[11] = e[9]; }
+        // (no branches: the row ends load a valid dword of the row and select the replicated pixel)
+        const u32 l = *reinterpret_cast<const u32*>(g > 0 ? row - 4 : row), r = *reinterpret_cast<const u32*>(g + 1 < ng ? row + 8 : row + 4);
+        e[0] = g > 0 ? (l >> 16) & 0xFFu : e[2]; e[1] = g > 0 ? l >> 24 : e[2];
+        e[10] = g + 1 < ng ? r & 0xFFu : e[9]; e[11] = g + 1 < ng ? (r >> 8) & 0xFFu : e[9];
         u32 oh[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) oh[k] = (1u << (e[k] & 31u)) & ~(e[k] >> 5);   // code 32 (rank 8) counts nowhere: 1 << 0 cleared
@@ -1628,9 +1632,10 @@ __device__ __forceinline__ void d_dmedian(const u32 vblock, const u8* __restrict
         }
     }
 }
+template <int ROWS>
 __global__ __launch_bounds__(256) void k_dmedian(const u8* __restrict__ code0, int w, int h, u8* __restrict__ quant0,
                                                   size_t tmp_stride, size_t out_stride, int gblocks, int nslots) {
-    d_dmedian(blockIdx.x, code0, w, h, quant0, tmp_stride, out_stride, gblocks, nslots);
+    d_dmedian<ROWS>(blockIdx.x, code0, w, h, quant0, tmp_stride, out_stride, gblocks, nslots);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2048,7 +2053,7 @@ __global__ __launch_bounds__(256) void k_phase(LmPhaseArgs a, LmPhaseGrid pg) {
         else if (b < e1) d_dnormal(b - e0, a.depth, a.w, a.h, a.dist_thr, a.diff_thr, a.normal_lut, a.ds, fs, fs, pg.g[1], a.nslots);
         else d_pyrdown8(b - e1, a.bgr0, a.w, a.h, a.bgr1, w1, h1, fs, pg.g[2], a.nslots);
     } else if (PH == 2) {
-        if (b < e0) d_dmedian(b, a.ds, a.w, a.h, a.qd0, fs, fs, pg.g[0], a.nslots);
+        if (b < e0) d_dmedian<DM_ROWS>(b, a.ds, a.w, a.h, a.qd0, fs, fs, pg.g[0], a.nslots);
         else if (b < e1) d_cblur(b - e0, a.bgr1, w1, h1, a.cs1, fs, fs, pg.g[1], a.nslots);
         else d_corient(b - e1, a.cs0, a.w, a.h, thr2, a.cs0 + a3_0, nullptr, fs, fs, pg.g[2], a.nslots);
     } else if (PH == 3) {
@@ -2090,7 +2095,7 @@ __global__ __launch_bounds__(256, 2) void k_bphase(LmPhaseArgs a, LmPhaseGrid pg
         else d_pyrdown16<PD_STRIP>(b - e1, a.bgr0, a.w, a.h, a.bgr1, w1, h1, fs, pg.g[2], n);
     } else if (PH == 2) {
         if (b < e0) d_cgrad<SG>(b, a.cs0, a.w, a.h, ithr, a.qc0, fs, fs, pg.g[0], n);
-        else if (b < e1) d_dmedian(b - e0, a.ds, a.w, a.h, a.qd0, fs, fs, pg.g[1], n);
+        else if (b < e1) d_dmedian<DM_ROWS_BATCH>(b - e0, a.ds, a.w, a.h, a.qd0, fs, fs, pg.g[1], n);
         else d_cblur_sh<16>(b - e1, a.bgr1, w1, h1, a.cs1, fs, fs, pg.g[2], n);
     } else {
         if (b < e0) d_cgrad<16>(b, a.cs1, w1, h1, ithr, a.qc1, fs, fs, pg.g[0], n);
@@ -2150,7 +2155,7 @@ __global__ __launch_bounds__(256, KIND >= 2 ? 1 : 2) void k_pair(LmPhaseArgs a, 
     u32 slot, tile;
     xcd_slot_tile_b(blockIdx.x, g0 + g1 + g2 + g3, n, slot, tile);
     if (KIND == 0) {
-        if (tile < g0) d_dmedian(xcd_vblock(slot, tile, g0, n), a.ds, a.w, a.h, a.qd0, fs, fs, (int)g0, (int)n);
+        if (tile < g0) d_dmedian<DM_ROWS_BATCH>(xcd_vblock(slot, tile, g0, n), a.ds, a.w, a.h, a.qd0, fs, fs, (int)g0, (int)n);
         else d_cblur_sh<16>(xcd_vblock(slot, tile - g0, g1, n), a.bgr1, w1, h1, a.cs1, fs, fs, (int)g1, (int)n);
     } else if (KIND == 1) {
         const float thr2 = a.weak_threshold * a.weak_threshold;
@@ -3197,6 +3202,8 @@ static int g_cblur_variant = 0;   // 0: by batch size (one-shot below 16 frames,
                                   // shared between neighbouring lanes (k_cblur_sh, r03: config 2 146.3 -> 150.7 K, config 3 81.9 -> 86.1 K
                                   // detections/s); A/B knob of tools/ and tests
 void lmk_set_cblur_variant(int v) { g_cblur_variant = v; }
+static int g_dmedian_variant = 0;   // 0: by batch size (4 output rows per lane below 16 frames, DM_ROWS_BATCH from there), 1 / 2: force either
+void lmk_set_dmedian_variant(int v) { g_dmedian_variant = v; }
 static int g_cgrad_variant = 0;   // 0: by batch size (fused k_cgrad from 16 frames), 1: k_corient + k_cvote, 2: k_cgrad, 3: k_cgrad with 32-row strips
 void lmk_set_cgrad_variant(int v) { g_cgrad_variant = v; }
 
@@ -3294,11 +3301,15 @@ void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_
                         bool lut_onehot, u8* quant, u8* scratch, size_t slot_stride, int nslots) {
     if (scratch && lut_onehot && (w % 8) == 0 && ((uintptr_t)depth & 15) == 0 && ((uintptr_t)scratch & 7) == 0 &&
         ((uintptr_t)quant & 7) == 0 && (slot_stride % 16) == 0) {
-        const int n_n = (w / 8) * h, n_m = (w / 8) * ((h + DM_ROWS - 1) / DM_ROWS);
+        const bool dm_batch = g_dmedian_variant == 2 || (g_dmedian_variant == 0 && nslots >= 16);
+        const int dm_rows = dm_batch ? DM_ROWS_BATCH : DM_ROWS;
+        const int n_n = (w / 8) * h, n_m = (w / 8) * ((h + dm_rows - 1) / dm_rows);
         hipLaunchKernelGGL(k_dnormal, dim3((unsigned)(((n_n + 255) / 256) * nslots)), dim3(256), 0, s, depth, w, h, dist_thr, diff_thr,
                            lut, scratch, slot_stride, slot_stride, (n_n + 255) / 256, nslots);
-        hipLaunchKernelGGL(k_dmedian, dim3((unsigned)(((n_m + 255) / 256) * nslots)), dim3(256), 0, s, scratch, w, h, quant,
-                           slot_stride, slot_stride, (n_m + 255) / 256, nslots);
+        if (dm_batch) hipLaunchKernelGGL(k_dmedian<DM_ROWS_BATCH>, dim3((unsigned)(((n_m + 255) / 256) * nslots)), dim3(256), 0, s, scratch, w, h, quant,
+                                             slot_stride, slot_stride, (n_m + 255) / 256, nslots);
+        else hipLaunchKernelGGL(k_dmedian<DM_ROWS>, dim3((unsigned)(((n_m + 255) / 256) * nslots)), dim3(256), 0, s, scratch, w, h, quant,
+                                slot_stride, slot_stride, (n_m + 255) / 256, nslots);
         return;
     }
     dim3 grid((w + DT_W - 1) / DT_W, (h + DT_H - 1) / DT_H, nslots);
@@ -3451,7 +3462,7 @@ void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0, bo
     const int sb = tall ? 32 : 16, sg = tall ? 32 : 16;
     auto bwaves = [&](int ww, int hh, int strip) { return (((ww * 3 / 16) * strips(hh, strip) + 61) / 62 + 3) / 4; };   // k_cblur_sh: 62 useful lanes per wave
     const int g_nrm = per((w / 8) * h), g_blur0 = bwaves(w, h, sb), g_pyr = (((w / 16) * strips(h1, PD_STRIP) + 61) / 62 + 3) / 4;   // k_pyrdown16
-    const int g_grad0 = gwaves(w, h, sg), g_med = per((w / 8) * strips(h, DM_ROWS)), g_blur1 = bwaves(w1, h1, 16);
+    const int g_grad0 = gwaves(w, h, sg), g_med = per((w / 8) * strips(h, DM_ROWS_BATCH)), g_blur1 = bwaves(w1, h1, 16);
     const int g_grad1 = gwaves(w1, h1, 16);
     const int g_sp = T0 == 5 ? per(((w / 5) / 8) * (h / 5)) : per((w / 32) * (h / 2));
     const int seg1 = (w1 / 8 + 39) / 40;
@@ -3499,7 +3510,7 @@ void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0, bo
             else hipLaunchKernelGGL(k_cblur_sh<16>, dim3((unsigned)(g_blur0 * n)), dim3(256), 0, s, a.bgr0, w, h, a.cs0, fs, fs, g_blur0, n);
         }
         if (tall) launch(k_bsplit<1, 32>, h1g); else launch(k_bsplit<1, 16>, h1g);
-        hipLaunchKernelGGL(k_dmedian, dim3((unsigned)(g_med * n)), dim3(256), 0, s, a.ds, w, h, a.qd0, fs, fs, g_med, n);
+        hipLaunchKernelGGL(k_dmedian<DM_ROWS_BATCH>, dim3((unsigned)(g_med * n)), dim3(256), 0, s, a.ds, w, h, a.qd0, fs, fs, g_med, n);
         // level 1 alone: 8-row strips when 16-row ones would leave SIMDs without a wave (as lmk_color_quantize chooses)
         const int waves16 = ((w1 / 16) * strips(h1, 16) + 61) / 62;
         if ((long)waves16 * n >= 1536) hipLaunchKernelGGL(k_cgrad<16>, dim3((unsigned)(g_grad1 * n)), dim3(256), 0, s, a.cs1, w1, h1, ithr, a.qc1, fs, fs, g_grad1, n);

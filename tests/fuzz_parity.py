@@ -50,9 +50,11 @@ while time.time() - t0 < budget * 0.5:
         det.set_tuning(lm.TUNE_PYRDOWN_VARIANT, kp)
         assert np.array_equal(det.stage_pyrdown(bgr), orc.pyrdown(bgr)), ("pyrdown", h, w, kp)
     dep = rand_depth(h, w)
+    det.set_tuning(lm.TUNE_DMEDIAN_VARIANT, int(rng.integers(0, 3)))   # median: 4 or 16 output rows per lane
     assert np.array_equal(det.stage_depth_quantize(dep), orc.depth_quantize(dep)), ("depth", h, w)
     n_stage += 1
 det.set_tuning(lm.TUNE_CBLUR_VARIANT, 0); det.set_tuning(lm.TUNE_CGRAD_VARIANT, 0); det.set_tuning(lm.TUNE_PYRDOWN_VARIANT, 0)
+det.set_tuning(lm.TUNE_DMEDIAN_VARIANT, 0)
 det.close()
 
 while time.time() - t0 < budget:

@@ -118,10 +118,13 @@ def test_pyrdown_both_kernels(lm, det, orc, frame0, variant):
         det.set_tuning(lm.TUNE_PYRDOWN_VARIANT, 0)
 
 
-@pytest.mark.parametrize("shape", [(480, 640), (960, 1280), (40, 48), (23, 91), (12, 12)])
-def test_depth_quantize_parity(det, orc, synth, shape):
+@pytest.mark.parametrize("median_rows", [0, 2])     # 0: by batch size (one frame: 4 output rows per lane), 2: the batch form (16)
+@pytest.mark.parametrize("shape", [(480, 640), (960, 1280), (40, 48), (23, 91), (12, 12), (17, 16), (33, 8)])
+def test_depth_quantize_parity(lm, det, orc, synth, shape, median_rows, request):
     rng = np.random.default_rng(shape[0])
     h, w = shape
+    det.set_tuning(lm.TUNE_DMEDIAN_VARIANT, median_rows)
+    request.addfinalizer(lambda: det.set_tuning(lm.TUNE_DMEDIAN_VARIANT, 0))
     _, depth = synth.make_frame(max(w, 64), max(h, 64), seed=shape[0] + 5)
     depth = np.ascontiguousarray(depth[:h, :w])
     assert np.array_equal(det.stage_depth_quantize(depth), orc.depth_quantize(depth))
