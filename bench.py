@@ -115,6 +115,8 @@ class Runner:
             det.set_tuning(lm.TUNE_BLUR_PYR, 0)
         if args.no_level_pairs:
             det.set_tuning(lm.TUNE_LEVEL_PAIRS, 0)
+        if args.blur_strip:
+            det.set_tuning(lm.TUNE_BLUR_STRIP, args.blur_strip)
         if args.no_prune:
             det.set_scan_variant(8)
         elif args.scan_variant:
@@ -365,6 +367,7 @@ def main():
                          "level-fused batch kernels (LM_TUNE_BATCH_PHASES = 0)")
     ap.add_argument("--cblur-variant", type=int, default=0, help="A/B knob: LM_TUNE_CBLUR_VARIANT (2: sliding window, 3: shared column sums)")
     ap.add_argument("--pyrdown-variant", type=int, default=0, help="A/B knob: LM_TUNE_PYRDOWN_VARIANT (1: k_pyrdown8, 2: row-walking k_pyrdown16)")
+    ap.add_argument("--blur-strip", type=int, default=0, choices=(0, 16, 32, 64), help="A/B knob: rows per strip of the level-0 blur (LM_TUNE_BLUR_STRIP)")
     ap.add_argument("--no-level-pairs", action="store_true", help="A/B knob: no slot-interleaved level pairs (LM_TUNE_LEVEL_PAIRS = 0)")
     ap.add_argument("--no-blur-pyr", action="store_true", help="A/B knob: level-0 blur and pyrDown as two launches (LM_TUNE_BLUR_PYR = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -224,6 +224,9 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
  *   4 below 16 frames -- many short waves --, 16 from there: 20 rows of horizontal sums per 16 outputs instead of 8 per 4),
  *   1 / 2 = force either. */
 #define LM_TUNE_DMEDIAN_VARIANT 11
+/* LM_TUNE_BLUR_STRIP (process-wide): rows per strip of the level-0 Gaussian blur inside the blur + pyrDown launch of a batch:
+ *   0 = by frame shape and batch size (default: as tall as still fills the chip), 16 / 32 / 64 = forced. */
+#define LM_TUNE_BLUR_STRIP 12
 int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 /* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame

@@ -46,6 +46,7 @@ TUNE_PYRDOWN_VARIANT = 8
 TUNE_BLUR_PYR = 9
 TUNE_LEVEL_PAIRS = 10
 TUNE_DMEDIAN_VARIANT = 11
+TUNE_BLUR_STRIP = 12
 
 
 class Rect(C.Structure):

@@ -1262,6 +1262,7 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
         case LM_TUNE_PYRDOWN_VARIANT: if (value < 0 || value > 2) break; lmk_set_pyrdown_variant(value); return LM_OK;
         case LM_TUNE_BLUR_PYR: if (value < 0 || value > 1) break; lmk_set_blur_pyr(value); return LM_OK;
         case LM_TUNE_LEVEL_PAIRS: if (value < 0 || value > 1) break; lmk_set_level_pairs(value); return LM_OK;
+        case LM_TUNE_BLUR_STRIP: if (value != 0 && value != 16 && value != 32 && value != 64) break; lmk_set_blur_strip(value); return LM_OK;
         case LM_TUNE_DMEDIAN_VARIANT: if (value < 0 || value > 2) break; lmk_set_dmedian_variant(value); return LM_OK;
         default: return fail(LM_ERR_INVALID, "unknown tuning key");
     }

@@ -24,6 +24,7 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
 // the two kernels itself).
 bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0, u8* bgr1, u8* quant0, size_t slot_stride, int nslots);
 void lmk_set_blur_pyr(int v);
+void lmk_set_blur_strip(int v);
 // a5: DepthNormal quantisation (normals + LUT + 5x5 median)
 // scratch: w*h bytes per slot (rank codes between the two streaming passes), nullptr or a NORMAL_LUT that is
 // not 0 / one-hot selects the LDS-tiled fallback kernel.

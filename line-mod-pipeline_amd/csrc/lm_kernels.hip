@@ -796,8 +796,11 @@ __device__ __forceinline__ void d_cblur_sh_st(const u32 slot, const u32 tile, co
     }
     u32x4 n0 = ld16(bgr + ((u32)clampi(y0 + 5, 0, h - 1) * pitch + bo));   // the pair of the next step
     u32x4 n1 = ld16(bgr + ((u32)clampi(y0 + 6, 0, h - 1) * pitch + bo));
-#pragma unroll 1
-    for (int y = y0;; y += 2) {
+    // one step = two output rows; the ring's four pairs keep their registers and the step's code names them by (B + k) & 3, B = the
+    // step number mod 4 known at compile time: the loop body is written four times (no moves between steps)
+    int y = y0;
+    auto step = [&](auto Bc) __attribute__((always_inline)) -> bool {
+        constexpr int B = decltype(Bc)::value;
         const bool more = y + 2 < y1;
         // the pair of the step after next is requested before this step's arithmetic
         const u32x4 m0 = ld16(bgr + ((u32)clampi(y + 7, 0, h - 1) * pitch + bo));
@@ -809,7 +812,7 @@ __device__ __forceinline__ void d_cblur_sh_st(const u32 slot, const u32 tile, co
             u32 T[2][4];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const u32 x0 = ring[2 * g][d][0], x1 = ring[2 * g][d][1], z0 = ring[2 * g + 1][d][0], z1 = ring[2 * g + 1][d][1];
+                const u32 x0 = ring[(B + 2 * g) & 3][d][0], x1 = ring[(B + 2 * g) & 3][d][1], z0 = ring[(B + 2 * g + 1) & 3][d][0], z1 = ring[(B + 2 * g + 1) & 3][d][1];
                 T[g][0] = __builtin_amdgcn_perm(z0, x0, 0x05040100u); T[g][1] = __builtin_amdgcn_perm(z0, x0, 0x07060302u);
                 T[g][2] = __builtin_amdgcn_perm(z1, x1, 0x05040100u); T[g][3] = __builtin_amdgcn_perm(z1, x1, 0x07060302u);
             }
@@ -859,13 +862,18 @@ __device__ __forceinline__ void d_cblur_sh_st(const u32 slot, const u32 tile, co
 #pragma unroll
         for (int r = 0; r < 2; ++r)
             if (writer && y + r < h) st16(S + ((u32)(y + r) * pitch + bo), u32x4{o4[r][0], o4[r][1], o4[r][2], o4[r][3]});
-        if (!more) return;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int d = 0; d < 4; ++d) { ring[k][d][0] = ring[k + 1][d][0]; ring[k][d][1] = ring[k + 1][d][1]; }
-        cbx_pair(ring[3], n0, n1);
+        if (!more) return false;
+        cbx_pair(ring[B & 3], n0, n1);            /* the oldest pair's registers take the newest: no ring moves */
         n0 = m0; n1 = m1;
+        y += 2;
+        return true;
+    };
+#pragma unroll 1
+    for (;;) {
+        if (!step(std::integral_constant<int, 0>())) return;
+        if (!step(std::integral_constant<int, 1>())) return;
+        if (!step(std::integral_constant<int, 2>())) return;
+        if (!step(std::integral_constant<int, 3>())) return;
     }
 }
 template <int STRIP>
@@ -2584,8 +2592,30 @@ __global__ __launch_bounds__(1024) void k_refine_plan(const LmDevHeader* __restr
 }
 
 #define PRUNE_REFINE true
+// The inner loop of the refinement, per (feature, candidate): one patch load (4 positions per lane) and four table lookups.
+// rf_patch: the dword-aligned 8-byte load + v_alignbyte that stands for a byte-misaligned dword load.  `se` is wave-uniform (a
+//   feature's offset + the candidate's shift); with a row pitch W that is a multiple of 4 (W4: 640 / 5, 1280 / 2, ...) the lane's
+//   own offset is one too, so the aligned base and the byte shift are SCALAR: one vector add per load instead of add + and + and
+//   (v_alignbyte_b32 reads only bits 1:0 of its shift operand, so the general form passes the address itself).
+// (Tried r03: the four lookups as ds_read_u8_d16 / _d16_hi pairs that pack (r0 | r1 << 16) in the load itself, -2 of 11 vector
+// instructions per feature and candidate: same time, alone and beside other lanes -- the kernel waits for the L1's 16 cycles per
+// patch load, not for the ALU -- and the compiler cannot see hand-issued LDS reads, so the lookups stay plain C.)
+template <bool W4>
+__device__ __forceinline__ u32 rf_patch(const u8* __restrict__ lm, u32 se, u32 lane_off) {
+    if (W4) {
+        const u32x2 d = ld8a4(lm + ((se & ~3u) + lane_off));
+        return __builtin_amdgcn_alignbyte(d[1], d[0], se);
+    }
+    const u32 t = se + lane_off;
+    const u32x2 d = ld8a4(lm + (t & ~3u));
+    return __builtin_amdgcn_alignbyte(d[1], d[0], t);
+}
+__device__ __forceinline__ void rf_lookup(const u8* __restrict__ tab, u32 v, u32& p01, u32& p23) {
+    const u32 r0 = tab[v & 0xFFu], r1 = tab[(v >> 8) & 0xFFu], r2 = tab[(v >> 16) & 0xFFu], r3 = tab[v >> 24];
+    p01 = r0 | (r1 << 16); p23 = r2 | (r3 << 16);
+}
 // One candidate of one slot: similarityLocal over the 16 x 16 patch, first-max argmax, rescore, threshold filter.
-template <bool LAST>
+template <bool LAST, bool W4>
 __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 i, const u8 (*resp)[256], int lane) {
     LmDevHeader* hdr = slot_ptr_s(a.hdr, a.aux_slot_stride, slot);
     LmCand* cand = slot_ptr_s(a.cand, a.aux_slot_stride, slot);
@@ -2628,23 +2658,13 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
         const u32 eff = ok ? (ft.off & 0x1FFFFFFFu) + shift : a.g.zero_off;
         const u32 lab = ft.off >> 29;
         for (int f = 0; f < cnt; f += 8) {
-            u32 v[8];
+            u32 v[8], q01[8], q23[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                // dword-aligned 8-byte load + v_alignbyte instead of a byte-misaligned dword load
-                const u32 t = (u32)__builtin_amdgcn_readlane((int)eff, f + k) + lane_off;
-                const u32x2 d = ld8a4(lm + (t & ~3u));
-                v[k] = __builtin_amdgcn_alignbyte(d[1], d[0], t & 3u);
-            }
+            for (int k = 0; k < 8; ++k) v[k] = rf_patch<W4>(lm, (u32)__builtin_amdgcn_readlane((int)eff, f + k), lane_off);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const u32 lb = (u32)__builtin_amdgcn_readlane((int)lab, f + k);
-                const u8* tab = resp[lb];
-                const u32 r0 = tab[v[k] & 0xFFu], r1 = tab[(v[k] >> 8) & 0xFFu];
-                const u32 r2 = tab[(v[k] >> 16) & 0xFFu], r3 = tab[v[k] >> 24];
-                s01 += r0 | (r1 << 16);
-                s23 += r2 | (r3 << 16);
-            }
+            for (int k = 0; k < 8; ++k) rf_lookup(resp[(u32)__builtin_amdgcn_readlane((int)lab, f + k)], v[k], q01[k], q23[k]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s01 += q01[k]; s23 += q23[k]; }
             f_left -= min(8, cnt - f);
             if (PRUNE_REFINE && (f & 8) && f_left > 0) {       // every second batch of eight
                 const u32 mx = pk_max_u16(s01, s23);
@@ -2691,14 +2711,14 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
 #ifndef RP_BATCH
 #define RP_BATCH 8   // features per load batch of refine_pair (x 2 candidates = loads in flight per wave)
 #endif
-template <bool LAST>
+template <bool LAST, bool W4>
 __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32 i, const u8 (*resp)[256], int lane) {
     LmCand* cand = slot_ptr_s(a.cand, a.aux_slot_stride, slot);
     const u32 tiA = (u32)__builtin_amdgcn_readfirstlane((int)cand[i].ti);
     const u32 tiB = (u32)__builtin_amdgcn_readfirstlane((int)cand[i + 1].ti);
     if (tiA != tiB || tiA == LM_DROPPED) {
-        refine_one<LAST>(a, slot, i, resp, lane);
-        refine_one<LAST>(a, slot, i + 1, resp, lane);
+        refine_one<LAST, W4>(a, slot, i, resp, lane);
+        refine_one<LAST, W4>(a, slot, i + 1, resp, lane);
         return;
     }
     LmDevHeader* hdr = slot_ptr_s(a.hdr, a.aux_slot_stride, slot);
@@ -2741,27 +2761,21 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
         }
         const u32 lab = ft.off >> 29;
         for (int f = 0; f < cnt; f += RP_BATCH) {
-            u32 v[2][RP_BATCH];
+            u32 v[2][RP_BATCH], q01[2][RP_BATCH], q23[2][RP_BATCH];
 #pragma unroll
             for (int k = 0; k < RP_BATCH; ++k)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const u32 t = (u32)__builtin_amdgcn_readlane((int)eff[c], f + k) + lane_off;
-                    const u32x2 d = ld8a4(lm + (t & ~3u));
-                    v[c][k] = __builtin_amdgcn_alignbyte(d[1], d[0], t & 3u);
-                }
+                for (int c = 0; c < 2; ++c) v[c][k] = rf_patch<W4>(lm, (u32)__builtin_amdgcn_readlane((int)eff[c], f + k), lane_off);
 #pragma unroll
             for (int k = 0; k < RP_BATCH; ++k) {
-                const u32 lb = (u32)__builtin_amdgcn_readlane((int)lab, f + k);
-                const u8* tab = resp[lb];
+                const u8* tab = resp[(u32)__builtin_amdgcn_readlane((int)lab, f + k)];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const u32 r0 = tab[v[c][k] & 0xFFu], r1 = tab[(v[c][k] >> 8) & 0xFFu];
-                    const u32 r2 = tab[(v[c][k] >> 16) & 0xFFu], r3 = tab[v[c][k] >> 24];
-                    s01[c] += r0 | (r1 << 16);
-                    s23[c] += r2 | (r3 << 16);
-                }
+                for (int c = 0; c < 2; ++c) rf_lookup(tab, v[c][k], q01[c][k], q23[c][k]);
             }
+#pragma unroll
+            for (int k = 0; k < RP_BATCH; ++k)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) { s01[c] += q01[c][k]; s23[c] += q23[c][k]; }
         }
     }
 #pragma unroll
@@ -2795,7 +2809,7 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
 // candidates w, w + waves, ... of the concatenated lists, so no wave idles while another slot of the XCD still has
 // work.  (Measured r02: the same 1.9 us per frame as a fixed share of workgroups per slot -- the kernel is bound by the
 // L2 lines a 16 x 16 patch pulls, 16 lines for 256 useful bytes, not by idle waves; kept because it cannot lose.)
-template <bool LAST>
+template <bool LAST, bool W4>
 __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
     // response of orientation o to spread byte v = max(LUT_lo[o][v & 15], LUT_hi[o][v >> 4]): 8 x 256 bytes in LDS,
     // built once per workgroup; a feature then costs one ds_read_u8 per position instead of two 16-entry
@@ -2838,23 +2852,23 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
             while (idx + 1 < xlen && xpre[idx + 1] <= g) ++idx;      // g only grows: the list position moves forward
             const u32 i = g - xpre[idx];
             if (g + 1 < xpre[idx + 1]) {
-                refine_pair<LAST>(a, xs[idx], i, resp, lane);
+                refine_pair<LAST, W4>(a, xs[idx], i, resp, lane);
             } else {
-                refine_one<LAST>(a, xs[idx], i, resp, lane);
+                refine_one<LAST, W4>(a, xs[idx], i, resp, lane);
                 if (g + 1 < total) {                                  // the second entry opens the next slot's list
                     u32 idx2 = idx;
                     while (idx2 + 1 < xlen && xpre[idx2 + 1] <= g + 1) ++idx2;
-                    refine_one<LAST>(a, xs[idx2], g + 1 - xpre[idx2], resp, lane);
+                    refine_one<LAST, W4>(a, xs[idx2], g + 1 - xpre[idx2], resp, lane);
                 }
             }
         }
     } else if (total <= nwaves) {
         // few frames: the list fits one round of waves, an entry per wave finishes sooner than pairs on half of them
-        if (wave0 < total) refine_one<LAST>(a, slot, wave0, resp, lane);
+        if (wave0 < total) refine_one<LAST, W4>(a, slot, wave0, resp, lane);
     } else {
         for (u32 i = 2u * wave0; i < total; i += 2u * nwaves) {
-            if (i + 1 < total) refine_pair<LAST>(a, slot, i, resp, lane);
-            else refine_one<LAST>(a, slot, i, resp, lane);
+            if (i + 1 < total) refine_pair<LAST, W4>(a, slot, i, resp, lane);
+            else refine_one<LAST, W4>(a, slot, i, resp, lane);
         }
     }
 }
@@ -3213,6 +3227,8 @@ size_t lmk_color_scratch_bytes(int w, int h) {
     return (px * 3 + 255) / 256 * 256 + (px + 255) / 256 * 256;
 }
 
+static int g_blur_strip = 0;   // rows per strip of the level-0 blur inside k_blur_pyr: 0 = by shape and batch size, 16 / 32 / 64 = forced (A/B, tests)
+void lmk_set_blur_strip(int v) { g_blur_strip = v; }
 static int g_blur_pyr = 1;   // level-0 blur and cv::pyrDown of a batch in one slot-interleaved launch (k_blur_pyr); 0: two launches
 void lmk_set_blur_pyr(int v) { g_blur_pyr = v; }
 bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0, u8* bgr1, u8* quant0, size_t slot_stride, int nslots) {
@@ -3223,7 +3239,13 @@ bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0,
     const int dh = h / 2;
     auto waves4 = [](int pairs) { return ((pairs + 61) / 62 + 3) / 4; };
     const int g_pyr = waves4((w / 16) * ((dh + PD_STRIP - 1) / PD_STRIP));
-    if (h > 640) {
+    // rows per blur strip: 16, or 32 for tall images.  A strip of S rows reads and sums S + 6 (16: 1.375 x the image, 32: 1.19 x, 64:
+    // 1.09 x) but taller strips measured no faster (r03, LM_TUNE_BLUR_STRIP: config 2 163.2 / 162.8 / 160.8 K detections/s at 16 /
+    // 32 / 64, config 3 90.8 / 90.7 K at 32 / 64): fewer, longer waves
+    if (g_blur_strip == 64) {
+        const int g_blur = waves4((w * 3 / 16) * ((h + 63) / 64));
+        hipLaunchKernelGGL(k_blur_pyr<64>, dim3((unsigned)((g_blur + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, g_blur, g_pyr, nslots);
+    } else if (g_blur_strip == 32 || (g_blur_strip == 0 && h > 640)) {
         const int g_blur = waves4((w * 3 / 16) * ((h + 31) / 32));
         hipLaunchKernelGGL(k_blur_pyr<32>, dim3((unsigned)((g_blur + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, g_blur, g_pyr, nslots);
     } else {
@@ -3586,8 +3608,9 @@ void lmk_refine(hipStream_t s, const LmRefineArgs& a_in, bool last, int nslots) 
     a.blocks_per_slot = 256; a.nslots = nslots;
     // with a plan the 256 workgroups of XCD x (8 per CU) are one queue over the candidates of the slots on its list
     dim3 grid(a.plan ? (unsigned)(8 * a.blocks_per_slot) : (unsigned)(a.blocks_per_slot * nslots), 1, 1);
-    if (last) hipLaunchKernelGGL(k_refine<true>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_refine<false>, grid, dim3(256), 0, s, a);
+    const bool w4 = (a.g.W & 3) == 0;     // the patch rows' pitch: scalar alignment arithmetic in rf_patch
+    if (last) { if (w4) hipLaunchKernelGGL((k_refine<true, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((k_refine<true, false>), grid, dim3(256), 0, s, a); }
+    else { if (w4) hipLaunchKernelGGL((k_refine<false, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((k_refine<false, false>), grid, dim3(256), 0, s, a); }
 }
 
 void lmk_emit_unrefined(hipStream_t s, const LmRefineArgs& a, int nslots) {

@@ -149,5 +149,5 @@ def test_bench_config5_line():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["config"]["baseline_config"] == 5 and d["config"]["templates_total"] == 24300 and d["scaling"] == "strong"
-    assert d["config"]["frames_per_step"] == 16 and d["config"]["lanes"] == 2 and d["value"] > 0
+    assert d["config"]["frames_per_step"] == 24 and d["config"]["lanes"] == 3 and d["value"] > 0       # three lanes x 8-frame batches
     assert d["config"]["matches_frame0"] > 0
