@@ -2,7 +2,8 @@
 
     s = (1282 min > 255 max) + (1384 min > 925 max),  q = |dy| > |dx| ? 4 - s : s,  label = (sign(dx) != sign(dy) ? -q : q) & 7
 
-with min / max of (|dx|, |dy|).  A 3x3 Sobel of 8-bit data gives |dx|, |dy| <= 1020; this test sweeps ALL of those
+with min / max of (|dx|, |dy|) -- computed on the device as q = [255 a < 1282 b] + [925 a < 1384 b] + [1384 a < 925 b] + [1282 a < 255 b]
+for (a, b) = (|dx|, |dy|), the same rule spelled out for both octants (four_sign_rule below).  A 3x3 Sobel of 8-bit data gives |dx|, |dy| <= 1020; this test sweeps ALL of those
 (2041 x 2041 pairs) against the oracle's float code (cv::phase -> convertTo(CV_8U, 16/360) -> & 7, SURVEY.md A.2 steps 4-5).
 """
 import numpy as np
@@ -18,6 +19,15 @@ def integer_rule(dx, dy):
     return (q & 7).astype(np.uint8)
 
 
+def four_sign_rule(dx, dy):
+    """The form k_cgrad computes since r03: q = how many of the four sector bounds of the first quadrant |dy| / |dx| exceeds
+    (one dot product per bound, its sign bit counted) -- the min / max rule spelled out for both octants."""
+    a, b = np.abs(dx).astype(np.int64), np.abs(dy).astype(np.int64)
+    q = ((255 * a - 1282 * b < 0).astype(np.int32) + (925 * a - 1384 * b < 0) + (1384 * a - 925 * b < 0) + (1282 * a - 255 * b < 0))
+    q = np.where((dx < 0) ^ (dy < 0), -q, q)
+    return (q & 7).astype(np.uint8)
+
+
 def test_integer_orientation_rule_matches_float_path_everywhere():
     from oracle import oracle as orc
     r = 1020
@@ -26,6 +36,7 @@ def test_integer_orientation_rule_matches_float_path_everywhere():
     got = integer_rule(dx, dy)
     assert want.shape == got.shape == (2 * r + 1, 2 * r + 1)
     assert np.array_equal(got, want)
+    assert np.array_equal(four_sign_rule(dx, dy), want)
     assert set(np.unique(want).tolist()) == set(range(8))
 
 
