@@ -49,7 +49,7 @@ CONFIGS = {
     # (tests/test_facade.py), not part of the timed hot path.
     5: dict(name="BASELINE configs[4] / SURVEY 8d config 5 (hot path): batches of 8 frames of 1280x960 RGB-D, T={5,8}, three classes x "
                  "8100 templates (variable geometry, level-0 bbox 96..320) in one class-list match",
-            W=1280, H=960, color_only=False, l0_size=None, size_range=(96, 320), seed_frames=1234, seed_bank=500, lanes=3, batch=24,
+            W=1280, H=960, color_only=False, l0_size=None, size_range=(96, 320), seed_frames=1234, seed_bank=500, lanes=3, batch=24, h2d_group=8,
             classes=3, templates_per_class=8100),
 }
 

@@ -67,6 +67,13 @@ __device__ __forceinline__ u32 mad24(u32 b, u32 a) {
     }
 }
 
+// p.lo * k.lo + p.hi * k.hi + c on unsigned 16-bit halves, k wave-uniform (VOP3P takes no literal: the taps live in an SGPR)
+__device__ __forceinline__ u32 udot2_u16(u32 p, u32 k, u32 c) {
+    u32 r;
+    asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(p), "s"(k), "v"(c));
+    return r;
+}
+
 // a * b for factors that fit 24 signed bits: v_mul_i32_i24, full rate (v_mul_lo_u32 is quarter rate, and __mul24 goes
 // through sign-extending shifts the compiler does not always fold)
 __device__ __forceinline__ int mul_i24(int a, int b) {
@@ -844,16 +851,22 @@ __device__ __forceinline__ void d_cblur_sh_st(const u32 slot, const u32 tile, co
                     E[25 + k] = last ? vb[r][13 + k % 3] : E[25 + k];
                 }
             }
+            // horizontal taps two at a time: the column sums fit 16 bits (<= 255 * 256), so Q[i] = (E[i], E[i + 3]) packs the two taps a
+            // v_dot2_u32_u16 multiplies; every Q serves three outputs (as taps 0-1, 2-3 and 4-5).  28 packs + 16 x (3 dot2 + 1 mad)
+            // instead of 16 x (3 adds + 5 mads: 72 is not an inline constant)
+            u32 Q[28];
+#pragma unroll
+            for (int i = 0; i < 28; ++i) Q[i] = E[i] | (E[i + 3] << 16);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 u32 packed = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i0 = 4 * j + q;                 // output byte i0: taps at E[i0], E[i0 + 3], ..., E[i0 + 18]
-                    u32 acc = mad24<8>(E[i0] + E[i0 + 18], 32768u);
-                    acc = mad24<28>(E[i0 + 3] + E[i0 + 15], acc);
-                    acc = mad24<56>(E[i0 + 6] + E[i0 + 12], acc);
-                    acc = mad24<72>(E[i0 + 9], acc);
+                    u32 acc = mad24<8>(E[i0 + 18], 32768u);
+                    acc = udot2_u16(Q[i0], 8u | (28u << 16), acc);
+                    acc = udot2_u16(Q[i0 + 6], 56u | (72u << 16), acc);
+                    acc = udot2_u16(Q[i0 + 12], 56u | (28u << 16), acc);
                     packed |= (acc >> 16) << (8 * q);
                 }
                 o4[r][j] = packed;
