@@ -82,6 +82,12 @@ __device__ __forceinline__ int mul_i24(int a, int b) {
     return r;
 }
 
+__device__ __forceinline__ int mad_i24(int a, int b, int c) {   // a * b + c, factors within 24 signed bits
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // v_pk_max_u16 on two u16 pairs
 __device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
@@ -1436,12 +1442,15 @@ __device__ __forceinline__ float dn_rcp(float d) {
     return __builtin_fmaf(err1, r1, q1);
 }
 __device__ __forceinline__ float dn_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-template <bool SMALL>
+// QUOT: the caller passes det / 625, ddx / 125, ddy / 125 (the packed taps' sums); with SMALL the two scalings of a component are one
+// 24-bit multiply, |ddx / 125| <= 8 * 6 * 248 and 125 * 1150 = 143750 < 2^24.
+template <bool SMALL, bool QUOT = false>
 __device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool valid, const u8* __restrict__ lut) {
     // same values as upstream's 64-bit integer products rounded once to float: |ddx| < 2^30 so the
     // double product is exact; |det * d| <= 22500 * 65535 < 2^31
-    float nx = SMALL ? (float)(ddx * 1150) : (float)((double)ddx * 1150.0);
-    float ny = SMALL ? (float)(ddy * 1150) : (float)((double)ddy * 1150.0);
+    if (QUOT) { det = mul_i24(det, 625); if (!SMALL) { ddx = mul_i24(ddx, 125); ddy = mul_i24(ddy, 125); } }
+    float nx = SMALL ? (float)(QUOT ? mul_i24(ddx, 143750) : ddx * 1150) : (float)((double)ddx * 1150.0);
+    float ny = SMALL ? (float)(QUOT ? mul_i24(ddy, 143750) : ddy * 1150) : (float)((double)ddy * 1150.0);
     float nz = (float)(-mul_i24(det, d));
     const float len = dn_sqrt(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
     const float inv = dn_rcp(len > 0 ? len : 1.0f);
@@ -1449,7 +1458,7 @@ __device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool v
     const int v1 = (int)__fadd_rn(__fmul_rn(nx, 10.f), 10.f);
     const int v2 = (int)__fadd_rn(__fmul_rn(ny, 10.f), 10.f);
     const int v3 = (int)__fadd_rn(__fmul_rn(nz, 20.f), 20.f);
-    const int flat = mul_i24(v3, 400) + mul_i24(v2, 20) + v1;   // |v| small: exact
+    const int flat = mad_i24(v3, 400, mad_i24(v2, 20, v1));   // |v| small: exact
     const bool in_lut = (u32)flat < 8000u;
     // the label's rank code straight from the second table (ensure_luts: 8 rank / 8 (rank - 4) + 4 / 32)
     const u32 ecode = lut[LMK_NORMAL_CODE_OFFSET + (in_lut ? flat : 0)];
@@ -1542,7 +1551,7 @@ __device__ __forceinline__ void d_dnormal_t(const u32 vblock, const u16* __restr
                         ddxq = mad_i16h<false>(cj, sx, mad_i16h<false>(ncx, sy, 0));
                         ddyq = mad_i16h<false>(ci, sy, mad_i16h<false>(ncx, sx, 0));
                     }
-                    const u32 e = dn_label<SMALL>(mul_i24(detq, 625), mul_i24(ddxq, 125), mul_i24(ddyq, 125), d, valid, lut);
+                    const u32 e = dn_label<SMALL, true>(detq, ddxq, ddyq, d, valid, lut);
                     out[p >> 2] |= e << (8 * (p & 3));
                 }
             }
