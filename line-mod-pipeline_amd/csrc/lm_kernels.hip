@@ -1640,9 +1640,12 @@ __device__ __forceinline__ void d_dmedian(const u32 vblock, const u8* __restrict
         u32 oh[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) oh[k] = (1u << (e[k] & 31u)) & ~(e[k] >> 5);   // code 32 (rank 8) counts nowhere: 1 << 0 cleared
+        u32 t3[10];                                       // shared partial sums: two three-operand adds per 5-sum
+#pragma unroll
+        for (int k = 0; k < 10; ++k) t3[k] = oh[k] + oh[k + 1] + oh[k + 2];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const u32 hs = oh[k] + oh[k + 1] + oh[k + 2] + oh[k + 3] + oh[k + 4];   // nibbles <= 5
+            const u32 hs = t3[k] + oh[k + 3] + oh[k + 4];   // nibbles <= 5
             const u32 E = hs & 0x0F0F0F0Fu, O = (hs >> 4) & 0x0F0F0F0Fu;
             if (i >= 5) { sumE[k] -= ringE[i % 5][k]; sumO[k] -= ringO[i % 5][k]; }
             ringE[i % 5][k] = E; ringO[i % 5][k] = O;
@@ -1660,11 +1663,10 @@ __device__ __forceinline__ void d_dmedian(const u32 vblock, const u8* __restrict
                     const u32 o1 = o0 + (o0 << 8), PO = o1 + (o1 << 16);                 // ... and it propagates to every byte
                     const u32 mE = (PE + 0x73737373u) & 0x80808080u;            // byte >= 13
                     const u32 mO = (PO + 0x73737373u) & 0x80808080u;
-                    // first byte that reached 13, ranks 0..3 in mE, 4..7 in mO, 8 if none: bit index 8 rank + 7 of the
-                    // 64-bit word mO:mE (ffs - 1 of an empty word is 0xFFFFFFFF: the min skips it).  No branches.
-                    const u32 fe = (u32)(__ffs((int)mE) - 1), fo = (u32)(__ffs((int)mO) - 1) | 32u;
-                    const u32 rank = min(min(fe, fo), 64u) >> 3;
-                    const u32 res = (1u << rank) >> 1;                             // ranks 0..8 -> 0, 1, 2, 4, ..., 128
+                    // The cumulative counts never decrease, so the ranks that reached 13 are exactly those from the median rank up:
+                    // with n of the eight there, the median rank is 8 - n (8 if none did) and its byte (1 << rank) >> 1 = 128 >> n
+                    // (ranks 0..8 -> 0, 1, 2, 4, ..., 128).  Two v_bcnt and a shift instead of two ffs, two min and three shifts.
+                    const u32 res = 128u >> (u32)(__builtin_popcount(mE) + __builtin_popcount(mO));
                     o[k >> 2] |= res << (8 * (k & 3));
                 }
                 *reinterpret_cast<u32x2*>(quant + (size_t)y * w + 8 * g) = u32x2{o[0], o[1]};
