@@ -285,9 +285,9 @@ __device__ __forceinline__ void d_pyrdown16_st(const u32 slot, const u32 tile, c
         // E[i + 6] = column sum of the lane's byte i, i = -6 .. 50: two pixels from the left neighbour, one from the right
         u32 EL[6], ER[3];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) EL[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)V[42 + k], 0x138, 0xf, 0xf, false);   // lane - 1
+        for (int k = 0; k < 6; ++k) EL[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)V[42 + k], 0x138, 0xf, 0xf, true);   // lane - 1
 #pragma unroll
-        for (int k = 0; k < 3; ++k) ER[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)V[k], 0x130, 0xf, 0xf, false);        // lane + 1
+        for (int k = 0; k < 3; ++k) ER[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)V[k], 0x130, 0xf, 0xf, true);        // lane + 1
         if (edge_wave) {
             // BORDER_REFLECT_101: pixel -2 -> 2 (bytes 6 .. 8), -1 -> 1 (bytes 3 .. 5); pixel sw -> sw - 2 (the lane's pixel 14: bytes 42 .. 44)
 #pragma unroll
@@ -843,8 +843,8 @@ __device__ __forceinline__ void d_cblur_sh_st(const u32 slot, const u32 tile, co
             u32 E[34];
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                E[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)vb[r][7 + k], 0x138, 0xf, 0xf, false);       // lane - 1
-                E[25 + k] = (u32)__builtin_amdgcn_update_dpp(0, (int)vb[r][k], 0x130, 0xf, 0xf, false);     // lane + 1
+                E[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)vb[r][7 + k], 0x138, 0xf, 0xf, true);       // lane - 1
+                E[25 + k] = (u32)__builtin_amdgcn_update_dpp(0, (int)vb[r][k], 0x130, 0xf, 0xf, true);     // lane + 1
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) E[9 + i] = vb[r][i];
@@ -1227,8 +1227,8 @@ __device__ __forceinline__ void d_cgrad(const u32 vblock, const u8* __restrict__
         cg_request(nx, S, r + 2, h, pitch, so, lo, ro);        /* S row of the next step */                 \
         u32 oh[16];                                                                                         \
         cg_labels(R[(K) % 3], R[((K) + 1) % 3], R[((K) + 2) % 3], (r <= 0 || r >= h - 1) ? 0u : 28u, first, last, ithr, oh, F[((K) + 2) % 3]); \
-        const u32 ohl = (u32)__builtin_amdgcn_update_dpp(0, (int)oh[15], 0x138, 0xf, 0xf, false);   /* lane - 1's pixel 15 */ \
-        const u32 ohr = (u32)__builtin_amdgcn_update_dpp(0, (int)oh[0], 0x130, 0xf, 0xf, false);    /* lane + 1's pixel 0 */  \
+        const u32 ohl = (u32)__builtin_amdgcn_update_dpp(0, (int)oh[15], 0x138, 0xf, 0xf, true);   /* lane - 1's pixel 15 */ \
+        const u32 ohr = (u32)__builtin_amdgcn_update_dpp(0, (int)oh[0], 0x130, 0xf, 0xf, true);    /* lane + 1's pixel 0 */  \
         _Pragma("unroll") for (int p = 0; p < 16; ++p)                                                      \
             H[((K) + 2) % 3][p] = (p == 0 ? ohl : oh[p - 1]) + oh[p] + (p == 15 ? ohr : oh[p + 1]);         \
         const int y = r - 1;                                   /* output row: centre of label rows r-2, r-1, r */ \
