@@ -47,6 +47,8 @@ struct __attribute__((packed, aligned(4))) U32x4A4 { u32x4 v; };
 struct __attribute__((packed, aligned(4))) U32x2A4 { u32x2 v; };
 __device__ __forceinline__ u32x4 ld16a4(const u8* p) { return reinterpret_cast<const U32x4A4*>(p)->v; }
 __device__ __forceinline__ u32x2 ld8a4(const u8* p) { return reinterpret_cast<const U32x2A4*>(p)->v; }
+struct __attribute__((packed, aligned(4))) U32x3A4 { u32 v[3]; };
+__device__ __forceinline__ void ld12a4(const u8* p, u32& d0, u32& d1, u32& d2) { const U32x3A4 t = *reinterpret_cast<const U32x3A4*>(p); d0 = t.v[0]; d1 = t.v[1]; d2 = t.v[2]; }
 // value of lane + 1 (0 for lane 63): v_mov_b32_dpp wave_shl:1 bound_ctrl:1 -- every lane is written, so the
 // destination needs no initialisation
 __device__ __forceinline__ u32 next_lane(u32 v) {
@@ -1461,7 +1463,7 @@ __device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool v
     const int flat = mad_i24(v3, 400, mad_i24(v2, 20, v1));   // |v| small: exact
     const bool in_lut = (u32)flat < 8000u;
     // the label's rank code straight from the second table (ensure_luts: 8 rank / 8 (rank - 4) + 4 / 32)
-    const u32 ecode = lut[LMK_NORMAL_CODE_OFFSET + (in_lut ? flat : 0)];
+    const u32 ecode = lut[LMK_NORMAL_CODE_OFFSET + (in_lut ? (u32)flat : 0u)];     // (unsigned: a 32-bit offset from the table's base)
     return (valid && len > 0 && in_lut) ? ecode : 0u;
 }
 
@@ -1628,13 +1630,15 @@ __device__ __forceinline__ void d_dmedian(const u32 vblock, const u8* __restrict
 #pragma unroll
     for (int i = 0; i < ROWS + 4; ++i) {                  // image row y0 - 2 + i, replicated at the borders
         const int yy = clampi(y0 - 2 + i, 0, h - 1);
-        const u8* row = code + (size_t)yy * w + 8 * g;
+        // (32-bit offsets from the slot's base: a 64-bit multiply-add per row address is four quarter-rate instructions)
+        const u32 ro = (u32)yy * (u32)w + 8u * (u32)g;
+        const u8* row = code + ro;
         const u32x2 c = *reinterpret_cast<const u32x2*>(row);
         u32 e[12];                                        // codes of pixels 8g-2 .. 8g+9
 #pragma unroll
         for (int k = 0; k < 8; ++k) e[2 + k] = (c[k >> 2] >> (8 * (k & 3))) & 0xFFu;
         // (no branches: the row ends load a valid dword of the row and select the replicated pixel)
-        const u32 l = *reinterpret_cast<const u32*>(g > 0 ? row - 4 : row), r = *reinterpret_cast<const u32*>(g + 1 < ng ? row + 8 : row + 4);
+        const u32 l = *reinterpret_cast<const u32*>(code + (g > 0 ? ro - 4u : ro)), r = *reinterpret_cast<const u32*>(code + (g + 1 < ng ? ro + 8u : ro + 4u));
         e[0] = g > 0 ? (l >> 16) & 0xFFu : e[2]; e[1] = g > 0 ? l >> 24 : e[2];
         e[10] = g + 1 < ng ? r & 0xFFu : e[9]; e[11] = g + 1 < ng ? (r >> 8) & 0xFFu : e[9];
         u32 oh[12];
@@ -1669,7 +1673,7 @@ __device__ __forceinline__ void d_dmedian(const u32 vblock, const u8* __restrict
                     const u32 res = 128u >> (u32)(__builtin_popcount(mE) + __builtin_popcount(mO));
                     o[k >> 2] |= res << (8 * (k & 3));
                 }
-                *reinterpret_cast<u32x2*>(quant + (size_t)y * w + 8 * g) = u32x2{o[0], o[1]};
+                *reinterpret_cast<u32x2*>(quant + ((u32)y * (u32)w + 8u * (u32)g)) = u32x2{o[0], o[1]};
             }
         }
     }
@@ -2779,6 +2783,8 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
         shift[c] = (u32)(by[c] * W + bx[c]);
     }
     u32 s01[2] = {0, 0}, s23[2] = {0, 0};
+    const int dcol = bx[1] - bx[0];                                   // wave-uniform
+    const bool same_rows = by[0] == by[1] && dcol >= 0 && dcol <= 4;
     for (int m = 0; m < a.M; ++m) {
         // (selects, not mt.count[m]: a runtime index into the struct copy would put it into scratch memory)
         const int cnt = (int)(m == 0 ? mt.count[0] : mt.count[1]);
@@ -2787,19 +2793,39 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
         ft.off = 0; ft.x = 0; ft.y = 0;
         if (lane < cnt) ft = a.feats[fstart + lane];
         u32 eff[2];
+        bool ok2[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int fx = ft.x + off_x[c], fy = ft.y + off_y[c];
             const bool ok = (lane < cnt) && fx >= 0 && fy >= 0 && fx < a.g.w && fy < a.g.h;
+            ok2[c] = ok;
             eff[c] = ok ? (ft.off & 0x1FFFFFFFu) + shift[c] : a.g.zero_off;
         }
         const u32 lab = ft.off >> 29;
+        // ONE load for both patches (r03): the two entries are neighbouring lattice positions of one template, i.e. the second
+        // patch is the first moved 0 .. 4 columns to the right in the same rows, and every feature lies inside the image for both.
+        // A lane then takes 12 bytes from the first patch's aligned address and cuts both its dwords out of them -- half the
+        // wave-loads (the L1 spends 16 cycles on each, whatever it returns), one more select pair per feature.
+        const bool share = W4 && same_rows && __all(lane >= cnt || (ok2[0] && ok2[1]));
         for (int f = 0; f < cnt; f += RP_BATCH) {
             u32 v[2][RP_BATCH], q01[2][RP_BATCH], q23[2][RP_BATCH];
+            if (share) {
+#pragma unroll
+                for (int k = 0; k < RP_BATCH; ++k) {
+                    const u32 se = (u32)__builtin_amdgcn_readlane((int)eff[0], f + k);
+                    u32 d0, d1, d2;
+                    ld12a4(lm + ((se & ~3u) + lane_off), d0, d1, d2);
+                    const u32 o = (se & 3u) + (u32)dcol;          // byte offset of the second patch's dword in the 12 bytes: 0 .. 7
+                    const bool up = o >= 4u;                      // wave-uniform
+                    v[0][k] = __builtin_amdgcn_alignbyte(d1, d0, se);
+                    v[1][k] = __builtin_amdgcn_alignbyte(up ? d2 : d1, up ? d1 : d0, o);
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < RP_BATCH; ++k)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) v[c][k] = rf_patch<W4>(lm, (u32)__builtin_amdgcn_readlane((int)eff[c], f + k), lane_off);
+            }
 #pragma unroll
             for (int k = 0; k < RP_BATCH; ++k) {
                 const u8* tab = resp[(u32)__builtin_amdgcn_readlane((int)lab, f + k)];
