@@ -30,6 +30,16 @@ def test_library_exports_every_declared_symbol(lm):
         assert getattr(lib, n).argtypes is not None, "no argtypes declared for %s" % n
 
 
+def test_tuning_keys_of_header_and_binding_agree(lm):
+    """Every LM_TUNE_* key of the header has its twin in the Python binding, with the same value, and no key is used twice."""
+    src = open(os.path.join(ROOT, "include", "linemod_hip.h")).read()
+    keys = {m.group(1): int(m.group(2)) for m in re.finditer(r"^#define LM_(TUNE_[A-Z0-9_]+)\s+(\d+)\s*$", src, flags=re.M)}
+    assert len(keys) >= 12 and len(set(keys.values())) == len(keys)
+    for name, value in keys.items():
+        assert getattr(lm, name, None) == value, name
+    assert sorted(n for n in dir(lm) if n.startswith("TUNE_")) == sorted(keys)
+
+
 def test_default_config_matches_reference_constructions(lm):
     # HighLevelLinemod.cpp:26-43: {ColorGradient, DepthNormal} T={5,8}; {ColorGradient} T={2,8}
     c = lm.default_config(color_only=False)
