@@ -382,9 +382,11 @@ int lm_time_scan(lm_detector* det, int slot, float threshold, int class_idx, int
 int lm_time_scan_batch(lm_detector* det, int first_slot, int n_slots, float threshold, int class_idx, int iters, int variant,
                        double* avg_us_out);
 /* Self-test (no upstream counterpart): the depth-normal kernel's float tail takes 1 / len and sqrt by sequences that drop the
- * compiler's exponent-range handling; this runs every float of the tail's domain through both forms on the device.
- * out[0] / out[1] = number of floats whose reciprocal / square root differ (0 / 0 expected). */
-int lm_selftest_float_tail(lm_detector* det, uint64_t out[2]);
+ * compiler's exponent-range handling; this runs every float of the tail's domain through both forms on the device, the reference
+ * being the correctly rounded 1.0f / x and sqrtf.  out[0] / out[1] = number of floats whose reciprocal / square root differ
+ * (0 / 0 expected); out[2] = floats on which the bare v_sqrt_f32 instruction differs (information only: the kernel does not
+ * rely on it); out[3] = 0. */
+int lm_selftest_float_tail(lm_detector* det, uint64_t out[4]);
 /* Per-stage average microseconds of the last lm_match_slot-style pipeline, measured with HIP events
  * over `iters` runs: out[0]=preprocess (a3-a10), out[1]=scan, out[2]=refine, out[3]=sort+copy. */
 int lm_time_stages(lm_detector* det, int slot, float threshold, int class_idx, int iters, double out_us[4]);

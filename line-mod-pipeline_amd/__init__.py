@@ -723,9 +723,11 @@ class Detector:
         return us.value
 
     def selftest_float_tail(self):
-        """(reciprocals, square roots) of the depth-normal tail's float domain that differ from the correctly rounded forms."""
-        out = (C.c_uint64 * 2)()
+        """(reciprocals, square roots) of the depth-normal tail's float domain that differ from the correctly rounded forms.
+        `self.last_bare_sqrt_mismatches` = floats on which the bare v_sqrt_f32 differs from the correctly rounded root."""
+        out = (C.c_uint64 * 4)()
         self._check(self.lib.lm_selftest_float_tail(self.h, out))
+        self.last_bare_sqrt_mismatches = int(out[2])
         return int(out[0]), int(out[1])
 
     def time_stages(self, slot, threshold, class_idx=-1, iters=20):

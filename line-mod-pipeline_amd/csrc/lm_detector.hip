@@ -2264,22 +2264,23 @@ int lm_time_scan_batch(lm_detector* d, int first_slot, int n_slots, float thresh
 }
 
 // Self-test of k_dnormal's float tail (lm_kernels.hip dn_rcp / dn_sqrt): every float of the tail's domain through the short
-// sequences and through the compiler's correctly rounded 1.0f / x and sqrtf on this device; out[0] / out[1] = floats that differ.
-int lm_selftest_float_tail(lm_detector* d, uint64_t out[2]) {
+// sequences and through the compiler's correctly rounded 1.0f / x and sqrtf (__builtin_sqrtf: v_sqrt_f32 + its +-1 ulp fix-up) on
+// this device; out[0] / out[1] = floats that differ, out[2] = floats on which the bare v_sqrt_f32 differs (information), out[3] = 0.
+int lm_selftest_float_tail(lm_detector* d, uint64_t out[4]) {
     int rc;
     if (!out) return fail(LM_ERR_INVALID, "null argument");
     if ((rc = ready_for_compute(d))) return rc;
     if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     unsigned long long* dev = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), 2 * sizeof(unsigned long long)));
-    hipError_t e = hipMemsetAsync(dev, 0, 2 * sizeof(unsigned long long), d->stream);
-    unsigned long long host[2] = {0, 0};
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), 4 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(dev, 0, 4 * sizeof(unsigned long long), d->stream);
+    unsigned long long host[4] = {0, 0, 0, 0};
     if (e == hipSuccess) { lmk_selftest_float_tail(d->stream, dev); e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, d->stream); }
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
     if (e == hipSuccess) e = hipGetLastError();
     (void)hipFree(dev);
     if (e != hipSuccess) return fail(LM_ERR_HIP, hipGetErrorString(e));
-    out[0] = host[0]; out[1] = host[1];
+    for (int k = 0; k < 4; ++k) out[k] = host[k];
     return LM_OK;
 }
 

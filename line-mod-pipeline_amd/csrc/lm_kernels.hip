@@ -1432,8 +1432,10 @@ __device__ __forceinline__ u32 hw_u16(const u32x4* A, int hw) {
 // or in [1, 2^82) and 1 <= len < 2^41: nx, ny, nz are integers below 2^40 in magnitude):
 // the compiler's correctly rounded 1.0f / x is v_div_scale x 2, v_rcp, six fused steps, v_div_fmas, v_div_fixup -- scale
 // and fixup only act on operands near the ends of the exponent range -- and its sqrtf scales denormal inputs around a
-// v_sqrt_f32.  Without those: 7 + 1 instructions instead of 11 + 6, bit-identical on the domain (lm_selftest_float_tail
-// sweeps every float of the domain against __fdiv_rn / __fsqrt_rn on the device; tests/test_gpu_stages.py).
+// v_sqrt_f32 and its +-1 ulp fix-up.  Without the range handling: 7 instructions instead of 11 for the reciprocal; the
+// square root keeps the fix-up (v_sqrt_f32 alone is a 1-ulp instruction: r04) and drops only the scaling.
+// lm_selftest_float_tail sweeps every float of the domain against the CORRECTLY ROUNDED 1.0f / x and sqrtf on the device
+// (__builtin_sqrtf; NOT __fsqrt_rn, which this build maps to the bare v_sqrt_f32) -- tests/test_gpu_stages.py.
 __device__ __forceinline__ float dn_rcp(float d) {
     const float r0 = __builtin_amdgcn_rcpf(d);
     const float e = __builtin_fmaf(-d, r0, 1.0f);
@@ -1443,7 +1445,20 @@ __device__ __forceinline__ float dn_rcp(float d) {
     const float err1 = __builtin_fmaf(-d, q1, 1.0f);
     return __builtin_fmaf(err1, r1, q1);
 }
-__device__ __forceinline__ float dn_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float dn_sqrt_bare(float x) { return __builtin_amdgcn_sqrtf(x); }
+// correctly rounded for x = 0 or a normal x: the hardware's root s is within 1 ulp, so the answer is s or a neighbour; with
+// r(t) = x - t * s (one rounding), the root is below s iff r(s-) <= 0 and above it iff r(s+) > 0 (the compiler's own sqrtf
+// fix-up without its denormal scaling).  x == 0 gives s == 0: both neighbours' residuals keep s.
+__device__ __forceinline__ float dn_sqrt(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __builtin_bit_cast(float, __builtin_bit_cast(u32, s) - 1u);
+    const float s_up = __builtin_bit_cast(float, __builtin_bit_cast(u32, s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x);
+    const float r_up = __builtin_fmaf(-s_up, s, x);
+    float r = r_dn <= 0.0f ? s_dn : s;
+    r = r_up > 0.0f ? s_up : r;
+    return x == 0.0f ? 0.0f : r;
+}
 // QUOT: the caller passes det / 625, ddx / 125, ddy / 125 (the packed taps' sums); with SMALL the two scalings of a component are one
 // 24-bit multiply, |ddx / 125| <= 8 * 6 * 248 and 125 * 1150 = 143750 < 2^24.
 template <bool SMALL, bool QUOT = false>
@@ -1467,18 +1482,22 @@ __device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool v
     return (valid && len > 0 && in_lut) ? ecode : 0u;
 }
 
-// every float of the tail's domain through dn_rcp / dn_sqrt and through the compiler's correctly rounded forms
+// every float of the tail's domain through dn_rcp / dn_sqrt and through the compiler's correctly rounded forms;
+// out[2]: the bare v_sqrt_f32 against the same reference (information: how often the 1-ulp instruction is off)
 __global__ __launch_bounds__(256) void k_selftest_float_tail(unsigned long long* __restrict__ out) {
     const u32 lo = 0x3F800000u, hi_rcp = (127u + 42u) << 23, hi_sqrt = (127u + 84u) << 23;   // 1.0f .. 2^42 / 2^84
-    unsigned long long bad_rcp = 0, bad_sqrt = 0;
+    unsigned long long bad_rcp = 0, bad_sqrt = 0, bad_bare = 0;
     for (u32 b = lo + blockIdx.x * 256u + threadIdx.x; b <= hi_sqrt; b += gridDim.x * 256u) {
         const float x = __builtin_bit_cast(float, b);
         if (b <= hi_rcp) bad_rcp += __builtin_bit_cast(u32, dn_rcp(x)) != __builtin_bit_cast(u32, __fdiv_rn(1.0f, x));
-        bad_sqrt += __builtin_bit_cast(u32, dn_sqrt(x)) != __builtin_bit_cast(u32, __fsqrt_rn(x));
+        const u32 want = __builtin_bit_cast(u32, __builtin_sqrtf(x));
+        bad_sqrt += __builtin_bit_cast(u32, dn_sqrt(x)) != want;
+        bad_bare += __builtin_bit_cast(u32, dn_sqrt_bare(x)) != want;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) bad_sqrt += __builtin_bit_cast(u32, dn_sqrt(0.0f)) != 0u;
     if (bad_rcp) atomicAdd(&out[0], bad_rcp);
     if (bad_sqrt) atomicAdd(&out[1], bad_sqrt);
+    if (bad_bare) atomicAdd(&out[2], bad_bare);
 }
 
 template <bool SMALL>

@@ -182,7 +182,14 @@ void orc_sobel3_s16c3(const uint8_t* s, int w, int h, int16_t* dx, int16_t* dy) 
 
 namespace {
 
-// cv::fastAtan2 polynomial, degrees (A.2 step 4).  Plain float ops, no fused multiply-add.
+// cv::fastAtan2 polynomial, degrees (A.2 step 4).  Two forms of the same polynomial exist upstream
+// [UPSTREAM-RECALLED, core/src/mathfuncs_core.simd.hpp]: the scalar atan_f32 (plain multiplies and adds) and the
+// vector v_atan_f32 that cv::phase runs on whole rows, whose three Horner steps are v_fma -- a true fused
+// multiply-add in the AVX2-dispatched build (every x86 wheel), an unfused a*b+c in the SSE2 baseline.
+// g_atan_variant selects: 0 = unfused (default), 1 = fused.  The two agree on the LABEL for every gradient a 3x3
+// Sobel of 8-bit data can produce (tests/test_orientation_rule.py sweeps all 2041^2; profiles/r04_atan_fma_sweep.log).
+int g_atan_variant = 0;
+
 inline float fast_atan2_deg(float y, float x) {
     const float p1 = 0.9997878412794807f * (float)(180.0 / 3.14159265358979323846);
     const float p3 = -0.3258083974640975f * (float)(180.0 / 3.14159265358979323846);
@@ -191,7 +198,14 @@ inline float fast_atan2_deg(float y, float x) {
     const float eps = (float)2.2204460492503131e-16;  // (float)DBL_EPSILON
     float ax = std::fabs(x), ay = std::fabs(y);
     float a, c, c2;
-    if (ax >= ay) {
+    if (g_atan_variant & 1) {
+        // v_atan_f32::compute: c = min / (max + eps); a = fma(fma(fma(cc, p7, p5), cc, p3), cc, p1) * c; select
+        float mn = ax < ay ? ax : ay, mx = ax < ay ? ay : ax;
+        c = mn / (mx + eps);
+        c2 = c * c;
+        a = std::fmaf(std::fmaf(std::fmaf(c2, p7, p5), c2, p3), c2, p1) * c;
+        if (!(ax >= ay)) a = 90.f - a;
+    } else if (ax >= ay) {
         c = ay / (ax + eps);
         c2 = c * c;
         a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
@@ -273,6 +287,36 @@ void orc_orientation_labels(const int32_t* dx, const int32_t* dy, size_t n, uint
     ORC_PAR_FOR
     for (size_t i = 0; i < n; ++i)
         label[i] = (u8)(sat_u8_rint(fast_atan2_deg((float)dy[i], (float)dx[i]) * scale + 0.0f) & 7);
+}
+
+// Which form of the fastAtan2 polynomial orc_color_quantize / orc_orientation_labels evaluate: bit 0 = the fused
+// multiply-adds of upstream's vector code path (above).  Returns the previous value.
+int orc_set_atan_variant(int variant) { int old = g_atan_variant; g_atan_variant = variant & 1; return old; }
+
+// The polynomial's angle itself (degrees), for the pinning hook: which of the two forms an OpenCV build runs shows in the
+// bits of cv::phase's output, not in the labels.
+void orc_fast_atan2(const float* y, const float* x, size_t n, int variant, float* angle) {
+    const int saved = orc_set_atan_variant(variant & 1);
+    for (size_t i = 0; i < n; ++i) angle[i] = fast_atan2_deg(y[i], x[i]);
+    orc_set_atan_variant(saved);
+}
+
+// The same labels with convertTo's working type widened to double (bit 1 of `variant`; bit 0 as above) -- a second
+// recall decision the sweep retires: raw16[i] = the 16-bin value before `& 7`, may be NULL.
+void orc_orientation_labels_variant(const int32_t* dx, const int32_t* dy, size_t n, int variant, uint8_t* label,
+                                    uint8_t* raw16) {
+    const int saved = orc_set_atan_variant(variant & 1);
+    const float scale = (float)(16.0 / 360.0);
+    ORC_PAR_FOR
+    for (size_t i = 0; i < n; ++i) {
+        float ang = fast_atan2_deg((float)dy[i], (float)dx[i]);
+        u8 r;
+        if (variant & 2) { long v = lrint((double)ang * (16.0 / 360.0)); r = (u8)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+        else r = sat_u8_rint(ang * scale + 0.0f);
+        if (raw16) raw16[i] = r;
+        label[i] = (u8)(r & 7);
+    }
+    orc_set_atan_variant(saved);
 }
 
 // a4: cv::pyrDown on CV_8UC3: 5x5 [1 4 6 4 1]^2/256, BORDER_REFLECT_101, (sum+128)>>8 (A.2 pyrDown).

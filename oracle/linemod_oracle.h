@@ -68,6 +68,10 @@ void orc_sobel3_s16c3(const uint8_t* src, int w, int h, int16_t* dx, int16_t* dy
 void orc_color_quantize(const uint8_t* bgr, int w, int h, float weak_threshold,
                         uint8_t* quantized, float* magnitude /* may be NULL */);              /* a3 quantizedOrientations   */
 void orc_orientation_labels(const int32_t* dx, const int32_t* dy, size_t n, uint8_t* label);  /* a3 steps 4-5 on given gradients */
+void orc_fast_atan2(const float* y, const float* x, size_t n, int variant, float* angle_degrees);   /* cv::fastAtan2 / cv::phase, either form */
+int  orc_set_atan_variant(int variant);   /* bit 0: fused multiply-adds in the fastAtan2 polynomial (upstream's v_atan_f32 on an AVX2 build); returns the old value */
+void orc_orientation_labels_variant(const int32_t* dx, const int32_t* dy, size_t n, int variant /* bit 0 fused, bit 1 double convertTo */,
+                                    uint8_t* label, uint8_t* raw16 /* may be NULL */);
 void orc_pyrdown_u8c3(const uint8_t* src, int w, int h, uint8_t* dst);                         /* a4 cv::pyrDown             */
 void orc_depth_quantize(const uint16_t* depth, int w, int h, int distance_threshold,
                         int difference_threshold, const uint8_t* normal_lut, uint8_t* quantized); /* a5 quantizedNormals  */

@@ -84,6 +84,10 @@ def load(path=None):
     lib.orc_color_quantize.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.orc_pyrdown_u8c3.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.orc_orientation_labels.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.orc_orientation_labels_variant.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]
+    lib.orc_fast_atan2.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
+    lib.orc_set_atan_variant.argtypes = [C.c_int]
+    lib.orc_set_atan_variant.restype = C.c_int
     lib.orc_depth_quantize.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.orc_resize_nn_half.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.orc_spread.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
@@ -169,6 +173,26 @@ def orientation_labels(dx, dy):
     """Orientation label (0..7) of the float path (fastAtan2 -> x 16/360 -> rint -> & 7) for int32 gradient arrays."""
     lib = load(); dx = _c(dx, np.int32); dy = _c(dy, np.int32)
     out = np.empty(dx.shape, np.uint8); lib.orc_orientation_labels(_ptr(dx), _ptr(dy), dx.size, _ptr(out)); return out
+
+
+def orientation_labels_variant(dx, dy, variant, want_raw16=False):
+    """As orientation_labels with upstream's OTHER code shapes: variant bit 0 = fused multiply-adds in the fastAtan2 polynomial
+    (v_atan_f32 on an AVX2 build), bit 1 = convertTo's scale applied in double."""
+    lib = load(); dx = _c(dx, np.int32); dy = _c(dy, np.int32)
+    out = np.empty(dx.shape, np.uint8); raw = np.empty(dx.shape, np.uint8) if want_raw16 else None
+    lib.orc_orientation_labels_variant(_ptr(dx), _ptr(dy), dx.size, int(variant), _ptr(out), _ptr(raw))
+    return (out, raw) if want_raw16 else out
+
+
+def fast_atan2(y, x, variant=0):
+    """cv::phase(x, y, angleInDegrees=True) for float32 arrays; variant 1 = the fused form."""
+    lib = load(); y = _c(y, np.float32); x = _c(x, np.float32)
+    out = np.empty(x.shape, np.float32); lib.orc_fast_atan2(_ptr(y), _ptr(x), x.size, int(variant), _ptr(out)); return out
+
+
+def set_atan_variant(variant):
+    """Selects the fastAtan2 form orc_color_quantize uses (0 unfused, 1 fused); returns the previous value."""
+    return load().orc_set_atan_variant(int(variant))
 
 
 def pyrdown(bgr):

@@ -88,10 +88,28 @@ def main():
             except Exception as e:                                 # noqa: BLE001 -- not every binding wraps write()
                 print("could not write the template file through these bindings:", e)
         print(name, "templates", det.numTemplates(), "matches@80", len(out[name + "_matches_80"]))
+    phase_vectors(cv2, out)
     f1_vectors(cv2, bgr, out)
     np.savez_compressed(os.path.join(HERE, "opencv_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "opencv_vectors.npz"))
     recover_normal_lut(cv2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a3 steps 4-5 on their own: cv::phase + convertTo(CV_8U, 16/360) over EVERY gradient a 3x3 Sobel of 8-bit data can produce
+# (|dx|, |dy| <= 1020).  The labels pin the oracle's rule and k_cgrad's integer rule; a sample of the raw angles tells which
+# form of the fastAtan2 polynomial this OpenCV build runs (fused v_fma on AVX2 builds, plain multiply-add otherwise:
+# tests/test_opencv_vectors.py compares the bits with both forms of the oracle and reports the one that matches).
+def phase_vectors(cv2, out):
+    r = 1020
+    dx, dy = np.meshgrid(np.arange(-r, r + 1, dtype=np.float32), np.arange(-r, r + 1, dtype=np.float32))
+    ang = cv2.phase(dx, dy, angleInDegrees=True)
+    q = cv2.convertScaleAbs(ang, alpha=16.0 / 360.0)     # |x| of a non-negative value: saturate_cast<uchar>(cvRound(..)) as convertTo does
+    out["phase_labels_2041"] = (q & 7).astype(np.uint8)
+    out["phase_raw16_2041"] = q.astype(np.uint8)
+    out["phase_sample_angles"] = ang.ravel()[::37].astype(np.float32)
+    out["opencv_build_cpu"] = np.array(" ".join(l.strip() for l in cv2.getBuildInformation().splitlines()
+                                                if "CPU/HW" in l or "Baseline" in l or "Dispatched" in l or "requested" in l))
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -67,6 +67,26 @@ def test_templates_and_matches_equal_opencv(orc, frame0, vec, name, color_only):
             pytest.xfail("RGB-D match list differs from OpenCV (expected while NORMAL_LUT is substituted)")
 
 
+def test_phase_labels_equal_opencv_and_report_the_polynomial_form(vec):
+    """cv::phase + convertTo over all 2041^2 Sobel gradients: labels (and the 16-bin values) must equal the oracle's -- in
+    either form of the fastAtan2 polynomial, they agree on every label (test_orientation_rule.py) -- and the bits of a
+    sample of raw angles say which form this OpenCV build evaluates (reported, not asserted)."""
+    if "phase_labels_2041" not in vec.files:
+        pytest.skip("vectors written by an older hook: no phase section")
+    from oracle import oracle as O
+    r = 1020
+    dx, dy = np.meshgrid(np.arange(-r, r + 1, dtype=np.int32), np.arange(-r, r + 1, dtype=np.int32))
+    lab, raw = O.orientation_labels_variant(dx, dy, 0, want_raw16=True)
+    assert np.array_equal(lab, vec["phase_labels_2041"])
+    assert np.array_equal(raw, vec["phase_raw16_2041"])
+    fy, fx = dy.astype(np.float32).ravel()[::37], dx.astype(np.float32).ravel()[::37]
+    want = vec["phase_sample_angles"]
+    same = {v: int((O.fast_atan2(fy, fx, v).view(np.uint32) == want.view(np.uint32)).sum()) for v in (0, 1)}
+    print("raw angles bit-equal to the unfused form: %d, to the fused form: %d of %d  (%s)"
+          % (same[0], same[1], want.size, str(vec["opencv_build_cpu"]) if "opencv_build_cpu" in vec.files else "?"))
+    assert max(same.values()) == want.size, "cv::phase matches neither form of the restated polynomial bit for bit: %r" % same
+
+
 # ---- NORMAL_LUT recovered from OpenCV's behaviour (the hook's recover_normal_lut) --------------------------------------
 @pytest.mark.skipif(not os.path.exists(LUT), reason="no recovered NORMAL_LUT: run tests/golden/make_opencv_vectors.py")
 def test_depth_normal_equals_opencv_with_the_recovered_lut(orc, frame0, vec):

@@ -50,3 +50,43 @@ def test_rule_thresholds_are_strictly_between_realised_ratios():
         assert hi.numerator * lo.denominator - lo.numerator * hi.denominator == 1   # neighbours in the Farey sequence
         assert mid.denominator > 1020
     assert integer_rule(np.array([0]), np.array([0]))[0] == 0
+
+
+def test_fused_and_unfused_fastatan2_give_the_same_labels_everywhere():
+    """upstream's vector code path (v_atan_f32, what cv::phase runs on rows) evaluates the polynomial's
+    three Horner steps as v_fma -- truly fused on an AVX2 build -- while the oracle and the float kernels restate the
+    scalar atan_f32.  Swept over every gradient a 3x3 Sobel of 8-bit data can produce: neither the 8-bin label nor the
+    16-bin value before `& 7` differs, with the scale of convertTo in float or in double.  So the integer rule's two
+    bound pairs hold for either build of OpenCV and the kernels need no second variant."""
+    from oracle import oracle as orc
+    r = 1020
+    dx, dy = np.meshgrid(np.arange(-r, r + 1, dtype=np.int32), np.arange(-r, r + 1, dtype=np.int32))
+    base, base16 = orc.orientation_labels_variant(dx, dy, 0, want_raw16=True)
+    assert np.array_equal(base, orc.orientation_labels(dx, dy))
+    report = []
+    for variant, name in ((1, "fused polynomial"), (2, "double convertTo"), (3, "fused polynomial + double convertTo")):
+        lab, raw = orc.orientation_labels_variant(dx, dy, variant, want_raw16=True)
+        report.append((name, int((lab != base).sum()), int((raw != base16).sum())))
+    print("pairs swept: %d" % dx.size)
+    for name, nl, nr in report:
+        print("%-40s labels differing: %d   16-bin values differing: %d" % (name, nl, nr))
+    assert all(nl == 0 and nr == 0 for _, nl, nr in report), report
+    assert np.array_equal(integer_rule(dx, dy), base)
+
+
+def test_color_quantize_is_unchanged_by_the_fused_variant():
+    """The whole a3 stage on the reference's benchmark frame and on noise, with the oracle's fastAtan2 switched to the
+    fused form: identical quantised images (the polynomial's values differ in the last bits, the labels never)."""
+    import os
+    from oracle import oracle as orc
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "frame0.npz"))
+    rng = np.random.default_rng(7)
+    imgs = [f["bgr"], rng.integers(0, 256, (96, 160, 3), dtype=np.uint8)]
+    for img in imgs:
+        a = orc.color_quantize(img)
+        old = orc.set_atan_variant(1)
+        try:
+            b = orc.color_quantize(img)
+        finally:
+            orc.set_atan_variant(old)
+        assert np.array_equal(a, b)
