@@ -117,6 +117,10 @@ class Runner:
             det.set_tuning(lm.TUNE_LEVEL_PAIRS, 0)
         if args.blur_strip:
             det.set_tuning(lm.TUNE_BLUR_STRIP, args.blur_strip)
+        if args.sort_split >= 0:
+            det.set_tuning(lm.TUNE_SORT_SPLIT, args.sort_split)
+        if args.no_work_weight:
+            det.set_tuning(lm.TUNE_WORK_WEIGHT, 0)
         if args.no_prune:
             det.set_scan_variant(8)
         elif args.scan_variant:
@@ -264,6 +268,9 @@ class Runner:
 
     def report(self):
         prof = self.det.get_profile()
+        counts = np.array([self.det.last_counts(i) for i in range(self.B)], np.int64).reshape(-1, 2)
+        self.list_stats = {"scan_candidates_per_frame": {"mean": round(float(counts[:, 0].mean()), 1), "max": int(counts[:, 0].max())},
+                           "refined_matches_per_frame_before_unique": {"mean": round(float(counts[:, 1].mean()), 1), "max": int(counts[:, 1].max())}}
         return {"prof": prof, "scan_load_bytes": self.det.scan_load_bytes(self.cls), "Bl": self.Bl, "NL": self.NL,
                 "matches0": int(self.bufs[(self.k - 1) % NBUF][1][0]) if self.k else 0}
 
@@ -370,6 +377,8 @@ def main():
     ap.add_argument("--blur-strip", type=int, default=0, choices=(0, 16, 32, 64), help="A/B knob: rows per strip of the level-0 blur (LM_TUNE_BLUR_STRIP)")
     ap.add_argument("--no-level-pairs", action="store_true", help="A/B knob: no slot-interleaved level pairs (LM_TUNE_LEVEL_PAIRS = 0)")
     ap.add_argument("--no-blur-pyr", action="store_true", help="A/B knob: level-0 blur and pyrDown as two launches (LM_TUNE_BLUR_PYR = 0)")
+    ap.add_argument("--sort-split", type=int, default=-1, choices=(-1, 0, 1, 2), help="A/B knob: LM_TUNE_SORT_SPLIT (0 one workgroup per frame, 1 chunk workgroups + merge launch, 2 adaptive = default)")
+    ap.add_argument("--no-work-weight", action="store_true", help="A/B knob: few-frame / batch kernel selection by frame count alone (LM_TUNE_WORK_WEIGHT = 0, r03)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the h2d_inclusive (streaming) leg")
     ap.add_argument("--h2d-group", type=int, default=0,
@@ -605,6 +614,7 @@ def main():
                        "baseline_config": args.config,
                        "templates_per_gpu": runner.n_total // world, "templates_total": runner.n_total,
                        "frames_per_step": B, "lanes": NL, "frames_per_sec": round(fps, 1), "matches_frame0": n_matches0,
+                       "list_lengths": runner.list_stats,
                        "unit_definition": "one detection = one frame answered against the whole %d-template bank "
                                           "(input frames resident in HBM)" % runner.n_total,
                        "template_frames_per_sec": round(fps * runner.n_total, 1),

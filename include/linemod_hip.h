@@ -227,6 +227,14 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
 /* LM_TUNE_BLUR_STRIP (process-wide): rows per strip of the level-0 Gaussian blur inside the blur + pyrDown launch of a batch:
  *   0 = by frame shape and batch size (default: as tall as still fills the chip), 16 / 32 / 64 = forced. */
 #define LM_TUNE_BLUR_STRIP 12
+/* LM_TUNE_WORK_WEIGHT: 1 (default, r04) = the few-frame / batch kernel selection of the pre-processing (the keys above that say
+ *   "below 16 frames") counts a frame as (level-0 pixels / (640 x 480)) frames, at least one -- a call's WORK decides, so
+ *   eight 1280 x 960 frames take the batch kernels; 0 = by frame count alone (r03).  Results never depend on it. */
+#define LM_TUNE_WORK_WEIGHT 13
+/* LM_TUNE_SORT_SPLIT: the device sort (a15) of lists longer than 1024 matches 0 = one workgroup per frame (r03), 1 = four chunk
+ *   workgroups per frame + a merge launch, 2 (default) = the latter while the lists this detector collected lately were that
+ *   long.  Same lists either way. */
+#define LM_TUNE_SORT_SPLIT 14
 int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 /* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame
@@ -330,6 +338,16 @@ int lm_merge_batch(const lm_match_t* packed, size_t rank_stride, const int32_t* 
  * merges the frames it owns, so the host work of the exchange does not grow with R. */
 int lm_merge_frames(const lm_match_t* packed, size_t rank_stride, const int32_t* counts, int n_ranks, int n_frames,
                     int frame_lo, int frame_hi, lm_match_t* out, size_t cap, int32_t* out_counts, size_t* n_out);
+/* The bookkeeping of lm_match_end_gathered on its own (host-only, no GPU, no RCCL: unit-testable at any world size).  all_cnt =
+ * the all-gathered lengths, n_ranks runs of n_frames + 1 ints (per-frame record counts of the rank's packed run, then the rank's
+ * status word: bit 0 lists exceed the fixed gather capacity, bit 1 a frame left to the host sort, bit 2 shard capacity overflow).
+ * Out: OR of the status words; first rank with bit 2 (-1: none); the frames [*f0, *f1) = [n * rank / R, n * (rank + 1) / R) this
+ * rank merges; counts[r * n_frames + i]; per rank the piece (start, length in records) of its packed run that holds exactly the
+ * owned frames -- the only records lm_match_end_gathered copies to the host.  counts / piece_* may be NULL. */
+int lm_gather_plan(const int32_t* all_cnt, int n_ranks, int n_frames, int rank, int* status, int* bad_rank, int* f0, int* f1,
+                   int32_t* counts, uint64_t* piece_start, uint64_t* piece_len);
+/* Records of the largest rank's packed run (at least 1): the per-rank buffer size of the sized second exchange. */
+int lm_gather_max_total(const int32_t* counts, int n_ranks, int n_frames, uint64_t* max_total);
 
 /* Template-bank persistence (Detector::write/writeClass/read/readClass, HighLevelLinemod.cpp:260,267,294,299):
  * own compact binary format, see DESIGN.md. */

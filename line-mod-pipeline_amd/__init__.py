@@ -47,6 +47,8 @@ TUNE_BLUR_PYR = 9
 TUNE_LEVEL_PAIRS = 10
 TUNE_DMEDIAN_VARIANT = 11
 TUNE_BLUR_STRIP = 12
+TUNE_WORK_WEIGHT = 13
+TUNE_SORT_SPLIT = 14
 
 
 class Rect(C.Structure):
@@ -70,7 +72,7 @@ EXPORTS = [
     "lm_prepare_slot", "lm_debug_read", "lm_stage_scan", "lm_time_scan", "lm_time_stages", "lm_set_scan_variant",
     "lm_last_counts", "lm_set_profiling", "lm_get_profile", "lm_scan_load_bytes",
     "lm_save_yaml", "lm_load_yaml", "lm_yaml_numbers", "lm_yaml_string", "lm_pack_matches", "lm_merge_batch",
-    "lm_match_begin", "lm_match_end", "lm_synchronize", "lm_merge_frames",
+    "lm_match_begin", "lm_match_end", "lm_synchronize", "lm_merge_frames", "lm_gather_plan", "lm_gather_max_total",
     "lm_upload_frame_pinned", "lm_upload_wait", "lm_host_alloc", "lm_host_free", "lm_set_stage_chunks",
     "lm_set_tuning", "lm_comm_init", "lm_comm_destroy", "lm_comm_info", "lm_match_begin_gathered",
     "lm_match_end_gathered", "lm_comm_barrier", "lm_comm_max", "lm_upload_frames_pinned",
@@ -127,6 +129,8 @@ def load_library(path=None):
     lib.lm_pack_matches.argtypes = [vp, sz, vp, i, vp, sz, C.POINTER(sz)]
     lib.lm_merge_batch.argtypes = [vp, sz, vp, i, i, vp, sz, vp, C.POINTER(sz)]
     lib.lm_merge_frames.argtypes = [vp, sz, vp, i, i, i, i, vp, sz, vp, C.POINTER(sz)]
+    lib.lm_gather_plan.argtypes = [vp, i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i), vp, vp, vp]
+    lib.lm_gather_max_total.argtypes = [vp, i, i, C.POINTER(C.c_uint64)]
     lib.lm_merge_matches.argtypes = [vp, vp, i, sz, vp, sz, C.POINTER(sz)]
     lib.lm_save_bank.argtypes = [vp, C.c_char_p]
     lib.lm_load_bank.argtypes = [vp, C.c_char_p]
@@ -283,6 +287,29 @@ def merge_batch(packed, counts, frame_lo=0, frame_hi=None):
     if rc:
         raise LinemodError(rc, lib.lm_last_error().decode())
     return out[:n.value], oc
+
+
+def gather_plan(all_cnt, n_ranks, n_frames, rank):
+    """lm_gather_plan: the host bookkeeping of lm_match_end_gathered on the all-gathered lengths (n_ranks runs of n_frames + 1
+    int32: per-frame counts, then the rank's status word).  Returns a dict: status, bad_rank, f0, f1, counts [R, n],
+    piece_start [R], piece_len [R], max_total (records of the largest rank's run)."""
+    lib = load_library()
+    all_cnt = _c(all_cnt, np.int32)
+    if all_cnt.size != n_ranks * (n_frames + 1):
+        raise ValueError("all_cnt must hold n_ranks * (n_frames + 1) values")
+    st, bad, f0, f1 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    counts = np.zeros((n_ranks, n_frames), np.int32)
+    ps, pl = np.zeros(n_ranks, np.uint64), np.zeros(n_ranks, np.uint64)
+    rc = lib.lm_gather_plan(_ptr(all_cnt), n_ranks, n_frames, rank, C.byref(st), C.byref(bad), C.byref(f0), C.byref(f1), _ptr(counts),
+                            _ptr(ps), _ptr(pl))
+    if rc:
+        raise LinemodError(rc, lib.lm_last_error().decode())
+    mt = C.c_uint64()
+    rc = lib.lm_gather_max_total(_ptr(counts), n_ranks, n_frames, C.byref(mt))
+    if rc:
+        raise LinemodError(rc, lib.lm_last_error().decode())
+    return {"status": st.value, "bad_rank": bad.value, "f0": f0.value, "f1": f1.value, "counts": counts,
+            "piece_start": ps, "piece_len": pl, "max_total": int(mt.value)}
 
 
 def merge_matches(lists):

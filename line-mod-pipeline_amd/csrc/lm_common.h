@@ -27,6 +27,7 @@ typedef uint64_t u64;
                                 // polluted by the other half's data); two items per wave
 #define LM_SCAN_FPAD 8          // feature lists are padded to a multiple of this with zero-block offsets
 #define LM_SORT_CAP 4096        // matches sorted on the device (LDS); more are sorted by the host
+#define LM_SORT_CHUNK 1024      // split form of the device sort: keys per chunk workgroup (LM_SORT_CAP / LM_SORT_CHUNK workgroups per frame)
 #define LM_INLINE_MATCHES 2048  // records the sort kernel also writes straight into host-mapped memory
 #define LM_DROPPED 0xFFFFFFFFu
 

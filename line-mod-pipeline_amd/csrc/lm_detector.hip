@@ -133,6 +133,10 @@ struct lm_detector {
                                      // 0 never, 1 always, 2 (default) when no other lane has work in flight -- measured r03: alone on the
                                      // chip the fused launches win (config 2: 4.81 -> 4.66, config 3: 8.54 -> 8.06 us per frame), beside two
                                      // other lanes the separate launches interleave better (config 2: 145 K against 140 K detections/s)
+    int sort_split_mode = 2;         // device sort: 0 one workgroup per frame (r03), 1 always the split form (chunk workgroups + merge launch),
+                                     // 2 (default) the split form while the recently collected lists were longer than LM_SORT_CHUNK keys
+    int sort_long_score = 0;         // see note_sort_length
+    int work_weight_by_pixels = 1;   // r04: the selection below counts a frame as level-0 pixels / (640 x 480) frames (LM_TUNE_WORK_WEIGHT = 0: by frame count, r03)
     int phase_max_slots = 15;        // calls of up to this many frames run a3-a10 as one launch per dependency level (LmPhaseArgs)
     int fork_max_slots = 0;          // measured r02: no gain (host launch rate, 3.4 us per launch, bounds small calls), so off by default
     int fork_depth_wait_slot = -1;   // forked single-frame call: the depth chain's stream waits for this slot's whole upload
@@ -148,7 +152,7 @@ struct lm_detector {
     int* d_raw_thr = nullptr;
     int* h_raw_thr = nullptr;
     float raw_thr_for = -1.0f;
-    u32* d_plan = nullptr;        // k_refine_plan output, one per lane: [8][cap] slots + [8] lengths + [8][cap + 1] running sums
+    u32* d_plan = nullptr;        // k_refine_plan output, one per lane: [8][cap] slots + [8] lengths + [8][cap + 1] running sums + [8][cap] first entries
     int plan_stride_cap = 0;
     u64* d_resp_tab = nullptr;
     u32* d_sim_lut = nullptr;
@@ -258,8 +262,8 @@ int ensure_device(lm_detector* d) {
     std::memset(d->host_blocks, 0, d->host_stride * S);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_raw_thr), 128 * sizeof(int)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d->h_raw_thr), 128 * sizeof(int)));
-    d->plan_stride_cap = std::max(S / 8 * 2, 2);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_plan), LM_NLANES * (16 * (size_t)d->plan_stride_cap + 16) * sizeof(u32)));
+    d->plan_stride_cap = std::max(S / 8, 1) + 8;    // pieces per XCD list: nslots / 8 + 8 (k_refine_plan)
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_plan), LM_NLANES * (24 * (size_t)d->plan_stride_cap + 16) * sizeof(u32)));
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     // lane 1's stream right behind lane 0's: the runtime deals streams to its hardware queues in creation order, and
     // two lanes that land on one queue run strictly one after the other (measured r02: 87 K instead of 102 K det/s)
@@ -386,6 +390,13 @@ bool ensure_fork(lm_detector* d) {
     return true;
 }
 
+// How many 640 x 480 frames one frame of this detector counts as in the few-frame / batch kernel selection (at least 1).
+int slot_weight(const lm_detector* d) {
+    const long px = (long)d->lw[0] * d->lh[0];
+    const int w = d->work_weight_by_pixels ? (int)(px / (640L * 480L)) : 1;
+    return w < 1 ? 1 : w;
+}
+
 // a3-a10 on the frames resident in slots [first, first + n).
 void enqueue_preprocess(lm_detector* d, int first, int n) {
     const lm_config& c = d->cfg;
@@ -393,12 +404,17 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
     const size_t fs = d->frame_stride;
     // ---- few frames: one launch per dependency level (lm_kernels.h LmPhaseArgs): 5 launches instead of 14;
     // ---- batches: the same with the batch kernels, 4 launches instead of 11 (LM_TUNE_BATCH_PHASES)
-    const bool few = n <= d->phase_max_slots;
+    // by WORK, not by frame count (r04): a frame counts as level-0 pixels / (640 x 480) frames, so the eight 1280 x 960 frames of a
+    // config-5 lane-step (32 VGA frames' worth of pixels) take the batch kernels, not the latency path
+    const int weight = slot_weight(d);
+    struct WeightGuard { explicit WeightGuard(int w) { lmk_set_slot_weight(w); } ~WeightGuard() { lmk_set_slot_weight(1); } } weight_guard(weight);
+    const int n_eff = n * weight;
+    const bool few = n_eff <= d->phase_max_slots;
     bool others_busy = false;
     for (int o = 0; o < LM_NLANES; ++o) others_busy |= (o != d->active && d->lanes[o].busy);
     const bool fuse_batch = d->batch_phases == 1 || (d->batch_phases == 2 && !others_busy);
     const bool pairs = lmk_level_pairs() != 0;      // slot-interleaved level pairs (k_pair), beside other lanes too
-    if ((few || ((fuse_batch || pairs) && n >= 16)) && n > d->fork_max_slots && L == 2) {     // (the fork experiment, when switched on, wins)
+    if ((few || ((fuse_batch || pairs) && n_eff >= 16)) && n > d->fork_max_slots && L == 2) {     // (the fork experiment, when switched on, wins)
         LmPhaseArgs pa{};
         pa.bgr0 = d->bgr(first, 0); pa.bgr1 = d->bgr(first, 1); pa.depth = M == 2 ? d->depth(first) : nullptr;
         pa.cs0 = d->cscratch(first, 0); pa.cs1 = d->cscratch(first, 1); pa.ds = d->dscratch(first);
@@ -553,8 +569,11 @@ LmRefineArgs make_refine_args(lm_detector* d, int first, int level, float thresh
 LmSortArgs make_sort_args(lm_detector* d, int first) {
     LmSortArgs a;
     a.hdr = reinterpret_cast<LmDevHeader*>(d->aux(first, d->off_hdr));
-    a.keys = reinterpret_cast<const u64*>(d->aux(first, d->off_keys));
+    a.keys = reinterpret_cast<u64*>(d->aux(first, d->off_keys));
     a.out = reinterpret_cast<LmOutMatch*>(d->aux(first, d->off_out));
+    // split form (four chunk workgroups per frame + a merge launch) when this detector's recent lists were long enough to need it:
+    // the lists are identical either way, so the choice may follow what the last collected frames looked like
+    a.split = d->sort_split_mode == 1 || (d->sort_split_mode == 2 && d->sort_long_score > 0);
     a.aux_slot_stride = d->aux_stride;
     a.host = d->host_block(first);
     a.host_slot_stride = d->host_stride;
@@ -586,9 +605,9 @@ int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, cons
     } else {
         // 8+ slots: balance the slots over the XCDs by their candidate counts (one plan per lane)
         u32* plan = nullptr;
-        const int plan_cap = n / 8;          // every XCD gets exactly its share of slots, the heavy ones spread out
-        if ((n % 8) == 0 && n <= 1024 && d->d_plan) {
-            plan = d->d_plan + (size_t)d->active * (16 * (size_t)d->plan_stride_cap + 16);
+        const int plan_cap = n / 8 + 8;      // pieces per XCD list: its share of the slots + room for the pieces of the heavy ones
+        if ((n % 8) == 0 && n <= 1016 && plan_cap <= d->plan_stride_cap && d->d_plan) {
+            plan = d->d_plan + (size_t)d->active * (24 * (size_t)d->plan_stride_cap + 16);
             lmk_refine_plan(d->stream, make_refine_args(d, first, L - 2, threshold), n, plan, plan_cap);
         }
         for (int l = L - 2; l >= 0; --l) {
@@ -650,6 +669,13 @@ int enqueue_match(lm_detector* d, int first, int n, float threshold, int class_i
 
 inline bool key_less(const u64* a, const u64* b) { return a[0] < b[0] || (a[0] == b[0] && a[1] < b[1]); }
 
+// The device sort's split form pays for lists longer than one chunk, and a launch lasts as long as its longest list: the score says
+// whether any of the last 4096 collected frames had such a list.
+inline void note_sort_length(lm_detector* d, u32 match_count) {
+    const int is_long = match_count > LM_SORT_CHUNK && match_count <= LM_SORT_CAP;
+    d->sort_long_score = is_long ? 4096 : std::max(d->sort_long_score - 1, 0);
+}
+
 // Delivers the sorted unique matches of one slot (the stream has been synchronised).
 int collect_slot(lm_detector* d, int slot, lm_match_t* out, size_t cap, size_t* n_out) {
     const LmHostBlock* hb = d->host_block(slot);
@@ -660,6 +686,7 @@ int collect_slot(lm_detector* d, int slot, lm_match_t* out, size_t cap, size_t* 
     if (h.match_count > d->max_match)
         return fail(LM_ERR_OVERFLOW, "refinement produced " + std::to_string(h.match_count) + " matches, capacity " +
                                          std::to_string(d->max_match) + " (raise lm_config.max_matches)");
+    note_sort_length(d, h.match_count);
     size_t n = 0;
     if (h.sorted_on_device) {
         n = h.out_count;
@@ -1264,6 +1291,8 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
         case LM_TUNE_LEVEL_PAIRS: if (value < 0 || value > 1) break; lmk_set_level_pairs(value); return LM_OK;
         case LM_TUNE_BLUR_STRIP: if (value != 0 && value != 16 && value != 32 && value != 64) break; lmk_set_blur_strip(value); return LM_OK;
         case LM_TUNE_DMEDIAN_VARIANT: if (value < 0 || value > 2) break; lmk_set_dmedian_variant(value); return LM_OK;
+        case LM_TUNE_WORK_WEIGHT: if (value < 0 || value > 1) break; d->work_weight_by_pixels = value; return LM_OK;
+        case LM_TUNE_SORT_SPLIT: if (value < 0 || value > 2) break; d->sort_split_mode = value; return LM_OK;
         default: return fail(LM_ERR_INVALID, "unknown tuning key");
     }
     return fail(LM_ERR_INVALID, "tuning value out of range");
@@ -1741,32 +1770,51 @@ static int gather_fallback(lm_detector* d, int lane, int first, int n, int f0, i
     HIP_TRY(hipMemcpyAsync(g.h_all_cnt, g.d_all_cnt, R * cb, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     std::vector<int32_t> cnt(R * (size_t)n);
-    size_t max_total = 1;
-    for (size_t r = 0; r < R; ++r) {
-        const int* c = g.h_all_cnt + r * (size_t)(n + 1);
-        if (c[n]) {
+    uint64_t max_total64 = 1;
+    {
+        int st_all = 0, bad = -1, pf0 = 0, pf1 = 0;
+        const int prc = lm_gather_plan(g.h_all_cnt, (int)R, n, comm->rank, &st_all, &bad, &pf0, &pf1, cnt.data(), nullptr, nullptr);
+        if (prc) return prc;
+        if (st_all) {
             if (local_rc) return fail(local_rc, local_msg);
-            return fail(LM_ERR_OVERFLOW, "rank " + std::to_string(r) + " could not deliver its match lists");
+            return fail(LM_ERR_OVERFLOW, "rank " + std::to_string(bad) + " could not deliver its match lists");
         }
-        size_t tot = 0;
-        for (int i = 0; i < n; ++i) { cnt[r * (size_t)n + (size_t)i] = c[i]; tot += (size_t)c[i]; }
-        max_total = std::max(max_total, tot);
+        (void)lm_gather_max_total(cnt.data(), (int)R, n, &max_total64);
     }
+    const size_t max_total = (size_t)max_total64;
     // 3. records, in buffers sized to the largest rank
+    // A rank-local failure here (an allocation on a nearly full device, a failed copy) must not leave the other ranks blocked in
+    // the sized all-gather: every rank reports whether it is ready, the flags are all-gathered, and all ranks go on
+    // or give up TOGETHER.
     LmOutMatch *d_send = nullptr, *d_recv = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_send), max_total * sizeof(LmOutMatch)));
-    if (hipMalloc(reinterpret_cast<void**>(&d_recv), R * max_total * sizeof(LmOutMatch)) != hipSuccess) {
-        hipFree(d_send);
-        return fail(LM_ERR_HIP, "hipMalloc of the sized exchange buffer failed");   // (every rank allocates the same size)
-    }
-    std::vector<lm_match_t> all(R * max_total);
+    std::vector<lm_match_t> all;
+    hipError_t he = hipMalloc(reinterpret_cast<void**>(&d_send), max_total * sizeof(LmOutMatch));
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_recv), R * max_total * sizeof(LmOutMatch));
+    bool host_ok = true;
+    try { all.resize(R * max_total); } catch (const std::bad_alloc&) { host_ok = false; }
+    if (he == hipSuccess && host_ok && !mine.empty())
+        he = hipMemcpyAsync(d_send, mine.data(), mine.size() * sizeof(lm_match_t), hipMemcpyHostToDevice, st);
+    int32_t ready = (he == hipSuccess && host_ok) ? 0 : 1;
+    std::vector<int32_t> ready_all(R, 0);
     bool ok = true;
-    hipError_t he = hipSuccess;
-    if (!mine.empty()) he = hipMemcpyAsync(d_send, mine.data(), mine.size() * sizeof(lm_match_t), hipMemcpyHostToDevice, st);
-    if (he == hipSuccess) ok = comm->all_gather(d_send, d_recv, max_total * sizeof(LmOutMatch), st, err);
-    if (he == hipSuccess && ok) he = hipMemcpyAsync(all.data(), d_recv, all.size() * sizeof(lm_match_t), hipMemcpyDeviceToHost, st);
+    hipError_t fe = hipMemcpyAsync(g.d_cnt, &ready, sizeof(ready), hipMemcpyHostToDevice, st);
+    if (fe == hipSuccess) ok = comm->all_gather(g.d_cnt, g.d_all_cnt, sizeof(int32_t), st, err);
+    if (fe == hipSuccess && ok) fe = hipMemcpyAsync(ready_all.data(), g.d_all_cnt, R * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (fe == hipSuccess && ok) fe = hipStreamSynchronize(st);
+    int not_ready = -1;
+    for (size_t r = 0; r < R; ++r) if (ready_all[r] && not_ready < 0) not_ready = (int)r;
+    if (!ok || fe != hipSuccess || not_ready >= 0) {
+        (void)hipFree(d_send); (void)hipFree(d_recv);
+        if (!ok) return fail(LM_ERR_HIP, err);
+        if (fe != hipSuccess) return fail(LM_ERR_HIP, std::string("sized exchange (readiness): ") + hipGetErrorString(fe));
+        if (he != hipSuccess) return fail(LM_ERR_HIP, std::string("sized exchange buffers: ") + hipGetErrorString(he));
+        if (!host_ok) return fail(LM_ERR_HIP, "sized exchange: host buffer allocation failed");
+        return fail(LM_ERR_HIP, "rank " + std::to_string(not_ready) + " could not set up the sized exchange; all ranks gave up together");
+    }
+    ok = comm->all_gather(d_send, d_recv, max_total * sizeof(LmOutMatch), st, err);
+    if (ok) he = hipMemcpyAsync(all.data(), d_recv, all.size() * sizeof(lm_match_t), hipMemcpyDeviceToHost, st);
     if (he == hipSuccess && ok) he = hipStreamSynchronize(st);
-    hipFree(d_send); hipFree(d_recv);
+    (void)hipFree(d_send); (void)hipFree(d_recv);
     if (!ok) return fail(LM_ERR_HIP, err);
     if (he != hipSuccess) return fail(LM_ERR_HIP, std::string("sized exchange: ") + hipGetErrorString(he));
     // 4. merge the frames this rank owns
@@ -1791,17 +1839,15 @@ int lm_match_end_gathered(lm_detector* d, int lane, lm_match_t* out, size_t cap,
     const int f0 = (int)((long long)n * rank / R), f1 = (int)((long long)n * (rank + 1) / R);
     if (first_frame) *first_frame = f0;
     if (n_frames) *n_frames = f1 - f0;
+    for (int i = 0; i < n; ++i) note_sort_length(d, d->host_block(ln.first + i)->hdr.match_count);
     // The status words every rank gathered are identical on all ranks, so all ranks take the same branch below (the
-    // fallback holds collectives).  bit 0: a rank's lists did not fit the fixed gather capacity; bit 1: a frame of a
-    // rank has more than LM_SORT_CAP matches (left to the host sort); bit 2: a rank overflowed its own candidate /
-    // match capacity (the single-GPU path fails on that too).
-    int status = 0, bad_rank = -1;
+    // fallback holds collectives): lm_gather_plan (lm_host.cpp, host-only and unit-tested at R = 2, 3, 8) reads them.
+    int status = 0, bad_rank = -1, pf0 = 0, pf1 = 0;
     std::vector<int32_t> cnt((size_t)R * n);
-    for (int r = 0; r < R; ++r) {
-        const int* c = g.h_all_cnt + (size_t)r * (n + 1);
-        status |= c[n];
-        if ((c[n] & 4) && bad_rank < 0) bad_rank = r;
-        std::memcpy(&cnt[(size_t)r * n], c, (size_t)n * sizeof(int32_t));
+    std::vector<uint64_t> piece_start((size_t)R), piece_len((size_t)R);
+    {
+        const int prc = lm_gather_plan(g.h_all_cnt, R, n, rank, &status, &bad_rank, &pf0, &pf1, cnt.data(), piece_start.data(), piece_len.data());
+        if (prc) return prc;
     }
     if (status & 4) {
         if (bad_rank == rank)      // this shard's own capacity overflow: same message as the ungathered path
@@ -1816,8 +1862,7 @@ int lm_match_end_gathered(lm_detector* d, int lane, lm_match_t* out, size_t cap,
         activate_lane(d, lane);
         int crc = LM_OK;
         for (int r = 0; r < R && !crc; ++r) {
-            size_t start = 0, len = 0;
-            for (int i = 0; i < f1; ++i) (i < f0 ? start : len) += (size_t)cnt[(size_t)r * n + i];
+            const size_t start = (size_t)piece_start[(size_t)r], len = (size_t)piece_len[(size_t)r];
             if (start + len > (size_t)g.cap_lane) { crc = fail(LM_ERR_INVALID, "gathered counts exceed the gather capacity"); break; }
             if (!len) continue;
             const size_t at = (size_t)r * g.cap_lane + start;
@@ -1831,6 +1876,55 @@ int lm_match_end_gathered(lm_detector* d, int lane, lm_match_t* out, size_t cap,
     }
     d->prof_exch_fallbacks += 1;
     return gather_fallback(d, lane, ln.first, n, f0, f1, out, cap, counts, n_out);
+}
+
+// 8e bookkeeping of the gathered path, host-only (lm_match_end_gathered and its sized fallback call it; tests/test_dist.py drives
+// it at R = 2, 3, 8 on synthetic gathered buffers).  all_cnt: what the all-gather of the lengths delivers, R runs of n + 1 ints
+// -- cnt[i] = records of frame i in that rank's packed run, [n] = the rank's status word (bit 0 lists did not fit the fixed
+// capacity, bit 1 a frame was left to the host sort, bit 2 the shard overflowed its own capacity).  Out: the OR of the status
+// words, the first rank with bit 2 set (or -1), the frames [f0, f1) rank `rank` merges, counts as [R][n], and per rank the
+// piece of its packed run that holds exactly the owned frames (start, len in records; frames are packed in order).
+int lm_gather_plan(const int32_t* all_cnt, int n_ranks, int n_frames, int rank, int* status, int* bad_rank, int* f0, int* f1,
+                   int32_t* counts, uint64_t* piece_start, uint64_t* piece_len) {
+    if (!all_cnt || n_ranks < 1 || n_frames < 0 || rank < 0 || rank >= n_ranks) return fail(LM_ERR_INVALID, "bad argument");
+    const int n = n_frames, R = n_ranks;
+    const int lo = (int)((long long)n * rank / R), hi = (int)((long long)n * (rank + 1) / R);
+    int st = 0, bad = -1;
+    for (int r = 0; r < R; ++r) {
+        const int32_t* c = all_cnt + (size_t)r * (size_t)(n + 1);
+        st |= c[n];
+        if ((c[n] & 4) && bad < 0) bad = r;
+        uint64_t start = 0, len = 0;
+        for (int i = 0; i < n; ++i) {
+            if (c[i] < 0) return fail(LM_ERR_INVALID, "negative count in the gathered lengths");
+            if (counts) counts[(size_t)r * n + i] = c[i];
+            if (i < lo) start += (uint64_t)c[i];
+            else if (i < hi) len += (uint64_t)c[i];
+        }
+        if (piece_start) piece_start[r] = start;
+        if (piece_len) piece_len[r] = len;
+    }
+    if (status) *status = st;
+    if (bad_rank) *bad_rank = bad;
+    if (f0) *f0 = lo;
+    if (f1) *f1 = hi;
+    return LM_OK;
+}
+
+// Records of the largest rank's packed run (at least 1): the per-rank buffer size of the sized second exchange.
+int lm_gather_max_total(const int32_t* counts, int n_ranks, int n_frames, uint64_t* max_total) {
+    if (!counts || !max_total || n_ranks < 1 || n_frames < 0) return fail(LM_ERR_INVALID, "bad argument");
+    uint64_t best = 1;
+    for (int r = 0; r < n_ranks; ++r) {
+        uint64_t tot = 0;
+        for (int i = 0; i < n_frames; ++i) {
+            if (counts[(size_t)r * n_frames + i] < 0) return fail(LM_ERR_INVALID, "negative count");
+            tot += (uint64_t)counts[(size_t)r * n_frames + i];
+        }
+        best = std::max(best, tot);
+    }
+    *max_total = best;
+    return LM_OK;
 }
 
 int lm_merge_matches(const lm_match_t* lists, const int32_t* counts, int n_lists, size_t stride, lm_match_t* out,

@@ -24,6 +24,7 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
 // the two kernels itself).
 bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0, u8* bgr1, u8* quant0, size_t slot_stride, int nslots);
 void lmk_set_blur_pyr(int v);
+void lmk_set_slot_weight(int w);   // frames count `w` times in the few-frame / batch kernel selection of this host thread's launches (1 = 640 x 480 frames)
 void lmk_set_blur_strip(int v);
 // a5: DepthNormal quantisation (normals + LUT + 5x5 median)
 // scratch: w*h bytes per slot (rank codes between the two streaming passes), nullptr or a NORMAL_LUT that is
@@ -95,14 +96,16 @@ void lmk_emit_unrefined(hipStream_t s, const LmRefineArgs& a, int nslots);
 
 struct LmSortArgs {
     LmDevHeader* hdr;
-    const u64* keys;
+    u64* keys;               // (hi, lo) per match; the split form sorts chunks of LM_SORT_CHUNK in place
     LmOutMatch* out;         // [LM_SORT_CAP] per slot
     size_t aux_slot_stride;
     LmHostBlock* host;       // host-mapped, slot 0
     size_t host_slot_stride;
     u32 cand_cap, match_cap;
+    int split;               // 1: lists longer than LM_SORT_CHUNK keys are sorted as chunks by LM_SORT_CAP / LM_SORT_CHUNK workgroups per
+                             // slot and merged by a second launch (k_merge_unique); same lists either way
 };
-// a15: sort + adjacent-unique of up to LM_SORT_CAP keys, one workgroup per slot.
+// a15: sort + adjacent-unique of up to LM_SORT_CAP keys, one workgroup per slot (split: four + one).
 void lmk_sort_unique(hipStream_t s, const LmSortArgs& a, int nslots);
 
 struct LmPackArgs {

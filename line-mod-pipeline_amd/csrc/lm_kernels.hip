@@ -2575,36 +2575,68 @@ __device__ __forceinline__ void emit_key(const LmRefineArgs& a, LmDevHeader* hdr
     }
 }
 
-// Slot -> XCD plan for k_refine.  Every slot must stay on ONE XCD (its spread memories live in that L2), but the
-// candidate counts differ a lot between frames (30 .. 1500), and the launch lasts as long as its busiest XCD
+// Slot -> XCD plan for k_refine.  A slot's candidates should stay on ONE XCD (its spread memories live in that L2), but the
+// candidate counts differ a lot between frames (30 .. 2700), and the launch lasts as long as its busiest XCD
 // (fixed round-robin: max / mean = 1.35 on the bench workload).  One workgroup ranks the slots by candidate
-// count (rank sort in LDS) and deals them, heaviest first, to the least loaded of the eight XCD lists (cap = nslots / 8
-// slots each).  The dealing is sequential by nature; it runs on eight lanes of one wave, lane x holding list x's load
+// count (rank sort in LDS) and deals them, heaviest first, to the least loaded of the eight XCD lists.
+// r04: the unit that is dealt is a PIECE of a slot's list.  A slot whose list is longer than 1 / 24 of all candidates of the
+// launch is cut into pieces of that size (even, so that list neighbours stay pairs), which go to different XCDs: with few
+// frames per launch (config 5: eight, one of them holding 62 % of the candidates) the heaviest slot no longer runs on 1 / 8 of
+// the chip while the rest idles; with many frames (config 2: 96) at most the one or two heaviest slots are cut.  At most
+// nslots + 24 pieces, cap = nslots / 8 + 8 per list.
+// The dealing is sequential by nature; it runs on eight lanes of one wave, lane x holding list x's load
 // and length, the least loaded list found by a three-step butterfly minimum over (load, list) keys -- about 6 us
 // instead of the 30 us of round 1's single thread, which sat on the critical path of every lane-step.  (Dealing in snake
 // order of the rank is fully parallel but balances the skewed counts worse: k_refine 254 instead of 215 us.)
-// plan layout: [8][cap] slot numbers, [8] list lengths, [8][cap + 1] running sums of the candidate counts along every list.
+// plan layout: [8][cap] slot numbers, [8] list lengths, [8][cap + 1] running sums of the piece lengths along every list,
+// [8][cap] first list entry of every piece.
+#define RP_MAXP 1056   // pieces: nslots (<= 1016) + 24, rounded up
 __global__ __launch_bounds__(1024) void k_refine_plan(const LmDevHeader* __restrict__ hdr0, size_t aux_slot_stride,
                                                        int nslots, u32 cand_cap, int cap, u32* __restrict__ plan) {
-    __shared__ u32 cnt[1024];
-    __shared__ u32 sorted_cnt[1024], sorted_slot[1024];
-    __shared__ u32 pl[2 * 1024 + 16 + 8];   // [8][cap] slots | [8] lengths | [8][cap + 1] running sums, cap <= 128
-    const int tid = threadIdx.x;
+    __shared__ u32 cnt[RP_MAXP], pslot[RP_MAXP], poff[RP_MAXP];        // pieces: length, slot, first entry
+    __shared__ u32 sorted_cnt[RP_MAXP], sorted_piece[RP_MAXP];
+    __shared__ u32 pl[8 * 136 * 3 + 16 + 8];   // [8][cap] slots | [8] lengths | [8][cap + 1] running sums | [8][cap] first entries, cap <= 136
+    __shared__ u32 wsum[16], wbase[17];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     u32 c = 0;
     if (tid < nslots) {
         c = slot_ptr_s(hdr0, aux_slot_stride, (u32)tid)->cand_count;
         if (c > cand_cap) c = cand_cap;
-        cnt[tid] = c;
     }
+    // all candidates of the launch -> piece size
+    u32 t = c;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) t += (u32)__shfl_xor((int)t, o, 64);
+    if (lane == 0) wsum[wv] = t;
     __syncthreads();
-    if (tid < nslots) {
+    u32 total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) total += wsum[k];
+    const u32 P = max(64u, ((total + 23u) / 24u + 1u) & ~1u);
+    const u32 np = tid < nslots ? max(1u, (c + P - 1u) / P) : 0u;         // pieces of this slot (an empty list is one empty piece)
+    // exclusive scan of np over the workgroup: where this slot's pieces go
+    u32 inc = np;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 v = (u32)__shfl_up((int)inc, o, 64); if (lane >= o) inc += v; }
+    __syncthreads();
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    if (tid == 0) { u32 acc = 0; for (int k = 0; k < 16; ++k) { wbase[k] = acc; acc += wsum[k]; } wbase[16] = acc; }
+    __syncthreads();
+    const u32 NP = wbase[16];
+    const u32 pbase = wbase[wv] + inc - np;
+    for (u32 k = 0; k < np; ++k) { cnt[pbase + k] = min(P, c - k * P); pslot[pbase + k] = (u32)tid; poff[pbase + k] = k * P; }
+    if (np == 1 && c == 0) cnt[pbase] = 0;
+    __syncthreads();
+    for (u32 e = (u32)tid; e < NP; e += 1024u) {
+        const u32 ce = cnt[e];
         u32 rank = 0;
 #pragma unroll 8
-        for (int j = 0; j < nslots; ++j) {
+        for (u32 j = 0; j < NP; ++j) {
             const u32 cj = cnt[j];
-            rank += (cj > c || (cj == c && j < tid)) ? 1u : 0u;
+            rank += (cj > ce || (cj == ce && j < e)) ? 1u : 0u;
         }
-        sorted_cnt[rank] = c; sorted_slot[rank] = (u32)tid;
+        sorted_cnt[rank] = ce; sorted_piece[rank] = e;
     }
     __syncthreads();
     if (tid < 64) {   // one wave; lanes 8.. mirror lanes 0..7 (x = lane & 7) so that the butterfly needs no masking
@@ -2614,38 +2646,46 @@ __global__ __launch_bounds__(1024) void k_refine_plan(const LmDevHeader* __restr
         // v_readlane instead of waiting for LDS, and the minimum goes through DPP, not through the LDS crossbar
         u32 rc[2], rs[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { rc[q] = sorted_cnt[(tid + 64 * q) & 1023]; rs[q] = sorted_slot[(tid + 64 * q) & 1023]; }
-        for (int r = 0; r < nslots; ++r) {
+        for (int q = 0; q < 2; ++q) { rc[q] = sorted_cnt[(tid + 64 * q) % RP_MAXP]; rs[q] = sorted_piece[(tid + 64 * q) % RP_MAXP]; }
+        for (u32 r = 0; r < NP; ++r) {
             u32 sc, ss;
             if (r < 128) {
-                const int src = r & 63;
+                const int src = (int)(r & 63u);
                 sc = (u32)__builtin_amdgcn_readlane((int)(r < 64 ? rc[0] : rc[1]), src);
                 ss = (u32)__builtin_amdgcn_readlane((int)(r < 64 ? rs[0] : rs[1]), src);
             } else {
-                sc = sorted_cnt[r]; ss = sorted_slot[r];
+                sc = sorted_cnt[r]; ss = sorted_piece[r];
             }
             u32 key = (int)len < cap ? ((load << 3) | x) : 0xFFFFFFFFu;      // loads stay below 2^29
             key = min(key, (u32)__builtin_amdgcn_mov_dpp((int)key, 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
             key = min(key, (u32)__builtin_amdgcn_mov_dpp((int)key, 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
             key = min(key, (u32)__builtin_amdgcn_mov_dpp((int)key, 0x141, 0xf, 0xf, true));   // row_half_mirror: lane i <-> 7 - i
             if ((key & 7u) == x) {
-                if (tid < 8) pl[x * cap + len] = ss;
-                len += 1; load += sc + 8u;                                   // + a little per slot
+                if (tid < 8) pl[x * cap + len] = ss;      // (the piece; turned into slot + first entry below)
+                len += 1; load += sc + 8u;                                   // + a little per piece
             }
         }
         if (tid < 8) pl[8 * cap + x] = len;
     }
     __syncthreads();
-    // running sums of the candidate counts along every XCD's list (k_refine's queue): [8][cap + 1] behind the lengths
+    // running sums of the piece lengths along every XCD's list (k_refine's queue): [8][cap + 1] behind the lengths; then the
+    // pieces' first entries, and the piece numbers replaced by their slots
     if (tid < 8) {
         u32 acc = 0;
         u32* pre = pl + 8 * cap + 8 + tid * (cap + 1);
+        u32* off = pl + 8 * cap + 8 + 8 * (cap + 1) + tid * cap;
         const u32 n = pl[8 * cap + tid];
-        for (u32 k = 0; k < n; ++k) { pre[k] = acc; acc += cnt[pl[tid * cap + k]]; }
+        for (u32 k = 0; k < n; ++k) {
+            const u32 pc = pl[tid * cap + k];
+            pre[k] = acc; acc += cnt[pc];
+            off[k] = poff[pc];
+            pl[tid * cap + k] = pslot[pc];
+        }
         for (u32 k = n; k <= (u32)cap; ++k) pre[k] = acc;
+        for (u32 k = n; k < (u32)cap; ++k) off[k] = 0;
     }
     __syncthreads();
-    for (int i = tid; i < 8 * cap + 8 + 8 * (cap + 1); i += 1024) plan[i] = pl[i];
+    for (int i = tid; i < 8 * cap + 8 + 8 * (cap + 1) + 8 * cap; i += 1024) plan[i] = pl[i];
 }
 
 #define PRUNE_REFINE true
@@ -2896,7 +2936,7 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
     __shared__ u8 resp[8][256];
     const int lane = threadIdx.x & 63;
     u32 slot = 0, tile = 0, total = 0;
-    const u32* xs = nullptr; const u32* xpre = nullptr;
+    const u32* xs = nullptr; const u32* xpre = nullptr; const u32* xoff = nullptr;
     u32 xlen = 0;
     if (a.plan) {   // block b runs on XCD b % 8 (see xcd_slot_tile)
         const u32 x = blockIdx.x & 7u;
@@ -2904,6 +2944,7 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
         xs = a.plan + (size_t)x * a.plan_cap;
         xlen = a.plan[(size_t)8 * a.plan_cap + x];
         xpre = a.plan + (size_t)8 * a.plan_cap + 8 + (size_t)x * (a.plan_cap + 1);
+        xoff = a.plan + (size_t)8 * a.plan_cap + 8 + (size_t)8 * (a.plan_cap + 1) + (size_t)x * a.plan_cap;     // first list entry of every piece
         total = xpre[xlen];
         if (tile * 8u >= total) return;
     } else {
@@ -2929,7 +2970,7 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
         u32 idx = 0;
         for (u32 g = 2u * wave0; g < total; g += 2u * nwaves) {
             while (idx + 1 < xlen && xpre[idx + 1] <= g) ++idx;      // g only grows: the list position moves forward
-            const u32 i = g - xpre[idx];
+            const u32 i = g - xpre[idx] + xoff[idx];
             if (g + 1 < xpre[idx + 1]) {
                 refine_pair<LAST, W4>(a, xs[idx], i, resp, lane);
             } else {
@@ -2937,7 +2978,7 @@ __global__ __launch_bounds__(256) void k_refine(LmRefineArgs a) {
                 if (g + 1 < total) {                                  // the second entry opens the next slot's list
                     u32 idx2 = idx;
                     while (idx2 + 1 < xlen && xpre[idx2 + 1] <= g + 1) ++idx2;
-                    refine_one<LAST, W4>(a, xs[idx2], g + 1 - xpre[idx2], resp, lane);
+                    refine_one<LAST, W4>(a, xs[idx2], g + 1 - xpre[idx2] + xoff[idx2], resp, lane);
                 }
             }
         }
@@ -2972,22 +3013,107 @@ __global__ __launch_bounds__(256) void k_emit_unrefined(LmRefineArgs a) {
 // The kernel also publishes the header to host-mapped memory together with the first
 // LM_INLINE_MATCHES records and re-arms the device counters for the next frame.
 // ------------------------------------------------------------------------------------------------
+// bitonic network over hi[0, N) / lo[0, N) in LDS, N a power of two, 1024 threads.  A wave's 64 pair-threads touch only "their"
+// 128 consecutive elements while j <= 64, and a wave's LDS operations execute in order: those stages need no workgroup
+// barrier, only the stages with j > 64 do (10 of the 66 stages of a 2048-element sort).
+__device__ __forceinline__ void sort_bitonic_lds(u64* hi, u64* lo, u32 N, int tid) {
+    bool local_pending = false;   // stages since the last barrier were wave-local
+    for (u32 k = 2; k <= N; k <<= 1)
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            if (j > 64 && local_pending) { __syncthreads(); local_pending = false; }
+            for (u32 t = tid; t < (N >> 1); t += 1024) {
+                u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
+                u32 p = i | j;
+                bool up = (i & k) == 0;
+                u64 ah = hi[i], al = lo[i], bh = hi[p], bl = lo[p];
+                bool gt = ah > bh || (ah == bh && al > bl);
+                if (gt == up) { hi[i] = bh; lo[i] = bl; hi[p] = ah; lo[p] = al; }
+            }
+            if (j > 64) __syncthreads();
+            else { __builtin_amdgcn_wave_barrier(); local_pending = true; }
+        }
+    __syncthreads();
+}
+
+// adjacent-unique + compaction of the sorted keys hi / lo [0, n) in LDS (block-wide exclusive scan of keep flags, chunks of 1024),
+// records to `out` and the first LM_INLINE_MATCHES to the host-mapped block, header published, list length left for k_pack_lists
+__device__ __forceinline__ void sort_unique_publish(const u64* hi, const u64* lo, u32 n, u32* wave_tot, LmDevHeader* hdr, LmOutMatch* out,
+                                                    LmHostBlock* hb, u32 cand_count, u32 match_count, int tid) {
+    u32 base = 0;
+    for (u32 c0 = 0; c0 < n; c0 += 1024) {
+        u32 i = c0 + tid;
+        u32 keep = 0;
+        if (i < n) keep = (i == 0) || !(lo[i] == lo[i - 1] && (hi[i] >> 32) == (hi[i - 1] >> 32));
+        unsigned long long bal = __ballot(keep);
+        int lane = tid & 63, wv = tid >> 6;
+        u32 pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wv] = __popcll(bal);
+        __syncthreads();
+        u32 woff = 0, tot = 0;
+        for (int k = 0; k < 16; ++k) { u32 t = wave_tot[k]; if (k < wv) woff += t; tot += t; }
+        if (keep) {
+            u64 h = hi[i], l = lo[i];
+            LmOutMatch m;
+            m.similarity = __uint_as_float(~(u32)(h >> 32));
+            m.template_id = (int)(u32)h;
+            m.class_idx = (int)(l >> 48);
+            m.y = (int)((l >> 24) & 0xFFFFFFu) - 0x800000;
+            m.x = (int)(l & 0xFFFFFFu) - 0x800000;
+            u32 pos = base + woff + pre;
+            out[pos] = m;
+            if (pos < LM_INLINE_MATCHES) hb->rec[pos] = m;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        hb->hdr.cand_count = cand_count; hb->hdr.match_count = match_count;
+        hb->hdr.out_count = base; hb->hdr.sorted_on_device = 1;
+        hdr->pad[0] = base;              // length of the sorted list in `out` (k_pack_lists)
+    }
+}
+
+// Split form (r04, a.split != 0): a list longer than LM_SORT_CHUNK keys is sorted as chunks of LM_SORT_CHUNK by the
+// workgroups blockIdx.y = 0 .. LM_SORT_CAP / LM_SORT_CHUNK - 1 of its frame (in place, in `keys`), and k_merge_unique -- the next
+// launch -- ranks every key against the other chunks by binary search, which replaces the last (and longest) phases of the
+// network and spreads the rest over four CUs per frame: a lane-step of few frames (config 5: 8) otherwise sorts on 8 of 256
+// CUs.  Lists of up to LM_SORT_CHUNK keys, overflowed ones and those left to the host are finished here by workgroup 0 as in
+// the plain form, and k_merge_unique leaves them alone (it finds the counters re-armed).
 __global__ __launch_bounds__(1024) void k_sort_unique(LmSortArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u64* hi = reinterpret_cast<u64*>(smem);
     u64* lo = hi + LM_SORT_CAP;
     __shared__ u32 wave_tot[16];
     LmDevHeader* hdr = slot_ptr(a.hdr, a.aux_slot_stride);
-    const u64* keys = slot_ptr(a.keys, a.aux_slot_stride);
+    u64* keys = slot_ptr(a.keys, a.aux_slot_stride);
     LmOutMatch* out = slot_ptr(a.out, a.aux_slot_stride);
     LmHostBlock* hb = reinterpret_cast<LmHostBlock*>(reinterpret_cast<u8*>(a.host) + (size_t)blockIdx.z * a.host_slot_stride);
     const int tid = threadIdx.x;
+    const u32 chunk = blockIdx.y;
     const u32 cand_count = hdr->cand_count, match_count = hdr->match_count;
     u32 n = match_count;
     if (n > a.match_cap) n = a.match_cap;
     __syncthreads();  // everyone has read the counters
+    const bool unsortable = n > LM_SORT_CAP || cand_count > a.cand_cap || match_count > a.match_cap;
+    if (a.split && !unsortable && n > LM_SORT_CHUNK) {
+        // this workgroup's chunk, sorted in place; counters stay armed for k_merge_unique
+        const u32 c0 = chunk * LM_SORT_CHUNK;
+        if (c0 >= n) return;
+        const u32 cnt = min(n - c0, (u32)LM_SORT_CHUNK);
+        u32 N = 64;
+        while (N < cnt) N <<= 1;
+        for (u32 i = tid; i < N; i += 1024) {
+            hi[i] = i < cnt ? keys[2 * (size_t)(c0 + i)] : ~0ull;
+            lo[i] = i < cnt ? keys[2 * (size_t)(c0 + i) + 1] : ~0ull;
+        }
+        __syncthreads();
+        sort_bitonic_lds(hi, lo, N, tid);
+        for (u32 i = tid; i < cnt; i += 1024) { keys[2 * (size_t)(c0 + i)] = hi[i]; keys[2 * (size_t)(c0 + i) + 1] = lo[i]; }
+        return;
+    }
+    if (chunk != 0) return;
     if (tid == 0) { hdr->cand_count = 0; hdr->match_count = 0; }
-    if (n > LM_SORT_CAP || cand_count > a.cand_cap || match_count > a.match_cap) {
+    if (unsortable) {
         if (tid == 0) {
             hb->hdr.cand_count = cand_count; hb->hdr.match_count = match_count;
             hb->hdr.out_count = 0; hb->hdr.sorted_on_device = 0;
@@ -3037,59 +3163,67 @@ __global__ __launch_bounds__(1024) void k_sort_unique(LmSortArgs a) {
             lo[i] = i < n ? keys[2 * (size_t)i + 1] : ~0ull;
         }
         __syncthreads();
-        // A wave's 64 pair-threads touch only "their" 128 consecutive elements while j <= 64, and a wave's LDS
-        // operations execute in order: those stages need no workgroup barrier, only the stages with j > 64 do
-        // (10 of the 66 stages of a 2048-element sort).
-        bool local_pending = false;   // stages since the last barrier were wave-local
-        for (u32 k = 2; k <= N; k <<= 1)
-            for (u32 j = k >> 1; j > 0; j >>= 1) {
-                if (j > 64 && local_pending) { __syncthreads(); local_pending = false; }
-                for (u32 t = tid; t < (N >> 1); t += 1024) {
-                    u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
-                    u32 p = i | j;
-                    bool up = (i & k) == 0;
-                    u64 ah = hi[i], al = lo[i], bh = hi[p], bl = lo[p];
-                    bool gt = ah > bh || (ah == bh && al > bl);
-                    if (gt == up) { hi[i] = bh; lo[i] = bl; hi[p] = ah; lo[p] = al; }
+        sort_bitonic_lds(hi, lo, N, tid);
+    }
+    sort_unique_publish(hi, lo, n, wave_tot, hdr, out, hb, cand_count, match_count, tid);
+}
+
+// Second launch of the split form: one workgroup per frame.  The frame's chunks (sorted by k_sort_unique) come into LDS, every key
+// finds its place in the whole list -- own index in its chunk + the number of keys of every other chunk that go before it (keys
+// of an earlier chunk win ties: the ranks are a permutation) -- the keys are scattered to their ranks, then the same unique +
+// compaction + publication as the plain form.  Frames k_sort_unique finished itself show up here with their counters re-armed.
+__global__ __launch_bounds__(1024) void k_merge_unique(LmSortArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u64* hi = reinterpret_cast<u64*>(smem);
+    u64* lo = hi + LM_SORT_CAP;
+    __shared__ u32 wave_tot[16];
+    LmDevHeader* hdr = slot_ptr(a.hdr, a.aux_slot_stride);
+    const u64* keys = slot_ptr(a.keys, a.aux_slot_stride);
+    LmOutMatch* out = slot_ptr(a.out, a.aux_slot_stride);
+    LmHostBlock* hb = reinterpret_cast<LmHostBlock*>(reinterpret_cast<u8*>(a.host) + (size_t)blockIdx.z * a.host_slot_stride);
+    const int tid = threadIdx.x;
+    const u32 cand_count = hdr->cand_count, match_count = hdr->match_count;
+    const u32 n = match_count;
+    __syncthreads();  // everyone has read the counters
+    if (n <= LM_SORT_CHUNK || n > LM_SORT_CAP || cand_count > a.cand_cap || match_count > a.match_cap) return;   // finished by k_sort_unique
+    if (tid == 0) { hdr->cand_count = 0; hdr->match_count = 0; }
+    for (u32 i = tid; i < n; i += 1024) { hi[i] = keys[2 * (size_t)i]; lo[i] = keys[2 * (size_t)i + 1]; }
+    __syncthreads();
+    constexpr int PER = LM_SORT_CAP / 1024;
+    u64 eh[PER], el[PER];
+    u32 rank[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const u32 i = (u32)tid + 1024u * (u32)k;
+        rank[k] = 0xFFFFFFFFu;
+        if (i >= n) continue;
+        eh[k] = hi[i]; el[k] = lo[i];
+        const u32 c = i / LM_SORT_CHUNK;
+        u32 r = i - c * LM_SORT_CHUNK;
+        for (u32 b = 0; b < n; b += LM_SORT_CHUNK) {
+            if (b == c * LM_SORT_CHUNK) continue;
+            const u32 len = min(n - b, (u32)LM_SORT_CHUNK);
+            const bool earlier = b < c * LM_SORT_CHUNK;      // its equal keys go before this one
+            u32 pos = 0;                                       // keys of the chunk that go before (eh, el)
+#pragma unroll
+            for (u32 step = LM_SORT_CHUNK; step >= 1; step >>= 1) {
+                const u32 q = pos + step;
+                if (q <= len) {
+                    const u64 h = hi[b + q - 1], l = lo[b + q - 1];
+                    const bool before = h < eh[k] || (h == eh[k] && (earlier ? l <= el[k] : l < el[k]));
+                    pos = before ? q : pos;
                 }
-                if (j > 64) __syncthreads();
-                else { __builtin_amdgcn_wave_barrier(); local_pending = true; }
             }
-        __syncthreads();
-    }
-    // adjacent-unique + compaction (block-wide exclusive scan of keep flags, chunks of 1024)
-    u32 base = 0;
-    for (u32 c0 = 0; c0 < n; c0 += 1024) {
-        u32 i = c0 + tid;
-        u32 keep = 0;
-        if (i < n) keep = (i == 0) || !(lo[i] == lo[i - 1] && (hi[i] >> 32) == (hi[i - 1] >> 32));
-        unsigned long long bal = __ballot(keep);
-        int lane = tid & 63, wv = tid >> 6;
-        u32 pre = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[wv] = __popcll(bal);
-        __syncthreads();
-        u32 woff = 0, tot = 0;
-        for (int k = 0; k < 16; ++k) { u32 t = wave_tot[k]; if (k < wv) woff += t; tot += t; }
-        if (keep) {
-            u64 h = hi[i], l = lo[i];
-            LmOutMatch m;
-            m.similarity = __uint_as_float(~(u32)(h >> 32));
-            m.template_id = (int)(u32)h;
-            m.class_idx = (int)(l >> 48);
-            m.y = (int)((l >> 24) & 0xFFFFFFu) - 0x800000;
-            m.x = (int)(l & 0xFFFFFFu) - 0x800000;
-            u32 pos = base + woff + pre;
-            out[pos] = m;
-            if (pos < LM_INLINE_MATCHES) hb->rec[pos] = m;
+            r += pos;
         }
-        base += tot;
-        __syncthreads();
+        rank[k] = r;
     }
-    if (tid == 0) {
-        hb->hdr.cand_count = cand_count; hb->hdr.match_count = match_count;
-        hb->hdr.out_count = base; hb->hdr.sorted_on_device = 1;
-        hdr->pad[0] = base;              // length of the sorted list in `out` (k_pack_lists)
-    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (rank[k] != 0xFFFFFFFFu) { hi[rank[k]] = eh[k]; lo[rank[k]] = el[k]; }
+    __syncthreads();
+    sort_unique_publish(hi, lo, n, wave_tot, hdr, out, hb, cand_count, match_count, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3266,11 +3400,18 @@ __global__ void k_nn_half(const u8* __restrict__ src0, int sp, u8* __restrict__ 
 // ================================================================================================
 // launchers
 // ================================================================================================
+// Kernel selection is by WORK, not by frame count (r04): the few-frame kernels (many short waves, finish sooner) and
+// the batch kernels (row-walking, fewer instructions per pixel) were tuned on 640 x 480 frames, where the break-even is 16 frames.
+// A call's frames count `weight` times, weight = level-0 pixels / (640 x 480) rounded down, at least 1: eight 1280 x 960 frames
+// (config 5) carry the pixels of 32 VGA frames and take the batch kernels.  Set per host thread around a call's launches.
+static thread_local int g_slot_weight = 1;
+void lmk_set_slot_weight(int w) { g_slot_weight = w < 1 ? 1 : w; }
+static inline int sel_slots(int nslots) { return nslots * g_slot_weight; }
 static int g_pyrdown_variant = 0;   // 0: by batch size (k_pyrdown8 below 16 frames, the row-walking k_pyrdown16 from there), 1: k_pyrdown8, 2: k_pyrdown16
 void lmk_set_pyrdown_variant(int v) { g_pyrdown_variant = v; }
 void lmk_pyrdown(hipStream_t s, const u8* src, int sw, int sh, u8* dst, size_t slot_stride, int nslots) {
     int dw = sw / 2, dh = sh / 2;
-    if (g_pyrdown_variant != 1 && (g_pyrdown_variant == 2 || nslots >= 16) && (sw % 16) == 0 && (sh % 2) == 0 && sh >= 4 &&
+    if (g_pyrdown_variant != 1 && (g_pyrdown_variant == 2 || sel_slots(nslots) >= 16) && (sw % 16) == 0 && (sh % 2) == 0 && sh >= 4 &&
         ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0 && (slot_stride % 16) == 0) {
         const int n_w = (((sw / 16) * ((dh + PD_STRIP - 1) / PD_STRIP) + 61) / 62 + 3) / 4;
         hipLaunchKernelGGL(k_pyrdown16<PD_STRIP>, dim3((unsigned)(n_w * nslots)), dim3(256), 0, s, src, sw, sh, dst, dw, dh, slot_stride, n_w, nslots);
@@ -3312,7 +3453,7 @@ static int g_blur_pyr = 1;   // level-0 blur and cv::pyrDown of a batch in one s
 void lmk_set_blur_pyr(int v) { g_blur_pyr = v; }
 bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0, u8* bgr1, u8* quant0, size_t slot_stride, int nslots) {
     // exactly the shapes lmk_color_quantize's streaming path and k_pyrdown16 take, batches only
-    if (!g_blur_pyr || nslots < 16 || g_cblur_variant == 1 || g_cblur_variant == 2 || g_pyrdown_variant == 1) return false;
+    if (!g_blur_pyr || sel_slots(nslots) < 16 || g_cblur_variant == 1 || g_cblur_variant == 2 || g_pyrdown_variant == 1) return false;
     if (!scratch0 || (w % 16) != 0 || (h % 2) != 0 || h < 4 || (slot_stride % 16) != 0) return false;
     if (((uintptr_t)bgr0 & 15) || ((uintptr_t)scratch0 & 15) || ((uintptr_t)quant0 & 15) || ((uintptr_t)bgr1 & 7)) return false;
     const int dh = h / 2;
@@ -3324,7 +3465,9 @@ bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0,
     if (g_blur_strip == 64) {
         const int g_blur = waves4((w * 3 / 16) * ((h + 63) / 64));
         hipLaunchKernelGGL(k_blur_pyr<64>, dim3((unsigned)((g_blur + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, g_blur, g_pyr, nslots);
-    } else if (g_blur_strip == 32 || (g_blur_strip == 0 && h > 640)) {
+    } else if (g_blur_strip == 32 || (g_blur_strip == 0 && h > 640 && (long)(waves4((w * 3 / 16) * ((h + 31) / 32)) + g_pyr) * nslots >= 768)) {
+        // (r04: 32-row strips only when they still give the chip three rounds of workgroups -- eight 1280 x 960 frames, config 5,
+        // are 312 workgroups of 32-row strips on 512 slots)
         const int g_blur = waves4((w * 3 / 16) * ((h + 31) / 32));
         hipLaunchKernelGGL(k_blur_pyr<32>, dim3((unsigned)((g_blur + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, g_blur, g_pyr, nslots);
     } else {
@@ -3349,7 +3492,7 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
         // eight dependent steps: 166 instead of 150 us per resident single-frame match); batches: the sliding window
         if (blurred) {
             // S is already in `scratch` (lmk_blur_pyrdown)
-        } else if (g_cblur_variant == 1 || (g_cblur_variant == 0 && nslots < 16)) {
+        } else if (g_cblur_variant == 1 || (g_cblur_variant == 0 && sel_slots(nslots) < 16)) {
             hipLaunchKernelGGL(k_cblur, dim3((unsigned)(((n_b + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_b + 255) / 256, nslots);
         } else if (g_cblur_variant == 3 || g_cblur_variant == 0) {
             // column sums shared between neighbouring lanes: 62 (strip, block) pairs per wave, four waves per workgroup
@@ -3373,7 +3516,7 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
         }
         // orientation + vote: fused for batches (k_cgrad), two kernels for few frames (many short waves) and whenever the
         // caller wants the magnitude image
-        if (!mag && (g_cgrad_variant >= 2 || (g_cgrad_variant == 0 && nslots >= 16))) {
+        if (!mag && (g_cgrad_variant >= 2 || (g_cgrad_variant == 0 && sel_slots(nslots) >= 16))) {
             const int ithr = thr2 >= 2147483648.f ? INT_MAX : (int)floorf(thr2);    // (float)m > thr2 <=> m > floor(thr2)
             // rows per strip: 16 (2 of 18 label rows are recomputed by the neighbouring strips), 8 when that would leave
             // SIMDs without a wave (a 320 x 240 level is 5 waves per frame at 16)
@@ -3402,7 +3545,7 @@ void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_
                         bool lut_onehot, u8* quant, u8* scratch, size_t slot_stride, int nslots) {
     if (scratch && lut_onehot && (w % 8) == 0 && ((uintptr_t)depth & 15) == 0 && ((uintptr_t)scratch & 7) == 0 &&
         ((uintptr_t)quant & 7) == 0 && (slot_stride % 16) == 0) {
-        const bool dm_batch = g_dmedian_variant == 2 || (g_dmedian_variant == 0 && nslots >= 16);
+        const bool dm_batch = g_dmedian_variant == 2 || (g_dmedian_variant == 0 && sel_slots(nslots) >= 16);
         const int dm_rows = dm_batch ? DM_ROWS_BATCH : DM_ROWS;
         const int n_n = (w / 8) * h, n_m = (w / 8) * ((h + dm_rows - 1) / dm_rows);
         hipLaunchKernelGGL(k_dnormal, dim3((unsigned)(((n_n + 255) / 256) * nslots)), dim3(256), 0, s, depth, w, h, dist_thr, diff_thr,
@@ -3461,7 +3604,7 @@ void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, 
             case 4: lm_fast_launch<4, 64>(LMF_ARGS); return;
             case 5:
                 // batches: the streaming kernel (one short wave per frame and band would not fill the chip for few frames)
-                if (mode == 1 && !src_shift && nslots >= 16 && (W % 8) == 0 && (h % 5) == 0 && (((uintptr_t)lm & 7) == 0) &&
+                if (mode == 1 && !src_shift && sel_slots(nslots) >= 16 && (W % 8) == 0 && (h % 5) == 0 && (((uintptr_t)lm & 7) == 0) &&
                     (lm_slot_stride % 8) == 0 && (((size_t)W * (h / 5)) % 8) == 0) {
                     const int n_l = (W / 8) * (h / 5);
                     hipLaunchKernelGGL(k_lm_spread5, dim3((unsigned)(((n_l + 255) / 256) * nslots)), dim3(256), 0, s, q, qpitch, w, h, lm,
@@ -3536,7 +3679,7 @@ void lmk_preprocess_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
 
 bool lmk_batch_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0, int mode1, bool lut_onehot) {
     if (!lmk_phases_supported(a, T0, T1, mode0, mode1, lut_onehot)) return false;
-    if (a.nslots < 16 || (a.w % 32) != 0 || (a.h % 2) != 0) return false;
+    if (sel_slots(a.nslots) < 16 || (a.w % 32) != 0 || (a.h % 2) != 0) return false;
     auto al = [](const void* p, uintptr_t m) { return ((uintptr_t)p & (m - 1)) == 0; };
     if (T0 == 5) {   // k_lm_spread5's shape
         const int W = a.w / 5;
@@ -3729,5 +3872,6 @@ void lmk_pack_lists(hipStream_t s, const LmPackArgs& a) {
 
 void lmk_sort_unique(hipStream_t s, const LmSortArgs& a, int nslots) {
     size_t shmem = (size_t)LM_SORT_CAP * 16;
-    hipLaunchKernelGGL(k_sort_unique, dim3(1, 1, nslots), dim3(1024), shmem, s, a);
+    hipLaunchKernelGGL(k_sort_unique, dim3(1, a.split ? LM_SORT_CAP / LM_SORT_CHUNK : 1, nslots), dim3(1024), shmem, s, a);
+    if (a.split) hipLaunchKernelGGL(k_merge_unique, dim3(1, 1, nslots), dim3(1024), shmem, s, a);
 }

@@ -160,3 +160,81 @@ def test_rendezvous_times_out_under_one_deadline(lm):
     with pytest.raises(lm.LinemodError):
         lm.rendezvous_broadcast(1, 2, bytes(128), port=_free_port(), timeout_s=2)     # nobody listens
     assert time.time() - t0 < 10
+
+
+def _random_sorted_lists(lm, rng, n_frames, max_len):
+    out = []
+    for _ in range(n_frames):
+        k = int(rng.integers(0, max_len + 1))
+        m = np.zeros(k, lm.MATCH_DTYPE)
+        m["x"] = rng.integers(0, 9, k); m["y"] = rng.integers(0, 9, k)
+        m["similarity"] = rng.integers(80, 86, k).astype(np.float32)
+        m["template_id"] = rng.integers(0, 400, k); m["class_idx"] = rng.integers(0, 2, k)
+        out.append(lm.merge_matches([m]))                      # sorted + unique, as a shard's device sort leaves it
+    return out
+
+
+@pytest.mark.parametrize("R", [2, 3, 8])
+def test_gathered_bookkeeping_at_world_sizes_2_3_8(lm, R):
+    """VERDICT r3 #6b: the `R > 1` branches of lm_match_end_gathered have never run on hardware (no node with more than one GPU),
+    so their host logic is factored out (lm_gather_plan / lm_gather_max_total / lm_merge_frames) and driven here on synthetic
+    gathered buffers in the WIRE layout of the two all-gathers: per rank n + 1 lengths (status word last) and a fixed-capacity
+    run of packed records.  For every rank: the frames it owns partition the lane's frames, only the owned piece of every rank's
+    run is "copied to the host" (everything else stays poisoned), and the merged lists equal a merge of the whole lists."""
+    rng = np.random.default_rng(100 + R)
+    for n in (1, 5, 8, 96):
+        shards = [_random_sorted_lists(lm, rng, n, 30) for _ in range(R)]          # shards[r][i] = rank r's list of frame i
+        cap_lane = max(sum(len(l) for l in sh) for sh in shards) + 5
+        all_cnt = np.zeros((R, n + 1), np.int32)
+        dev = np.zeros((R, cap_lane), lm.MATCH_DTYPE)                              # what ncclAllGather leaves in device memory
+        for r in range(R):
+            all_cnt[r, :n] = [len(l) for l in shards[r]]
+            run = np.concatenate(shards[r]) if n else np.zeros(0, lm.MATCH_DTYPE)
+            dev[r, :len(run)] = run
+        owned = []
+        for rank in range(R):
+            plan = lm.gather_plan(all_cnt, R, n, rank)
+            assert plan["status"] == 0 and plan["bad_rank"] == -1
+            assert (plan["f0"], plan["f1"]) == (n * rank // R, n * (rank + 1) // R)
+            assert np.array_equal(plan["counts"], all_cnt[:, :n])
+            assert plan["max_total"] == max(1, int(all_cnt[:, :n].sum(1).max()))
+            owned.append((plan["f0"], plan["f1"]))
+            host = np.zeros((R, cap_lane), lm.MATCH_DTYPE)
+            host["x"] = -12345; host["template_id"] = -1                            # never-copied records are poison
+            for r in range(R):
+                a, l = int(plan["piece_start"][r]), int(plan["piece_len"][r])
+                assert a == int(all_cnt[r, :plan["f0"]].sum()) and l == int(all_cnt[r, plan["f0"]:plan["f1"]].sum())
+                host[r, a:a + l] = dev[r, a:a + l]                                 # the one D2H piece per rank
+            merged, mc = lm.merge_batch(host, plan["counts"], plan["f0"], plan["f1"])
+            pos = 0
+            for i in range(plan["f0"], plan["f1"]):
+                exp = lm.merge_matches([shards[r][i] for r in range(R)])
+                got = merged[pos:pos + mc[i - plan["f0"]]]
+                assert got.tobytes() == exp.tobytes(), (R, n, rank, i)
+                pos += mc[i - plan["f0"]]
+            assert pos == len(merged)
+        assert owned[0][0] == 0 and owned[-1][1] == n and all(owned[k][1] == owned[k + 1][0] for k in range(R - 1))
+
+
+def test_gathered_bookkeeping_status_words_and_fallback_sizes(lm):
+    """Status words travel with the lengths, so every rank takes the same branch: bit 0 / bit 1 on ANY rank sends all ranks to the
+    sized second exchange, bit 2 names the first overflowing rank; the sized exchange's buffers follow the largest rank."""
+    R, n = 8, 6
+    all_cnt = np.zeros((R, n + 1), np.int32)
+    all_cnt[:, :n] = np.arange(R * n).reshape(R, n) % 7
+    all_cnt[5, n] = 1
+    all_cnt[2, n] = 2
+    for rank in range(R):
+        p = lm.gather_plan(all_cnt, R, n, rank)
+        assert p["status"] == 3 and p["bad_rank"] == -1
+        assert p["max_total"] == int(all_cnt[:, :n].sum(1).max())
+    all_cnt[6, n] = 4
+    all_cnt[3, n] = 4
+    assert [lm.gather_plan(all_cnt, R, n, r)["bad_rank"] for r in range(R)] == [3] * R
+    bad = all_cnt.copy(); bad[1, 2] = -1
+    with pytest.raises(lm.LinemodError):
+        lm.gather_plan(bad, R, n, 0)
+    with pytest.raises(lm.LinemodError):
+        lm.gather_plan(all_cnt, R, n, R)
+    empty = np.zeros((R, n + 1), np.int32)
+    assert lm.gather_plan(empty, R, n, 0)["max_total"] == 1          # buffers of the sized exchange are never empty

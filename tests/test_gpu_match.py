@@ -535,3 +535,31 @@ def test_batch_of_32_frames_takes_the_batch_kernels(lm, orc, synth):
         for i in range(16):
             assert_matches_equal(out[i, :cnt[i]], exp[16 * lane + i])
     d.close()
+
+
+def test_split_sort_equals_plain_sort_and_oracle(lm, orc, synth):
+    """a15 on the device has two forms (LM_TUNE_SORT_SPLIT): one workgroup per frame, or -- for lists longer than 1024 keys --
+    four chunk workgroups per frame and a merge launch that ranks every key against the other chunks.  Eight crowded frames at
+    thresholds that put the lists of refined matches on both sides of 1024, 2048, 3072 and of LM_SORT_CAP = 4096 (beyond it the
+    host sorts): every list of every form against the oracle's, plus the adaptive default after it has seen long lists."""
+    d, o = _pair(lm, orc, True, frame_slots=8)
+    frames = [synth.make_frame(640, 480, seed=900 + i)[0] for i in range(8)]
+    frames[5] = np.full((480, 640, 3), 127, np.uint8)
+    o.prepare(frames[0], None)
+    q = {(l, 0): o.stage(0, l, 0).reshape(480 >> l, 640 >> l) for l in range(2)}
+    descs, feats, _ = synth.make_bank(60, 1, 2, seed=77, quantized=q, crop_fraction=0.5, T0=d.get_T(0))
+    d.add_class("c", descs, feats); o.add_class("c", descs, feats)
+    for i, b in enumerate(frames):
+        d.upload_frame(i, b, None)
+    lengths = set()
+    for thr in (20.0, 30.0, 35.0, 45.0, 60.0):
+        exp = [o.match(frames[i], None, thr, threads=8, cap=1 << 18) for i in range(8)]
+        for mode in (0, 1, 2, 2):
+            d.set_tuning(lm.TUNE_SORT_SPLIT, mode)
+            out, counts = d.match_batch(8, thr, cap_per_frame=1 << 15)
+            for i in range(8):
+                assert_matches_equal(out[i, :counts[i]], exp[i])
+        lengths.update(d.last_counts(i)[1] for i in range(8))
+    buckets = {min(n // 1024, 4) for n in lengths}
+    assert {0, 1, 4} <= buckets and len(buckets) >= 4, sorted(lengths)       # short lists, several chunk counts, host-sorted ones
+    d.close()
