@@ -62,7 +62,7 @@ def quantized_from_gpu(det, bgr, depth, M, L=2):
             for l in range(L) for m in range(M)}
 
 
-CAP = 4096       # match records per frame in the result buffers (a shard's list must fit: SURVEY.md 8e)
+CAP = 4096       # match records per frame in the result buffers (a shard's list must fit: SURVEY.md 8e); Runner.cap grows with the bank
 NBUF = 3         # result buffers in rotation
 
 
@@ -107,6 +107,8 @@ class Runner:
             det.set_tuning(lm.TUNE_FORK_MAX_SLOTS, 1 << 20)
         if args.no_batch_phases:
             det.set_tuning(lm.TUNE_BATCH_PHASES, 0)
+        if args.batch_phases >= 0:
+            det.set_tuning(lm.TUNE_BATCH_PHASES, args.batch_phases)
         if args.cblur_variant:
             det.set_tuning(lm.TUNE_CBLUR_VARIANT, args.cblur_variant)
         if args.pyrdown_variant:
@@ -132,7 +134,9 @@ class Runner:
         if B % self.NL or B < self.NL:
             self.NL = 1
         self.Bl = B // self.NL                           # frames per lane and launch
-        self.bufs = [(np.zeros((B, CAP), lm.MATCH_DTYPE), np.zeros(B, np.int32)) for _ in range(NBUF)]
+        # a frame's list grows with the bank: 4408 matches at 24 300 templates on one GPU (config 4's whole bank, the weak-scaling denominator)
+        self.cap = cap = CAP if self.n_total // max(world, 1) <= 8000 else 4 * CAP
+        self.bufs = [(np.zeros((B, cap), lm.MATCH_DTYPE), np.zeros(B, np.int32)) for _ in range(NBUF)]
         self.views = [[(o[l * self.Bl:(l + 1) * self.Bl], cn[l * self.Bl:(l + 1) * self.Bl]) for l in range(self.NL)]
                       for o, cn in self.bufs]
         self.k = 0
@@ -142,7 +146,7 @@ class Runner:
             # fixed gather capacity: 1024 records per frame and rank on average over a lane-step (the bench bank yields
             # about 530 per frame and 3000-template shard at threshold 80); lists beyond it take the sized second exchange
             det.comm_init(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, args.gather_cap or 1024)
-            self.gbuf = [(np.zeros(self.Bl * CAP // 4, lm.MATCH_DTYPE), np.zeros(self.Bl, np.int32)) for _ in range(self.NL)]
+            self.gbuf = [(np.zeros(self.Bl * self.cap // 4, lm.MATCH_DTYPE), np.zeros(self.Bl, np.int32)) for _ in range(self.NL)]
 
     # ------------------------------------------------------------------------------------------
     def run_steps(self, n, after_step=None):
@@ -168,7 +172,7 @@ class Runner:
                         self.last_owned = (f0, nf, int(cn[0]) if nf else 0)
                 else:
                     o, cn = self.views[k % NBUF][l]
-                    det.match_end(l, CAP, out=o, counts=cn)
+                    det.match_end(l, self.cap, out=o, counts=cn)
                 if k + 1 < k0 + n:
                     begin(l, l * Bl, Bl, thr, self.cls)
             if after_step is not None:
@@ -181,13 +185,13 @@ class Runner:
         det.set_profiling(True)
         for _ in range(steps):
             det.match_begin(0, 0, self.Bl, self.args.threshold, self.cls)
-            det.match_end(0, CAP, out=self.views[0][0][0], counts=self.views[0][0][1])
+            det.match_end(0, self.cap, out=self.views[0][0][0], counts=self.views[0][0][1])
         prof = det.get_profile()
         det.set_profiling(False)
         # one more launch with the scan's feature counters on: what fraction of the feature loads the pruning keeps
         det.set_scan_stats(True)
         det.match_begin(0, 0, self.Bl, self.args.threshold, self.cls)
-        det.match_end(0, CAP, out=self.views[0][0][0], counts=self.views[0][0][1])
+        det.match_end(0, self.cap, out=self.views[0][0][0], counts=self.views[0][0][1])
         loaded, total = det.get_scan_stats()
         lane_issued, lane_total = det.get_scan_lane_stats()
         det.set_scan_stats(False)
@@ -234,7 +238,7 @@ class Runner:
         def end(k):
             for l in range(NL):
                 o, cn = self.views[k % NBUF][l]
-                det.match_end(l, CAP, out=o, counts=cn)
+                det.match_end(l, self.cap, out=o, counts=cn)
 
         counts = []
         for phase, n in (("warm", 3), ("timed", steps)):
@@ -372,6 +376,7 @@ def main():
     ap.add_argument("--no-batch-phases", action="store_true",
                     help="A/B knob: one launch per pre-processing kernel (eleven per lane-step) instead of the four launches of "
                          "level-fused batch kernels (LM_TUNE_BATCH_PHASES = 0)")
+    ap.add_argument("--batch-phases", type=int, default=-1, choices=(-1, 0, 1, 2), help="A/B knob: LM_TUNE_BATCH_PHASES (1: level-fused launches also beside other lanes)")
     ap.add_argument("--cblur-variant", type=int, default=0, help="A/B knob: LM_TUNE_CBLUR_VARIANT (2: sliding window, 3: shared column sums)")
     ap.add_argument("--pyrdown-variant", type=int, default=0, help="A/B knob: LM_TUNE_PYRDOWN_VARIANT (1: k_pyrdown8, 2: row-walking k_pyrdown16)")
     ap.add_argument("--blur-strip", type=int, default=0, choices=(0, 16, 32, 64), help="A/B knob: rows per strip of the level-0 blur (LM_TUNE_BLUR_STRIP)")
@@ -456,7 +461,7 @@ def main():
         distmod = importlib.import_module("line-mod-pipeline_amd.dist")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        gather = distmod.ShardGather(lm.merge_matches, cap=CAP, pack_fn=lm.pack_matches, merge_batch_fn=lm.merge_batch)
+        gather = distmod.ShardGather(lm.merge_matches, cap=runner.cap, pack_fn=lm.pack_matches, merge_batch_fn=lm.merge_batch)
 
     def after_step(k):
         o, cn = runner.bufs[k % NBUF]
@@ -513,12 +518,19 @@ def main():
     span_us = prof["stage_us"][1] / max(prof["launches"], 1)
     alg_bytes = prof["scan_bytes"] / max(prof["launches"], 1)
     ol_us = one_lane["stage_us"][1] / max(one_lane["launches"], 1)
-    traffic, traffic_src = pmc_traffic(args.config, Bl)
-    l2c = l2_counters(args.config, Bl)
+    cmeta = counters_meta(args, runner.n_total // world, Bl)
+    ctr, ctr_reason = load_counters(cmeta)
+    traffic = traffic_src = None
+    if ctr:
+        for k, v in ctr["kernels"].items():
+            if k.startswith(kernel) and "hbm_bytes_per_launch" in v:
+                traffic, traffic_src = v["hbm_bytes_per_launch"], ctr["source"]
+    l2c = ctr if ctr and any("TCP_TCC_READ_REQ_sum" in v for v in ctr["kernels"].values()) else None
 
     def rate(nbytes, us):
         return nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
 
+    wl_cfg = CONFIGS[args.config]
     roofline = {
         "bound": "l2", "achieved": round(rate(l2_bytes, ol_us), 1), "peak": L2_PEAK_GBS, "unit": "GB/s",
         "frac": round(rate(l2_bytes, ol_us) / L2_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -531,9 +543,8 @@ def main():
         "measured": "HIP events on the launch stream around every %s launch of %d launches (%d frames each) on one lane "
                     "with nothing running beside them, in this process right after the timed region; rocprofv3 "
                     "--kernel-trace --stats of `bench.py --lanes 1` agrees (profiles/)" % (kernel, one_lane["launches"], Bl),
-        "why_l2": "the scanned level's linear memories (nibble-packed, 0.6 MB per 640x480 frame) are L2-resident: the "
-                  "kernel is bound by what its vector loads request from the L2s (load_bytes_per_launch) against the "
-                  "guide's 34.5 TB/s aggregate L2 rate; HBM traffic (`traffic`, PMC) is ~0.4 % of the algorithmic bytes",
+        "why_l2": why_l2(runner, wl_cfg, traffic, alg_bytes, ctr, kernel),
+        "counter_file": ctr["source"] if ctr else None, "counter_file_reason": ctr_reason,
         "hbm_algorithmic": {
             "bound": "hbm", "achieved": round(rate(alg_bytes, ol_us), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(rate(alg_bytes, ol_us) / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg_bytes,
@@ -560,6 +571,8 @@ def main():
             if not ks or us <= 0:
                 return None
             c = l2c["kernels"][ks[0]]
+            if "TCP_TCC_READ_REQ_sum" not in c:
+                return None
             req = c.get("TCP_TCC_READ_REQ_sum", 0.0)
             hit, miss = c.get("TCC_HIT_sum", 0.0), c.get("TCC_MISS_sum", 0.0)
             return {"kernel_in_counter_file": ks[0], "TCP_TCC_READ_REQ_per_launch": req, "bytes_per_request": bpr,
@@ -593,6 +606,7 @@ def main():
                                "note": "similarityLocal + refinement (a14): one wave per candidate, a 16 x 16 patch per feature pulls "
                                        "16-17 lines of 128 B for 256 useful bytes; by the counters neither the L2 (this fraction), nor the "
                                        "L1 tag pipeline, nor the vector ALU is saturated on its own (DESIGN.md section 5)"}
+    roofline_pre = preprocess_roofline(ctr, ctr_reason, one_lane, Bl)
 
     result = None
     h2d = cpu = None
@@ -633,6 +647,8 @@ def main():
                        "parallelism": "template-shard x%d" % world},
             "roofline": roofline,
             "roofline_refine": roofline_refine,
+            "roofline_preprocess": roofline_pre,
+            "counters_meta": cmeta,
             "cpu_baseline": cpu,
         }
         sys.stdout.flush()
@@ -644,6 +660,90 @@ def main():
     return result
 
 
+HBM_ACHIEVABLE_GBS = 6300.0   # MI355X_MICROARCH.md: measured streaming ceiling of HBM3E on this part (what a copy kernel reaches)
+N_SIMD = 1024                 # 256 CUs x 4 SIMDs
+PRE_PREFIXES = ("k_blur_pyr", "k_cblur", "k_cgrad", "k_corient", "k_cvote", "k_pyrdown", "k_dnormal", "k_dmedian", "k_lm_", "k_linear_memories",
+                "k_phase", "k_bphase", "k_bsplit", "k_pair", "k_color_quantize", "k_depth_quantize", "k_nn_half", "k_pre")
+
+
+def why_l2(runner, wl, traffic, alg_bytes, ctr, kernel):
+    """Why the scan is priced against the L2 rate, from THIS config's working set and -- when a counter file matches -- its
+    measured HBM traffic and L2 hit rate (the sentence used to be config 2's for every config)."""
+    W1, H1, M = wl["W"] // 2, wl["H"] // 2, runner.M
+    lm_bytes = M * 8 * W1 * H1 // 2                              # nibble-packed response memories of the scanned level, per frame
+    bank = runner.n_total // max(runner.world, 1) * M * 31 * 4   # u32 offsets of the shard's level-1 features
+    msg = ("scanned level per frame: %.2f MB of nibble-packed linear memories (%d modalities x 8 orientations x %d x %d positions / 2); "
+           "a wave scans two frames, an XCD works on one slot pair at a time: %.2f MB + %.2f MB of bank offsets against a 4 MB L2 per XCD"
+           % (lm_bytes / 1e6, M, W1, H1, 2 * lm_bytes / 1e6, bank / 1e6))
+    fits = 2 * lm_bytes + bank <= 4.0e6
+    if traffic is not None and alg_bytes:
+        msg += "; measured HBM-side traffic of the kernel %.1f MB per launch = %.2f %% of the algorithmic bytes" % (traffic / 1e6, 100.0 * traffic / alg_bytes)
+    if ctr:
+        for k, v in ctr["kernels"].items():
+            if k.startswith(kernel) and v.get("TCC_HIT_sum") is not None and v.get("TCC_MISS_sum") is not None and v["TCC_HIT_sum"] + v["TCC_MISS_sum"] > 0:
+                msg += ", L2 hit rate %.1f %%" % (100.0 * v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]))
+    msg += ("; the working set fits the L2, so the kernel is bound by what its vector loads request from the L2s against the guide's 34.5 TB/s "
+            "aggregate L2 rate" if fits else
+            "; the working set does NOT fit one XCD's L2: part of the requests are served by the fabric (Infinity Cache / HBM), and the "
+            "L2-rate fraction is an upper-bound yard-stick for this config -- `traffic` against the 8 TB/s HBM peak is reported beside it")
+    return msg
+
+
+def preprocess_roofline(ctr, reason, one_lane, Bl):
+    """Per-kernel roofline entries of the pre-processing (a3-a10) and of every other kernel that takes >= 5 % of a one-lane step,
+    from the committed counter file of THIS command (kernel stats + PMC passes): HBM-side bytes / clean duration against the
+    8 TB/s peak and the 6.3 TB/s achievable rate, vector-ALU activity against the SIMDs' cycles; the bound is named from the
+    numbers."""
+    if not ctr:
+        return {"kernels": None, "reason": reason}
+    ks = ctr["kernels"]
+    step_us = sum(v.get("avg_us", 0.0) * v.get("calls", 0) for v in ks.values() if v.get("calls", 0) >= 8)
+    calls = [v["calls"] for k, v in ks.items() if k.startswith("k_scan") and "calls" in v]
+    steps = max(calls) if calls else 1
+    out, pre_us, pre_bytes = [], 0.0, 0.0
+    for k, v in sorted(ks.items(), key=lambda kv: -kv[1].get("avg_us", 0) * kv[1].get("calls", 0)):
+        if "avg_us" not in v or v.get("calls", 0) < 8 or k.startswith("__amd"):
+            continue
+        per_step = v["calls"] / steps
+        is_pre = k.startswith(PRE_PREFIXES)
+        if is_pre:
+            pre_us += v["avg_us"] * per_step
+            pre_bytes += v.get("hbm_bytes_per_launch", 0.0) * per_step
+        if v["avg_us"] * v["calls"] < 0.05 * step_us and not is_pre:
+            continue
+        e = {"kernel": k, "stage": "preprocess" if is_pre else "match", "avg_us": v["avg_us"], "launches_per_step": round(per_step, 2),
+             "share_of_one_lane_step": round(v["avg_us"] * v["calls"] / step_us, 4) if step_us else None}
+        us = v["avg_us"]
+        if "hbm_bytes_per_launch" in v and us > 0:
+            gbs = v["hbm_bytes_per_launch"] / (us * 1e-6) / 1e9
+            e.update({"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "hbm_read_bytes_per_launch": v.get("hbm_read_bytes_per_launch"),
+                      "hbm_write_bytes_per_launch": v.get("hbm_write_bytes_per_launch"), "hbm_GBps": round(gbs, 1),
+                      "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "frac_of_hbm_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4)})
+        if "TCP_TCC_READ_REQ_sum" in v and us > 0:
+            l2 = v["TCP_TCC_READ_REQ_sum"] * ctr.get("bytes_per_request", 128) / (us * 1e-6) / 1e9
+            e.update({"l2_read_GBps": round(l2, 1), "frac_of_l2_peak": round(l2 / L2_PEAK_GBS, 4)})
+        if "SQ_ACTIVE_INST_VALU" in v and v.get("GRBM_GUI_ACTIVE"):
+            cyc = v["GRBM_GUI_ACTIVE"] / max(v.get("GRBM_GUI_ACTIVE_instances", 1), 1)     # cycles the kernel held the chip
+            e.update({"valu_busy": round(v["SQ_ACTIVE_INST_VALU"] * 4.0 / N_SIMD / cyc, 4),
+                      "valu_insts_per_launch": v.get("SQ_INSTS_VALU"),
+                      "valu_insts_per_simd_cycle": round(v.get("SQ_INSTS_VALU", 0.0) / N_SIMD / cyc, 4),
+                      "kernel_cycles": round(cyc)})
+        fr_h, fr_v, fr_l = e.get("frac_of_hbm_achievable", 0.0), e.get("valu_busy", 0.0), e.get("frac_of_l2_peak", 0.0)
+        best = max((fr_h, "hbm"), (fr_v, "valu"), (fr_l, "l2"))
+        e["bound"] = best[1] if best[0] >= 0.6 else "none saturated (latency / occupancy): hbm %.2f, valu %.2f, l2 %.2f" % (fr_h, fr_v, fr_l)
+        out.append(e)
+    live = one_lane["stage_us"][0] / max(one_lane["launches"], 1)
+    return {"kernels": out, "source": ctr["source"],
+            "preprocess_sum_of_kernels_us_per_launch": round(pre_us, 1), "preprocess_live_us_per_launch": round(live, 1),
+            "preprocess_hbm_bytes_per_frame": round(pre_bytes / Bl), "frames_per_launch": Bl,
+            "definitions": "per kernel from the committed counter file of this very command (one lane, one launch per kernel; meta must equal "
+                           "this run's, counters_meta): hbm_* = (2 x FETCH_SIZE + WRITE_SIZE) KB per launch / clean avg duration, against the 8 TB/s "
+                           "peak and the 6.3 TB/s a streaming kernel achieves; valu_busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel "
+                           "cycles), kernel cycles = GRBM_GUI_ACTIVE per XCD; valu_insts_per_simd_cycle = SQ_INSTS_VALU / (1024 x cycles) "
+                           "(the issue classes of DESIGN.md section 5 cost 1 / 2.7 and 1 / 4.5 per cycle); l2_* = TCP_TCC_READ_REQ x 128 B; "
+                           "bound = the largest of (hbm achievable, valu busy, l2) if >= 0.6; preprocess_live = HIP events of this run"}
+
+
 def pci_bus_number(s):
     """'0000:c1:00.0' -> domain << 16 | bus << 8 | device << 3 | function (exact in a double)."""
     dom, bus, rest = s.strip().split(":")
@@ -651,38 +751,51 @@ def pci_bus_number(s):
     return (int(dom, 16) << 16) | (int(bus, 16) << 8) | (int(dev, 16) << 3) | int(fn, 16)
 
 
-def pmc_traffic(config, frames_per_launch):
-    """HBM bytes per scan launch from the committed rocprofv3 PMC passes of this same command (profiles/summarize_pmc.py:
-    2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes).  PMC counters cannot be read from inside the process, so this is null
-    unless a committed pass matches the config and frames_per_launch."""
+def kernel_source_sha16():
+    """Identity of the kernel sources a counter file was collected with: sha256 over the product's csrc files, first 16 hex digits."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_*.json")), reverse=True):
-        try:
-            d = json.load(open(path))
-        except Exception:
-            continue
-        if d.get("frames_per_launch") != frames_per_launch or d.get("baseline_config", 2) != config:
-            continue
-        for k, v in d.get("kernels", {}).items():
-            if k.startswith("k_scan"):
-                return v["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
-    return None, None
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "line-mod-pipeline_amd", "csrc", "*"))):
+        if path.endswith((".hip", ".h", ".cpp")):
+            h.update(os.path.basename(path).encode() + b"\0" + open(path, "rb").read())
+    return h.hexdigest()[:16]
 
 
-def l2_counters(config, frames_per_launch):
-    """Per-kernel L1 / L2 counters per launch from the committed rocprofv3 --pmc passes (tools/collect_counters.sh,
-    profiles/summarize_l2.py): TCP_TCC_READ_REQ, TCP_TOTAL_CACHE_ACCESSES, TCC_REQ / HIT / MISS, and the calibrated size of a
-    TCP -> TCC read request.  None unless a committed file matches the config and the frames per launch."""
+COUNTER_KEYS = ("baseline_config", "frames_per_launch", "threshold", "templates_per_gpu", "scan_variant", "no_prune", "byte_responses",
+                "kernel_source_sha16")
+
+
+def counters_meta(args, templates_per_gpu, frames_per_launch):
+    """What a committed counter file must agree with before bench.py lets it describe this run."""
+    return {"baseline_config": args.config, "frames_per_launch": frames_per_launch, "threshold": args.threshold,
+            "templates_per_gpu": templates_per_gpu, "scan_variant": args.scan_variant, "no_prune": bool(args.no_prune),
+            "byte_responses": bool(args.byte_responses), "kernel_source_sha16": kernel_source_sha16()}
+
+
+def load_counters(meta, profiles_dir=None):
+    """The newest profiles/*_counters_c<config>.json (tools/collect_counters.sh, profiles/summarize_counters.py) whose `meta`
+    equals this run's in every key of COUNTER_KEYS -- same workload, same launch shape, same scan variant, same kernel sources.
+    Returns (counters or None, reason): PMC counters cannot be read from inside the process, so without a matching file the line
+    carries no counter-based figure and says why."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*l2_counters_*.json")), reverse=True):
+    paths = sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "*_counters_c%d.json" % meta["baseline_config"])), reverse=True)
+    if not paths:
+        return None, "no profiles/*_counters_c%d.json committed" % meta["baseline_config"]
+    why = []
+    for path in paths:
         try:
             d = json.load(open(path))
-        except Exception:  # noqa: BLE001
+        except Exception as e:  # noqa: BLE001
+            why.append("%s: unreadable (%s)" % (os.path.basename(path), e))
             continue
-        if d.get("frames_per_launch") == frames_per_launch and d.get("baseline_config") == config and d.get("kernels"):
+        m = d.get("meta") or {}
+        diff = [k for k in COUNTER_KEYS if m.get(k) != meta[k]]
+        if not diff and d.get("kernels"):
             d["source"] = os.path.relpath(path, ROOT)
-            return d
-    return None
+            return d, None
+        why.append("%s differs in %s" % (os.path.basename(path), ", ".join("%s (file %r, run %r)" % (k, m.get(k), meta[k]) for k in diff)))
+    return None, "; ".join(why)
 
 
 def cgroup_cpus():

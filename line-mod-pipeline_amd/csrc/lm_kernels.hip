@@ -1399,6 +1399,11 @@ __device__ __forceinline__ u32 pk_min_u16(u32 a, u32 b) {
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ u32 pk_mul_lo_u16(u32 a, u32 b) {   // per half: low 16 bits of a * b
+    u32 r;
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ u32 pk_sub_i16_op(u32 a, u32 b) {
     u32 r;
     asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -1456,8 +1461,7 @@ __device__ __forceinline__ float dn_sqrt(float x) {
     const float r_dn = __builtin_fmaf(-s_dn, s, x);
     const float r_up = __builtin_fmaf(-s_up, s, x);
     float r = r_dn <= 0.0f ? s_dn : s;
-    r = r_up > 0.0f ? s_up : r;
-    return x == 0.0f ? 0.0f : r;
+    return r_up > 0.0f ? s_up : r;           // (x == 0: s = 0, s- is a NaN whose residual compares false, r(s+) = 0: stays 0)
 }
 // QUOT: the caller passes det / 625, ddx / 125, ddy / 125 (the packed taps' sums); with SMALL the two scalings of a component are one
 // 24-bit multiply, |ddx / 125| <= 8 * 6 * 248 and 125 * 1150 = 143750 < 2^24.
@@ -1538,7 +1542,10 @@ __device__ __forceinline__ void d_dnormal_t(const u32 vblock, const u16* __restr
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const u32 C = D[1][4 + k];
-                u32 ci = 0, cj = 0, cx = 0, sx = 0, sy = 0;
+                // f (0 / 1) and the gated delta of the eight neighbours, [jj + 1][ii + 1]; then the five sums from SHARED partial sums
+                // (r04: the diagonal counts and the diagonal delta differences serve two accumulators each -- 16 adds instead of 28 --
+                // and the gate is one multiply by f instead of a negate and an and)
+                u32 F[3][3], G[3][3];
 #pragma unroll
                 for (int jj = -1; jj <= 1; ++jj)
 #pragma unroll
@@ -1550,11 +1557,16 @@ __device__ __forceinline__ void d_dnormal_t(const u32 vblock, const u16* __restr
                                              : __builtin_amdgcn_alignbit(Dr[2 + k], Dr[1 + k], 16);
                         const u32 up = pk_sub_u16_sat(N, C), dn = pk_sub_u16_sat(C, N);      // one of them is 0
                         const u32 f = pk_min_u16(pk_sub_u16_sat(THR, up | dn), 0x00010001u);  // |delta| < diff_thr ? 1 : 0
-                        const u32 fd = pk_sub_i16(up, dn) & pk_sub_i16_op(0u, f);                 // the gated delta
-                        if (ii != 0) { ci += f; sx = ii > 0 ? pk_add_i16(sx, fd) : pk_sub_i16(sx, fd); }
-                        if (jj != 0) { cj += f; sy = jj > 0 ? pk_add_i16(sy, fd) : pk_sub_i16(sy, fd); }
-                        if (ii != 0 && jj != 0) cx = ii * jj > 0 ? pk_add_i16(cx, f) : pk_sub_i16(cx, f);
+                        F[jj + 1][ii + 1] = f;
+                        G[jj + 1][ii + 1] = pk_mul_lo_u16(pk_sub_i16(up, dn), f);             // the gated delta
                     }
+                const u32 fdp = F[2][2] + F[0][0], fdm = F[2][0] + F[0][2];                   // diagonals with ii jj > 0 / < 0
+                const u32 cd = fdp + fdm;
+                const u32 cx = pk_sub_i16(fdp, fdm);
+                const u32 ci = F[1][2] + F[1][0] + cd, cj = F[2][1] + F[0][1] + cd;
+                const u32 ga = pk_sub_i16(G[2][2], G[0][0]), gb = pk_sub_i16(G[0][2], G[2][0]);
+                const u32 sx = pk_add_i16(pk_add_i16(pk_sub_i16(G[1][2], G[1][0]), ga), gb);   // sum of ii * gated delta
+                const u32 sy = pk_sub_i16(pk_add_i16(pk_sub_i16(G[2][1], G[0][1]), ga), gb);   // sum of jj * gated delta
                 const u32 ncx = pk_sub_i16(0u, cx);
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {

@@ -151,3 +151,42 @@ def test_bench_config5_line():
     assert d["config"]["baseline_config"] == 5 and d["config"]["templates_total"] == 24300 and d["scaling"] == "strong"
     assert d["config"]["frames_per_step"] == 24 and d["config"]["lanes"] == 3 and d["value"] > 0       # three lanes x 8-frame batches
     assert d["config"]["matches_frame0"] > 0
+
+
+def test_counter_files_are_used_only_for_the_command_they_were_collected_with(tmp_path):
+    """the roofline figures that come from committed PMC passes must describe THIS run: bench.load_counters takes a
+    file only when workload, launch shape, threshold, templates, scan variant and the kernel sources' hash all agree, and says
+    which key differed otherwise.  preprocess_roofline turns a matching file into per-kernel fractions (CPU-only test)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sha = bench.kernel_source_sha16()
+    assert len(sha) == 16 and sha == bench.kernel_source_sha16()
+    meta = {"baseline_config": 2, "frames_per_launch": 96, "threshold": 80.0, "templates_per_gpu": 3000, "scan_variant": 0,
+            "no_prune": False, "byte_responses": False, "kernel_source_sha16": sha}
+    assert bench.load_counters(meta, str(tmp_path)) == (None, "no profiles/*_counters_c2.json committed")
+    kernels = {
+        "k_scan4<6, true, 2, false>": {"calls": 33, "avg_us": 167.0, "hbm_bytes_per_launch": 60e6, "TCP_TCC_READ_REQ_sum": 32.4e6,
+                                       "TCC_HIT_sum": 98.6, "TCC_MISS_sum": 1.4},
+        "k_blur_pyr<16>": {"calls": 33, "avg_us": 70.0, "hbm_bytes_per_launch": 311e6, "hbm_read_bytes_per_launch": 200e6,
+                           "hbm_write_bytes_per_launch": 111e6, "SQ_ACTIVE_INST_VALU": 0.5 * 1024 * 168000 / 4, "SQ_INSTS_VALU": 3.0e7,
+                           "GRBM_GUI_ACTIVE": 8 * 168000.0, "GRBM_GUI_ACTIVE_instances": 8},
+        "k_refine_plan": {"calls": 33, "avg_us": 1.0},
+    }
+    for name, m in (("r04_counters_c2.json", dict(meta, threshold=60.0)), ("r03_counters_c2.json", dict(meta, kernel_source_sha16="0" * 16))):
+        json.dump({"meta": m, "kernels": kernels, "bytes_per_request": 128}, open(tmp_path / name, "w"))
+    got, why = bench.load_counters(meta, str(tmp_path))
+    assert got is None and "threshold" in why and "kernel_source_sha16" in why
+    json.dump({"meta": meta, "kernels": kernels, "bytes_per_request": 128}, open(tmp_path / "r05_counters_c2.json", "w"))
+    got, why = bench.load_counters(meta, str(tmp_path))
+    assert why is None and got["source"].endswith("r05_counters_c2.json")
+    one_lane = {"stage_us": [380.0 * 10, 0, 0, 0], "launches": 10}
+    pre = bench.preprocess_roofline(got, None, one_lane, 96)
+    by = {e["kernel"]: e for e in pre["kernels"]}
+    b = by["k_blur_pyr<16>"]
+    assert b["stage"] == "preprocess" and abs(b["hbm_GBps"] - 311e6 / 70e-6 / 1e9) < 1 and abs(b["frac_of_hbm_peak"] - b["hbm_GBps"] / 8000) < 1e-3
+    assert abs(b["valu_busy"] - 0.5) < 1e-3 and b["bound"] == "hbm"          # 4.4 TB/s = 0.70 of the achievable 6.3
+    assert "k_refine_plan" not in by and by["k_scan4<6, true, 2, false>"]["stage"] == "match"
+    assert pre["preprocess_hbm_bytes_per_frame"] == round(311e6 / 96) and pre["preprocess_live_us_per_launch"] == 380.0
+    assert bench.preprocess_roofline(None, "because", one_lane, 96) == {"kernels": None, "reason": "because"}
