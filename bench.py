@@ -115,6 +115,8 @@ class Runner:
             det.set_tuning(lm.TUNE_PYRDOWN_VARIANT, args.pyrdown_variant)
         if args.no_blur_pyr:
             det.set_tuning(lm.TUNE_BLUR_PYR, 0)
+        if args.blur_pyr >= 0:
+            det.set_tuning(lm.TUNE_BLUR_PYR, args.blur_pyr)
         if args.no_level_pairs:
             det.set_tuning(lm.TUNE_LEVEL_PAIRS, 0)
         if args.blur_strip:
@@ -381,6 +383,7 @@ def main():
     ap.add_argument("--pyrdown-variant", type=int, default=0, help="A/B knob: LM_TUNE_PYRDOWN_VARIANT (1: k_pyrdown8, 2: row-walking k_pyrdown16)")
     ap.add_argument("--blur-strip", type=int, default=0, choices=(0, 16, 32, 64), help="A/B knob: rows per strip of the level-0 blur (LM_TUNE_BLUR_STRIP)")
     ap.add_argument("--no-level-pairs", action="store_true", help="A/B knob: no slot-interleaved level pairs (LM_TUNE_LEVEL_PAIRS = 0)")
+    ap.add_argument("--blur-pyr", type=int, default=-1, choices=(-1, 0, 1, 2, 3), help="A/B knob: LM_TUNE_BLUR_PYR (1: blur and pyrDown tiles of a slot back to back, 2: dealt out evenly, 3: by frame size = default)")
     ap.add_argument("--no-blur-pyr", action="store_true", help="A/B knob: level-0 blur and pyrDown as two launches (LM_TUNE_BLUR_PYR = 0)")
     ap.add_argument("--sort-split", type=int, default=-1, choices=(-1, 0, 1, 2), help="A/B knob: LM_TUNE_SORT_SPLIT (0 one workgroup per frame, 1 chunk workgroups + merge launch, 2 adaptive = default)")
     ap.add_argument("--no-work-weight", action="store_true", help="A/B knob: few-frame / batch kernel selection by frame count alone (LM_TUNE_WORK_WEIGHT = 0, r03)")

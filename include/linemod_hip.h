@@ -212,7 +212,10 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
  *   frames, the row-walking kernel whose column sums travel between lanes from there), 1 / 2 = force either. */
 #define LM_TUNE_PYRDOWN_VARIANT 8
 /* LM_TUNE_BLUR_PYR (process-wide): batches run the level-0 Gaussian blur and cv::pyrDown level 0 -> 1 as ONE launch whose
- *   blocks are interleaved per frame slot (default 1; 0 = two launches). */
+ *   blocks are interleaved per frame slot: 1 = [all blur tiles | all pyrDown tiles] of a slot back to back (r03); 2 = a slot's blur
+ *   and pyrDown tiles dealt out evenly (r04), so the tiles of a band of rows run side by side and the second reader finds the
+ *   rows in the L2; 3 (default) = 2 for frames of more than 2 MB, 1 below (measured: pays at 1280 x 960, not at 640 x 480);
+ *   0 = two launches. */
 #define LM_TUNE_BLUR_PYR 9
 /* LM_TUNE_LEVEL_PAIRS (process-wide): batches of 16+ frames run the level-1 kernels inside the level-0 grids of their own
  *   register class, interleaved per frame slot (k_pair: median(0) | blur(1); gradient(0) | gradient(1); all four linear-memory

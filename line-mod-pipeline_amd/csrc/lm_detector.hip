@@ -1287,7 +1287,7 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
         case LM_TUNE_COPY_STREAMS: if (value < 1 || value > LM_NCOPY) break; d->n_copy_streams = value; return LM_OK;
         case LM_TUNE_BATCH_PHASES: if (value < 0 || value > 2) break; d->batch_phases = value; return LM_OK;
         case LM_TUNE_PYRDOWN_VARIANT: if (value < 0 || value > 2) break; lmk_set_pyrdown_variant(value); return LM_OK;
-        case LM_TUNE_BLUR_PYR: if (value < 0 || value > 1) break; lmk_set_blur_pyr(value); return LM_OK;
+        case LM_TUNE_BLUR_PYR: if (value < 0 || value > 3) break; lmk_set_blur_pyr(value != 0); lmk_set_blur_pyr_interleave(value == 2 ? 1 : value == 3 ? 2 : 0); return LM_OK;
         case LM_TUNE_LEVEL_PAIRS: if (value < 0 || value > 1) break; lmk_set_level_pairs(value); return LM_OK;
         case LM_TUNE_BLUR_STRIP: if (value != 0 && value != 16 && value != 32 && value != 64) break; lmk_set_blur_strip(value); return LM_OK;
         case LM_TUNE_DMEDIAN_VARIANT: if (value < 0 || value > 2) break; lmk_set_dmedian_variant(value); return LM_OK;

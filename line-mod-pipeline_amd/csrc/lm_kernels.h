@@ -24,6 +24,7 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
 // the two kernels itself).
 bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0, u8* bgr1, u8* quant0, size_t slot_stride, int nslots);
 void lmk_set_blur_pyr(int v);
+void lmk_set_blur_pyr_interleave(int v);
 void lmk_set_slot_weight(int w);   // frames count `w` times in the few-frame / batch kernel selection of this host thread's launches (1 = 640 x 480 frames)
 void lmk_set_blur_strip(int v);
 // a5: DepthNormal quantisation (normals + LUT + 5x5 median)

@@ -916,11 +916,21 @@ __global__ __launch_bounds__(256, 2) void k_cblur_sh(const u8* __restrict__ bgr0
 // the combined tile count), so the second reader finds the rows in that XCD's L2.  Both parts are of one register class.
 template <int SB>
 __global__ __launch_bounds__(256, 2) void k_blur_pyr(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0, u8* __restrict__ bgr1,
-                                                     size_t slot_stride, int g_blur, int g_pyr, int nslots) {
+                                                     size_t slot_stride, int g_blur, int g_pyr, int nslots, int interleave) {
     u32 slot, tile;
     xcd_slot_tile_b(blockIdx.x, (u32)(g_blur + g_pyr), (u32)nslots, slot, tile);
-    if (tile < (u32)g_blur) d_cblur_sh_st<SB>(slot, tile, bgr0, w, h, s0, slot_stride, slot_stride);
-    else d_pyrdown16_st<PD_STRIP>(slot, tile - (u32)g_blur, bgr0, w, h, bgr1, w >> 1, h >> 1, slot_stride);
+    if (!interleave) {
+        if (tile < (u32)g_blur) d_cblur_sh_st<SB>(slot, tile, bgr0, w, h, s0, slot_stride, slot_stride);
+        else d_pyrdown16_st<PD_STRIP>(slot, tile - (u32)g_blur, bgr0, w, h, bgr1, w >> 1, h >> 1, slot_stride);
+        return;
+    }
+    // r04: the two kinds of tiles of a slot are dealt out evenly (Bresenham), so that the pyrDown tile of a band of rows is dispatched
+    // among the blur tiles of the same band and finds the rows in the XCD's L2 while they are hot -- back to back ([all blur | all
+    // pyrDown]) the second reader came after the slot's 0.9 - 3.7 MB had left a 4 MB L2 shared with the other slots in flight.
+    const u32 G = (u32)(g_blur + g_pyr);
+    const u32 p1 = (tile + 1u) * (u32)g_pyr / G, p0 = tile * (u32)g_pyr / G;     // pyrDown tiles among the first tile + 1 / tile
+    if (p1 != p0) d_pyrdown16_st<PD_STRIP>(slot, p0, bgr0, w, h, bgr1, w >> 1, h >> 1, slot_stride);
+    else d_cblur_sh_st<SB>(slot, tile - p0, bgr0, w, h, s0, slot_stride, slot_stride);
 }
 
 // a2+a3  Sobel(S, BORDER_REPLICATE) + strongest channel + fastAtan2 + 16 -> 8 bins + magnitude flag.
@@ -3461,6 +3471,12 @@ size_t lmk_color_scratch_bytes(int w, int h) {
 
 static int g_blur_strip = 0;   // rows per strip of the level-0 blur inside k_blur_pyr: 0 = by shape and batch size, 16 / 32 / 64 = forced (A/B, tests)
 void lmk_set_blur_strip(int v) { g_blur_strip = v; }
+// k_blur_pyr: a slot's blur and pyrDown tiles dealt out evenly by rows (r04) instead of back to back.  Measured (tools/ab_blur_pyr.sh,
+// profiles/r04_ab_experiments.log): 1280 x 960 (3.7 MB per frame, never L2-resident back to back) reads 8.64 -> 7.54 MB per frame, the launch
+// 271.7 -> 260.1 us per 128 frames, config 3 +0.8 %; 640 x 480 reads 2.09 -> 1.98 MB but the launch gets 4 us LONGER (70.7 -> 74.7) and the
+// headline does not move: 2 (auto) deals evenly only frames of more than 2 MB, 1 always, 0 never.
+static int g_blur_pyr_interleave_mode = 2;
+void lmk_set_blur_pyr_interleave(int v) { g_blur_pyr_interleave_mode = v; }
 static int g_blur_pyr = 1;   // level-0 blur and cv::pyrDown of a batch in one slot-interleaved launch (k_blur_pyr); 0: two launches
 void lmk_set_blur_pyr(int v) { g_blur_pyr = v; }
 bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0, u8* bgr1, u8* quant0, size_t slot_stride, int nslots) {
@@ -3469,6 +3485,7 @@ bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0,
     if (!scratch0 || (w % 16) != 0 || (h % 2) != 0 || h < 4 || (slot_stride % 16) != 0) return false;
     if (((uintptr_t)bgr0 & 15) || ((uintptr_t)scratch0 & 15) || ((uintptr_t)quant0 & 15) || ((uintptr_t)bgr1 & 7)) return false;
     const int dh = h / 2;
+    const int g_blur_pyr_interleave = g_blur_pyr_interleave_mode == 1 || (g_blur_pyr_interleave_mode == 2 && (long)w * h * 3 > 2000000L);
     auto waves4 = [](int pairs) { return ((pairs + 61) / 62 + 3) / 4; };
     const int g_pyr = waves4((w / 16) * ((dh + PD_STRIP - 1) / PD_STRIP));
     // rows per blur strip: 16, or 32 for tall images.  A strip of S rows reads and sums S + 6 (16: 1.375 x the image, 32: 1.19 x, 64:
@@ -3476,15 +3493,15 @@ bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0,
     // 32 / 64, config 3 90.8 / 90.7 K at 32 / 64): fewer, longer waves
     if (g_blur_strip == 64) {
         const int g_blur = waves4((w * 3 / 16) * ((h + 63) / 64));
-        hipLaunchKernelGGL(k_blur_pyr<64>, dim3((unsigned)((g_blur + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, g_blur, g_pyr, nslots);
+        hipLaunchKernelGGL(k_blur_pyr<64>, dim3((unsigned)((g_blur + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, g_blur, g_pyr, nslots, g_blur_pyr_interleave);
     } else if (g_blur_strip == 32 || (g_blur_strip == 0 && h > 640 && (long)(waves4((w * 3 / 16) * ((h + 31) / 32)) + g_pyr) * nslots >= 768)) {
         // (r04: 32-row strips only when they still give the chip three rounds of workgroups -- eight 1280 x 960 frames, config 5,
         // are 312 workgroups of 32-row strips on 512 slots)
         const int g_blur = waves4((w * 3 / 16) * ((h + 31) / 32));
-        hipLaunchKernelGGL(k_blur_pyr<32>, dim3((unsigned)((g_blur + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, g_blur, g_pyr, nslots);
+        hipLaunchKernelGGL(k_blur_pyr<32>, dim3((unsigned)((g_blur + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, g_blur, g_pyr, nslots, g_blur_pyr_interleave);
     } else {
         const int g_blur = waves4((w * 3 / 16) * ((h + CBS_STRIP - 1) / CBS_STRIP));
-        hipLaunchKernelGGL(k_blur_pyr<CBS_STRIP>, dim3((unsigned)((g_blur + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, g_blur, g_pyr, nslots);
+        hipLaunchKernelGGL(k_blur_pyr<CBS_STRIP>, dim3((unsigned)((g_blur + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, g_blur, g_pyr, nslots, g_blur_pyr_interleave);
     }
     return true;
 }

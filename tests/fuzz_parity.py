@@ -89,8 +89,8 @@ while time.time() - t0 < budget:
     assert got.tobytes() == exp.tobytes(), ("match", color_only, T, w, h, n, thr, variant, len(got), len(exp))
     if nb > 1:
         d.set_tuning(lm.TUNE_PHASE_MAX_SLOTS, int(rng.choice([15, 0])))
-        d.set_tuning(lm.TUNE_BATCH_PHASES, int(rng.choice([0, 1, 2])))     # 16+ frames: level-fused batch launches or one per kernel
-        d.set_tuning(lm.TUNE_BLUR_PYR, int(rng.choice([0, 1])))            # level-0 blur + pyrDown in one launch or apart
+        d.set_tuning(lm.TUNE_BATCH_PHASES, int(rng.choice([0, 1, 2, 3])))     # 16+ frames: level-fused batch launches or one per kernel
+        d.set_tuning(lm.TUNE_BLUR_PYR, int(rng.choice([0, 1, 2, 3])))         # level-0 blur + pyrDown apart, in one launch back to back, or dealt out evenly
         d.set_tuning(lm.TUNE_BLUR_STRIP, int(rng.choice([0, 16, 32, 64])))      # rows per blur strip inside k_blur_pyr
         d.set_tuning(lm.TUNE_LEVEL_PAIRS, int(rng.choice([0, 1])))         # level-1 kernels inside the level-0 grids (k_pair) or not
         for k in range(nb):

@@ -256,10 +256,10 @@ def test_batches_take_one_launch_per_dependency_level(lm, orc, synth, color_only
     for k in range(n):
         b, dp = frames[(3 * k + 1) % 4]
         d.upload_frame(k, b, None if color_only else dp)
-    for phases, blur_pyr, pairs in ((0, 1, 1), (1, 1, 0), (0, 1, 0), (2, 1, 0), (0, 0, 0), (1, 0, 0), (1, 0, 1)):
+    for phases, blur_pyr, pairs in ((0, 1, 1), (1, 1, 0), (0, 1, 0), (2, 1, 0), (0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 2, 0), (1, 2, 0), (2, 2, 1)):
         d.set_tuning(lm.TUNE_BATCH_PHASES, phases)
         d.set_tuning(lm.TUNE_BLUR_STRIP, (0, 16, 32, 64)[(phases + 2 * pairs + blur_pyr) % 4])      # rows per blur strip inside k_blur_pyr
-        d.set_tuning(lm.TUNE_BLUR_PYR, blur_pyr)     # level-0 blur + pyrDown in one slot-interleaved launch, or apart
+        d.set_tuning(lm.TUNE_BLUR_PYR, blur_pyr)     # level-0 blur + pyrDown apart (0), in one launch back to back per slot (1), or dealt out evenly (2)
         d.set_tuning(lm.TUNE_LEVEL_PAIRS, pairs)     # level-1 kernels inside the level-0 grids of their register class (k_pair)
         for nb in (n, 16):
             out, cnt = d.match_batch(nb, THR, 0)
@@ -275,7 +275,7 @@ def test_batches_take_one_launch_per_dependency_level(lm, orc, synth, color_only
                 for mod in range(M):
                     assert np.array_equal(d.debug_read(k, 0, level, mod), o.stage(0, level, mod)), (phases, blur_pyr, pairs, k, level, mod)
                     assert np.array_equal(d.debug_read(k, 2, level, mod), o.stage(2, level, mod)), (phases, blur_pyr, pairs, k, level, mod)
-    d.set_tuning(lm.TUNE_BLUR_PYR, 1)
+    d.set_tuning(lm.TUNE_BLUR_PYR, 3)
     d.set_tuning(lm.TUNE_LEVEL_PAIRS, 0)
     d.set_tuning(lm.TUNE_BLUR_STRIP, 0)
     d.close()
