@@ -83,11 +83,15 @@ class Runner:
         if world > 1 and quota is not None and quota < 2 * world:
             flags |= lm.FLAG_BLOCKING_SYNC      # fewer CPUs than busy processes: do not spin while waiting for the GPU
         self.stream_sets = 2 if (world == 1 and not args.no_h2d) else 1
-        cfg = lm.default_config(color_only=wl["color_only"], width=W, height=H, device=local_rank, shard_rank=rank,
-                                shard_size=world, frame_slots=max(B, 1) * self.stream_sets, flags=flags)
+        # --parallelism template-shard (default): every rank holds 1 / N of the bank and sees the same frames, the lists are
+        # exchanged; frame-shard: every rank holds the WHOLE bank and matches its own frames, nothing is exchanged
+        self.frame_shard = getattr(args, "parallelism", "template-shard") == "frame-shard"
+        cfg = lm.default_config(color_only=wl["color_only"], width=W, height=H, device=local_rank, shard_rank=0 if self.frame_shard else rank,
+                                shard_size=1 if self.frame_shard else world, frame_slots=max(B, 1) * self.stream_sets, flags=flags)
         self.det = det = lm.Detector(cfg)
         # ---- workload: seeded synthetic frames + fixed-geometry bank
-        self.frames = [synth.make_frame(W, H, seed=wl["seed_frames"] + i) for i in range(B)]
+        seed0 = wl["seed_frames"] + (rank * B if self.frame_shard else 0)          # frame-shard: every rank its own frames
+        self.frames = [synth.make_frame(W, H, seed=seed0 + i) for i in range(B)]
         q = quantized_from_gpu(det, self.frames[0][0], self.frames[0][1], M)
         self.banks = []
         if wl.get("classes"):
@@ -143,11 +147,12 @@ class Runner:
                       for o, cn in self.bufs]
         self.k = 0
         self.last_owned = None
-        if exchange == "rccl":
+        if exchange in ("rccl", "rccl-barrier"):
             port = int(os.environ.get("MASTER_PORT", "29500")) + 1
             # fixed gather capacity: 1024 records per frame and rank on average over a lane-step (the bench bank yields
             # about 530 per frame and 3000-template shard at threshold 80); lists beyond it take the sized second exchange
             det.comm_init(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, args.gather_cap or 1024)
+        if exchange == "rccl":
             self.gbuf = [(np.zeros(self.Bl * self.cap // 4, lm.MATCH_DTYPE), np.zeros(self.Bl, np.int32)) for _ in range(self.NL)]
 
     # ------------------------------------------------------------------------------------------
@@ -290,9 +295,23 @@ def launch_ranks(n, argv):
     processes."""
     port = os.environ.get("MASTER_PORT")
     if not port:
-        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:     # a free port for this run (+1 is the ids' rendezvous)
-            sk.bind(("127.0.0.1", 0))
-            port = str(sk.getsockname()[1])
+        # a free port for this run whose successor is free as well: port + 1 is the rendezvous of the communicators' ids
+        for _ in range(64):
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                cand = sk.getsockname()[1]
+            if cand >= 65535:
+                continue
+            try:
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk2:
+                    sk2.bind(("127.0.0.1", cand + 1))
+            except OSError:
+                continue
+            port = str(cand)
+            break
+        else:
+            sys.stderr.write("bench.py: found no free port pair for the rendezvous\n")
+            return 1
     import threading
     procs = []
     captured = []
@@ -365,6 +384,11 @@ def main():
                          "for N > 1 with weak scaling, BASELINE config 4's dense viewpoint sphere: 24 300 x N / 8 in the "
                          "whole bank (N = 8: 24 300, 3037 / 3038 per GPU)")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--parallelism", default="template-shard", choices=("template-shard", "frame-shard"),
+                    help="template-shard (default, SURVEY 8e): the bank is split over the ranks, every rank pre-processes the same frames, the "
+                         "per-shard lists are all-gathered and merged; frame-shard: every rank holds the whole bank and matches its OWN frames -- "
+                         "no exchange, and the pre-processing (a3-a10, half of a rank's time) scales with N too: the split for batch workloads "
+                         "(BASELINE config 5) whose bank fits one GPU")
     ap.add_argument("--threshold", type=float, default=80.0)
     ap.add_argument("--gather-cap", type=int, default=0, help="lm_comm_init recs_per_frame_cap (0 = 1024)")
     ap.add_argument("--byte-responses", action="store_true", help="LM_FLAG_BYTE_RESPONSES: byte scan kernel (A/B)")
@@ -387,6 +411,9 @@ def main():
     ap.add_argument("--no-blur-pyr", action="store_true", help="A/B knob: level-0 blur and pyrDown as two launches (LM_TUNE_BLUR_PYR = 0)")
     ap.add_argument("--sort-split", type=int, default=-1, choices=(-1, 0, 1, 2), help="A/B knob: LM_TUNE_SORT_SPLIT (0 one workgroup per frame, 1 chunk workgroups + merge launch, 2 adaptive = default)")
     ap.add_argument("--no-work-weight", action="store_true", help="A/B knob: few-frame / batch kernel selection by frame count alone (LM_TUNE_WORK_WEIGHT = 0, r03)")
+    ap.add_argument("--no-pose-e2e", action="store_true", help="config 5: skip the pose_e2e leg (PoseDetection::detectBatch end to end, tools/pose_e2e_bench.cpp)")
+    ap.add_argument("--pose-e2e-iters", type=int, default=5)
+    ap.add_argument("--pose-e2e-host-colour", action="store_true", help="pose_e2e leg: also time the colour check on the host (one full-frame mask per match)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the h2d_inclusive (streaming) leg")
     ap.add_argument("--h2d-group", type=int, default=0,
@@ -403,7 +430,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     args = ap.parse_args()
 
-    if CONFIGS[args.config].get("classes"):
+    if CONFIGS[args.config].get("classes") and args.parallelism != "frame-shard":
         args.scaling = "strong"            # config 5's bank is fixed (3 x 8100 templates): N ranks shard it, it does not grow with N
     if not args.batch:
         args.batch = CONFIGS[args.config]["batch"] if not args.lanes else (128 if args.config != 5 else 8) * args.lanes
@@ -422,7 +449,10 @@ def main():
                          % (args.gpus, world))
     if not 0 <= rank < world:
         raise SystemExit("RANK %d outside WORLD_SIZE %d" % (rank, world))
-    if not args.templates:
+    if args.parallelism == "frame-shard":
+        args.templates_total = args.templates or 3000          # the whole bank on every rank; the frames grow with N (weak scaling)
+        args.scaling = "weak"
+    elif not args.templates:
         args.templates_total = (CONFIG4_TEMPLATES * world + 4) // 8 if (world > 1 and args.scaling == "weak") else 3000
     else:
         args.templates_total = args.templates * world if args.scaling == "weak" else args.templates
@@ -441,11 +471,16 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    frame_shard = args.parallelism == "frame-shard"
+    if frame_shard and args.functional_gloo:
+        raise SystemExit("--functional-gloo checks the exchange of the template-shard path; frame-shard has none")
     exchange = "gloo" if (args.functional_gloo and world > 1) else ("rccl" if (world > 1 or args.force_rccl) else "none")
+    if frame_shard and exchange == "rccl":
+        exchange = "rccl-barrier"           # the communicator only carries the barrier and the max of the ranks' times
     runner = Runner(args, rank, world, local_rank, exchange)
     det = runner.det
     rccl_ranks, bus_ids = None, [det.pci_bus_id()]
-    if exchange == "rccl":
+    if exchange in ("rccl", "rccl-barrier"):
         # the communicator really has one rank per GPU asked for, and the ranks really sit on different GPUs
         crank, cworld = det.comm_info()
         if cworld != args.gpus or crank != rank:
@@ -475,7 +510,7 @@ def main():
 
     def fence():
         # a barrier over the ranks + a device-wide synchronisation on both sides of the timed region
-        if exchange == "rccl":
+        if exchange in ("rccl", "rccl-barrier"):
             det.comm_barrier()                          # hipDeviceSynchronize + ncclAllReduce + hipDeviceSynchronize
         elif exchange == "gloo":
             det.synchronize()
@@ -494,7 +529,7 @@ def main():
     exch_us, exch_n, exch_fb = det.get_exchange_profile() if exchange == "rccl" else (0.0, 0, 0)
     det.set_profiling(False)
     one_lane = runner.one_lane_profile()
-    if exchange == "rccl":
+    if exchange in ("rccl", "rccl-barrier"):
         dt = det.comm_max([dt])[0]
     elif exchange == "gloo":
         import torch
@@ -504,7 +539,7 @@ def main():
 
     prof, Bl, NL = rep["prof"], rep["Bl"], rep["NL"]
     B = args.batch
-    fps = B * args.steps / dt
+    fps = B * (world if frame_shard else 1) * args.steps / dt          # frame-shard: every rank answered its own B frames per step
     if exchange == "rccl":
         n_matches0 = runner.last_owned[2] if runner.last_owned else 0        # merged list of the first owned frame
     elif exchange == "gloo":
@@ -521,7 +556,7 @@ def main():
     span_us = prof["stage_us"][1] / max(prof["launches"], 1)
     alg_bytes = prof["scan_bytes"] / max(prof["launches"], 1)
     ol_us = one_lane["stage_us"][1] / max(one_lane["launches"], 1)
-    cmeta = counters_meta(args, runner.n_total // world, Bl)
+    cmeta = counters_meta(args, runner.n_total if frame_shard else runner.n_total // world, Bl)
     ctr, ctr_reason = load_counters(cmeta)
     traffic = traffic_src = None
     if ctr:
@@ -618,6 +653,9 @@ def main():
             h2d = runner.streaming(max(args.steps // 4, 8))
         except Exception as e:                          # the bench line must still be printed
             h2d = {"error": "%s: %s" % (type(e).__name__, e)}
+    pose = None
+    if rank == 0 and world == 1 and CONFIGS[args.config].get("classes") and not args.no_pose_e2e:
+        pose = pose_e2e(args, runner, lm, 1e6 / fps)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, runner, lm)
@@ -629,15 +667,17 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl["name"] + ", threshold %g" % args.threshold,
                        "baseline_config": args.config,
-                       "templates_per_gpu": runner.n_total // world, "templates_total": runner.n_total,
-                       "frames_per_step": B, "lanes": NL, "frames_per_sec": round(fps, 1), "matches_frame0": n_matches0,
+                       "templates_per_gpu": runner.n_total if frame_shard else runner.n_total // world, "templates_total": runner.n_total,
+                       "frames_per_step": B * (world if frame_shard else 1), "lanes": NL, "frames_per_sec": round(fps, 1), "matches_frame0": n_matches0,
                        "list_lengths": runner.list_stats,
                        "unit_definition": "one detection = one frame answered against the whole %d-template bank "
                                           "(input frames resident in HBM)" % runner.n_total,
                        "template_frames_per_sec": round(fps * runner.n_total, 1),
                        "exchange": {"none": "single GPU", "gloo": "torch.distributed gloo (functional check only)",
                                     "rccl": "2 x ncclAllGather per lane-step from liblinemod_hip.so on the lane's stream; "
-                                            "each rank merges the frames it owns"}[exchange],
+                                            "each rank merges the frames it owns",
+                                    "rccl-barrier": "none in the data path (frame-shard: whole bank per rank, own frames per rank); the RCCL "
+                                                    "communicator carries only the barrier and the max of the ranks' times"}[exchange],
                        "rccl_ranks": rccl_ranks, "pci_bus_ids": bus_ids,
                        "functional_gloo": bool(args.functional_gloo) or None,
                        "exchange_span_us_per_lane_step": round(exch_us / exch_n, 2) if exch_n else None,
@@ -647,10 +687,11 @@ def main():
                                              "the gathered lists: k_pack_lists + 2 x ncclAllGather + 2 copies, per lane-step "
                                              "of %d frames (contains the wait for the slowest rank)" % Bl if exch_n else None,
                        "h2d_inclusive": h2d,
-                       "parallelism": "template-shard x%d" % world},
+                       "parallelism": "%s x%d" % (args.parallelism, world)},
             "roofline": roofline,
             "roofline_refine": roofline_refine,
             "roofline_preprocess": roofline_pre,
+            "pose_e2e": pose,
             "counters_meta": cmeta,
             "cpu_baseline": cpu,
         }
@@ -752,6 +793,76 @@ def pci_bus_number(s):
     dom, bus, rest = s.strip().split(":")
     dev, fn = rest.split(".")
     return (int(dom, 16) << 16) | (int(bus, 16) << 8) | (int(dev, 16) << 3) | int(fn, 16)
+
+
+def pose_e2e(args, runner, lm, hot_path_us_per_frame_resident):
+    """BASELINE configs[4] as it is worded -- "end-to-end PoseDetection incl. depth/color check" (VERDICT r3 #9): the C++ facade
+    lmamd::PoseDetection::detectBatch (tools/pose_e2e_bench.cpp, built here with g++ against liblinemod_hip.so and run as a child
+    process) on this run's own bank and its first 8 frames -- principal-point shift on the host, upload, one class-list match on
+    the GPU, then the reference's post-processing of every (class, frame).  The bank travels as the library's compact bank file;
+    the templates' poses (the reference's raw 48-byte Template records, HighLevelLinemod.h:130-148) are synthetic: bounding box =
+    the template's level-0 size, median depth and camera distance spread over the frames' depth range."""
+    import hashlib
+    import struct
+    import tempfile
+    try:
+        tools = os.path.join(ROOT, "tools", "pose_e2e_bench.cpp")
+        host = sorted(os.path.join(ROOT, "line-mod-pipeline_amd", "host", f) for f in os.listdir(os.path.join(ROOT, "line-mod-pipeline_amd", "host")) if f.endswith(".cpp"))
+        h = hashlib.sha256()
+        for path in [tools] + host + [lm.LIB_PATH]:
+            h.update(open(path, "rb").read())
+        exe = os.path.join(tempfile.gettempdir(), "lm_pose_e2e_bench_" + h.hexdigest()[:16])
+        if not os.path.exists(exe):
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-o", exe + ".tmp", tools] + host +
+                                  ["-L" + os.path.dirname(lm.LIB_PATH), "-llinemod_hip", "-Wl,-rpath," + os.path.dirname(lm.LIB_PATH)])
+            os.replace(exe + ".tmp", exe)
+        nf = min(8, len(runner.frames))
+        with tempfile.TemporaryDirectory() as td:
+            bank, pose, raw = os.path.join(td, "bench.bank"), os.path.join(td, "poses.bin"), os.path.join(td, "frames.raw")
+            runner.det.save_bank(bank)
+            rng = np.random.default_rng(99)
+            with open(pose, "wb") as f:
+                f.write(struct.pack("<I", len(runner.banks)))
+                for _, descs, _ in runner.banks:
+                    per = 2 * runner.M
+                    d0 = descs[0::per]                                   # level 0, modality 0 of every template
+                    rec = np.zeros(len(d0), np.dtype([("t", "<f4", 3), ("q", "<f4", 4), ("bb", "<i4", 4), ("md", "<u2"), ("pad", "<u2")]))
+                    rec["t"][:, 2] = -rng.uniform(600, 800, len(d0)); rec["q"][:, 3] = 1.0
+                    rec["bb"][:, 2] = d0["width"]; rec["bb"][:, 3] = d0["height"]
+                    rec["md"] = rng.integers(500, 1200, len(d0))
+                    assert rec.dtype.itemsize == 48
+                    f.write(struct.pack("<Q", len(rec))); f.write(rec.tobytes())
+            with open(raw, "wb") as f:
+                for bgr, depth in runner.frames[:nf]:
+                    f.write(np.ascontiguousarray(bgr).tobytes()); f.write(np.ascontiguousarray(depth, np.uint16).tobytes())
+            out = {}
+            for mode in (0, 1) if args.pose_e2e_host_colour else (0,):
+                r = subprocess.run([exe, bank, pose, raw, str(runner.W), str(runner.H), str(nf), str(args.threshold), str(args.pose_e2e_iters), str(mode)],
+                                   capture_output=True, text=True, timeout=900)
+                if r.returncode != 0:
+                    return {"error": "pose_e2e_bench exited with %d: %s" % (r.returncode, r.stderr[-500:])}
+                out["host" if mode else "gpu"] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        g = out["gpu"]
+        total = g["us_per_frame"]
+        res = {"value": round(1e6 / total, 1), "unit": "frames/s through PoseDetection::detectBatch (one batch of %d frames at a time, no lanes; host post-processing on up to 16 threads)" % nf,
+               "us_per_frame": total,
+               "breakdown_us_per_frame": {"principal_point_shift_host": g["shift_us_per_frame"], "upload_pageable": g["upload_us_per_frame"],
+                                          "hot_path_gpu_a3_a15": g["hot_path_us_per_frame"], "post_processing": g["post_us_per_frame"]},
+               "host_share": round(1.0 - g["hot_path_us_per_frame"] / total, 4),
+               "hot_path_us_per_frame_in_the_timed_region_above": round(hot_path_us_per_frame_resident, 2),
+               "post_processing_us_per_frame_by_part": g.get("post_us_per_frame_by_part"), "post_processing_counts_per_frame": g.get("per_frame_counts"),
+               "matches_per_frame": g["matches_per_frame"], "grouped_poses_per_frame": g["grouped_poses_per_frame"],
+               "classes": g["classes"], "templates": g["templates"], "frames": nf, "iterations": g["iterations"],
+               "note": "the reference's call pattern (PoseDetection.cpp:45-126, HighLevelLinemod.cpp:157-175,206-253,424-515) on the bench's bank and frames: "
+                       "post_processing = grouping + colour check (counts on the GPU, lm_color_check_counts) on the calling thread, then depth check + poses "
+                       "of the independent match groups on up to 16 host threads (the by-part figures are summed over the threads); synthetic "
+                       "template poses whose median depths rarely pass the depth check, so nearly every match of every surviving group is tested -- a "
+                       "pessimistic load for the reference's nth_element over the template's bounding box per tested match; `value` of the line is the hot path alone with resident frames and three lanes"}
+        if "host" in out:
+            res["with_host_colour_check_us_per_frame"] = out["host"]["us_per_frame"]
+        return res
+    except Exception as e:  # the bench line must still be printed
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def kernel_source_sha16():

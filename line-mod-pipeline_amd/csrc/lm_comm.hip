@@ -106,6 +106,9 @@ bool tcp_broadcast(int rank, int world, const char* addr, int port, int timeout_
             ::close(ls);
             return false;
         }
+        // the listening socket never blocks: a connection reset between poll() and accept() must send us back to poll() under the
+        // one deadline, not park us in accept()
+        fcntl(ls, F_SETFL, fcntl(ls, F_GETFL, 0) | O_NONBLOCK);
         std::vector<bool> seen((size_t)world, false);
         int served = 0, strays = 0;
         while (served < world - 1) {
@@ -120,9 +123,10 @@ bool tcp_broadcast(int rank, int world, const char* addr, int port, int timeout_
                 return false;
             }
             int fd = ::accept(ls, nullptr, nullptr);
-            if (fd < 0) continue;
-            // a peer that connects sends its 8 bytes at once: a short timeout keeps a silent stray from eating the deadline
-            set_io_timeout(fd, std::min(ms_left(deadline), 5000));
+            if (fd < 0) continue;                        // EAGAIN / ECONNABORTED: poll again
+            fcntl(fd, F_SETFL, fcntl(fd, F_GETFL, 0) & ~O_NONBLOCK);     // (an accepted socket may inherit the flag: the handshake below uses timeouts)
+            // a peer that connects sends its 8 bytes at once: half a second keeps a few silent strays from eating the real peers' retry window
+            set_io_timeout(fd, std::max(1, std::min(ms_left(deadline), 500)));
             int32_t hs[2] = {0, -1};
             const bool hello = recv_all(fd, hs, sizeof(hs)) && hs[0] == LM_RDV_MAGIC && hs[1] > 0 && hs[1] < world && !seen[(size_t)hs[1]];
             if (hello) {

@@ -2,10 +2,13 @@
 #include "HighLevelLinemod.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <fstream>
 #include <stdexcept>
+#include <thread>
 
 #include "PostProcess.h"
 #include "TemplateGenerator.h"
@@ -102,6 +105,7 @@ bool HighLevelLineMOD::detectTemplateBatch(std::vector<std::vector<Image>>& in_f
                                            std::vector<std::vector<lm_match_t>>& out_matches,
                                            std::vector<std::vector<std::vector<ObjectPose>>>& out_poses) {
     const int n = (int)in_frames.size();
+    error.clear();
     out_matches.assign((size_t)n, {});
     out_poses.assign((size_t)n, {});
     if (n == 0) return false;
@@ -143,9 +147,13 @@ bool HighLevelLineMOD::detectTemplatesBatch(std::vector<std::vector<Image>>& in_
                                             std::vector<std::vector<std::vector<std::vector<ObjectPose>>>>& out_poses) {
     const int n = (int)in_frames.size();
     const size_t nc = in_classNumbers.size();
+    error.clear();
     out_matches.assign(nc, std::vector<std::vector<lm_match_t>>((size_t)n));
     out_poses.assign(nc, std::vector<std::vector<std::vector<ObjectPose>>>((size_t)n));
     if (n == 0 || nc == 0) return false;
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const clk::time_point t_up = clk::now();
     for (int i = 0; i < n; ++i) {
         if (in_frames[(size_t)i].empty()) { error = "no images"; return false; }
         const Image& color = in_frames[(size_t)i][0];
@@ -156,6 +164,7 @@ bool HighLevelLineMOD::detectTemplatesBatch(std::vector<std::vector<Image>>& in_
                             match_depth ? static_cast<const uint16_t*>(match_depth->data) : nullptr,
                             match_depth ? match_depth->stride : 0) != LM_OK) { error = lm_last_error(); return false; }
     }
+    const clk::time_point t_match = clk::now();
     std::vector<int32_t> cls(in_classNumbers.begin(), in_classNumbers.end());
     size_t cap = 4096;
     std::vector<lm_match_t> buf;
@@ -174,9 +183,24 @@ bool HighLevelLineMOD::detectTemplatesBatch(std::vector<std::vector<Image>>& in_
         if (rc != LM_OK) { error = lm_last_error(); return false; }
         break;
     }
+    const clk::time_point t_post = clk::now();
+    stageTimes.upload += secs(t_up, t_match); stageTimes.match += secs(t_match, t_post); stageTimes.frames += n;
     bool any = false;
+    // ---- step 1, this thread (it owns the detector): split the mixed lists by class; per (class, frame) grouping + the GPU colour counts
+    struct Unit { size_t c; int i; PostProcessor pp; PostProcessor::Prepared prep; const std::vector<TemplatePose>* tpl; const uint16_t* depth; std::vector<uint16_t> dense; };
+    std::vector<Unit> units;
+    PostProcessSettings ps;
+    ps.onlyColorModality = onlyColorModality;
+    ps.videoWidth = videoWidth; ps.videoHeight = videoHeight; ps.fy = fy;
+    ps.stepSize = settings.stepSize; ps.percentToPassCheck = settings.percentToPassCheck;
+    ps.numberWantedPoses = settings.numberWantedPoses;
+    ps.radiusThresholdNewObject = settings.radiusThresholdNewObject;
+    ps.discardGroupRatio = settings.discardGroupRatio;
+    ps.useDepthImprovement = settings.useDepthImprovement; ps.depthOffset = settings.depthOffset;
+    units.reserve(nc * (size_t)n);
     for (int i = 0; i < n; ++i) {
         const lm_match_t* m = buf.data() + cap * (size_t)i;
+        stageTimes.matches += counts[(size_t)i];
         // the mixed list is in the total order; a class's sub-list keeps it
         for (size_t c = 0; c < nc; ++c) {
             std::vector<lm_match_t>& dst = out_matches[c][(size_t)i];
@@ -190,10 +214,61 @@ bool HighLevelLineMOD::detectTemplatesBatch(std::vector<std::vector<Image>>& in_
             }
             if (dst.empty()) continue;
             any = true;
+            const uint16_t cls_no = in_classNumbers[c];
+            if (!(cls_no < modelTemplates->size()) || (*modelTemplates)[cls_no].empty()) continue;       // no template poses: no post-processing
+            ModelProperties props;
+            if (cls_no < modProps->size()) props = (*modProps)[cls_no];
+            const Image& color = in_frames[(size_t)i][0];
             const Image* depth_img = in_frames[(size_t)i].size() >= 2 ? &in_frames[(size_t)i][1] : nullptr;
-            out_poses[c][(size_t)i] = postProcess(dst, in_frames[(size_t)i][0], depth_img, in_classNumbers[c], gpuColorCheck ? i : -1);
+            units.push_back(Unit{c, i, PostProcessor(detector, ps), {}, &(*modelTemplates)[cls_no], nullptr, {}});
+            Unit& u = units.back();
+            if (depth_img) {
+                u.depth = static_cast<const uint16_t*>(depth_img->data);
+                if (depth_img->stride && depth_img->stride != (size_t)videoWidth * 2) {
+                    u.dense.resize((size_t)videoWidth * videoHeight);
+                    for (int y = 0; y < videoHeight; ++y)
+                        std::memcpy(&u.dense[(size_t)y * videoWidth], reinterpret_cast<const uint8_t*>(depth_img->data) + (size_t)y * depth_img->stride, (size_t)videoWidth * 2);
+                    u.depth = u.dense.data();
+                }
+            }
+            u.prep = u.pp.prepare(dst, static_cast<const uint8_t*>(color.data), color.stride, *u.tpl, props, gpuColorCheck ? i : -1);
+            if (!u.pp.lastError().empty()) error = u.pp.lastError();
         }
     }
+    // ---- step 2, any thread: one task per group of every unit (the sequential accept / break loop of a group: colour verdict,
+    // depth check, pose); results land in per-task slots and are put together in group order afterwards
+    struct Task { size_t unit, group; };
+    std::vector<Task> tasks;
+    for (size_t k = 0; k < units.size(); ++k)
+        for (size_t g = 0; g < units[k].prep.groups.size(); ++g) tasks.push_back(Task{k, g});
+    std::vector<std::vector<ObjectPose>> results(tasks.size());
+    int nthreads = postThreads > 0 ? postThreads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    nthreads = (int)std::min<size_t>((size_t)nthreads, std::max<size_t>(tasks.size(), 1));
+    std::vector<PostProcessor::Times> wt((size_t)nthreads);
+    std::atomic<size_t> next{0};
+    auto worker = [&](int w) {
+        for (;;) {
+            const size_t t = next.fetch_add(1);
+            if (t >= tasks.size()) break;
+            const Unit& u = units[tasks[t].unit];
+            results[t] = u.pp.finish_group(u.prep, tasks[t].group, out_matches[u.c][(size_t)u.i], u.depth, *u.tpl, &wt[(size_t)w]);
+        }
+    };
+    if (nthreads <= 1) worker(0);
+    else {
+        std::vector<std::thread> th;
+        for (int w = 1; w < nthreads; ++w) th.emplace_back(worker, w);
+        worker(0);
+        for (std::thread& t : th) t.join();
+    }
+    for (const PostProcessor::Times& t : wt) PostProcessor::times().add(t);
+    for (size_t t = 0; t < tasks.size(); ++t) {
+        if (results[t].empty()) continue;
+        const Unit& u = units[tasks[t].unit];
+        stageTimes.poses += (long)results[t].size();
+        out_poses[u.c][(size_t)u.i].push_back(std::move(results[t]));
+    }
+    stageTimes.post += secs(t_post, clk::now());
     return any;
 }
 
@@ -211,12 +286,16 @@ void HighLevelLineMOD::writeLinemod() {
     }
 }
 
-void HighLevelLineMOD::readLinemod() {
+void HighLevelLineMOD::readLinemod() { readLinemodFrom("linemod_templates.yml.gz", "linemod_tempPosFile.bin"); }
+
+void HighLevelLineMOD::readLinemodFrom(const std::string& templateFile, const std::string& poseFile) {
     templates->clear();
     modelTemplates->clear();
     // detector->read(fs.root()); readClass per entry of "classes"  (:292-303)
-    if (lm_load_yaml(detector, "linemod_templates.yml.gz") != LM_OK) { error = lm_last_error(); std::printf("ERROR::%s\n", error.c_str()); }
-    std::ifstream f("linemod_tempPosFile.bin", std::ios::in | std::ios::binary);
+    auto ends_with = [&](const char* suf) { const std::string t(suf); return templateFile.size() >= t.size() && templateFile.compare(templateFile.size() - t.size(), t.size(), t) == 0; };
+    const bool yaml = ends_with(".yml") || ends_with(".yml.gz") || ends_with(".yaml");
+    if ((yaml ? lm_load_yaml(detector, templateFile.c_str()) : lm_load_bank(detector, templateFile.c_str())) != LM_OK) { error = lm_last_error(); std::printf("ERROR::%s\n", error.c_str()); }
+    std::ifstream f(poseFile, std::ios::in | std::ios::binary);
     uint32_t nvec = 0;
     if (f && f.read(reinterpret_cast<char*>(&nvec), sizeof(nvec))) {
         for (uint32_t c = 0; c < nvec; ++c) {

@@ -99,6 +99,10 @@ public:
                               std::vector<std::vector<std::vector<std::vector<ObjectPose>>>>& out_poses);
     // colour checks of the post-processing on the GPU (default) or on the host (the reference's one-match-at-a-time way)
     void setGpuColorCheck(bool on) { gpuColorCheck = on; }
+    // host threads of detectTemplatesBatch's post-processing (r04): the groups of all (class, frame) pairs of a batch are independent
+    // once their colour counts are known, and the reference's depth check (an nth_element over the template's bounding box per
+    // tested match) is 80 % of the batch's wall time on ONE thread.  0 (default) = one per hardware thread, at most 16; 1 = serial.
+    void setPostThreads(int n) { postThreads = n < 0 ? 0 : n; }
     // detector frame slots needed by detectTemplateBatch: lm_config.frame_slots (default 8)
     static constexpr int kBatchSlots = 8;
 
@@ -110,6 +114,17 @@ public:
     // reference's own raw pose file "linemod_tempPosFile.bin" (:272-284, :302-318).
     void writeLinemod();
     void readLinemod();
+    // readLinemod from named files: a template file in cv::FileStorage's YAML layout (".yml" / ".yml.gz") or this library's
+    // compact bank file (anything else: lm_load_bank), plus the raw pose file.  readLinemod() = the reference's two fixed names.
+    void readLinemodFrom(const std::string& templateFile, const std::string& poseFile);
+
+    // Where the wall time of the batch entry points went (not in the reference; bench.py's pose_e2e leg): seconds accumulated since
+    // resetTimes() -- upload = lm_upload_frame of every frame (staging copy + H2D enqueue), match = the hot path (lm_match_batch*,
+    // a3-a15 on the GPU, synchronous), post = the reference's post-processing of every (class, frame): grouping, colour check
+    // (GPU counts or host masks), depth check, poses.
+    struct StageTimes { double upload = 0, match = 0, post = 0; long frames = 0, matches = 0, poses = 0; };
+    const StageTimes& times() const { return stageTimes; }
+    void resetTimes() { stageTimes = StageTimes(); }
 
     // :68-110.  From one rendered colour+depth pair: one template per in-plane rotation angleStart..angleStop
     // (warpAffine of mask / binarised colour / depth, erode, Detector::addTemplate), with the template
@@ -137,6 +152,8 @@ private:
     std::vector<ModelProperties>* modProps;                   // :169
     std::string error;
     bool gpuColorCheck = true;
+    int postThreads = 0;
+    StageTimes stageTimes;
     void readColorRanges();
     std::vector<std::vector<ObjectPose>> postProcess(const std::vector<lm_match_t>& in_matches, const Image& color,
                                                      const Image* depth_img, uint16_t in_classNumber, int gpu_slot);

@@ -78,34 +78,47 @@ void PoseDetection::detect(std::vector<Image>& in_imgs, std::string const& in_cl
         for (const ObjectPose& p : finalObjectPoses) in_objPose.push_back(p);
 }
 
-void PoseDetection::detectBatch(std::vector<std::vector<Image>>& in_frames, std::string const& in_className,
+bool PoseDetection::detectBatch(std::vector<std::vector<Image>>& in_frames, std::string const& in_className,
                                 uint16_t const& in_numberOfObjects, std::vector<std::vector<ObjectPose>>& out) {
+    error.clear();
+    out.assign(in_frames.size(), {});
     const uint16_t numClassIndex = findIndexInVector(in_className, ids);
-    std::vector<Shifted> bufs(in_frames.size());
+    if (numClassIndex >= ids.size()) { error = "unknown class name: " + in_className; return false; }   // (find's not-found index = ids.size())
+    if (in_frames.size() > (size_t)HighLevelLineMOD::kBatchSlots) { error = "batch of " + std::to_string(in_frames.size()) + " frames exceeds the detector's frame slots"; return false; }
+    if (batchBufs.size() < in_frames.size()) batchBufs.resize(in_frames.size());
     std::vector<std::vector<Image>> shifted(in_frames.size());
-    for (size_t i = 0; i < in_frames.size(); ++i) shiftFrame(in_frames[i], bufs[i], shifted[i]);
+    for (size_t i = 0; i < in_frames.size(); ++i) shiftFrame(in_frames[i], batchBufs[i], shifted[i]);
     std::vector<std::vector<lm_match_t>> m;
     std::vector<std::vector<std::vector<ObjectPose>>> groups;
     line->detectTemplateBatch(shifted, numClassIndex, m, groups);
-    out.assign(in_frames.size(), {});
-    for (size_t i = 0; i < in_frames.size(); ++i) pickFinal(groups[i], in_numberOfObjects, out[i]);
+    if (!line->lastError().empty()) { error = line->lastError(); return false; }     // (the batch entry points clear it on entry)
+    for (size_t i = 0; i < in_frames.size() && i < groups.size(); ++i) pickFinal(groups[i], in_numberOfObjects, out[i]);
     finalObjectPoses = out.empty() ? std::vector<ObjectPose>() : out.back();
+    return true;
 }
 
-void PoseDetection::detectBatch(std::vector<std::vector<Image>>& in_frames, std::vector<std::string> const& in_classNames,
+bool PoseDetection::detectBatch(std::vector<std::vector<Image>>& in_frames, std::vector<std::string> const& in_classNames,
                                 uint16_t const& in_numberOfObjects, std::vector<std::vector<std::vector<ObjectPose>>>& out) {
+    error.clear();
+    out.assign(in_classNames.size(), std::vector<std::vector<ObjectPose>>(in_frames.size()));
     std::vector<uint16_t> idx;
-    for (const std::string& nme : in_classNames) idx.push_back(findIndexInVector(nme, ids));
-    std::vector<Shifted> bufs(in_frames.size());
+    for (const std::string& nme : in_classNames) {
+        const uint16_t k = findIndexInVector(nme, ids);
+        if (k >= ids.size()) { error = "unknown class name: " + nme; return false; }
+        idx.push_back(k);
+    }
+    if (in_frames.size() > (size_t)HighLevelLineMOD::kBatchSlots) { error = "batch of " + std::to_string(in_frames.size()) + " frames exceeds the detector's frame slots"; return false; }
+    if (batchBufs.size() < in_frames.size()) batchBufs.resize(in_frames.size());
     std::vector<std::vector<Image>> shifted(in_frames.size());
-    for (size_t i = 0; i < in_frames.size(); ++i) shiftFrame(in_frames[i], bufs[i], shifted[i]);
+    for (size_t i = 0; i < in_frames.size(); ++i) shiftFrame(in_frames[i], batchBufs[i], shifted[i]);
     std::vector<std::vector<std::vector<lm_match_t>>> m;
     std::vector<std::vector<std::vector<std::vector<ObjectPose>>>> groups;
     line->detectTemplatesBatch(shifted, idx, m, groups);
-    out.assign(in_classNames.size(), std::vector<std::vector<ObjectPose>>(in_frames.size()));
-    for (size_t c = 0; c < in_classNames.size(); ++c)
-        for (size_t i = 0; i < in_frames.size(); ++i) pickFinal(groups[c][i], in_numberOfObjects, out[c][i]);
+    if (!line->lastError().empty()) { error = line->lastError(); return false; }     // (the batch entry points clear it on entry)
+    for (size_t c = 0; c < in_classNames.size() && c < groups.size(); ++c)
+        for (size_t i = 0; i < in_frames.size() && i < groups[c].size(); ++i) pickFinal(groups[c][i], in_numberOfObjects, out[c][i]);
     finalObjectPoses = (out.empty() || out.back().empty()) ? std::vector<ObjectPose>() : out.back().back();
+    return true;
 }
 
 }  // namespace lmamd

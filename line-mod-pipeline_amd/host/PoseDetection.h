@@ -31,15 +31,19 @@ public:
     void detect(std::vector<Image>& in_imgs, std::string const& in_className, uint16_t const& in_numberOfObjects,
                 std::vector<ObjectPose>& in_objPose, bool in_displayResults);
     // The same for a batch of frames in one pass over the GPU (BASELINE config 5): out[i] = final poses of frame i.
-    void detectBatch(std::vector<std::vector<Image>>& in_frames, std::string const& in_className,
+    // Returns false -- with the reason in lastError() -- when the class name is unknown, the batch exceeds the detector's frame
+    // slots, or the match fails (capacity overflow, ...): "nothing detected" is true with empty pose lists (r04, ADVICE r3: the
+    // reference's void detect cannot tell the two apart; the C ABI underneath can).
+    bool detectBatch(std::vector<std::vector<Image>>& in_frames, std::string const& in_className,
                      uint16_t const& in_numberOfObjects, std::vector<std::vector<ObjectPose>>& out_objPoses);
     // Several objects in the same batch of frames (BASELINE config 5: >= 3 models): one upload and one pre-processing per
     // frame for ALL the classes (the reference calls detect once per class name on the same camera frame and pays
     // Detector::match's pyramid each time, PoseDetection.cpp:45-66).  out[c][i] = final poses of class in_classNames[c] in
     // frame i.
-    void detectBatch(std::vector<std::vector<Image>>& in_frames, std::vector<std::string> const& in_classNames,
+    bool detectBatch(std::vector<std::vector<Image>>& in_frames, std::vector<std::string> const& in_classNames,
                      uint16_t const& in_numberOfObjects, std::vector<std::vector<std::vector<ObjectPose>>>& out_objPoses);
     const std::vector<ObjectPose>& getFinalObjectPoses() const { return finalObjectPoses; }
+    const std::string& lastError() const { return error; }
 
 private:
     uint16_t findIndexInVector(std::string const& in_stringToFind, std::vector<std::string>& in_vectorToLookIn);   // :134-140
@@ -49,8 +53,10 @@ private:
     std::vector<std::string> ids;
     std::vector<std::vector<ObjectPose>> detectedPoses;
     std::vector<ObjectPose> finalObjectPoses;
+    std::string error;
     // shifted copies of one frame (translateImg works in place on clones, :54-59)
     struct Shifted { std::vector<uint8_t> color; std::vector<uint16_t> depth; };
+    std::vector<Shifted> batchBufs;      // detectBatch's shifted frames, kept between calls (6 MB of fresh pages per 1280 x 960 frame otherwise)
     void shiftFrame(const std::vector<Image>& in_imgs, Shifted& buf, std::vector<Image>& out);
     void pickFinal(const std::vector<std::vector<ObjectPose>>& groups, uint16_t nObjects, std::vector<ObjectPose>& out);
 };

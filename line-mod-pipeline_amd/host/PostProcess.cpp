@@ -3,6 +3,7 @@
 #include "PostProcess.h"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstring>
@@ -136,46 +137,39 @@ void bgr2hsv_inrange(const uint8_t* bgr, int w, int h, size_t stride, const doub
     }
 }
 
-void translate_u8c3(const uint8_t* src, int w, int h, int ox, int oy, std::vector<uint8_t>& dst) {
-    dst.assign((size_t)w * h * 3, 0);
+// (row-wise: the shift is an integer translation with zeros shifted in, so every destination row is one memcpy of the overlapping
+// span; the per-pixel form of r03 took 1.1 ms per 1280 x 960 RGB-D frame, bench.py's pose_e2e leg)
+template <typename T, int C>
+static void translate_rows(const T* src, int w, int h, int ox, int oy, std::vector<T>& dst) {
+    dst.resize((size_t)w * h * C);                                // (a reused buffer keeps its pages; every element is written below)
+    const int x0 = std::max(ox, 0), x1 = std::min(w + ox, w);     // destination columns [x0, x1) have a source pixel
+    const int y0 = std::max(oy, 0), y1 = std::min(h + oy, h);
     for (int y = 0; y < h; ++y) {
-        int sy = y - oy;
-        if (sy < 0 || sy >= h) continue;
-        for (int x = 0; x < w; ++x) {
-            int sx = x - ox;
-            if (sx < 0 || sx >= w) continue;
-            std::memcpy(&dst[((size_t)y * w + x) * 3], &src[((size_t)sy * w + sx) * 3], 3);
-        }
+        T* row = &dst[(size_t)y * w * C];
+        if (y < y0 || y >= y1 || x1 <= x0) { std::memset(row, 0, (size_t)w * C * sizeof(T)); continue; }
+        if (x0 > 0) std::memset(row, 0, (size_t)x0 * C * sizeof(T));
+        std::memcpy(row + (size_t)x0 * C, &src[((size_t)(y - oy) * w + (x0 - ox)) * C], (size_t)(x1 - x0) * C * sizeof(T));
+        if (x1 < w) std::memset(row + (size_t)x1 * C, 0, (size_t)(w - x1) * C * sizeof(T));
     }
 }
-void translate_u16(const uint16_t* src, int w, int h, int ox, int oy, std::vector<uint16_t>& dst) {
-    dst.assign((size_t)w * h, 0);
-    for (int y = 0; y < h; ++y) {
-        int sy = y - oy;
-        if (sy < 0 || sy >= h) continue;
-        for (int x = 0; x < w; ++x) {
-            int sx = x - ox;
-            if (sx >= 0 && sx < w) dst[(size_t)y * w + x] = src[(size_t)sy * w + sx];
-        }
-    }
-}
+void translate_u8c3(const uint8_t* src, int w, int h, int ox, int oy, std::vector<uint8_t>& dst) { translate_rows<uint8_t, 3>(src, w, h, ox, oy, dst); }
+void translate_u16(const uint16_t* src, int w, int h, int ox, int oy, std::vector<uint16_t>& dst) { translate_rows<uint16_t, 1>(src, w, h, ox, oy, dst); }
 
-// medianMat (:336-349).  NOTE the reference's quirk, kept on purpose: it partitions at n/4 but returns
-// element n/position (position = 5), i.e. some element of the lower quarter in whatever order
-// std::nth_element left it.  Using the same std::nth_element on the same row-major data reproduces
-// it when built against the same standard library.
 uint16_t median_mat(const uint16_t* depth, int w, int h, Rect bb, uint8_t position) {
     int x0 = std::max(bb.x, 0), y0 = std::max(bb.y, 0);
     int x1 = std::min(bb.x + bb.width, w), y1 = std::min(bb.y + bb.height, h);   // cv::Mat ROI would assert; we clip
-    std::vector<uint16_t> v;
-    for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) {
-            uint16_t d = depth[(size_t)y * w + x];
-            v.push_back(d > 1 ? d : (uint16_t)65535);   // threshold(.., 1, 65535) inverted and added with saturation
-        }
-    if (v.empty() || position == 0) return 65535;
-    std::nth_element(v.begin(), v.begin() + v.size() / 4, v.end());
-    return v[v.size() / position];
+    if (x1 <= x0 || y1 <= y0 || position == 0) return 65535;
+    static thread_local std::vector<uint16_t> v;      // (one buffer per thread: a call per match, thousands per frame batch)
+    const size_t rw = (size_t)(x1 - x0), n = rw * (size_t)(y1 - y0);
+    v.resize(n);
+    uint16_t* o = v.data();
+    for (int y = y0; y < y1; ++y) {
+        const uint16_t* r = depth + (size_t)y * w + x0;
+        for (size_t x = 0; x < rw; ++x) o[x] = r[x] > 1 ? r[x] : (uint16_t)65535;   // threshold(.., 1, 65535) inverted and added with saturation
+        o += rw;
+    }
+    std::nth_element(v.begin(), v.begin() + (ptrdiff_t)(n / 4), v.end());
+    return v[n / position];
 }
 
 std::vector<Pt> convex_hull(std::vector<Pt> p) {   // Andrew's monotone chain, counter-clockwise, collinear points dropped
@@ -292,7 +286,7 @@ void calculate_template_pose(Vec3 cam, int16_t inplaneRot, float t[3], float q[4
 // ==================================================================================================
 // PostProcessor
 // ==================================================================================================
-bool PostProcessor::color_counts(const lm_match_t& m, const std::vector<uint8_t>& color_mask, long* in_hull, long* in_both) {
+bool PostProcessor::color_counts(const lm_match_t& m, const std::vector<uint8_t>& color_mask, long* in_hull, long* in_both) const {
     std::vector<Pt> pts;
     const int M = lm_num_modalities(det);
     *in_hull = 0; *in_both = 0;
@@ -313,13 +307,13 @@ static bool color_verdict(long in_hull, long in_both, uint16_t percentToPassChec
     return nonZer > (float)percentToPassCheck;
 }
 
-bool PostProcessor::color_check(const lm_match_t& m, const std::vector<uint8_t>& color_mask) {
+bool PostProcessor::color_check(const lm_match_t& m, const std::vector<uint8_t>& color_mask) const {
     long in_hull = 0, in_both = 0;
     if (!color_counts(m, color_mask, &in_hull, &in_both)) return false;
     return color_verdict(in_hull, in_both, st.percentToPassCheck);
 }
 
-bool PostProcessor::depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth) {
+bool PostProcessor::depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth) const {
     const TemplatePose& tp = t[(size_t)m.template_id];
     if (st.useDepthImprovement) {
         Rect bb{m.x, m.y, tp.bb[2], tp.bb[3]};
@@ -331,7 +325,7 @@ bool PostProcessor::depth_check(const lm_match_t& m, const uint16_t* depth, cons
     return true;
 }
 
-ObjectPose PostProcessor::make_pose(const lm_match_t& m, const std::vector<TemplatePose>& t, int32_t tempDepth) {
+ObjectPose PostProcessor::make_pose(const lm_match_t& m, const std::vector<TemplatePose>& t, int32_t tempDepth) const {
     const TemplatePose& tp = t[(size_t)m.template_id];
     const int halfW = st.videoWidth / 2, halfH = st.videoHeight / 2;
     // matchToPixelCoord (:497-503)
@@ -354,6 +348,72 @@ ObjectPose PostProcessor::make_pose(const lm_match_t& m, const std::vector<Templ
     return pose;
 }
 
+PostProcessor::Times& PostProcessor::times() { static thread_local Times t; return t; }
+
+PostProcessor::Prepared PostProcessor::prepare(const std::vector<lm_match_t>& matches, const uint8_t* bgr, size_t bgr_stride,
+                                               const std::vector<TemplatePose>& templates, const ModelProperties& props, int gpu_slot) {
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    Times& tm = times();
+    Prepared p;
+    p.gpu = gpu_slot >= 0;
+    if (matches.empty()) return p;
+    const int w = st.videoWidth, h = st.videoHeight;
+    const clk::time_point t_g = clk::now();
+    p.groups = discard_small_groups(group_similar_matches(matches, st.radiusThresholdNewObject), st.discardGroupRatio);
+    const clk::time_point t_c = clk::now();
+    tm.grouping += secs(t_g, t_c); tm.groups += (long)p.groups.size();
+    // colour check: on the host one match at a time as the reference does (:424-434), or every match of every surviving
+    // group in one GPU batch up front -- the sequential accept / break logic of finish_group then only looks the verdicts up
+    p.gpos.assign(matches.size(), (size_t)-1);
+    if (p.gpu) {
+        std::vector<lm_match_t> todo;
+        for (const MatchGroup& g : p.groups)
+            for (uint32_t idx : g.matchIndices)
+                if ((size_t)matches[idx].template_id < templates.size()) { p.gpos[idx] = todo.size(); todo.push_back(matches[idx]); }
+        p.gin.resize(todo.size()); p.gboth.resize(todo.size());
+        if (lm_color_check_counts(det, gpu_slot, props.lowerColorRange, props.upperColorRange, todo.data(), todo.size(),
+                                  p.gin.data(), p.gboth.data()) != LM_OK) {
+            // loud, never a silent switch of implementation: frames of up to 4992 rows run on the GPU; beyond that the
+            // caller selects the host check (HighLevelLineMOD::setGpuColorCheck(false))
+            error = lm_last_error();
+            p.failed = true;
+            p.groups.clear();
+        }
+    } else {
+        bgr2hsv_inrange(bgr, w, h, bgr_stride, props.lowerColorRange, props.upperColorRange, p.color_mask);   // :159-161
+    }
+    tm.colour += secs(t_c, clk::now()); tm.colour_checks += (long)p.gin.size();
+    return p;
+}
+
+// :165-174, applyPostProcessing (:382-421) for one group
+std::vector<ObjectPose> PostProcessor::finish_group(const Prepared& p, size_t group, const std::vector<lm_match_t>& matches, const uint16_t* depth_rows,
+                                                    const std::vector<TemplatePose>& templates, Times* tm) const {
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    std::vector<ObjectPose> objPoses;
+    for (uint32_t idx : p.groups[group].matchIndices) {
+        const lm_match_t& m = matches[idx];
+        if ((size_t)m.template_id >= templates.size()) continue;
+        int32_t tempDepth = (int32_t)templates[(size_t)m.template_id].translation[2];
+        bool ok = p.gpu ? color_verdict((long)p.gin[p.gpos[idx]], (long)p.gboth[p.gpos[idx]], st.percentToPassCheck)
+                        : color_check(m, p.color_mask);
+        if (ok && depth_rows) {                                                       // && short-circuit like the reference
+            const clk::time_point t_d = clk::now();
+            ok = depth_check(m, depth_rows, templates, &tempDepth);
+            if (tm) { tm->depth += secs(t_d, clk::now()); tm->depth_checks += 1; }
+        }
+        if (ok) {
+            const clk::time_point t_p = clk::now();
+            objPoses.push_back(make_pose(m, templates, tempDepth));
+            if (tm) { tm->pose += secs(t_p, clk::now()); tm->poses += 1; }
+        }
+        if (objPoses.size() == st.numberWantedPoses) break;
+    }
+    return objPoses;
+}
+
 std::vector<std::vector<ObjectPose>> PostProcessor::run(const std::vector<lm_match_t>& matches, const uint8_t* bgr,
                                                         size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
                                                         const std::vector<TemplatePose>& templates, const ModelProperties& props,
@@ -362,46 +422,16 @@ std::vector<std::vector<ObjectPose>> PostProcessor::run(const std::vector<lm_mat
     if (matches.empty()) return poses;
     const int w = st.videoWidth, h = st.videoHeight;
     std::vector<uint16_t> dense_depth;
-    if (depth) {
-        if (depth_stride == 0) depth_stride = (size_t)w * 2;
+    const uint16_t* depth_rows = depth;                 // dense rows: used where they are (no copy per class and frame)
+    if (depth && depth_stride != 0 && depth_stride != (size_t)w * 2) {
         dense_depth.resize((size_t)w * h);
         for (int y = 0; y < h; ++y)
             std::memcpy(&dense_depth[(size_t)y * w], reinterpret_cast<const uint8_t*>(depth) + y * depth_stride, (size_t)w * 2);
+        depth_rows = dense_depth.data();
     }
-    std::vector<MatchGroup> groups = discard_small_groups(group_similar_matches(matches, st.radiusThresholdNewObject), st.discardGroupRatio);
-    // colour check: on the host one match at a time as the reference does (:424-434), or every match of every surviving
-    // group in one GPU batch up front -- the sequential accept / break logic below then only looks the verdicts up
-    std::vector<uint8_t> color_mask;
-    std::vector<int64_t> gin, gboth;
-    std::vector<size_t> gpos(matches.size(), (size_t)-1);
-    if (gpu_slot >= 0) {
-        std::vector<lm_match_t> todo;
-        for (const MatchGroup& g : groups)
-            for (uint32_t idx : g.matchIndices)
-                if ((size_t)matches[idx].template_id < templates.size()) { gpos[idx] = todo.size(); todo.push_back(matches[idx]); }
-        gin.resize(todo.size()); gboth.resize(todo.size());
-        if (lm_color_check_counts(det, gpu_slot, props.lowerColorRange, props.upperColorRange, todo.data(), todo.size(),
-                                  gin.data(), gboth.data()) != LM_OK) {
-            // loud, never a silent switch of implementation: frames of up to 4992 rows run on the GPU; beyond that the
-            // caller selects the host check (HighLevelLineMOD::setGpuColorCheck(false))
-            error = lm_last_error();
-            return poses;
-        }
-    } else {
-        bgr2hsv_inrange(bgr, w, h, bgr_stride, props.lowerColorRange, props.upperColorRange, color_mask);   // :159-161
-    }
-    for (const MatchGroup& g : groups) {   // :165-174, applyPostProcessing (:382-421)
-        std::vector<ObjectPose> objPoses;
-        for (uint32_t idx : g.matchIndices) {
-            const lm_match_t& m = matches[idx];
-            if ((size_t)m.template_id >= templates.size()) continue;
-            int32_t tempDepth = (int32_t)templates[(size_t)m.template_id].translation[2];
-            bool ok = gpu_slot >= 0 ? color_verdict((long)gin[gpos[idx]], (long)gboth[gpos[idx]], st.percentToPassCheck)
-                                    : color_check(m, color_mask);
-            if (ok && depth) ok = depth_check(m, dense_depth.data(), templates, &tempDepth);   // && short-circuit like the reference
-            if (ok) objPoses.push_back(make_pose(m, templates, tempDepth));
-            if (objPoses.size() == st.numberWantedPoses) break;
-        }
+    const Prepared p = prepare(matches, bgr, bgr_stride, templates, props, gpu_slot);
+    for (size_t g = 0; g < p.groups.size(); ++g) {
+        std::vector<ObjectPose> objPoses = finish_group(p, g, matches, depth_rows, templates, &times());
         if (!objPoses.empty()) poses.push_back(objPoses);
     }
     return poses;

@@ -93,15 +93,38 @@ public:
                                              const uint16_t* depth, size_t depth_stride,
                                              const std::vector<TemplatePose>& templates, const ModelProperties& props,
                                              int gpu_slot = -1);
+    // where run()'s wall time went, accumulated over all PostProcessors of the thread since resetTimes() (bench.py's pose_e2e leg)
+    struct Times {
+        double grouping = 0, colour = 0, depth = 0, pose = 0; long colour_checks = 0, depth_checks = 0, poses = 0, groups = 0;
+        void add(const Times& o) { grouping += o.grouping; colour += o.colour; depth += o.depth; pose += o.pose; colour_checks += o.colour_checks;
+                                   depth_checks += o.depth_checks; poses += o.poses; groups += o.groups; }
+    };
+    static Times& times();
+    static void resetTimes() { times() = Times(); }
+    // run() in two steps (r04): prepare = grouping + the colour verdict inputs of every match of the surviving groups (uses the
+    // detector when gpu_slot >= 0: NOT thread-safe, call it from the thread that owns the detector); finish_group = the sequential
+    // accept / break loop of ONE group (colour verdict, depth check, pose), which touches nothing shared and may run on any thread --
+    // the groups of a frame, and of different frames and classes, are independent.  run() = prepare + finish_group in order.
+    struct Prepared {
+        std::vector<MatchGroup> groups;
+        std::vector<int64_t> gin, gboth;          // GPU colour counts, [gpos[match index]]
+        std::vector<size_t> gpos;
+        std::vector<uint8_t> color_mask;          // host colour check: the frame's HSV in-range mask
+        bool gpu = false, failed = false;
+    };
+    Prepared prepare(const std::vector<lm_match_t>& matches, const uint8_t* bgr, size_t bgr_stride,
+                     const std::vector<TemplatePose>& templates, const ModelProperties& props, int gpu_slot);
+    std::vector<ObjectPose> finish_group(const Prepared& p, size_t group, const std::vector<lm_match_t>& matches, const uint16_t* dense_depth,
+                                         const std::vector<TemplatePose>& templates, Times* tm) const;
     // the two counts of colorCheck for one match, on the host (also the checker of the GPU path)
-    bool color_counts(const lm_match_t& m, const std::vector<uint8_t>& color_mask, long* in_hull, long* in_both);
+    bool color_counts(const lm_match_t& m, const std::vector<uint8_t>& color_mask, long* in_hull, long* in_both) const;
     const std::string& lastError() const { return error; }
 
 private:
-    bool color_check(const lm_match_t& m, const std::vector<uint8_t>& color_mask);                          // :424-434
+    bool color_check(const lm_match_t& m, const std::vector<uint8_t>& color_mask) const;                    // :424-434
     std::string error;
-    bool depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth);  // :437-457
-    ObjectPose make_pose(const lm_match_t& m, const std::vector<TemplatePose>& t, int32_t tempDepth);       // :459-515
+    bool depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth) const;  // :437-457
+    ObjectPose make_pose(const lm_match_t& m, const std::vector<TemplatePose>& t, int32_t tempDepth) const; // :459-515
     lm_detector* det;
     PostProcessSettings st;
 };

@@ -190,3 +190,17 @@ def test_counter_files_are_used_only_for_the_command_they_were_collected_with(tm
     assert "k_refine_plan" not in by and by["k_scan4<6, true, 2, false>"]["stage"] == "match"
     assert pre["preprocess_hbm_bytes_per_frame"] == round(311e6 / 96) and pre["preprocess_live_us_per_launch"] == 380.0
     assert bench.preprocess_roofline(None, "because", one_lane, 96) == {"kernels": None, "reason": "because"}
+
+
+@pytest.mark.gpu
+def test_bench_frame_shard_on_a_single_rank_communicator():
+    """--parallelism frame-shard (whole bank per rank, own frames per rank, no exchange): on a 1-GPU box the path runs with a
+    single-rank RCCL communicator that only carries the barrier and the max over ranks; the line says so."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--parallelism", "frame-shard", "--force-rccl", "--no-h2d"] + SMALL,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["config"]["parallelism"] == "frame-shard x1" and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["templates_per_gpu"] == d["config"]["templates_total"] == 300
+    assert "none in the data path" in d["config"]["exchange"] and d["config"]["rccl_ranks"] == 1
+    assert d["config"]["matches_frame0"] > 0
