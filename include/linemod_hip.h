@@ -189,9 +189,10 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
 /* LM_TUNE_COPY_STREAMS: copy streams the uploads are dealt to, slot -> stream round-robin (1..4, default 4: one
  *   in-order stream moved 0.6-0.9 MB images at 25.6 GB/s, several keep several DMA engines busy). */
 #define LM_TUNE_COPY_STREAMS 3
-/* LM_TUNE_CBLUR_VARIANT (process-wide): Gaussian blur kernel 0 = by batch size (default: one-shot below 16 frames, the row
- *   walker with shared column sums from there), 1 = one-shot, 2 = r02's sliding window, 3 = row walker with the column sums
- *   shared between neighbouring lanes (r03). */
+/* LM_TUNE_CBLUR_VARIANT (process-wide): Gaussian blur kernel 0 = by batch size and frame size (default: one-shot below 16 frames;
+ *   batches: frames of up to 2 MB on the matrix cores, larger ones the row walker), 1 = one-shot, 2 = r02's sliding window,
+ *   3 = row walker with the column sums shared between neighbouring lanes (r03), 4 = the two banded products of the 8-bit
+ *   Gaussian as v_mfma_i32_32x32x32_i8 (r04; rows of a multiple of 32 bytes, other shapes take 3).  Same bytes from all. */
 #define LM_TUNE_CBLUR_VARIANT 4
 /* LM_TUNE_CGRAD_VARIANT (process-wide): gradient orientation + 3x3 vote 0 = by batch size (default: two kernels below 16
  *   frames, the fused strip kernel from there), 1 = two kernels, 2 = fused, 3 = fused with 32-row strips (what tall

@@ -1281,7 +1281,7 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
     switch (key) {
         case LM_TUNE_FORK_MAX_SLOTS: if (value < 0) break; d->fork_max_slots = value; return LM_OK;
         case LM_TUNE_MATCH_UPLOAD_MODE: if (value < 0 || value > 2) break; d->match_upload_mode = value; return LM_OK;
-        case LM_TUNE_CBLUR_VARIANT: if (value < 0 || value > 3) break; lmk_set_cblur_variant(value); return LM_OK;
+        case LM_TUNE_CBLUR_VARIANT: if (value < 0 || value > 4) break; lmk_set_cblur_variant(value); return LM_OK;
         case LM_TUNE_PHASE_MAX_SLOTS: if (value < 0) break; d->phase_max_slots = value; return LM_OK;
         case LM_TUNE_CGRAD_VARIANT: if (value < 0 || value > 3) break; lmk_set_cgrad_variant(value); return LM_OK;
         case LM_TUNE_COPY_STREAMS: if (value < 1 || value > LM_NCOPY) break; d->n_copy_streams = value; return LM_OK;

@@ -909,6 +909,175 @@ __global__ __launch_bounds__(256, 2) void k_cblur_sh(const u8* __restrict__ bgr0
                                                    size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
     d_cblur_sh<STRIP>(blockIdx.x, bgr0, w, h, s0, in_stride, tmp_stride, gblocks, nslots);
 }
+// ------------------------------------------------------------------------------------------------
+// a1+a2 on the MATRIX CORES (r04 experiment; LM_TUNE_CBLUR_VARIANT = 4).  The 7-tap Gaussian of the 8-bit path is two
+// banded-Toeplitz integer products with taps {8, 28, 56, 72, 56, 28, 8} that fit i8; v_mfma_i32_32x32x32_i8 runs beside the vector
+// ALU, which is what every other kernel of the pipeline is short of.
+//   horizontal:  C1[row][n] = sum_k (X[row][k] - 128) * Th[k][n]        X = raw bytes (A operand, xor 0x80), Th = the band over BYTE
+//                columns (the channels interleave: tap t sits 3 (t - 3) bytes away), 32 output bytes from 64 input bytes = two
+//                K-blocks.  C1 = S1 - 32768 with S1 the 8.8 row sum (taps sum to 256), so C1 fits 16 bits: hi = C1 >> 8 in
+//                [-128, 126], lo = C1 & 255.
+//   vertical:    the accumulator tile has its byte COLUMN on the lane and its 32 rows in the 16 registers, i.e. it is already the
+//                A operand (as C1 transposed) of a product that sums over rows: Z[n][j] = sum_rho C1[rho][n] * Tv[rho][j] -- no LDS,
+//                no lane movement.  hi and (lo - 128) go through the same Tv; 256 Zhi + Zlo + constants = sum_v sum_h w w x,
+//                and the output byte is bits 16..23 of (that + 32768): the ONE rounding of the 8-bit path.
+//                Output rows j of a step lie across the boundary of the previous and the current 32-row tile (rows -16 .. 15
+//                of the current one), so a step is two K-blocks again and the walk down a strip recomputes nothing.
+//   result:      lane = output row, registers = 4-byte groups of the 32 byte columns: one dword store per group.
+// Which k a lane's operand bytes stand for is the same function in A and B (both are built here), so only the documented
+// C/D map is relied on: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), col = lane & 31.
+// BORDER_REPLICATE: rows by clamping the row a lane loads; the 16 byte columns before / behind a row are built from the row's
+// first / last pixel by v_perm (channels repeat with period 3).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+// Tile shape (second form, r04): a product's 32 "rows" need not be 32 image rows -- the band is shift-invariant, so operand row
+// m = 4 yy + cc stands for image row yy (of 8) and the 32-byte column chunk cc (of 4) of a 128-byte wide wave.  The four lanes of a
+// load quad then read ONE row (16 bytes every 32: one 128-B line per quad instead of four -- the first form, 32 image rows per
+// tile, ran at a quarter of the L1's rate and stored 8-byte pieces of 32 different lines), the vertical band becomes block-diagonal
+// in cc (zeros where input and output chunk differ: the matrix cores have the time), a step is 8 new rows, and after two
+// v_permlane32_swap a lane holds 16 consecutive output bytes: a store instruction writes 8 whole 128-B lines.
+struct MxTab { u32 v[64][16]; };      // per lane: B0 | B1 (horizontal band, K-blocks 0 / 1) | BvP | BvC (vertical band, previous / current tile)
+static constexpr int mx_tap(int t) { return t == 0 || t == 6 ? 8 : t == 1 || t == 5 ? 28 : t == 2 || t == 4 ? 56 : t == 3 ? 72 : 0; }
+static constexpr int mx_w(int t) { return (t < 0 || t > 6) ? 0 : mx_tap(t); }
+static constexpr MxTab mx_make_tab() {
+    MxTab T{};
+    for (int lane = 0; lane < 64; ++lane) {
+        const int n = lane & 31, hh = lane >> 5;
+        const int yo = n >> 2, cco = n & 3;                                  // as the vertical product's output column: (output row, chunk)
+        for (int q = 0; q < 4; ++q) {
+            u32 b0 = 0, b1 = 0, vp = 0, vc = 0;
+            for (int e = 0; e < 4; ++e) {
+                const int j = 4 * q + e, k = 16 * hh + j;
+                const int d0 = k - 16 - n, d1 = k + 16 - n;                 // input byte minus output byte, K-block 0 / 1
+                const int w0 = (d0 % 3 == 0) ? mx_w(d0 / 3 + 3) : 0, w1 = (d1 % 3 == 0) ? mx_w(d1 / 3 + 3) : 0;
+                const int m = (j & 3) + 8 * (j >> 2) + 4 * hh;              // operand row of the accumulator tile this operand byte holds
+                const int yy = m >> 2, cc = m & 3;
+                const int wp = cc == cco ? mx_w(yy - yo - 1) : 0, wc = cc == cco ? mx_w(yy - yo + 7) : 0;
+                b0 |= (u32)w0 << (8 * e); b1 |= (u32)w1 << (8 * e); vp |= (u32)wp << (8 * e); vc |= (u32)wc << (8 * e);
+            }
+            T.v[lane][q] = b0; T.v[lane][4 + q] = b1; T.v[lane][8 + q] = vp; T.v[lane][12 + q] = vc;
+        }
+    }
+    return T;
+}
+__device__ const MxTab g_mx_tab = mx_make_tab();
+#define MX_WAVE_BYTES 128   // byte columns per wave (4 chunks of 32)
+__device__ __forceinline__ void permlane32_swap_lo(u32& a, u32& b) {   // a[lanes 32..63] <-> b[lanes 0..31]
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+__device__ __forceinline__ void d_cblur_mx_st(const u32 slot, const u32 tile, const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0, size_t in_stride,
+                                              size_t tmp_stride, int gx, int strip_rows) {
+    const u8* bgr = slot_ptr_s(bgr0, in_stride, slot);
+    u8* S = slot_ptr_s(s0, tmp_stride, slot);
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int yy = r >> 2, cc = r & 3;
+    const int cx = (int)(tile % (u32)gx), sy = (int)(tile / (u32)gx);
+    const int W3 = w * 3;
+    const int c0 = (cx * 4 + wave) * MX_WAVE_BYTES;
+    if (c0 >= W3) return;
+    const int Y0 = sy * strip_rows, Y1 = min(Y0 + strip_rows, h);
+    const u32 pitch = (u32)W3;
+    i32x4 B0, B1, BP, BC;
+    {
+        const u32x4* tp = reinterpret_cast<const u32x4*>(g_mx_tab.v[lane]);
+        const u32x4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+        B0 = i32x4{(int)t0[0], (int)t0[1], (int)t0[2], (int)t0[3]}; B1 = i32x4{(int)t1[0], (int)t1[1], (int)t1[2], (int)t1[3]};
+        BP = i32x4{(int)t2[0], (int)t2[1], (int)t2[2], (int)t2[3]}; BC = i32x4{(int)t3[0], (int)t3[1], (int)t3[2], (int)t3[3]};
+    }
+    // this lane's chunk: output bytes [cch, cch + 32) of its row; operand bytes of K-block kb: cch - 16 + 32 kb + 16 hh .. + 15
+    const int cch = c0 + 32 * cc;
+    const bool active = cch < W3;
+    const bool rep_l = active && cch == 0 && hh == 0;               // K-block 0: the 16 bytes before the row
+    const bool rep_r = active && cch + 32 == W3 && hh == 1;         // K-block 1: the 16 bytes behind the row
+    const bool edge_wave = __any(rep_l || rep_r);
+    const u32 off0 = (u32)(!active ? 0 : rep_l ? 0 : cch - 16 + 16 * hh);
+    const u32 off1 = (u32)(!active ? 0 : rep_r ? W3 - 16 : cch + 16 + 16 * hh);
+    auto load_tile = [&](int yt, u32x4 (&A)[2]) {
+        const u32 row = (u32)clampi(yt + yy, 0, h - 1) * pitch;
+        u32x4 v0 = ld16(bgr + (row + off0)), v1 = ld16(bgr + (row + off1));
+        if (edge_wave) {
+            // BORDER_REPLICATE: the bytes before a row repeat the channels of pixel 0 (bytes 0, 1, 2 of the row: channel (t + 2) % 3 at
+            // byte t - 16), the bytes behind it those of the last pixel (bytes 1, 2, 3 of the row's last dword: channel t % 3)
+            const u32 dl = v0[0], dr = v1[3];
+            const u32 l0 = __builtin_amdgcn_perm(dl, dl, 0x02010002u), l1 = __builtin_amdgcn_perm(dl, dl, 0x00020100u), l2 = __builtin_amdgcn_perm(dl, dl, 0x01000201u);
+            const u32 r0 = __builtin_amdgcn_perm(dr, dr, 0x01030201u), r1 = __builtin_amdgcn_perm(dr, dr, 0x02010302u), r2 = __builtin_amdgcn_perm(dr, dr, 0x03020103u);
+            v0 = rep_l ? u32x4{l0, l1, l2, l0} : v0;
+            v1 = rep_r ? u32x4{r0, r1, r2, r0} : v1;
+        }
+        A[0] = u32x4{v0[0] ^ 0x80808080u, v0[1] ^ 0x80808080u, v0[2] ^ 0x80808080u, v0[3] ^ 0x80808080u};
+        A[1] = u32x4{v1[0] ^ 0x80808080u, v1[1] ^ 0x80808080u, v1[2] ^ 0x80808080u, v1[3] ^ 0x80808080u};
+    };
+    // horizontal pass of one tile (8 rows x 4 chunks): the accumulator tile, packed to its hi / lo operand bytes
+    auto horizontal = [&](const u32x4 (&A)[2], i32x4& Hi, i32x4& Lo) {
+        i32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        c = __builtin_amdgcn_mfma_i32_32x32x32_i8(i32x4{(int)A[0][0], (int)A[0][1], (int)A[0][2], (int)A[0][3]}, B0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_i32_32x32x32_i8(i32x4{(int)A[1][0], (int)A[1][1], (int)A[1][2], (int)A[1][3]}, B1, c, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const u32 r0 = (u32)c[4 * g], r1 = (u32)c[4 * g + 1], r2 = (u32)c[4 * g + 2], r3 = (u32)c[4 * g + 3];
+            const u32 a01 = __builtin_amdgcn_perm(r1, r0, 0x05010400u), a23 = __builtin_amdgcn_perm(r3, r2, 0x05010400u);   // (lo0, lo1, hi0, hi1)
+            Lo[g] = (int)(__builtin_amdgcn_perm(a23, a01, 0x05040100u) ^ 0x80808080u);
+            Hi[g] = (int)__builtin_amdgcn_perm(a23, a01, 0x07060302u);
+        }
+    };
+    u32x4 A[2], An[2];
+    i32x4 hiP, loP, hiC, loC;
+    // step m writes the rows Y0 + 8 m .. + 7: (output row of the step) yo = yy, previous tile = rows Y0 + 8 m - 4 .. + 3, current
+    // tile = rows Y0 + 8 m + 4 .. + 11 (the table's taps: previous tile row yy is tap yy - yo - 1, current tile row yy tap yy - yo + 7)
+    load_tile(Y0 - 4, A);
+    horizontal(A, hiP, loP);
+    const int steps = (Y1 - Y0 + 7) / 8;
+    const int KC = 32768 + 128 * 256 + 32768 * 256;        // rounding + the two biases (lo - 128; C1 = S1 - 32768), taps sum to 256
+    load_tile(Y0 + 4, A);
+    const u32 so = (u32)(cch + 16 * hh);                     // after the swaps: lower lanes bytes 0 .. 15 of the chunk, upper lanes 16 .. 31
+    for (int m = 0; m < steps; ++m) {
+        if (m + 1 < steps) load_tile(Y0 + 8 * (m + 1) + 4, An);              // the next tile travels while this one is multiplied
+        horizontal(A, hiC, loC);
+        i32x16 zh = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        i32x16 zl = {KC, KC, KC, KC, KC, KC, KC, KC, KC, KC, KC, KC, KC, KC, KC, KC};
+        zh = __builtin_amdgcn_mfma_i32_32x32x32_i8(hiP, BP, zh, 0, 0, 0);
+        zh = __builtin_amdgcn_mfma_i32_32x32x32_i8(hiC, BC, zh, 0, 0, 0);
+        zl = __builtin_amdgcn_mfma_i32_32x32x32_i8(loP, BP, zl, 0, 0, 0);
+        zl = __builtin_amdgcn_mfma_i32_32x32x32_i8(loC, BC, zl, 0, 0, 0);
+        u32 D[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32 v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((u32)zh[4 * g + e] << 8) + (u32)zl[4 * g + e];
+            const u32 a01 = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), a23 = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u);   // byte 2 of each
+            D[g] = __builtin_amdgcn_perm(a23, a01, 0x05040100u);             // bytes 8 g + 4 hh .. + 3 of the chunk
+        }
+        permlane32_swap_lo(D[0], D[2]);                      // lower lanes: D0 = bytes 0-3, D2 = 4-7; upper lanes: D0 = 16-19, D2 = 20-23
+        permlane32_swap_lo(D[1], D[3]);                      // lower lanes: D1 = 8-11, D3 = 12-15; upper lanes: D1 = 24-27, D3 = 28-31
+        const int yout = Y0 + 8 * m + yy;
+        if (active && yout < Y1) st16(S + ((u32)yout * pitch + so), u32x4{D[0], D[2], D[1], D[3]});
+        hiP = hiC; loP = loC;
+        A[0] = An[0]; A[1] = An[1];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_cblur_mx(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0, size_t in_stride,
+                                                     size_t tmp_stride, int gx, int gy, int strip_rows, int nslots) {
+    u32 slot, tile;
+    xcd_slot_tile_b(blockIdx.x, (u32)(gx * gy), (u32)nslots, slot, tile);
+    d_cblur_mx_st(slot, tile, bgr0, w, h, s0, in_stride, tmp_stride, gx, strip_rows);
+}
+// the matrix-core blur of level 0 and cv::pyrDown (k_pyrdown16's tiles, vector ALU) in ONE grid, a slot's tiles dealt out evenly like
+// k_blur_pyr's: the two readers of the raw image run side by side on the slot's XCD, and the pyrDown's vector work fills the issue slots
+// the matrix-core tiles leave idle
+__global__ __launch_bounds__(256, 2) void k_blur_mx_pyr(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0, u8* __restrict__ bgr1,
+                                                        size_t slot_stride, int gx, int gy, int strip_rows, int g_pyr, int nslots) {
+    u32 slot, tile;
+    const u32 g_blur = (u32)(gx * gy), G = g_blur + (u32)g_pyr;
+    xcd_slot_tile_b(blockIdx.x, G, (u32)nslots, slot, tile);
+    const u32 p1 = (tile + 1u) * (u32)g_pyr / G, p0 = tile * (u32)g_pyr / G;     // pyrDown tiles among the first tile + 1 / tile
+    if (p1 != p0) d_pyrdown16_st<PD_STRIP>(slot, p0, bgr0, w, h, bgr1, w >> 1, h >> 1, slot_stride);
+    else d_cblur_mx_st(slot, tile - p0, bgr0, w, h, s0, slot_stride, slot_stride, gx, strip_rows);
+}
+
 // Level-0 blur AND cv::pyrDown of the same frames in ONE grid, interleaved per slot (r03; VERDICT r2 #2b "blur + pyrDown from
 // one pass over the raw image", as far as it pays): both read the raw level-0 image, and launched apart they read it from
 // HBM twice (k_pyrdown8: 110 MB per 96-frame launch of config 2, 590 MB per 128 frames of config 3 -- it runs at the HBM rate).
@@ -3453,11 +3622,17 @@ void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, i
     hipLaunchKernelGGL(k_nn_half, grid, dim3(256), 0, s, src, src_pitch, dst, dw, dh, slot_stride);
 }
 
+// r04: 4 = the blur on the matrix cores (k_cblur_mx; inside k_blur_mx_pyr at level 0 of a batch).  Measured (tools/ab_blur_mx.sh,
+// profiles/r04_ab_experiments.log): bit-identical; alone on the chip no faster than k_cblur_sh (the launch is bound by its pyrDown tiles and
+// by memory), beside the other lanes config 2 +1.5 .. 2 % (the vector ALU is what the whole pipeline is short of), config 3 -0.8 % (HBM-bound
+// launch).  Hence 0 = auto takes it for batches of frames of up to 2 MB and k_cblur_sh above.
+static bool mx_auto(int w, int h, int nslots);
 static int g_cblur_variant = 0;   // 0: by batch size (one-shot below 16 frames, k_cblur_sh from there), 1: one-shot blur (k_cblur),
                                   // 2: sliding-window blur (k_cblur_sw, r02's batch kernel), 3: sliding window with the column sums
                                   // shared between neighbouring lanes (k_cblur_sh, r03: config 2 146.3 -> 150.7 K, config 3 81.9 -> 86.1 K
                                   // detections/s); A/B knob of tools/ and tests
 void lmk_set_cblur_variant(int v) { g_cblur_variant = v; }
+static bool mx_auto(int w, int h, int nslots) { return g_cblur_variant == 0 && sel_slots(nslots) >= 16 && (long)w * h * 3 <= 2000000L && ((w * 3) % 32) == 0; }
 static int g_dmedian_variant = 0;   // 0: by batch size (4 output rows per lane below 16 frames, DM_ROWS_BATCH from there), 1 / 2: force either
 void lmk_set_dmedian_variant(int v) { g_dmedian_variant = v; }
 static int g_cgrad_variant = 0;   // 0: by batch size (fused k_cgrad from 16 frames), 1: k_corient + k_cvote, 2: k_cgrad, 3: k_cgrad with 32-row strips
@@ -3488,6 +3663,14 @@ bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0,
     const int g_blur_pyr_interleave = g_blur_pyr_interleave_mode == 1 || (g_blur_pyr_interleave_mode == 2 && (long)w * h * 3 > 2000000L);
     auto waves4 = [](int pairs) { return ((pairs + 61) / 62 + 3) / 4; };
     const int g_pyr = waves4((w / 16) * ((dh + PD_STRIP - 1) / PD_STRIP));
+    if (g_cblur_variant == 4 || mx_auto(w, h, nslots)) {
+        if (((w * 3) % 32) != 0) return false;
+        const int gx = (w * 3 + 4 * MX_WAVE_BYTES - 1) / (4 * MX_WAVE_BYTES);
+        const int strip_rows = h > 640 ? 96 : 48;
+        const int gy = (h + strip_rows - 1) / strip_rows;
+        hipLaunchKernelGGL(k_blur_mx_pyr, dim3((unsigned)((gx * gy + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, gx, gy, strip_rows, g_pyr, nslots);
+        return true;
+    }
     // rows per blur strip: 16, or 32 for tall images.  A strip of S rows reads and sums S + 6 (16: 1.375 x the image, 32: 1.19 x, 64:
     // 1.09 x) but taller strips measured no faster (r03, LM_TUNE_BLUR_STRIP: config 2 163.2 / 162.8 / 160.8 K detections/s at 16 /
     // 32 / 64, config 3 90.8 / 90.7 K at 32 / 64): fewer, longer waves
@@ -3521,9 +3704,16 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
         // eight dependent steps: 166 instead of 150 us per resident single-frame match); batches: the sliding window
         if (blurred) {
             // S is already in `scratch` (lmk_blur_pyrdown)
+        } else if ((g_cblur_variant == 4 || mx_auto(w, h, nslots)) && ((w * 3) % 32) == 0 && h >= 1) {
+            // r04 experiment: the blur on the matrix cores (k_cblur_mx); a workgroup = four waves side by side, each 128 byte columns
+            // wide, walking down a strip of rows in steps of 8 (one extra tile of 8 rows per strip for the vertical taps)
+            const int gx = (w * 3 + 4 * MX_WAVE_BYTES - 1) / (4 * MX_WAVE_BYTES);
+            const int strip_rows = h > 640 ? 96 : 48;
+            const int gy = (h + strip_rows - 1) / strip_rows;
+            hipLaunchKernelGGL(k_cblur_mx, dim3((unsigned)(gx * gy * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, gx, gy, strip_rows, nslots);
         } else if (g_cblur_variant == 1 || (g_cblur_variant == 0 && sel_slots(nslots) < 16)) {
             hipLaunchKernelGGL(k_cblur, dim3((unsigned)(((n_b + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_b + 255) / 256, nslots);
-        } else if (g_cblur_variant == 3 || g_cblur_variant == 0) {
+        } else if (g_cblur_variant == 3 || g_cblur_variant == 0 || g_cblur_variant == 4) {
             // column sums shared between neighbouring lanes: 62 (strip, block) pairs per wave, four waves per workgroup
             if (h > 640) {
                 const int n_w = (((w * 3 / 16) * ((h + 31) / 32) + 61) / 62 + 3) / 4;

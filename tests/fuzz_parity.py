@@ -38,11 +38,11 @@ def rand_depth(h, w):
 
 
 while time.time() - t0 < budget * 0.5:
-    w = int(rng.choice([16, 32, 48, 64, 80, 96, 160, 320, 640, 24, 40, 56, 37, 53, 70]))
+    w = int(rng.choice([16, 32, 48, 64, 80, 96, 128, 160, 192, 320, 640, 24, 40, 56, 37, 53, 70]))
     h = int(rng.integers(8, 130))
     bgr = rand_bgr(h, w)
     thr = float(rng.choice([10.0, 0.0, 30.0, 200.0]))
-    kb, kg = int(rng.integers(0, 4)), int(rng.integers(0, 4))      # blur / gradient kernels: by batch size, few-frame, batch
+    kb, kg = int(rng.integers(0, 5)), int(rng.integers(0, 4))      # blur / gradient kernels: by batch size, few-frame, batch; blur 4 = matrix cores
     det.set_tuning(lm.TUNE_CBLUR_VARIANT, kb); det.set_tuning(lm.TUNE_CGRAD_VARIANT, kg)
     assert np.array_equal(det.stage_color_quantize(bgr, thr), orc.color_quantize(bgr, thr)), ("colour", h, w, thr, kb, kg)
     if h % 2 == 0 and w % 2 == 0 and h >= 4:
@@ -89,7 +89,7 @@ while time.time() - t0 < budget:
     assert got.tobytes() == exp.tobytes(), ("match", color_only, T, w, h, n, thr, variant, len(got), len(exp))
     if nb > 1:
         d.set_tuning(lm.TUNE_PHASE_MAX_SLOTS, int(rng.choice([15, 0])))
-        d.set_tuning(lm.TUNE_BATCH_PHASES, int(rng.choice([0, 1, 2, 3])))     # 16+ frames: level-fused batch launches or one per kernel
+        d.set_tuning(lm.TUNE_BATCH_PHASES, int(rng.choice([0, 1, 2])))     # 16+ frames: level-fused batch launches or one per kernel
         d.set_tuning(lm.TUNE_BLUR_PYR, int(rng.choice([0, 1, 2, 3])))         # level-0 blur + pyrDown apart, in one launch back to back, or dealt out evenly
         d.set_tuning(lm.TUNE_BLUR_STRIP, int(rng.choice([0, 16, 32, 64])))      # rows per blur strip inside k_blur_pyr
         d.set_tuning(lm.TUNE_LEVEL_PAIRS, int(rng.choice([0, 1])))         # level-1 kernels inside the level-0 grids (k_pair) or not

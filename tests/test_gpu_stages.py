@@ -33,7 +33,7 @@ def test_color_quantize_parity(det, orc, shape):
         assert np.array_equal(mag, emag)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_color_quantize_both_blur_kernels(lm, det, orc, frame0, variant):
     """The Gaussian blur has three kernels -- one shot (few frames), sliding window (batches) and the sliding window whose
     column sums travel between neighbouring lanes (r03) -- chosen by batch size:
@@ -41,10 +41,14 @@ def test_color_quantize_both_blur_kernels(lm, det, orc, frame0, variant):
     det.set_tuning(lm.TUNE_CBLUR_VARIANT, variant)
     try:
         rng = np.random.default_rng(variant)
-        for shape in [(480, 640), (240, 320), (960, 1280), (16, 64), (17, 64), (50, 16), (130, 160), (33, 48)]:
+        # (variant 4, the matrix-core blur, takes rows of a multiple of 32 bytes -- 3 w % 32 == 0; other shapes fall back to variant 3)
+        for shape in [(480, 640), (240, 320), (960, 1280), (16, 64), (17, 64), (50, 16), (130, 160), (33, 48), (97, 128), (200, 192), (1, 64), (31, 64), (96, 64), (193, 256)]:
             for smooth in (True, False):
                 bgr = _rand_bgr(rng, shape[0], shape[1], smooth)
                 assert np.array_equal(det.stage_color_quantize(bgr), orc.color_quantize(bgr)), (variant, shape, smooth)
+        for extreme in (0, 255):
+            bgr = np.full((64, 128, 3), extreme, np.uint8); bgr[20:40, 30:90] = 255 - extreme
+            assert np.array_equal(det.stage_color_quantize(bgr), orc.color_quantize(bgr)), (variant, extreme)
         assert np.array_equal(det.stage_color_quantize(frame0[0]), orc.color_quantize(frame0[0]))
     finally:
         det.set_tuning(lm.TUNE_CBLUR_VARIANT, 0)
