@@ -407,8 +407,9 @@ int lm_time_scan_batch(lm_detector* det, int first_slot, int n_slots, float thre
  * compiler's exponent-range handling; this runs every float of the tail's domain through both forms on the device, the reference
  * being the correctly rounded 1.0f / x and sqrtf.  out[0] / out[1] = number of floats whose reciprocal / square root differ
  * (0 / 0 expected); out[2] = floats on which the bare v_sqrt_f32 instruction differs (information only: the kernel does not
- * rely on it); out[3] = 0. */
-int lm_selftest_float_tail(lm_detector* det, uint64_t out[4]);
+ * rely on it); out[3], out[4], out[5] = the same counts for the longer sequences the kernel used before (v_rcp + six fused steps;
+ * v_sqrt + the +-1 ulp fix-up) and for v_sqrt + one step with v_rsq: all 0 expected; out[6], out[7] = 0. */
+int lm_selftest_float_tail(lm_detector* det, uint64_t out[8]);
 /* Per-stage average microseconds of the last lm_match_slot-style pipeline, measured with HIP events
  * over `iters` runs: out[0]=preprocess (a3-a10), out[1]=scan, out[2]=refine, out[3]=sort+copy. */
 int lm_time_stages(lm_detector* det, int slot, float threshold, int class_idx, int iters, double out_us[4]);

@@ -752,9 +752,10 @@ class Detector:
     def selftest_float_tail(self):
         """(reciprocals, square roots) of the depth-normal tail's float domain that differ from the correctly rounded forms.
         `self.last_bare_sqrt_mismatches` = floats on which the bare v_sqrt_f32 differs from the correctly rounded root."""
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 8)()
         self._check(self.lib.lm_selftest_float_tail(self.h, out))
         self.last_bare_sqrt_mismatches = int(out[2])
+        self.last_candidate_mismatches = {"v_rcp + six steps (r03)": int(out[3]), "v_sqrt + fix-up": int(out[4]), "v_sqrt + v_rsq step": int(out[5])}
         return int(out[0]), int(out[1])
 
     def time_stages(self, slot, threshold, class_idx=-1, iters=20):

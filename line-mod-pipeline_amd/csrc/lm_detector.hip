@@ -284,7 +284,7 @@ int ensure_device(lm_detector* d) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_scan_stat), 4096 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(d->d_scan_stat, 0, 4096 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_sim_lut), 256));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_normal_lut), 2 * 8000));    // the table, then its labels as rank codes (LMK_NORMAL_CODE_OFFSET)
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_normal_lut), 2 * 8000 + 16));    // the table, then its labels as rank codes (LMK_NORMAL_CODE_OFFSET) + a zero entry for indices outside the table
     HIP_TRY(hipDeviceSynchronize());
     d->dev_ready = true;
     d->luts_dirty = true;
@@ -308,7 +308,7 @@ int ensure_luts(lm_detector* d) {
     HIP_TRY(hipMemcpy(d->d_sim_lut, d->sim_lut, 256, hipMemcpyHostToDevice));
     {
         // k_dnormal writes the label's RANK CODE (lm_kernels.hip, a5 streaming form): looked up directly from a second table
-        u8 both[2 * 8000];
+        u8 both[2 * 8000 + 16] = {};                      // [LMK_NORMAL_CODE_OFFSET + 8000 ..] = 0: the code of an index outside the table
         std::memcpy(both, d->normal_lut, 8000);
         for (int i = 0; i < 8000; ++i) {
             const u8 v = d->normal_lut[i];
@@ -2359,22 +2359,23 @@ int lm_time_scan_batch(lm_detector* d, int first_slot, int n_slots, float thresh
 
 // Self-test of k_dnormal's float tail (lm_kernels.hip dn_rcp / dn_sqrt): every float of the tail's domain through the short
 // sequences and through the compiler's correctly rounded 1.0f / x and sqrtf (__builtin_sqrtf: v_sqrt_f32 + its +-1 ulp fix-up) on
-// this device; out[0] / out[1] = floats that differ, out[2] = floats on which the bare v_sqrt_f32 differs (information), out[3] = 0.
-int lm_selftest_float_tail(lm_detector* d, uint64_t out[4]) {
+// this device; out[0] / out[1] = floats that differ, out[2] = floats on which the bare v_sqrt_f32 differs (information), out[3..5] = the same
+// for the longer sequences used before (v_rcp + six steps; v_sqrt + fix-up) and for v_sqrt + one v_rsq step, out[6..7] = 0.
+int lm_selftest_float_tail(lm_detector* d, uint64_t out[8]) {
     int rc;
     if (!out) return fail(LM_ERR_INVALID, "null argument");
     if ((rc = ready_for_compute(d))) return rc;
     if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     unsigned long long* dev = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), 4 * sizeof(unsigned long long)));
-    hipError_t e = hipMemsetAsync(dev, 0, 4 * sizeof(unsigned long long), d->stream);
-    unsigned long long host[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), 8 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), d->stream);
+    unsigned long long host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (e == hipSuccess) { lmk_selftest_float_tail(d->stream, dev); e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, d->stream); }
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
     if (e == hipSuccess) e = hipGetLastError();
     (void)hipFree(dev);
     if (e != hipSuccess) return fail(LM_ERR_HIP, hipGetErrorString(e));
-    for (int k = 0; k < 4; ++k) out[k] = host[k];
+    for (int k = 0; k < 8; ++k) out[k] = host[k];
     return LM_OK;
 }
 

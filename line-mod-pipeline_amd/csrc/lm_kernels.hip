@@ -1620,7 +1620,7 @@ __device__ __forceinline__ u32 hw_u16(const u32x4* A, int hw) {
 // square root keeps the fix-up (v_sqrt_f32 alone is a 1-ulp instruction: r04) and drops only the scaling.
 // lm_selftest_float_tail sweeps every float of the domain against the CORRECTLY ROUNDED 1.0f / x and sqrtf on the device
 // (__builtin_sqrtf; NOT __fsqrt_rn, which this build maps to the bare v_sqrt_f32) -- tests/test_gpu_stages.py.
-__device__ __forceinline__ float dn_rcp(float d) {
+__device__ __forceinline__ float dn_rcp7(float d) {       // r03: v_rcp + six fused steps (the compiler's sequence without its range handling)
     const float r0 = __builtin_amdgcn_rcpf(d);
     const float e = __builtin_fmaf(-d, r0, 1.0f);
     const float r1 = __builtin_fmaf(e, r0, r0);
@@ -1633,7 +1633,7 @@ __device__ __forceinline__ float dn_sqrt_bare(float x) { return __builtin_amdgcn
 // correctly rounded for x = 0 or a normal x: the hardware's root s is within 1 ulp, so the answer is s or a neighbour; with
 // r(t) = x - t * s (one rounding), the root is below s iff r(s-) <= 0 and above it iff r(s+) > 0 (the compiler's own sqrtf
 // fix-up without its denormal scaling).  x == 0 gives s == 0: both neighbours' residuals keep s.
-__device__ __forceinline__ float dn_sqrt(float x) {
+__device__ __forceinline__ float dn_sqrt9(float x) {      // v_sqrt + the +-1 ulp fix-up (the compiler's sequence without its denormal scaling)
     const float s = __builtin_amdgcn_sqrtf(x);
     const float s_dn = __builtin_bit_cast(float, __builtin_bit_cast(u32, s) - 1u);
     const float s_up = __builtin_bit_cast(float, __builtin_bit_cast(u32, s) + 1u);
@@ -1644,8 +1644,30 @@ __device__ __forceinline__ float dn_sqrt(float x) {
 }
 // QUOT: the caller passes det / 625, ddx / 125, ddy / 125 (the packed taps' sums); with SMALL the two scalings of a component are one
 // 24-bit multiply, |ddx / 125| <= 8 * 6 * 248 and 125 * 1150 = 143750 < 2^24.
+// Shorter sequences (r04), adopted because the exhaustive sweep below finds NO float of the domain on which they differ from the
+// correctly rounded results on this hardware (profiles/r04_float_tail_sweep.log): 3 + 5 instructions instead of 7 + 9.
+// dn_sqrt(0) is a NaN here (0 * inf); the caller only asks `len > 0`, which is false for it as for 0.
+__device__ __forceinline__ float dn_rcp3(float d) {          // v_rcp + ONE Newton step
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+__device__ __forceinline__ float dn_sqrt5(float x) {         // v_rsq + one coupled step: g = x y, h = y / 2, g + (x - g g) h
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = __fmul_rn(x, y), hf = __fmul_rn(0.5f, y);
+    const float e = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(e, hf, g);
+}
+__device__ __forceinline__ float dn_sqrt4(float x) {         // v_sqrt + one step with the reciprocal root: s + (x - s s) (y / 2)
+    const float s = __builtin_amdgcn_sqrtf(x), y = __builtin_amdgcn_rsqf(x);
+    const float e = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(e, __fmul_rn(0.5f, y), s);
+}
+__device__ __forceinline__ float dn_rcp(float d) { return dn_rcp3(d); }
+__device__ __forceinline__ float dn_sqrt(float x) { return dn_sqrt5(x); }
+// `ok` = the pixel's depth passes the distance threshold (the row-end columns are masked by the caller, once per lane, r04).
 template <bool SMALL, bool QUOT = false>
-__device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool valid, const u8* __restrict__ lut) {
+__device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool ok, const u8* __restrict__ lut) {
     // same values as upstream's 64-bit integer products rounded once to float: |ddx| < 2^30 so the
     // double product is exact; |det * d| <= 22500 * 65535 < 2^31
     if (QUOT) { det = mul_i24(det, 625); if (!SMALL) { ddx = mul_i24(ddx, 125); ddy = mul_i24(ddy, 125); } }
@@ -1653,34 +1675,41 @@ __device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool v
     float ny = SMALL ? (float)(QUOT ? mul_i24(ddy, 143750) : ddy * 1150) : (float)((double)ddy * 1150.0);
     float nz = (float)(-mul_i24(det, d));
     const float len = dn_sqrt(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
-    const float inv = dn_rcp(len > 0 ? len : 1.0f);
+    // len == 0 (all three components 0): 1 / 0 = inf, 0 * inf = NaN, (int)NaN = 0 -- any index; the select below returns 0 for it
+    const float inv = dn_rcp(len);
     nx = __fmul_rn(nx, inv); ny = __fmul_rn(ny, inv); nz = __fmul_rn(nz, inv);
     const int v1 = (int)__fadd_rn(__fmul_rn(nx, 10.f), 10.f);
     const int v2 = (int)__fadd_rn(__fmul_rn(ny, 10.f), 10.f);
     const int v3 = (int)__fadd_rn(__fmul_rn(nz, 20.f), 20.f);
-    const int flat = mad_i24(v3, 400, mad_i24(v2, 20, v1));   // |v| small: exact
-    const bool in_lut = (u32)flat < 8000u;
-    // the label's rank code straight from the second table (ensure_luts: 8 rank / 8 (rank - 4) + 4 / 32)
-    const u32 ecode = lut[LMK_NORMAL_CODE_OFFSET + (in_lut ? (u32)flat : 0u)];     // (unsigned: a 32-bit offset from the table's base)
-    return (valid && len > 0 && in_lut) ? ecode : 0u;
+    const u32 flat = (u32)mad_i24(v3, 400, mad_i24(v2, 20, v1));   // |v| small: exact; negative = far outside as unsigned
+    // the label's rank code straight from the second table (ensure_luts: 8 rank / 8 (rank - 4) + 4 / 32), whose entry 8000 is 0:
+    // an index outside the table (nz == 0 gives v3 == 20) reads that instead of taking a compare and two selects
+    const u32 ecode = lut[LMK_NORMAL_CODE_OFFSET + min(flat, 8000u)];
+    return (ok && len > 0) ? ecode : 0u;
 }
 
 // every float of the tail's domain through dn_rcp / dn_sqrt and through the compiler's correctly rounded forms;
 // out[2]: the bare v_sqrt_f32 against the same reference (information: how often the 1-ulp instruction is off)
 __global__ __launch_bounds__(256) void k_selftest_float_tail(unsigned long long* __restrict__ out) {
     const u32 lo = 0x3F800000u, hi_rcp = (127u + 42u) << 23, hi_sqrt = (127u + 84u) << 23;   // 1.0f .. 2^42 / 2^84
-    unsigned long long bad_rcp = 0, bad_sqrt = 0, bad_bare = 0;
+    unsigned long long bad_rcp = 0, bad_sqrt = 0, bad_bare = 0, c_rcp3 = 0, c_sqrt5 = 0, c_sqrt4 = 0;
     for (u32 b = lo + blockIdx.x * 256u + threadIdx.x; b <= hi_sqrt; b += gridDim.x * 256u) {
         const float x = __builtin_bit_cast(float, b);
         if (b <= hi_rcp) bad_rcp += __builtin_bit_cast(u32, dn_rcp(x)) != __builtin_bit_cast(u32, __fdiv_rn(1.0f, x));
         const u32 want = __builtin_bit_cast(u32, __builtin_sqrtf(x));
         bad_sqrt += __builtin_bit_cast(u32, dn_sqrt(x)) != want;
         bad_bare += __builtin_bit_cast(u32, dn_sqrt_bare(x)) != want;
+        if (b <= hi_rcp) c_rcp3 += __builtin_bit_cast(u32, dn_rcp7(x)) != __builtin_bit_cast(u32, __fdiv_rn(1.0f, x));
+        c_sqrt5 += __builtin_bit_cast(u32, dn_sqrt9(x)) != want;
+        c_sqrt4 += __builtin_bit_cast(u32, dn_sqrt4(x)) != want;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) bad_sqrt += __builtin_bit_cast(u32, dn_sqrt(0.0f)) != 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) bad_sqrt += dn_sqrt(0.0f) > 0.0f ? 1u : 0u;     // (0 or a NaN: what the caller's `len > 0` needs)
     if (bad_rcp) atomicAdd(&out[0], bad_rcp);
     if (bad_sqrt) atomicAdd(&out[1], bad_sqrt);
     if (bad_bare) atomicAdd(&out[2], bad_bare);
+    if (c_rcp3) atomicAdd(&out[3], c_rcp3);
+    if (c_sqrt5) atomicAdd(&out[4], c_sqrt5);
+    if (c_sqrt4) atomicAdd(&out[5], c_sqrt4);
 }
 
 template <bool SMALL>
@@ -1698,6 +1727,8 @@ __device__ __forceinline__ void d_dnormal_t(const u32 vblock, const u16* __restr
     u32 out[2] = {0, 0};
     if (y >= 5 && y < h - 6) {
         u32x4 R[3][3];   // rows y-5, y, y+5; pixels 8g-8 .. 8g+15
+        // (r04, tried and reverted: the row-end blocks loaded without branches or selects from the lane's own block (only the masked columns
+        // would notice) with 32-bit offsets -- fewer instructions, k_dnormal 82.3 -> 87.1 us per 96-frame launch)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const u8* row = reinterpret_cast<const u8*>(depth + (size_t)(y + 5 * (j - 1)) * w) + 16 * g - 16;
@@ -1750,9 +1781,8 @@ __device__ __forceinline__ void d_dnormal_t(const u32 vblock, const u16* __restr
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int p = 2 * k + hh;
-                    const int x = 8 * g + p;
                     const int d = hh ? (int)(C >> 16) : (int)(C & 0xFFFFu);
-                    const bool valid = x >= 5 && x < w - 6 && d < dist_thr;
+                    const bool valid = d < dist_thr;         // (columns x < 5 and x >= w - 6: xmask below)
                     int detq, ddxq, ddyq;                    // det / 625, ddx / 125, ddy / 125 of the per-pixel loop
                     if (hh) {
                         detq = mad_i16h<true>(ci, cj, mad_i16h<true>(ncx, cx, 0));
@@ -1772,9 +1802,8 @@ __device__ __forceinline__ void d_dnormal_t(const u32 vblock, const u16* __restr
         for (int p = 0; p < 8; ++p) {
             // BRANCHLESS: every pixel runs the whole computation and the result is selected at the end (most pixels
             // are valid); with a branch per pixel the eight pixels' chains cannot be interleaved by the scheduler
-            const int x = 8 * g + p;
             const int d = (int)hw_u16(R[1], 8 + p);
-            const bool valid = x >= 5 && x < w - 6 && d < dist_thr;
+            const bool valid = d < dist_thr;                 // (columns x < 5 and x >= w - 6: xmask below)
             // sums over the neighbours that pass the bilateral gate |delta| < diff_thr (f = 1):
             //   ci / cj = how many with i != 0 / j != 0, cx = f(+,+) + f(-,-) - f(+,-) - f(-,+),
             //   sx / sy = sum of f delta over i = +5 minus over i = -5 / the same for j
@@ -1803,6 +1832,14 @@ __device__ __forceinline__ void d_dnormal_t(const u32 vblock, const u16* __restr
             out[p >> 2] |= e << (8 * (p & 3));
         }
         }
+    }
+    // columns x < 5 and x >= w - 6 stay 0 (upstream's loop bounds): one byte mask per lane instead of two compares per pixel
+    {
+        const int xlo = 5 - 8 * g, xhi = (w - 6) - 8 * g;            // valid pixels of this lane: xlo <= p < xhi
+        unsigned long long m = ~0ull;
+        if (xlo > 0) m &= xlo >= 8 ? 0ull : (~0ull << (8 * xlo));
+        if (xhi < 8) m &= xhi <= 0 ? 0ull : (~0ull >> (8 * (8 - xhi)));
+        out[0] &= (u32)m; out[1] &= (u32)(m >> 32);
     }
     *reinterpret_cast<u32x2*>(code + (size_t)y * w + 8 * g) = u32x2{out[0], out[1]};
 }

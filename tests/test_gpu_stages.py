@@ -155,14 +155,17 @@ def test_depth_quantize_thresholds_and_full_range(lm, orc, diff_thr):
 
 
 def test_depth_normal_float_tail_sequences_are_exact(lm):
-    """k_dnormal takes 1 / len and sqrt by sequences without the compiler's exponent-range handling (dn_rcp: v_rcp + six fused
-    steps, no v_div_scale / v_div_fixup; dn_sqrt: v_sqrt_f32 + the +-1 ulp fix-up, no denormal scaling).  Every float of the
+    """k_dnormal takes 1 / len and sqrt by short sequences (r04: dn_rcp = v_rcp + ONE Newton step, dn_sqrt = v_rsq + one coupled
+    step g + (x - g g) y / 2; r03's longer forms -- v_rcp + six fused steps, v_sqrt_f32 + the +-1 ulp fix-up -- are swept beside
+    them).  Every float of the
     tail's domain -- len in [1, 2^42], squared lengths in [1, 2^84] and 0 -- goes through both forms on the device, against
     the CORRECTLY ROUNDED 1.0f / x and sqrtf (r04: the reference used to be __fsqrt_rn, which this build lowers to the same
     bare v_sqrt_f32 the kernel used -- a test that could not fail); none may differ."""
     d = lm.Detector(color_only=False)
     assert d.selftest_float_tail() == (0, 0)
     print("floats on which the bare v_sqrt_f32 is not the correctly rounded root: %d" % d.last_bare_sqrt_mismatches)
+    print("the longer sequences of r03 / r04a, floats that differ:", d.last_candidate_mismatches)
+    assert all(v == 0 for v in d.last_candidate_mismatches.values())
     d.close()
 
 
