@@ -744,6 +744,13 @@ def preprocess_roofline(ctr, reason, one_lane, Bl):
     step_us = sum(v.get("avg_us", 0.0) * v.get("calls", 0) for v in ks.values() if v.get("calls", 0) >= 8)
     calls = [v["calls"] for k, v in ks.items() if k.startswith("k_scan") and "calls" in v]
     steps = max(calls) if calls else 1
+    # shader clock under load: GRBM_GUI_ACTIVE of the longest kernel (the scan; the counter comes as ONE row per dispatch that sums the 8
+    # XCDs) over its duration -- short kernels' GUI_ACTIVE contains launch overhead, so every kernel's cycles are its duration x this clock
+    clock_ghz = None
+    for k, v in ks.items():
+        if k.startswith("k_scan") and v.get("GRBM_GUI_ACTIVE") and v.get("avg_us"):
+            inst = max(v.get("GRBM_GUI_ACTIVE_instances", 1), 1)
+            clock_ghz = v["GRBM_GUI_ACTIVE"] / (8.0 if inst == 1 else inst) / v["avg_us"] / 1e3
     out, pre_us, pre_bytes = [], 0.0, 0.0
     for k, v in sorted(ks.items(), key=lambda kv: -kv[1].get("avg_us", 0) * kv[1].get("calls", 0)):
         if "avg_us" not in v or v.get("calls", 0) < 8 or k.startswith("__amd"):
@@ -766,8 +773,8 @@ def preprocess_roofline(ctr, reason, one_lane, Bl):
         if "TCP_TCC_READ_REQ_sum" in v and us > 0:
             l2 = v["TCP_TCC_READ_REQ_sum"] * ctr.get("bytes_per_request", 128) / (us * 1e-6) / 1e9
             e.update({"l2_read_GBps": round(l2, 1), "frac_of_l2_peak": round(l2 / L2_PEAK_GBS, 4)})
-        if "SQ_ACTIVE_INST_VALU" in v and v.get("GRBM_GUI_ACTIVE"):
-            cyc = v["GRBM_GUI_ACTIVE"] / max(v.get("GRBM_GUI_ACTIVE_instances", 1), 1)     # cycles the kernel held the chip
+        if "SQ_ACTIVE_INST_VALU" in v and clock_ghz:
+            cyc = us * clock_ghz * 1e3                                   # shader cycles of the clean launch
             e.update({"valu_busy": round(v["SQ_ACTIVE_INST_VALU"] * 4.0 / N_SIMD / cyc, 4),
                       "valu_insts_per_launch": v.get("SQ_INSTS_VALU"),
                       "valu_insts_per_simd_cycle": round(v.get("SQ_INSTS_VALU", 0.0) / N_SIMD / cyc, 4),
@@ -780,10 +787,12 @@ def preprocess_roofline(ctr, reason, one_lane, Bl):
     return {"kernels": out, "source": ctr["source"],
             "preprocess_sum_of_kernels_us_per_launch": round(pre_us, 1), "preprocess_live_us_per_launch": round(live, 1),
             "preprocess_hbm_bytes_per_frame": round(pre_bytes / Bl), "frames_per_launch": Bl,
+            "shader_clock_GHz_under_load": round(clock_ghz, 3) if clock_ghz else None,
             "definitions": "per kernel from the committed counter file of this very command (one lane, one launch per kernel; meta must equal "
                            "this run's, counters_meta): hbm_* = (2 x FETCH_SIZE + WRITE_SIZE) KB per launch / clean avg duration, against the 8 TB/s "
                            "peak and the 6.3 TB/s a streaming kernel achieves; valu_busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel "
-                           "cycles), kernel cycles = GRBM_GUI_ACTIVE per XCD; valu_insts_per_simd_cycle = SQ_INSTS_VALU / (1024 x cycles) "
+                           "cycles), kernel cycles = clean duration x the shader clock under load (GRBM_GUI_ACTIVE of the scan / 8 XCDs / its "
+                           "duration); valu_insts_per_simd_cycle = SQ_INSTS_VALU / (1024 x cycles) "
                            "(the issue classes of DESIGN.md section 5 cost 1 / 2.7 and 1 / 4.5 per cycle); l2_* = TCP_TCC_READ_REQ x 128 B; "
                            "bound = the largest of (hbm achievable, valu busy, l2) if >= 0.6; preprocess_live = HIP events of this run"}
 

@@ -168,9 +168,9 @@ def test_counter_files_are_used_only_for_the_command_they_were_collected_with(tm
     assert bench.load_counters(meta, str(tmp_path)) == (None, "no profiles/*_counters_c2.json committed")
     kernels = {
         "k_scan4<6, true, 2, false>": {"calls": 33, "avg_us": 167.0, "hbm_bytes_per_launch": 60e6, "TCP_TCC_READ_REQ_sum": 32.4e6,
-                                       "TCC_HIT_sum": 98.6, "TCC_MISS_sum": 1.4},
+                                       "TCC_HIT_sum": 98.6, "TCC_MISS_sum": 1.4, "GRBM_GUI_ACTIVE": 8 * 2.4e3 * 167.0, "GRBM_GUI_ACTIVE_instances": 1},
         "k_blur_pyr<16>": {"calls": 33, "avg_us": 70.0, "hbm_bytes_per_launch": 311e6, "hbm_read_bytes_per_launch": 200e6,
-                           "hbm_write_bytes_per_launch": 111e6, "SQ_ACTIVE_INST_VALU": 0.5 * 1024 * 168000 / 4, "SQ_INSTS_VALU": 3.0e7,
+                           "hbm_write_bytes_per_launch": 111e6, "SQ_ACTIVE_INST_VALU": 0.5 * 1024 * (70.0 * 2.4e3) / 4, "SQ_INSTS_VALU": 3.0e7,
                            "GRBM_GUI_ACTIVE": 8 * 168000.0, "GRBM_GUI_ACTIVE_instances": 8},
         "k_refine_plan": {"calls": 33, "avg_us": 1.0},
     }
