@@ -722,14 +722,21 @@ def why_l2(runner, wl, traffic, alg_bytes, ctr, kernel):
     fits = 2 * lm_bytes + bank <= 4.0e6
     if traffic is not None and alg_bytes:
         msg += "; measured HBM-side traffic of the kernel %.1f MB per launch = %.2f %% of the algorithmic bytes" % (traffic / 1e6, 100.0 * traffic / alg_bytes)
+    hit = None
     if ctr:
         for k, v in ctr["kernels"].items():
             if k.startswith(kernel) and v.get("TCC_HIT_sum") is not None and v.get("TCC_MISS_sum") is not None and v["TCC_HIT_sum"] + v["TCC_MISS_sum"] > 0:
-                msg += ", L2 hit rate %.1f %%" % (100.0 * v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]))
-    msg += ("; the working set fits the L2, so the kernel is bound by what its vector loads request from the L2s against the guide's 34.5 TB/s "
-            "aggregate L2 rate" if fits else
-            "; the working set does NOT fit one XCD's L2: part of the requests are served by the fabric (Infinity Cache / HBM), and the "
-            "L2-rate fraction is an upper-bound yard-stick for this config -- `traffic` against the 8 TB/s HBM peak is reported beside it")
+                hit = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+                msg += ", measured L2 hit rate %.1f %%" % (100.0 * hit)
+    if fits:
+        msg += ("; the working set fits the L2, so the kernel is bound by what its vector loads request from the L2s against the guide's 34.5 TB/s "
+                "aggregate L2 rate")
+    elif hit is not None and hit >= 0.95:
+        msg += ("; the nominal working set exceeds one XCD's L2, yet the requests hit it (work items are ordered by template and chunk, so "
+                "neighbouring waves touch the same lines of the same frame pair): the L2 -> L1 line rate is the binding roof here too")
+    else:
+        msg += ("; the working set does NOT fit one XCD's L2 and no counter file of this command says how often the requests hit it: the "
+                "L2-rate fraction is an upper-bound yard-stick for this config -- `traffic` against the 8 TB/s HBM peak is reported beside it")
     return msg
 
 

@@ -3669,6 +3669,12 @@ static int g_cblur_variant = 0;   // 0: by batch size (one-shot below 16 frames,
                                   // shared between neighbouring lanes (k_cblur_sh, r03: config 2 146.3 -> 150.7 K, config 3 81.9 -> 86.1 K
                                   // detections/s); A/B knob of tools/ and tests
 void lmk_set_cblur_variant(int v) { g_cblur_variant = v; }
+static int mx_strip_rows(int h) {      // rows per strip of the matrix-core blur (one extra 8-row tile per strip); LM_MX_STRIP overrides (experiments)
+    static const int forced = [] { const char* e = getenv("LM_MX_STRIP"); return e ? atoi(e) : 0; }();
+    if (forced >= 8) return forced / 8 * 8;
+    (void)h;
+    return 96;      // (measured r04: 48 / 96 / 192 / 480 rows are within 1 % of each other on configs 2 and 3; 96 best)
+}
 static bool mx_auto(int w, int h, int nslots) { return g_cblur_variant == 0 && sel_slots(nslots) >= 16 && (long)w * h * 3 <= 2000000L && ((w * 3) % 32) == 0; }
 static int g_dmedian_variant = 0;   // 0: by batch size (4 output rows per lane below 16 frames, DM_ROWS_BATCH from there), 1 / 2: force either
 void lmk_set_dmedian_variant(int v) { g_dmedian_variant = v; }
@@ -3703,7 +3709,7 @@ bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0,
     if (g_cblur_variant == 4 || mx_auto(w, h, nslots)) {
         if (((w * 3) % 32) != 0) return false;
         const int gx = (w * 3 + 4 * MX_WAVE_BYTES - 1) / (4 * MX_WAVE_BYTES);
-        const int strip_rows = h > 640 ? 96 : 48;
+        const int strip_rows = mx_strip_rows(h);
         const int gy = (h + strip_rows - 1) / strip_rows;
         hipLaunchKernelGGL(k_blur_mx_pyr, dim3((unsigned)((gx * gy + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, gx, gy, strip_rows, g_pyr, nslots);
         return true;
@@ -3745,7 +3751,7 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
             // r04 experiment: the blur on the matrix cores (k_cblur_mx); a workgroup = four waves side by side, each 128 byte columns
             // wide, walking down a strip of rows in steps of 8 (one extra tile of 8 rows per strip for the vertical taps)
             const int gx = (w * 3 + 4 * MX_WAVE_BYTES - 1) / (4 * MX_WAVE_BYTES);
-            const int strip_rows = h > 640 ? 96 : 48;
+            const int strip_rows = mx_strip_rows(h);
             const int gy = (h + strip_rows - 1) / strip_rows;
             hipLaunchKernelGGL(k_cblur_mx, dim3((unsigned)(gx * gy * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, gx, gy, strip_rows, nslots);
         } else if (g_cblur_variant == 1 || (g_cblur_variant == 0 && sel_slots(nslots) < 16)) {
