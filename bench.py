@@ -706,7 +706,7 @@ def main():
 
 HBM_ACHIEVABLE_GBS = 6300.0   # MI355X_MICROARCH.md: measured streaming ceiling of HBM3E on this part (what a copy kernel reaches)
 N_SIMD = 1024                 # 256 CUs x 4 SIMDs
-PRE_PREFIXES = ("k_blur_pyr", "k_cblur", "k_cgrad", "k_corient", "k_cvote", "k_pyrdown", "k_dnormal", "k_dmedian", "k_lm_", "k_linear_memories",
+PRE_PREFIXES = ("k_blur_pyr", "k_blur_mx", "k_cblur", "k_cgrad", "k_corient", "k_cvote", "k_pyrdown", "k_dnormal", "k_dmedian", "k_lm_", "k_linear_memories",
                 "k_phase", "k_bphase", "k_bsplit", "k_pair", "k_color_quantize", "k_depth_quantize", "k_nn_half", "k_pre")
 
 
