@@ -129,6 +129,8 @@ class Runner:
             det.set_tuning(lm.TUNE_SORT_SPLIT, args.sort_split)
         if args.no_work_weight:
             det.set_tuning(lm.TUNE_WORK_WEIGHT, 0)
+        if args.scan_list_order >= 0:
+            det.set_tuning(lm.TUNE_SCAN_LIST_ORDER, args.scan_list_order)
         if args.no_prune:
             det.set_scan_variant(8)
         elif args.scan_variant:
@@ -410,6 +412,7 @@ def main():
     ap.add_argument("--blur-pyr", type=int, default=-1, choices=(-1, 0, 1, 2, 3), help="A/B knob: LM_TUNE_BLUR_PYR (1: blur and pyrDown tiles of a slot back to back, 2: dealt out evenly, 3: by frame size = default)")
     ap.add_argument("--no-blur-pyr", action="store_true", help="A/B knob: level-0 blur and pyrDown as two launches (LM_TUNE_BLUR_PYR = 0)")
     ap.add_argument("--sort-split", type=int, default=-1, choices=(-1, 0, 1, 2), help="A/B knob: LM_TUNE_SORT_SPLIT (0 one workgroup per frame, 1 chunk workgroups + merge launch, 2 adaptive = default)")
+    ap.add_argument("--scan-list-order", type=int, default=-1, choices=(-1, 0, 1, 2, 3), help="A/B knob: LM_TUNE_SCAN_LIST_ORDER (0 ascending offsets, 1 round-robin over orientations, 2 descending, 3 farthest-point = default)")
     ap.add_argument("--no-work-weight", action="store_true", help="A/B knob: few-frame / batch kernel selection by frame count alone (LM_TUNE_WORK_WEIGHT = 0, r03)")
     ap.add_argument("--no-pose-e2e", action="store_true", help="config 5: skip the pose_e2e leg (PoseDetection::detectBatch end to end, tools/pose_e2e_bench.cpp)")
     ap.add_argument("--pose-e2e-iters", type=int, default=5)

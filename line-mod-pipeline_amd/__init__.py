@@ -49,6 +49,7 @@ TUNE_DMEDIAN_VARIANT = 11
 TUNE_BLUR_STRIP = 12
 TUNE_WORK_WEIGHT = 13
 TUNE_SORT_SPLIT = 14
+TUNE_SCAN_LIST_ORDER = 15
 
 
 class Rect(C.Structure):

@@ -133,6 +133,7 @@ struct lm_detector {
                                      // 0 never, 1 always, 2 (default) when no other lane has work in flight -- measured r03: alone on the
                                      // chip the fused launches win (config 2: 4.81 -> 4.66, config 3: 8.54 -> 8.06 us per frame), beside two
                                      // other lanes the separate launches interleave better (config 2: 145 K against 140 K detections/s)
+    int scan_list_order = 3;         // LM_TUNE_SCAN_LIST_ORDER (lm_host.h build_device_bank)
     int sort_split_mode = 2;         // device sort: 0 one workgroup per frame (r03), 1 always the split form (chunk workgroups + merge launch),
                                      // 2 (default) the split form while the recently collected lists were longer than LM_SORT_CHUNK keys
     int sort_long_score = 0;         // see note_sort_length
@@ -326,7 +327,7 @@ int ensure_bank(lm_detector* d) {
     HIP_TRY(hipDeviceSynchronize());
     free_device_bank(d);
     std::string err;
-    if (!lmh::build_device_bank(d->bank, d->cfg, d->geom, d->hb, err)) return fail(LM_ERR_INVALID, err);
+    if (!lmh::build_device_bank(d->bank, d->cfg, d->geom, d->hb, d->scan_list_order, err)) return fail(LM_ERR_INVALID, err);
     int rc;
     if ((rc = upload_vec(&d->d_item_t, d->hb.item_t))) return rc;
     if ((rc = upload_vec(&d->d_item_chunk, d->hb.item_chunk))) return rc;
@@ -1293,6 +1294,7 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
         case LM_TUNE_DMEDIAN_VARIANT: if (value < 0 || value > 2) break; lmk_set_dmedian_variant(value); return LM_OK;
         case LM_TUNE_WORK_WEIGHT: if (value < 0 || value > 1) break; d->work_weight_by_pixels = value; return LM_OK;
         case LM_TUNE_SORT_SPLIT: if (value < 0 || value > 2) break; d->sort_split_mode = value; return LM_OK;
+        case LM_TUNE_SCAN_LIST_ORDER: if (value < 0 || value > 3) break; d->scan_list_order = value; d->bank_dirty = true; return LM_OK;
         default: return fail(LM_ERR_INVALID, "unknown tuning key");
     }
     return fail(LM_ERR_INVALID, "tuning value out of range");

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace lmh {
@@ -106,7 +107,7 @@ int Bank::add_class(const std::string& id, int n_templates, const lm_template_de
 //     unshifted feature plus (x, y) for the bounds test after the patch offset is applied.
 // ------------------------------------------------------------------------------------------------
 bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom* geom, DeviceBankHost& out,
-                       std::string& err) {
+                       int scan_list_order, std::string& err) {
     const int M = cfg.num_modalities, L = cfg.pyramid_levels;
     out = DeviceBankHost();
     const LmLevelGeom& gl = geom[L - 1];
@@ -166,6 +167,54 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
                 // together and step through their lists in step) read from the same few linear memories at a
                 // time, so part of the traffic is served by the CU's L1 instead of L2
                 std::sort(out.scan_off.begin() + (ptrdiff_t)list_begin, out.scan_off.end());
+                {
+                    // r04: the ORDER of a list decides how soon the scan's exact pruning gives up on a work item (the sums do not depend
+                    // on it).  Sorted by offset (0) a list starts with ALL its features of orientation 0, whose responses rise and fall
+                    // together over the frame.  3 (default): greedy farthest-point order in (x, y, orientation) -- every next feature is the
+                    // one farthest from all chosen so far, an orientation step counting like 4 pixels -- so the first features sample the
+                    // template's whole extent and all its orientations.  Measured, share of the feature loads the pruned scan makes /
+                    // scan launch (profiles/r04_ab_experiments.log): config 2 49.7 % / 167 us (0), 48.2 % / 164 (1: round-robin over the
+                    // orientations), 50.5 % (2: descending offsets), 46.3 % / 158.5 (3); config 3 42.7 % / 409 -> 39.8 % / 392.
+                    const int feat_order = scan_list_order;
+                    if (feat_order == 2) std::reverse(out.scan_off.begin() + (ptrdiff_t)list_begin, out.scan_off.end());
+                    if (feat_order == 1) {
+                        std::vector<std::vector<u32>> by_label(8);
+                        for (size_t q = list_begin; q < out.scan_off.size(); ++q) {
+                            const u32 rel = out.scan_off[q] / osc - (u32)m * gl.mod_stride;
+                            by_label[std::min<u32>(rel / gl.ori_stride, 7u)].push_back(out.scan_off[q]);
+                        }
+                        size_t q = list_begin;
+                        for (size_t r = 0; q < out.scan_off.size(); ++r)
+                            for (int lb = 0; lb < 8; ++lb) if (r < by_label[lb].size()) out.scan_off[q++] = by_label[lb][r];
+                    }
+                    if (feat_order == 3) {
+                        struct FP { u32 off; int x, y, lab; };
+                        std::vector<FP> fp;
+                        for (const lm_feature& f : t.features) {
+                            if (f.x < 0 || f.x >= gl.w || f.y < 0 || f.y >= gl.h) continue;
+                            const u32 off = osc * ((u32)m * gl.mod_stride + (u32)f.label * gl.ori_stride) +
+                                            (u32)((f.y % gl.T) * gl.T + (f.x % gl.T)) * gl.wh + (u32)(f.y / gl.T) * gl.W + (u32)(f.x / gl.T);
+                            fp.push_back(FP{off, f.x, f.y, f.label});
+                        }
+                        std::vector<long> best(fp.size(), (long)1 << 40);
+                        std::vector<char> used(fp.size(), 0);
+                        size_t cur = 0;
+                        for (size_t q = 1; q < fp.size(); ++q) if (fp[q].off < fp[cur].off) cur = q;     // starts at the smallest offset
+                        for (size_t r = 0; r < fp.size(); ++r) {
+                            out.scan_off[list_begin + r] = fp[cur].off;
+                            used[cur] = 1;
+                            size_t nxt = cur; long far = -1;
+                            for (size_t q = 0; q < fp.size(); ++q) {
+                                if (used[q]) continue;
+                                const int dl = std::min((fp[q].lab - fp[cur].lab) & 7, (fp[cur].lab - fp[q].lab) & 7);
+                                const long dd = (long)(fp[q].x - fp[cur].x) * (fp[q].x - fp[cur].x) + (long)(fp[q].y - fp[cur].y) * (fp[q].y - fp[cur].y) + 16L * dl * dl;
+                                best[q] = std::min(best[q], dd);
+                                if (best[q] > far || (best[q] == far && fp[q].off < fp[nxt].off)) { far = best[q]; nxt = q; }
+                            }
+                            cur = nxt;
+                        }
+                    }
+                }
                 for (; k < out.fpad; ++k) out.scan_off.push_back(osc * gl.zero_off);
             }
             const int chunk = gl.nibble ? LM_SCAN4_CHUNK : LM_SCAN_CHUNK;

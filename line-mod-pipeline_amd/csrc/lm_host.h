@@ -61,8 +61,10 @@ inline void shard_range(int n, int rank, int size, int* lo, int* hi) {
     *hi = (int)((long long)n * (rank + 1) / size);
 }
 
+// scan_list_order: how a (template, modality) list of the scanned level is ordered -- 0 ascending offsets (r01-r03), 1 dealt round-robin over the
+// orientation labels, 2 descending offsets, 3 (default) greedy farthest-point order in (x, y, orientation); the sums do not depend on it
 bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom* geom, DeviceBankHost& out,
-                       std::string& err);
+                       int scan_list_order, std::string& err);
 
 // Convex hulls of the level-0 features (all modalities) of EVERY template of the bank, not only this shard's: the
 // colour check runs on merged match lists (host/PostProcess.cpp color_check; HighLevelLinemod.cpp:113-135).

@@ -92,6 +92,7 @@ while time.time() - t0 < budget:
         d.set_tuning(lm.TUNE_BATCH_PHASES, int(rng.choice([0, 1, 2])))     # 16+ frames: level-fused batch launches or one per kernel
         d.set_tuning(lm.TUNE_BLUR_PYR, int(rng.choice([0, 1, 2, 3])))         # level-0 blur + pyrDown apart, in one launch back to back, or dealt out evenly
         d.set_tuning(lm.TUNE_BLUR_STRIP, int(rng.choice([0, 16, 32, 64])))      # rows per blur strip inside k_blur_pyr
+        d.set_tuning(lm.TUNE_SCAN_LIST_ORDER, int(rng.choice([0, 1, 2, 3])))    # order of the scan's feature lists (same sums)
         d.set_tuning(lm.TUNE_LEVEL_PAIRS, int(rng.choice([0, 1])))         # level-1 kernels inside the level-0 grids (k_pair) or not
         for k in range(nb):
             d.upload_frame(k, bgr, None if color_only else depth)

@@ -464,6 +464,13 @@ def test_scan_pruning_is_exact(lm, orc, synth, color_only, thr):
         assert lanes[32][0] < 0.8 * lanes[16][0]                # dead lanes leave the loads' exec mask
     d.set_scan_variant(0)                                       # the default picks one of the two pruning rules by modality count
     assert np.array_equal(d.stage_scan(0, thr), exp)
+    # the order of a template's feature list (r04: farthest-point order by default) changes how soon the pruning stops, never the
+    # candidate list
+    for order in (0, 2, 1, 3):
+        d.set_tuning(lm.TUNE_SCAN_LIST_ORDER, order)
+        d.prepare_slot(0)
+        assert np.array_equal(d.stage_scan(0, thr), exp), order
+        assert_matches_equal(d.match_slot(0, thr, cap=1 << 16), o.match(bgr, dep, thr, threads=8))
     # the measurement hook over a batch of prepared slots (incl. the timing-only variant without the shift-undo)
     d.prepare_slot(1)
     assert d.time_scan_batch(0, 2, thr, iters=2) > 0 and d.time_scan_batch(0, 2, thr, iters=2, variant=8 | 64) > 0
