@@ -863,7 +863,7 @@ def pose_e2e(args, runner, lm, hot_path_us_per_frame_resident):
                 out["host" if mode else "gpu"] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         g = out["gpu"]
         total = g["us_per_frame"]
-        res = {"value": round(1e6 / total, 1), "unit": "frames/s through PoseDetection::detectBatch (one batch of %d frames at a time, no lanes; host post-processing on up to 16 threads)" % nf,
+        res = {"value": round(1e6 / total, 1), "unit": "frames/s through PoseDetection::detectBatch (one batch of %d frames at a time, no lanes; host post-processing on up to 32 threads)" % nf,
                "us_per_frame": total,
                "breakdown_us_per_frame": {"principal_point_shift_host": g["shift_us_per_frame"], "upload_pageable": g["upload_us_per_frame"],
                                           "hot_path_gpu_a3_a15": g["hot_path_us_per_frame"], "post_processing": g["post_us_per_frame"]},
@@ -874,7 +874,7 @@ def pose_e2e(args, runner, lm, hot_path_us_per_frame_resident):
                "classes": g["classes"], "templates": g["templates"], "frames": nf, "iterations": g["iterations"],
                "note": "the reference's call pattern (PoseDetection.cpp:45-126, HighLevelLinemod.cpp:157-175,206-253,424-515) on the bench's bank and frames: "
                        "post_processing = grouping + colour check (counts on the GPU, lm_color_check_counts) on the calling thread, then depth check + poses "
-                       "of the independent match groups on up to 16 host threads (the by-part figures are summed over the threads); synthetic "
+                       "of the independent match groups on up to 32 host threads (the by-part figures are summed over the threads); synthetic "
                        "template poses whose median depths rarely pass the depth check, so nearly every match of every surviving group is tested -- a "
                        "pessimistic load for the reference's nth_element over the template's bounding box per tested match; `value` of the line is the hot path alone with resident frames and three lanes"}
         if "host" in out:

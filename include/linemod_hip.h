@@ -161,6 +161,11 @@ int lm_match_classes(lm_detector* det, const uint8_t* bgr, size_t bgr_stride, co
  * be uploaded to (LM_ERR_INVALID).  The source buffer may be reused as soon as lm_upload_frame returns. */
 int lm_upload_frame(lm_detector* det, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
                     size_t depth_stride);
+/* lm_upload_frame of the frame translated by (shift_x, shift_y) pixels with zeros shifted in -- the reference's translateImg on
+ * both images before the match (principal-point shift: PoseDetection.cpp:54-59, 192-197) -- done while the staging buffer is
+ * filled: one pass over the frame instead of a translated host copy followed by the staging copy.  Same asynchronous contract. */
+int lm_upload_frame_shifted(lm_detector* det, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
+                            size_t depth_stride, int shift_x, int shift_y);
 /* The same for a source in PINNED host memory (lm_host_alloc, hipHostMalloc, hipHostRegister): no staging copy, the
  * DMA engine reads the caller's buffer, which therefore must stay untouched until lm_upload_wait(det, slot) returns
  * or a match that covers the slot has been collected.  This is the path that reaches the PCIe rate. */

@@ -73,7 +73,7 @@ EXPORTS = [
     "lm_prepare_slot", "lm_debug_read", "lm_stage_scan", "lm_time_scan", "lm_time_stages", "lm_set_scan_variant",
     "lm_last_counts", "lm_set_profiling", "lm_get_profile", "lm_scan_load_bytes",
     "lm_save_yaml", "lm_load_yaml", "lm_yaml_numbers", "lm_yaml_string", "lm_pack_matches", "lm_merge_batch",
-    "lm_match_begin", "lm_match_end", "lm_synchronize", "lm_merge_frames", "lm_gather_plan", "lm_gather_max_total",
+    "lm_upload_frame_shifted", "lm_match_begin", "lm_match_end", "lm_synchronize", "lm_merge_frames", "lm_gather_plan", "lm_gather_max_total",
     "lm_upload_frame_pinned", "lm_upload_wait", "lm_host_alloc", "lm_host_free", "lm_set_stage_chunks",
     "lm_set_tuning", "lm_comm_init", "lm_comm_destroy", "lm_comm_info", "lm_match_begin_gathered",
     "lm_match_end_gathered", "lm_comm_barrier", "lm_comm_max", "lm_upload_frames_pinned",
@@ -123,6 +123,7 @@ def load_library(path=None):
     lib.lm_get_template.argtypes = [vp, i, i, i, i, C.POINTER(i), C.POINTER(i), vp, C.POINTER(i)]
     lib.lm_match.argtypes = [vp, vp, sz, vp, sz, f, i, vp, sz, C.POINTER(sz)]
     lib.lm_upload_frame.argtypes = [vp, i, vp, sz, vp, sz]
+    lib.lm_upload_frame_shifted.argtypes = [vp, i, vp, sz, vp, sz, i, i]
     lib.lm_match_slot.argtypes = [vp, i, f, i, vp, sz, C.POINTER(sz)]
     lib.lm_match_batch.argtypes = [vp, i, f, i, vp, sz, vp]
     lib.lm_match_begin.argtypes = [vp, i, i, i, f, i]
@@ -527,6 +528,14 @@ class Detector:
         if bgr.shape != (self.cfg.height, self.cfg.width, 3):
             raise ValueError("frame size does not match the detector")
         self._check(self.lib.lm_upload_frame(self.h, slot, _ptr(bgr), 0, _ptr(depth), 0))
+
+    def upload_frame_shifted(self, slot, bgr, depth, shift_x, shift_y):
+        """upload_frame of the frame translated by (shift_x, shift_y) pixels, zeros shifted in (the reference's principal-point shift)."""
+        bgr = _c(bgr, np.uint8)
+        depth = None if depth is None else _c(depth, np.uint16)
+        if bgr.shape != (self.cfg.height, self.cfg.width, 3):
+            raise ValueError("frame size does not match the detector")
+        self._check(self.lib.lm_upload_frame_shifted(self.h, slot, _ptr(bgr), 0, _ptr(depth), 0, int(shift_x), int(shift_y)))
 
     def upload_frame_pinned(self, slot, bgr, depth=None):
         """Source arrays must live in pinned host memory (PinnedBuffer) and stay untouched until upload_wait(slot)

@@ -785,11 +785,29 @@ int copy_image(hipStream_t st, u8* dst, u8* staging, const u8* src, size_t strid
     return LM_OK;
 }
 
+// The same with the image translated by (ox, oy) pixels, zeros shifted in (cv::warpAffine with a pure translation as the reference's
+// translateImg does, PoseDetection.cpp:54-59,192-197): the shift happens while the staging buffer is filled, so a shifted upload costs
+// one pass over the image instead of two.  px = bytes per pixel.
+int copy_image_shifted(hipStream_t st, u8* dst, u8* staging, const u8* src, size_t stride, int w, int h, int px, int ox, int oy) {
+    const size_t row_bytes = (size_t)w * px;
+    const int x0 = std::max(ox, 0), x1 = std::min(w + ox, w);        // destination columns [x0, x1) have a source pixel
+    const int y0 = std::max(oy, 0), y1 = std::min(h + oy, h);
+    for (int y = 0; y < h; ++y) {
+        u8* row = staging + (size_t)y * row_bytes;
+        if (y < y0 || y >= y1 || x1 <= x0) { std::memset(row, 0, row_bytes); continue; }
+        if (x0 > 0) std::memset(row, 0, (size_t)x0 * px);
+        std::memcpy(row + (size_t)x0 * px, src + (size_t)(y - oy) * stride + (size_t)(x0 - ox) * px, (size_t)(x1 - x0) * px);
+        if (x1 < w) std::memset(row + (size_t)x1 * px, 0, (size_t)(w - x1) * px);
+    }
+    HIP_TRY(hipMemcpyAsync(dst, staging, row_bytes * (size_t)h, hipMemcpyHostToDevice, st));
+    return LM_OK;
+}
+
 // Frame -> slot.  inline_stream == nullptr: the copies go to the copy stream and the slot gets an upload ticket
 // (consumers call wait_uploads); otherwise they are issued on `inline_stream` itself, in order with the kernels
 // the caller enqueues behind them (single-frame calls: no cross-stream dependency on the latency path).
 int upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
-                 size_t depth_stride, bool pinned = false, hipStream_t inline_stream = nullptr) {
+                 size_t depth_stride, bool pinned = false, hipStream_t inline_stream = nullptr, int shift_x = 0, int shift_y = 0) {
     const lm_config& c = d->cfg;
     Slot& s = d->slots[slot];
     if (!bgr) return fail(LM_ERR_INVALID, "sources.size() != modalities.size(): colour image missing");
@@ -821,12 +839,18 @@ int upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride
         s.has_frame = true;
         return LM_OK;
     }
-    if ((rc = copy_image(st, d->bgr(slot, 0), s.h_bgr, bgr, bgr_stride, (size_t)c.width * 3, c.height, pinned, d->stage_chunks))) return rc;
+    const bool shifted = shift_x != 0 || shift_y != 0;
+    if (shifted) {
+        if ((rc = copy_image_shifted(st, d->bgr(slot, 0), s.h_bgr, bgr, bgr_stride, c.width, c.height, 3, shift_x, shift_y))) return rc;
+    } else if ((rc = copy_image(st, d->bgr(slot, 0), s.h_bgr, bgr, bgr_stride, (size_t)c.width * 3, c.height, pinned, d->stage_chunks))) return rc;
     if (!inline_stream && c.num_modalities == 2) HIP_TRY(hipEventRecord(s.ev_bgr, st));
-    if (c.num_modalities == 2 &&
-        (rc = copy_image(st, reinterpret_cast<u8*>(d->depth(slot)), reinterpret_cast<u8*>(s.h_depth),
-                         reinterpret_cast<const u8*>(depth), depth_stride, (size_t)c.width * 2, c.height, pinned, d->stage_chunks)))
-        return rc;
+    if (c.num_modalities == 2) {
+        if (shifted) rc = copy_image_shifted(st, reinterpret_cast<u8*>(d->depth(slot)), reinterpret_cast<u8*>(s.h_depth),
+                                             reinterpret_cast<const u8*>(depth), depth_stride, c.width, c.height, 2, shift_x, shift_y);
+        else rc = copy_image(st, reinterpret_cast<u8*>(d->depth(slot)), reinterpret_cast<u8*>(s.h_depth),
+                             reinterpret_cast<const u8*>(depth), depth_stride, (size_t)c.width * 2, c.height, pinned, d->stage_chunks);
+        if (rc) return rc;
+    }
     if (!inline_stream) {
         HIP_TRY(hipEventRecord(s.ev_up, st));
         s.up_stream = cs;
@@ -1192,6 +1216,14 @@ int lm_upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_str
     if ((rc = ready_for_compute(d))) return rc;
     if ((rc = check_slots(d, slot, 1))) return rc;
     return upload_frame(d, slot, bgr, bgr_stride, depth, depth_stride);
+}
+
+int lm_upload_frame_shifted(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
+                            size_t depth_stride, int shift_x, int shift_y) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if ((rc = check_slots(d, slot, 1))) return rc;
+    return upload_frame(d, slot, bgr, bgr_stride, depth, depth_stride, false, nullptr, shift_x, shift_y);
 }
 
 struct PinnedBlock { const u8* p; size_t bytes; };

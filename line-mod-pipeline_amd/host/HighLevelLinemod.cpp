@@ -160,9 +160,19 @@ bool HighLevelLineMOD::detectTemplatesBatch(std::vector<std::vector<Image>>& in_
         const Image* depth_img = in_frames[(size_t)i].size() >= 2 ? &in_frames[(size_t)i][1] : nullptr;
         const Image* match_depth = onlyColorModality ? nullptr : depth_img;
         if (color.width != videoWidth || color.height != videoHeight) { error = "frame size differs from the detector's"; return false; }
-        if (lm_upload_frame(detector, i, static_cast<const uint8_t*>(color.data), color.stride,
-                            match_depth ? static_cast<const uint16_t*>(match_depth->data) : nullptr,
-                            match_depth ? match_depth->stride : 0) != LM_OK) { error = lm_last_error(); return false; }
+        // a pending shift (Image::shift_*): applied while the staging buffer is filled; both images of the frame carry the same one
+        int urc;
+        if (color.shift_x || color.shift_y) {
+            if (depth_img && (depth_img->shift_x != color.shift_x || depth_img->shift_y != color.shift_y)) { error = "colour and depth image carry different pending shifts"; return false; }
+            if (!gpuColorCheck) { error = "the host colour check reads the colour image: shift it before the call (pending shifts need the GPU colour check)"; return false; }
+            urc = lm_upload_frame_shifted(detector, i, static_cast<const uint8_t*>(color.data), color.stride,
+                                          match_depth ? static_cast<const uint16_t*>(match_depth->data) : nullptr, match_depth ? match_depth->stride : 0,
+                                          color.shift_x, color.shift_y);
+        } else {
+            urc = lm_upload_frame(detector, i, static_cast<const uint8_t*>(color.data), color.stride,
+                                  match_depth ? static_cast<const uint16_t*>(match_depth->data) : nullptr, match_depth ? match_depth->stride : 0);
+        }
+        if (urc != LM_OK) { error = lm_last_error(); return false; }
     }
     const clk::time_point t_match = clk::now();
     std::vector<int32_t> cls(in_classNumbers.begin(), in_classNumbers.end());
@@ -187,7 +197,7 @@ bool HighLevelLineMOD::detectTemplatesBatch(std::vector<std::vector<Image>>& in_
     stageTimes.upload += secs(t_up, t_match); stageTimes.match += secs(t_match, t_post); stageTimes.frames += n;
     bool any = false;
     // ---- step 1, this thread (it owns the detector): split the mixed lists by class; per (class, frame) grouping + the GPU colour counts
-    struct Unit { size_t c; int i; PostProcessor pp; PostProcessor::Prepared prep; const std::vector<TemplatePose>* tpl; const uint16_t* depth; std::vector<uint16_t> dense; };
+    struct Unit { size_t c; int i; PostProcessor pp; PostProcessor::Prepared prep; const std::vector<TemplatePose>* tpl; const uint16_t* depth; std::vector<uint16_t> dense; ModelProperties props; };
     std::vector<Unit> units;
     PostProcessSettings ps;
     ps.onlyColorModality = onlyColorModality;
@@ -220,8 +230,9 @@ bool HighLevelLineMOD::detectTemplatesBatch(std::vector<std::vector<Image>>& in_
             if (cls_no < modProps->size()) props = (*modProps)[cls_no];
             const Image& color = in_frames[(size_t)i][0];
             const Image* depth_img = in_frames[(size_t)i].size() >= 2 ? &in_frames[(size_t)i][1] : nullptr;
-            units.push_back(Unit{c, i, PostProcessor(detector, ps), {}, &(*modelTemplates)[cls_no], nullptr, {}});
+            units.push_back(Unit{c, i, PostProcessor(detector, ps), {}, &(*modelTemplates)[cls_no], nullptr, {}, {}});
             Unit& u = units.back();
+            u.pp.setDepthShift(color.shift_x, color.shift_y);       // the host depth check reads the UNSHIFTED image through the pending shift
             if (depth_img) {
                 u.depth = static_cast<const uint16_t*>(depth_img->data);
                 if (depth_img->stride && depth_img->stride != (size_t)videoWidth * 2) {
@@ -231,8 +242,47 @@ bool HighLevelLineMOD::detectTemplatesBatch(std::vector<std::vector<Image>>& in_
                     u.depth = u.dense.data();
                 }
             }
-            u.prep = u.pp.prepare(dst, static_cast<const uint8_t*>(color.data), color.stride, *u.tpl, props, gpuColorCheck ? i : -1);
-            if (!u.pp.lastError().empty()) error = u.pp.lastError();
+            if (gpuColorCheck) {
+                u.prep = u.pp.prepare_groups(dst, *u.tpl);          // the colour counts follow, one GPU call per frame and HSV range
+                u.props = props;
+            } else {
+                u.prep = u.pp.prepare(dst, static_cast<const uint8_t*>(color.data), color.stride, *u.tpl, props, -1);
+                if (!u.pp.lastError().empty()) error = u.pp.lastError();
+            }
+        }
+        if (gpuColorCheck) {
+            // the units of this frame (they are the tail of `units`): classes with the same HSV range share ONE lm_color_check_counts call
+            // (the colour mask of the frame is computed once per call: three classes = one mask instead of three)
+            size_t first = units.size();
+            while (first > 0 && units[first - 1].i == i) --first;
+            std::vector<char> done(units.size() - first, 0);
+            for (size_t a = first; a < units.size(); ++a) {
+                if (done[a - first]) continue;
+                std::vector<size_t> same;
+                std::vector<lm_match_t> todo;
+                for (size_t b = a; b < units.size(); ++b) {
+                    if (done[b - first]) continue;
+                    bool eq = true;
+                    for (int k = 0; k < 3; ++k) eq = eq && units[a].props.lowerColorRange[k] == units[b].props.lowerColorRange[k] && units[a].props.upperColorRange[k] == units[b].props.upperColorRange[k];
+                    if (!eq) continue;
+                    done[b - first] = 1; same.push_back(b);
+                    todo.insert(todo.end(), units[b].prep.todo.begin(), units[b].prep.todo.end());
+                }
+                std::vector<int64_t> gin(todo.size()), gboth(todo.size());
+                const clk::time_point t_c = clk::now();
+                if (!todo.empty() && lm_color_check_counts(detector, i, units[a].props.lowerColorRange, units[a].props.upperColorRange, todo.data(), todo.size(),
+                                                           gin.data(), gboth.data()) != LM_OK) {
+                    error = lm_last_error();
+                    for (size_t b : same) { units[b].prep.failed = true; units[b].prep.groups.clear(); }
+                    continue;
+                }
+                PostProcessor::times().colour += secs(t_c, clk::now()); PostProcessor::times().colour_checks += (long)todo.size();
+                size_t at = 0;
+                for (size_t b : same) {
+                    PostProcessor::set_counts(units[b].prep, gin.data() + at, gboth.data() + at);
+                    at += units[b].prep.todo.size();
+                }
+            }
         }
     }
     // ---- step 2, any thread: one task per group of every unit (the sequential accept / break loop of a group: colour verdict,
@@ -242,7 +292,7 @@ bool HighLevelLineMOD::detectTemplatesBatch(std::vector<std::vector<Image>>& in_
     for (size_t k = 0; k < units.size(); ++k)
         for (size_t g = 0; g < units[k].prep.groups.size(); ++g) tasks.push_back(Task{k, g});
     std::vector<std::vector<ObjectPose>> results(tasks.size());
-    int nthreads = postThreads > 0 ? postThreads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    int nthreads = postThreads > 0 ? postThreads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
     nthreads = (int)std::min<size_t>((size_t)nthreads, std::max<size_t>(tasks.size(), 1));
     std::vector<PostProcessor::Times> wt((size_t)nthreads);
     std::atomic<size_t> next{0};

@@ -27,6 +27,11 @@ struct Image {
     int width = 0, height = 0;
     size_t stride = 0;  // bytes per row, 0 = dense
     int type = 0;
+    // r04: a translation still to be applied (zeros shifted in): detectTemplatesBatch applies it while the staging buffer of the upload
+    // is filled (lm_upload_frame_shifted) and the host depth check reads the depth image through it -- PoseDetection's principal-point
+    // shift without a translated host copy.  Both images of a frame carry the same value; needs the GPU colour check (the host colour
+    // check reads the colour image as it is).
+    int shift_x = 0, shift_y = 0;
 };
 
 struct Vec3 { float x = 0, y = 0, z = 0; };
@@ -99,9 +104,10 @@ public:
                               std::vector<std::vector<std::vector<std::vector<ObjectPose>>>>& out_poses);
     // colour checks of the post-processing on the GPU (default) or on the host (the reference's one-match-at-a-time way)
     void setGpuColorCheck(bool on) { gpuColorCheck = on; }
+    bool usesGpuColorCheck() const { return gpuColorCheck; }
     // host threads of detectTemplatesBatch's post-processing (r04): the groups of all (class, frame) pairs of a batch are independent
     // once their colour counts are known, and the reference's depth check (an nth_element over the template's bounding box per
-    // tested match) is 80 % of the batch's wall time on ONE thread.  0 (default) = one per hardware thread, at most 16; 1 = serial.
+    // tested match) is 80 % of the batch's wall time on ONE thread.  0 (default) = one per hardware thread, at most 32; 1 = serial.
     void setPostThreads(int n) { postThreads = n < 0 ? 0 : n; }
     // detector frame slots needed by detectTemplateBatch: lm_config.frame_slots (default 8)
     static constexpr int kBatchSlots = 8;

@@ -110,7 +110,17 @@ bool PoseDetection::detectBatch(std::vector<std::vector<Image>>& in_frames, std:
     if (in_frames.size() > (size_t)HighLevelLineMOD::kBatchSlots) { error = "batch of " + std::to_string(in_frames.size()) + " frames exceeds the detector's frame slots"; return false; }
     if (batchBufs.size() < in_frames.size()) batchBufs.resize(in_frames.size());
     std::vector<std::vector<Image>> shifted(in_frames.size());
-    for (size_t i = 0; i < in_frames.size(); ++i) shiftFrame(in_frames[i], batchBufs[i], shifted[i]);
+    if (line->usesGpuColorCheck()) {
+        // r04: nothing is translated on the host -- the frames go up through lm_upload_frame_shifted (the shift happens while the
+        // staging buffer is filled) and the host depth check reads the untranslated depth image through the same shift
+        const int ox = (int)(-camParams.cx + camParams.videoWidth / 2), oy = (int)(-camParams.cy + camParams.videoHeight / 2);
+        for (size_t i = 0; i < in_frames.size(); ++i) {
+            shifted[i] = in_frames[i];
+            for (Image& im : shifted[i]) { im.shift_x = ox; im.shift_y = oy; }
+        }
+    } else {
+        for (size_t i = 0; i < in_frames.size(); ++i) shiftFrame(in_frames[i], batchBufs[i], shifted[i]);
+    }
     std::vector<std::vector<std::vector<lm_match_t>>> m;
     std::vector<std::vector<std::vector<std::vector<ObjectPose>>>> groups;
     line->detectTemplatesBatch(shifted, idx, m, groups);

@@ -155,7 +155,8 @@ static void translate_rows(const T* src, int w, int h, int ox, int oy, std::vect
 void translate_u8c3(const uint8_t* src, int w, int h, int ox, int oy, std::vector<uint8_t>& dst) { translate_rows<uint8_t, 3>(src, w, h, ox, oy, dst); }
 void translate_u16(const uint16_t* src, int w, int h, int ox, int oy, std::vector<uint16_t>& dst) { translate_rows<uint16_t, 1>(src, w, h, ox, oy, dst); }
 
-uint16_t median_mat(const uint16_t* depth, int w, int h, Rect bb, uint8_t position) {
+// (shift_x, shift_y): `depth` is the frame before a translation by that many pixels with zeros shifted in; bb is in the translated frame
+uint16_t median_mat(const uint16_t* depth, int w, int h, Rect bb, uint8_t position, int shift_x, int shift_y) {
     int x0 = std::max(bb.x, 0), y0 = std::max(bb.y, 0);
     int x1 = std::min(bb.x + bb.width, w), y1 = std::min(bb.y + bb.height, h);   // cv::Mat ROI would assert; we clip
     if (x1 <= x0 || y1 <= y0 || position == 0) return 65535;
@@ -163,9 +164,16 @@ uint16_t median_mat(const uint16_t* depth, int w, int h, Rect bb, uint8_t positi
     const size_t rw = (size_t)(x1 - x0), n = rw * (size_t)(y1 - y0);
     v.resize(n);
     uint16_t* o = v.data();
+    // columns of the translated frame that have a source pixel: [sx0, sx1); the others (and whole rows without a source row) are the
+    // zeros shifted in, which threshold(.., 1, 65535) inverted turns into 65535 like every depth <= 1
+    const int sx0 = std::min(std::max(std::max(shift_x, 0), x0), x1), sx1 = std::max(std::min(std::min(w + shift_x, w), x1), sx0);
     for (int y = y0; y < y1; ++y) {
-        const uint16_t* r = depth + (size_t)y * w + x0;
-        for (size_t x = 0; x < rw; ++x) o[x] = r[x] > 1 ? r[x] : (uint16_t)65535;   // threshold(.., 1, 65535) inverted and added with saturation
+        const int sy = y - shift_y;
+        if (sy < 0 || sy >= h) { for (size_t x = 0; x < rw; ++x) o[x] = 65535; o += rw; continue; }
+        const uint16_t* r = depth + (size_t)sy * w - shift_x;                  // r[x] = source pixel of translated column x
+        for (int x = x0; x < sx0; ++x) o[x - x0] = 65535;
+        for (int x = sx0; x < sx1; ++x) o[x - x0] = r[x] > 1 ? r[x] : (uint16_t)65535;   // threshold(.., 1, 65535) inverted and added with saturation
+        for (int x = sx1; x < x1; ++x) o[x - x0] = 65535;
         o += rw;
     }
     std::nth_element(v.begin(), v.begin() + (ptrdiff_t)(n / 4), v.end());
@@ -317,7 +325,7 @@ bool PostProcessor::depth_check(const lm_match_t& m, const uint16_t* depth, cons
     const TemplatePose& tp = t[(size_t)m.template_id];
     if (st.useDepthImprovement) {
         Rect bb{m.x, m.y, tp.bb[2], tp.bb[3]};
-        int32_t depthDiff = (int32_t)((float)((int32_t)median_mat(depth, st.videoWidth, st.videoHeight, bb, 5) - (int32_t)tp.medianDepth) - st.depthOffset);
+        int32_t depthDiff = (int32_t)((float)((int32_t)median_mat(depth, st.videoWidth, st.videoHeight, bb, 5, depth_ox, depth_oy) - (int32_t)tp.medianDepth) - st.depthOffset);
         *tempDepth = (int32_t)(tp.translation[2] + (float)depthDiff);
         return std::abs(depthDiff) < (int32_t)st.stepSize;
     }
@@ -350,40 +358,47 @@ ObjectPose PostProcessor::make_pose(const lm_match_t& m, const std::vector<Templ
 
 PostProcessor::Times& PostProcessor::times() { static thread_local Times t; return t; }
 
+PostProcessor::Prepared PostProcessor::prepare_groups(const std::vector<lm_match_t>& matches, const std::vector<TemplatePose>& templates) {
+    using clk = std::chrono::steady_clock;
+    Times& tm = times();
+    Prepared p;
+    if (matches.empty()) return p;
+    const clk::time_point t_g = clk::now();
+    p.groups = discard_small_groups(group_similar_matches(matches, st.radiusThresholdNewObject), st.discardGroupRatio);
+    p.gpos.assign(matches.size(), (size_t)-1);
+    for (const MatchGroup& g : p.groups)
+        for (uint32_t idx : g.matchIndices)
+            if ((size_t)matches[idx].template_id < templates.size()) { p.gpos[idx] = p.todo.size(); p.todo.push_back(matches[idx]); }
+    tm.grouping += std::chrono::duration<double>(clk::now() - t_g).count(); tm.groups += (long)p.groups.size();
+    return p;
+}
+
 PostProcessor::Prepared PostProcessor::prepare(const std::vector<lm_match_t>& matches, const uint8_t* bgr, size_t bgr_stride,
                                                const std::vector<TemplatePose>& templates, const ModelProperties& props, int gpu_slot) {
     using clk = std::chrono::steady_clock;
-    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     Times& tm = times();
-    Prepared p;
-    p.gpu = gpu_slot >= 0;
+    Prepared p = prepare_groups(matches, templates);
     if (matches.empty()) return p;
     const int w = st.videoWidth, h = st.videoHeight;
-    const clk::time_point t_g = clk::now();
-    p.groups = discard_small_groups(group_similar_matches(matches, st.radiusThresholdNewObject), st.discardGroupRatio);
     const clk::time_point t_c = clk::now();
-    tm.grouping += secs(t_g, t_c); tm.groups += (long)p.groups.size();
     // colour check: on the host one match at a time as the reference does (:424-434), or every match of every surviving
     // group in one GPU batch up front -- the sequential accept / break logic of finish_group then only looks the verdicts up
-    p.gpos.assign(matches.size(), (size_t)-1);
-    if (p.gpu) {
-        std::vector<lm_match_t> todo;
-        for (const MatchGroup& g : p.groups)
-            for (uint32_t idx : g.matchIndices)
-                if ((size_t)matches[idx].template_id < templates.size()) { p.gpos[idx] = todo.size(); todo.push_back(matches[idx]); }
-        p.gin.resize(todo.size()); p.gboth.resize(todo.size());
-        if (lm_color_check_counts(det, gpu_slot, props.lowerColorRange, props.upperColorRange, todo.data(), todo.size(),
-                                  p.gin.data(), p.gboth.data()) != LM_OK) {
+    if (gpu_slot >= 0) {
+        std::vector<int64_t> gin(p.todo.size()), gboth(p.todo.size());
+        if (lm_color_check_counts(det, gpu_slot, props.lowerColorRange, props.upperColorRange, p.todo.data(), p.todo.size(),
+                                  gin.data(), gboth.data()) != LM_OK) {
             // loud, never a silent switch of implementation: frames of up to 4992 rows run on the GPU; beyond that the
             // caller selects the host check (HighLevelLineMOD::setGpuColorCheck(false))
             error = lm_last_error();
             p.failed = true;
             p.groups.clear();
+        } else {
+            set_counts(p, gin.data(), gboth.data());
         }
     } else {
         bgr2hsv_inrange(bgr, w, h, bgr_stride, props.lowerColorRange, props.upperColorRange, p.color_mask);   // :159-161
     }
-    tm.colour += secs(t_c, clk::now()); tm.colour_checks += (long)p.gin.size();
+    tm.colour += std::chrono::duration<double>(clk::now() - t_c).count(); tm.colour_checks += (long)p.gin.size();
     return p;
 }
 

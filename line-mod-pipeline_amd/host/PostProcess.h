@@ -67,7 +67,7 @@ void bgr2hsv_inrange(const uint8_t* bgr, int w, int h, size_t stride, const doub
 void translate_u8c3(const uint8_t* src, int w, int h, int ox, int oy, std::vector<uint8_t>& dst);
 void translate_u16(const uint16_t* src, int w, int h, int ox, int oy, std::vector<uint16_t>& dst);
 // HighLevelLineMOD::medianMat (:336-349): zeros -> 65535, crop, nth_element at n/4, returns element n/position.
-uint16_t median_mat(const uint16_t* depth, int w, int h, Rect bb, uint8_t position);
+uint16_t median_mat(const uint16_t* depth, int w, int h, Rect bb, uint8_t position, int shift_x = 0, int shift_y = 0);
 struct Pt { int x, y; };
 std::vector<Pt> convex_hull(std::vector<Pt> pts);                   // cv::convexHull (hull vertices, ccw, no collinear points)
 // templateMask (:113-135) restricted to the hull's bounding box: returns (pixels in hull, pixels in hull
@@ -109,16 +109,28 @@ public:
         std::vector<MatchGroup> groups;
         std::vector<int64_t> gin, gboth;          // GPU colour counts, [gpos[match index]]
         std::vector<size_t> gpos;
+        std::vector<lm_match_t> todo;             // the matches whose counts are wanted, in gpos order (prepare_groups)
         std::vector<uint8_t> color_mask;          // host colour check: the frame's HSV in-range mask
         bool gpu = false, failed = false;
     };
     Prepared prepare(const std::vector<lm_match_t>& matches, const uint8_t* bgr, size_t bgr_stride,
                      const std::vector<TemplatePose>& templates, const ModelProperties& props, int gpu_slot);
+    // prepare() in two halves for callers that batch the GPU colour counts of several classes of one frame into ONE
+    // lm_color_check_counts call (same HSV range): the grouping + the list of matches whose counts are wanted (host only), then the
+    // counts, in p.todo's order
+    Prepared prepare_groups(const std::vector<lm_match_t>& matches, const std::vector<TemplatePose>& templates);
+    static void set_counts(Prepared& p, const int64_t* in_hull, const int64_t* in_both) {
+        p.gin.assign(in_hull, in_hull + p.todo.size()); p.gboth.assign(in_both, in_both + p.todo.size()); p.gpu = true;
+    }
     std::vector<ObjectPose> finish_group(const Prepared& p, size_t group, const std::vector<lm_match_t>& matches, const uint16_t* dense_depth,
                                          const std::vector<TemplatePose>& templates, Times* tm) const;
     // the two counts of colorCheck for one match, on the host (also the checker of the GPU path)
     bool color_counts(const lm_match_t& m, const std::vector<uint8_t>& color_mask, long* in_hull, long* in_both) const;
     const std::string& lastError() const { return error; }
+    // The depth image handed to run() / finish_group() is the frame BEFORE a translation by (ox, oy) with zeros shifted in (the
+    // reference's principal-point shift): the depth check then reads pixel (x - ox, y - oy), 0 outside -- the same values the
+    // translated copy would hold, without making the copy.  Match coordinates are in the translated frame either way.
+    void setDepthShift(int ox, int oy) { depth_ox = ox; depth_oy = oy; }
 
 private:
     bool color_check(const lm_match_t& m, const std::vector<uint8_t>& color_mask) const;                    // :424-434
@@ -127,6 +139,7 @@ private:
     ObjectPose make_pose(const lm_match_t& m, const std::vector<TemplatePose>& t, int32_t tempDepth) const; // :459-515
     lm_detector* det;
     PostProcessSettings st;
+    int depth_ox = 0, depth_oy = 0;
 };
 
 }  // namespace lmamd

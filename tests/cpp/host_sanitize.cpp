@@ -50,7 +50,7 @@ static void digest(const lmh::Bank& bank, const lm_config& cfg) {
     make_geom(cfg, geom);
     lmh::DeviceBankHost hb;
     std::string err;
-    (void)lmh::build_device_bank(bank, cfg, geom, hb, err);
+    for (int order = 0; order <= 3; ++order) (void)lmh::build_device_bank(bank, cfg, geom, hb, order, err);     // every order of the scan lists
     lmh::HullTable ht;
     lmh::build_hull_table(bank, cfg.num_modalities, ht);
 }

@@ -279,3 +279,31 @@ def test_batches_take_one_launch_per_dependency_level(lm, orc, synth, color_only
     d.set_tuning(lm.TUNE_LEVEL_PAIRS, 0)
     d.set_tuning(lm.TUNE_BLUR_STRIP, 0)
     d.close()
+
+
+def test_shifted_upload_equals_upload_of_the_shifted_frame(lm, orc, synth):
+    """lm_upload_frame_shifted = the reference's translateImg (zeros shifted in) folded into the staging copy: every shift, also beyond the
+    frame, must give the match list of the host-shifted frame."""
+    W, H = 640, 480
+    bgr, depth = synth.make_frame(W, H, seed=4242)
+    d = lm.Detector(color_only=False, width=W, height=H, frame_slots=2)
+    o = orc.Detector(color_only=False)
+    o.prepare(bgr, depth)
+    q = {(l, m): o.stage(0, l, m).reshape(H >> l, W >> l) for l in range(2) for m in range(2)}
+    descs, feats, _ = synth.make_bank(40, 2, 2, seed=9, quantized=q, crop_fraction=0.5, frame_size=(W, H), T0=5)
+    d.add_class("c", descs, feats)
+
+    def host_shift(img, ox, oy):
+        out = np.zeros_like(img)
+        x0, x1, y0, y1 = max(ox, 0), min(W + ox, W), max(oy, 0), min(H + oy, H)
+        if x1 > x0 and y1 > y0:
+            out[y0:y1, x0:x1] = img[y0 - oy:y1 - oy, x0 - ox:x1 - ox]
+        return out
+
+    for ox, oy in ((0, 0), (-12, 10), (37, -5), (-640, 3), (5, 480), (1, 1)):
+        d.upload_frame_shifted(0, bgr, depth, ox, oy)
+        d.upload_frame(1, host_shift(bgr, ox, oy), host_shift(depth, ox, oy))
+        out, cnt = d.match_batch(2, 70.0)
+        assert cnt[0] == cnt[1] and out[0, :cnt[0]].tobytes() == out[1, :cnt[1]].tobytes(), (ox, oy)
+        assert np.array_equal(d.debug_read(0, 0, 0, 1), d.debug_read(1, 0, 0, 1)), (ox, oy)      # the depth modality's quantised image
+    d.close()
