@@ -765,7 +765,7 @@ class Detector:
         out = (C.c_uint64 * 8)()
         self._check(self.lib.lm_selftest_float_tail(self.h, out))
         self.last_bare_sqrt_mismatches = int(out[2])
-        self.last_candidate_mismatches = {"v_rcp + six steps (r03)": int(out[3]), "v_sqrt + fix-up": int(out[4]), "v_sqrt + v_rsq step": int(out[5])}
+        self.last_candidate_mismatches = {"v_rcp + six steps (r03)": int(out[3]), "v_sqrt + fix-up": int(out[4]), "v_sqrt + v_rsq step": int(out[5]), "1 / root from the root's own v_rsq + one step": int(out[6])}
         return int(out[0]), int(out[1])
 
     def time_stages(self, slot, threshold, class_idx=-1, iters=20):

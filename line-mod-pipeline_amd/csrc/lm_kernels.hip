@@ -1663,6 +1663,13 @@ __device__ __forceinline__ float dn_sqrt4(float x) {         // v_sqrt + one ste
     const float e = __builtin_fmaf(-s, s, x);
     return __builtin_fmaf(e, __fmul_rn(0.5f, y), s);
 }
+// candidate (r04): 1 / sqrt(x) rounded like 1.0f / sqrtf(x) from the SAME v_rsq the root uses -- one Newton step on the reciprocal of the
+// (exact) root starting at y: no v_rcp.  Kept or dropped by the sweep below.
+__device__ __forceinline__ float dn_inv_from_rsq(float x, float len) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float e = __builtin_fmaf(-len, y, 1.0f);
+    return __builtin_fmaf(e, y, y);
+}
 __device__ __forceinline__ float dn_rcp(float d) { return dn_rcp3(d); }
 __device__ __forceinline__ float dn_sqrt(float x) { return dn_sqrt5(x); }
 // `ok` = the pixel's depth passes the distance threshold (the row-end columns are masked by the caller, once per lane, r04).
@@ -1692,7 +1699,7 @@ __device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool o
 // out[2]: the bare v_sqrt_f32 against the same reference (information: how often the 1-ulp instruction is off)
 __global__ __launch_bounds__(256) void k_selftest_float_tail(unsigned long long* __restrict__ out) {
     const u32 lo = 0x3F800000u, hi_rcp = (127u + 42u) << 23, hi_sqrt = (127u + 84u) << 23;   // 1.0f .. 2^42 / 2^84
-    unsigned long long bad_rcp = 0, bad_sqrt = 0, bad_bare = 0, c_rcp3 = 0, c_sqrt5 = 0, c_sqrt4 = 0;
+    unsigned long long bad_rcp = 0, bad_sqrt = 0, bad_bare = 0, c_rcp3 = 0, c_sqrt5 = 0, c_sqrt4 = 0, c_inv = 0;
     for (u32 b = lo + blockIdx.x * 256u + threadIdx.x; b <= hi_sqrt; b += gridDim.x * 256u) {
         const float x = __builtin_bit_cast(float, b);
         if (b <= hi_rcp) bad_rcp += __builtin_bit_cast(u32, dn_rcp(x)) != __builtin_bit_cast(u32, __fdiv_rn(1.0f, x));
@@ -1702,6 +1709,7 @@ __global__ __launch_bounds__(256) void k_selftest_float_tail(unsigned long long*
         if (b <= hi_rcp) c_rcp3 += __builtin_bit_cast(u32, dn_rcp7(x)) != __builtin_bit_cast(u32, __fdiv_rn(1.0f, x));
         c_sqrt5 += __builtin_bit_cast(u32, dn_sqrt9(x)) != want;
         c_sqrt4 += __builtin_bit_cast(u32, dn_sqrt4(x)) != want;
+        c_inv += __builtin_bit_cast(u32, dn_inv_from_rsq(x, dn_sqrt(x))) != __builtin_bit_cast(u32, __fdiv_rn(1.0f, __builtin_sqrtf(x)));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) bad_sqrt += dn_sqrt(0.0f) > 0.0f ? 1u : 0u;     // (0 or a NaN: what the caller's `len > 0` needs)
     if (bad_rcp) atomicAdd(&out[0], bad_rcp);
@@ -1710,6 +1718,7 @@ __global__ __launch_bounds__(256) void k_selftest_float_tail(unsigned long long*
     if (c_rcp3) atomicAdd(&out[3], c_rcp3);
     if (c_sqrt5) atomicAdd(&out[4], c_sqrt5);
     if (c_sqrt4) atomicAdd(&out[5], c_sqrt4);
+    if (c_inv) atomicAdd(&out[6], c_inv);
 }
 
 template <bool SMALL>
@@ -3669,12 +3678,11 @@ static int g_cblur_variant = 0;   // 0: by batch size (one-shot below 16 frames,
                                   // shared between neighbouring lanes (k_cblur_sh, r03: config 2 146.3 -> 150.7 K, config 3 81.9 -> 86.1 K
                                   // detections/s); A/B knob of tools/ and tests
 void lmk_set_cblur_variant(int v) { g_cblur_variant = v; }
-static int mx_strip_rows(int h) {      // rows per strip of the matrix-core blur (one extra 8-row tile per strip); LM_MX_STRIP overrides (experiments)
-    static const int forced = [] { const char* e = getenv("LM_MX_STRIP"); return e ? atoi(e) : 0; }();
-    if (forced >= 8) return forced / 8 * 8;
-    (void)h;
-    return 96;      // (measured r04: 48 / 96 / 192 / 480 rows are within 1 % of each other on configs 2 and 3; 96 best)
-}
+static int g_blur_strip = 0;   // rows per strip of the level-0 blur inside k_blur_pyr / of the matrix-core blur: 0 = by shape and batch size, 16 / 32 / 64 = forced (A/B, tests)
+void lmk_set_blur_strip(int v) { g_blur_strip = v; }
+// rows per strip of the matrix-core blur (one extra 8-row tile per strip for the vertical taps).  Measured r04 (profiles/r04_ab_experiments.log):
+// 48 / 96 / 192 / 480 rows are within 1 % of each other on configs 2 and 3, 96 best; LM_TUNE_BLUR_STRIP forces 16 / 32 / 64.
+static int mx_strip_rows() { return g_blur_strip ? g_blur_strip : 96; }
 static bool mx_auto(int w, int h, int nslots) { return g_cblur_variant == 0 && sel_slots(nslots) >= 16 && (long)w * h * 3 <= 2000000L && ((w * 3) % 32) == 0; }
 static int g_dmedian_variant = 0;   // 0: by batch size (4 output rows per lane below 16 frames, DM_ROWS_BATCH from there), 1 / 2: force either
 void lmk_set_dmedian_variant(int v) { g_dmedian_variant = v; }
@@ -3687,8 +3695,6 @@ size_t lmk_color_scratch_bytes(int w, int h) {
     return (px * 3 + 255) / 256 * 256 + (px + 255) / 256 * 256;
 }
 
-static int g_blur_strip = 0;   // rows per strip of the level-0 blur inside k_blur_pyr: 0 = by shape and batch size, 16 / 32 / 64 = forced (A/B, tests)
-void lmk_set_blur_strip(int v) { g_blur_strip = v; }
 // k_blur_pyr: a slot's blur and pyrDown tiles dealt out evenly by rows (r04) instead of back to back.  Measured (tools/ab_blur_pyr.sh,
 // profiles/r04_ab_experiments.log): 1280 x 960 (3.7 MB per frame, never L2-resident back to back) reads 8.64 -> 7.54 MB per frame, the launch
 // 271.7 -> 260.1 us per 128 frames, config 3 +0.8 %; 640 x 480 reads 2.09 -> 1.98 MB but the launch gets 4 us LONGER (70.7 -> 74.7) and the
@@ -3709,7 +3715,7 @@ bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0,
     if (g_cblur_variant == 4 || mx_auto(w, h, nslots)) {
         if (((w * 3) % 32) != 0) return false;
         const int gx = (w * 3 + 4 * MX_WAVE_BYTES - 1) / (4 * MX_WAVE_BYTES);
-        const int strip_rows = mx_strip_rows(h);
+        const int strip_rows = mx_strip_rows();
         const int gy = (h + strip_rows - 1) / strip_rows;
         hipLaunchKernelGGL(k_blur_mx_pyr, dim3((unsigned)((gx * gy + g_pyr) * nslots)), dim3(256), 0, s, bgr0, w, h, scratch0, bgr1, slot_stride, gx, gy, strip_rows, g_pyr, nslots);
         return true;
@@ -3751,7 +3757,7 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
             // r04 experiment: the blur on the matrix cores (k_cblur_mx); a workgroup = four waves side by side, each 128 byte columns
             // wide, walking down a strip of rows in steps of 8 (one extra tile of 8 rows per strip for the vertical taps)
             const int gx = (w * 3 + 4 * MX_WAVE_BYTES - 1) / (4 * MX_WAVE_BYTES);
-            const int strip_rows = mx_strip_rows(h);
+            const int strip_rows = mx_strip_rows();
             const int gy = (h + strip_rows - 1) / strip_rows;
             hipLaunchKernelGGL(k_cblur_mx, dim3((unsigned)(gx * gy * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, gx, gy, strip_rows, nslots);
         } else if (g_cblur_variant == 1 || (g_cblur_variant == 0 && sel_slots(nslots) < 16)) {
