@@ -7,6 +7,7 @@
 // read out of bounds, overflow, or hang.
 // usage: host_sanitize <opencv_style_templates.yml> <iterations> <seed> <scratch dir>
 #include <cstdint>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -50,7 +51,19 @@ static void digest(const lmh::Bank& bank, const lm_config& cfg) {
     make_geom(cfg, geom);
     lmh::DeviceBankHost hb;
     std::string err;
-    for (int order = 0; order <= 3; ++order) (void)lmh::build_device_bank(bank, cfg, geom, hb, order, err);     // every order of the scan lists
+    // every order of the scan lists (LM_TUNE_SCAN_LIST_ORDER): each must be a permutation of the ascending lists, list by list
+    std::vector<u32> base;
+    size_t fpad = 0;
+    for (int order = 0; order <= 3; ++order) {
+        if (!lmh::build_device_bank(bank, cfg, geom, hb, order, err)) return;
+        if (order == 0) { base = hb.scan_off; fpad = (size_t)hb.fpad; continue; }
+        if (hb.scan_off.size() != base.size() || fpad == 0) { std::printf("scan list order %d changes the list sizes\n", order); std::abort(); }
+        for (size_t at = 0; at + fpad <= base.size(); at += fpad) {
+            std::vector<u32> a(base.begin() + (ptrdiff_t)at, base.begin() + (ptrdiff_t)(at + fpad)), b(hb.scan_off.begin() + (ptrdiff_t)at, hb.scan_off.begin() + (ptrdiff_t)(at + fpad));
+            std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+            if (a != b) { std::printf("scan list order %d is not a permutation of the ascending list at %zu\n", order, at); std::abort(); }
+        }
+    }
     lmh::HullTable ht;
     lmh::build_hull_table(bank, cfg.num_modalities, ht);
 }

@@ -99,6 +99,34 @@ int main() {
         translate_u16(d.data(), 4, 3, 1, -1, o);
         CHECK(o[0] == 0 && o[1] == 5 && o[2] == 6 && o[3] == 7 && o[8] == 0 && o[11] == 0);
     }
+    // ---- r04: the row-wise translation against the per-pixel definition, every kind of shift (also beyond the frame), both types;
+    // and the depth check's median read THROUGH a pending shift against the median on the translated copy
+    {
+        const int W = 37, H = 23;
+        std::vector<uint8_t> c((size_t)W * H * 3), co;
+        std::vector<uint16_t> d((size_t)W * H), dd;
+        uint32_t r = 12345;
+        auto rnd = [&]() { r = r * 1664525u + 1013904223u; return r >> 8; };
+        for (uint8_t& v : c) v = (uint8_t)rnd();
+        for (uint16_t& v : d) v = (uint16_t)(rnd() % 7 == 0 ? rnd() % 2 : 400 + rnd() % 900);     // holes (0 / 1) and depths
+        const int shifts[][2] = {{0, 0}, {5, -3}, {-12, 10}, {36, 22}, {-36, -22}, {37, 0}, {0, -23}, {100, 100}, {1, 1}};
+        for (const auto& sh : shifts) {
+            const int ox = sh[0], oy = sh[1];
+            translate_u8c3(c.data(), W, H, ox, oy, co);
+            translate_u16(d.data(), W, H, ox, oy, dd);
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    const int sx = x - ox, sy = y - oy;
+                    const bool in = sx >= 0 && sx < W && sy >= 0 && sy < H;
+                    CHECK(dd[(size_t)y * W + x] == (in ? d[(size_t)sy * W + sx] : 0));
+                    for (int k = 0; k < 3; ++k) CHECK(co[((size_t)y * W + x) * 3 + k] == (in ? c[((size_t)sy * W + sx) * 3 + k] : 0));
+                }
+            const Rect boxes[] = {{0, 0, W, H}, {3, 2, 10, 8}, {-4, -4, 12, 12}, {30, 18, 20, 20}, {10, 5, 1, 1}, {40, 5, 3, 3}, {12, 0, 25, 23}};
+            for (const Rect& bb : boxes)
+                for (uint8_t pos : {(uint8_t)5, (uint8_t)4, (uint8_t)0})
+                    CHECK(median_mat(d.data(), W, H, bb, pos, ox, oy) == median_mat(dd.data(), W, H, bb, pos));
+        }
+    }
     // ---- CameraViewPoints (CameraViewPoints.cpp): shipped model = rotationally symmetric, planes (1,1,1),
     // subdivisions 3 -> 13 viewpoints on the quarter arc (13 x 15 x 10 = 1950 templates)
     {
