@@ -415,7 +415,9 @@ def main():
     ap.add_argument("--scan-list-order", type=int, default=-1, choices=(-1, 0, 1, 2, 3), help="A/B knob: LM_TUNE_SCAN_LIST_ORDER (0 ascending offsets, 1 round-robin over orientations, 2 descending, 3 farthest-point = default)")
     ap.add_argument("--no-work-weight", action="store_true", help="A/B knob: few-frame / batch kernel selection by frame count alone (LM_TUNE_WORK_WEIGHT = 0, r03)")
     ap.add_argument("--no-pose-e2e", action="store_true", help="config 5: skip the pose_e2e leg (PoseDetection::detectBatch end to end, tools/pose_e2e_bench.cpp)")
-    ap.add_argument("--pose-e2e-iters", type=int, default=5)
+    ap.add_argument("--pose-e2e-iters", type=int, default=20)
+    ap.add_argument("--pose-e2e-threads", type=int, default=0, help="pose_e2e leg: host threads of the facade's pool (0 = one per usable CPU, at most 32)")
+    ap.add_argument("--pose-e2e-wrap", default="", help="pose_e2e leg: command prefix for the child process (e.g. a rocprofv3 trace command ending in --)")
     ap.add_argument("--pose-e2e-host-colour", action="store_true", help="pose_e2e leg: also time the colour check on the host (one full-frame mask per match)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the h2d_inclusive (streaming) leg")
@@ -854,31 +856,46 @@ def pose_e2e(args, runner, lm, hot_path_us_per_frame_resident):
             with open(raw, "wb") as f:
                 for bgr, depth in runner.frames[:nf]:
                     f.write(np.ascontiguousarray(bgr).tobytes()); f.write(np.ascontiguousarray(depth, np.uint16).tobytes())
+            keep = os.environ.get("LM_POSE_E2E_KEEP")          # experiments: keep the child's inputs and binary for runs by hand
+            if keep:
+                import shutil
+                os.makedirs(keep, exist_ok=True)
+                for src in (bank, pose, raw, exe):
+                    shutil.copy(src, os.path.join(keep, os.path.basename(src) if src != exe else "pose_e2e_bench"))
             out = {}
             for mode in (0, 1) if args.pose_e2e_host_colour else (0,):
-                r = subprocess.run([exe, bank, pose, raw, str(runner.W), str(runner.H), str(nf), str(args.threshold), str(args.pose_e2e_iters), str(mode)],
+                r = subprocess.run(args.pose_e2e_wrap.split() + [exe, bank, pose, raw, str(runner.W), str(runner.H), str(nf), str(args.threshold), str(args.pose_e2e_iters), str(mode), str(args.pose_e2e_threads)],
                                    capture_output=True, text=True, timeout=900)
                 if r.returncode != 0:
                     return {"error": "pose_e2e_bench exited with %d: %s" % (r.returncode, r.stderr[-500:])}
                 out["host" if mode else "gpu"] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         g = out["gpu"]
-        total = g["us_per_frame"]
-        res = {"value": round(1e6 / total, 1), "unit": "frames/s through PoseDetection::detectBatch (one batch of %d frames at a time, no lanes; host post-processing on up to 32 threads)" % nf,
+        ser, pip, pin = g["serial"], g["pipelined"], g["pipelined_pinned"]
+        total = pip["us_per_frame"]
+        res = {"value": round(1e6 / total, 1),
+               "unit": "frames/s through PoseDetection::detectBatchBegin / detectBatchEnd, pageable frames, steady state (batches of %d frames, two in flight; %d host threads)" % (nf, g["host_threads"]),
                "us_per_frame": total,
-               "breakdown_us_per_frame": {"principal_point_shift_host": g["shift_us_per_frame"], "upload_pageable": g["upload_us_per_frame"],
-                                          "hot_path_gpu_a3_a15": g["hot_path_us_per_frame"], "post_processing": g["post_us_per_frame"]},
-               "host_share": round(1.0 - g["hot_path_us_per_frame"] / total, 4),
+               "us_per_frame_serial": ser["us_per_frame"], "us_per_frame_pipelined_pinned_frames": pin["us_per_frame"],
+               "poses_identical_across_passes": g["poses_identical_across_passes"],
+               "share_of_wall_pipelined": {"gpu_hot_path": pip["gpu_share_of_wall"], "pcie_link": pip["link_share_of_wall"],
+                                           "host_in_begin_staging_and_enqueue": round(pip["in_begin_us_per_frame"] / total, 4),
+                                           "host_waiting_for_the_gpu": round(pip["waiting_for_the_gpu_us_per_frame"] / total, 4),
+                                           "host_post_processing": round(pip["post_us_per_frame"] / total, 4)},
+               "serial": ser, "pipelined": pip, "pipelined_pinned": pin,
                "hot_path_us_per_frame_in_the_timed_region_above": round(hot_path_us_per_frame_resident, 2),
-               "post_processing_us_per_frame_by_part": g.get("post_us_per_frame_by_part"), "post_processing_counts_per_frame": g.get("per_frame_counts"),
                "matches_per_frame": g["matches_per_frame"], "grouped_poses_per_frame": g["grouped_poses_per_frame"],
-               "classes": g["classes"], "templates": g["templates"], "frames": nf, "iterations": g["iterations"],
-               "note": "the reference's call pattern (PoseDetection.cpp:45-126, HighLevelLinemod.cpp:157-175,206-253,424-515) on the bench's bank and frames: "
-                       "post_processing = grouping + colour check (counts on the GPU, lm_color_check_counts) on the calling thread, then depth check + poses "
-                       "of the independent match groups on up to 32 host threads (the by-part figures are summed over the threads); synthetic "
-                       "template poses whose median depths rarely pass the depth check, so nearly every match of every surviving group is tested -- a "
-                       "pessimistic load for the reference's nth_element over the template's bounding box per tested match; `value` of the line is the hot path alone with resident frames and three lanes"}
+               "classes": g["classes"], "templates": g["templates"], "frames": nf, "iterations": g["iterations"], "host_threads": g["host_threads"],
+               "note": "the reference's call pattern (PoseDetection.cpp:45-126, HighLevelLinemod.cpp:157-175,206-253,424-515) on the bench's bank and frames, three passes over the same "
+                       "batches with bit-identical poses: serial = one detectBatch at a time (r04's figure: shift + upload + match + post-processing as a sum); pipelined = "
+                       "detectBatchBegin(k + 1) before detectBatchEnd(k) on two slot sets / lanes: the staging copies (pool, shift applied while copying), the transfer and the "
+                       "GPU hot path of batch k + 1 run behind the host post-processing of batch k; pipelined_pinned = the same with frames in pinned memory (row-offset DMA copy, no "
+                       "staging).  Post-processing = per-frame grouping on the pool, the colour counts of the whole batch in one GPU call on the colour-check stream, then depth "
+                       "check + poses of the independent match groups on the pool (by-part figures are CPU time summed over the threads).  gpu_hot_path = HIP-event spans of "
+                       "a3-a15 per lane-step; pcie_link = the batch's bytes over the link alone, measured in the same process.  Synthetic template poses whose median depths "
+                       "rarely pass the depth check, so nearly every match of every surviving group is tested -- a pessimistic load for the reference's nth_element over the "
+                       "template's bounding box per tested match; `value` of the line is the hot path alone with resident frames and three lanes"}
         if "host" in out:
-            res["with_host_colour_check_us_per_frame"] = out["host"]["us_per_frame"]
+            res["with_host_colour_check_us_per_frame_pipelined"] = out["host"]["pipelined"]["us_per_frame"]
         return res
     except Exception as e:  # the bench line must still be printed
         return {"error": "%s: %s" % (type(e).__name__, e)}

@@ -175,6 +175,23 @@ int lm_upload_frame_pinned(lm_detector* det, int slot, const uint8_t* bgr, size_
  * detector) at frames + i * frame_stride (0 = densely packed), pinned, into slots [first_slot, first_slot + n_slots).
  * lm_upload_frame_pinned makes the same single copy per frame when it is handed such a contiguous pair. */
 int lm_upload_frames_pinned(lm_detector* det, int first_slot, int n_slots, const uint8_t* frames, size_t frame_stride);
+/* lm_upload_frame_shifted for a source in PINNED host memory (r05): the DMA engine copies the overlapping rectangle row by row
+ * (hipMemcpy2DAsync) behind a memset of the destination: no staging copy and no host pass over the pixels.  Same contract as
+ * lm_upload_frame_pinned.  Shifts beyond the frame size are clamped (an all-zero frame either way). */
+int lm_upload_frame_pinned_shifted(lm_detector* det, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
+                                   size_t depth_stride, int shift_x, int shift_y);
+/* Staged uploads of PAGEABLE frames (r05): lm_upload_frame[_shifted] in three steps, so that a pool of host threads fills the pinned
+ * staging buffers of a whole batch in parallel (the staging copy of a 1280 x 960 RGB-D frame is 6 MB: 277 us on one thread) while
+ * the thread that owns the detector goes on:
+ *     lm_stage_reserve(det, first, n)                    owner thread: the slots' earlier uploads have landed, their staging buffers exist
+ *     lm_stage_rows(det, slot, ..., row0, row1) x many   ANY thread, disjoint row ranges of a slot concurrently: rows [row0, row1) of both
+ *                                                        images, translated by (shift_x, shift_y) with zeros shifted in; host memory only
+ *     lm_upload_staged(det, slot)                        owner thread, after all rows of the slot are in: the H2D copies + upload ticket
+ * The source may be reused as soon as the lm_stage_rows calls covering it have returned. */
+int lm_stage_reserve(lm_detector* det, int first_slot, int n_slots);
+int lm_stage_rows(lm_detector* det, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
+                  int shift_x, int shift_y, int row0, int row1);
+int lm_upload_staged(lm_detector* det, int slot);
 /* Host waits until the upload of `slot` (-1: of every slot) has landed in device memory. */
 int lm_upload_wait(lm_detector* det, int slot);
 /* Pinned host memory for frame sources (hipHostMalloc); needs a HIP device. */
@@ -289,6 +306,11 @@ int lm_match_begin_classes(lm_detector* det, int lane, int first_slot, int n_slo
 int lm_synchronize(lm_detector* det);
 int lm_match_end(lm_detector* det, int lane, lm_match_t* out, size_t cap_per_frame, int32_t* counts);
 
+/* The lists of the last COMPLETED match on slots [first_slot, first_slot + n_slots) once more -- they stay in the slots' result blocks
+ * until the next upload to / match on the slot: what a caller does after LM_ERR_OVERFLOW (counts[] held the capacity needed) instead
+ * of a second pass over the GPU.  LM_ERR_INVALID when a slot holds no completed match or belongs to a match in flight. */
+int lm_match_collect(lm_detector* det, int first_slot, int n_slots, lm_match_t* out, size_t cap_per_frame, int32_t* counts);
+
 /* ---- f1: the colour check of the reference's match post-processing, batched on the GPU ----------
  * For every match of the list (any class / template of the bank, e.g. a merged multi-GPU list): templateMask =
  * fillPoly of the convex hull of the template's level-0 features moved to (match.x, match.y)
@@ -299,6 +321,13 @@ int lm_match_end(lm_detector* det, int lane, lm_match_t* out, size_t cap_per_fra
  * one bit per pixel, built once per call, and one wave rasterises one hull. */
 int lm_color_check_counts(lm_detector* det, int slot, const double lower_hsv[3], const double upper_hsv[3],
                           const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both);
+
+/* The same for a list whose matches lie in SEVERAL resident frames (slot_of_match[i] = the slot of match i's frame): one colour-mask
+ * launch for the slots the list names, one hull launch for all matches, one wait -- a batch's colour checks in one call.
+ * r05: both forms run on a stream and buffers of their own and only refuse slots that belong to a match in flight, so the checks of
+ * batch k overlap the match of batch k + 1 on another lane. */
+int lm_color_check_counts_slots(lm_detector* det, const int32_t* slot_of_match, const double lower_hsv[3], const double upper_hsv[3],
+                                const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both);
 
 /* ---- multi-GPU: template-bank shards + the ONE exchange step of the path ------------------------
  * One process per GPU; every rank creates its detector with lm_config.shard_rank / shard_size (contiguous template_id
@@ -419,7 +448,9 @@ int lm_time_scan_batch(lm_detector* det, int first_slot, int n_slots, float thre
  * being the correctly rounded 1.0f / x and sqrtf.  out[0] / out[1] = number of floats whose reciprocal / square root differ
  * (0 / 0 expected); out[2] = floats on which the bare v_sqrt_f32 instruction differs (information only: the kernel does not
  * rely on it); out[3], out[4], out[5] = the same counts for the longer sequences the kernel used before (v_rcp + six fused steps;
- * v_sqrt + the +-1 ulp fix-up) and for v_sqrt + one step with v_rsq: all 0 expected; out[6], out[7] = 0. */
+ * v_sqrt + the +-1 ulp fix-up) and for v_sqrt + one step with v_rsq: all 0 expected; out[6] = floats on which a REJECTED candidate
+ * (the reciprocal taken from the root's own v_rsq plus one Newton step) differs -- non-zero (84) by design: it shows that the sweep
+ * discriminates; out[7] = 0.  The 8-word form dates from lm_version "0.3": a caller built against an older header passes 2 words. */
 int lm_selftest_float_tail(lm_detector* det, uint64_t out[8]);
 /* Per-stage average microseconds of the last lm_match_slot-style pipeline, measured with HIP events
  * over `iters` runs: out[0]=preprocess (a3-a10), out[1]=scan, out[2]=refine, out[3]=sort+copy. */

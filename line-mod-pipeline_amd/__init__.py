@@ -83,6 +83,8 @@ EXPORTS = [
     "lm_get_exchange_profile", "lm_get_stage_counts", "lm_get_scan_lane_stats", "lm_match_classes",
     "lm_time_scan_batch",
     "lm_selftest_float_tail",
+    "lm_upload_frame_pinned_shifted", "lm_stage_reserve", "lm_stage_rows", "lm_upload_staged", "lm_match_collect",
+    "lm_color_check_counts_slots",
 ]
 
 _lib = None
@@ -187,6 +189,12 @@ def load_library(path=None):
     lib.lm_get_exchange_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.lm_get_stage_counts.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.lm_get_scan_lane_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.lm_upload_frame_pinned_shifted.argtypes = [vp, i, vp, sz, vp, sz, i, i]
+    lib.lm_stage_reserve.argtypes = [vp, i, i]
+    lib.lm_stage_rows.argtypes = [vp, i, vp, sz, vp, sz, i, i, i, i]
+    lib.lm_upload_staged.argtypes = [vp, i]
+    lib.lm_match_collect.argtypes = [vp, i, i, vp, sz, vp]
+    lib.lm_color_check_counts_slots.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, sz, vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -803,6 +811,47 @@ class Detector:
         lo, hi = (C.c_double * 3)(*lower_hsv), (C.c_double * 3)(*upper_hsv)
         self._check(self.lib.lm_color_check_counts(self.h, slot, lo, hi, _ptr(m), len(m), _ptr(a), _ptr(b)))
         return a, b
+
+    def color_check_counts_slots(self, slot_of_match, lower_hsv, upper_hsv, matches):
+        """The same for a list whose matches lie in several resident frames: ONE mask launch, one hull launch, one wait."""
+        m = _c(matches, MATCH_DTYPE)
+        sl = _c(slot_of_match, np.int32)
+        if sl.size != len(m):
+            raise ValueError("one slot per match")
+        a, b = np.zeros(len(m), np.int64), np.zeros(len(m), np.int64)
+        lo, hi = (C.c_double * 3)(*lower_hsv), (C.c_double * 3)(*upper_hsv)
+        self._check(self.lib.lm_color_check_counts_slots(self.h, _ptr(sl), lo, hi, _ptr(m), len(m), _ptr(a), _ptr(b)))
+        return a, b
+
+    def upload_frame_pinned_shifted(self, slot, bgr, depth, shift_x, shift_y):
+        """upload_frame_shifted from pinned memory: the DMA engine's row-offset copy, no staging pass."""
+        if bgr.dtype != np.uint8 or not bgr.flags.c_contiguous or bgr.shape != (self.cfg.height, self.cfg.width, 3):
+            raise ValueError("pinned colour frame must be a C-contiguous uint8 [h, w, 3] array of the detector's size")
+        if depth is not None and (depth.dtype != np.uint16 or not depth.flags.c_contiguous):
+            raise ValueError("pinned depth frame must be a C-contiguous uint16 array")
+        self._check(self.lib.lm_upload_frame_pinned_shifted(self.h, slot, _ptr(bgr), 0, _ptr(depth), 0, int(shift_x), int(shift_y)))
+
+    def stage_reserve(self, first_slot, n_slots):
+        self._check(self.lib.lm_stage_reserve(self.h, first_slot, n_slots))
+
+    def stage_rows(self, slot, bgr, depth, shift_x, shift_y, row0, row1):
+        """Rows [row0, row1) of both images into the slot's pinned staging buffers (host memory only; any thread)."""
+        bgr = _c(bgr, np.uint8)
+        depth = None if depth is None else _c(depth, np.uint16)
+        self._check(self.lib.lm_stage_rows(self.h, slot, _ptr(bgr), 0, _ptr(depth), 0, int(shift_x), int(shift_y), int(row0), int(row1)))
+
+    def upload_staged(self, slot):
+        self._check(self.lib.lm_upload_staged(self.h, slot))
+
+    def match_collect(self, first_slot, n_slots, cap_per_frame=4096):
+        """The lists of the last completed match on the slots once more (after LM_ERR_OVERFLOW: with the capacity counts[] named)."""
+        out = np.zeros((n_slots, cap_per_frame), MATCH_DTYPE)
+        counts = np.zeros(n_slots, np.int32)
+        rc = self.lib.lm_match_collect(self.h, first_slot, n_slots, _ptr(out), cap_per_frame, _ptr(counts))
+        if rc == LM_ERR_OVERFLOW:
+            return None, counts
+        self._check(rc)
+        return out, counts
 
     def set_scan_stats(self, enable=True):
         self._check(self.lib.lm_set_scan_stats(self.h, 1 if enable else 0))

@@ -55,6 +55,8 @@ struct Slot {
     hipEvent_t ev_bgr = nullptr;     // recorded behind the colour image alone (RGB-D: the depth copy follows it)
     unsigned long long up_seq = 0;
     int up_stream = 0;               // which copy stream carried the upload (tickets are per stream)
+    bool staging_open = false;       // lm_stage_reserve has run: lm_stage_rows may fill the staging buffers, lm_upload_staged sends them
+    bool matched = false;            // a match on the frame the slot holds has completed: its lists are still in the slot's result block (lm_match_collect)
 };
 
 }  // namespace
@@ -80,6 +82,7 @@ struct lm_detector {
         int* h_raw_thr = nullptr;
         float raw_thr_for = -1.0f;
         bool created = false, busy = false, timed = false;
+        hipEvent_t ev_done = nullptr;    // recorded behind the last command of the lane's match in flight (lm_match_end waits for IT, see wait_lane_done)
         int first = 0, n = 0;
         std::vector<int> classes;                       // class list of the match in flight ({-1} = all classes)
         unsigned long long waited_seq[LM_NCOPY] = {};   // newest upload ticket per copy stream this lane's stream waits for
@@ -125,6 +128,10 @@ struct lm_detector {
     u32* d_hull_class_base = nullptr; u32* d_hull_off = nullptr; int16_t* d_hull_xy = nullptr;
     int* d_hsv_div = nullptr;
     size_t off_cmask = 0; int cmask_wpr = 0;
+    // r05: the colour check has its own (high-priority) stream and buffers, so that it runs beside the lanes: the post-processing of
+    // batch k overlaps the match of batch k + 1 (HighLevelLineMOD::detectTemplatesBatchBegin / End)
+    hipStream_t cc_stream = nullptr;
+    u8* cc_dev = nullptr; u8* cc_host = nullptr; size_t cc_cap = 0;       // room for cc_cap matches: records | slot index | two counts
     LmComm* comm[LM_NLANES] = {};   // one communicator per lane: the lanes' collectives never wait for each other
     int comm_recs_per_frame = 0;
     Gather gather[LM_NLANES];
@@ -785,21 +792,40 @@ int copy_image(hipStream_t st, u8* dst, u8* staging, const u8* src, size_t strid
     return LM_OK;
 }
 
-// The same with the image translated by (ox, oy) pixels, zeros shifted in (cv::warpAffine with a pure translation as the reference's
-// translateImg does, PoseDetection.cpp:54-59,192-197): the shift happens while the staging buffer is filled, so a shifted upload costs
-// one pass over the image instead of two.  px = bytes per pixel.
-int copy_image_shifted(hipStream_t st, u8* dst, u8* staging, const u8* src, size_t stride, int w, int h, int px, int ox, int oy) {
+// Rows [r0, r1) of the image translated by (ox, oy) pixels, zeros shifted in (cv::warpAffine with a pure translation as the
+// reference's translateImg does, PoseDetection.cpp:54-59,192-197), into the dense staging buffer: the shift happens while the staging
+// buffer is filled, so a shifted upload costs one pass over the image instead of two.  px = bytes per pixel.  Host memory only:
+// any thread may fill disjoint row ranges (lm_stage_rows).  |ox| <= w and |oy| <= h (callers clamp: anything beyond is an all-zero frame).
+void stage_rows_shifted(u8* staging, const u8* src, size_t stride, int w, int h, int px, int ox, int oy, int r0, int r1) {
     const size_t row_bytes = (size_t)w * px;
     const int x0 = std::max(ox, 0), x1 = std::min(w + ox, w);        // destination columns [x0, x1) have a source pixel
     const int y0 = std::max(oy, 0), y1 = std::min(h + oy, h);
-    for (int y = 0; y < h; ++y) {
+    for (int y = r0; y < r1; ++y) {
         u8* row = staging + (size_t)y * row_bytes;
         if (y < y0 || y >= y1 || x1 <= x0) { std::memset(row, 0, row_bytes); continue; }
         if (x0 > 0) std::memset(row, 0, (size_t)x0 * px);
         std::memcpy(row + (size_t)x0 * px, src + (size_t)(y - oy) * stride + (size_t)(x0 - ox) * px, (size_t)(x1 - x0) * px);
         if (x1 < w) std::memset(row + (size_t)x1 * px, 0, (size_t)(w - x1) * px);
     }
-    HIP_TRY(hipMemcpyAsync(dst, staging, row_bytes * (size_t)h, hipMemcpyHostToDevice, st));
+}
+inline int clamp_shift(int v, int extent) { return v < -extent ? -extent : (v > extent ? extent : v); }
+
+int copy_image_shifted(hipStream_t st, u8* dst, u8* staging, const u8* src, size_t stride, int w, int h, int px, int ox, int oy) {
+    stage_rows_shifted(staging, src, stride, w, h, px, ox, oy, 0, h);
+    HIP_TRY(hipMemcpyAsync(dst, staging, (size_t)w * px * (size_t)h, hipMemcpyHostToDevice, st));
+    return LM_OK;
+}
+
+// The translated image from PINNED host memory: the DMA engine copies the overlapping rectangle row by row (hipMemcpy2DAsync) behind
+// a memset of the destination -- no staging copy, no host pass over the pixels at all.
+int copy_image_shifted_pinned(hipStream_t st, u8* dst, const u8* src, size_t stride, int w, int h, int px, int ox, int oy) {
+    const size_t row_bytes = (size_t)w * px;
+    const int x0 = std::max(ox, 0), x1 = std::min(w + ox, w);
+    const int y0 = std::max(oy, 0), y1 = std::min(h + oy, h);
+    HIP_TRY(hipMemsetAsync(dst, 0, row_bytes * (size_t)h, st));
+    if (x1 > x0 && y1 > y0)
+        HIP_TRY(hipMemcpy2DAsync(dst + (size_t)y0 * row_bytes + (size_t)x0 * px, row_bytes, src + (size_t)(y0 - oy) * stride + (size_t)(x0 - ox) * px, stride,
+                                 (size_t)(x1 - x0) * px, (size_t)(y1 - y0), hipMemcpyHostToDevice, st));
     return LM_OK;
 }
 
@@ -819,14 +845,16 @@ int upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride
     for (const lm_detector::Lane& ln : d->lanes)
         if (ln.busy && slot >= ln.first && slot < ln.first + ln.n) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
     int rc;
-    s.prepared = false;
+    s.prepared = false; s.matched = false; s.staging_open = false;
+    shift_x = clamp_shift(shift_x, c.width); shift_y = clamp_shift(shift_y, c.height);     // (beyond: an all-zero frame either way)
     // the slot's previous upload may still be reading the staging buffer (and must land before this one anyway)
     if ((rc = wait_slot_upload(d, s))) return rc;
     if (!pinned && (rc = ensure_staging(d, s))) return rc;
     const int cs = slot % d->n_copy_streams;
     hipStream_t st = inline_stream ? inline_stream : d->copy_stream[cs];
     const size_t bgr_bytes = (size_t)c.width * c.height * 3;
-    if (pinned && c.num_modalities == 2 && bgr_stride == (size_t)c.width * 3 && depth_stride == (size_t)c.width * 2 &&
+    const bool shifted = shift_x != 0 || shift_y != 0;
+    if (pinned && !shifted && c.num_modalities == 2 && bgr_stride == (size_t)c.width * 3 && depth_stride == (size_t)c.width * 2 &&
         reinterpret_cast<const u8*>(depth) == bgr + bgr_bytes) {
         // [colour | depth] contiguous on the host, as in the frame arena: one DMA transfer
         HIP_TRY(hipMemcpyAsync(d->bgr(slot, 0), bgr, bgr_bytes + (size_t)c.width * c.height * 2, hipMemcpyHostToDevice, st));
@@ -839,13 +867,16 @@ int upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride
         s.has_frame = true;
         return LM_OK;
     }
-    const bool shifted = shift_x != 0 || shift_y != 0;
-    if (shifted) {
+    if (shifted && pinned) {
+        if ((rc = copy_image_shifted_pinned(st, d->bgr(slot, 0), bgr, bgr_stride, c.width, c.height, 3, shift_x, shift_y))) return rc;
+    } else if (shifted) {
         if ((rc = copy_image_shifted(st, d->bgr(slot, 0), s.h_bgr, bgr, bgr_stride, c.width, c.height, 3, shift_x, shift_y))) return rc;
     } else if ((rc = copy_image(st, d->bgr(slot, 0), s.h_bgr, bgr, bgr_stride, (size_t)c.width * 3, c.height, pinned, d->stage_chunks))) return rc;
     if (!inline_stream && c.num_modalities == 2) HIP_TRY(hipEventRecord(s.ev_bgr, st));
     if (c.num_modalities == 2) {
-        if (shifted) rc = copy_image_shifted(st, reinterpret_cast<u8*>(d->depth(slot)), reinterpret_cast<u8*>(s.h_depth),
+        if (shifted && pinned) rc = copy_image_shifted_pinned(st, reinterpret_cast<u8*>(d->depth(slot)), reinterpret_cast<const u8*>(depth), depth_stride,
+                                                               c.width, c.height, 2, shift_x, shift_y);
+        else if (shifted) rc = copy_image_shifted(st, reinterpret_cast<u8*>(d->depth(slot)), reinterpret_cast<u8*>(s.h_depth),
                                              reinterpret_cast<const u8*>(depth), depth_stride, c.width, c.height, 2, shift_x, shift_y);
         else rc = copy_image(st, reinterpret_cast<u8*>(d->depth(slot)), reinterpret_cast<u8*>(s.h_depth),
                              reinterpret_cast<const u8*>(depth), depth_stride, (size_t)c.width * 2, c.height, pinned, d->stage_chunks);
@@ -939,6 +970,17 @@ int wait_stream(lm_detector* d) {
     return LM_OK;
 }
 
+// lm_match_end's wait (r05).  hipStreamSynchronize on a stream whose work is long done still enqueues a marker and waits for it, and
+// HIP streams share a few hardware queues: the marker lands behind the event-record barriers of a COPY stream on the same queue,
+// which wait for the NEXT batch's H2D copies -- measured in the streamed PoseDetection (profiles/r05_e2e_timeline.txt): the lane's
+// kernels had finished 4.6 ms earlier, the sync still took 0.43-0.52 ms = the next batch's upload.  An event recorded right behind the
+// lane's last command when it was enqueued has no such false dependency.
+int wait_lane_done(lm_detector* d, lm_detector::Lane& ln) {
+    HIP_TRY(hipEventSynchronize(ln.ev_done));
+    for (int k = 0; k < LM_NCOPY; ++k) if (d->waited_seq[k] > d->up_seq_done[k]) d->up_seq_done[k] = d->waited_seq[k];
+    return LM_OK;
+}
+
 int run_match(lm_detector* d, int first, int n, float threshold, std::vector<int> classes, bool prepared = false) {
     if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     for (int i = 0; i < n; ++i) {
@@ -950,6 +992,7 @@ int run_match(lm_detector* d, int first, int n, float threshold, std::vector<int
     if ((rc = enqueue_match(d, first, n, threshold, classes, d->profiling, prepared))) return rc;
     if ((rc = wait_stream(d))) return rc;
     if (d->profiling) account_profile(d, n, classes);   // HIP events on the launch stream bracket every stage
+    for (int i = 0; i < n; ++i) d->slots[first + i].matched = true;
     return LM_OK;
 }
 int run_match(lm_detector* d, int first, int n, float threshold, int class_idx) {
@@ -964,7 +1007,7 @@ int run_match(lm_detector* d, int first, int n, float threshold, int class_idx) 
 extern "C" {
 
 const char* lm_last_error(void) { return g_err.c_str(); }
-const char* lm_version(void) { return "linemod_hip 0.2 (gfx950)"; }
+const char* lm_version(void) { return "linemod_hip 0.3 (gfx950)"; }
 
 void lm_default_config(lm_config* c, int color_only, int width, int height) {
     std::memset(c, 0, sizeof(*c));
@@ -1070,11 +1113,14 @@ void lm_destroy(lm_detector* d) {
             }
             if (ln.stream) hipStreamDestroy(ln.stream);
         }
+        for (auto& ln : d->lanes) if (ln.ev_done) hipEventDestroy(ln.ev_done);
         free_device_bank(d);
         for (auto& c : d->comm) { delete c; c = nullptr; }
         free_gather(d);
         hipFree(d->d_scan_stat);
         hipFree(d->d_hull_class_base); hipFree(d->d_hull_off); hipFree(d->d_hull_xy); hipFree(d->d_hsv_div);
+        if (d->cc_stream) hipStreamDestroy(d->cc_stream);
+        hipFree(d->cc_dev); if (d->cc_host) hipHostFree(d->cc_host);
         hipFree(d->d_resp_tab); hipFree(d->d_sim_lut); hipFree(d->d_normal_lut); hipFree(d->d_scratch);
     }
     delete d;
@@ -1259,8 +1305,80 @@ int lm_upload_frames_pinned(lm_detector* d, int first_slot, int n_slots, const u
         Slot& s = d->slots[first_slot + i];
         if (c.num_modalities == 2) HIP_TRY(hipEventRecord(s.ev_bgr, st));
         HIP_TRY(hipEventRecord(s.ev_up, st));
-        s.up_stream = cs; s.up_seq = seq; s.has_frame = true; s.prepared = false;
+        s.up_stream = cs; s.up_seq = seq; s.has_frame = true; s.prepared = false; s.matched = false; s.staging_open = false;
     }
+    return LM_OK;
+}
+
+int lm_upload_frame_pinned_shifted(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth,
+                                   size_t depth_stride, int shift_x, int shift_y) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if ((rc = check_slots(d, slot, 1))) return rc;
+    return upload_frame(d, slot, bgr, bgr_stride, depth, depth_stride, true, nullptr, shift_x, shift_y);
+}
+
+// ---- staged uploads (r05): the staging copy of a pageable frame split from the transfer, so that a host thread pool fills the
+// pinned staging buffers of a batch (row ranges in parallel) while the thread that owns the detector does something else:
+//     lm_stage_reserve(first, n)                       owner thread: the slots' earlier uploads have landed, staging exists
+//     lm_stage_rows(slot, ..., row0, row1)  x many     ANY thread, disjoint row ranges: host memory only, no HIP call
+//     lm_upload_staged(slot)                           owner thread: the H2D copies + the slot's upload ticket
+int lm_stage_reserve(lm_detector* d, int first_slot, int n_slots) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if ((rc = check_slots(d, first_slot, n_slots))) return rc;
+    for (const lm_detector::Lane& ln : d->lanes)
+        if (ln.busy && first_slot < ln.first + ln.n && ln.first < first_slot + n_slots) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
+    for (int i = 0; i < n_slots; ++i) {
+        Slot& s = d->slots[first_slot + i];
+        if ((rc = wait_slot_upload(d, s))) return rc;
+        if ((rc = ensure_staging(d, s))) return rc;
+        s.staging_open = true;
+    }
+    return LM_OK;
+}
+
+int lm_stage_rows(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
+                  int shift_x, int shift_y, int row0, int row1) {
+    if (!d || !d->dev_ready) return fail(LM_ERR_INVALID, "lm_stage_reserve first");
+    if (slot < 0 || slot >= (int)d->slots.size()) return fail(LM_ERR_INVALID, "slot out of range");
+    const lm_config& c = d->cfg;
+    const Slot& s = d->slots[slot];
+    if (!s.staging_open || !s.h_bgr) return fail(LM_ERR_INVALID, "lm_stage_reserve first");
+    if (!bgr) return fail(LM_ERR_INVALID, "sources.size() != modalities.size(): colour image missing");
+    if (c.num_modalities == 2 && !depth) return fail(LM_ERR_INVALID, "sources.size() != modalities.size(): depth image missing");
+    if (bgr_stride == 0) bgr_stride = (size_t)c.width * 3;
+    if (depth_stride == 0) depth_stride = (size_t)c.width * 2;
+    if (bgr_stride < (size_t)c.width * 3 || depth_stride < (size_t)c.width * 2) return fail(LM_ERR_INVALID, "stride smaller than a row");
+    if (row0 < 0 || row1 > c.height || row0 > row1) return fail(LM_ERR_INVALID, "row range outside the frame");
+    const int ox = clamp_shift(shift_x, c.width), oy = clamp_shift(shift_y, c.height);
+    stage_rows_shifted(s.h_bgr, bgr, bgr_stride, c.width, c.height, 3, ox, oy, row0, row1);
+    if (c.num_modalities == 2)
+        stage_rows_shifted(reinterpret_cast<u8*>(s.h_depth), reinterpret_cast<const u8*>(depth), depth_stride, c.width, c.height, 2, ox, oy, row0, row1);
+    return LM_OK;
+}
+
+int lm_upload_staged(lm_detector* d, int slot) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if ((rc = check_slots(d, slot, 1))) return rc;
+    Slot& s = d->slots[slot];
+    if (!s.staging_open) return fail(LM_ERR_INVALID, "lm_stage_reserve first");
+    for (const lm_detector::Lane& ln : d->lanes)
+        if (ln.busy && slot >= ln.first && slot < ln.first + ln.n) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
+    const lm_config& c = d->cfg;
+    const int cs = slot % d->n_copy_streams;
+    hipStream_t st = d->copy_stream[cs];
+    s.prepared = false; s.matched = false; s.staging_open = false;
+    HIP_TRY(hipMemcpyAsync(d->bgr(slot, 0), s.h_bgr, (size_t)c.width * c.height * 3, hipMemcpyHostToDevice, st));
+    if (c.num_modalities == 2) {
+        HIP_TRY(hipEventRecord(s.ev_bgr, st));
+        HIP_TRY(hipMemcpyAsync(d->depth(slot), s.h_depth, (size_t)c.width * c.height * 2, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipEventRecord(s.ev_up, st));
+    s.up_stream = cs;
+    s.up_seq = d->up_seq_next[cs]++;
+    s.has_frame = true;
     return LM_OK;
 }
 
@@ -1357,7 +1475,7 @@ static int upload_split(lm_detector* d, int slot, const uint8_t* bgr, const uint
     const lm_config& c = d->cfg;
     Slot& s = d->slots[slot];
     int rc;
-    s.prepared = false;
+    s.prepared = false; s.matched = false; s.staging_open = false;
     if ((rc = wait_slot_upload(d, s))) return rc;
     if (!pinned && (rc = ensure_staging(d, s))) return rc;
     const size_t nb = (size_t)c.width * c.height * 3, nd = c.num_modalities == 2 ? (size_t)c.width * c.height * 2 : 0;
@@ -1515,6 +1633,14 @@ static int begin_lane(lm_detector* d, int lane, int first_slot, int n_slots, flo
     rc = enqueue_match(d, first_slot, n_slots, threshold, classes, d->profiling);
     if (!rc && gathered) rc = enqueue_gather(d, lane, first_slot, n_slots);
     if (!rc) {
+        if (!ln.ev_done && hipEventCreateWithFlags(&ln.ev_done, ((d->cfg.flags & LM_FLAG_BLOCKING_SYNC) ? hipEventBlockingSync : 0) | hipEventDisableTiming) != hipSuccess) {
+            ln.ev_done = nullptr;
+            rc = fail(LM_ERR_HIP, "hipEventCreate failed");
+        }
+        if (!rc && hipEventRecord(ln.ev_done, d->stream) != hipSuccess) rc = fail(LM_ERR_HIP, "hipEventRecord failed");
+        if (rc) (void)hipStreamSynchronize(d->stream);      // what was enqueued must not outlive the failed call
+    }
+    if (!rc) {
         ln.busy = true; ln.first = first_slot; ln.n = n_slots; ln.classes = classes; ln.timed = d->profiling;
         d->gather[lane].active = gathered;
     }
@@ -1544,11 +1670,12 @@ int lm_match_end(lm_detector* d, int lane, lm_match_t* out, size_t cap_per_frame
     if (d->gather[lane].active) return fail(LM_ERR_INVALID, "the lane's match was begun with lm_match_begin_gathered: collect it with lm_match_end_gathered");
     HIP_TRY(hipSetDevice(d->cfg.device));
     activate_lane(d, lane);
-    const int wrc = wait_stream(d);
+    const int wrc = wait_lane_done(d, ln);
     if (!wrc && ln.timed) account_profile(d, ln.n, ln.classes);
     activate_lane(d, 0);
     ln.busy = false;
     if (wrc) return wrc;
+    for (int i = 0; i < ln.n; ++i) d->slots[ln.first + i].matched = true;
     int first_err = LM_OK;
     std::string first_msg;
     for (int i = 0; i < ln.n; ++i) {
@@ -1559,6 +1686,19 @@ int lm_match_end(lm_detector* d, int lane, lm_match_t* out, size_t cap_per_frame
     }
     if (first_err) return fail(first_err, first_msg);
     return LM_OK;
+}
+
+// The lists of the last completed match on slots [first_slot, first_slot + n_slots) once more (they stay in the slots' result blocks
+// until the next upload or match): what a caller does after LM_ERR_OVERFLOW told it the capacity it needs -- no second pass over the GPU.
+int lm_match_collect(lm_detector* d, int first_slot, int n_slots, lm_match_t* out, size_t cap_per_frame, int32_t* counts) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if ((rc = check_slots(d, first_slot, n_slots))) return rc;
+    for (const lm_detector::Lane& ln : d->lanes)
+        if (ln.busy && first_slot < ln.first + ln.n && ln.first < first_slot + n_slots) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
+    for (int i = 0; i < n_slots; ++i)
+        if (!d->slots[first_slot + i].matched) return fail(LM_ERR_INVALID, "slot " + std::to_string(first_slot + i) + " holds no completed match");
+    return collect_range(d, first_slot, n_slots, out, cap_per_frame, counts);
 }
 
 // ---- f1: colour check of many matches of one resident frame (HighLevelLinemod.cpp:113-135,159-161,424-434) ------
@@ -1588,15 +1728,56 @@ static int ensure_hulls(lm_detector* d) {
     return LM_OK;
 }
 
-int lm_color_check_counts(lm_detector* d, int slot, const double lower_hsv[3], const double upper_hsv[3],
-                          const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both) {
+// The colour check's own stream and buffers (r05): nothing of it touches a lane, so it runs while other lanes match other slots.
+static int ensure_colour_check(lm_detector* d, size_t n) {
+    if (!d->cc_stream) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
+        // highest priority: a handful of short launches that the host waits for must not queue behind a lane's long kernels
+        if (hipStreamCreateWithPriority(&d->cc_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipStreamCreateWithFlags(&d->cc_stream, hipStreamNonBlocking));
+        }
+    }
+    if (n > d->cc_cap) {
+        const size_t cap = std::max<size_t>(align_up(n, 4096), 16384);
+        const size_t bytes = cap * (sizeof(lm_match_t) + sizeof(int) + 2 * sizeof(long long));
+        HIP_TRY(hipStreamSynchronize(d->cc_stream));
+        u8* dev = nullptr; u8* host = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), bytes));
+        if (hipHostMalloc(reinterpret_cast<void**>(&host), bytes) != hipSuccess) { (void)hipFree(dev); return fail(LM_ERR_HIP, "hipHostMalloc of the colour check's buffers failed"); }
+        (void)hipFree(d->cc_dev); if (d->cc_host) (void)hipHostFree(d->cc_host);
+        d->cc_dev = dev; d->cc_host = host; d->cc_cap = cap;
+    }
+    return LM_OK;
+}
+
+// slot_of: per match the slot its frame is resident in, or nullptr = all in `one_slot`.
+static int colour_check(lm_detector* d, const int32_t* slot_of, int one_slot, const double lower_hsv[3], const double upper_hsv[3],
+                        const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = check_slots(d, slot, 1))) return rc;
     if (!lower_hsv || !upper_hsv || (n && (!matches || !in_hull || !in_both))) return fail(LM_ERR_INVALID, "null argument");
-    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    if (!d->slots[slot].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
+    const int S = (int)d->slots.size();
+    int s_lo = S, s_hi = -1;
+    std::vector<char> used((size_t)S, 0);
+    if (!slot_of) {
+        if ((rc = check_slots(d, one_slot, 1))) return rc;
+        used[(size_t)one_slot] = 1; s_lo = s_hi = one_slot;
+    } else {
+        for (size_t i = 0; i < n; ++i) {
+            if (slot_of[i] < 0 || slot_of[i] >= S) return fail(LM_ERR_INVALID, "slot out of range");
+            used[(size_t)slot_of[i]] = 1; s_lo = std::min(s_lo, slot_of[i]); s_hi = std::max(s_hi, slot_of[i]);
+        }
+    }
     if (n == 0) return LM_OK;
+    for (int sl = s_lo; sl <= s_hi; ++sl) {
+        if (!used[(size_t)sl]) continue;
+        if (!d->slots[(size_t)sl].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
+        for (const lm_detector::Lane& ln : d->lanes)
+            if (ln.busy && sl >= ln.first && sl < ln.first + ln.n) return fail(LM_ERR_INVALID, "slot belongs to a match in flight: call lm_match_end first");
+    }
+    if (d->hulls_dirty && any_lane_busy(d)) return fail(LM_ERR_INVALID, "the bank changed while a lane has a match in flight: call lm_match_end first");
     if ((rc = ensure_hulls(d))) return rc;
     const int nc = (int)d->bank.classes.size();
     for (size_t i = 0; i < n; ++i) {
@@ -1604,30 +1785,51 @@ int lm_color_check_counts(lm_detector* d, int slot, const double lower_hsv[3], c
         if (m.class_idx < 0 || m.class_idx >= nc || m.template_id < 0 || m.template_id >= (int)d->bank.classes[(size_t)m.class_idx].pyramids.size())
             return fail(LM_ERR_INVALID, "match " + std::to_string(i) + " names a template the bank does not hold");
     }
-    const size_t mb = align_up(n * sizeof(lm_match_t), 256);
-    if ((rc = ensure_scratch(d, mb + n * 2 * sizeof(long long)))) return rc;
-    u8* base = static_cast<u8*>(d->d_scratch);
-    if ((rc = enqueue_upload_wait(d, slot, 1))) return rc;
+    if ((rc = ensure_colour_check(d, n))) return rc;
+    hipStream_t st = d->cc_stream;
+    // the frames' uploads (copy streams) must have landed before the mask kernel reads them
+    for (int sl = s_lo; sl <= s_hi; ++sl) {
+        const Slot& s = d->slots[(size_t)sl];
+        if (used[(size_t)sl] && s.up_seq > d->up_seq_done[s.up_stream]) HIP_TRY(hipStreamWaitEvent(st, s.ev_up, 0));
+    }
+    const size_t off_slot = d->cc_cap * sizeof(lm_match_t), off_out = off_slot + d->cc_cap * sizeof(int);
+    std::memcpy(d->cc_host, matches, n * sizeof(lm_match_t));
+    if (slot_of) { int* hs = reinterpret_cast<int*>(d->cc_host + off_slot); for (size_t i = 0; i < n; ++i) hs[i] = slot_of[i] - s_lo; }
+    HIP_TRY(hipMemcpyAsync(d->cc_dev, d->cc_host, n * sizeof(lm_match_t), hipMemcpyHostToDevice, st));
+    if (slot_of) HIP_TRY(hipMemcpyAsync(d->cc_dev + off_slot, d->cc_host + off_slot, n * sizeof(int), hipMemcpyHostToDevice, st));
     LmHsvRange rg;
     for (int k = 0; k < 3; ++k) { rg.lo[k] = (int)std::lrint(lower_hsv[k]); rg.hi[k] = (int)std::lrint(upper_hsv[k]); }
-    u32* mask = reinterpret_cast<u32*>(d->frame_arena + (size_t)slot * d->frame_stride + d->off_cmask);
-    lmk_hsv_mask(d->stream, d->bgr(slot, 0), d->cfg.width, d->cfg.height, rg, d->d_hsv_div, mask, d->cmask_wpr, 0, 0, 1);
-    HIP_TRY(hipMemcpyAsync(base, matches, n * sizeof(lm_match_t), hipMemcpyHostToDevice, d->stream));
+    // ONE mask launch for the slots [s_lo, s_hi] (a slot in between that the list does not name costs a mask nobody reads)
+    u32* mask = reinterpret_cast<u32*>(d->frame_arena + (size_t)s_lo * d->frame_stride + d->off_cmask);
+    lmk_hsv_mask(st, d->bgr(s_lo, 0), d->cfg.width, d->cfg.height, rg, d->d_hsv_div, mask, d->cmask_wpr, d->frame_stride, d->frame_stride, s_hi - s_lo + 1);
     LmHullArgs a;
-    a.matches = reinterpret_cast<const LmOutMatch*>(base); a.n = (u32)n;
+    a.matches = reinterpret_cast<const LmOutMatch*>(d->cc_dev); a.n = (u32)n;
     a.class_base = d->d_hull_class_base; a.hull_off = d->d_hull_off; a.hull_xy = d->d_hull_xy;
     a.mask = mask; a.wpr = d->cmask_wpr; a.w = d->cfg.width; a.h = d->cfg.height;
-    a.out = reinterpret_cast<long long*>(base + mb);
-    if (!lmk_hull_counts(d->stream, a)) {
-        (void)wait_stream(d);
+    a.match_slot = slot_of ? reinterpret_cast<const int*>(d->cc_dev + off_slot) : nullptr;
+    a.mask_slot_words = d->frame_stride / 4;
+    a.out = reinterpret_cast<long long*>(d->cc_dev + off_out);
+    if (!lmk_hull_counts(st, a)) {
+        (void)hipStreamSynchronize(st);
         return fail(LM_ERR_INVALID, "frame too tall for the GPU colour check (more than 4992 rows): use the host colour check");
     }
-    std::vector<long long> out(2 * n);
-    HIP_TRY(hipMemcpyAsync(out.data(), a.out, out.size() * sizeof(long long), hipMemcpyDeviceToHost, d->stream));
-    if ((rc = wait_stream(d))) return rc;
+    HIP_TRY(hipMemcpyAsync(d->cc_host + off_out, a.out, n * 2 * sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
+    const long long* out = reinterpret_cast<const long long*>(d->cc_host + off_out);
     for (size_t i = 0; i < n; ++i) { in_hull[i] = out[2 * i]; in_both[i] = out[2 * i + 1]; }
     return LM_OK;
+}
+
+int lm_color_check_counts(lm_detector* d, int slot, const double lower_hsv[3], const double upper_hsv[3],
+                          const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both) {
+    return colour_check(d, nullptr, slot, lower_hsv, upper_hsv, matches, n, in_hull, in_both);
+}
+
+int lm_color_check_counts_slots(lm_detector* d, const int32_t* slot_of_match, const double lower_hsv[3], const double upper_hsv[3],
+                                const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both) {
+    if (n && !slot_of_match) return fail(LM_ERR_INVALID, "null argument");
+    return colour_check(d, slot_of_match, 0, lower_hsv, upper_hsv, matches, n, in_hull, in_both);
 }
 
 // ---- multi-GPU exchange: RCCL all-gather of the per-shard lists ---------------------------------
@@ -1864,7 +2066,7 @@ int lm_match_end_gathered(lm_detector* d, int lane, lm_match_t* out, size_t cap,
     if (!ln.busy || !g.active) return fail(LM_ERR_INVALID, "lane has no gathered match in flight");
     HIP_TRY(hipSetDevice(d->cfg.device));
     activate_lane(d, lane);
-    const int wrc = wait_stream(d);
+    const int wrc = wait_lane_done(d, ln);
     if (!wrc && ln.timed) account_profile(d, ln.n, ln.classes, true);
     activate_lane(d, 0);
     ln.busy = false; g.active = false;

@@ -169,6 +169,8 @@ struct LmHullArgs {
     const u32* hull_off;         // [n_templates + 1] first vertex of every template's hull
     const int16_t* hull_xy;      // vertices (x, y) relative to the template origin
     const u32* mask; int wpr;    // colour bit mask of the frame
+    const int* match_slot;       // optional [n]: match i lies in the frame whose mask starts mask_slot_words * match_slot[i] words behind `mask`
+    size_t mask_slot_words;
     int w, h;
     long long* out;              // [n][2]: pixels in the hull, pixels in the hull with the colour bit set
 };

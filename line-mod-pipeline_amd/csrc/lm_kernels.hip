@@ -1681,8 +1681,11 @@ __device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool o
     float nx = SMALL ? (float)(QUOT ? mul_i24(ddx, 143750) : ddx * 1150) : (float)((double)ddx * 1150.0);
     float ny = SMALL ? (float)(QUOT ? mul_i24(ddy, 143750) : ddy * 1150) : (float)((double)ddy * 1150.0);
     float nz = (float)(-mul_i24(det, d));
-    const float len = dn_sqrt(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
-    // len == 0 (all three components 0): 1 / 0 = inf, 0 * inf = NaN, (int)NaN = 0 -- any index; the select below returns 0 for it
+    const float len0 = dn_sqrt(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+    // all three components 0: dn_sqrt(0) is a NaN (0 * inf) and a float -> int conversion of a NaN is undefined -- the
+    // select keeps every value below defined: with len = 1 the components stay 0, (v1, v2, v3) = (10, 10, 20) and the index 8210
+    // is outside the table, whose entry 8000 is the code 0 the oracle's `len > 0` guard gives (so no second test at the end)
+    const float len = len0 > 0.0f ? len0 : 1.0f;
     const float inv = dn_rcp(len);
     nx = __fmul_rn(nx, inv); ny = __fmul_rn(ny, inv); nz = __fmul_rn(nz, inv);
     const int v1 = (int)__fadd_rn(__fmul_rn(nx, 10.f), 10.f);
@@ -1692,22 +1695,22 @@ __device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool o
     // the label's rank code straight from the second table (ensure_luts: 8 rank / 8 (rank - 4) + 4 / 32), whose entry 8000 is 0:
     // an index outside the table (nz == 0 gives v3 == 20) reads that instead of taking a compare and two selects
     const u32 ecode = lut[LMK_NORMAL_CODE_OFFSET + min(flat, 8000u)];
-    return (ok && len > 0) ? ecode : 0u;
+    return ok ? ecode : 0u;
 }
 
 // every float of the tail's domain through dn_rcp / dn_sqrt and through the compiler's correctly rounded forms;
 // out[2]: the bare v_sqrt_f32 against the same reference (information: how often the 1-ulp instruction is off)
 __global__ __launch_bounds__(256) void k_selftest_float_tail(unsigned long long* __restrict__ out) {
     const u32 lo = 0x3F800000u, hi_rcp = (127u + 42u) << 23, hi_sqrt = (127u + 84u) << 23;   // 1.0f .. 2^42 / 2^84
-    unsigned long long bad_rcp = 0, bad_sqrt = 0, bad_bare = 0, c_rcp3 = 0, c_sqrt5 = 0, c_sqrt4 = 0, c_inv = 0;
+    unsigned long long bad_rcp = 0, bad_sqrt = 0, bad_bare = 0, c_rcp7 = 0, c_sqrt9 = 0, c_sqrt4 = 0, c_inv = 0;
     for (u32 b = lo + blockIdx.x * 256u + threadIdx.x; b <= hi_sqrt; b += gridDim.x * 256u) {
         const float x = __builtin_bit_cast(float, b);
         if (b <= hi_rcp) bad_rcp += __builtin_bit_cast(u32, dn_rcp(x)) != __builtin_bit_cast(u32, __fdiv_rn(1.0f, x));
         const u32 want = __builtin_bit_cast(u32, __builtin_sqrtf(x));
         bad_sqrt += __builtin_bit_cast(u32, dn_sqrt(x)) != want;
         bad_bare += __builtin_bit_cast(u32, dn_sqrt_bare(x)) != want;
-        if (b <= hi_rcp) c_rcp3 += __builtin_bit_cast(u32, dn_rcp7(x)) != __builtin_bit_cast(u32, __fdiv_rn(1.0f, x));
-        c_sqrt5 += __builtin_bit_cast(u32, dn_sqrt9(x)) != want;
+        if (b <= hi_rcp) c_rcp7 += __builtin_bit_cast(u32, dn_rcp7(x)) != __builtin_bit_cast(u32, __fdiv_rn(1.0f, x));
+        c_sqrt9 += __builtin_bit_cast(u32, dn_sqrt9(x)) != want;
         c_sqrt4 += __builtin_bit_cast(u32, dn_sqrt4(x)) != want;
         c_inv += __builtin_bit_cast(u32, dn_inv_from_rsq(x, dn_sqrt(x))) != __builtin_bit_cast(u32, __fdiv_rn(1.0f, __builtin_sqrtf(x)));
     }
@@ -1715,8 +1718,8 @@ __global__ __launch_bounds__(256) void k_selftest_float_tail(unsigned long long*
     if (bad_rcp) atomicAdd(&out[0], bad_rcp);
     if (bad_sqrt) atomicAdd(&out[1], bad_sqrt);
     if (bad_bare) atomicAdd(&out[2], bad_bare);
-    if (c_rcp3) atomicAdd(&out[3], c_rcp3);
-    if (c_sqrt5) atomicAdd(&out[4], c_sqrt5);
+    if (c_rcp7) atomicAdd(&out[3], c_rcp7);
+    if (c_sqrt9) atomicAdd(&out[4], c_sqrt9);
     if (c_sqrt4) atomicAdd(&out[5], c_sqrt4);
     if (c_inv) atomicAdd(&out[6], c_inv);
 }
@@ -3560,9 +3563,11 @@ __global__ __launch_bounds__(256) void k_hull_counts(LmHullArgs a) {
     const bool live = i < a.n;                       // dead waves still take part in the barriers
     int n = 0, mx = 0, my = 0;
     u32 off0 = 0;
+    const u32* mask_row0 = a.mask;      // the colour mask of the match's frame (lists that span several slots: match_slot)
     if (live) {
         const LmOutMatch m = a.matches[i];
         mx = m.x; my = m.y;
+        if (a.match_slot) mask_row0 += (size_t)a.match_slot[i] * a.mask_slot_words;
         const u32 idx = a.class_base[m.class_idx] + (u32)m.template_id;
         off0 = a.hull_off[idx];
         n = (int)(a.hull_off[idx + 1] - off0);
@@ -3612,7 +3617,7 @@ __global__ __launch_bounds__(256) void k_hull_counts(LmHullArgs a) {
         L = max(L, 0); R = min(R, a.w - 1);
         if (L > R) continue;
         in_hull += R - L + 1;
-        const u32* row = a.mask + (size_t)y * a.wpr;
+        const u32* row = mask_row0 + (size_t)y * a.wpr;
         for (int wi = L >> 5; wi <= (R >> 5); ++wi) {
             const int b0 = wi == (L >> 5) ? (L & 31) : 0, b1 = wi == (R >> 5) ? (R & 31) : 31;
             const u32 mk = (0xFFFFFFFFu >> (31 - b1)) & (0xFFFFFFFFu << b0);

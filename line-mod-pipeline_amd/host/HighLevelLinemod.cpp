@@ -6,14 +6,32 @@
 #include <cstdio>
 #include <cstring>
 #include <chrono>
+#include <deque>
+#include <memory>
 #include <fstream>
 #include <stdexcept>
 #include <thread>
 
 #include "PostProcess.h"
+#include "WorkerPool.h"
 #include "TemplateGenerator.h"
 
 namespace lmamd {
+
+// ---- the batch entry point for several classes, as a stream (r05) ---------------------------------------------------------------
+// One batch in flight: its slot set (= lane), the frames' views, the class list, the staging copies' task group.
+struct HighLevelLineMOD::Stream {
+    struct Batch {
+        int set = 0, n = 0;
+        std::vector<std::vector<Image>> frames;
+        std::vector<uint16_t> classes;
+    };
+    std::deque<Batch> inflight;            // oldest first
+    bool set_busy[kBatchSets] = {};
+    int next_set = 0;
+    std::unique_ptr<WorkerPool> pool;
+    int pool_threads = 0;
+};
 
 HighLevelLineMOD::HighLevelLineMOD(CameraParameters const& cam, TemplateGenerationSettings const& ts)
     : onlyColorModality(ts.onlyUseColorModality),
@@ -30,6 +48,7 @@ HighLevelLineMOD::HighLevelLineMOD(CameraParameters const& cam, TemplateGenerati
     cfg.device = ts.device;
     cfg.shard_rank = ts.shardRank;
     cfg.shard_size = ts.shardSize;
+    cfg.frame_slots = kBatchSlots * kBatchSets;      // two slot sets: a batch matching while the one before it is post-processed
     if (lm_create(&cfg, &detector) != LM_OK) {
         delete templates; delete modelTemplates; delete modProps;
         throw std::runtime_error(lm_last_error());
@@ -37,6 +56,11 @@ HighLevelLineMOD::HighLevelLineMOD(CameraParameters const& cam, TemplateGenerati
 }
 
 HighLevelLineMOD::~HighLevelLineMOD() {
+    if (stream_) {
+        // batches still in flight: their lanes must finish before the detector goes away (results are dropped)
+        while (!stream_->inflight.empty()) { (void)lm_match_end(detector, stream_->inflight.front().set, nullptr, 0, nullptr); stream_->inflight.pop_front(); }
+        delete stream_;
+    }
     lm_destroy(detector);  // detector.release(), :50
     delete templates; delete modelTemplates; delete modProps;
 }
@@ -53,6 +77,9 @@ bool HighLevelLineMOD::detectTemplate(std::vector<Image>& in_imgs, uint16_t in_c
     posesMultipleObj.clear();
     matches.clear();
     if (in_imgs.empty()) { error = "no images"; return false; }
+    if (batchesInFlight() != 0) { error = "batches are in flight: collect them with detectTemplatesBatchEnd first"; return false; }
+    for (const Image& im : in_imgs)       // (only detectTemplatesBatch applies Image::shift_*; silently matching the unshifted frame would return wrong poses)
+        if (im.shift_x || im.shift_y) { error = "pending image shifts (Image::shift_*) are applied by detectTemplatesBatch only: translate the images before this call"; return false; }
     const Image& color = in_imgs[0];
     const Image* depth_img = in_imgs.size() >= 2 ? &in_imgs[1] : nullptr;
     // a colour-only detector pops the depth image before match() and pushes it back afterwards (:146-156)
@@ -109,8 +136,12 @@ bool HighLevelLineMOD::detectTemplateBatch(std::vector<std::vector<Image>>& in_f
     out_matches.assign((size_t)n, {});
     out_poses.assign((size_t)n, {});
     if (n == 0) return false;
+    if (batchesInFlight() != 0) { error = "batches are in flight: collect them with detectTemplatesBatchEnd first"; return false; }
+    if (n > kBatchSlots) { error = "batch of " + std::to_string(n) + " frames exceeds a slot set (" + std::to_string(kBatchSlots) + ")"; return false; }
     for (int i = 0; i < n; ++i) {
         if (in_frames[(size_t)i].empty()) { error = "no images"; return false; }
+        for (const Image& im : in_frames[(size_t)i])
+            if (im.shift_x || im.shift_y) { error = "pending image shifts (Image::shift_*) are applied by detectTemplatesBatch only: translate the images before this call"; return false; }
         const Image& color = in_frames[(size_t)i][0];
         const Image* depth_img = in_frames[(size_t)i].size() >= 2 ? &in_frames[(size_t)i][1] : nullptr;
         const Image* match_depth = onlyColorModality ? nullptr : depth_img;
@@ -142,63 +173,139 @@ bool HighLevelLineMOD::detectTemplateBatch(std::vector<std::vector<Image>>& in_f
     return any;
 }
 
+HighLevelLineMOD::Stream& HighLevelLineMOD::stream() {
+    if (!stream_) stream_ = new Stream();
+    Stream& st = *stream_;
+    const int want = postThreads > 0 ? postThreads : std::min(usable_cpus(), 32);
+    if ((!st.pool || st.pool_threads != want) && st.inflight.empty()) {
+        st.pool.reset();                       // joins the old workers first
+        st.pool.reset(new WorkerPool(want));
+        st.pool_threads = want;
+    }
+    return st;
+}
+
+void HighLevelLineMOD::setPostThreads(int n) { postThreads = n < 0 ? 0 : n; }
+int HighLevelLineMOD::postThreadsInUse() const { return stream_ && stream_->pool ? stream_->pool_threads : 0; }
+int HighLevelLineMOD::batchesInFlight() const { return stream_ ? (int)stream_->inflight.size() : 0; }
+
 bool HighLevelLineMOD::detectTemplatesBatch(std::vector<std::vector<Image>>& in_frames, const std::vector<uint16_t>& in_classNumbers,
                                             std::vector<std::vector<std::vector<lm_match_t>>>& out_matches,
                                             std::vector<std::vector<std::vector<std::vector<ObjectPose>>>>& out_poses) {
-    const int n = (int)in_frames.size();
-    const size_t nc = in_classNumbers.size();
-    error.clear();
-    out_matches.assign(nc, std::vector<std::vector<lm_match_t>>((size_t)n));
-    out_poses.assign(nc, std::vector<std::vector<std::vector<ObjectPose>>>((size_t)n));
-    if (n == 0 || nc == 0) return false;
+    out_matches.assign(in_classNumbers.size(), std::vector<std::vector<lm_match_t>>(in_frames.size()));
+    out_poses.assign(in_classNumbers.size(), std::vector<std::vector<std::vector<ObjectPose>>>(in_frames.size()));
+    if (batchesInFlight() != 0) { error = "batches are in flight: collect them with detectTemplatesBatchEnd first"; return false; }
+    if (!detectTemplatesBatchBegin(in_frames, in_classNumbers)) return false;
+    return detectTemplatesBatchEnd(out_matches, out_poses);
+}
+
+bool HighLevelLineMOD::detectTemplatesBatchBegin(std::vector<std::vector<Image>>& in_frames, const std::vector<uint16_t>& in_classNumbers) {
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const int n = (int)in_frames.size();
+    error.clear();
+    if (n == 0 || in_classNumbers.empty()) { error = "no frames or no classes"; return false; }
+    if (n > kBatchSlots) { error = "batch of " + std::to_string(n) + " frames exceeds a slot set (" + std::to_string(kBatchSlots) + ")"; return false; }
+    Stream& st = stream();
+    if ((int)st.inflight.size() >= kBatchSets) { error = "all slot sets are in flight: call detectTemplatesBatchEnd first"; return false; }
     const clk::time_point t_up = clk::now();
     for (int i = 0; i < n; ++i) {
         if (in_frames[(size_t)i].empty()) { error = "no images"; return false; }
         const Image& color = in_frames[(size_t)i][0];
         const Image* depth_img = in_frames[(size_t)i].size() >= 2 ? &in_frames[(size_t)i][1] : nullptr;
-        const Image* match_depth = onlyColorModality ? nullptr : depth_img;
         if (color.width != videoWidth || color.height != videoHeight) { error = "frame size differs from the detector's"; return false; }
-        // a pending shift (Image::shift_*): applied while the staging buffer is filled; both images of the frame carry the same one
-        int urc;
-        if (color.shift_x || color.shift_y) {
-            if (depth_img && (depth_img->shift_x != color.shift_x || depth_img->shift_y != color.shift_y)) { error = "colour and depth image carry different pending shifts"; return false; }
-            if (!gpuColorCheck) { error = "the host colour check reads the colour image: shift it before the call (pending shifts need the GPU colour check)"; return false; }
-            urc = lm_upload_frame_shifted(detector, i, static_cast<const uint8_t*>(color.data), color.stride,
-                                          match_depth ? static_cast<const uint16_t*>(match_depth->data) : nullptr, match_depth ? match_depth->stride : 0,
-                                          color.shift_x, color.shift_y);
-        } else {
-            urc = lm_upload_frame(detector, i, static_cast<const uint8_t*>(color.data), color.stride,
-                                  match_depth ? static_cast<const uint16_t*>(match_depth->data) : nullptr, match_depth ? match_depth->stride : 0);
-        }
-        if (urc != LM_OK) { error = lm_last_error(); return false; }
+        if (depth_img && (depth_img->width != videoWidth || depth_img->height != videoHeight)) { error = "depth image size differs from the detector's"; return false; }
+        // a pending shift (Image::shift_*): both images of the frame carry the same one (checked whether or not it is zero: ADVICE r4)
+        if (depth_img && (depth_img->shift_x != color.shift_x || depth_img->shift_y != color.shift_y)) { error = "colour and depth image carry different pending shifts"; return false; }
+        if ((color.shift_x || color.shift_y) && !gpuColorCheck) { error = "the host colour check reads the colour image: shift it before the call (pending shifts need the GPU colour check)"; return false; }
+        if (!onlyColorModality && !depth_img) { error = "sources.size() != modalities.size(): depth image missing"; return false; }
     }
-    const clk::time_point t_match = clk::now();
+    int set = -1;
+    for (int k = 0; k < kBatchSets; ++k) { const int c = (st.next_set + k) % kBatchSets; if (!st.set_busy[c]) { set = c; break; } }
+    if (set < 0) { error = "no free slot set"; return false; }
+    const int first = set * kBatchSlots;
+    // pageable frames: staging copies on the pool, ~1 MB of rows per task, all frames side by side; pinned frames: straight to the DMA engine
+    bool any_pageable = false;
+    for (int i = 0; i < n; ++i) any_pageable |= !in_frames[(size_t)i][0].pinned;
+    if (any_pageable && lm_stage_reserve(detector, first, n) != LM_OK) { error = lm_last_error(); return false; }
+    WorkerPool::Group staging;
+    std::atomic<long long> staging_ns{0};
+    std::atomic<int> stage_rc{LM_OK};
+    const int rows_per_task = std::max(16, (int)((1 << 20) / ((size_t)videoWidth * (onlyColorModality ? 3 : 5))));
+    for (int i = 0; i < n; ++i) {
+        const Image& color = in_frames[(size_t)i][0];
+        const Image* depth_img = in_frames[(size_t)i].size() >= 2 ? &in_frames[(size_t)i][1] : nullptr;
+        const Image* match_depth = onlyColorModality ? nullptr : depth_img;
+        if (color.pinned) {
+            const int urc = lm_upload_frame_pinned_shifted(detector, first + i, static_cast<const uint8_t*>(color.data), color.stride,
+                                                           match_depth ? static_cast<const uint16_t*>(match_depth->data) : nullptr, match_depth ? match_depth->stride : 0,
+                                                           color.shift_x, color.shift_y);
+            if (urc != LM_OK) { error = lm_last_error(); st.pool->wait(staging); return false; }
+            continue;
+        }
+        for (int r0 = 0; r0 < videoHeight; r0 += rows_per_task) {
+            const int r1 = std::min<int>(r0 + rows_per_task, videoHeight);
+            lm_detector* det = detector;
+            const uint8_t* cp = static_cast<const uint8_t*>(color.data);
+            const uint16_t* dp = match_depth ? static_cast<const uint16_t*>(match_depth->data) : nullptr;
+            const size_t cs = color.stride, ds = match_depth ? match_depth->stride : 0;
+            const int sx = color.shift_x, sy = color.shift_y, slot = first + i;
+            st.pool->submit(staging, [det, slot, cp, cs, dp, ds, sx, sy, r0, r1, &staging_ns, &stage_rc] {
+                const clk::time_point t0 = clk::now();
+                const int rc = lm_stage_rows(det, slot, cp, cs, dp, ds, sx, sy, r0, r1);
+                if (rc != LM_OK) stage_rc.store(rc);
+                staging_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count());
+            }, true);
+        }
+    }
+    st.pool->wait(staging);
+    stageTimes.staging_cpu += (double)staging_ns.load() * 1e-9;
+    if (!staging.error.empty() || stage_rc.load() != LM_OK) { error = staging.error.empty() ? "staging copy failed (lm_stage_rows)" : staging.error; return false; }
+    for (int i = 0; i < n; ++i)
+        if (!in_frames[(size_t)i][0].pinned && lm_upload_staged(detector, first + i) != LM_OK) { error = lm_last_error(); return false; }
     std::vector<int32_t> cls(in_classNumbers.begin(), in_classNumbers.end());
+    if (lm_match_begin_classes(detector, /*lane*/ set, first, n, detectorThreshold, cls.data(), (int)cls.size()) != LM_OK) { error = lm_last_error(); return false; }
+    Stream::Batch b;
+    b.set = set; b.n = n; b.frames = in_frames; b.classes = in_classNumbers;
+    st.inflight.push_back(std::move(b));
+    st.set_busy[set] = true;
+    st.next_set = (set + 1) % kBatchSets;
+    stageTimes.upload += secs(t_up, clk::now());
+    return true;
+}
+
+bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vector<lm_match_t>>>& out_matches,
+                                               std::vector<std::vector<std::vector<std::vector<ObjectPose>>>>& out_poses) {
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    error.clear();
+    if (!stream_ || stream_->inflight.empty()) { error = "no batch in flight"; out_matches.clear(); out_poses.clear(); return false; }
+    Stream& st = *stream_;
+    const Stream::Batch b = std::move(st.inflight.front());
+    st.inflight.pop_front();
+    st.set_busy[b.set] = false;
+    const int n = b.n, first = b.set * kBatchSlots;
+    const size_t nc = b.classes.size();
+    out_matches.assign(nc, std::vector<std::vector<lm_match_t>>((size_t)n));
+    out_poses.assign(nc, std::vector<std::vector<std::vector<ObjectPose>>>((size_t)n));
+    const clk::time_point t_match = clk::now();
     size_t cap = 4096;
-    std::vector<lm_match_t> buf;
+    std::vector<lm_match_t> buf(cap * (size_t)n);
     std::vector<int32_t> counts((size_t)n);
-    for (;;) {
-        buf.resize(cap * (size_t)n);
-        int rc = lm_match_batch_classes(detector, 0, n, detectorThreshold, cls.data(), (int)cls.size(), buf.data(), cap, counts.data());
+    {
+        int rc = lm_match_end(detector, b.set, buf.data(), cap, counts.data());
         size_t need = 0;
         for (int32_t c : counts) need = std::max(need, (size_t)c);
         if (rc == LM_ERR_OVERFLOW && need > cap) {
-            // the frames are still resident and prepared: only a11-a15 run again (the reference consumes ALL matches)
+            // the lists are still in the slots' result blocks: fetch them again with room for all (the reference consumes ALL matches)
             cap = need;
             buf.resize(cap * (size_t)n);
-            rc = lm_match_prepared(detector, 0, n, detectorThreshold, cls.data(), (int)cls.size(), buf.data(), cap, counts.data());
+            rc = lm_match_collect(detector, first, n, buf.data(), cap, counts.data());
         }
         if (rc != LM_OK) { error = lm_last_error(); return false; }
-        break;
     }
     const clk::time_point t_post = clk::now();
-    stageTimes.upload += secs(t_up, t_match); stageTimes.match += secs(t_match, t_post); stageTimes.frames += n;
-    bool any = false;
-    // ---- step 1, this thread (it owns the detector): split the mixed lists by class; per (class, frame) grouping + the GPU colour counts
-    struct Unit { size_t c; int i; PostProcessor pp; PostProcessor::Prepared prep; const std::vector<TemplatePose>* tpl; const uint16_t* depth; std::vector<uint16_t> dense; ModelProperties props; };
-    std::vector<Unit> units;
+    stageTimes.match += secs(t_match, t_post); stageTimes.frames += n;
     PostProcessSettings ps;
     ps.onlyColorModality = onlyColorModality;
     ps.videoWidth = videoWidth; ps.videoHeight = videoHeight; ps.fy = fy;
@@ -207,110 +314,112 @@ bool HighLevelLineMOD::detectTemplatesBatch(std::vector<std::vector<Image>>& in_
     ps.radiusThresholdNewObject = settings.radiusThresholdNewObject;
     ps.discardGroupRatio = settings.discardGroupRatio;
     ps.useDepthImprovement = settings.useDepthImprovement; ps.depthOffset = settings.depthOffset;
+    // ---- step 1, pool (one task per frame): split the mixed list by class, per (class, frame) the grouping (host only)
+    struct Unit { size_t c = 0; int i = 0; bool live = false; PostProcessor pp; PostProcessor::Prepared prep; const std::vector<TemplatePose>* tpl = nullptr;
+                  const uint16_t* depth = nullptr; std::vector<uint16_t> dense; ModelProperties props;
+                  Unit(lm_detector* d, const PostProcessSettings& s) : pp(d, s) {} };
+    std::vector<Unit> units;
     units.reserve(nc * (size_t)n);
+    for (int i = 0; i < n; ++i) for (size_t c = 0; c < nc; ++c) { units.emplace_back(detector, ps); units.back().c = c; units.back().i = i; }
+    std::vector<PostProcessor::Times> frame_times((size_t)n);
+    WorkerPool::Group grouping;
     for (int i = 0; i < n; ++i) {
-        const lm_match_t* m = buf.data() + cap * (size_t)i;
         stageTimes.matches += counts[(size_t)i];
-        // the mixed list is in the total order; a class's sub-list keeps it
-        for (size_t c = 0; c < nc; ++c) {
-            std::vector<lm_match_t>& dst = out_matches[c][(size_t)i];
-            // Match::operator== compares x, y, similarity and class; std::unique removed the ADJACENT duplicates of the mixed
-            // list, where a match of another class may sit between two equal ones of this class: filtering and removing
-            // adjacent duplicates once more gives exactly the list a one-class match() returns
-            for (int32_t k = 0; k < counts[(size_t)i]; ++k) {
-                if (m[k].class_idx != (int32_t)in_classNumbers[c]) continue;
-                if (!dst.empty() && dst.back().x == m[k].x && dst.back().y == m[k].y && dst.back().similarity == m[k].similarity) continue;
-                dst.push_back(m[k]);
+        st.pool->submit(grouping, [&, i] {
+            const lm_match_t* m = buf.data() + cap * (size_t)i;
+            for (size_t c = 0; c < nc; ++c) {
+                // the mixed list is in the total order; a class's sub-list keeps it.  Match::operator== compares x, y, similarity and
+                // class; std::unique removed the ADJACENT duplicates of the mixed list, where a match of another class may sit between
+                // two equal ones of this class: filtering and removing adjacent duplicates once more gives exactly the list a one-class
+                // match() returns
+                std::vector<lm_match_t>& dst = out_matches[c][(size_t)i];
+                for (int32_t k = 0; k < counts[(size_t)i]; ++k) {
+                    if (m[k].class_idx != (int32_t)b.classes[c]) continue;
+                    if (!dst.empty() && dst.back().x == m[k].x && dst.back().y == m[k].y && dst.back().similarity == m[k].similarity) continue;
+                    dst.push_back(m[k]);
+                }
+                if (dst.empty()) continue;
+                const uint16_t cls_no = b.classes[c];
+                if (!(cls_no < modelTemplates->size()) || (*modelTemplates)[cls_no].empty()) continue;       // no template poses: no post-processing
+                Unit& u = units[(size_t)i * nc + c];
+                u.live = true;
+                u.tpl = &(*modelTemplates)[cls_no];
+                if (cls_no < modProps->size()) u.props = (*modProps)[cls_no];
+                const Image& color = b.frames[(size_t)i][0];
+                const Image* depth_img = b.frames[(size_t)i].size() >= 2 ? &b.frames[(size_t)i][1] : nullptr;
+                u.pp.setDepthShift(color.shift_x, color.shift_y);       // the host depth check reads the UNSHIFTED image through the pending shift
+                if (depth_img) {
+                    u.depth = static_cast<const uint16_t*>(depth_img->data);
+                    if (depth_img->stride && depth_img->stride != (size_t)videoWidth * 2) {
+                        u.dense.resize((size_t)videoWidth * videoHeight);
+                        for (int y = 0; y < videoHeight; ++y)
+                            std::memcpy(&u.dense[(size_t)y * videoWidth], reinterpret_cast<const uint8_t*>(depth_img->data) + (size_t)y * depth_img->stride, (size_t)videoWidth * 2);
+                        u.depth = u.dense.data();
+                    }
+                }
+                if (gpuColorCheck) u.prep = u.pp.prepare_groups(dst, *u.tpl, &frame_times[(size_t)i]);   // the colour counts follow, one GPU call per HSV range
+                else u.prep = u.pp.prepare(dst, static_cast<const uint8_t*>(color.data), color.stride, *u.tpl, u.props, -1, &frame_times[(size_t)i]);
             }
-            if (dst.empty()) continue;
-            any = true;
-            const uint16_t cls_no = in_classNumbers[c];
-            if (!(cls_no < modelTemplates->size()) || (*modelTemplates)[cls_no].empty()) continue;       // no template poses: no post-processing
-            ModelProperties props;
-            if (cls_no < modProps->size()) props = (*modProps)[cls_no];
-            const Image& color = in_frames[(size_t)i][0];
-            const Image* depth_img = in_frames[(size_t)i].size() >= 2 ? &in_frames[(size_t)i][1] : nullptr;
-            units.push_back(Unit{c, i, PostProcessor(detector, ps), {}, &(*modelTemplates)[cls_no], nullptr, {}, {}});
-            Unit& u = units.back();
-            u.pp.setDepthShift(color.shift_x, color.shift_y);       // the host depth check reads the UNSHIFTED image through the pending shift
-            if (depth_img) {
-                u.depth = static_cast<const uint16_t*>(depth_img->data);
-                if (depth_img->stride && depth_img->stride != (size_t)videoWidth * 2) {
-                    u.dense.resize((size_t)videoWidth * videoHeight);
-                    for (int y = 0; y < videoHeight; ++y)
-                        std::memcpy(&u.dense[(size_t)y * videoWidth], reinterpret_cast<const uint8_t*>(depth_img->data) + (size_t)y * depth_img->stride, (size_t)videoWidth * 2);
-                    u.depth = u.dense.data();
-                }
+        });
+    }
+    st.pool->wait(grouping);
+    if (!grouping.error.empty()) { error = grouping.error; return false; }
+    bool any = false;
+    for (size_t c = 0; c < nc; ++c) for (int i = 0; i < n; ++i) any = any || !out_matches[c][(size_t)i].empty();
+    for (const Unit& u : units) if (u.live && !u.pp.lastError().empty()) error = u.pp.lastError();
+    // ---- step 2, this thread (it owns the detector): the colour counts of the WHOLE batch -- classes with the same HSV range share ONE
+    // lm_color_check_counts_slots call (one mask launch for the batch's frames, one hull launch for all their matches, one wait), on
+    // the detector's colour-check stream beside whatever the other lane is matching
+    if (gpuColorCheck) {
+        std::vector<char> done(units.size(), 0);
+        for (size_t a = 0; a < units.size(); ++a) {
+            if (done[a] || !units[a].live) continue;
+            std::vector<size_t> same;
+            std::vector<lm_match_t> todo;
+            std::vector<int32_t> slot_of;
+            for (size_t q = a; q < units.size(); ++q) {
+                if (done[q] || !units[q].live) continue;
+                bool eq = true;
+                for (int k = 0; k < 3; ++k) eq = eq && units[a].props.lowerColorRange[k] == units[q].props.lowerColorRange[k] && units[a].props.upperColorRange[k] == units[q].props.upperColorRange[k];
+                if (!eq) continue;
+                done[q] = 1; same.push_back(q);
+                todo.insert(todo.end(), units[q].prep.todo.begin(), units[q].prep.todo.end());
+                slot_of.insert(slot_of.end(), units[q].prep.todo.size(), (int32_t)(first + units[q].i));
             }
-            if (gpuColorCheck) {
-                u.prep = u.pp.prepare_groups(dst, *u.tpl);          // the colour counts follow, one GPU call per frame and HSV range
-                u.props = props;
-            } else {
-                u.prep = u.pp.prepare(dst, static_cast<const uint8_t*>(color.data), color.stride, *u.tpl, props, -1);
-                if (!u.pp.lastError().empty()) error = u.pp.lastError();
+            std::vector<int64_t> gin(todo.size()), gboth(todo.size());
+            const clk::time_point t_c = clk::now();
+            if (!todo.empty() && lm_color_check_counts_slots(detector, slot_of.data(), units[a].props.lowerColorRange, units[a].props.upperColorRange, todo.data(), todo.size(),
+                                                             gin.data(), gboth.data()) != LM_OK) {
+                // loud, never a silent switch of implementation (frames of more than 4992 rows: setGpuColorCheck(false))
+                error = lm_last_error();
+                for (size_t q : same) { units[q].prep.failed = true; units[q].prep.groups.clear(); }
+                continue;
             }
-        }
-        if (gpuColorCheck) {
-            // the units of this frame (they are the tail of `units`): classes with the same HSV range share ONE lm_color_check_counts call
-            // (the colour mask of the frame is computed once per call: three classes = one mask instead of three)
-            size_t first = units.size();
-            while (first > 0 && units[first - 1].i == i) --first;
-            std::vector<char> done(units.size() - first, 0);
-            for (size_t a = first; a < units.size(); ++a) {
-                if (done[a - first]) continue;
-                std::vector<size_t> same;
-                std::vector<lm_match_t> todo;
-                for (size_t b = a; b < units.size(); ++b) {
-                    if (done[b - first]) continue;
-                    bool eq = true;
-                    for (int k = 0; k < 3; ++k) eq = eq && units[a].props.lowerColorRange[k] == units[b].props.lowerColorRange[k] && units[a].props.upperColorRange[k] == units[b].props.upperColorRange[k];
-                    if (!eq) continue;
-                    done[b - first] = 1; same.push_back(b);
-                    todo.insert(todo.end(), units[b].prep.todo.begin(), units[b].prep.todo.end());
-                }
-                std::vector<int64_t> gin(todo.size()), gboth(todo.size());
-                const clk::time_point t_c = clk::now();
-                if (!todo.empty() && lm_color_check_counts(detector, i, units[a].props.lowerColorRange, units[a].props.upperColorRange, todo.data(), todo.size(),
-                                                           gin.data(), gboth.data()) != LM_OK) {
-                    error = lm_last_error();
-                    for (size_t b : same) { units[b].prep.failed = true; units[b].prep.groups.clear(); }
-                    continue;
-                }
-                PostProcessor::times().colour += secs(t_c, clk::now()); PostProcessor::times().colour_checks += (long)todo.size();
-                size_t at = 0;
-                for (size_t b : same) {
-                    PostProcessor::set_counts(units[b].prep, gin.data() + at, gboth.data() + at);
-                    at += units[b].prep.todo.size();
-                }
+            PostProcessor::times().colour += secs(t_c, clk::now()); PostProcessor::times().colour_checks += (long)todo.size();
+            size_t at = 0;
+            for (size_t q : same) {
+                PostProcessor::set_counts(units[q].prep, gin.data() + at, gboth.data() + at);
+                at += units[q].prep.todo.size();
             }
         }
     }
-    // ---- step 2, any thread: one task per group of every unit (the sequential accept / break loop of a group: colour verdict,
-    // depth check, pose); results land in per-task slots and are put together in group order afterwards
+    // ---- step 3, pool: one task per group of every unit (the sequential accept / break loop of a group: colour verdict, depth check,
+    // pose); results land in per-task slots and are put together in group order afterwards
     struct Task { size_t unit, group; };
     std::vector<Task> tasks;
     for (size_t k = 0; k < units.size(); ++k)
-        for (size_t g = 0; g < units[k].prep.groups.size(); ++g) tasks.push_back(Task{k, g});
+        if (units[k].live) for (size_t g = 0; g < units[k].prep.groups.size(); ++g) tasks.push_back(Task{k, g});
     std::vector<std::vector<ObjectPose>> results(tasks.size());
-    int nthreads = postThreads > 0 ? postThreads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
-    nthreads = (int)std::min<size_t>((size_t)nthreads, std::max<size_t>(tasks.size(), 1));
-    std::vector<PostProcessor::Times> wt((size_t)nthreads);
-    std::atomic<size_t> next{0};
-    auto worker = [&](int w) {
-        for (;;) {
-            const size_t t = next.fetch_add(1);
-            if (t >= tasks.size()) break;
+    std::vector<PostProcessor::Times> wt(tasks.size());
+    WorkerPool::Group finishing;
+    for (size_t t = 0; t < tasks.size(); ++t)
+        st.pool->submit(finishing, [&, t] {
             const Unit& u = units[tasks[t].unit];
-            results[t] = u.pp.finish_group(u.prep, tasks[t].group, out_matches[u.c][(size_t)u.i], u.depth, *u.tpl, &wt[(size_t)w]);
-        }
-    };
-    if (nthreads <= 1) worker(0);
-    else {
-        std::vector<std::thread> th;
-        for (int w = 1; w < nthreads; ++w) th.emplace_back(worker, w);
-        worker(0);
-        for (std::thread& t : th) t.join();
-    }
+            results[t] = u.pp.finish_group(u.prep, tasks[t].group, out_matches[u.c][(size_t)u.i], u.depth, *u.tpl, &wt[t]);
+        });
+    st.pool->wait(finishing);
+    if (!finishing.error.empty()) { error = finishing.error; return false; }
+    for (const PostProcessor::Times& t : frame_times) PostProcessor::times().add(t);
     for (const PostProcessor::Times& t : wt) PostProcessor::times().add(t);
     for (size_t t = 0; t < tasks.size(); ++t) {
         if (results[t].empty()) continue;

@@ -32,6 +32,9 @@ struct Image {
     // shift without a translated host copy.  Both images of a frame carry the same value; needs the GPU colour check (the host colour
     // check reads the colour image as it is).
     int shift_x = 0, shift_y = 0;
+    // r05: `data` lies in PINNED host memory (lm_host_alloc, hipHostMalloc, hipHostRegister): the batch entry points hand it to the DMA
+    // engine as it is (lm_upload_frame_pinned[_shifted]) -- no staging copy; it must stay untouched until the batch has been collected.
+    bool pinned = false;
 };
 
 struct Vec3 { float x = 0, y = 0, z = 0; };
@@ -102,14 +105,30 @@ public:
     bool detectTemplatesBatch(std::vector<std::vector<Image>>& in_frames, const std::vector<uint16_t>& in_classNumbers,
                               std::vector<std::vector<std::vector<lm_match_t>>>& out_matches,
                               std::vector<std::vector<std::vector<std::vector<ObjectPose>>>>& out_poses);
+    // The same as a STREAM (r05): up to kBatchSets batches in flight.  Begin hands the frames to the detector's next free
+    // slot set (staging copies of pageable frames on the host pool, transfers on the copy streams), enqueues the class-list match on
+    // that set's lane and returns; End collects the OLDEST batch begun (match lists, then the reference's post-processing with the colour
+    // counts on the GPU's colour-check stream and the depth checks on the host pool).  With
+    //     Begin(0);  loop { Begin(k + 1); End(k); }  End(last)
+    // the upload and the GPU hot path of batch k + 1 run while the host post-processes batch k.  The frames of a batch must stay valid
+    // and unchanged until its End has returned (the depth check reads the depth image, the DMA engine reads pinned frames).  Results are
+    // the same lists and poses, bit for bit, as detectTemplatesBatch's, which is Begin + End.  Returns of End as detectTemplatesBatch.
+    bool detectTemplatesBatchBegin(std::vector<std::vector<Image>>& in_frames, const std::vector<uint16_t>& in_classNumbers);
+    bool detectTemplatesBatchEnd(std::vector<std::vector<std::vector<lm_match_t>>>& out_matches,
+                                 std::vector<std::vector<std::vector<std::vector<ObjectPose>>>>& out_poses);
+    int batchesInFlight() const;
+    static constexpr int kBatchSets = 2;
     // colour checks of the post-processing on the GPU (default) or on the host (the reference's one-match-at-a-time way)
     void setGpuColorCheck(bool on) { gpuColorCheck = on; }
     bool usesGpuColorCheck() const { return gpuColorCheck; }
     // host threads of detectTemplatesBatch's post-processing (r04): the groups of all (class, frame) pairs of a batch are independent
     // once their colour counts are known, and the reference's depth check (an nth_element over the template's bounding box per
     // tested match) is 80 % of the batch's wall time on ONE thread.  0 (default) = one per hardware thread, at most 32; 1 = serial.
-    void setPostThreads(int n) { postThreads = n < 0 ? 0 : n; }
-    // detector frame slots needed by detectTemplateBatch: lm_config.frame_slots (default 8)
+    // r05: the threads are a persistent pool owned by this object (WorkerPool.h; built on first use, rebuilt when the number changes
+    // while no batch is in flight); 0 = one per CPU this process may use (hardware threads cut by the cgroup CPU quota), at most 32.
+    void setPostThreads(int n);
+    int postThreadsInUse() const;
+    // frames per batch: a slot set of the detector (the detector is created with kBatchSlots * kBatchSets frame slots)
     static constexpr int kBatchSlots = 8;
 
     // The raw, sorted, unique match list of the last detectTemplate (the reference's private `matches`).
@@ -128,7 +147,10 @@ public:
     // resetTimes() -- upload = lm_upload_frame of every frame (staging copy + H2D enqueue), match = the hot path (lm_match_batch*,
     // a3-a15 on the GPU, synchronous), post = the reference's post-processing of every (class, frame): grouping, colour check
     // (GPU counts or host masks), depth check, poses.
-    struct StageTimes { double upload = 0, match = 0, post = 0; long frames = 0, matches = 0, poses = 0; };
+    // r05, streamed use: upload = wall time inside Begin (staging copies on the pool + enqueue), match = time End spent WAITING for the
+    // lane (0 when the GPU finished behind the previous batch's post-processing), post = the rest of End; staging_cpu = the staging
+    // copies' time summed over the pool's threads.
+    struct StageTimes { double upload = 0, match = 0, post = 0, staging_cpu = 0; long frames = 0, matches = 0, poses = 0; };
     const StageTimes& times() const { return stageTimes; }
     void resetTimes() { stageTimes = StageTimes(); }
 
@@ -160,6 +182,9 @@ private:
     bool gpuColorCheck = true;
     int postThreads = 0;
     StageTimes stageTimes;
+    struct Stream;                       // the batches in flight + the pool (HighLevelLinemod.cpp)
+    Stream* stream_ = nullptr;
+    Stream& stream();
     void readColorRanges();
     std::vector<std::vector<ObjectPose>> postProcess(const std::vector<lm_match_t>& in_matches, const Image& color,
                                                      const Image* depth_img, uint16_t in_classNumber, int gpu_slot);

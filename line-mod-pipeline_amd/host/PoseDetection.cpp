@@ -99,8 +99,14 @@ bool PoseDetection::detectBatch(std::vector<std::vector<Image>>& in_frames, std:
 
 bool PoseDetection::detectBatch(std::vector<std::vector<Image>>& in_frames, std::vector<std::string> const& in_classNames,
                                 uint16_t const& in_numberOfObjects, std::vector<std::vector<std::vector<ObjectPose>>>& out) {
-    error.clear();
     out.assign(in_classNames.size(), std::vector<std::vector<ObjectPose>>(in_frames.size()));
+    if (line->batchesInFlight() != 0) { error = "batches are in flight: collect them with detectBatchEnd first"; return false; }
+    if (!detectBatchBegin(in_frames, in_classNames)) return false;
+    return detectBatchEnd(in_numberOfObjects, out);
+}
+
+bool PoseDetection::detectBatchBegin(std::vector<std::vector<Image>>& in_frames, std::vector<std::string> const& in_classNames) {
+    error.clear();
     std::vector<uint16_t> idx;
     for (const std::string& nme : in_classNames) {
         const uint16_t k = findIndexInVector(nme, ids);
@@ -108,25 +114,41 @@ bool PoseDetection::detectBatch(std::vector<std::vector<Image>>& in_frames, std:
         idx.push_back(k);
     }
     if (in_frames.size() > (size_t)HighLevelLineMOD::kBatchSlots) { error = "batch of " + std::to_string(in_frames.size()) + " frames exceeds the detector's frame slots"; return false; }
-    if (batchBufs.size() < in_frames.size()) batchBufs.resize(in_frames.size());
+    // (before anything is translated: a refused Begin must not touch the buffers of a batch in flight)
+    if (line->batchesInFlight() >= HighLevelLineMOD::kBatchSets) { error = "all slot sets are in flight: call detectBatchEnd first"; return false; }
     std::vector<std::vector<Image>> shifted(in_frames.size());
     if (line->usesGpuColorCheck()) {
-        // r04: nothing is translated on the host -- the frames go up through lm_upload_frame_shifted (the shift happens while the
-        // staging buffer is filled) and the host depth check reads the untranslated depth image through the same shift
+        // r04: nothing is translated on the host -- the frames go up with the shift applied while the staging buffer is filled (or by the
+        // DMA engine's row-offset copy for pinned frames) and the host depth check reads the untranslated depth image through the same shift
         const int ox = (int)(-camParams.cx + camParams.videoWidth / 2), oy = (int)(-camParams.cy + camParams.videoHeight / 2);
         for (size_t i = 0; i < in_frames.size(); ++i) {
             shifted[i] = in_frames[i];
             for (Image& im : shifted[i]) { im.shift_x = ox; im.shift_y = oy; }
         }
     } else {
-        for (size_t i = 0; i < in_frames.size(); ++i) shiftFrame(in_frames[i], batchBufs[i], shifted[i]);
+        // host colour check: translated copies, one buffer set per batch in flight (they must outlive the batch's End)
+        const size_t base = streamBufNext * (size_t)HighLevelLineMOD::kBatchSlots;
+        streamBufNext = (streamBufNext + 1) % (size_t)HighLevelLineMOD::kBatchSets;
+        if (batchBufs.size() < (size_t)HighLevelLineMOD::kBatchSlots * HighLevelLineMOD::kBatchSets) batchBufs.resize((size_t)HighLevelLineMOD::kBatchSlots * HighLevelLineMOD::kBatchSets);
+        for (size_t i = 0; i < in_frames.size(); ++i) shiftFrame(in_frames[i], batchBufs[base + i], shifted[i]);
     }
+    if (!line->detectTemplatesBatchBegin(shifted, idx)) { error = line->lastError(); return false; }
+    streamShape.push_back({in_classNames.size(), in_frames.size()});
+    return true;
+}
+
+bool PoseDetection::detectBatchEnd(uint16_t const& in_numberOfObjects, std::vector<std::vector<std::vector<ObjectPose>>>& out) {
+    error.clear();
+    if (streamShape.empty()) { error = "no batch in flight"; out.clear(); return false; }
+    const std::pair<size_t, size_t> shape = streamShape.front();
+    streamShape.pop_front();
+    out.assign(shape.first, std::vector<std::vector<ObjectPose>>(shape.second));
     std::vector<std::vector<std::vector<lm_match_t>>> m;
     std::vector<std::vector<std::vector<std::vector<ObjectPose>>>> groups;
-    line->detectTemplatesBatch(shifted, idx, m, groups);
+    line->detectTemplatesBatchEnd(m, groups);
     if (!line->lastError().empty()) { error = line->lastError(); return false; }     // (the batch entry points clear it on entry)
-    for (size_t c = 0; c < in_classNames.size() && c < groups.size(); ++c)
-        for (size_t i = 0; i < in_frames.size() && i < groups[c].size(); ++i) pickFinal(groups[c][i], in_numberOfObjects, out[c][i]);
+    for (size_t c = 0; c < shape.first && c < groups.size(); ++c)
+        for (size_t i = 0; i < shape.second && i < groups[c].size(); ++i) pickFinal(groups[c][i], in_numberOfObjects, out[c][i]);
     finalObjectPoses = (out.empty() || out.back().empty()) ? std::vector<ObjectPose>() : out.back().back();
     return true;
 }

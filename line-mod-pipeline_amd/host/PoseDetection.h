@@ -5,7 +5,9 @@
 // (OpenGL renderer, ICP refinement :72-84 -- off in the shipped settings --, Hodan error :96-104, drawing and imshow
 // :105-123) needs a display / OpenGL / OpenCV and is out of scope.
 #pragma once
+#include <deque>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "HighLevelLinemod.h"
@@ -42,6 +44,14 @@ public:
     // frame i.
     bool detectBatch(std::vector<std::vector<Image>>& in_frames, std::vector<std::string> const& in_classNames,
                      uint16_t const& in_numberOfObjects, std::vector<std::vector<std::vector<ObjectPose>>>& out_objPoses);
+    // The several-objects form as a STREAM (r05): Begin hands a batch to the GPU (upload + class-list match on the next free slot set)
+    // and returns, End collects the oldest batch begun and runs its post-processing --
+    //     detectBatchBegin(b0);  loop { detectBatchBegin(b[k + 1]); detectBatchEnd(n, out[k]); }  detectBatchEnd(n, out[last])
+    // overlaps the transfer and the GPU hot path of batch k + 1 with the host's colour / depth checks of batch k.  Up to
+    // HighLevelLineMOD::kBatchSets batches in flight; a batch's frames must stay valid until its End has returned.  Same poses, bit
+    // for bit, as detectBatch (which is Begin + End).
+    bool detectBatchBegin(std::vector<std::vector<Image>>& in_frames, std::vector<std::string> const& in_classNames);
+    bool detectBatchEnd(uint16_t const& in_numberOfObjects, std::vector<std::vector<std::vector<ObjectPose>>>& out_objPoses);
     const std::vector<ObjectPose>& getFinalObjectPoses() const { return finalObjectPoses; }
     const std::string& lastError() const { return error; }
 
@@ -57,6 +67,8 @@ private:
     // shifted copies of one frame (translateImg works in place on clones, :54-59)
     struct Shifted { std::vector<uint8_t> color; std::vector<uint16_t> depth; };
     std::vector<Shifted> batchBufs;      // detectBatch's shifted frames, kept between calls (6 MB of fresh pages per 1280 x 960 frame otherwise)
+    size_t streamBufNext = 0;            // which buffer set the next detectBatchBegin translates into (host colour check only)
+    std::deque<std::pair<size_t, size_t>> streamShape;   // (classes, frames) of the batches in flight, oldest first
     void shiftFrame(const std::vector<Image>& in_imgs, Shifted& buf, std::vector<Image>& out);
     void pickFinal(const std::vector<std::vector<ObjectPose>>& groups, uint16_t nObjects, std::vector<ObjectPose>& out);
 };

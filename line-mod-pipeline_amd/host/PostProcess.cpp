@@ -7,6 +7,9 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace lmamd {
 
@@ -142,6 +145,7 @@ void bgr2hsv_inrange(const uint8_t* bgr, int w, int h, size_t stride, const doub
 template <typename T, int C>
 static void translate_rows(const T* src, int w, int h, int ox, int oy, std::vector<T>& dst) {
     dst.resize((size_t)w * h * C);                                // (a reused buffer keeps its pages; every element is written below)
+    ox = std::max(-w, std::min(w, ox)); oy = std::max(-h, std::min(h, oy));       // (beyond the frame: all zeros either way; no overflow in w + ox)
     const int x0 = std::max(ox, 0), x1 = std::min(w + ox, w);     // destination columns [x0, x1) have a source pixel
     const int y0 = std::max(oy, 0), y1 = std::min(h + oy, h);
     for (int y = 0; y < h; ++y) {
@@ -155,12 +159,44 @@ static void translate_rows(const T* src, int w, int h, int ox, int oy, std::vect
 void translate_u8c3(const uint8_t* src, int w, int h, int ox, int oy, std::vector<uint8_t>& dst) { translate_rows<uint8_t, 3>(src, w, h, ox, oy, dst); }
 void translate_u16(const uint16_t* src, int w, int h, int ox, int oy, std::vector<uint16_t>& dst) { translate_rows<uint16_t, 1>(src, w, h, ox, oy, dst); }
 
-// (shift_x, shift_y): `depth` is the frame before a translation by that many pixels with zeros shifted in; bb is in the translated frame
-uint16_t median_mat(const uint16_t* depth, int w, int h, Rect bb, uint8_t position, int shift_x, int shift_y) {
+// ---- medianMat (:336-349) ------------------------------------------------------------------------------------------------------------
+// The crop of the (translated) depth image with threshold(.., 1, 65535) inverted and added -- depths <= 1 and the zeros shifted in become
+// 65535 -- as one dense vector, plus two by-products of the same pass (r05): the smallest value and how many values lie below `below`.
+#if defined(__x86_64__)
+// (a 16-bit lane counts one element in sixteen: no overflow for rows below 2^20 pixels)
+__attribute__((target("avx2"))) static void crop_row_avx2(const uint16_t* r, int n, uint16_t* o, uint16_t below, uint16_t* mn, size_t* cnt) {
+    const __m256i lim = _mm256_set1_epi16((short)below), fe = _mm256_set1_epi16((short)0xFFFE), zero = _mm256_setzero_si256();
+    __m256i vmin = _mm256_set1_epi16((short)0xFFFF), acc = zero;
+    int x = 0;
+    for (; x + 16 <= n; x += 16) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(r + x));
+        const __m256i t = _mm256_or_si256(v, _mm256_cmpeq_epi16(_mm256_and_si256(v, fe), zero));       // v <= 1 -> 65535
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(o + x), t);
+        vmin = _mm256_min_epu16(vmin, t);
+        acc = _mm256_sub_epi16(acc, _mm256_andnot_si256(_mm256_cmpeq_epi16(_mm256_max_epu16(t, lim), t), _mm256_set1_epi16(-1)));   // t < below: max(t, below) != t
+    }
+    alignas(32) uint16_t a[16];
+    _mm256_store_si256(reinterpret_cast<__m256i*>(a), acc); for (uint16_t q : a) *cnt += q;
+    _mm256_store_si256(reinterpret_cast<__m256i*>(a), vmin); for (uint16_t q : a) *mn = std::min(*mn, q);
+    for (; x < n; ++x) { const uint16_t t = r[x] > 1 ? r[x] : (uint16_t)65535; o[x] = t; *mn = std::min(*mn, t); *cnt += t < below; }
+}
+#endif
+static void crop_row(const uint16_t* r, int n, uint16_t* o, uint16_t below, uint16_t* mn, size_t* cnt) {
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) { crop_row_avx2(r, n, o, below, mn, cnt); return; }
+#endif
+    for (int x = 0; x < n; ++x) { const uint16_t t = r[x] > 1 ? r[x] : (uint16_t)65535; o[x] = t; *mn = std::min(*mn, t); *cnt += t < below; }
+}
+
+// (shift_x, shift_y): `depth` is the frame before a translation by that many pixels with zeros shifted in; bb is in the translated frame.
+// Returns the element count (0: empty crop).
+static size_t crop_depth(const uint16_t* depth, int w, int h, Rect bb, int shift_x, int shift_y, std::vector<uint16_t>& v, uint16_t below, uint16_t* mn, size_t* cnt_below) {
+    shift_x = std::max(-w, std::min(w, shift_x)); shift_y = std::max(-h, std::min(h, shift_y));   // (beyond the frame: all zeros either way; no overflow in w + shift)
     int x0 = std::max(bb.x, 0), y0 = std::max(bb.y, 0);
-    int x1 = std::min(bb.x + bb.width, w), y1 = std::min(bb.y + bb.height, h);   // cv::Mat ROI would assert; we clip
-    if (x1 <= x0 || y1 <= y0 || position == 0) return 65535;
-    static thread_local std::vector<uint16_t> v;      // (one buffer per thread: a call per match, thousands per frame batch)
+    int x1 = (int)std::min<long long>((long long)bb.x + bb.width, w), y1 = (int)std::min<long long>((long long)bb.y + bb.height, h);   // cv::Mat ROI would assert; we clip
+    *mn = 65535; *cnt_below = 0;
+    if (x1 <= x0 || y1 <= y0) return 0;
     const size_t rw = (size_t)(x1 - x0), n = rw * (size_t)(y1 - y0);
     v.resize(n);
     uint16_t* o = v.data();
@@ -170,14 +206,49 @@ uint16_t median_mat(const uint16_t* depth, int w, int h, Rect bb, uint8_t positi
     for (int y = y0; y < y1; ++y) {
         const int sy = y - shift_y;
         if (sy < 0 || sy >= h) { for (size_t x = 0; x < rw; ++x) o[x] = 65535; o += rw; continue; }
-        const uint16_t* r = depth + (size_t)sy * w - shift_x;                  // r[x] = source pixel of translated column x
+        const uint16_t* r = depth + (size_t)sy * w;                            // source row; translated column x reads r[x - shift_x] (indexed from the row base: ADVICE r4)
         for (int x = x0; x < sx0; ++x) o[x - x0] = 65535;
-        for (int x = sx0; x < sx1; ++x) o[x - x0] = r[x] > 1 ? r[x] : (uint16_t)65535;   // threshold(.., 1, 65535) inverted and added with saturation
+        if (sx1 > sx0) crop_row(r + (sx0 - shift_x), sx1 - sx0, o + (sx0 - x0), below, mn, cnt_below);
         for (int x = sx1; x < x1; ++x) o[x - x0] = 65535;
         o += rw;
     }
+    return n;
+}
+
+uint16_t median_mat(const uint16_t* depth, int w, int h, Rect bb, uint8_t position, int shift_x, int shift_y) {
+    static thread_local std::vector<uint16_t> v;      // (one buffer per thread: a call per match, thousands per frame batch)
+    if (position == 0) return 65535;
+    uint16_t mn; size_t cb;
+    const size_t n = crop_depth(depth, w, h, bb, shift_x, shift_y, v, 0, &mn, &cb);
+    if (n == 0) return 65535;
     std::nth_element(v.begin(), v.begin() + (ptrdiff_t)(n / 4), v.end());
     return v[n / position];
+}
+
+// medianMat when all the caller wants to know is whether the result lies in [win_lo, win_hi], and the result itself if it does (the
+// depth check, :437-457).  The reference's value is v[n / position] AFTER nth_element(begin, begin + n / 4, end): an element at or
+// before the nth position, so (for position >= 4) it is at most the (n / 4)-th order statistic and at least the smallest element --
+// WHICH of those elements it is depends on the library's partition order, which is why the value itself must come from the very same
+// std::nth_element.  But when more than n / 4 elements lie below win_lo the (n / 4)-th order statistic does, and when the smallest
+// element lies above win_hi everything does: the verdict "outside" is then certain without the selection (r05: one vectorised pass
+// over the crop instead of the partition passes; exact, never a different verdict or value).  Returns true and *median when inside.
+bool median_mat_in_window(const uint16_t* depth, int w, int h, Rect bb, uint8_t position, int shift_x, int shift_y, int win_lo, int win_hi,
+                          uint16_t* median, bool* decided_early) {
+    static thread_local std::vector<uint16_t> v;
+    if (decided_early) *decided_early = false;
+    uint16_t m = 65535;
+    if (position != 0) {
+        uint16_t mn; size_t cb;
+        const uint16_t below = (uint16_t)std::max(0, std::min(win_lo, 65535));
+        const size_t n = crop_depth(depth, w, h, bb, shift_x, shift_y, v, below, &mn, &cb);
+        if (n != 0) {
+            if (position >= 4 && win_lo <= 65535 && (cb >= n / 4 + 1 || (int)mn > win_hi)) { if (decided_early) *decided_early = true; return false; }
+            std::nth_element(v.begin(), v.begin() + (ptrdiff_t)(n / 4), v.end());
+            m = v[n / position];
+        }
+    }
+    *median = m;
+    return (int)m >= win_lo && (int)m <= win_hi;
 }
 
 std::vector<Pt> convex_hull(std::vector<Pt> p) {   // Andrew's monotone chain, counter-clockwise, collinear points dropped
@@ -321,13 +392,29 @@ bool PostProcessor::color_check(const lm_match_t& m, const std::vector<uint8_t>&
     return color_verdict(in_hull, in_both, st.percentToPassCheck);
 }
 
-bool PostProcessor::depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth) const {
+// depthDiff of a median (:441-447): monotone non-decreasing in the median (exact int -> float, a float subtraction, truncation)
+static inline int32_t depth_diff(int med, const TemplatePose& tp, float depthOffset) {
+    return (int32_t)((float)((int32_t)med - (int32_t)tp.medianDepth) - depthOffset);
+}
+
+bool PostProcessor::depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth, bool* decided_early) const {
     const TemplatePose& tp = t[(size_t)m.template_id];
+    if (decided_early) *decided_early = false;
     if (st.useDepthImprovement) {
         Rect bb{m.x, m.y, tp.bb[2], tp.bb[3]};
-        int32_t depthDiff = (int32_t)((float)((int32_t)median_mat(depth, st.videoWidth, st.videoHeight, bb, 5, depth_ox, depth_oy) - (int32_t)tp.medianDepth) - st.depthOffset);
+        // the medians that pass |depthDiff| < stepSize are an interval [lo, hi] of 0 .. 65535 (depth_diff is monotone): two bisections
+        const int32_t step = (int32_t)st.stepSize;
+        int lo = 0, hi = 65536;                              // lo: first median with depthDiff > -step
+        while (lo < hi) { const int mid = (lo + hi) / 2; if (depth_diff(mid, tp, st.depthOffset) > -step) hi = mid; else lo = mid + 1; }
+        const int win_lo = lo;
+        lo = -1; hi = 65535;                                 // hi: last median with depthDiff < step
+        while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (depth_diff(mid, tp, st.depthOffset) < step) lo = mid; else hi = mid - 1; }
+        const int win_hi = lo;
+        uint16_t med = 0;
+        if (win_lo > win_hi || !median_mat_in_window(depth, st.videoWidth, st.videoHeight, bb, 5, depth_ox, depth_oy, win_lo, win_hi, &med, decided_early)) return false;
+        const int32_t depthDiff = depth_diff(med, tp, st.depthOffset);
         *tempDepth = (int32_t)(tp.translation[2] + (float)depthDiff);
-        return std::abs(depthDiff) < (int32_t)st.stepSize;
+        return std::abs(depthDiff) < step;                   // (true: med is inside the window)
     }
     *tempDepth = (int32_t)tp.translation[2];
     return true;
@@ -358,9 +445,9 @@ ObjectPose PostProcessor::make_pose(const lm_match_t& m, const std::vector<Templ
 
 PostProcessor::Times& PostProcessor::times() { static thread_local Times t; return t; }
 
-PostProcessor::Prepared PostProcessor::prepare_groups(const std::vector<lm_match_t>& matches, const std::vector<TemplatePose>& templates) {
+PostProcessor::Prepared PostProcessor::prepare_groups(const std::vector<lm_match_t>& matches, const std::vector<TemplatePose>& templates, Times* tmp) {
     using clk = std::chrono::steady_clock;
-    Times& tm = times();
+    Times& tm = tmp ? *tmp : times();
     Prepared p;
     if (matches.empty()) return p;
     const clk::time_point t_g = clk::now();
@@ -374,10 +461,10 @@ PostProcessor::Prepared PostProcessor::prepare_groups(const std::vector<lm_match
 }
 
 PostProcessor::Prepared PostProcessor::prepare(const std::vector<lm_match_t>& matches, const uint8_t* bgr, size_t bgr_stride,
-                                               const std::vector<TemplatePose>& templates, const ModelProperties& props, int gpu_slot) {
+                                               const std::vector<TemplatePose>& templates, const ModelProperties& props, int gpu_slot, Times* tmp) {
     using clk = std::chrono::steady_clock;
-    Times& tm = times();
-    Prepared p = prepare_groups(matches, templates);
+    Times& tm = tmp ? *tmp : times();
+    Prepared p = prepare_groups(matches, templates, tmp);
     if (matches.empty()) return p;
     const int w = st.videoWidth, h = st.videoHeight;
     const clk::time_point t_c = clk::now();
@@ -416,8 +503,9 @@ std::vector<ObjectPose> PostProcessor::finish_group(const Prepared& p, size_t gr
                         : color_check(m, p.color_mask);
         if (ok && depth_rows) {                                                       // && short-circuit like the reference
             const clk::time_point t_d = clk::now();
-            ok = depth_check(m, depth_rows, templates, &tempDepth);
-            if (tm) { tm->depth += secs(t_d, clk::now()); tm->depth_checks += 1; }
+            bool early = false;
+            ok = depth_check(m, depth_rows, templates, &tempDepth, &early);
+            if (tm) { tm->depth += secs(t_d, clk::now()); tm->depth_checks += 1; tm->depth_decided_early += early ? 1 : 0; }
         }
         if (ok) {
             const clk::time_point t_p = clk::now();

@@ -68,6 +68,10 @@ void translate_u8c3(const uint8_t* src, int w, int h, int ox, int oy, std::vecto
 void translate_u16(const uint16_t* src, int w, int h, int ox, int oy, std::vector<uint16_t>& dst);
 // HighLevelLineMOD::medianMat (:336-349): zeros -> 65535, crop, nth_element at n/4, returns element n/position.
 uint16_t median_mat(const uint16_t* depth, int w, int h, Rect bb, uint8_t position, int shift_x = 0, int shift_y = 0);
+// The same when only medians inside [win_lo, win_hi] matter (the depth check): false = outside, decided -- when it can be -- from the crop's
+// smallest element and the number of elements below win_lo instead of the selection; true + *median = the reference's value.
+bool median_mat_in_window(const uint16_t* depth, int w, int h, Rect bb, uint8_t position, int shift_x, int shift_y, int win_lo, int win_hi,
+                          uint16_t* median, bool* decided_early = nullptr);
 struct Pt { int x, y; };
 std::vector<Pt> convex_hull(std::vector<Pt> pts);                   // cv::convexHull (hull vertices, ccw, no collinear points)
 // templateMask (:113-135) restricted to the hull's bounding box: returns (pixels in hull, pixels in hull
@@ -96,8 +100,9 @@ public:
     // where run()'s wall time went, accumulated over all PostProcessors of the thread since resetTimes() (bench.py's pose_e2e leg)
     struct Times {
         double grouping = 0, colour = 0, depth = 0, pose = 0; long colour_checks = 0, depth_checks = 0, poses = 0, groups = 0;
+        long depth_decided_early = 0; // depth checks whose failing verdict was certain from the crop's minimum / count below the pass window (no nth_element)
         void add(const Times& o) { grouping += o.grouping; colour += o.colour; depth += o.depth; pose += o.pose; colour_checks += o.colour_checks;
-                                   depth_checks += o.depth_checks; poses += o.poses; groups += o.groups; }
+                                   depth_checks += o.depth_checks; poses += o.poses; groups += o.groups; depth_decided_early += o.depth_decided_early; }
     };
     static Times& times();
     static void resetTimes() { times() = Times(); }
@@ -113,12 +118,13 @@ public:
         std::vector<uint8_t> color_mask;          // host colour check: the frame's HSV in-range mask
         bool gpu = false, failed = false;
     };
+    // tm: where the call's times go (nullptr = the calling thread's times(); pool tasks hand in their own block)
     Prepared prepare(const std::vector<lm_match_t>& matches, const uint8_t* bgr, size_t bgr_stride,
-                     const std::vector<TemplatePose>& templates, const ModelProperties& props, int gpu_slot);
+                     const std::vector<TemplatePose>& templates, const ModelProperties& props, int gpu_slot, Times* tm = nullptr);
     // prepare() in two halves for callers that batch the GPU colour counts of several classes of one frame into ONE
     // lm_color_check_counts call (same HSV range): the grouping + the list of matches whose counts are wanted (host only), then the
     // counts, in p.todo's order
-    Prepared prepare_groups(const std::vector<lm_match_t>& matches, const std::vector<TemplatePose>& templates);
+    Prepared prepare_groups(const std::vector<lm_match_t>& matches, const std::vector<TemplatePose>& templates, Times* tm = nullptr);
     static void set_counts(Prepared& p, const int64_t* in_hull, const int64_t* in_both) {
         p.gin.assign(in_hull, in_hull + p.todo.size()); p.gboth.assign(in_both, in_both + p.todo.size()); p.gpu = true;
     }
@@ -135,7 +141,8 @@ public:
 private:
     bool color_check(const lm_match_t& m, const std::vector<uint8_t>& color_mask) const;                    // :424-434
     std::string error;
-    bool depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth) const;  // :437-457
+    // decided_early (r05): the verdict "fails" came from median_mat_in_window's bounds, without the selection
+    bool depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth, bool* decided_early = nullptr) const;  // :437-457
     ObjectPose make_pose(const lm_match_t& m, const std::vector<TemplatePose>& t, int32_t tempDepth) const; // :459-515
     lm_detector* det;
     PostProcessSettings st;

@@ -174,6 +174,63 @@ int main(int argc, char** argv) {
             std::printf("\n");
         }
     }
-    if (!line.lastError().empty()) std::printf("last error: %s\n", line.lastError().c_str());
+    // ---- r05: the same batches as a STREAM (detectBatchBegin / detectBatchEnd, two batches in flight): three different batches (the
+    // frames in order, reversed, rotated by three), serial = one detectBatch each; streamed with pageable frames, with pinned frames
+    // (DMA row-offset copy instead of a staging copy) and with the host colour check -- every pose of every pass printed for pytest
+    {
+        uint8_t* pin = nullptr;
+        const size_t cb = (size_t)W * H * 3, db = (size_t)W * H * 2;
+        if (lm_host_alloc((cb + db) * NF, reinterpret_cast<void**>(&pin)) != LM_OK) { std::printf("lm_host_alloc failed: %s\n", lm_last_error()); return 1; }
+        for (int i = 0; i < NF; ++i) { std::memcpy(pin + (size_t)i * (cb + db), fb[i].data(), cb); std::memcpy(pin + (size_t)i * (cb + db) + cb, fd[i].data(), db); }
+        auto make = [&](int which, bool pinned) {
+            std::vector<std::vector<Image>> b(NF, std::vector<Image>(2));
+            for (int i = 0; i < NF; ++i) {
+                const int src = which == 0 ? i : which == 1 ? NF - 1 - i : (i + 3) % NF;
+                b[i][0] = frames[src][0]; b[i][1] = frames[src][1];
+                if (pinned) { b[i][0].data = pin + (size_t)src * (cb + db); b[i][1].data = pin + (size_t)src * (cb + db) + cb; b[i][0].pinned = b[i][1].pinned = true; }
+            }
+            return b;
+        };
+        auto dump = [&](const char* tag, int bi, const std::vector<std::vector<std::vector<ObjectPose>>>& poses) {
+            for (int c = 0; c < 3; ++c)
+                for (int i = 0; i < NF; ++i) {
+                    std::printf("stream %s batch %d frame %d class %d poses %zu", tag, bi, i, c, poses[c][i].size());
+                    for (const ObjectPose& p : poses[c][i])
+                        std::printf(" t %.9g %.9g %.9g q %.9g %.9g %.9g %.9g bb %d %d %d %d", p.translation.x, p.translation.y, p.translation.z,
+                                    p.quaternions.w, p.quaternions.x, p.quaternions.y, p.quaternions.z, p.boundingBox.x, p.boundingBox.y,
+                                    p.boundingBox.width, p.boundingBox.height);
+                    std::printf("\n");
+                }
+        };
+        std::vector<std::vector<std::vector<ObjectPose>>> poses;
+        for (int pass = 0; pass < 4; ++pass) {       // 0 serial, 1 streamed pageable, 2 streamed pinned, 3 streamed with the host colour check
+            const char* tag = pass == 0 ? "serial" : pass == 1 ? "piped" : pass == 2 ? "pinned" : "hostcc";
+            line.setGpuColorCheck(pass != 3);
+            std::vector<std::vector<Image>> bt[3] = {make(0, pass == 2), make(1, pass == 2), make(2, pass == 2)};
+            if (pass == 0) {
+                for (int bi = 0; bi < 3; ++bi) {
+                    if (!pd.detectBatch(bt[bi], all_names, 1, poses)) { std::printf("detectBatch failed: %s\n", pd.lastError().c_str()); return 1; }
+                    dump(tag, bi, poses);
+                }
+                continue;
+            }
+            if (!pd.detectBatchBegin(bt[0], all_names)) { std::printf("detectBatchBegin failed: %s\n", pd.lastError().c_str()); return 1; }
+            for (int bi = 0; bi < 3; ++bi) {
+                if (bi + 1 < 3 && !pd.detectBatchBegin(bt[bi + 1], all_names)) { std::printf("detectBatchBegin failed: %s\n", pd.lastError().c_str()); return 1; }
+                if (bi == 0) {     // a third batch in flight is refused, loudly, and the stream goes on
+                    const bool third = pd.detectBatchBegin(bt[2], all_names);
+                    std::printf("stream %s third_begin_refused %d\n", tag, third ? 0 : 1);
+                    if (third) return 1;
+                }
+                if (!pd.detectBatchEnd(1, poses)) { std::printf("detectBatchEnd failed: %s\n", pd.lastError().c_str()); return 1; }
+                dump(tag, bi, poses);
+            }
+            std::vector<std::vector<std::vector<ObjectPose>>> none;
+            std::printf("stream %s end_without_batch_refused %d\n", tag, pd.detectBatchEnd(1, none) ? 0 : 1);
+        }
+        line.setGpuColorCheck(true);
+        lm_host_free(pin);
+    }
+    if (!line.lastError().empty() && line.lastError() != "no batch in flight") std::printf("last error: %s\n", line.lastError().c_str());
     return 0;
 }

@@ -127,6 +127,37 @@ int main() {
                     CHECK(median_mat(d.data(), W, H, bb, pos, ox, oy) == median_mat(dd.data(), W, H, bb, pos));
         }
     }
+    // ---- r05: the depth check's bounded median (median_mat_in_window) against the plain one on random crops, windows and shifts --
+    // "inside the window" and the value agree with median_mat every time (the early verdict is a proof, never a guess), early verdicts
+    // happen on both sides (count below the window / minimum above it), and widths around the 16-pixel vector step are covered
+    {
+        uint32_t r = 777;
+        auto rnd = [&]() { r = r * 1664525u + 1013904223u; return r >> 8; };
+        long early = 0, inside = 0, outside_late = 0, total = 0;
+        for (int W : {64, 50, 33, 17, 16, 15, 129}) {
+            const int H = 40;
+            std::vector<uint16_t> d((size_t)W * H);
+            for (int kind = 0; kind < 3; ++kind) {
+                for (uint16_t& v : d) v = (uint16_t)(rnd() % 9 == 0 ? rnd() % 2 : kind == 0 ? 500 + rnd() % 600 : kind == 1 ? 800 + rnd() % 8 : rnd() % 65536);
+                for (int it = 0; it < 400; ++it) {
+                    const Rect bb{(int)(rnd() % (unsigned)(W + 10)) - 5, (int)(rnd() % (unsigned)(H + 10)) - 5, 1 + (int)(rnd() % (unsigned)W), 1 + (int)(rnd() % (unsigned)H)};
+                    const int ox = it % 3 == 0 ? (int)(rnd() % 21) - 10 : 0, oy = it % 3 == 0 ? (int)(rnd() % 21) - 10 : 0;
+                    int lo = (int)(rnd() % 1400), hi = lo + (int)(rnd() % 300) - 20;           // sometimes an empty window
+                    if (it % 11 == 0) { lo = 65535 - (int)(rnd() % 3); hi = 65535 + (int)(rnd() % 2); }   // the holes' value
+                    if (it % 13 == 0) { lo = -5; hi = (int)(rnd() % 900); }
+                    const uint16_t want = median_mat(d.data(), W, H, bb, 5, ox, oy);
+                    uint16_t got = 12345; bool e = false;
+                    const bool in = median_mat_in_window(d.data(), W, H, bb, 5, ox, oy, lo, hi, &got, &e);
+                    CHECK(in == ((int)want >= lo && (int)want <= hi));
+                    if (in) CHECK(got == want);
+                    if (!e && !in) CHECK(got == want);
+                    early += e; inside += in; outside_late += (!in && !e); ++total;
+                }
+            }
+        }
+        CHECK(early > total / 4); CHECK(inside > total / 50); CHECK(outside_late > 0);
+        std::fprintf(stderr, "median_mat_in_window: %ld crops, %ld inside the window, %ld outside by the bounds, %ld outside after the selection\n", total, inside, early, outside_late);
+    }
     // ---- CameraViewPoints (CameraViewPoints.cpp): shipped model = rotationally symmetric, planes (1,1,1),
     // subdivisions 3 -> 13 viewpoints on the quarter arc (13 x 15 x 10 = 1950 templates)
     {

@@ -154,6 +154,25 @@ def test_depth_quantize_thresholds_and_full_range(lm, orc, diff_thr):
     d.close()
 
 
+@pytest.mark.parametrize("diff_thr", [50, 250, 6000])     # the three bodies of k_dnormal: packed taps + integer products, packed + double products, per-pixel taps
+def test_depth_quantize_zero_length_normal(lm, orc, diff_thr):
+    """a pixel whose normal has all three components 0 -- depth 0 among zeros (nz = -det * 0), or every one of the eight
+    taps outside the bilateral gate (det = ddx = ddy = 0) -- makes the float tail's length 0; dn_sqrt(0) is a NaN and a float -> int
+    conversion of a NaN is undefined.  The kernel now selects len = 1 for it, which lands on the table's "outside" entry = label 0,
+    the oracle's `len > 0` result; whole images of such pixels, and lattices that mix them with ordinary ones."""
+    h, w = 64, 96
+    d = lm.Detector(color_only=False, width=w, height=h, T=[4, 8], difference_threshold=diff_thr)
+    zeros = np.zeros((h, w), np.uint16)
+    yy, xx = np.mgrid[0:h, 0:w]
+    lattice = np.where(((yy // 5) + (xx // 5)) % 2 == 0, 300, 300 + 4 * diff_thr).clip(0, 65535).astype(np.uint16)   # every tap 5 away crosses the gate
+    mixed = lattice.copy(); mixed[20:40, 30:70] = 0; mixed[5:15, 5:25] = 700
+    for depth in (zeros, lattice, mixed):
+        got, exp = d.stage_depth_quantize(depth), orc.depth_quantize(depth, 2000, diff_thr)
+        assert np.array_equal(got, exp), diff_thr
+    assert not d.stage_depth_quantize(zeros).any()
+    d.close()
+
+
 def test_depth_normal_float_tail_sequences_are_exact(lm):
     """k_dnormal takes 1 / len and sqrt by short sequences (r04: dn_rcp = v_rcp + ONE Newton step, dn_sqrt = v_rsq + one coupled
     step g + (x - g g) y / 2; r03's longer forms -- v_rcp + six fused steps, v_sqrt_f32 + the +-1 ulp fix-up -- are swept beside

@@ -307,3 +307,127 @@ def test_shifted_upload_equals_upload_of_the_shifted_frame(lm, orc, synth):
         assert cnt[0] == cnt[1] and out[0, :cnt[0]].tobytes() == out[1, :cnt[1]].tobytes(), (ox, oy)
         assert np.array_equal(d.debug_read(0, 0, 0, 1), d.debug_read(1, 0, 0, 1)), (ox, oy)      # the depth modality's quantised image
     d.close()
+
+
+def _translate(img, ox, oy):
+    """numpy restatement of the reference's translateImg (warpAffine with a pure integer translation, zeros shifted in)."""
+    out = np.zeros_like(img)
+    h, w = img.shape[:2]
+    x0, x1 = max(ox, 0), min(w + ox, w)
+    y0, y1 = max(oy, 0), min(h + oy, h)
+    if x1 > x0 and y1 > y0:
+        out[y0:y1, x0:x1] = img[y0 - oy:y1 - oy, x0 - ox:x1 - ox]
+    return out
+
+
+def test_staged_and_pinned_shifted_uploads_equal_the_translated_frame(lm, orc, synth):
+    """r05: the three-step staged upload (lm_stage_reserve, lm_stage_rows over row ranges filled by several threads,
+    lm_upload_staged) and the pinned row-offset copy (lm_upload_frame_pinned_shifted) put the same frame into a slot as uploading
+    the host-translated frame: the match lists equal the oracle's on the numpy-translated frame, for shifts of both signs,
+    a shift larger than the frame (clamped: an all-zero frame) and no shift."""
+    import threading
+    d, frames, _ = _setup(lm, orc, synth, n_frames=2)
+    o = orc.Detector(color_only=False)
+    o.add_class("c", *_bank_of(d, lm))
+    pb = lm.PinnedBuffer(W * H * 5)
+    pc, pd_ = pb.view(np.uint8, (H, W, 3)), pb.view(np.uint16, (H, W), offset=W * H * 3)
+    for (sx, sy) in ((-12, 10), (7, -5), (0, 0), (33, 0), (0, -41), (5 * W, 3)):
+        bgr, depth = frames[(sx + sy) % 2]
+        tb, td = _translate(bgr, max(-W, min(W, sx)), max(-H, min(H, sy))), _translate(depth, max(-W, min(W, sx)), max(-H, min(H, sy)))
+        exp = o.match(tb, td, THR, threads=8)
+        # staged: rows dealt to four threads in interleaved pieces
+        d.stage_reserve(2, 1)
+        pieces = [(r, min(r + 37, H)) for r in range(0, H, 37)]
+        th = [threading.Thread(target=lambda k=k: [d.stage_rows(2, bgr, depth, sx, sy, a, b) for (a, b) in pieces[k::4]]) for k in range(4)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        d.upload_staged(2)
+        out, c = d.match_batch_classes(2, 1, THR, [0])
+        assert_matches_equal(out[0, :c[0]], exp)
+        # pinned: the DMA engine's row-offset copy
+        pc[...] = bgr
+        pd_[...] = depth
+        d.upload_frame_pinned_shifted(3, pc, pd_, sx, sy)
+        out, c = d.match_batch_classes(3, 1, THR, [0])
+        assert_matches_equal(out[0, :c[0]], exp)
+        # and the r04 one-call form
+        d.upload_frame_shifted(4, bgr, depth, sx, sy)
+        out, c = d.match_batch_classes(4, 1, THR, [0])
+        assert_matches_equal(out[0, :c[0]], exp)
+    with pytest.raises(lm.LinemodError):
+        d.stage_rows(5, frames[0][0], frames[0][1], 0, 0, 0, H)      # no lm_stage_reserve for slot 5
+    with pytest.raises(lm.LinemodError):
+        d.upload_staged(5)
+    d.stage_reserve(5, 1)
+    with pytest.raises(lm.LinemodError):
+        d.stage_rows(5, frames[0][0], frames[0][1], 0, 0, 0, H + 1)  # row range outside the frame
+    pb.close([d])
+    d.close()
+
+
+def _bank_of(d, lm):
+    """(descs, features) of class 0 of detector d, read back through lm_get_template (whole pyramids, [template][level * M + modality])."""
+    M, L = d.num_modalities, d.pyramid_levels
+    descs, feats = [], []
+    for t in range(d.class_num_templates(0)):
+        for l in range(L):
+            for m in range(M):
+                w, h, f = d.get_template(0, t, l, m)
+                descs.append((w, h, l, len(f)))
+                feats.append(f)
+    return np.array(descs, lm.DESC_DTYPE), np.concatenate(feats)
+
+
+def test_match_collect_redelivers_after_overflow(lm, orc, synth):
+    """r05: lm_match_end with too small a buffer reports LM_ERR_OVERFLOW and the lengths; lm_match_collect then hands over the same lists
+    without a second pass over the GPU, until the slot is uploaded to again."""
+    d, frames, exp = _setup(lm, orc, synth, n_frames=3)
+    for k in range(3):
+        d.upload_frame(k, *frames[k])
+    big = max(len(e) for e in exp)
+    assert big > 4
+    d.match_begin(1, 0, 3, THR, 0)
+    with pytest.raises(lm.LinemodError) as ei:
+        d.match_end(1, cap_per_frame=2, n_slots=3)
+    assert ei.value.code == lm.LM_ERR_OVERFLOW
+    stage0 = d.get_stage_counts()
+    out, c = d.match_collect(0, 3, cap_per_frame=big)
+    assert d.get_stage_counts() == stage0                  # nothing ran on the GPU
+    for k in range(3):
+        assert_matches_equal(out[k, :c[k]], exp[k])
+    d.upload_frame(1, *frames[2])
+    with pytest.raises(lm.LinemodError):
+        d.match_collect(0, 3, cap_per_frame=big)           # slot 1 holds a frame no match has run on
+    out, c = d.match_collect(0, 1, cap_per_frame=big)
+    assert_matches_equal(out[0, :c[0]], exp[0])
+    d.close()
+
+
+def test_colour_check_of_a_batch_in_one_call_beside_a_busy_lane(lm, orc, synth):
+    """r05: lm_color_check_counts_slots (a list spanning several resident frames: one mask launch, one hull launch) returns, per match,
+    what lm_color_check_counts returns for that match's slot alone -- also while ANOTHER lane has a match in flight (own stream and
+    buffers); slots of the busy lane are refused."""
+    d, frames, exp = _setup(lm, orc, synth, n_frames=4)
+    for k in range(8):
+        d.upload_frame(k, *frames[k % 4])
+    lo, hi = (0, 0, 60), (255, 200, 255)
+    out, c = d.match_batch_classes(0, 4, THR, [0])
+    lists = [out[k, :min(c[k], 300)].copy() for k in range(4)]
+    assert sum(len(l) for l in lists) > 20
+    single = [d.color_check_counts(k, lo, hi, lists[k]) for k in range(4)]
+    allm = np.concatenate(lists)
+    slot_of = np.concatenate([np.full(len(l), k, np.int32) for k, l in enumerate(lists)])
+    perm = np.random.default_rng(5).permutation(len(allm))             # any order of the list
+    d.match_begin(1, 4, 4, THR, 0)                                       # lane 1 busy on slots 4..7
+    a, b = d.color_check_counts_slots(slot_of[perm], lo, hi, allm[perm])
+    inv = np.argsort(perm)
+    assert np.array_equal(a[inv], np.concatenate([s[0] for s in single])) and np.array_equal(b[inv], np.concatenate([s[1] for s in single]))
+    assert a.sum() > 0 and 0 < b.sum() < a.sum()
+    a1, b1 = d.color_check_counts(2, lo, hi, lists[2])                  # the one-slot form beside the busy lane
+    assert np.array_equal(a1, single[2][0]) and np.array_equal(b1, single[2][1])
+    with pytest.raises(lm.LinemodError):
+        d.color_check_counts_slots(np.full(len(lists[0]), 5, np.int32), lo, hi, lists[0])     # slot 5 belongs to the match in flight
+    out1, c1 = d.match_end(1, n_slots=4)
+    for k in range(4):
+        assert_matches_equal(out1[k, :c1[k]], exp[k])
+    d.close()
