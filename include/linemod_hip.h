@@ -328,6 +328,12 @@ int lm_color_check_counts(lm_detector* det, int slot, const double lower_hsv[3],
  * batch k overlap the match of batch k + 1 on another lane. */
 int lm_color_check_counts_slots(lm_detector* det, const int32_t* slot_of_match, const double lower_hsv[3], const double upper_hsv[3],
                                 const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both);
+/* The two halves of lm_color_check_counts_slots: begin enqueues the copies and the two launches on the colour-check stream and returns,
+ * end waits and delivers the counts of the list begun (one check in flight per detector; `matches` may be reused after begin returns).
+ * Between them the calling thread is free -- HighLevelLineMOD starts the first depth checks of a batch's groups meanwhile. */
+int lm_color_check_begin_slots(lm_detector* det, const int32_t* slot_of_match, const double lower_hsv[3], const double upper_hsv[3],
+                               const lm_match_t* matches, size_t n);
+int lm_color_check_end(lm_detector* det, int64_t* in_hull, int64_t* in_both);
 
 /* ---- multi-GPU: template-bank shards + the ONE exchange step of the path ------------------------
  * One process per GPU; every rank creates its detector with lm_config.shard_rank / shard_size (contiguous template_id

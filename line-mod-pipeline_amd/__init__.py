@@ -84,7 +84,7 @@ EXPORTS = [
     "lm_time_scan_batch",
     "lm_selftest_float_tail",
     "lm_upload_frame_pinned_shifted", "lm_stage_reserve", "lm_stage_rows", "lm_upload_staged", "lm_match_collect",
-    "lm_color_check_counts_slots",
+    "lm_color_check_counts_slots", "lm_color_check_begin_slots", "lm_color_check_end",
 ]
 
 _lib = None
@@ -195,6 +195,8 @@ def load_library(path=None):
     lib.lm_upload_staged.argtypes = [vp, i]
     lib.lm_match_collect.argtypes = [vp, i, i, vp, sz, vp]
     lib.lm_color_check_counts_slots.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, sz, vp, vp]
+    lib.lm_color_check_begin_slots.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, sz]
+    lib.lm_color_check_end.argtypes = [vp, vp, vp]
     if path is None:
         _lib = lib
     return lib

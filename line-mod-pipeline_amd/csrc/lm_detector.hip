@@ -132,6 +132,7 @@ struct lm_detector {
     // batch k overlaps the match of batch k + 1 (HighLevelLineMOD::detectTemplatesBatchBegin / End)
     hipStream_t cc_stream = nullptr;
     u8* cc_dev = nullptr; u8* cc_host = nullptr; size_t cc_cap = 0;       // room for cc_cap matches: records | slot index | two counts
+    size_t cc_pending = 0; bool cc_inflight = false;                      // lm_color_check_begin_slots enqueued a check of cc_pending matches
     LmComm* comm[LM_NLANES] = {};   // one communicator per lane: the lanes' collectives never wait for each other
     int comm_recs_per_frame = 0;
     Gather gather[LM_NLANES];
@@ -1753,11 +1754,12 @@ static int ensure_colour_check(lm_detector* d, size_t n) {
 }
 
 // slot_of: per match the slot its frame is resident in, or nullptr = all in `one_slot`.
-static int colour_check(lm_detector* d, const int32_t* slot_of, int one_slot, const double lower_hsv[3], const double upper_hsv[3],
-                        const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both) {
+static int colour_check_enqueue(lm_detector* d, const int32_t* slot_of, int one_slot, const double lower_hsv[3], const double upper_hsv[3],
+                                const lm_match_t* matches, size_t n) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
-    if (!lower_hsv || !upper_hsv || (n && (!matches || !in_hull || !in_both))) return fail(LM_ERR_INVALID, "null argument");
+    if (d->cc_inflight) return fail(LM_ERR_INVALID, "a colour check is in flight: call lm_color_check_end first");
+    if (!lower_hsv || !upper_hsv || (n && !matches)) return fail(LM_ERR_INVALID, "null argument");
     const int S = (int)d->slots.size();
     int s_lo = S, s_hi = -1;
     std::vector<char> used((size_t)S, 0);
@@ -1814,16 +1816,48 @@ static int colour_check(lm_detector* d, const int32_t* slot_of, int one_slot, co
         return fail(LM_ERR_INVALID, "frame too tall for the GPU colour check (more than 4992 rows): use the host colour check");
     }
     HIP_TRY(hipMemcpyAsync(d->cc_host + off_out, a.out, n * 2 * sizeof(long long), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    d->cc_pending = n; d->cc_inflight = true;
+    return LM_OK;
+}
+
+static int colour_check_finish(lm_detector* d, int64_t* in_hull, int64_t* in_both) {
+    if (!d || !d->cc_inflight) return fail(LM_ERR_INVALID, "no colour check in flight");
+    const size_t n = d->cc_pending;
+    d->cc_inflight = false; d->cc_pending = 0;
+    if (n && (!in_hull || !in_both)) { (void)hipStreamSynchronize(d->cc_stream); return fail(LM_ERR_INVALID, "null argument"); }
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    HIP_TRY(hipStreamSynchronize(d->cc_stream));
     HIP_TRY(hipGetLastError());
+    const size_t off_out = d->cc_cap * sizeof(lm_match_t) + d->cc_cap * sizeof(int);
     const long long* out = reinterpret_cast<const long long*>(d->cc_host + off_out);
     for (size_t i = 0; i < n; ++i) { in_hull[i] = out[2 * i]; in_both[i] = out[2 * i + 1]; }
     return LM_OK;
 }
 
+static int colour_check(lm_detector* d, const int32_t* slot_of, int one_slot, const double lower_hsv[3], const double upper_hsv[3],
+                        const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both) {
+    if (n && (!in_hull || !in_both)) return fail(LM_ERR_INVALID, "null argument");
+    int rc;
+    if ((rc = colour_check_enqueue(d, slot_of, one_slot, lower_hsv, upper_hsv, matches, n))) return rc;
+    if (!d->cc_inflight) return LM_OK;       // n == 0
+    return colour_check_finish(d, in_hull, in_both);
+}
+
 int lm_color_check_counts(lm_detector* d, int slot, const double lower_hsv[3], const double upper_hsv[3],
                           const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both) {
     return colour_check(d, nullptr, slot, lower_hsv, upper_hsv, matches, n, in_hull, in_both);
+}
+
+int lm_color_check_begin_slots(lm_detector* d, const int32_t* slot_of_match, const double lower_hsv[3], const double upper_hsv[3],
+                               const lm_match_t* matches, size_t n) {
+    if (n && !slot_of_match) return fail(LM_ERR_INVALID, "null argument");
+    if (n == 0) { if (d) { if (d->cc_inflight) return fail(LM_ERR_INVALID, "a colour check is in flight: call lm_color_check_end first"); d->cc_inflight = true; d->cc_pending = 0; } return d ? LM_OK : fail(LM_ERR_INVALID, "null detector"); }
+    return colour_check_enqueue(d, slot_of_match, 0, lower_hsv, upper_hsv, matches, n);
+}
+
+int lm_color_check_end(lm_detector* d, int64_t* in_hull, int64_t* in_both) {
+    if (d && d->cc_inflight && d->cc_pending == 0) { d->cc_inflight = false; return LM_OK; }     // an empty list was begun: nothing was enqueued
+    return colour_check_finish(d, in_hull, in_both);
 }
 
 int lm_color_check_counts_slots(lm_detector* d, const int32_t* slot_of_match, const double lower_hsv[3], const double upper_hsv[3],

@@ -489,30 +489,54 @@ PostProcessor::Prepared PostProcessor::prepare(const std::vector<lm_match_t>& ma
     return p;
 }
 
-// :165-174, applyPostProcessing (:382-421) for one group
+// ---- :165-174, applyPostProcessing (:382-421) for one group, in pieces (r05) -----------------------------------------------------------
+// The reference walks a group's matches in order: colour check && depth check -> pose, until numberWantedPoses poses are collected.  The
+// two checks of a match are pure functions of the frame, so they may be evaluated ahead of the walk (in parallel, on any thread); the
+// walk itself -- which verdicts COUNT -- stays sequential: accept_range.  finish_group = one match at a time, nothing evaluated in vain.
+bool PostProcessor::colour_ok(const Prepared& p, uint32_t idx, const lm_match_t& m) const {
+    return p.gpu ? color_verdict((long)p.gin[p.gpos[idx]], (long)p.gboth[p.gpos[idx]], st.percentToPassCheck) : color_check(m, p.color_mask);
+}
+
+void PostProcessor::depth_part(const lm_match_t& m, const uint16_t* depth_rows, const std::vector<TemplatePose>& templates, MatchVerdict& v, Times* tm) const {
+    using clk = std::chrono::steady_clock;
+    v.depth_done = true; v.depth_ok = true;
+    if ((size_t)m.template_id >= templates.size()) return;
+    v.tempDepth = (int32_t)templates[(size_t)m.template_id].translation[2];
+    if (!depth_rows) return;
+    const clk::time_point t_d = clk::now();
+    bool early = false;
+    v.depth_ok = depth_check(m, depth_rows, templates, &v.tempDepth, &early);
+    if (tm) { tm->depth += std::chrono::duration<double>(clk::now() - t_d).count(); tm->depth_checks += 1; tm->depth_decided_early += early ? 1 : 0; }
+}
+
+bool PostProcessor::accept_range(const Prepared& p, size_t group, const std::vector<lm_match_t>& matches, const std::vector<TemplatePose>& templates,
+                                 size_t from, size_t to, const MatchVerdict* v, std::vector<ObjectPose>& objPoses, Times* tm) const {
+    using clk = std::chrono::steady_clock;
+    const std::vector<uint32_t>& idxs = p.groups[group].matchIndices;
+    for (size_t k = from; k < to && k < idxs.size(); ++k) {
+        const lm_match_t& m = matches[idxs[k]];
+        if ((size_t)m.template_id >= templates.size()) continue;
+        if (v[k - from].colour_ok && v[k - from].depth_ok) {                        // (a depth verdict evaluated ahead of a failed colour check is simply not looked at)
+            const clk::time_point t_p = clk::now();
+            objPoses.push_back(make_pose(m, templates, v[k - from].tempDepth));
+            if (tm) { tm->pose += std::chrono::duration<double>(clk::now() - t_p).count(); tm->poses += 1; }
+        }
+        if (objPoses.size() == st.numberWantedPoses) return true;
+    }
+    return false;
+}
+
 std::vector<ObjectPose> PostProcessor::finish_group(const Prepared& p, size_t group, const std::vector<lm_match_t>& matches, const uint16_t* depth_rows,
                                                     const std::vector<TemplatePose>& templates, Times* tm) const {
-    using clk = std::chrono::steady_clock;
-    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     std::vector<ObjectPose> objPoses;
-    for (uint32_t idx : p.groups[group].matchIndices) {
-        const lm_match_t& m = matches[idx];
+    const std::vector<uint32_t>& idxs = p.groups[group].matchIndices;
+    for (size_t k = 0; k < idxs.size(); ++k) {
+        const lm_match_t& m = matches[idxs[k]];
         if ((size_t)m.template_id >= templates.size()) continue;
-        int32_t tempDepth = (int32_t)templates[(size_t)m.template_id].translation[2];
-        bool ok = p.gpu ? color_verdict((long)p.gin[p.gpos[idx]], (long)p.gboth[p.gpos[idx]], st.percentToPassCheck)
-                        : color_check(m, p.color_mask);
-        if (ok && depth_rows) {                                                       // && short-circuit like the reference
-            const clk::time_point t_d = clk::now();
-            bool early = false;
-            ok = depth_check(m, depth_rows, templates, &tempDepth, &early);
-            if (tm) { tm->depth += secs(t_d, clk::now()); tm->depth_checks += 1; tm->depth_decided_early += early ? 1 : 0; }
-        }
-        if (ok) {
-            const clk::time_point t_p = clk::now();
-            objPoses.push_back(make_pose(m, templates, tempDepth));
-            if (tm) { tm->pose += secs(t_p, clk::now()); tm->poses += 1; }
-        }
-        if (objPoses.size() == st.numberWantedPoses) break;
+        MatchVerdict v;
+        v.colour_ok = colour_ok(p, idxs[k], m);
+        if (v.colour_ok) depth_part(m, depth_rows, templates, v, tm);                 // && short-circuit like the reference
+        if (accept_range(p, group, matches, templates, k, k + 1, &v, objPoses, tm)) break;
     }
     return objPoses;
 }

@@ -130,6 +130,16 @@ public:
     }
     std::vector<ObjectPose> finish_group(const Prepared& p, size_t group, const std::vector<lm_match_t>& matches, const uint16_t* dense_depth,
                                          const std::vector<TemplatePose>& templates, Times* tm) const;
+    // finish_group in pieces (r05): a match's two checks are pure functions of the frame and may be evaluated ahead of the sequential
+    // walk, which alone decides which verdicts count (HighLevelLineMOD's streamed post-processing evaluates a group's depth checks in
+    // growing waves on the pool).  colour_ok = the lookup of the GPU counts (or the host check); depth_part = the depth check (:437-457);
+    // accept_range = the reference's walk over matches [from, to) of the group (v[k - from] = verdict of the k-th), true = the group has
+    // its numberWantedPoses poses.  finish_group = these three, one match at a time.
+    struct MatchVerdict { bool colour_ok = false, depth_done = false, depth_ok = true; int32_t tempDepth = 0; };
+    bool colour_ok(const Prepared& p, uint32_t idx, const lm_match_t& m) const;
+    void depth_part(const lm_match_t& m, const uint16_t* dense_depth, const std::vector<TemplatePose>& templates, MatchVerdict& v, Times* tm) const;
+    bool accept_range(const Prepared& p, size_t group, const std::vector<lm_match_t>& matches, const std::vector<TemplatePose>& templates,
+                      size_t from, size_t to, const MatchVerdict* v, std::vector<ObjectPose>& objPoses, Times* tm) const;
     // the two counts of colorCheck for one match, on the host (also the checker of the GPU path)
     bool color_counts(const lm_match_t& m, const std::vector<uint8_t>& color_mask, long* in_hull, long* in_both) const;
     const std::string& lastError() const { return error; }

@@ -383,7 +383,11 @@ void orc_depth_quantize(const uint16_t* depth, int w, int h, int distance_thresh
             }
             raw[(size_t)y * w + x] = out;
         }
-    // medianBlur(dst, dst, 5): BORDER_REPLICATE
+    orc_median5_u8(raw.data(), w, h, quantized);
+}
+
+// medianBlur(src, dst, 5) on CV_8UC1: BORDER_REPLICATE (exported on its own for tests/test_oracle_independent.py)
+void orc_median5_u8(const uint8_t* raw, int w, int h, uint8_t* quantized) {
     ORC_PAR_FOR
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
@@ -1066,4 +1070,20 @@ extern "C" int orc_add_template(orc_detector* d, const char* class_id, const uin
     if (ci < 0) { d->classes.push_back(ClassEntry{class_id, {}}); ci = (int)d->classes.size() - 1; }
     d->classes[ci].pyramids.push_back(std::move(tp));
     return (int)d->classes[ci].pyramids.size() - 1;
+}
+
+// ---- the two image primitives of extractTemplate on their own (tests/test_oracle_independent.py checks them, like the ones above,
+// against scipy.ndimage -- an implementation this file's author did not write)
+extern "C" {
+void orc_erode3_u8(const uint8_t* src, int w, int h, int iters, uint8_t* dst) {
+    std::vector<u8> m(src, src + (size_t)w * h);
+    erode3(m, w, h, iters);
+    std::memcpy(dst, m.data(), m.size());
+}
+void orc_dist_c(const uint8_t* src, int w, int h, float* dst) {
+    std::vector<u8> m(src, src + (size_t)w * h);
+    std::vector<float> o;
+    dist_c(m, w, h, o);
+    std::memcpy(dst, o.data(), o.size() * sizeof(float));
+}
 }

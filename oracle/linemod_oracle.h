@@ -75,6 +75,9 @@ void orc_orientation_labels_variant(const int32_t* dx, const int32_t* dy, size_t
 void orc_pyrdown_u8c3(const uint8_t* src, int w, int h, uint8_t* dst);                         /* a4 cv::pyrDown             */
 void orc_depth_quantize(const uint16_t* depth, int w, int h, int distance_threshold,
                         int difference_threshold, const uint8_t* normal_lut, uint8_t* quantized); /* a5 quantizedNormals  */
+void orc_median5_u8(const uint8_t* src, int w, int h, uint8_t* dst);                            /* a5 medianBlur(.., 5), BORDER_REPLICATE */
+void orc_erode3_u8(const uint8_t* src, int w, int h, int iters, uint8_t* dst);                  /* extractTemplate: erode 3x3 */
+void orc_dist_c(const uint8_t* src, int w, int h, float* dst);                                  /* extractTemplate: distanceTransform(DIST_C, 3) */
 void orc_resize_nn_half(const uint8_t* src, int w, int h, uint8_t* dst);                       /* a6 NN resize               */
 void orc_spread(const uint8_t* src, int w, int h, int T, uint8_t* dst);                        /* a8 spread                  */
 void orc_response_maps(const uint8_t* spread, int n, const uint8_t* lut, uint8_t* maps);       /* a9 computeResponseMaps     */

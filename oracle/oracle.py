@@ -52,7 +52,9 @@ def build(force=False, arch=None, out=None):
         override = os.environ.get("LINEMOD_ORACLE_LIB")      # e.g. the sanitizer build (make -C oracle asan) in tests/test_sanitize.py
         if override:
             return override
-        if force or not os.path.exists(_LIB_PATH):
+        src_newer = os.path.exists(_LIB_PATH) and any(os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+                                                       for f in ("linemod_oracle.cpp", "linemod_oracle.h"))
+        if force or src_newer or not os.path.exists(_LIB_PATH):     # (an edited source must not meet a stale library)
             subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
         return _LIB_PATH
     out = out or os.path.join(_HERE, "_build", "liblinemod_oracle_native.so")
@@ -206,6 +208,23 @@ def depth_quantize(depth, distance_threshold=2000, difference_threshold=50, lut=
     out = np.empty((h, w), np.uint8)
     lib.orc_depth_quantize(_ptr(depth), w, h, distance_threshold, difference_threshold, _ptr(lut), _ptr(out))
     return out
+
+
+def median5(img):
+    """medianBlur(img, 5) on 8-bit, BORDER_REPLICATE (the tail of DepthNormal's quantizedNormals)."""
+    lib = load(); img = _c(img, np.uint8); h, w = img.shape
+    out = np.empty((h, w), np.uint8); lib.orc_median5_u8(_ptr(img), w, h, _ptr(out)); return out
+
+
+def erode3(mask, iters=1):
+    lib = load(); mask = _c(mask, np.uint8); h, w = mask.shape
+    out = np.empty((h, w), np.uint8); lib.orc_erode3_u8(_ptr(mask), w, h, int(iters), _ptr(out)); return out
+
+
+def dist_c(src):
+    """distanceTransform(src, DIST_C, 3): chessboard distance to the nearest zero pixel."""
+    lib = load(); src = _c(src, np.uint8); h, w = src.shape
+    out = np.empty((h, w), np.float32); lib.orc_dist_c(_ptr(src), w, h, _ptr(out)); return out
 
 
 def resize_nn_half(img):
