@@ -23,6 +23,11 @@
 #include "lm_median25.h"
 
 namespace {
+// r05 timing experiments (WRONG RESULTS, never set outside tools/ab_refine_tiles.sh): bit 0 = k_refine reads its 16 x 16 patch as if the
+// spread memory were tiled 8 rows x 16 columns per 128-B line (about 4 lines per patch instead of 16-17): the upper bound of what the
+// tiled layout could save; bit 1 = k_refine without its exact pruning (so that two runs with different sums do the same work);
+// bit 2 = k_lm_spread5 stores its 8-byte pieces where the tiled layout would put them (the producer's side of the same layout).
+__device__ int g_lm_experiment = 0;
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(1))) U32x4U { u32x4 v; };
@@ -2330,6 +2335,8 @@ __device__ __forceinline__ void d_lm_spread5(const u32 vblock, const u8* __restr
 #pragma unroll
         for (int d = 0; d < 11; ++d) V[d] = Hr[j][d] | Hr[j + 1][d] | Hr[j + 2][d] | Hr[j + 3][d] | Hr[j + 4][d];
         u8* dst = lm + (size_t)(j * 5) * wh + (size_t)band * W + 8 * g;
+        if (g_lm_experiment & 4)     // (timing experiment) tile (band / 8, g / 2) of 128 B, row band % 8, half g % 2
+            dst = lm + (size_t)(j * 5) * wh + ((size_t)(band >> 3) * (size_t)(W >> 4) + (size_t)(g >> 1)) * 128 + (size_t)(band & 7) * 16 + (size_t)(g & 1) * 8;
 #pragma unroll
         for (int c0 = 0; c0 < 5; ++c0)
             *reinterpret_cast<u32x2*>(dst + (size_t)c0 * wh) = u32x2{gather4_stride5(V, c0), gather4_stride5(V, c0 + 20)};
@@ -2961,7 +2968,8 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
     const int T = a.g.T, W = a.g.W;
     const int border = 8 * T;
     const int offset = T / 2 + (T % 2 - 1);
-    const u32 lane_off = (u32)((lane >> 2) * W + (lane & 3) * 4);
+    const int ex = g_lm_experiment;
+    const u32 lane_off = (ex & 1) ? (u32)(((lane >> 5) * 8 * W) + ((lane >> 2) & 7) * 16 + (lane & 3) * 4) : (u32)((lane >> 2) * W + (lane & 3) * 4);
     LmCand c = cand[i];
     u32 ti = (u32)__builtin_amdgcn_readfirstlane((int)c.ti);
     if (ti == LM_DROPPED) return;
@@ -3003,7 +3011,7 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
 #pragma unroll
             for (int k = 0; k < 8; ++k) { s01 += q01[k]; s23 += q23[k]; }
             f_left -= min(8, cnt - f);
-            if (PRUNE_REFINE && (f & 8) && f_left > 0) {       // every second batch of eight
+            if (PRUNE_REFINE && !(ex & 2) && (f & 8) && f_left > 0) {       // every second batch of eight
                 const u32 mx = pk_max_u16(s01, s23);
                 const u32 best_now = wave_max_u32(max(mx & 0xFFFFu, mx >> 16));
                 const float reach = __fdiv_rn(__fmul_rn((float)(int)(best_now + 4u * (u32)f_left), 100.f), denom);
@@ -3064,7 +3072,7 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
     const int T = a.g.T, W = a.g.W;
     const int border = 8 * T;
     const int offset = T / 2 + (T % 2 - 1);
-    const u32 lane_off = (u32)((lane >> 2) * W + (lane & 3) * 4);
+    const u32 lane_off = (g_lm_experiment & 1) ? (u32)(((lane >> 5) * 8 * W) + ((lane >> 2) & 7) * 16 + (lane & 3) * 4) : (u32)((lane >> 2) * W + (lane & 3) * 4);
     const u32 ti = tiA;
     const LmRefMeta mt = a.meta[ti];
     const int max_x = a.g.w - mt.width - border, max_y = a.g.h - mt.height - border;
@@ -4092,6 +4100,7 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
 #undef SCAN_LAUNCH
 }
 
+void lmk_set_experiment(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lm_experiment), &v, sizeof(v)); }
 void lmk_refine_plan(hipStream_t s, const LmRefineArgs& a, int nslots, u32* plan, int plan_cap) {
     hipLaunchKernelGGL(k_refine_plan, dim3(1), dim3(1024), 0, s, a.hdr, a.aux_slot_stride, nslots, a.cand_cap, plan_cap, plan);
 }
