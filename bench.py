@@ -416,6 +416,8 @@ def main():
     ap.add_argument("--no-work-weight", action="store_true", help="A/B knob: few-frame / batch kernel selection by frame count alone (LM_TUNE_WORK_WEIGHT = 0, r03)")
     ap.add_argument("--no-pose-e2e", action="store_true", help="config 5: skip the pose_e2e leg (PoseDetection::detectBatch end to end, tools/pose_e2e_bench.cpp)")
     ap.add_argument("--pose-e2e-iters", type=int, default=20)
+    ap.add_argument("--no-latency", action="store_true", help="skip the `latency` block (one 640x480 colour-only frame per call against 1950 templates: the reference's call pattern)")
+    ap.add_argument("--latency-calls", type=int, default=300)
     ap.add_argument("--pose-e2e-threads", type=int, default=0, help="pose_e2e leg: host threads of the facade's pool (0 = one per usable CPU, at most 32)")
     ap.add_argument("--pose-e2e-wrap", default="", help="pose_e2e leg: command prefix for the child process (e.g. a rocprofv3 trace command ending in --)")
     ap.add_argument("--pose-e2e-host-colour", action="store_true", help="pose_e2e leg: also time the colour check on the host (one full-frame mask per match)")
@@ -658,6 +660,9 @@ def main():
             h2d = runner.streaming(max(args.steps // 4, 8))
         except Exception as e:                          # the bench line must still be printed
             h2d = {"error": "%s: %s" % (type(e).__name__, e)}
+    lat = None
+    if rank == 0 and world == 1 and not args.no_latency:
+        lat = latency(args, lm)
     pose = None
     if rank == 0 and world == 1 and CONFIGS[args.config].get("classes") and not args.no_pose_e2e:
         pose = pose_e2e(args, runner, lm, 1e6 / fps)
@@ -696,6 +701,8 @@ def main():
             "roofline": roofline,
             "roofline_refine": roofline_refine,
             "roofline_preprocess": roofline_pre,
+            "roofline_pipeline": pipeline_roofline(ctr, ctr_reason, NL, dt / args.steps * 1e3, B, Bl),
+            "latency": lat,
             "pose_e2e": pose,
             "counters_meta": cmeta,
             "cpu_baseline": cpu,
@@ -899,6 +906,97 @@ def pose_e2e(args, runner, lm, hot_path_us_per_frame_resident):
         return res
     except Exception as e:  # the bench line must still be printed
         return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def latency(args, lm):
+    """The reference's own call pattern (VERDICT r4 #5b): ONE 640 x 480 frame per detect() (detector.cpp:17-45), the shipped
+    colour-only modality and bank size (linemod_settings.yml:20-27: 13 viewpoints x 15 radii x 10 in-plane rotations = 1 950
+    templates), one lm_match per frame -- resident frame (lm_match_slot), frame in pinned host memory, frame in pageable memory.
+    Median and 95th percentile of `--latency-calls` calls each, a different frame every call."""
+    import time
+    W, H, NT = 640, 480, 1950
+    try:
+        synth = importlib.import_module("line-mod-pipeline_amd.synth")
+        d = lm.Detector(lm.default_config(color_only=True, width=W, height=H, frame_slots=8))
+        frames = [synth.make_frame(W, H, seed=1234 + i) for i in range(8)]
+        q = quantized_from_gpu(d, frames[0][0], None, 1)
+        descs, feats, _ = synth.make_bank(NT, 1, 2, seed=4321, quantized=q, crop_fraction=0.1, frame_size=(W, H), T0=d.get_T(0))
+        d.add_class("lagergehaeuse.ply", descs, feats)
+        out = np.zeros(1 << 16, lm.MATCH_DTYPE)
+        for i in range(8):
+            d.upload_frame(i, frames[i][0], None)
+        pb = lm.PinnedBuffer(8 * W * H * 3)
+        pf = [pb.view(np.uint8, (H, W, 3), offset=k * W * H * 3) for k in range(8)]
+        for k in range(8):
+            pf[k][...] = frames[k][0]
+        n = max(int(args.latency_calls), 20)
+
+        def timed(fn):
+            for k in range(20):
+                fn(k)
+            ts = np.empty(n)
+            for k in range(n):
+                t = time.perf_counter()
+                fn(k)
+                ts[k] = time.perf_counter() - t
+            return {"median_us": round(float(np.median(ts)) * 1e6, 1), "p95_us": round(float(np.percentile(ts, 95)) * 1e6, 1), "min_us": round(float(ts.min()) * 1e6, 1)}
+        lists = [len(d.match_slot(k, args.threshold, 0, out=out)) for k in range(8)]
+        res = {"resident_frame": timed(lambda k: d.match_slot(k % 8, args.threshold, 0, out=out)),
+               "pinned_host_frame": timed(lambda k: d.match(pf[k % 8], None, args.threshold, 0, out=out)),
+               "pageable_host_frame": timed(lambda k: d.match(frames[k % 8][0], None, args.threshold, 0, out=out))}
+        # where a resident frame's time goes: HIP-event spans of the four stages (same call, profiling on)
+        d.set_profiling(True)
+        for k in range(50):
+            d.match_slot(k % 8, args.threshold, 0, out=out)
+        prof = d.get_profile()
+        d.set_profiling(False)
+        pb.close([d])
+        d.close()
+        res.update({"calls": n, "workload": "one 640x480 frame per call, ColorGradient only (T = {2, 8}), %d templates of variable geometry, threshold %g" % (NT, args.threshold),
+                    "matches_per_frame": lists,
+                    "gpu_stage_us_resident": dict(zip(["preprocess", "scan", "refine", "sort"], [round(v / max(prof["launches"], 1), 1) for v in prof["stage_us"]])),
+                    "note": "wall time of ONE synchronous call on one host thread (time.perf_counter around lm_match_slot / lm_match through ctypes, caller-owned result "
+                            "buffer): the reference's loop (detector.cpp:17-45 -> PoseDetection::detect -> HighLevelLineMOD::detectTemplate -> Detector::match) with the "
+                            "shipped settings (linemod_settings.yml:20-27).  Few frames take the latency launch shape: the pre-processing as one launch per dependency "
+                            "level (k_phase), copies inline on the compute stream.  gpu_stage_us_resident = HIP-event spans inside the resident-frame call; the rest of "
+                            "its wall time is launch + synchronisation overhead of the host (about 12 launches per call)"})
+        return res
+    except Exception as e:  # the bench line must still be printed
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def pipeline_roofline(ctr, reason, NL, ms_per_step, frames_per_step, Bl):
+    """The whole step against the vector-issue roof (VERDICT r4 #5a): the hot kernels sit within 30 % of the L2 AND the VALU roofs, and
+    what bounds the three-lane step is the vector ALU -- VALU-active cycles of every kernel of a lane-step (SQ_ACTIVE_INST_VALU x 4 from
+    the committed counter file of this command) x lanes, over the SIMD cycles the step lasts."""
+    if not ctr:
+        return {"frac": None, "reason": reason}
+    ks = ctr["kernels"]
+    clock_ghz = None
+    for k, v in ks.items():
+        if k.startswith("k_scan") and v.get("GRBM_GUI_ACTIVE") and v.get("avg_us"):
+            inst = max(v.get("GRBM_GUI_ACTIVE_instances", 1), 1)
+            clock_ghz = v["GRBM_GUI_ACTIVE"] / (8.0 if inst == 1 else inst) / v["avg_us"] / 1e3
+    calls = [v["calls"] for k, v in ks.items() if k.startswith("k_scan") and "calls" in v]
+    steps = max(calls) if calls else 1
+    if not clock_ghz:
+        return {"frac": None, "reason": "no shader clock in the counter file"}
+    active = insts = 0.0
+    for k, v in ks.items():
+        if k.startswith("__amd") or "SQ_ACTIVE_INST_VALU" not in v or v.get("calls", 0) < 8:
+            continue
+        per_step = v["calls"] / steps
+        active += v["SQ_ACTIVE_INST_VALU"] * 4.0 * per_step
+        insts += v.get("SQ_INSTS_VALU", 0.0) * per_step
+    lane_steps = frames_per_step / float(Bl)
+    cycles = ms_per_step * 1e-3 * clock_ghz * 1e9 * N_SIMD
+    return {"bound": "valu", "frac": round(active * lane_steps / cycles, 4), "valu_wave_insts_per_lane_step": round(insts),
+            "valu_active_simd_cycles_per_lane_step": round(active), "cycles_per_valu_inst": round(active / insts, 2) if insts else None,
+            "lane_steps_per_step": lane_steps, "shader_clock_GHz_under_load": round(clock_ghz, 3), "simds": N_SIMD, "source": ctr["source"],
+            "note": "sum over the kernels of one lane-step (counter file of this command, one lane, %d frames per launch) of SQ_ACTIVE_INST_VALU x 4 = SIMD cycles "
+                    "in which a vector instruction executes, x the lane-steps of a step, over (1024 SIMDs x shader clock x ms_per_step): how much of the chip's vector "
+                    "issue time the timed step uses.  Perfect overlap of the lanes would reach 1.0; what is left is launch boundaries, tails and the kernels "
+                    "that wait for memory" % Bl}
 
 
 def kernel_source_sha16():

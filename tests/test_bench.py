@@ -9,7 +9,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--steps", "6", "--warmup", "2", "--batch", "16", "--lanes", "2", "--templates", "300", "--no-cpu-baseline"]
+SMALL = ["--steps", "6", "--warmup", "2", "--batch", "16", "--lanes", "2", "--templates", "300", "--no-cpu-baseline", "--latency-calls", "40"]
 
 
 def _json_line(out):
@@ -34,6 +34,14 @@ def test_bench_one_gpu_line():
     assert h["value"] > 0 and h["h2d_GBps"] > 0 and h["matches_step0_step1"][0] > 0
     # the streaming leg matches different frames per slot every step
     assert d["config"]["baseline_config"] == 2
+    # r05: the reference's own call pattern in the line (one 640x480 colour-only frame per call, 1950 templates) and the step's vector-issue roof
+    lat = d["latency"]
+    assert "error" not in lat, lat
+    for leg in ("resident_frame", "pinned_host_frame", "pageable_host_frame"):
+        assert 0 < lat[leg]["min_us"] <= lat[leg]["median_us"] <= lat[leg]["p95_us"] < 20000, lat
+    assert lat["resident_frame"]["median_us"] <= lat["pageable_host_frame"]["median_us"]
+    assert sum(lat["gpu_stage_us_resident"].values()) <= lat["resident_frame"]["median_us"] * 1.2
+    assert "roofline_pipeline" in d and ("frac" in d["roofline_pipeline"])       # None + reason when no counter file matches this (small) command
 
 
 @pytest.mark.gpu
