@@ -294,7 +294,6 @@ int ensure_device(lm_detector* d) {
     HIP_TRY(hipMemset(d->d_scan_stat, 0, 4096 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_sim_lut), 256));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_normal_lut), 2 * 8000 + 16));    // the table, then its labels as rank codes (LMK_NORMAL_CODE_OFFSET) + a zero entry for indices outside the table
-    if (const char* ex = std::getenv("LM_EXPERIMENT")) lmk_set_experiment(std::atoi(ex));     // timing experiments with wrong results (tools/ only)
     HIP_TRY(hipDeviceSynchronize());
     d->dev_ready = true;
     d->luts_dirty = true;

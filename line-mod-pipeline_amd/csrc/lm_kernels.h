@@ -162,7 +162,6 @@ void lmk_set_dmedian_variant(int v);
 // correctly rounded ones (device counters, zeroed by the caller)
 void lmk_selftest_float_tail(hipStream_t s, unsigned long long* out2);
 int lmk_level_pairs();
-void lmk_set_experiment(int v);   // r05 timing experiments with WRONG results (lm_kernels.hip g_lm_experiment); env LM_EXPERIMENT at device set-up
 
 struct LmHullArgs {
     const LmOutMatch* matches; u32 n;

@@ -23,11 +23,6 @@
 #include "lm_median25.h"
 
 namespace {
-// r05 timing experiments (WRONG RESULTS, never set outside tools/ab_refine_tiles.sh): bit 0 = k_refine reads its 16 x 16 patch as if the
-// spread memory were tiled 8 rows x 16 columns per 128-B line (about 4 lines per patch instead of 16-17): the upper bound of what the
-// tiled layout could save; bit 1 = k_refine without its exact pruning (so that two runs with different sums do the same work);
-// bit 2 = k_lm_spread5 stores its 8-byte pieces where the tiled layout would put them (the producer's side of the same layout).
-__device__ int g_lm_experiment = 0;
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(1))) U32x4U { u32x4 v; };
@@ -1703,6 +1698,40 @@ __device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool o
     return ok ? ecode : 0u;
 }
 
+// The same tail for the TWO pixels of a packed pair at once (r05): gfx950 multiplies, adds and fuses FP32 pairwise (v_pk_mul_f32, v_pk_add_f32,
+// v_pk_fma_f32 -- IEEE results, lane for lane the scalar instructions'), so the 20 multiply / add / fma of a pixel's tail become 10 per
+// pixel; conversions, v_rsq / v_rcp, the index arithmetic and the table read stay per pixel.  Same operation order, same roundings as
+// dn_label (-ffp-contract=off: nothing is fused that the scalar form does not fuse): bit-identical labels (tests/test_gpu_stages.py).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool SMALL>
+__device__ __forceinline__ void dn_label2(int det0, int ddx0, int ddy0, int d0, bool ok0, int det1, int ddx1, int ddy1, int d1, bool ok1,
+                                          const u8* __restrict__ lut, u32& e0, u32& e1) {
+    // QUOT form only (the packed-taps path): det / 625, ddx / 125, ddy / 125 come in
+    det0 = mul_i24(det0, 625); det1 = mul_i24(det1, 625);
+    if (!SMALL) { ddx0 = mul_i24(ddx0, 125); ddy0 = mul_i24(ddy0, 125); ddx1 = mul_i24(ddx1, 125); ddy1 = mul_i24(ddy1, 125); }
+    f32x2 nx, ny, nz;
+    nx[0] = SMALL ? (float)mul_i24(ddx0, 143750) : (float)((double)ddx0 * 1150.0);
+    nx[1] = SMALL ? (float)mul_i24(ddx1, 143750) : (float)((double)ddx1 * 1150.0);
+    ny[0] = SMALL ? (float)mul_i24(ddy0, 143750) : (float)((double)ddy0 * 1150.0);
+    ny[1] = SMALL ? (float)mul_i24(ddy1, 143750) : (float)((double)ddy1 * 1150.0);
+    nz[0] = (float)(-mul_i24(det0, d0)); nz[1] = (float)(-mul_i24(det1, d1));
+    const f32x2 sq = (nx * nx + ny * ny) + nz * nz;
+    // dn_sqrt5, pairwise: g = x y, h = y / 2, g + (x - g g) h
+    f32x2 y; y[0] = __builtin_amdgcn_rsqf(sq[0]); y[1] = __builtin_amdgcn_rsqf(sq[1]);
+    const f32x2 g = sq * y, hf = y * 0.5f;
+    const f32x2 len0 = __builtin_elementwise_fma(__builtin_elementwise_fma(-g, g, sq), hf, g);
+    f32x2 len; len[0] = len0[0] > 0.0f ? len0[0] : 1.0f; len[1] = len0[1] > 0.0f ? len0[1] : 1.0f;     // (zero-length normal: see dn_label)
+    // dn_rcp3, pairwise
+    f32x2 r0; r0[0] = __builtin_amdgcn_rcpf(len[0]); r0[1] = __builtin_amdgcn_rcpf(len[1]);
+    const f32x2 inv = __builtin_elementwise_fma(__builtin_elementwise_fma(-len, r0, (f32x2)(1.0f)), r0, r0);
+    nx = nx * inv; ny = ny * inv; nz = nz * inv;
+    const f32x2 t1 = nx * 10.f + 10.f, t2 = ny * 10.f + 10.f, t3 = nz * 20.f + 20.f;
+    const u32 flat0 = (u32)mad_i24((int)t3[0], 400, mad_i24((int)t2[0], 20, (int)t1[0]));
+    const u32 flat1 = (u32)mad_i24((int)t3[1], 400, mad_i24((int)t2[1], 20, (int)t1[1]));
+    const u32 c0 = lut[LMK_NORMAL_CODE_OFFSET + min(flat0, 8000u)], c1 = lut[LMK_NORMAL_CODE_OFFSET + min(flat1, 8000u)];
+    e0 = ok0 ? c0 : 0u; e1 = ok1 ? c1 : 0u;
+}
+
 // every float of the tail's domain through dn_rcp / dn_sqrt and through the compiler's correctly rounded forms;
 // out[2]: the bare v_sqrt_f32 against the same reference (information: how often the 1-ulp instruction is off)
 __global__ __launch_bounds__(256) void k_selftest_float_tail(unsigned long long* __restrict__ out) {
@@ -1795,24 +1824,14 @@ __device__ __forceinline__ void d_dnormal_t(const u32 vblock, const u16* __restr
                 const u32 sx = pk_add_i16(pk_add_i16(pk_sub_i16(G[1][2], G[1][0]), ga), gb);   // sum of ii * gated delta
                 const u32 sy = pk_sub_i16(pk_add_i16(pk_sub_i16(G[2][1], G[0][1]), ga), gb);   // sum of jj * gated delta
                 const u32 ncx = pk_sub_i16(0u, cx);
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int p = 2 * k + hh;
-                    const int d = hh ? (int)(C >> 16) : (int)(C & 0xFFFFu);
-                    const bool valid = d < dist_thr;         // (columns x < 5 and x >= w - 6: xmask below)
-                    int detq, ddxq, ddyq;                    // det / 625, ddx / 125, ddy / 125 of the per-pixel loop
-                    if (hh) {
-                        detq = mad_i16h<true>(ci, cj, mad_i16h<true>(ncx, cx, 0));
-                        ddxq = mad_i16h<true>(cj, sx, mad_i16h<true>(ncx, sy, 0));
-                        ddyq = mad_i16h<true>(ci, sy, mad_i16h<true>(ncx, sx, 0));
-                    } else {
-                        detq = mad_i16h<false>(ci, cj, mad_i16h<false>(ncx, cx, 0));
-                        ddxq = mad_i16h<false>(cj, sx, mad_i16h<false>(ncx, sy, 0));
-                        ddyq = mad_i16h<false>(ci, sy, mad_i16h<false>(ncx, sx, 0));
-                    }
-                    const u32 e = dn_label<SMALL, true>(detq, ddxq, ddyq, d, valid, lut);
-                    out[p >> 2] |= e << (8 * (p & 3));
-                }
+                // det / 625, ddx / 125, ddy / 125 of the per-pixel loop, for the low and the high pixel of the pair; then the float tail of both at once
+                const int d0 = (int)(C & 0xFFFFu), d1 = (int)(C >> 16);
+                const int detq0 = mad_i16h<false>(ci, cj, mad_i16h<false>(ncx, cx, 0)), detq1 = mad_i16h<true>(ci, cj, mad_i16h<true>(ncx, cx, 0));
+                const int ddxq0 = mad_i16h<false>(cj, sx, mad_i16h<false>(ncx, sy, 0)), ddxq1 = mad_i16h<true>(cj, sx, mad_i16h<true>(ncx, sy, 0));
+                const int ddyq0 = mad_i16h<false>(ci, sy, mad_i16h<false>(ncx, sx, 0)), ddyq1 = mad_i16h<true>(ci, sy, mad_i16h<true>(ncx, sx, 0));
+                u32 e0, e1;                                  // (valid = d < dist_thr; columns x < 5 and x >= w - 6: xmask below)
+                dn_label2<SMALL>(detq0, ddxq0, ddyq0, d0, d0 < dist_thr, detq1, ddxq1, ddyq1, d1, d1 < dist_thr, lut, e0, e1);
+                out[k >> 1] |= (e0 | (e1 << 8)) << (16 * (k & 1));
             }
         } else {
 #pragma unroll
@@ -2335,8 +2354,6 @@ __device__ __forceinline__ void d_lm_spread5(const u32 vblock, const u8* __restr
 #pragma unroll
         for (int d = 0; d < 11; ++d) V[d] = Hr[j][d] | Hr[j + 1][d] | Hr[j + 2][d] | Hr[j + 3][d] | Hr[j + 4][d];
         u8* dst = lm + (size_t)(j * 5) * wh + (size_t)band * W + 8 * g;
-        if (g_lm_experiment & 4)     // (timing experiment) tile (band / 8, g / 2) of 128 B, row band % 8, half g % 2
-            dst = lm + (size_t)(j * 5) * wh + ((size_t)(band >> 3) * (size_t)(W >> 4) + (size_t)(g >> 1)) * 128 + (size_t)(band & 7) * 16 + (size_t)(g & 1) * 8;
 #pragma unroll
         for (int c0 = 0; c0 < 5; ++c0)
             *reinterpret_cast<u32x2*>(dst + (size_t)c0 * wh) = u32x2{gather4_stride5(V, c0), gather4_stride5(V, c0 + 20)};
@@ -2968,8 +2985,7 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
     const int T = a.g.T, W = a.g.W;
     const int border = 8 * T;
     const int offset = T / 2 + (T % 2 - 1);
-    const int ex = g_lm_experiment;
-    const u32 lane_off = (ex & 1) ? (u32)(((lane >> 5) * 8 * W) + ((lane >> 2) & 7) * 16 + (lane & 3) * 4) : (u32)((lane >> 2) * W + (lane & 3) * 4);
+    const u32 lane_off = (u32)((lane >> 2) * W + (lane & 3) * 4);
     LmCand c = cand[i];
     u32 ti = (u32)__builtin_amdgcn_readfirstlane((int)c.ti);
     if (ti == LM_DROPPED) return;
@@ -3011,7 +3027,7 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
 #pragma unroll
             for (int k = 0; k < 8; ++k) { s01 += q01[k]; s23 += q23[k]; }
             f_left -= min(8, cnt - f);
-            if (PRUNE_REFINE && !(ex & 2) && (f & 8) && f_left > 0) {       // every second batch of eight
+            if (PRUNE_REFINE && (f & 8) && f_left > 0) {       // every second batch of eight
                 const u32 mx = pk_max_u16(s01, s23);
                 const u32 best_now = wave_max_u32(max(mx & 0xFFFFu, mx >> 16));
                 const float reach = __fdiv_rn(__fmul_rn((float)(int)(best_now + 4u * (u32)f_left), 100.f), denom);
@@ -3072,7 +3088,7 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
     const int T = a.g.T, W = a.g.W;
     const int border = 8 * T;
     const int offset = T / 2 + (T % 2 - 1);
-    const u32 lane_off = (g_lm_experiment & 1) ? (u32)(((lane >> 5) * 8 * W) + ((lane >> 2) & 7) * 16 + (lane & 3) * 4) : (u32)((lane >> 2) * W + (lane & 3) * 4);
+    const u32 lane_off = (u32)((lane >> 2) * W + (lane & 3) * 4);
     const u32 ti = tiA;
     const LmRefMeta mt = a.meta[ti];
     const int max_x = a.g.w - mt.width - border, max_y = a.g.h - mt.height - border;
@@ -4100,7 +4116,6 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
 #undef SCAN_LAUNCH
 }
 
-void lmk_set_experiment(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lm_experiment), &v, sizeof(v)); }
 void lmk_refine_plan(hipStream_t s, const LmRefineArgs& a, int nslots, u32* plan, int plan_cap) {
     hipLaunchKernelGGL(k_refine_plan, dim3(1), dim3(1024), 0, s, a.hdr, a.aux_slot_stride, nslots, a.cand_cap, plan_cap, plan);
 }

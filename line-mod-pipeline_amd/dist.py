@@ -23,6 +23,32 @@ def shard_range(n, rank, size):
     return n * rank // size, n * (rank + 1) // size
 
 
+def frame_range(n_frames, rank, size):
+    """Frame-shard (bench.py --parallelism frame-shard): every rank holds the WHOLE bank and answers the
+    frames [n*r/R, n*(r+1)/R) of a batch -- the same contiguous rule as the template shards.  Nothing is exchanged in the data
+    path; a caller that wants all lists on one rank gathers them (gather_frame_lists)."""
+    return n_frames * rank // size, n_frames * (rank + 1) // size
+
+
+def gather_frame_lists(lists, n_frames, group=None):
+    """The frame-shard counterpart of ShardGather: every rank hands in the lists of the frames it owns (frame_range order) and
+    receives the lists of all n_frames frames, in frame order -- one all_gather_object (control plane of a test / a collector
+    process; the bench's frame-shard mode exchanges nothing)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return list(lists)
+    parts = [None] * world
+    dist.all_gather_object(parts, [np.asarray(l) for l in lists], group=group)
+    out = []
+    for r in range(world):
+        f0, f1 = frame_range(n_frames, r, world)
+        if len(parts[r]) != f1 - f0:
+            raise ValueError("rank %d delivered %d lists for its %d frames" % (r, len(parts[r]), f1 - f0))
+        out.extend(parts[r])
+    return out
+
+
 class ShardGather:
     """All-gather + merge of per-shard match lists for a batch of frames.
 

@@ -69,6 +69,19 @@ def main():
     small = distmod.ShardGather(lm.merge_matches, cap=1, pack_fn=lm.pack_matches, merge_batch_fn=lm.merge_batch)
     got0 = small.gather_merge(rec0, np.array([len(m0)], np.int32))
     ok &= got0[0].tobytes() == full0.tobytes()
+    # frame-shard: every rank holds the WHOLE bank and answers only its own frames of a batch; the union of the ranks'
+    # lists, in frame order, is what one process returns for the whole batch -- and nothing but that gather crosses the ranks
+    NF = 5
+    fr = [synth.make_frame(640, 480, seed=300 + i) for i in range(NF)]
+    f0, f1 = distmod.frame_range(NF, rank, world)
+    mine = [o.match(fr[i][0], fr[i][1], thr, 0) for i in range(f0, f1)]
+    every = distmod.gather_frame_lists(mine, NF)
+    ok &= len(every) == NF and sum(len(l) for l in every) > 0
+    covered = sorted(sum([list(range(*distmod.frame_range(NF, r, world))) for r in range(world)], []))
+    ok &= covered == list(range(NF))                                        # every frame has exactly one owner
+    if rank == 0:
+        for i in range(NF):
+            ok &= every[i].tobytes() == o.match(fr[i][0], fr[i][1], thr, 0).tobytes()
     dist.barrier()
     dist.destroy_process_group()
     print("RANK %d %s" % (rank, "OK" if ok else "FAIL"), flush=True)

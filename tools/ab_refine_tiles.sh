@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the LM_EXPERIMENT switch these runs need lived in lm_kernels.hip for commit 'k_refine on a tiled spread memory: measured ...' only (git log); results: profiles/r05_ab_experiments.log section 2.
 # r05: what could the 8 x 16 tiled spread memory buy?  Timing experiments with WRONG results (LM_EXPERIMENT, lm_kernels.hip):
 #   2     k_refine without pruning, linear layout            (baseline of the consumer experiment: same work for both layouts)
 #   3     k_refine without pruning, patch read as if tiled   (about 4 lines per patch instead of 16-17; none of the extra address arithmetic)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the LM_EXPERIMENT switch these runs need lived in lm_kernels.hip for commit 'k_refine on a tiled spread memory: measured ...' only (git log); results: profiles/r05_ab_experiments.log section 2.
 # second half of tools/ab_refine_tiles.sh: the producer (k_lm_spread5 as its own launch: --no-batch-phases), 96-frame launches of config 2
 set -u
 OUT=${1:-gpurun_out/r05_refine_tiles}
