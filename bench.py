@@ -107,8 +107,6 @@ class Runner:
         for name, descs, feats in self.banks:
             det.add_class(name, descs, feats)
         self.cls = -1 if len(self.banks) > 1 else 0       # all classes of the bank = upstream's class list of all ids
-        if args.fork:
-            det.set_tuning(lm.TUNE_FORK_MAX_SLOTS, 1 << 20)
         if args.no_batch_phases:
             det.set_tuning(lm.TUNE_BATCH_PHASES, 0)
         if args.batch_phases >= 0:
@@ -121,8 +119,6 @@ class Runner:
             det.set_tuning(lm.TUNE_BLUR_PYR, 0)
         if args.blur_pyr >= 0:
             det.set_tuning(lm.TUNE_BLUR_PYR, args.blur_pyr)
-        if args.no_level_pairs:
-            det.set_tuning(lm.TUNE_LEVEL_PAIRS, 0)
         if args.blur_strip:
             det.set_tuning(lm.TUNE_BLUR_STRIP, args.blur_strip)
         if args.sort_split >= 0:
@@ -398,17 +394,13 @@ def main():
     ap.add_argument("--no-prune", action="store_true",
                     help="exhaustive similarity scan: every feature of every template at every position, even where the "
                          "threshold is already out of reach (scan variant bit 3; A/B of the exact pruning)")
-    ap.add_argument("--fork", action="store_true",
-                    help="A/B knob: run the three independent pre-processing chains of a lane-step (colour level 0 | pyrDown + "
-                         "colour level 1 | depth) on three streams joined by events (LM_TUNE_FORK_MAX_SLOTS)")
     ap.add_argument("--no-batch-phases", action="store_true",
                     help="A/B knob: one launch per pre-processing kernel (eleven per lane-step) instead of the four launches of "
                          "level-fused batch kernels (LM_TUNE_BATCH_PHASES = 0)")
     ap.add_argument("--batch-phases", type=int, default=-1, choices=(-1, 0, 1, 2), help="A/B knob: LM_TUNE_BATCH_PHASES (1: level-fused launches also beside other lanes)")
-    ap.add_argument("--cblur-variant", type=int, default=0, help="A/B knob: LM_TUNE_CBLUR_VARIANT (2: sliding window, 3: shared column sums)")
+    ap.add_argument("--cblur-variant", type=int, default=0, help="A/B knob: LM_TUNE_CBLUR_VARIANT (1: one-shot, 3: shared column sums, 4: matrix cores)")
     ap.add_argument("--pyrdown-variant", type=int, default=0, help="A/B knob: LM_TUNE_PYRDOWN_VARIANT (1: k_pyrdown8, 2: row-walking k_pyrdown16)")
     ap.add_argument("--blur-strip", type=int, default=0, choices=(0, 16, 32, 64), help="A/B knob: rows per strip of the level-0 blur (LM_TUNE_BLUR_STRIP)")
-    ap.add_argument("--no-level-pairs", action="store_true", help="A/B knob: no slot-interleaved level pairs (LM_TUNE_LEVEL_PAIRS = 0)")
     ap.add_argument("--blur-pyr", type=int, default=-1, choices=(-1, 0, 1, 2, 3), help="A/B knob: LM_TUNE_BLUR_PYR (1: blur and pyrDown tiles of a slot back to back, 2: dealt out evenly, 3: by frame size = default)")
     ap.add_argument("--no-blur-pyr", action="store_true", help="A/B knob: level-0 blur and pyrDown as two launches (LM_TUNE_BLUR_PYR = 0)")
     ap.add_argument("--sort-split", type=int, default=-1, choices=(-1, 0, 1, 2), help="A/B knob: LM_TUNE_SORT_SPLIT (0 one workgroup per frame, 1 chunk workgroups + merge launch, 2 adaptive = default)")

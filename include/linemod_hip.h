@@ -200,19 +200,14 @@ void lm_host_free(void* p);
 /* Pageable sources: number of pieces the staging memcpy is cut into so that it overlaps the DMA (default 1:
  * on the MI355X host every extra hipMemcpyAsync call cost more than the overlap won). */
 int lm_set_stage_chunks(lm_detector* det, int chunks);
-/* Launch-shape knobs (results never depend on them; tools/ and the tests flip them for A/B runs).
- * LM_TUNE_FORK_MAX_SLOTS: calls on at most this many frames run the three independent preprocess chains (colour
- *   level 0 | pyrDown + colour of the levels above | depth) on three streams joined by events (default 0 = off: small calls are bound by the host's launch rate, measured r02);
- * LM_TUNE_MATCH_UPLOAD_MODE: lm_match's copies 1 = on the copy stream with the depth chain alone waiting for the depth
- *   image, 2 = in pieces over all copy streams (measured r02: the four event pairs cost more than the parallel
- *   transfers win, 133 -> 167 us), 0 = inline on the compute stream (default). */
-#define LM_TUNE_FORK_MAX_SLOTS 1
-#define LM_TUNE_MATCH_UPLOAD_MODE 2
+/* Launch-shape knobs (results never depend on them; tools/ and the tests flip them for A/B runs).  Keys 1, 2 and 10 (three concurrent
+ * pre-processing chains for single frames; lm_match's copies on the copy streams; level-1 kernels inside the level-0 grids) lost their
+ * A/B runs in r02 / r03 (DESIGN_HISTORY.md) and were removed with their code in r05: lm_set_tuning rejects them. */
 /* LM_TUNE_COPY_STREAMS: copy streams the uploads are dealt to, slot -> stream round-robin (1..4, default 4: one
  *   in-order stream moved 0.6-0.9 MB images at 25.6 GB/s, several keep several DMA engines busy). */
 #define LM_TUNE_COPY_STREAMS 3
 /* LM_TUNE_CBLUR_VARIANT (process-wide): Gaussian blur kernel 0 = by batch size and frame size (default: one-shot below 16 frames;
- *   batches: frames of up to 2 MB on the matrix cores, larger ones the row walker), 1 = one-shot, 2 = r02's sliding window,
+ *   batches: frames of up to 2 MB on the matrix cores, larger ones the row walker), 1 = one-shot, (2 = r02's sliding window: deleted in r05, rejected,)
  *   3 = row walker with the column sums shared between neighbouring lanes (r03), 4 = the two banded products of the 8-bit
  *   Gaussian as v_mfma_i32_32x32x32_i8 (r04; rows of a multiple of 32 bytes, other shapes take 3).  Same bytes from all. */
 #define LM_TUNE_CBLUR_VARIANT 4
@@ -240,12 +235,6 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
  *   rows in the L2; 3 (default) = 2 for frames of more than 2 MB, 1 below (measured: pays at 1280 x 960, not at 640 x 480);
  *   0 = two launches. */
 #define LM_TUNE_BLUR_PYR 9
-/* LM_TUNE_LEVEL_PAIRS (process-wide): batches of 16+ frames run the level-1 kernels inside the level-0 grids of their own
- *   register class, interleaved per frame slot (k_pair: median(0) | blur(1); gradient(0) | gradient(1); all four linear-memory
- *   kernels) -- five launches per RGB-D batch instead of ten.  Default 0 (measured r03: no gain over what LM_TUNE_BATCH_PHASES
- *   chooses); 1 = on.  Same
- *   pyramids and frame shapes as LM_TUNE_BATCH_PHASES; results never depend on it. */
-#define LM_TUNE_LEVEL_PAIRS 10
 /* LM_TUNE_DMEDIAN_VARIANT (process-wide): 5 x 5 median of the normals' labels, output rows per lane 0 = by batch size (default:
  *   4 below 16 frames -- many short waves --, 16 from there: 20 rows of horizontal sums per 16 outputs instead of 8 per 4),
  *   1 / 2 = force either. */

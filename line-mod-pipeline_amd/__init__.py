@@ -35,8 +35,6 @@ class Config(C.Structure):
 
 FLAG_BYTE_RESPONSES = 1
 FLAG_BLOCKING_SYNC = 2
-TUNE_FORK_MAX_SLOTS = 1
-TUNE_MATCH_UPLOAD_MODE = 2
 TUNE_COPY_STREAMS = 3
 TUNE_CBLUR_VARIANT = 4
 TUNE_CGRAD_VARIANT = 5
@@ -44,7 +42,6 @@ TUNE_PHASE_MAX_SLOTS = 6
 TUNE_BATCH_PHASES = 7
 TUNE_PYRDOWN_VARIANT = 8
 TUNE_BLUR_PYR = 9
-TUNE_LEVEL_PAIRS = 10
 TUNE_DMEDIAN_VARIANT = 11
 TUNE_BLUR_STRIP = 12
 TUNE_WORK_WEIGHT = 13

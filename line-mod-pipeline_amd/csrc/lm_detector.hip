@@ -108,13 +108,8 @@ struct lm_detector {
     size_t frame_stride = 0;
     size_t off_bgr[LM_MAX_LEVELS] = {}, off_depth = 0, off_quant[LM_MAX_LEVELS][2] = {}, off_lm[LM_MAX_LEVELS] = {};
     // colour-quantisation scratch S | qn: one region for level 0, one (sized for level 1) shared by the levels above,
-    // and the rank-code image of the depth passes -- disjoint, so the three chains may run concurrently (fork_streams)
+    // and the rank-code image of the depth passes -- disjoint, so independent kernels of one dependency level may run in one launch (k_phase)
     size_t off_cscratch = 0, off_cscratch1 = 0, off_dscratch = 0;
-    // Small calls (n <= LM_FORK_MAX_SLOTS frames) are bound by the latency of 16 dependent launches, not by
-    // throughput: the colour chain of level 0, the pyrDown + colour chain of the levels above and the depth chain are
-    // independent until the scan, so they are forked onto two more streams of the lane and joined with events.
-    struct Fork { hipStream_t s[2] = {nullptr, nullptr}; hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr}; bool ok = false; };
-    Fork forks[LM_NLANES];   // per lane
     // ---- multi-GPU exchange: RCCL communicator + per-lane gather buffers
     struct Gather {
         int* d_cnt = nullptr; LmOutMatch* d_rec = nullptr;          // this rank's packed lists (k_pack_lists)
@@ -147,10 +142,6 @@ struct lm_detector {
     int sort_long_score = 0;         // see note_sort_length
     int work_weight_by_pixels = 1;   // r04: the selection below counts a frame as level-0 pixels / (640 x 480) frames (LM_TUNE_WORK_WEIGHT = 0: by frame count, r03)
     int phase_max_slots = 15;        // calls of up to this many frames run a3-a10 as one launch per dependency level (LmPhaseArgs)
-    int fork_max_slots = 0;          // measured r02: no gain (host launch rate, 3.4 us per launch, bounds small calls), so off by default
-    int fork_depth_wait_slot = -1;   // forked single-frame call: the depth chain's stream waits for this slot's whole upload
-    hipEvent_t ev_split[LM_NCOPY] = {};   // lm_match upload mode 2: one per copy stream
-    int match_upload_mode = 0;       // lm_match: 0 = copies inline on the compute stream (default, faster), 1 = copy stream + split events
     // aux arena: [slot][LmDevHeader | cand | keys | out]
     u8* aux_arena = nullptr;
     size_t aux_stride = 0;
@@ -374,7 +365,6 @@ void enqueue_depth_pyramid(lm_detector* d, int first, int n) {
 }
 
 int wait_uploads(lm_detector* d, hipStream_t stream, int first, int n, unsigned long long* seqs);
-bool ensure_fork(lm_detector* d);
 
 // one modality's linear memories of level l (a6-a10)
 void enqueue_lm(lm_detector* d, hipStream_t st, int first, int n, int l, int m) {
@@ -387,16 +377,6 @@ void enqueue_lm(lm_detector* d, hipStream_t st, int first, int n, int l, int m) 
     else   // level l of the depth modality reads the quantised image of level l-1 at (2y, 2x)
         lmk_linear_memories(st, d->quant(first, l - 1, 1), d->lw[l - 1], 1, sp, g.w, g.h, g.T, d->d_resp_tab, dst,
                             g.ori_stride, fs, fs, n);
-}
-
-bool ensure_fork(lm_detector* d) {
-    lm_detector::Fork& f = d->forks[d->active];
-    if (f.ok) return true;
-    for (auto& st : f.s) if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
-    if (!f.fork && hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess) return false;
-    for (auto& e : f.join) if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
-    f.ok = true;
-    return true;
 }
 
 // How many 640 x 480 frames one frame of this detector counts as in the few-frame / batch kernel selection (at least 1).
@@ -422,8 +402,7 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
     bool others_busy = false;
     for (int o = 0; o < LM_NLANES; ++o) others_busy |= (o != d->active && d->lanes[o].busy);
     const bool fuse_batch = d->batch_phases == 1 || (d->batch_phases == 2 && !others_busy);
-    const bool pairs = lmk_level_pairs() != 0;      // slot-interleaved level pairs (k_pair), beside other lanes too
-    if ((few || ((fuse_batch || pairs) && n_eff >= 16)) && n > d->fork_max_slots && L == 2) {     // (the fork experiment, when switched on, wins)
+    if ((few || (fuse_batch && n_eff >= 16)) && L == 2) {
         LmPhaseArgs pa{};
         pa.bgr0 = d->bgr(first, 0); pa.bgr1 = d->bgr(first, 1); pa.depth = M == 2 ? d->depth(first) : nullptr;
         pa.cs0 = d->cscratch(first, 0); pa.cs1 = d->cscratch(first, 1); pa.ds = d->dscratch(first);
@@ -442,46 +421,10 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
                 return;
             }
             if (!few && lmk_batch_phases_supported(pa, d->geom[0].T, d->geom[1].T, mode(0), mode(1), onehot)) {
-                lmk_preprocess_batch_phases(d->stream, pa, d->geom[0].T, pairs);
+                lmk_preprocess_batch_phases(d->stream, pa, d->geom[0].T);
                 return;
             }
         }
-    }
-    // ---- few frames: three concurrent chains (latency-bound regime; measured no gain, off by default)
-    if (n <= d->fork_max_slots && L >= 2 && ensure_fork(d)) {
-        lm_detector::Fork& f = d->forks[d->active];
-        hipStream_t s0 = d->stream, s1 = f.s[0], s2 = f.s[1];
-        (void)hipEventRecord(f.fork, s0);
-        (void)hipStreamWaitEvent(s1, f.fork, 0);
-        if (M == 2) (void)hipStreamWaitEvent(s2, f.fork, 0);
-        if (M == 2 && d->fork_depth_wait_slot == first) (void)hipStreamWaitEvent(s2, d->slots[first].ev_up, 0);
-        d->fork_depth_wait_slot = -1;
-        // s1: pyrDown + colour chain + linear memories of the levels above 0
-        for (int l = 1; l < L; ++l) {
-            lmk_pyrdown(s1, d->bgr(first, l - 1), d->lw[l - 1], d->lh[l - 1], d->bgr(first, l), fs, n);
-            lmk_color_quantize(s1, d->bgr(first, l), d->lw[l], d->lh[l], c.weak_threshold, d->quant(first, l, 0), nullptr,
-                               d->cscratch(first, 1), fs, n);
-            enqueue_lm(d, s1, first, n, l, 0);
-        }
-        (void)hipEventRecord(f.join[0], s1);
-        // s2: depth chain + the depth modality's linear memories of every level
-        if (M == 2) {
-            lmk_depth_quantize(s2, d->depth(first), d->lw[0], d->lh[0], c.distance_threshold, c.difference_threshold,
-                               d->d_normal_lut, normal_lut_onehot(d), d->quant(first, 0, 1), d->dscratch(first), fs, n);
-            if (L > 2) {
-                for (int l = 1; l < L; ++l)
-                    lmk_nn_half(s2, d->quant(first, l - 1, 1), d->lw[l - 1], d->quant(first, l, 1), d->lw[l], d->lh[l], fs, n);
-            }
-            for (int l = 0; l < L; ++l) enqueue_lm(d, s2, first, n, l, 1);
-            (void)hipEventRecord(f.join[1], s2);
-        }
-        // s0: colour chain + linear memories of level 0, then join
-        lmk_color_quantize(s0, d->bgr(first, 0), d->lw[0], d->lh[0], c.weak_threshold, d->quant(first, 0, 0), nullptr,
-                           d->cscratch(first, 0), fs, n);
-        enqueue_lm(d, s0, first, n, 0, 0);
-        (void)hipStreamWaitEvent(s0, f.join[0], 0);
-        if (M == 2) (void)hipStreamWaitEvent(s0, f.join[1], 0);
-        return;
     }
     // batches: the level-0 blur and pyrDown 0 -> 1 share one slot-interleaved launch (the raw image comes from HBM once)
     const bool blur_pyr = L >= 2 && lmk_blur_pyrdown(d->stream, d->bgr(first, 0), d->lw[0], d->lh[0], d->cscratch(first, 0), d->bgr(first, 1),
@@ -637,17 +580,6 @@ int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, cons
 // The active lane's stream waits for the copy-stream uploads of the slots it is about to read.
 int enqueue_upload_wait(lm_detector* d, int first, int n) {
     int rc;
-    d->fork_depth_wait_slot = -1;
-    Slot& s = d->slots[first];
-    if (n == 1 && d->cfg.num_modalities == 2 && d->cfg.pyramid_levels >= 2 && n <= d->fork_max_slots &&
-        s.up_seq > d->up_seq_done[s.up_stream] && ensure_fork(d)) {
-        // one RGB-D frame through the forked chains: the colour chains start behind the colour copy, only the depth
-        // chain waits for the depth copy (enqueue_preprocess makes its stream wait for ev_up)
-        HIP_TRY(hipStreamWaitEvent(d->stream, s.ev_bgr, 0));
-        d->fork_depth_wait_slot = first;
-        if (s.up_seq > d->waited_seq[s.up_stream]) d->waited_seq[s.up_stream] = s.up_seq;
-        return LM_OK;
-    }
     unsigned long long seqs[LM_NCOPY];
     if ((rc = wait_uploads(d, d->stream, first, n, seqs))) return rc;
     for (int k = 0; k < LM_NCOPY; ++k) if (seqs[k] > d->waited_seq[k]) d->waited_seq[k] = seqs[k];
@@ -1093,16 +1025,10 @@ void lm_destroy(lm_detector* d) {
             if (s.ev_bgr) hipEventDestroy(s.ev_bgr);
         }
         for (auto& cs : d->copy_stream) if (cs) hipStreamDestroy(cs);
-        for (auto& f : d->forks) {
-            for (auto& st : f.s) if (st) hipStreamDestroy(st);
-            if (f.fork) hipEventDestroy(f.fork);
-            for (auto& e : f.join) if (e) hipEventDestroy(e);
-        }
         hipFree(d->frame_arena); hipFree(d->aux_arena); hipHostFree(d->host_blocks);
         hipFree(d->d_raw_thr); hipHostFree(d->h_raw_thr); hipFree(d->d_plan);
         activate_lane(d, 0);
         for (auto& ev : d->blocking_ev) if (ev) hipEventDestroy(ev);
-        for (auto& ev : d->ev_split) if (ev) hipEventDestroy(ev);
         for (auto& ev : d->ev) if (ev) hipEventDestroy(ev);
         if (d->stream) hipStreamDestroy(d->stream);
         for (int l = 1; l < LM_NLANES; ++l) {
@@ -1431,16 +1357,13 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
     if (!d) return fail(LM_ERR_INVALID, "null detector");
     if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     switch (key) {
-        case LM_TUNE_FORK_MAX_SLOTS: if (value < 0) break; d->fork_max_slots = value; return LM_OK;
-        case LM_TUNE_MATCH_UPLOAD_MODE: if (value < 0 || value > 2) break; d->match_upload_mode = value; return LM_OK;
-        case LM_TUNE_CBLUR_VARIANT: if (value < 0 || value > 4) break; lmk_set_cblur_variant(value); return LM_OK;
+        case LM_TUNE_CBLUR_VARIANT: if (value < 0 || value > 4 || value == 2) break; lmk_set_cblur_variant(value); return LM_OK;
         case LM_TUNE_PHASE_MAX_SLOTS: if (value < 0) break; d->phase_max_slots = value; return LM_OK;
         case LM_TUNE_CGRAD_VARIANT: if (value < 0 || value > 3) break; lmk_set_cgrad_variant(value); return LM_OK;
         case LM_TUNE_COPY_STREAMS: if (value < 1 || value > LM_NCOPY) break; d->n_copy_streams = value; return LM_OK;
         case LM_TUNE_BATCH_PHASES: if (value < 0 || value > 2) break; d->batch_phases = value; return LM_OK;
         case LM_TUNE_PYRDOWN_VARIANT: if (value < 0 || value > 2) break; lmk_set_pyrdown_variant(value); return LM_OK;
         case LM_TUNE_BLUR_PYR: if (value < 0 || value > 3) break; lmk_set_blur_pyr(value != 0); lmk_set_blur_pyr_interleave(value == 2 ? 1 : value == 3 ? 2 : 0); return LM_OK;
-        case LM_TUNE_LEVEL_PAIRS: if (value < 0 || value > 1) break; lmk_set_level_pairs(value); return LM_OK;
         case LM_TUNE_BLUR_STRIP: if (value != 0 && value != 16 && value != 32 && value != 64) break; lmk_set_blur_strip(value); return LM_OK;
         case LM_TUNE_DMEDIAN_VARIANT: if (value < 0 || value > 2) break; lmk_set_dmedian_variant(value); return LM_OK;
         case LM_TUNE_WORK_WEIGHT: if (value < 0 || value > 1) break; d->work_weight_by_pixels = value; return LM_OK;
@@ -1469,62 +1392,19 @@ static bool is_pinned_host(const void* p, size_t bytes) {
     return false;
 }
 
-// lm_match upload mode 2: one frame in pieces over all copy streams (one in-order stream moves 1.5 MB at 25-32 GB/s, four
-// in parallel at 55); the compute stream waits for one event per copy stream.  Pageable sources go through the slot's
-// staging buffer piece by piece, so the memcpy of a piece overlaps the transfer of the previous one.
-static int upload_split(lm_detector* d, int slot, const uint8_t* bgr, const uint16_t* depth, bool pinned) {
-    const lm_config& c = d->cfg;
-    Slot& s = d->slots[slot];
-    int rc;
-    s.prepared = false; s.matched = false; s.staging_open = false;
-    if ((rc = wait_slot_upload(d, s))) return rc;
-    if (!pinned && (rc = ensure_staging(d, s))) return rc;
-    const size_t nb = (size_t)c.width * c.height * 3, nd = c.num_modalities == 2 ? (size_t)c.width * c.height * 2 : 0;
-    const int K = d->n_copy_streams;
-    const size_t piece = align_up((nb + nd + K - 1) / K, 4096);
-    int j = 0;
-    bool used[LM_NCOPY] = {};
-    for (int part = 0; part < 2; ++part) {
-        const u8* src = part == 0 ? bgr : reinterpret_cast<const u8*>(depth);
-        u8* stage = part == 0 ? s.h_bgr : reinterpret_cast<u8*>(s.h_depth);
-        u8* dst = part == 0 ? d->bgr(slot, 0) : reinterpret_cast<u8*>(d->depth(slot));
-        const size_t n = part == 0 ? nb : nd;
-        for (size_t off = 0; off < n; off += piece) {
-            const size_t len = std::min(piece, n - off);
-            const u8* from = src + off;
-            if (!pinned) { std::memcpy(stage + off, src + off, len); from = stage + off; }
-            HIP_TRY(hipMemcpyAsync(dst + off, from, len, hipMemcpyHostToDevice, d->copy_stream[j]));
-            used[j] = true;
-            j = (j + 1) % K;
-        }
-    }
-    for (int k = 0; k < K; ++k) {
-        if (!used[k]) continue;
-        if (!d->ev_split[k]) HIP_TRY(hipEventCreateWithFlags(&d->ev_split[k], hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(d->ev_split[k], d->copy_stream[k]));
-        HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_split[k], 0));
-    }
-    s.has_frame = true;
-    return LM_OK;
-}
-
 static int match_host_frame(lm_detector* d, const uint8_t* bgr, size_t bgr_stride, const uint16_t* depth, size_t depth_stride,
                             float threshold, std::vector<int> classes, lm_match_t* out, size_t cap, size_t* n_out) {
     int rc;
     if ((rc = ready_for_compute(d))) return rc;
     if ((rc = ensure_bank(d))) return rc;
     if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    // mode 1: copy stream; the colour chains wait for the colour copy only, the depth chain for the depth copy.
-    // mode 0: copies on the compute stream itself, in order with the kernels (no cross-stream hop)
-    // frames that already live in pinned host memory (lm_host_alloc, hipHostMalloc, hipHostRegister) skip the staging copy
+    // the copies go inline on the compute stream, in order with the kernels (r02 measured the copy-stream forms -- one stream with split
+    // events, pieces over all copy streams -- slower for one frame: 133 -> 167 us; they were deleted in r05).  Frames that already live
+    // in pinned host memory (lm_host_alloc, hipHostMalloc, hipHostRegister) skip the staging copy
     const size_t hh = (size_t)d->cfg.height;
     const bool pinned = bgr && is_pinned_host(bgr, (bgr_stride ? bgr_stride : (size_t)d->cfg.width * 3) * hh) &&
                         (d->cfg.num_modalities < 2 || (depth && is_pinned_host(depth, (depth_stride ? depth_stride : (size_t)d->cfg.width * 2) * hh)));
-    const bool dense = (bgr_stride == 0 || bgr_stride == (size_t)d->cfg.width * 3) &&
-                       (d->cfg.num_modalities < 2 || depth_stride == 0 || depth_stride == (size_t)d->cfg.width * 2);
-    if (d->match_upload_mode == 2 && dense && bgr && (d->cfg.num_modalities < 2 || depth)) {
-        if ((rc = upload_split(d, 0, bgr, depth, pinned))) return rc;
-    } else if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride, pinned, d->match_upload_mode == 1 ? nullptr : d->stream))) return rc;
+    if ((rc = upload_frame(d, 0, bgr, bgr_stride, depth, depth_stride, pinned, d->stream))) return rc;
     if ((rc = run_match(d, 0, 1, threshold, std::move(classes)))) return rc;
     return collect_slot(d, 0, out, cap, n_out);
 }

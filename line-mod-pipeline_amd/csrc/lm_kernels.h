@@ -15,7 +15,7 @@ void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, i
 // form when w % 4 == 0; without it (or for other widths) the fused LDS-tiled kernel runs.
 size_t lmk_color_scratch_bytes(int w, int h);
 void lmk_set_cgrad_variant(int v);   // 0: by batch size (default), 1: k_corient + k_cvote, 2: fused k_cgrad, 3: fused, 32-row strips
-void lmk_set_cblur_variant(int v);   // 0: by batch size (default), 1: one-shot blur, 2: sliding-window blur
+void lmk_set_cblur_variant(int v);   // 0: by batch size (default), 1: one-shot blur, 3: row walker with shared column sums, 4: matrix cores
 // blurred: the level's Gaussian-blurred image S is already in `scratch` (lmk_blur_pyrdown ran): orientation + vote only.
 void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_threshold, u8* quant, float* mag,
                         u8* scratch, size_t slot_stride, int nslots, bool blurred = false);
@@ -154,14 +154,11 @@ void lmk_preprocess_phases(hipStream_t s, const LmPhaseArgs& a, int T0);
 // memories): the kernels of one dependency level share one grid, so the short level-1 launches fill the tail of the
 // long level-0 ones; four launches per lane-step instead of eleven.
 bool lmk_batch_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0, int mode1, bool lut_onehot);
-// pairs: the slot-interleaved level pairs (k_pair: five launches for an RGB-D batch) instead of the register-class fusion
-void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0, bool pairs = false);
-void lmk_set_level_pairs(int v);
+void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0);
 void lmk_set_dmedian_variant(int v);
 // out2[0] / out2[1] += floats of k_dnormal's tail domain on which its short reciprocal / square root differ from the compiler's
 // correctly rounded ones (device counters, zeroed by the caller)
 void lmk_selftest_float_tail(hipStream_t s, unsigned long long* out2);
-int lmk_level_pairs();
 
 struct LmHullArgs {
     const LmOutMatch* matches; u32 n;

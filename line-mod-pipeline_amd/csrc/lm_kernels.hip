@@ -117,7 +117,7 @@ __device__ __forceinline__ void xcd_slot_tile_b(u32 b, u32 G, u32 B, u32& slot, 
 }
 __device__ __forceinline__ void xcd_slot_tile(u32 G, u32 B, u32& slot, u32& tile) { xcd_slot_tile_b(blockIdx.x, G, B, slot, tile); }
 // the block index at which a grid of G tiles x B slots would hold (slot, tile): lets a kernel that interleaves several parts per
-// slot (k_pair) hand a part's tile to the part's device function, which decodes it with xcd_slot_tile_b again
+// slot hand a part's tile to the part's device function, which decodes it with xcd_slot_tile_b again
 __device__ __forceinline__ u32 xcd_vblock(u32 slot, u32 tile, u32 G, u32 B) {
     return (B & 7u) == 0 ? ((((slot >> 3) * G + tile) << 3) | (slot & 7u)) : slot * G + tile;
 }
@@ -606,169 +606,9 @@ __global__ __launch_bounds__(256) void k_cblur(const u8* __restrict__ bgr0, int 
     d_cblur(blockIdx.x, bgr0, w, h, s0, in_stride, tmp_stride, gblocks, nslots);
 }
 
-// a1+a2, sliding-window form of k_cblur (the default).  Same arithmetic; what changes is how the rows reach the
-// registers.  k_cblur loads 8 source rows x 3 blocks for every 2 output rows (each source row is fetched by four
-// different lanes: 24 wave-loads per 2 KiB of output, 12 x read amplification through the L1) and every wave is one
-// load -> compute -> store shot, so at 4 waves per SIMD most of its time is memory latency.  Here a lane owns a column
-// block for a STRIP of CBS_STRIP rows and slides an 8-row window down it two rows at a time: the ring keeps the six
-// rows the next step re-uses, the two new rows are requested one step ahead (6 wave-loads per step, in flight while the
-// current step computes) -- a quarter of the L1 lookups, and the latency hides inside the wave.  The loop is unrolled
-// over the four ring phases so every register index is static (no moves: the ring rotates by renaming).
-#define CBS_STRIP 16
-__device__ __forceinline__ void cbs_request(const u8* bgr, int y, int h, u32 pitch, int b, int nblk, u32x4& c, u32x4& p, u32x4& n) {
-    // always three loads from valid addresses (the neighbour block is clamped at the row ends, where cbs_window does
-    // not use it): no exec-mask branches around loads; 32-bit offsets from the slot's base pointer
-    const u32 ro = (u32)clampi(y, 0, h - 1) * pitch;
-    c = ld16(bgr + (ro + 16u * (u32)b));
-    p = ld16(bgr + (ro + 16u * (u32)max(b - 1, 0)));
-    n = ld16(bgr + (ro + 16u * (u32)min(b + 1, nblk - 1)));
-}
-// window dwords of one row (bytes -12 .. +27 around the block), BORDER_REPLICATE at the row ends
-__device__ __forceinline__ void cbs_window(u32 (&w)[10], const u32x4& c, const u32x4& p, const u32x4& n, int b, int nblk) {
-    if (b > 0) { w[0] = p[1]; w[1] = p[2]; w[2] = p[3]; }
-    else {   // bytes -12..-1 replicate pixel 0 channel-wise: [B G R B][G R B G][R B G R]
-        w[0] = __builtin_amdgcn_perm(c[0], c[0], 0x00020100u);
-        w[1] = __builtin_amdgcn_perm(c[0], c[0], 0x01000201u);
-        w[2] = __builtin_amdgcn_perm(c[0], c[0], 0x02010002u);
-    }
-    w[3] = c[0]; w[4] = c[1]; w[5] = c[2]; w[6] = c[3];
-    if (b + 1 < nblk) { w[7] = n[0]; w[8] = n[1]; w[9] = n[2]; }
-    else {   // bytes 3w.. replicate the last pixel (bytes 1..3 of the last dword)
-        w[7] = __builtin_amdgcn_perm(c[3], c[3], 0x01030201u);
-        w[8] = __builtin_amdgcn_perm(c[3], c[3], 0x02010302u);
-        w[9] = __builtin_amdgcn_perm(c[3], c[3], 0x03020103u);
-    }
-}
-// The ring holds row PAIRS already interleaved (the first stage of the 4 x 4 byte transpose): pair k = source rows
-// (2k, 2k + 1) of the window as x0 = bytes {r0.0 r1.0 r0.1 r1.1}, x1 = {r0.2 r1.2 r0.3 r1.3} per window dword, so a
-// step only interleaves its NEW pair; logical pair i (source rows y - 3 + 2i, + 1) = ring[(i + P) & 3].
-__device__ __forceinline__ void cbs_pair(u32 (&pr)[10][2], const u32 (&r0)[10], const u32 (&r1)[10]) {
-#pragma unroll
-    for (int d = 0; d < 10; ++d) {
-        pr[d][0] = __builtin_amdgcn_perm(r1[d], r0[d], 0x05010400u);
-        pr[d][1] = __builtin_amdgcn_perm(r1[d], r0[d], 0x07030602u);
-    }
-}
-// two output rows (y, y + 1) from the four ring pairs
-template <int P>
-__device__ __forceinline__ void cbs_step(const u32 (&ring)[4][10][2], u32 (&o4)[2][4]) {
-    const u32 wA0 = 8u | (28u << 8) | (56u << 16) | (72u << 24), wB0 = 56u | (28u << 8) | (8u << 16);
-    const u32 wA1 = (8u << 8) | (28u << 16) | (56u << 24), wB1 = 72u | (56u << 8) | (28u << 16) | (8u << 24);
-    // Column sums are produced window dword by window dword; output dword j needs window dwords j .. j + 6 (taps at
-    // bytes -9 .. +9), so it is emitted as soon as dword j + 6 is done: at most 7 dwords of column sums are alive.
-    u32 vb[2][40];                                         // column sums per window byte (<= 65280)
-#pragma unroll
-    for (int d = 0; d < 10; ++d) {
-        u32 T[2][4];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {                      // second stage: rows 4g .. 4g+3 of one byte column per dword
-            const u32 x0 = ring[(2 * g + P) & 3][d][0], x1 = ring[(2 * g + P) & 3][d][1];
-            const u32 z0 = ring[(2 * g + 1 + P) & 3][d][0], z1 = ring[(2 * g + 1 + P) & 3][d][1];
-            T[g][0] = __builtin_amdgcn_perm(z0, x0, 0x05040100u); T[g][1] = __builtin_amdgcn_perm(z0, x0, 0x07060302u);
-            T[g][2] = __builtin_amdgcn_perm(z1, x1, 0x05040100u); T[g][3] = __builtin_amdgcn_perm(z1, x1, 0x07060302u);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            vb[0][4 * d + c] = __builtin_amdgcn_udot4(T[0][c], wA0, __builtin_amdgcn_udot4(T[1][c], wB0, 0u, false), false);
-            vb[1][4 * d + c] = __builtin_amdgcn_udot4(T[0][c], wA1, __builtin_amdgcn_udot4(T[1][c], wB1, 0u, false), false);
-        }
-        if (d >= 6) {
-            const int j = d - 6;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                u32 packed = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i0 = 12 + 4 * j + q - 9;   // taps at window bytes i0, i0 + 3, ..., i0 + 18; sums < 2^16
-                    u32 acc = mad24<8>(vb[r][i0] + vb[r][i0 + 18], 32768u);
-                    acc = mad24<28>(vb[r][i0 + 3] + vb[r][i0 + 15], acc);
-                    acc = mad24<56>(vb[r][i0 + 6] + vb[r][i0 + 12], acc);
-                    acc = mad24<72>(vb[r][i0 + 9], acc);
-                    packed |= (acc >> 16) << (8 * q);
-                }
-                o4[r][j] = packed;
-            }
-        }
-    }
-}
-
-template <int STRIP>
-__device__ __forceinline__ void d_cblur_sw(const u32 vblock, const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
-                                           size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
-    u32 slot, tile;
-    xcd_slot_tile_b(vblock, (u32)gblocks, (u32)nslots, slot, tile);
-    const u8* bgr = slot_ptr_s(bgr0, in_stride, slot);
-    u8* S = slot_ptr_s(s0, tmp_stride, slot);
-    const int nblk = (w * 3) >> 4;
-    const int gid = (int)(tile * 256u) + (int)threadIdx.x;
-    const int strip = gid / nblk, b = gid - strip * nblk;
-    const int y0 = strip * STRIP;
-    if (y0 >= h) return;
-    const u32 pitch = (u32)w * 3u;
-    u32 ring[4][10][2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {   // the first window (source rows y0 - 3 .. y0 + 4), one pair at a time
-        u32x4 c[2], p[2], n[2];
-        cbs_request(bgr, y0 - 3 + 2 * k, h, pitch, b, nblk, c[0], p[0], n[0]);
-        cbs_request(bgr, y0 - 2 + 2 * k, h, pitch, b, nblk, c[1], p[1], n[1]);
-        u32 w0[10], w1[10];
-        cbs_window(w0, c[0], p[0], n[0], b, nblk); cbs_window(w1, c[1], p[1], n[1], b, nblk);
-        cbs_pair(ring[k], w0, w1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const int y1 = min(y0 + STRIP, h);
-    const u32 bo = 16u * (u32)b, po = 16u * (u32)max(b - 1, 0), no = 16u * (u32)min(b + 1, nblk - 1);
-    // Requests run TWO steps ahead (a step is about 1.3 us of arithmetic at two waves per SIMD, a miss under load takes
-    // longer): set A holds the rows of the next step, set B those of the step after; the loop body is written twice so
-    // that the two sets swap roles by name.  Rows past the strip are requested too (clamped, never used): no branches
-    // around loads; all addresses first, then the six loads back to back.
-#define CBS_REQUEST(Y, C0, P0, N0, C1, P1, N1)                                                              \
-    {                                                                                                       \
-        const u32 r0 = (u32)clampi((Y), 0, h - 1) * pitch, r1 = (u32)clampi((Y) + 1, 0, h - 1) * pitch;     \
-        const u32 a0 = r0 + bo, a1 = r0 + po, a2 = r0 + no, a3 = r1 + bo, a4 = r1 + po, a5 = r1 + no;       \
-        __builtin_amdgcn_sched_barrier(0);                                                                  \
-        C0 = ld16(bgr + a0); P0 = ld16(bgr + a1); N0 = ld16(bgr + a2);                                      \
-        C1 = ld16(bgr + a3); P1 = ld16(bgr + a4); N1 = ld16(bgr + a5);                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                  \
-    }
-    // one step: request the pair of step + 2 into the set that was consumed last, compute, THEN consume the set of step
-    // + 1 (the empty asm keeps the window assembly -- and with it the s_waitcnt -- behind the arithmetic), then store
-#define CBS_STEP(RC0, RP0, RN0, RC1, RP1, RN1, UC0, UP0, UN0, UC1, UP1, UN1)                                \
-    {                                                                                                       \
-        const bool more = y + 2 < y1;                                                                       \
-        CBS_REQUEST(y + 7, RC0, RP0, RN0, RC1, RP1, RN1)                                                    \
-        u32 o4[2][4];                                                                                       \
-        cbs_step<0>(ring, o4);                                                                              \
-        asm volatile("" : "+v"(UC0), "+v"(UP0), "+v"(UN0), "+v"(UC1), "+v"(UP1), "+v"(UN1), "+v"(o4[0][0]), "+v"(o4[1][3]) : : "memory"); \
-        if (more) {                                                                                         \
-            _Pragma("unroll") for (int k = 0; k < 3; ++k)                                                   \
-                _Pragma("unroll") for (int d = 0; d < 10; ++d) { ring[k][d][0] = ring[k + 1][d][0]; ring[k][d][1] = ring[k + 1][d][1]; } \
-            u32 w0[10], w1[10];                                                                             \
-            cbs_window(w0, UC0, UP0, UN0, b, nblk); cbs_window(w1, UC1, UP1, UN1, b, nblk);                 \
-            cbs_pair(ring[3], w0, w1);                                                                      \
-        }                                                                                                   \
-        _Pragma("unroll") for (int r = 0; r < 2; ++r)                                                       \
-            if (y + r < h) st16(S + ((u32)(y + r) * pitch + bo), u32x4{o4[r][0], o4[r][1], o4[r][2], o4[r][3]}); \
-        if (!more) return;                                                                                  \
-        y += 2;                                                                                             \
-    }
-    u32x4 ac0, ap0, an0, ac1, ap1, an1, bc0, bp0, bn0, bc1, bp1, bn1;
-    int y = y0;
-    CBS_REQUEST(y + 5, ac0, ap0, an0, ac1, ap1, an1)         // the pair of step 1
-    for (;;) {
-        CBS_STEP(bc0, bp0, bn0, bc1, bp1, bn1, ac0, ap0, an0, ac1, ap1, an1)
-        CBS_STEP(ac0, ap0, an0, ac1, ap1, an1, bc0, bp0, bn0, bc1, bp1, bn1)
-    }
-#undef CBS_STEP
-#undef CBS_REQUEST
-}
-template <int STRIP>
-__global__ __launch_bounds__(256, 2) void k_cblur_sw(const u8* __restrict__ bgr0, int w, int h, u8* __restrict__ s0,
-                                                   size_t in_stride, size_t tmp_stride, int gblocks, int nslots) {
-    d_cblur_sw<STRIP>(blockIdx.x, bgr0, w, h, s0, in_stride, tmp_stride, gblocks, nslots);
-}
-
-// a1+a2, sliding window with the COLUMN SUMS SHARED between neighbouring lanes (r03).  k_cblur_sw gives every lane the
+#define CBS_STRIP 16     // rows per strip of the row-walking blur (k_cblur_sh) for images of up to 640 rows
+// a1+a2, sliding window with the COLUMN SUMS SHARED between neighbouring lanes (r03).  r02's sliding-window kernel (k_cblur_sw,
+// deleted in r05: it lost its A/B to this one in r03 and was the default nowhere) gave every lane the
 // whole 40-byte window of its 16 output bytes: it loads three blocks per row and runs the vertical pass (4 x 4 byte
 // transposes + v_dot4) on ten window dwords for four output dwords -- 2.5 x the vertical work and 3 x the loads.  Here a
 // lane loads and sums ONLY its own block; the nine column sums to the left and to the right of it come from the adjacent
@@ -2466,48 +2306,6 @@ __global__ __launch_bounds__(256, PART == 1 ? 2 : 1) void k_bsplit(LmPhaseArgs a
     }
 }
 
-// Level PAIRS (r03, VERDICT r2 #2a): the level-1 launches of a batch are small grids of long dependent row walks
-// (k_cgrad<8> of 320 x 240: 40 us for a quarter of the 73 us level-0 work; blur 23 us; the two response-memory launches 17
-// + 18 us).  Each rides in the grid of a kernel of ITS OWN register class, interleaved per frame slot the way k_blur_pyr
-// interleaves blur and pyrDown (a slot's tiles back to back on the slot's XCD):
-//   0: median(0) | blur(1)            (107 / 120 VGPRs)       1: gradient + vote(0) | gradient + vote(1)   (237)
-//   2: colour spread memory(0) | depth spread memory(0) | depth response memories(1) | colour response memories(1)
-//   3: colour only: spread memory(0) | response memories(1)
-// pg.g[i] = tiles per slot of part i.  Chain of an RGB-D batch: k_blur_pyr, k_dnormal, k_pair<0>, <1>, <2> -- five launches
-// instead of ten; colour only: k_blur_pyr, k_cblur_sh(1), k_pair<1>, <3> -- four instead of six.
-template <int KIND, int T0, int SG>
-__global__ __launch_bounds__(256, KIND >= 2 ? 1 : 2) void k_pair(LmPhaseArgs a, LmPhaseGrid pg) {
-    const size_t fs = a.slot_stride;
-    const int w1 = a.w >> 1, h1 = a.h >> 1;
-    const u32 n = (u32)a.nslots;
-    const u32 g0 = (u32)pg.g[0], g1 = (u32)pg.g[1], g2 = (u32)pg.g[2], g3 = (u32)pg.g[3];
-    u32 slot, tile;
-    xcd_slot_tile_b(blockIdx.x, g0 + g1 + g2 + g3, n, slot, tile);
-    if (KIND == 0) {
-        if (tile < g0) d_dmedian<DM_ROWS_BATCH>(xcd_vblock(slot, tile, g0, n), a.ds, a.w, a.h, a.qd0, fs, fs, (int)g0, (int)n);
-        else d_cblur_sh<16>(xcd_vblock(slot, tile - g0, g1, n), a.bgr1, w1, h1, a.cs1, fs, fs, (int)g1, (int)n);
-    } else if (KIND == 1) {
-        const float thr2 = a.weak_threshold * a.weak_threshold;
-        const int ithr = thr2 >= 2147483648.f ? INT_MAX : (int)floorf(thr2);
-        if (tile < g0) d_cgrad<SG>(xcd_vblock(slot, tile, g0, n), a.cs0, a.w, a.h, ithr, a.qc0, fs, fs, (int)g0, (int)n);
-        else d_cgrad<16>(xcd_vblock(slot, tile - g0, g1, n), a.cs1, w1, h1, ithr, a.qc1, fs, fs, (int)g1, (int)n);
-    } else if (KIND == 2) {
-        // g2 = g3 = segments per band x bands of the level-1 response memories; d_lm_fast takes the segments per band
-        const int seg1 = (w1 / 8 + 39) / 40;
-        if (tile < g0) d_lm_spread5(xcd_vblock(slot, tile, g0, n), a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, (int)g0, (int)n);
-        else if (tile < g0 + g1) d_lm_spread5(xcd_vblock(slot, tile - g0, g1, n), a.qd0, a.w, a.w, a.h, a.lm_d0, fs, fs, (int)g1, (int)n);
-        else if (tile < g0 + g1 + g2) d_lm_fast<8, 40, 1, 2>(xcd_vblock(slot, tile - g0 - g1, g2, n), a.qd0, a.w, w1, h1, a.resp_tab, a.lm_d1, a.ori_stride1, fs, fs, seg1, (int)n);
-        else d_lm_fast<8, 40, 0, 2>(xcd_vblock(slot, tile - g0 - g1 - g2, g3, n), a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1, fs, fs, seg1, (int)n);
-    } else {
-        const int seg1 = (w1 / 8 + 39) / 40;
-        if (tile < g0) {
-            if (T0 == 5) d_lm_spread5(xcd_vblock(slot, tile, g0, n), a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, (int)g0, (int)n);
-            else d_lm_spread2(xcd_vblock(slot, tile, g0, n), a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, (int)g0, (int)n);
-        }
-        else d_lm_fast<8, 40, 0, 2>(xcd_vblock(slot, tile - g0, g1, n), a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1, fs, fs, seg1, (int)n);
-    }
-}
-
 template <int UNROLL, bool XCD_MAP>
 __global__ __launch_bounds__(256) void k_scan(LmScanArgs a) {
     const int lane = threadIdx.x & 63;
@@ -3703,7 +3501,7 @@ void lmk_nn_half(hipStream_t s, const u8* src, int src_pitch, u8* dst, int dw, i
 // launch).  Hence 0 = auto takes it for batches of frames of up to 2 MB and k_cblur_sh above.
 static bool mx_auto(int w, int h, int nslots);
 static int g_cblur_variant = 0;   // 0: by batch size (one-shot below 16 frames, k_cblur_sh from there), 1: one-shot blur (k_cblur),
-                                  // 2: sliding-window blur (k_cblur_sw, r02's batch kernel), 3: sliding window with the column sums
+                                  // (2 was r02's sliding-window k_cblur_sw, deleted in r05,) 3: sliding window with the column sums
                                   // shared between neighbouring lanes (k_cblur_sh, r03: config 2 146.3 -> 150.7 K, config 3 81.9 -> 86.1 K
                                   // detections/s); A/B knob of tools/ and tests
 void lmk_set_cblur_variant(int v) { g_cblur_variant = v; }
@@ -3791,7 +3589,7 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
             hipLaunchKernelGGL(k_cblur_mx, dim3((unsigned)(gx * gy * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, gx, gy, strip_rows, nslots);
         } else if (g_cblur_variant == 1 || (g_cblur_variant == 0 && sel_slots(nslots) < 16)) {
             hipLaunchKernelGGL(k_cblur, dim3((unsigned)(((n_b + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_b + 255) / 256, nslots);
-        } else if (g_cblur_variant == 3 || g_cblur_variant == 0 || g_cblur_variant == 4) {
+        } else {
             // column sums shared between neighbouring lanes: 62 (strip, block) pairs per wave, four waves per workgroup
             if (h > 640) {
                 const int n_w = (((w * 3 / 16) * ((h + 31) / 32) + 61) / 62 + 3) / 4;
@@ -3799,16 +3597,6 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
             } else {
                 const int n_w = (((w * 3 / 16) * ((h + CBS_STRIP - 1) / CBS_STRIP) + 61) / 62 + 3) / 4;
                 hipLaunchKernelGGL(k_cblur_sh<CBS_STRIP>, dim3((unsigned)(n_w * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, n_w, nslots);
-            }
-        } else {
-            // rows per strip: 16, or 32 for tall images (fewer re-read window rows per strip; a 480-row image would
-            // not give enough waves at 32)
-            if (h > 640) {
-                const int n_s = (w * 3 / 16) * ((h + 31) / 32);                 // 16-byte blocks x row strips
-                hipLaunchKernelGGL(k_cblur_sw<32>, dim3((unsigned)(((n_s + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_s + 255) / 256, nslots);
-            } else {
-                const int n_s = (w * 3 / 16) * ((h + CBS_STRIP - 1) / CBS_STRIP);
-                hipLaunchKernelGGL(k_cblur_sw<CBS_STRIP>, dim3((unsigned)(((n_s + 255) / 256) * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, (n_s + 255) / 256, nslots);
             }
         }
         // orientation + vote: fused for batches (k_cgrad), two kernels for few frames (many short waves) and whenever the
@@ -3985,15 +3773,10 @@ bool lmk_batch_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0,
     return true;
 }
 
-static int g_level_pairs = 0;   // 1: batches run the level-1 kernels inside the level-0 grids of their register class (k_pair).  Measured r03: no gain
-                                // (config 2 one lane 4.46 plain, 4.27 register-class fusion, 4.30 pairs us per frame; 152-153 K against 155-157 K
-                                // detections/s beside other lanes; config 3 7.28 against 6.81 us), so off; kept as a tested knob
 void lmk_selftest_float_tail(hipStream_t s, unsigned long long* out2) {
     hipLaunchKernelGGL(k_selftest_float_tail, dim3(8192), dim3(256), 0, s, out2);
 }
-void lmk_set_level_pairs(int v) { g_level_pairs = v; }
-int lmk_level_pairs() { return g_level_pairs; }
-void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0, bool pairs) {
+void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
     const int w = a.w, h = a.h, w1 = w / 2, h1 = h / 2, n = a.nslots;
     const bool dep = a.depth != nullptr;
     const bool tall = h > 640;                                     // 32-row strips at level 0 (fewer re-read window rows)
@@ -4012,28 +3795,6 @@ void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0, bo
         const u32 nb = pg.nb[0] + pg.nb[1] + pg.nb[2] + pg.nb[3];
         hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, s, a, pg);
     };
-    if (pairs) {
-        // slot-interleaved level pairs (k_pair); needs the blur + pyrDown launch's shapes, else the forms below
-        const size_t fs = a.slot_stride;
-        const int g_lm1 = seg1 * (h1 / 8);
-        if (lmk_blur_pyrdown(s, a.bgr0, w, h, a.cs0, a.bgr1, a.qc0, fs, n)) {
-            auto launch_pair = [&](auto kern, int p0, int p1, int p2, int p3) {
-                const LmPhaseGrid pg = {{0u, 0u, 0u, 0u}, {p0, p1, p2, p3}};
-                hipLaunchKernelGGL(kern, dim3((unsigned)((p0 + p1 + p2 + p3) * n)), dim3(256), 0, s, a, pg);
-            };
-            if (dep) {
-                hipLaunchKernelGGL(k_dnormal, dim3((unsigned)(g_nrm * n)), dim3(256), 0, s, a.depth, w, h, a.dist_thr, a.diff_thr, a.normal_lut, a.ds, fs, fs, g_nrm, n);
-                launch_pair(k_pair<0, 5, 16>, g_med, g_blur1, 0, 0);
-            } else {
-                hipLaunchKernelGGL(k_cblur_sh<16>, dim3((unsigned)(g_blur1 * n)), dim3(256), 0, s, a.bgr1, w1, h1, a.cs1, fs, fs, g_blur1, n);
-            }
-            if (tall) launch_pair(k_pair<1, 5, 32>, g_grad0, g_grad1, 0, 0); else launch_pair(k_pair<1, 5, 16>, g_grad0, g_grad1, 0, 0);
-            if (dep) launch_pair(k_pair<2, 5, 16>, g_sp, g_sp, g_lm1, g_lm1);
-            else if (T0 == 5) launch_pair(k_pair<3, 5, 16>, g_sp, g_lm1, 0, 0);
-            else launch_pair(k_pair<3, 2, 16>, g_sp, g_lm1, 0, 0);
-            return;
-        }
-    }
     if (dep) {
         // RGB-D: only kernels of one register class share a grid (see k_bsplit)
         const float thr2 = a.weak_threshold * a.weak_threshold;

@@ -42,7 +42,7 @@ while time.time() - t0 < budget * 0.5:
     h = int(rng.integers(8, 130))
     bgr = rand_bgr(h, w)
     thr = float(rng.choice([10.0, 0.0, 30.0, 200.0]))
-    kb, kg = int(rng.integers(0, 5)), int(rng.integers(0, 4))      # blur / gradient kernels: by batch size, few-frame, batch; blur 4 = matrix cores
+    kb, kg = int(rng.choice([0, 1, 3, 4])), int(rng.integers(0, 4))      # blur / gradient kernels: by batch size, few-frame, batch; blur 4 = matrix cores
     det.set_tuning(lm.TUNE_CBLUR_VARIANT, kb); det.set_tuning(lm.TUNE_CGRAD_VARIANT, kg)
     assert np.array_equal(det.stage_color_quantize(bgr, thr), orc.color_quantize(bgr, thr)), ("colour", h, w, thr, kb, kg)
     if h % 2 == 0 and w % 2 == 0 and h >= 4:
@@ -93,7 +93,6 @@ while time.time() - t0 < budget:
         d.set_tuning(lm.TUNE_BLUR_PYR, int(rng.choice([0, 1, 2, 3])))         # level-0 blur + pyrDown apart, in one launch back to back, or dealt out evenly
         d.set_tuning(lm.TUNE_BLUR_STRIP, int(rng.choice([0, 16, 32, 64])))      # rows per blur strip inside k_blur_pyr
         d.set_tuning(lm.TUNE_SCAN_LIST_ORDER, int(rng.choice([0, 1, 2, 3])))    # order of the scan's feature lists (same sums)
-        d.set_tuning(lm.TUNE_LEVEL_PAIRS, int(rng.choice([0, 1])))         # level-1 kernels inside the level-0 grids (k_pair) or not
         for k in range(nb):
             d.upload_frame(k, bgr, None if color_only else depth)
         outb, cntb = d.match_batch(nb, thr, 0, cap_per_frame=max(len(exp), 1))

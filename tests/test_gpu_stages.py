@@ -33,10 +33,10 @@ def test_color_quantize_parity(det, orc, shape):
         assert np.array_equal(mag, emag)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 3, 4])
 def test_color_quantize_both_blur_kernels(lm, det, orc, frame0, variant):
-    """The Gaussian blur has three kernels -- one shot (few frames), sliding window (batches) and the sliding window whose
-    column sums travel between neighbouring lanes (r03) -- chosen by batch size:
+    """The Gaussian blur has three kernels -- one shot (few frames, 1), the row walker whose column sums travel between neighbouring
+    lanes (batches, 3) and the matrix-core form (4); r02's plain sliding window (2) was deleted in r05 -- chosen by batch size:
     force each (LM_TUNE_CBLUR_VARIANT) on shapes that hit strip ends, row ends and both pyramid levels' widths."""
     det.set_tuning(lm.TUNE_CBLUR_VARIANT, variant)
     try:

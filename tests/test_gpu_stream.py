@@ -124,12 +124,11 @@ def test_single_frame_calls_with_staging_chunks(lm, orc, synth, chunks):
 
 
 @pytest.mark.parametrize("color_only", [False, True])
-@pytest.mark.parametrize("fork,mode", [(0, 0), (0, 1), (2, 0), (2, 1), (0, 2)])
-def test_single_frame_fork_and_upload_modes(lm, orc, synth, color_only, fork, mode):
-    """Single-frame calls run the three independent preprocess chains on three streams (LM_TUNE_FORK_MAX_SLOTS) and
-    lm_match may send its copies through the copy stream with the depth chain alone waiting for the depth image
-    (LM_TUNE_MATCH_UPLOAD_MODE 1) or in pieces over all copy streams (2): same lists whatever the launch shape, frames
-    changing every call."""
+def test_single_frame_host_and_resident_calls(lm, orc, synth, color_only):
+    """Single-frame calls -- lm_match on a host frame (copies inline on the compute stream) and an upload immediately followed by
+    lm_match_slot -- with frames changing every call: same lists.  (r05: the launch-shape knobs this test used to sweep, three
+    concurrent pre-processing chains and lm_match's copies on the copy streams, lost their A/B runs in r02 and were deleted;
+    lm_set_tuning rejects their keys.)"""
     d = lm.Detector(color_only=color_only, width=W, height=H, frame_slots=4)
     o = orc.Detector(color_only=color_only)
     M = 1 if color_only else 2
@@ -139,8 +138,11 @@ def test_single_frame_fork_and_upload_modes(lm, orc, synth, color_only, fork, mo
     descs, feats, _ = synth.make_bank(150, M, 2, seed=5, quantized=q, crop_fraction=0.3, frame_size=(W, H), T0=d.get_T(0))
     d.add_class("c", descs, feats)
     o.add_class("c", descs, feats)
-    d.set_tuning(lm.TUNE_FORK_MAX_SLOTS, fork)
-    d.set_tuning(lm.TUNE_MATCH_UPLOAD_MODE, mode)
+    for removed_key in (1, 2, 10):
+        with pytest.raises(lm.LinemodError):
+            d.set_tuning(removed_key, 0)
+    with pytest.raises(lm.LinemodError):
+        d.set_tuning(lm.TUNE_CBLUR_VARIANT, 2)             # r02's sliding-window blur: deleted
     exp = [o.match(b, None if color_only else dp, 70.0, threads=8) for b, dp in frames]
     for rnd in range(5):
         for f, (b, dp) in enumerate(frames):
@@ -256,11 +258,10 @@ def test_batches_take_one_launch_per_dependency_level(lm, orc, synth, color_only
     for k in range(n):
         b, dp = frames[(3 * k + 1) % 4]
         d.upload_frame(k, b, None if color_only else dp)
-    for phases, blur_pyr, pairs in ((0, 1, 1), (1, 1, 0), (0, 1, 0), (2, 1, 0), (0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 2, 0), (1, 2, 0), (2, 2, 1)):
+    for phases, blur_pyr, pairs in ((0, 1, 1), (1, 1, 0), (0, 1, 0), (2, 1, 0), (0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 2, 0), (1, 2, 0), (2, 2, 1)):      # (pairs: only varies the blur strip since r05)
         d.set_tuning(lm.TUNE_BATCH_PHASES, phases)
         d.set_tuning(lm.TUNE_BLUR_STRIP, (0, 16, 32, 64)[(phases + 2 * pairs + blur_pyr) % 4])      # rows per blur strip inside k_blur_pyr
         d.set_tuning(lm.TUNE_BLUR_PYR, blur_pyr)     # level-0 blur + pyrDown apart (0), in one launch back to back per slot (1), or dealt out evenly (2)
-        d.set_tuning(lm.TUNE_LEVEL_PAIRS, pairs)     # level-1 kernels inside the level-0 grids of their register class (k_pair)
         for nb in (n, 16):
             out, cnt = d.match_batch(nb, THR, 0)
             for k in range(nb):
@@ -276,7 +277,6 @@ def test_batches_take_one_launch_per_dependency_level(lm, orc, synth, color_only
                     assert np.array_equal(d.debug_read(k, 0, level, mod), o.stage(0, level, mod)), (phases, blur_pyr, pairs, k, level, mod)
                     assert np.array_equal(d.debug_read(k, 2, level, mod), o.stage(2, level, mod)), (phases, blur_pyr, pairs, k, level, mod)
     d.set_tuning(lm.TUNE_BLUR_PYR, 3)
-    d.set_tuning(lm.TUNE_LEVEL_PAIRS, 0)
     d.set_tuning(lm.TUNE_BLUR_STRIP, 0)
     d.close()
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: LM_PLAN_SNAKE existed for this A/B only (profiles/r05_ab_experiments.log section 3); the fused sort + merge it also timed was reverted.
 # r05: the refine plan dealt sequentially (least loaded list first) against snake order of the ranked pieces; and the fused sort + merge.
 OUT=${1:-gpurun_out/r05_plan}
 mkdir -p $OUT
