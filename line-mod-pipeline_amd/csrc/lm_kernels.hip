@@ -1545,7 +1545,7 @@ __device__ __forceinline__ u32 dn_label(int det, int ddx, int ddy, int d, bool o
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool SMALL>
 __device__ __forceinline__ void dn_label2(int det0, int ddx0, int ddy0, int d0, bool ok0, int det1, int ddx1, int ddy1, int d1, bool ok1,
-                                          const u8* __restrict__ lut, u32& e0, u32& e1) {
+                                          const __amdgpu_buffer_rsrc_t lut_rsrc, u32& e0, u32& e1) {
     // QUOT form only (the packed-taps path): det / 625, ddx / 125, ddy / 125 come in
     det0 = mul_i24(det0, 625); det1 = mul_i24(det1, 625);
     if (!SMALL) { ddx0 = mul_i24(ddx0, 125); ddy0 = mul_i24(ddy0, 125); ddx1 = mul_i24(ddx1, 125); ddy1 = mul_i24(ddy1, 125); }
@@ -1568,7 +1568,10 @@ __device__ __forceinline__ void dn_label2(int det0, int ddx0, int ddy0, int d0, 
     const f32x2 t1 = nx * 10.f + 10.f, t2 = ny * 10.f + 10.f, t3 = nz * 20.f + 20.f;
     const u32 flat0 = (u32)mad_i24((int)t3[0], 400, mad_i24((int)t2[0], 20, (int)t1[0]));
     const u32 flat1 = (u32)mad_i24((int)t3[1], 400, mad_i24((int)t2[1], 20, (int)t1[1]));
-    const u32 c0 = lut[LMK_NORMAL_CODE_OFFSET + min(flat0, 8000u)], c1 = lut[LMK_NORMAL_CODE_OFFSET + min(flat1, 8000u)];
+    // (buffer loads: the table's base sits in a scalar resource descriptor and the index is the whole per-lane address -- no 64-bit
+    // vector add per pixel; an index past the table reads its entry 8000 = code 0, see ensure_luts)
+    const u32 c0 = (u32)__builtin_amdgcn_raw_buffer_load_b8(lut_rsrc, (int)(LMK_NORMAL_CODE_OFFSET + min(flat0, 8000u)), 0, 0);
+    const u32 c1 = (u32)__builtin_amdgcn_raw_buffer_load_b8(lut_rsrc, (int)(LMK_NORMAL_CODE_OFFSET + min(flat1, 8000u)), 0, 0);
     e0 = ok0 ? c0 : 0u; e1 = ok1 ? c1 : 0u;
 }
 
@@ -1625,6 +1628,7 @@ __device__ __forceinline__ void d_dnormal_t(const u32 vblock, const u16* __restr
             }
         }
         if (diff_thr >= 0 && diff_thr <= 5461) {   // (a negative threshold gates every neighbour out: the per-pixel loop below gives f = 0 like the oracle)
+            const __amdgpu_buffer_rsrc_t lut_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u8*>(lut), 0, 2 * 8000 + 16, 0x00020000);
             // PACKED taps: two pixels per instruction.  A dword of a depth row is a pixel pair, the neighbours five pixels
             // to the side are one v_alignbit away; |delta| by two saturating subtracts, the gate |delta| < diff_thr by a
             // third, and ci / cj / cx / sx / sy accumulate as i16 pairs (|sx| <= 6 (diff_thr - 1) < 2^15 needs
@@ -1670,7 +1674,7 @@ __device__ __forceinline__ void d_dnormal_t(const u32 vblock, const u16* __restr
                 const int ddxq0 = mad_i16h<false>(cj, sx, mad_i16h<false>(ncx, sy, 0)), ddxq1 = mad_i16h<true>(cj, sx, mad_i16h<true>(ncx, sy, 0));
                 const int ddyq0 = mad_i16h<false>(ci, sy, mad_i16h<false>(ncx, sx, 0)), ddyq1 = mad_i16h<true>(ci, sy, mad_i16h<true>(ncx, sx, 0));
                 u32 e0, e1;                                  // (valid = d < dist_thr; columns x < 5 and x >= w - 6: xmask below)
-                dn_label2<SMALL>(detq0, ddxq0, ddyq0, d0, d0 < dist_thr, detq1, ddxq1, ddyq1, d1, d1 < dist_thr, lut, e0, e1);
+                dn_label2<SMALL>(detq0, ddxq0, ddyq0, d0, d0 < dist_thr, detq1, ddxq1, ddyq1, d1, d1 < dist_thr, lut_rsrc, e0, e1);
                 out[k >> 1] |= (e0 | (e1 << 8)) << (16 * (k & 1));
             }
         } else {

@@ -13,7 +13,7 @@ CFGS=${2:-"2 3 5"}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --no-h2d --no-pose-e2e --steps 20 --warmup 2"
+COMMON="--no-cpu-baseline --no-h2d --no-pose-e2e --no-latency --steps 20 --warmup 2"
 for CFG in $CFGS; do
   if [ $CFG = 2 ]; then BL=96; elif [ $CFG = 3 ]; then BL=128; else BL=8; fi
   ONE="--config $CFG --lanes 1 --batch $BL $COMMON --no-batch-phases"

@@ -17,15 +17,20 @@ if len(sys.argv) > 2 and sys.argv[1] == "--summarize":
 lm = importlib.import_module("line-mod-pipeline_amd")
 synth = importlib.import_module("line-mod-pipeline_amd.synth")
 W, H = 640, 480
-d = lm.Detector(lm.default_config(color_only=False, width=W, height=H, frame_slots=8))
+CO = os.environ.get("LM_COLOR_ONLY") == "1"      # r05: the reference's shipped modality (bench.py's `latency` block): colour only, 1950 templates of variable size
+M = 1 if CO else 2
+d = lm.Detector(lm.default_config(color_only=CO, width=W, height=H, frame_slots=8))
 frames = [synth.make_frame(W, H, seed=1234 + i) for i in range(8)]
-d.upload_frame(0, frames[0][0], frames[0][1]); d.prepare_slot(0)
-q = {(l, m): d.debug_read(0, 0, l, m).reshape(H >> l, W >> l) for l in range(2) for m in range(2)}
-descs, feats, _ = synth.make_bank(3000, 2, 2, seed=4321, fixed_l0_size=(96, 96), quantized=q, crop_fraction=0.1,
-                                  frame_size=(W, H), T0=d.get_T(0))
+d.upload_frame(0, frames[0][0], None if CO else frames[0][1]); d.prepare_slot(0)
+q = {(l, m): d.debug_read(0, 0, l, m).reshape(H >> l, W >> l) for l in range(2) for m in range(M)}
+if CO:
+    descs, feats, _ = synth.make_bank(1950, 1, 2, seed=4321, quantized=q, crop_fraction=0.1, frame_size=(W, H), T0=d.get_T(0))
+else:
+    descs, feats, _ = synth.make_bank(3000, 2, 2, seed=4321, fixed_l0_size=(96, 96), quantized=q, crop_fraction=0.1,
+                                      frame_size=(W, H), T0=d.get_T(0))
 d.add_class("c", descs, feats)
 for i, (b, dp) in enumerate(frames):
-    d.upload_frame(i, b, dp)
+    d.upload_frame(i, b, None if CO else dp)
 if os.environ.get("LM_PHASES") is not None:
     d.set_tuning(lm.TUNE_PHASE_MAX_SLOTS, int(os.environ["LM_PHASES"]))
 for k in range(40):
