@@ -93,9 +93,22 @@ while time.time() - t0 < budget:
         d.set_tuning(lm.TUNE_BLUR_PYR, int(rng.choice([0, 1, 2, 3])))         # level-0 blur + pyrDown apart, in one launch back to back, or dealt out evenly
         d.set_tuning(lm.TUNE_BLUR_STRIP, int(rng.choice([0, 16, 32, 64])))      # rows per blur strip inside k_blur_pyr
         d.set_tuning(lm.TUNE_SCAN_LIST_ORDER, int(rng.choice([0, 1, 2, 3])))    # order of the scan's feature lists (same sums)
+        # r05: every way a frame reaches a slot -- the one-call upload, the staged upload (rows in random pieces; a zero shift here, the
+        # shifted forms are swept in tests/test_gpu_stream.py) -- and the lists once more through lm_match_collect
+        staged = bool(rng.integers(0, 2))
+        if staged:
+            d.stage_reserve(0, nb)
         for k in range(nb):
-            d.upload_frame(k, bgr, None if color_only else depth)
+            if staged:
+                cut = sorted(set([0, h] + [int(v) for v in rng.integers(0, h + 1, 3)]))
+                for a, b in zip(cut[:-1], cut[1:]):
+                    d.stage_rows(k, bgr, None if color_only else depth, 0, 0, a, b)
+                d.upload_staged(k)
+            else:
+                d.upload_frame(k, bgr, None if color_only else depth)
         outb, cntb = d.match_batch(nb, thr, 0, cap_per_frame=max(len(exp), 1))
+        outc2, cntc2 = d.match_collect(0, nb, cap_per_frame=max(len(exp), 1))
+        assert np.array_equal(cntb, cntc2) and outb.tobytes() == outc2.tobytes(), ("collect", color_only, T, w, h, n, thr, nb)
         for k in range(nb):
             assert cntb[k] == len(exp) and outb[k, :cntb[k]].tobytes() == exp.tobytes(), ("batch", color_only, T, w, h, n, thr, nb, k)
         n_batch += 1
