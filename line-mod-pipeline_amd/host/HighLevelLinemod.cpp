@@ -15,6 +15,7 @@
 #include <thread>
 
 #include "PostProcess.h"
+#include "GroupWaves.h"
 #include "WorkerPool.h"
 #include "TemplateGenerator.h"
 
@@ -379,64 +380,59 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
     // .. 16 matches on the pool and the walk (PostProcessor::accept_range) consumes a wave when it is complete: same verdicts, same
     // poses; at most the checks of the wave in which the walk stops are evaluated in vain (none when the first match passes, the
     // common case on real frames).  The first wave starts before the colour counts are back: a token per group holds its walk.
-    struct GroupRun {
-        const Unit* u = nullptr; size_t g = 0, n = 0, next = 0, from = 0, to = 0, wave = 0;
-        std::vector<PostProcessor::MatchVerdict> v;      // of the current wave
-        std::atomic<int> left{0};
+    struct GroupState {     // what the walk of one group reads and writes (host/GroupWaves.h schedules the evaluations and the walk)
+        const Unit* u = nullptr; size_t g = 0;
+        std::vector<PostProcessor::MatchVerdict> v;      // one per match of the group
         std::vector<ObjectPose> poses;
         std::mutex mu; PostProcessor::Times tm;
         void add(const PostProcessor::Times& t) { std::lock_guard<std::mutex> g_(mu); tm.add(t); }
     };
     size_t n_groups = 0;
     for (const Unit& u : units) if (u.live) n_groups += u.prep.groups.size();
-    std::vector<GroupRun> runs(n_groups);
+    std::vector<GroupState> runs(n_groups);
+    std::vector<size_t> lengths(n_groups);
     {
         size_t at = 0;
         for (const Unit& u : units)
-            if (u.live) for (size_t g = 0; g < u.prep.groups.size(); ++g) { runs[at].u = &u; runs[at].g = g; runs[at].n = u.prep.groups[g].matchIndices.size(); ++at; }
+            if (u.live) for (size_t g = 0; g < u.prep.groups.size(); ++g) {
+                runs[at].u = &u; runs[at].g = g; lengths[at] = u.prep.groups[g].matchIndices.size();
+                runs[at].v.assign(lengths[at], PostProcessor::MatchVerdict());
+                ++at;
+            }
     }
     WorkerPool::Group finishing;
-    WorkerPool* pool = st.pool.get();
-    std::function<void(GroupRun&)> advance;
-    // hands the next wave of the group to the pool; `token`: one more count that the caller takes off when the colour counts are in
-    auto start_wave = [&](GroupRun& r, bool token, bool colour_known) {
-        r.wave = r.wave == 0 ? 1 : std::min<size_t>(2 * r.wave, 16);
-        r.from = r.next; r.to = std::min(r.n, r.from + r.wave); r.next = r.to;
-        r.v.assign(r.to - r.from, PostProcessor::MatchVerdict());
-        r.left.store((int)(r.to - r.from) + (token ? 1 : 0));
-        // (the bounds as locals: once the wave's last task is queued another thread may finish the wave and start the next one, moving r.from / r.to)
-        const size_t wave_from = r.from, wave_to = r.to;
-        for (size_t k = wave_from; k < wave_to; ++k)
-            pool->submit(finishing, [&r, k, colour_known, &advance, this] {
-                const Unit& u = *r.u;
-                const std::vector<lm_match_t>& ms = *u.matches;
-                const uint32_t idx = u.prep.groups[r.g].matchIndices[k];
-                const lm_match_t& m = ms[idx];
-                PostProcessor::MatchVerdict& v = r.v[k - r.from];
-                PostProcessor::Times t;
-                if ((size_t)m.template_id < u.tpl->size()) {
-                    // colour verdict known (later waves; the host colour check computes it here): the depth check only runs behind a passed
-                    // colour check, as in the reference; first wave of the GPU colour check: the depth check runs ahead of the verdict
-                    if (colour_known) { v.colour_ok = u.pp.colour_ok(u.prep, idx, m); if (v.colour_ok) u.pp.depth_part(m, u.depth, *u.tpl, v, &t); }
-                    else u.pp.depth_part(m, u.depth, *u.tpl, v, &t);
-                }
-                r.add(t);
-                if (r.left.fetch_sub(1) == 1) advance(r);
-            });
-    };
-    advance = [&](GroupRun& r) {
-        const Unit& u = *r.u;
-        const std::vector<lm_match_t>& ms = *u.matches;
-        if (u.prep.failed) return;
-        for (size_t k = r.from; k < r.to; ++k) {          // (first wave of the GPU colour check: the verdicts came in after the depth checks)
+    GroupWaves waves(*st.pool, finishing, lengths,
+        // a match's checks, on any pool thread.  early (the first wave, before the GPU's colour counts are back): the depth check runs ahead
+        // of the colour verdict; otherwise the depth check only runs behind a passed colour check, as in the reference (the host colour
+        // check computes its verdict here)
+        [&runs](size_t gi, size_t k, bool early) {
+            GroupState& r = runs[gi];
+            const Unit& u = *r.u;
             const uint32_t idx = u.prep.groups[r.g].matchIndices[k];
-            if (!r.v[k - r.from].colour_ok && u.prep.gpu && (size_t)ms[idx].template_id < u.tpl->size()) r.v[k - r.from].colour_ok = u.pp.colour_ok(u.prep, idx, ms[idx]);
-        }
-        PostProcessor::Times t;
-        const bool done = u.pp.accept_range(u.prep, r.g, ms, *u.tpl, r.from, r.to, r.v.data(), r.poses, &t);
-        r.add(t);
-        if (!done && r.next < r.n) start_wave(r, false, true);
-    };
+            const lm_match_t& m = (*u.matches)[idx];
+            PostProcessor::MatchVerdict& v = r.v[k];
+            PostProcessor::Times t;
+            if ((size_t)m.template_id < u.tpl->size()) {
+                if (!early) { v.colour_ok = u.pp.colour_ok(u.prep, idx, m); if (v.colour_ok) u.pp.depth_part(m, u.depth, *u.tpl, v, &t); }
+                else u.pp.depth_part(m, u.depth, *u.tpl, v, &t);
+            }
+            r.add(t);
+        },
+        // the reference's walk over a complete wave (PostProcessor::accept_range); true = the group has its poses
+        [&runs](size_t gi, size_t from, size_t to) {
+            GroupState& r = runs[gi];
+            const Unit& u = *r.u;
+            const std::vector<lm_match_t>& ms = *u.matches;
+            if (u.prep.failed) return true;
+            for (size_t k = from; k < to; ++k) {          // (first wave of the GPU colour check: the verdicts came in after the depth checks)
+                const uint32_t idx = u.prep.groups[r.g].matchIndices[k];
+                if (!r.v[k].colour_ok && u.prep.gpu && (size_t)ms[idx].template_id < u.tpl->size()) r.v[k].colour_ok = u.pp.colour_ok(u.prep, idx, ms[idx]);
+            }
+            PostProcessor::Times t;
+            const bool done = u.pp.accept_range(u.prep, r.g, ms, *u.tpl, from, to, r.v.data() + from, r.poses, &t);
+            r.add(t);
+            return done;
+        });
     for (Unit& u : units) if (u.live) u.matches = &out_matches[u.c][(size_t)u.i];
     if (gpuColorCheck) {
         // the units by HSV range; the first range's check is asynchronous
@@ -459,16 +455,13 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
             std::vector<int64_t> gin(todo.size()), gboth(todo.size());
             const clk::time_point t_c = clk::now();
             int crc = lm_color_check_begin_slots(detector, slot_of.data(), units[a].props.lowerColorRange, units[a].props.upperColorRange, todo.data(), todo.size());
-            if (crc == LM_OK && first_range) {
-                // while the GPU counts: the first wave of every group (all ranges' groups: their walks wait for the tokens)
-                for (GroupRun& r : runs) if (r.n) start_wave(r, true, false);
-            }
+            if (crc == LM_OK && first_range) waves.start(true);      // while the GPU counts: the first wave of every group (all ranges' groups: their walks wait for the tokens)
             if (crc == LM_OK) crc = lm_color_check_end(detector, gin.data(), gboth.data());
             if (crc != LM_OK) {
                 // loud, never a silent switch of implementation (frames of more than 4992 rows: setGpuColorCheck(false))
                 error = lm_last_error();
                 for (size_t q : same) { units[q].prep.failed = true; }
-                if (first_range) for (GroupRun& r : runs) if (r.n && r.wave == 0) start_wave(r, true, false);      // (every group holds a token below)
+                if (first_range) waves.start(true);      // (every group holds a token below; groups already started are left alone)
                 first_range = false;
                 continue;
             }
@@ -480,14 +473,15 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
                 at += units[q].prep.todo.size();
             }
         }
-        for (GroupRun& r : runs) if (r.n && r.left.fetch_sub(1) == 1) advance(r);     // the tokens: every count is in
+        waves.start(true);                // (no live unit at all: nothing to start; otherwise a no-op)
+        waves.release_tokens();           // every count is in
     } else {
-        for (GroupRun& r : runs) if (r.n) start_wave(r, false, true);
+        waves.start(false);
     }
     st.pool->wait(finishing);
     if (!finishing.error.empty()) { error = finishing.error; return false; }
     for (const PostProcessor::Times& t : frame_times) PostProcessor::times().add(t);
-    for (GroupRun& r : runs) {
+    for (GroupState& r : runs) {
         PostProcessor::times().add(r.tm);
         if (r.poses.empty() || r.u->prep.failed) continue;
         stageTimes.poses += (long)r.poses.size();

@@ -76,19 +76,19 @@ public:
             if (front) q.push_front(Task{&g, std::move(fn)}); else q.push_back(Task{&g, std::move(fn)});
         }
         cv.notify_one();
+        done_cv.notify_one();           // a caller sleeping in wait() helps with the new task
     }
 
-    // Returns when every task of `g` has finished; the caller runs queued tasks (of any group) meanwhile.
+    // Returns when every task of `g` has finished; the caller runs queued tasks (of any group) meanwhile and sleeps when there is
+    // nothing to run (woken by a submit or by the group's last task).
     void wait(Group& g) {
-        while (g.pending.load(std::memory_order_acquire) > 0) {
+        for (;;) {
             Task t;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                if (q.empty()) {
-                    // tasks of g are running on workers: sleep until one of them finishes (done_cv) or new work shows up
-                    if (g.pending.load(std::memory_order_acquire) > 0) done_cv.wait_for(lk, std::chrono::microseconds(200));
-                    continue;
-                }
+                done_cv.wait(lk, [&] { return !q.empty() || g.pending.load(std::memory_order_acquire) == 0; });
+                if (q.empty()) return;                  // (the group is done)
+                if (g.pending.load(std::memory_order_acquire) == 0) return;
                 t = std::move(q.front()); q.pop_front();
             }
             run(t);
@@ -101,7 +101,11 @@ private:
         try { t.fn(); }
         catch (const std::exception& e) { t.g->fail(e.what()); }
         catch (...) { t.g->fail("unknown exception in a pool task"); }
-        if (t.g->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) done_cv.notify_all();
+        if (t.g->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            // (through the mutex: a waiter is either before its check of `pending` -- and will see 0 -- or asleep -- and is woken)
+            { std::lock_guard<std::mutex> lk(mu); }
+            done_cv.notify_all();
+        }
     }
     void loop() {
         for (;;) {

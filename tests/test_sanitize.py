@@ -48,3 +48,20 @@ def test_oracle_under_asan_ubsan(tmp_path):
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "passed" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_facade_pool_and_waves_under_sanitizers(tmp_path, sanitizer):
+    """r05: the facade's host concurrency -- the persistent pool (host/WorkerPool.h) and the wave scheduler of the groups' dependent
+    depth-check walks (host/GroupWaves.h), neither of which touches the GPU -- under ThreadSanitizer and ASan / UBSan: hundreds of
+    rounds of random groups, with and without the token that holds the walks until the colour counts are in, a staging group
+    jumping the queue, an exception inside a task (tests/cpp/group_waves_tsan.cpp).  The walks must look at exactly the items the
+    plain sequential walk looks at, in order, each evaluated exactly once before; the sanitizers must stay silent."""
+    exe = str(tmp_path / "group_waves")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=" + sanitizer, "-fno-omit-frame-pointer", "-pthread", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "group_waves_tsan.cpp")])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+    for threads in (3, 16):                                  # fewer and more threads than this container has CPUs
+        r = subprocess.run([exe, "150", str(threads)], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and r.stdout.strip().startswith("OK"), r.stdout[-1500:] + r.stderr[-4000:]
+        assert "ThreadSanitizer" not in r.stderr and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
