@@ -317,6 +317,11 @@ int lm_color_check_counts(lm_detector* det, int slot, const double lower_hsv[3],
  * batch k overlap the match of batch k + 1 on another lane. */
 int lm_color_check_counts_slots(lm_detector* det, const int32_t* slot_of_match, const double lower_hsv[3], const double upper_hsv[3],
                                 const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both);
+/* The colour masks of slots [first_slot, first_slot + n_slots) for one HSV range, enqueued on `lane`'s stream AHEAD of the match the
+ * caller begins on that lane next: when the lane has been collected the masks are there, and a colour check of those slots for the
+ * same range skips its mask launch (only the hull launch is left between lm_match_end and the counts).  An upload to a slot, or a
+ * colour check with another range, invalidates the slot's mask. */
+int lm_color_mask_prepare(lm_detector* det, int lane, int first_slot, int n_slots, const double lower_hsv[3], const double upper_hsv[3]);
 /* The two halves of lm_color_check_counts_slots: begin enqueues the copies and the two launches on the colour-check stream and returns,
  * end waits and delivers the counts of the list begun (one check in flight per detector; `matches` may be reused after begin returns).
  * Between them the calling thread is free -- HighLevelLineMOD starts the first depth checks of a batch's groups meanwhile. */

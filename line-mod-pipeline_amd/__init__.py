@@ -81,7 +81,7 @@ EXPORTS = [
     "lm_time_scan_batch",
     "lm_selftest_float_tail",
     "lm_upload_frame_pinned_shifted", "lm_stage_reserve", "lm_stage_rows", "lm_upload_staged", "lm_match_collect",
-    "lm_color_check_counts_slots", "lm_color_check_begin_slots", "lm_color_check_end",
+    "lm_color_check_counts_slots", "lm_color_check_begin_slots", "lm_color_check_end", "lm_color_mask_prepare",
 ]
 
 _lib = None
@@ -194,6 +194,7 @@ def load_library(path=None):
     lib.lm_color_check_counts_slots.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, sz, vp, vp]
     lib.lm_color_check_begin_slots.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, sz]
     lib.lm_color_check_end.argtypes = [vp, vp, vp]
+    lib.lm_color_mask_prepare.argtypes = [vp, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if path is None:
         _lib = lib
     return lib
@@ -821,6 +822,11 @@ class Detector:
         lo, hi = (C.c_double * 3)(*lower_hsv), (C.c_double * 3)(*upper_hsv)
         self._check(self.lib.lm_color_check_counts_slots(self.h, _ptr(sl), lo, hi, _ptr(m), len(m), _ptr(a), _ptr(b)))
         return a, b
+
+    def color_mask_prepare(self, lane, first_slot, n_slots, lower_hsv, upper_hsv):
+        """The slots' colour masks for one HSV range on `lane`'s stream, ahead of the match begun on that lane next."""
+        lo, hi = (C.c_double * 3)(*lower_hsv), (C.c_double * 3)(*upper_hsv)
+        self._check(self.lib.lm_color_mask_prepare(self.h, lane, first_slot, n_slots, lo, hi))
 
     def upload_frame_pinned_shifted(self, slot, bgr, depth, shift_x, shift_y):
         """upload_frame_shifted from pinned memory: the DMA engine's row-offset copy, no staging pass."""

@@ -55,6 +55,8 @@ struct Slot {
     hipEvent_t ev_bgr = nullptr;     // recorded behind the colour image alone (RGB-D: the depth copy follows it)
     unsigned long long up_seq = 0;
     int up_stream = 0;               // which copy stream carried the upload (tickets are per stream)
+    bool mask_ready = false;         // the slot's colour bit mask holds inRange(HSV(frame), mask_lo, mask_hi) of the frame the slot holds (lm_color_mask_prepare)
+    int mask_lo[3] = {0, 0, 0}, mask_hi[3] = {0, 0, 0};
     bool staging_open = false;       // lm_stage_reserve has run: lm_stage_rows may fill the staging buffers, lm_upload_staged sends them
     bool matched = false;            // a match on the frame the slot holds has completed: its lists are still in the slot's result block (lm_match_collect)
 };
@@ -778,7 +780,7 @@ int upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride
     for (const lm_detector::Lane& ln : d->lanes)
         if (ln.busy && slot >= ln.first && slot < ln.first + ln.n) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
     int rc;
-    s.prepared = false; s.matched = false; s.staging_open = false;
+    s.prepared = false; s.matched = false; s.mask_ready = false; s.staging_open = false;
     shift_x = clamp_shift(shift_x, c.width); shift_y = clamp_shift(shift_y, c.height);     // (beyond: an all-zero frame either way)
     // the slot's previous upload may still be reading the staging buffer (and must land before this one anyway)
     if ((rc = wait_slot_upload(d, s))) return rc;
@@ -1232,7 +1234,7 @@ int lm_upload_frames_pinned(lm_detector* d, int first_slot, int n_slots, const u
         Slot& s = d->slots[first_slot + i];
         if (c.num_modalities == 2) HIP_TRY(hipEventRecord(s.ev_bgr, st));
         HIP_TRY(hipEventRecord(s.ev_up, st));
-        s.up_stream = cs; s.up_seq = seq; s.has_frame = true; s.prepared = false; s.matched = false; s.staging_open = false;
+        s.up_stream = cs; s.up_seq = seq; s.has_frame = true; s.prepared = false; s.matched = false; s.mask_ready = false; s.staging_open = false;
     }
     return LM_OK;
 }
@@ -1296,7 +1298,7 @@ int lm_upload_staged(lm_detector* d, int slot) {
     const lm_config& c = d->cfg;
     const int cs = slot % d->n_copy_streams;
     hipStream_t st = d->copy_stream[cs];
-    s.prepared = false; s.matched = false; s.staging_open = false;
+    s.prepared = false; s.matched = false; s.mask_ready = false; s.staging_open = false;
     HIP_TRY(hipMemcpyAsync(d->bgr(slot, 0), s.h_bgr, (size_t)c.width * c.height * 3, hipMemcpyHostToDevice, st));
     if (c.num_modalities == 2) {
         HIP_TRY(hipEventRecord(s.ev_bgr, st));
@@ -1681,9 +1683,20 @@ static int colour_check_enqueue(lm_detector* d, const int32_t* slot_of, int one_
     if (slot_of) HIP_TRY(hipMemcpyAsync(d->cc_dev + off_slot, d->cc_host + off_slot, n * sizeof(int), hipMemcpyHostToDevice, st));
     LmHsvRange rg;
     for (int k = 0; k < 3; ++k) { rg.lo[k] = (int)std::lrint(lower_hsv[k]); rg.hi[k] = (int)std::lrint(upper_hsv[k]); }
-    // ONE mask launch for the slots [s_lo, s_hi] (a slot in between that the list does not name costs a mask nobody reads)
+    // ONE mask launch for the slots [s_lo, s_hi] (a slot in between that the list does not name costs a mask nobody reads) -- unless
+    // every named slot's mask was prepared for this very range beside its match (lm_color_mask_prepare)
     u32* mask = reinterpret_cast<u32*>(d->frame_arena + (size_t)s_lo * d->frame_stride + d->off_cmask);
-    lmk_hsv_mask(st, d->bgr(s_lo, 0), d->cfg.width, d->cfg.height, rg, d->d_hsv_div, mask, d->cmask_wpr, d->frame_stride, d->frame_stride, s_hi - s_lo + 1);
+    bool prepared = true;
+    for (int sl = s_lo; sl <= s_hi && prepared; ++sl) {
+        const Slot& s = d->slots[(size_t)sl];
+        if (!used[(size_t)sl]) continue;
+        prepared = s.mask_ready;
+        for (int k = 0; k < 3 && prepared; ++k) prepared = s.mask_lo[k] == rg.lo[k] && s.mask_hi[k] == rg.hi[k];
+    }
+    if (!prepared) {
+        lmk_hsv_mask(st, d->bgr(s_lo, 0), d->cfg.width, d->cfg.height, rg, d->d_hsv_div, mask, d->cmask_wpr, d->frame_stride, d->frame_stride, s_hi - s_lo + 1);
+        for (int sl = s_lo; sl <= s_hi; ++sl) d->slots[(size_t)sl].mask_ready = false;      // (overwritten for this call's range; not recorded as prepared)
+    }
     LmHullArgs a;
     a.matches = reinterpret_cast<const LmOutMatch*>(d->cc_dev); a.n = (u32)n;
     a.class_base = d->d_hull_class_base; a.hull_off = d->d_hull_off; a.hull_xy = d->d_hull_xy;
@@ -1721,6 +1734,40 @@ static int colour_check(lm_detector* d, const int32_t* slot_of, int one_slot, co
     if ((rc = colour_check_enqueue(d, slot_of, one_slot, lower_hsv, upper_hsv, matches, n))) return rc;
     if (!d->cc_inflight) return LM_OK;       // n == 0
     return colour_check_finish(d, in_hull, in_both);
+}
+
+// The colour masks of slots [first_slot, first_slot + n_slots) for one HSV range, enqueued on `lane`'s stream AHEAD of the match that
+// the caller begins on that lane next (lm_match_begin*): when the lane has been collected the masks are there, and a colour check of
+// those slots for the same range skips its mask launch -- only the hull launch is left between lm_match_end and the counts.
+int lm_color_mask_prepare(lm_detector* d, int lane, int first_slot, int n_slots, const double lower_hsv[3], const double upper_hsv[3]) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if (lane < 0 || lane >= LM_NLANES) return fail(LM_ERR_INVALID, "lane out of range (0 .. 3)");
+    if ((rc = check_slots(d, first_slot, n_slots))) return rc;
+    if (!lower_hsv || !upper_hsv || n_slots <= 0) return fail(LM_ERR_INVALID, "bad argument");
+    if (d->lanes[lane].busy) return fail(LM_ERR_INVALID, "lane is busy: prepare the masks before lm_match_begin");
+    for (const lm_detector::Lane& ln : d->lanes)
+        if (ln.busy && first_slot < ln.first + ln.n && ln.first < first_slot + n_slots) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
+    for (int i = 0; i < n_slots; ++i)
+        if (!d->slots[first_slot + i].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot " + std::to_string(first_slot + i));
+    if (d->hulls_dirty && any_lane_busy(d)) return fail(LM_ERR_INVALID, "the bank changed while a lane has a match in flight: call lm_match_end first");
+    if ((rc = ensure_hulls(d))) return rc;                 // (also uploads the HSV division tables)
+    if ((rc = ensure_lane(d, lane))) return rc;
+    LmHsvRange rg;
+    for (int k = 0; k < 3; ++k) { rg.lo[k] = (int)std::lrint(lower_hsv[k]); rg.hi[k] = (int)std::lrint(upper_hsv[k]); }
+    activate_lane(d, lane);
+    rc = enqueue_upload_wait(d, first_slot, n_slots);
+    if (!rc) {
+        u32* mask = reinterpret_cast<u32*>(d->frame_arena + (size_t)first_slot * d->frame_stride + d->off_cmask);
+        lmk_hsv_mask(d->stream, d->bgr(first_slot, 0), d->cfg.width, d->cfg.height, rg, d->d_hsv_div, mask, d->cmask_wpr, d->frame_stride, d->frame_stride, n_slots);
+        for (int i = 0; i < n_slots; ++i) {
+            Slot& s = d->slots[first_slot + i];
+            s.mask_ready = true;
+            for (int k = 0; k < 3; ++k) { s.mask_lo[k] = rg.lo[k]; s.mask_hi[k] = rg.hi[k]; }
+        }
+    }
+    activate_lane(d, 0);
+    return rc;
 }
 
 int lm_color_check_counts(lm_detector* d, int slot, const double lower_hsv[3], const double upper_hsv[3],

@@ -267,6 +267,20 @@ bool HighLevelLineMOD::detectTemplatesBatchBegin(std::vector<std::vector<Image>>
     for (int i = 0; i < n; ++i)
         if (!in_frames[(size_t)i][0].pinned && lm_upload_staged(detector, first + i) != LM_OK) { error = lm_last_error(); return false; }
     std::vector<int32_t> cls(in_classNumbers.begin(), in_classNumbers.end());
+    if (gpuColorCheck) {
+        // when the classes that will be post-processed share ONE HSV range (the usual case: one kind of part), the frames' colour masks are
+        // computed on the lane ahead of the match, so that End's colour check is the hull launch alone
+        const ModelProperties* range = nullptr;
+        bool one = true;
+        for (uint16_t c : in_classNumbers) {
+            if (!(c < modelTemplates->size()) || (*modelTemplates)[c].empty()) continue;
+            static const ModelProperties kDefault;
+            const ModelProperties* p = c < modProps->size() ? &(*modProps)[c] : &kDefault;
+            if (!range) { range = p; continue; }
+            for (int k = 0; k < 3; ++k) one = one && range->lowerColorRange[k] == p->lowerColorRange[k] && range->upperColorRange[k] == p->upperColorRange[k];
+        }
+        if (range && one && lm_color_mask_prepare(detector, /*lane*/ set, first, n, range->lowerColorRange, range->upperColorRange) != LM_OK) { error = lm_last_error(); return false; }
+    }
     if (lm_match_begin_classes(detector, /*lane*/ set, first, n, detectorThreshold, cls.data(), (int)cls.size()) != LM_OK) { error = lm_last_error(); return false; }
     Stream::Batch b;
     b.set = set; b.n = n; b.frames = in_frames; b.classes = in_classNumbers;

@@ -107,17 +107,12 @@ Vec3 rotate(const Vec3& v, float angle, const Vec3& normal) {   // glm::rotate(v
 // followed by cv::inRange with scalar bounds (HighLevelLinemod.cpp:159-161).
 void bgr2hsv_inrange(const uint8_t* bgr, int w, int h, size_t stride, const double lower[3], const double upper[3],
                      std::vector<uint8_t>& mask) {
-    static int sdiv[256], hdiv[256];
-    static bool init = false;
     const int shift = 12;
-    if (!init) {
-        sdiv[0] = hdiv[0] = 0;
-        for (int i = 1; i < 256; ++i) {
-            sdiv[i] = (int)std::lrint((255 << shift) / (1.0 * i));
-            hdiv[i] = (int)std::lrint((180 << shift) / (6.0 * i));
-        }
-        init = true;
-    }
+    // (a function-local static with an initialiser: built once, thread-safely -- r05 calls this from the pool's threads)
+    struct DivTables { int sdiv[256], hdiv[256]; DivTables() { sdiv[0] = hdiv[0] = 0; for (int i = 1; i < 256; ++i) { sdiv[i] = (int)std::lrint((255 << 12) / (1.0 * i)); hdiv[i] = (int)std::lrint((180 << 12) / (6.0 * i)); } } };
+    static const DivTables tables;
+    const int* sdiv = tables.sdiv;
+    const int* hdiv = tables.hdiv;
     int lo[3], hi[3];
     for (int k = 0; k < 3; ++k) { lo[k] = (int)std::lrint(lower[k]); hi[k] = (int)std::lrint(upper[k]); }
     if (stride == 0) stride = (size_t)w * 3;

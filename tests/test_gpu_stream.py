@@ -430,4 +430,25 @@ def test_colour_check_of_a_batch_in_one_call_beside_a_busy_lane(lm, orc, synth):
     out1, c1 = d.match_end(1, n_slots=4)
     for k in range(4):
         assert_matches_equal(out1[k, :c1[k]], exp[k])
+    # lm_color_mask_prepare: the masks computed on the lane AHEAD of the match; the check afterwards (same range) skips its mask launch
+    # and counts the same; another range recomputes; an upload invalidates the slot's mask (a stale mask would give the old frame's counts)
+    d.color_mask_prepare(1, 0, 4, lo, hi)
+    d.match_begin(1, 0, 4, THR, 0)
+    with pytest.raises(lm.LinemodError):
+        d.color_mask_prepare(1, 0, 4, lo, hi)                            # the lane is busy
+    out0, c0 = d.match_end(1, n_slots=4)
+    a2, b2 = d.color_check_counts_slots(slot_of, lo, hi, allm)
+    assert np.array_equal(a2, np.concatenate([s[0] for s in single])) and np.array_equal(b2, np.concatenate([s[1] for s in single]))
+    lo2, hi2 = (0, 0, 120), (255, 255, 255)
+    a3, b3 = d.color_check_counts_slots(slot_of, lo2, hi2, allm)
+    ref3 = [d.color_check_counts(k, lo2, hi2, lists[k]) for k in range(4)]
+    assert np.array_equal(b3, np.concatenate([r[1] for r in ref3])) and not np.array_equal(b3, b2)
+    d.color_mask_prepare(0, 0, 4, lo, hi)
+    d.upload_frame(0, *frames[3])                                        # slot 0 now holds another frame: its prepared mask is stale
+    d.match_begin(0, 0, 4, THR, 0)
+    d.match_end(0, n_slots=4)
+    a4, b4 = d.color_check_counts_slots(np.zeros(len(lists[0]), np.int32), lo, hi, lists[0])
+    d.upload_frame(5, *frames[3])
+    a5, b5 = d.color_check_counts(5, lo, hi, lists[0])                   # the same frame in a slot that never had a prepared mask
+    assert np.array_equal(a4, a5) and np.array_equal(b4, b5)
     d.close()

@@ -61,7 +61,7 @@ def test_facade_pool_and_waves_under_sanitizers(tmp_path, sanitizer):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=" + sanitizer, "-fno-omit-frame-pointer", "-pthread", "-o", exe,
                            os.path.join(ROOT, "tests", "cpp", "group_waves_tsan.cpp")])
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
-    for threads in (3, 16):                                  # fewer and more threads than this container has CPUs
+    for threads in (1, 3, 16):                               # the caller alone; fewer and more threads than this container has CPUs
         r = subprocess.run([exe, "150", str(threads)], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0 and r.stdout.strip().startswith("OK"), r.stdout[-1500:] + r.stderr[-4000:]
         assert "ThreadSanitizer" not in r.stderr and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
