@@ -23,12 +23,17 @@ namespace lmamd {
 
 // ---- the batch entry point for several classes, as a stream (r05) ---------------------------------------------------------------
 // One batch in flight: its slot set (= lane), the frames' views, the class list, the staging copies' task group.
+struct HighLevelLineMOD::Batch {
+    // the staging copies of a batch's pageable frames, running on the pool after Begin has returned
+    struct Staging { WorkerPool::Group group; std::atomic<long long> ns{0}; std::atomic<int> rc{LM_OK}; };
+    int set = 0, n = 0;
+    std::vector<std::vector<Image>> frames;
+    std::vector<uint16_t> classes;
+    std::unique_ptr<Staging> staging;     // pending staging copies (nullptr: none were needed)
+    bool begun = false;                   // the transfers and the match are enqueued (finishBegin has run)
+    std::string begin_error;              // why finishBegin failed (reported by the batch's End)
+};
 struct HighLevelLineMOD::Stream {
-    struct Batch {
-        int set = 0, n = 0;
-        std::vector<std::vector<Image>> frames;
-        std::vector<uint16_t> classes;
-    };
     std::deque<Batch> inflight;            // oldest first
     bool set_busy[kBatchSets] = {};
     int next_set = 0;
@@ -61,7 +66,12 @@ HighLevelLineMOD::HighLevelLineMOD(CameraParameters const& cam, TemplateGenerati
 HighLevelLineMOD::~HighLevelLineMOD() {
     if (stream_) {
         // batches still in flight: their lanes must finish before the detector goes away (results are dropped)
-        while (!stream_->inflight.empty()) { (void)lm_match_end(detector, stream_->inflight.front().set, nullptr, 0, nullptr); stream_->inflight.pop_front(); }
+        while (!stream_->inflight.empty()) {
+            Batch& fb = stream_->inflight.front();
+            if (fb.staging && stream_->pool) stream_->pool->wait(fb.staging->group);       // (the tasks hold pointers into the batch)
+            if (fb.begun && fb.begin_error.empty()) (void)lm_match_end(detector, fb.set, nullptr, 0, nullptr);
+            stream_->inflight.pop_front();
+        }
         delete stream_;
     }
     lm_destroy(detector);  // detector.release(), :50
@@ -231,9 +241,9 @@ bool HighLevelLineMOD::detectTemplatesBatchBegin(std::vector<std::vector<Image>>
     bool any_pageable = false;
     for (int i = 0; i < n; ++i) any_pageable |= !in_frames[(size_t)i][0].pinned;
     if (any_pageable && lm_stage_reserve(detector, first, n) != LM_OK) { error = lm_last_error(); return false; }
-    WorkerPool::Group staging;
-    std::atomic<long long> staging_ns{0};
-    std::atomic<int> stage_rc{LM_OK};
+    Batch b;
+    b.set = set; b.n = n; b.frames = in_frames; b.classes = in_classNumbers;
+    if (any_pageable) b.staging.reset(new Batch::Staging());
     const int rows_per_task = std::max(16, (int)((1 << 20) / ((size_t)videoWidth * (onlyColorModality ? 3 : 5))));
     for (int i = 0; i < n; ++i) {
         const Image& color = in_frames[(size_t)i][0];
@@ -243,7 +253,7 @@ bool HighLevelLineMOD::detectTemplatesBatchBegin(std::vector<std::vector<Image>>
             const int urc = lm_upload_frame_pinned_shifted(detector, first + i, static_cast<const uint8_t*>(color.data), color.stride,
                                                            match_depth ? static_cast<const uint16_t*>(match_depth->data) : nullptr, match_depth ? match_depth->stride : 0,
                                                            color.shift_x, color.shift_y);
-            if (urc != LM_OK) { error = lm_last_error(); st.pool->wait(staging); return false; }
+            if (urc != LM_OK) { error = lm_last_error(); if (b.staging) st.pool->wait(b.staging->group); return false; }
             continue;
         }
         for (int r0 = 0; r0 < videoHeight; r0 += rows_per_task) {
@@ -253,41 +263,62 @@ bool HighLevelLineMOD::detectTemplatesBatchBegin(std::vector<std::vector<Image>>
             const uint16_t* dp = match_depth ? static_cast<const uint16_t*>(match_depth->data) : nullptr;
             const size_t cs = color.stride, ds = match_depth ? match_depth->stride : 0;
             const int sx = color.shift_x, sy = color.shift_y, slot = first + i;
-            st.pool->submit(staging, [det, slot, cp, cs, dp, ds, sx, sy, r0, r1, &staging_ns, &stage_rc] {
+            Batch::Staging* sg = b.staging.get();
+            st.pool->submit(sg->group, [det, slot, cp, cs, dp, ds, sx, sy, r0, r1, sg] {
                 const clk::time_point t0 = clk::now();
                 const int rc = lm_stage_rows(det, slot, cp, cs, dp, ds, sx, sy, r0, r1);
-                if (rc != LM_OK) stage_rc.store(rc);
-                staging_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count());
+                if (rc != LM_OK) sg->rc.store(rc);
+                sg->ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count());
             }, true);
         }
     }
-    st.pool->wait(staging);
-    stageTimes.staging_cpu += (double)staging_ns.load() * 1e-9;
-    if (!staging.error.empty() || stage_rc.load() != LM_OK) { error = staging.error.empty() ? "staging copy failed (lm_stage_rows)" : staging.error; return false; }
+    st.inflight.push_back(std::move(b));
+    st.set_busy[set] = true;
+    st.next_set = (set + 1) % kBatchSets;
+    // Nothing older in flight: nobody else will drive this batch on, so the transfers and the match are enqueued here and now (the serial
+    // use, Begin; End).  Otherwise Begin returns at once: the staging copies run on the pool beside the older batch's End, which completes
+    // this batch (finishBegin) while its own colour check is on the GPU -- the host's share of an upload disappears behind work that is
+    // waiting anyway (r05: "in Begin" 68-160 us per frame with pageable frames before this).
+    bool ok = true;
+    if (st.inflight.size() == 1) ok = finishBegin(st.inflight.back());
+    stageTimes.upload += secs(t_up, clk::now());
+    return ok;
+}
+
+// The second half of Begin: the staging copies are in, the transfers and the class-list match go to the batch's lane.
+bool HighLevelLineMOD::finishBegin(Batch& b) {
+    using clk = std::chrono::steady_clock;
+    if (b.begun) return b.begin_error.empty();
+    b.begun = true;
+    Stream& st = *stream_;
+    const clk::time_point t0 = clk::now();
+    const int n = b.n, first = b.set * kBatchSlots, set = b.set;
+    auto failed = [&](const std::string& why) { b.begin_error = why; error = why; stageTimes.upload += std::chrono::duration<double>(clk::now() - t0).count(); return false; };
+    if (b.staging) {
+        st.pool->wait(b.staging->group);
+        stageTimes.staging_cpu += (double)b.staging->ns.load() * 1e-9;
+        if (!b.staging->group.error.empty() || b.staging->rc.load() != LM_OK)
+            return failed(b.staging->group.error.empty() ? "staging copy failed (lm_stage_rows)" : b.staging->group.error);
+    }
     for (int i = 0; i < n; ++i)
-        if (!in_frames[(size_t)i][0].pinned && lm_upload_staged(detector, first + i) != LM_OK) { error = lm_last_error(); return false; }
-    std::vector<int32_t> cls(in_classNumbers.begin(), in_classNumbers.end());
+        if (!b.frames[(size_t)i][0].pinned && lm_upload_staged(detector, first + i) != LM_OK) return failed(lm_last_error());
+    std::vector<int32_t> cls(b.classes.begin(), b.classes.end());
     if (gpuColorCheck) {
         // when the classes that will be post-processed share ONE HSV range (the usual case: one kind of part), the frames' colour masks are
         // computed on the lane ahead of the match, so that End's colour check is the hull launch alone
         const ModelProperties* range = nullptr;
         bool one = true;
-        for (uint16_t c : in_classNumbers) {
+        for (uint16_t c : b.classes) {
             if (!(c < modelTemplates->size()) || (*modelTemplates)[c].empty()) continue;
             static const ModelProperties kDefault;
             const ModelProperties* p = c < modProps->size() ? &(*modProps)[c] : &kDefault;
             if (!range) { range = p; continue; }
             for (int k = 0; k < 3; ++k) one = one && range->lowerColorRange[k] == p->lowerColorRange[k] && range->upperColorRange[k] == p->upperColorRange[k];
         }
-        if (range && one && lm_color_mask_prepare(detector, /*lane*/ set, first, n, range->lowerColorRange, range->upperColorRange) != LM_OK) { error = lm_last_error(); return false; }
+        if (range && one && lm_color_mask_prepare(detector, /*lane*/ set, first, n, range->lowerColorRange, range->upperColorRange) != LM_OK) return failed(lm_last_error());
     }
-    if (lm_match_begin_classes(detector, /*lane*/ set, first, n, detectorThreshold, cls.data(), (int)cls.size()) != LM_OK) { error = lm_last_error(); return false; }
-    Stream::Batch b;
-    b.set = set; b.n = n; b.frames = in_frames; b.classes = in_classNumbers;
-    st.inflight.push_back(std::move(b));
-    st.set_busy[set] = true;
-    st.next_set = (set + 1) % kBatchSets;
-    stageTimes.upload += secs(t_up, clk::now());
+    if (lm_match_begin_classes(detector, /*lane*/ set, first, n, detectorThreshold, cls.data(), (int)cls.size()) != LM_OK) return failed(lm_last_error());
+    stageTimes.upload += std::chrono::duration<double>(clk::now() - t0).count();
     return true;
 }
 
@@ -298,9 +329,25 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
     error.clear();
     if (!stream_ || stream_->inflight.empty()) { error = "no batch in flight"; out_matches.clear(); out_poses.clear(); return false; }
     Stream& st = *stream_;
-    const Stream::Batch b = std::move(st.inflight.front());
+    if (!finishBegin(st.inflight.front())) {      // (a no-op for a batch that has begun; a failed second half of Begin is reported here)
+        const std::string why = st.inflight.front().begin_error;
+        st.set_busy[st.inflight.front().set] = false;
+        st.inflight.pop_front();
+        out_matches.clear(); out_poses.clear();
+        error = why;
+        return false;
+    }
+    const Batch b = std::move(st.inflight.front());
     st.inflight.pop_front();
     st.set_busy[b.set] = false;
+    // the NEXT batch, if its Begin was deferred (completed below, right after this batch's lists are in)
+    double driven = 0;                    // (seconds of this End spent on the next batch's Begin: accounted as upload, not as post-processing)
+    auto drive_next = [&] {
+        if (st.inflight.empty() || st.inflight.front().begun) return;
+        const clk::time_point t = clk::now();
+        (void)finishBegin(st.inflight.front());
+        driven += secs(t, clk::now());
+    };
     const int n = b.n, first = b.set * kBatchSlots;
     const size_t nc = b.classes.size();
     out_matches.assign(nc, std::vector<std::vector<lm_match_t>>((size_t)n));
@@ -321,8 +368,12 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
         }
         if (rc != LM_OK) { error = lm_last_error(); return false; }
     }
+    // the next batch, if its Begin was deferred: its staging copies have been running on the pool since its Begin (this thread helps with
+    // what is left), now its transfers and its match go to the other lane -- before this batch's post-processing, which they run beside
+    drive_next();
     const clk::time_point t_post = clk::now();
-    stageTimes.match += secs(t_match, t_post); stageTimes.frames += n;
+    stageTimes.match += secs(t_match, t_post) - driven; stageTimes.frames += n;
+    driven = 0;
     PostProcessSettings ps;
     ps.onlyColorModality = onlyColorModality;
     ps.videoWidth = videoWidth; ps.videoHeight = videoHeight; ps.fy = fy;
@@ -501,7 +552,7 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
         stageTimes.poses += (long)r.poses.size();
         out_poses[r.u->c][(size_t)r.u->i].push_back(std::move(r.poses));
     }
-    stageTimes.post += secs(t_post, clk::now());
+    stageTimes.post += secs(t_post, clk::now()) - driven;
     return any;
 }
 

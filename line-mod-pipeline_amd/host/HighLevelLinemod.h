@@ -183,8 +183,10 @@ private:
     int postThreads = 0;
     StageTimes stageTimes;
     struct Stream;                       // the batches in flight + the pool (HighLevelLinemod.cpp)
+    struct Batch;                        // one batch in flight
     Stream* stream_ = nullptr;
     Stream& stream();
+    bool finishBegin(Batch& b);          // second half of Begin: staging copies in -> transfers + match enqueued on the batch's lane
     void readColorRanges();
     std::vector<std::vector<ObjectPose>> postProcess(const std::vector<lm_match_t>& in_matches, const Image& color,
                                                      const Image* depth_img, uint16_t in_classNumber, int gpu_slot);
