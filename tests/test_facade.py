@@ -45,14 +45,9 @@ def test_facade_bank_and_queries_cpu(lm, golden0, frame0, driver):
     _prepare(lm, golden0, frame0, d, "rgbd", False)
     out = _run(exe, d, False, 80.0)
     assert out[0] == "classes 1 templates 6" and out[1] == "class lagergehaeuse.ply"
-    # linemod_settings.yml in the reference's layout (its own values), read like utility.cpp does
-    (d / "linemod_settings.yml").write_text(
-        "%YAML:1.0\n---\n# ###### CAMERA PARAMETERS ######\nvideo width: 640\nvideo height: 480\ncamera fx: 1044.87\n"
-        "camera fy: 1045.69141\ncamera cx: 320\ncamera cy: 240\n\ndistortion parameters: !!opencv-matrix\n   rows: 1\n"
-        "   cols: 5\n   dt: d\n   data: [ -2.7167827743927644e-03, 2.0942424424199252e-01,\n       1.1120545920170163e-03, "
-        "-6.6420567497010334e-03, 0. ]\nmodel folder: models/\nmodel file ending: \".ply\"\nonly use color modality: 1\n"
-        "in plane rotation starting angle: -45\nin plane rotation stopping angle: 45\nin plane rotation angle step: 10\n"
-        "distance start: 500\ndistance stop: 1200\ndistance step: 50\ndetector threshold: 80\ndepth offset: 30\n")
+    # the reference's own linemod_settings.yml, byte for byte (tests/golden/reference_data/), read like utility.cpp does
+    import shutil
+    shutil.copyfile(os.path.join(ROOT, "tests", "golden", "reference_data", "linemod_settings.yml"), d / "linemod_settings.yml")
     out = _run(exe, d, False, 80.0)
     (d / "linemod_settings.yml").unlink()
     assert out[0] == "settings 640 480 1045.69141 -45 45 10 50 30.0 models/"
