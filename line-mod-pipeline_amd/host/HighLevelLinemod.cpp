@@ -389,13 +389,14 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
     std::vector<Unit> units;
     units.reserve(nc * (size_t)n);
     for (int i = 0; i < n; ++i) for (size_t c = 0; c < nc; ++c) { units.emplace_back(detector, ps); units.back().c = c; units.back().i = i; }
-    std::vector<PostProcessor::Times> frame_times((size_t)n);
+    std::vector<PostProcessor::Times> frame_times((size_t)n * nc);
     WorkerPool::Group grouping;
     for (int i = 0; i < n; ++i) {
         stageTimes.matches += counts[(size_t)i];
-        st.pool->submit(grouping, [&, i] {
+        for (size_t c = 0; c < nc; ++c)              // one task per (frame, class): 24 tasks for config 5's batch of 8 x 3 (a frame's three at once left half the pool idle)
+        st.pool->submit(grouping, [&, i, c] {
             const lm_match_t* m = buf.data() + cap * (size_t)i;
-            for (size_t c = 0; c < nc; ++c) {
+            {
                 // the mixed list is in the total order; a class's sub-list keeps it.  Match::operator== compares x, y, similarity and
                 // class; std::unique removed the ADJACENT duplicates of the mixed list, where a match of another class may sit between
                 // two equal ones of this class: filtering and removing adjacent duplicates once more gives exactly the list a one-class
@@ -406,9 +407,9 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
                     if (!dst.empty() && dst.back().x == m[k].x && dst.back().y == m[k].y && dst.back().similarity == m[k].similarity) continue;
                     dst.push_back(m[k]);
                 }
-                if (dst.empty()) continue;
+                if (dst.empty()) return;
                 const uint16_t cls_no = b.classes[c];
-                if (!(cls_no < modelTemplates->size()) || (*modelTemplates)[cls_no].empty()) continue;       // no template poses: no post-processing
+                if (!(cls_no < modelTemplates->size()) || (*modelTemplates)[cls_no].empty()) return;       // no template poses: no post-processing
                 Unit& u = units[(size_t)i * nc + c];
                 u.live = true;
                 u.tpl = &(*modelTemplates)[cls_no];
@@ -425,8 +426,8 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
                         u.depth = u.dense.data();
                     }
                 }
-                if (gpuColorCheck) u.prep = u.pp.prepare_groups(dst, *u.tpl, &frame_times[(size_t)i]);   // the colour counts follow, one GPU call per HSV range
-                else u.prep = u.pp.prepare(dst, static_cast<const uint8_t*>(color.data), color.stride, *u.tpl, u.props, -1, &frame_times[(size_t)i]);
+                if (gpuColorCheck) u.prep = u.pp.prepare_groups(dst, *u.tpl, &frame_times[(size_t)i * nc + c]);   // the colour counts follow, one GPU call per HSV range
+                else u.prep = u.pp.prepare(dst, static_cast<const uint8_t*>(color.data), color.stride, *u.tpl, u.props, -1, &frame_times[(size_t)i * nc + c]);
             }
         });
     }
