@@ -719,8 +719,9 @@ int copy_image(hipStream_t st, u8* dst, u8* staging, const u8* src, size_t strid
     for (int k = 0; k < chunks; ++k) {
         const int r0 = (int)((long long)rows * k / chunks), r1 = (int)((long long)rows * (k + 1) / chunks);
         if (r1 <= r0) continue;
-        if (stride == row_bytes) std::memcpy(staging + (size_t)r0 * row_bytes, src + (size_t)r0 * stride, (size_t)(r1 - r0) * row_bytes);
-        else for (int y = r0; y < r1; ++y) std::memcpy(staging + (size_t)y * row_bytes, src + (size_t)y * stride, row_bytes);
+        if (stride == row_bytes) lmh::copy_stream(staging + (size_t)r0 * row_bytes, src + (size_t)r0 * stride, (size_t)(r1 - r0) * row_bytes);
+        else for (int y = r0; y < r1; ++y) lmh::copy_stream(staging + (size_t)y * row_bytes, src + (size_t)y * stride, row_bytes);
+        lmh::copy_stream_fence();
         HIP_TRY(hipMemcpyAsync(dst + (size_t)r0 * row_bytes, staging + (size_t)r0 * row_bytes, (size_t)(r1 - r0) * row_bytes,
                                hipMemcpyHostToDevice, st));
     }
@@ -739,9 +740,10 @@ void stage_rows_shifted(u8* staging, const u8* src, size_t stride, int w, int h,
         u8* row = staging + (size_t)y * row_bytes;
         if (y < y0 || y >= y1 || x1 <= x0) { std::memset(row, 0, row_bytes); continue; }
         if (x0 > 0) std::memset(row, 0, (size_t)x0 * px);
-        std::memcpy(row + (size_t)x0 * px, src + (size_t)(y - oy) * stride + (size_t)(x0 - ox) * px, (size_t)(x1 - x0) * px);
+        lmh::copy_stream(row + (size_t)x0 * px, src + (size_t)(y - oy) * stride + (size_t)(x0 - ox) * px, (size_t)(x1 - x0) * px);     // non-temporal stores: the DMA engine reads this next
         if (x1 < w) std::memset(row + (size_t)x1 * px, 0, (size_t)(w - x1) * px);
     }
+    lmh::copy_stream_fence();
 }
 inline int clamp_shift(int v, int extent) { return v < -extent ? -extent : (v > extent ? extent : v); }
 

@@ -1,5 +1,8 @@
 // lm_host.cpp -- host-only parts of liblinemod_hip.so (see lm_host.h).
 #include "lm_host.h"
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -423,4 +426,32 @@ bool load_bank(Bank& bank, const lm_config& cfg, const char* path, std::string& 
     return true;
 }
 
+
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void copy_stream_avx2(unsigned char* d, const unsigned char* s, size_t n) {
+    const size_t head = (32 - (reinterpret_cast<uintptr_t>(d) & 31)) & 31;
+    if (head) { std::memcpy(d, s, head); d += head; s += head; n -= head; }
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i)), b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + 64)), e = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i), a); _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + 64), c); _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + 96), e);
+    }
+    for (; i + 32 <= n; i += 32) _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i), _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i)));
+    if (i < n) std::memcpy(d + i, s + i, n - i);
+}
+#endif
+void copy_stream(void* dst, const void* src, size_t n) {
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2 && n >= 256) { copy_stream_avx2(static_cast<unsigned char*>(dst), static_cast<const unsigned char*>(src), n); return; }
+#endif
+    std::memcpy(dst, src, n);
+}
+void copy_stream_fence() {
+#if defined(__x86_64__)
+    _mm_sfence();
+#endif
+}
 }  // namespace lmh

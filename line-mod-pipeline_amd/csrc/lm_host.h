@@ -88,4 +88,11 @@ void sort_unique(std::vector<lm_match_t>& v);
 bool save_bank(const Bank& bank, const lm_config& cfg, const char* path, std::string& err);
 bool load_bank(Bank& bank, const lm_config& cfg, const char* path, std::string& err);
 
+
+// memcpy for the staging copies of uploads (r05): the destination -- a pinned staging buffer -- is read next by the DMA engine, never by
+// this CPU, so the bytes go out with non-temporal stores (no read-for-ownership of the destination lines, no cache pollution: a
+// third less DRAM traffic for a copy that is bound by it).  Falls back to memcpy without AVX2 or for short runs.  copy_stream_fence()
+// once after a batch of calls, before the buffer is handed to the DMA engine.
+void copy_stream(void* dst, const void* src, size_t n);
+void copy_stream_fence();
 }  // namespace lmh

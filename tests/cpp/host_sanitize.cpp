@@ -76,6 +76,22 @@ int main(int argc, char** argv) {
     std::string text, err;
     if (!lmy::read_text_file(argv[1], text, err)) { std::printf("cannot read %s: %s\n", argv[1], err.c_str()); return 2; }
     const lm_config cfg0 = make_cfg(2);
+    // ---- r05: the staging copies' non-temporal memcpy against memcpy, every alignment of source and destination, lengths around its 32- /
+    // 128-byte steps and its fallback threshold; the bytes before and after the destination stay untouched
+    {
+        std::vector<unsigned char> src(5000), dst(5200), ref(5200);
+        for (size_t i = 0; i < src.size(); ++i) src[i] = (unsigned char)rng();
+        const size_t lens[] = {0, 1, 31, 32, 33, 127, 128, 129, 255, 256, 257, 300, 1000, 3840, 4097};
+        for (size_t len : lens)
+            for (size_t so = 0; so < 40; so += 7)
+                for (size_t dof = 0; dof < 70; dof += 9) {
+                    std::fill(dst.begin(), dst.end(), (unsigned char)0xAB); std::fill(ref.begin(), ref.end(), (unsigned char)0xAB);
+                    lmh::copy_stream(dst.data() + 64 + dof, src.data() + so, len);
+                    std::memcpy(ref.data() + 64 + dof, src.data() + so, len);
+                    lmh::copy_stream_fence();
+                    if (dst != ref) { std::printf("copy_stream differs from memcpy (len %zu, src +%zu, dst +%zu)\n", len, so, dof); return 1; }
+                }
+    }
     // ---- the valid file: parse, load, digest, write, re-load, bank file round trip
     lmh::Bank good;
     {
