@@ -25,7 +25,8 @@ namespace lmamd {
 // One batch in flight: its slot set (= lane), the frames' views, the class list, the staging copies' task group.
 struct HighLevelLineMOD::Batch {
     // the staging copies of a batch's pageable frames, running on the pool after Begin has returned
-    struct Staging { WorkerPool::Group group; std::atomic<long long> ns{0}; std::atomic<int> rc{LM_OK}; };
+    // (one task group per frame: a frame is handed to the DMA engine as soon as ITS rows are in, while the pool still copies the others)
+    struct Staging { WorkerPool::Group frame[kBatchSlots]; std::atomic<long long> ns{0}; std::atomic<int> rc{LM_OK}; };
     int set = 0, n = 0;
     std::vector<std::vector<Image>> frames;
     std::vector<uint16_t> classes;
@@ -68,7 +69,7 @@ HighLevelLineMOD::~HighLevelLineMOD() {
         // batches still in flight: their lanes must finish before the detector goes away (results are dropped)
         while (!stream_->inflight.empty()) {
             Batch& fb = stream_->inflight.front();
-            if (fb.staging && stream_->pool) stream_->pool->wait(fb.staging->group);       // (the tasks hold pointers into the batch)
+            if (fb.staging && stream_->pool) for (WorkerPool::Group& g : fb.staging->frame) stream_->pool->wait(g);       // (the tasks hold pointers into the batch)
             if (fb.begun && fb.begin_error.empty()) (void)lm_match_end(detector, fb.set, nullptr, 0, nullptr);
             stream_->inflight.pop_front();
         }
@@ -253,7 +254,7 @@ bool HighLevelLineMOD::detectTemplatesBatchBegin(std::vector<std::vector<Image>>
             const int urc = lm_upload_frame_pinned_shifted(detector, first + i, static_cast<const uint8_t*>(color.data), color.stride,
                                                            match_depth ? static_cast<const uint16_t*>(match_depth->data) : nullptr, match_depth ? match_depth->stride : 0,
                                                            color.shift_x, color.shift_y);
-            if (urc != LM_OK) { error = lm_last_error(); if (b.staging) st.pool->wait(b.staging->group); return false; }
+            if (urc != LM_OK) { error = lm_last_error(); if (b.staging) for (WorkerPool::Group& g : b.staging->frame) st.pool->wait(g); return false; }
             continue;
         }
         for (int r0 = 0; r0 < videoHeight; r0 += rows_per_task) {
@@ -264,7 +265,7 @@ bool HighLevelLineMOD::detectTemplatesBatchBegin(std::vector<std::vector<Image>>
             const size_t cs = color.stride, ds = match_depth ? match_depth->stride : 0;
             const int sx = color.shift_x, sy = color.shift_y, slot = first + i;
             Batch::Staging* sg = b.staging.get();
-            st.pool->submit(sg->group, [det, slot, cp, cs, dp, ds, sx, sy, r0, r1, sg] {
+            st.pool->submit(sg->frame[i], [det, slot, cp, cs, dp, ds, sx, sy, r0, r1, sg] {
                 const clk::time_point t0 = clk::now();
                 const int rc = lm_stage_rows(det, slot, cp, cs, dp, ds, sx, sy, r0, r1);
                 if (rc != LM_OK) sg->rc.store(rc);
@@ -294,14 +295,22 @@ bool HighLevelLineMOD::finishBegin(Batch& b) {
     const clk::time_point t0 = clk::now();
     const int n = b.n, first = b.set * kBatchSlots, set = b.set;
     auto failed = [&](const std::string& why) { b.begin_error = why; error = why; stageTimes.upload += std::chrono::duration<double>(clk::now() - t0).count(); return false; };
-    if (b.staging) {
-        st.pool->wait(b.staging->group);
-        stageTimes.staging_cpu += (double)b.staging->ns.load() * 1e-9;
-        if (!b.staging->group.error.empty() || b.staging->rc.load() != LM_OK)
-            return failed(b.staging->group.error.empty() ? "staging copy failed (lm_stage_rows)" : b.staging->group.error);
+    // the tasks were queued at the FRONT one after the other, so the pool takes them last frame first: frames are waited for, and sent,
+    // in that order -- the transfer of a frame runs while the rows of the next ones are still being copied
+    for (int i = n - 1; i >= 0; --i) {
+        if (b.frames[(size_t)i][0].pinned) continue;
+        st.pool->wait(b.staging->frame[i]);
+        if (!b.staging->frame[i].error.empty() || b.staging->rc.load() != LM_OK) {
+            for (int k = i - 1; k >= 0; --k) st.pool->wait(b.staging->frame[k]);
+            return failed(b.staging->frame[i].error.empty() ? "staging copy failed (lm_stage_rows)" : b.staging->frame[i].error);
+        }
+        if (lm_upload_staged(detector, first + i) != LM_OK) {
+            const std::string why = lm_last_error();
+            for (int k = i - 1; k >= 0; --k) st.pool->wait(b.staging->frame[k]);
+            return failed(why);
+        }
     }
-    for (int i = 0; i < n; ++i)
-        if (!b.frames[(size_t)i][0].pinned && lm_upload_staged(detector, first + i) != LM_OK) return failed(lm_last_error());
+    if (b.staging) stageTimes.staging_cpu += (double)b.staging->ns.load() * 1e-9;
     std::vector<int32_t> cls(b.classes.begin(), b.classes.end());
     if (gpuColorCheck) {
         // when the classes that will be post-processed share ONE HSV range (the usual case: one kind of part), the frames' colour masks are
