@@ -127,6 +127,8 @@ class Runner:
             det.set_tuning(lm.TUNE_WORK_WEIGHT, 0)
         if args.scan_list_order >= 0:
             det.set_tuning(lm.TUNE_SCAN_LIST_ORDER, args.scan_list_order)
+        if args.scan_form >= 0:
+            det.set_tuning(lm.TUNE_SCAN_FORM, args.scan_form)
         if args.no_prune:
             det.set_scan_variant(8)
         elif args.scan_variant:
@@ -199,9 +201,13 @@ class Runner:
         det.match_end(0, self.cap, out=self.views[0][0][0], counts=self.views[0][0][1])
         loaded, total = det.get_scan_stats()
         lane_issued, lane_total = det.get_scan_lane_stats()
+        form = det.get_scan_form_stats()
         det.set_scan_stats(False)
+        prof["scan1_lanes_per_frame"] = form[3]
+        prof["scan1_survivors_per_frame"] = form[2] / self.Bl if form[3] else None
         prof["features_loaded_fraction"] = loaded / total if total else 1.0
         prof["lane_loads_fraction"] = lane_issued / lane_total if lane_total else 1.0
+        prof["lane_loads_issued"] = lane_issued
         return prof
 
     def streaming(self, steps):
@@ -405,6 +411,7 @@ def main():
     ap.add_argument("--no-blur-pyr", action="store_true", help="A/B knob: level-0 blur and pyrDown as two launches (LM_TUNE_BLUR_PYR = 0)")
     ap.add_argument("--sort-split", type=int, default=-1, choices=(-1, 0, 1, 2), help="A/B knob: LM_TUNE_SORT_SPLIT (0 one workgroup per frame, 1 chunk workgroups + merge launch, 2 adaptive = default)")
     ap.add_argument("--scan-list-order", type=int, default=-1, choices=(-1, 0, 1, 2, 3), help="A/B knob: LM_TUNE_SCAN_LIST_ORDER (0 ascending offsets, 1 round-robin over orientations, 2 descending, 3 farthest-point = default)")
+    ap.add_argument("--scan-form", type=int, default=-1, choices=(-1, 0, 1, 2), help="A/B knob: LM_TUNE_SCAN_FORM (0 by cost = default, 1 the nibble scan k_scan4, 2 the bit-plane scan k_scan1)")
     ap.add_argument("--no-work-weight", action="store_true", help="A/B knob: few-frame / batch kernel selection by frame count alone (LM_TUNE_WORK_WEIGHT = 0, r03)")
     ap.add_argument("--no-pose-e2e", action="store_true", help="config 5: skip the pose_e2e leg (PoseDetection::detectBatch end to end, tools/pose_e2e_bench.cpp)")
     ap.add_argument("--pose-e2e-iters", type=int, default=20)
@@ -548,10 +555,12 @@ def main():
         n_matches0 = rep["matches0"]
 
     # ---- roofline of the dominant kernel (similarity scan)
-    kernel = "k_scan4" if not args.byte_responses else "k_scan"
+    kernel = "k_scan1" if one_lane.get("scan1_lanes_per_frame") else ("k_scan4" if not args.byte_responses else "k_scan")
     kept = one_lane.get("features_loaded_fraction", 1.0)
     kept_lanes = one_lane.get("lane_loads_fraction", kept)
     l2_bytes = rep["scan_load_bytes"] * Bl * kept_lanes      # bytes the scan's vector loads really request per launch (16 B per active lane)
+    if one_lane.get("lane_loads_issued"):
+        l2_bytes = 16.0 * one_lane["lane_loads_issued"]      # the same from the kernel's own count (both scan forms; one launch of Bl frames)
     span_us = prof["stage_us"][1] / max(prof["launches"], 1)
     alg_bytes = prof["scan_bytes"] / max(prof["launches"], 1)
     ol_us = one_lane["stage_us"][1] / max(one_lane["launches"], 1)
@@ -560,7 +569,7 @@ def main():
     traffic = traffic_src = None
     if ctr:
         for k, v in ctr["kernels"].items():
-            if k.startswith(kernel) and "hbm_bytes_per_launch" in v:
+            if kernel_is(k, kernel) and "hbm_bytes_per_launch" in v:
                 traffic, traffic_src = v["hbm_bytes_per_launch"], ctr["source"]
     l2c = ctr if ctr and any("TCP_TCC_READ_REQ_sum" in v for v in ctr["kernels"].values()) else None
 
@@ -594,6 +603,7 @@ def main():
                     "the other lane's kernels hold the chip, so it is not a kernel duration"},
         "stage_us_per_frame_one_lane": dict(zip(["preprocess", "scan", "refine", "sort"],
                                                 [round(v / max(one_lane["frames"], 1), 2) for v in one_lane["stage_us"]])),
+        "scan1_lanes_per_frame": one_lane.get("scan1_lanes_per_frame"), "scan1_survivors_per_frame": one_lane.get("scan1_survivors_per_frame"),
         "stage_note": "one lane alone on the chip: with LM_TUNE_BATCH_PHASES at its default (auto) the pre-processing of a lone "
                       "lane of 16+ frames runs as level-fused launches, while lanes that run beside others -- the timed region "
                       "with %d lanes -- take one launch per kernel (measured r03: fused wins alone, loses beside other lanes); "
@@ -604,7 +614,7 @@ def main():
         bpr = l2c["bytes_per_request"]
 
         def from_counters(prefix, us):
-            ks = [k for k in l2c["kernels"] if k.startswith(prefix)]
+            ks = [k for k in l2c["kernels"] if kernel_is(k, prefix)]
             if not ks or us <= 0:
                 return None
             c = l2c["kernels"][ks[0]]
@@ -729,7 +739,7 @@ def why_l2(runner, wl, traffic, alg_bytes, ctr, kernel):
     hit = None
     if ctr:
         for k, v in ctr["kernels"].items():
-            if k.startswith(kernel) and v.get("TCC_HIT_sum") is not None and v.get("TCC_MISS_sum") is not None and v["TCC_HIT_sum"] + v["TCC_MISS_sum"] > 0:
+            if kernel_is(k, kernel) and v.get("TCC_HIT_sum") is not None and v.get("TCC_MISS_sum") is not None and v["TCC_HIT_sum"] + v["TCC_MISS_sum"] > 0:
                 hit = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
                 msg += ", measured L2 hit rate %.1f %%" % (100.0 * hit)
     if fits:
@@ -744,6 +754,16 @@ def why_l2(runner, wl, traffic, alg_bytes, ctr, kernel):
     return msg
 
 
+def is_scan_kernel(k):
+    """the similarity scan's main kernel in a counter file (k_scan, k_scan4<..>, k_scan1 -- not k_scan1_exact, its short second half)"""
+    return k.startswith("k_scan") and not k.startswith("k_scan1_exact")
+
+
+def kernel_is(k, name):
+    """counter-file key k names kernel `name` (template arguments aside); a name that ends in '<' is a prefix"""
+    return k == name or k.startswith(name + "<") or (name.endswith("<") and k.startswith(name))
+
+
 def preprocess_roofline(ctr, reason, one_lane, Bl):
     """Per-kernel roofline entries of the pre-processing (a3-a10) and of every other kernel that takes >= 5 % of a one-lane step,
     from the committed counter file of THIS command (kernel stats + PMC passes): HBM-side bytes / clean duration against the
@@ -753,13 +773,13 @@ def preprocess_roofline(ctr, reason, one_lane, Bl):
         return {"kernels": None, "reason": reason}
     ks = ctr["kernels"]
     step_us = sum(v.get("avg_us", 0.0) * v.get("calls", 0) for v in ks.values() if v.get("calls", 0) >= 8)
-    calls = [v["calls"] for k, v in ks.items() if k.startswith("k_scan") and "calls" in v]
+    calls = [v["calls"] for k, v in ks.items() if is_scan_kernel(k) and "calls" in v]
     steps = max(calls) if calls else 1
     # shader clock under load: GRBM_GUI_ACTIVE of the longest kernel (the scan; the counter comes as ONE row per dispatch that sums the 8
     # XCDs) over its duration -- short kernels' GUI_ACTIVE contains launch overhead, so every kernel's cycles are its duration x this clock
     clock_ghz = None
     for k, v in ks.items():
-        if k.startswith("k_scan") and v.get("GRBM_GUI_ACTIVE") and v.get("avg_us"):
+        if is_scan_kernel(k) and v.get("GRBM_GUI_ACTIVE") and v.get("avg_us"):
             inst = max(v.get("GRBM_GUI_ACTIVE_instances", 1), 1)
             clock_ghz = v["GRBM_GUI_ACTIVE"] / (8.0 if inst == 1 else inst) / v["avg_us"] / 1e3
     out, pre_us, pre_bytes = [], 0.0, 0.0
@@ -966,10 +986,10 @@ def pipeline_roofline(ctr, reason, NL, ms_per_step, frames_per_step, Bl):
     ks = ctr["kernels"]
     clock_ghz = None
     for k, v in ks.items():
-        if k.startswith("k_scan") and v.get("GRBM_GUI_ACTIVE") and v.get("avg_us"):
+        if is_scan_kernel(k) and v.get("GRBM_GUI_ACTIVE") and v.get("avg_us"):
             inst = max(v.get("GRBM_GUI_ACTIVE_instances", 1), 1)
             clock_ghz = v["GRBM_GUI_ACTIVE"] / (8.0 if inst == 1 else inst) / v["avg_us"] / 1e3
-    calls = [v["calls"] for k, v in ks.items() if k.startswith("k_scan") and "calls" in v]
+    calls = [v["calls"] for k, v in ks.items() if is_scan_kernel(k) and "calls" in v]
     steps = max(calls) if calls else 1
     if not clock_ghz:
         return {"frac": None, "reason": "no shader clock in the counter file"}

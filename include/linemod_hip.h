@@ -256,6 +256,17 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
  *   orientations, so the exact pruning gives up on a work item sooner (49.7 -> 46.3 % of the feature loads on config 2).
  *   The similarity sums, and therefore every result, do not depend on it; changing it rebuilds the device bank. */
 #define LM_TUNE_SCAN_LIST_ORDER 15
+/* LM_TUNE_SCAN_FORM (r05): which kernel scans the lowest level when it keeps nibble-packed memories: 0 (default) = by cost -- the
+ *   bit-plane scan k_scan1 (counts the features a position MISSES on one bit per position and orientation, then takes the exact
+ *   sums of the few positions the miss bound leaves: k_scan1_exact) for detectors of ONE modality, when it needs at least a fifth
+ *   fewer waves than the nibble scan k_scan4 and the threshold is at least LM_TUNE_SCAN1_MIN_THRESHOLD (measured: +9 % on the
+ *   colour-only 1280 x 960 workload, a loss with two modalities, where k_scan4's exact pruning stops far sooner than the miss
+ *   bound); 1 = always k_scan4; 2 = k_scan1 whenever the level has planes.  The candidate lists, and therefore every result, are
+ *   the same. */
+#define LM_TUNE_SCAN_FORM 16
+/* LM_TUNE_SCAN1_MIN_THRESHOLD (r05): similarity threshold in percent (0..100, default 50) below which LM_TUNE_SCAN_FORM 0 keeps
+ *   k_scan4: the lower the threshold the more positions survive the miss bound and need their exact sums. */
+#define LM_TUNE_SCAN1_MIN_THRESHOLD 17
 int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 /* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame
@@ -486,6 +497,10 @@ int lm_get_scan_stats(lm_detector* det, uint64_t* features_loaded, uint64_t* fea
  * the threshold leaves the exec mask of the loads that follow.  lane_loads_issued: 16-byte lane-loads really made (a live
  * lane's right neighbour included); lane_loads_unpruned: 64 x the feature loads of an exhaustive scan. */
 int lm_get_scan_lane_stats(lm_detector* det, uint64_t* lane_loads_issued, uint64_t* lane_loads_unpruned);
+/* r05, the bit-plane scan (LM_TUNE_SCAN_FORM): out[0] = scan launches of lm_match* that took k_scan1 and out[1] = all of them since
+ * the detector was created; out[2] = positions that survived k_scan1's miss bound and had their exact sums taken since
+ * lm_set_scan_stats(1) (a superset of the candidates); out[3] = lanes per frame of the last scan launch (0: it was k_scan4). */
+int lm_get_scan_form_stats(lm_detector* det, int64_t out[4]);
 /* Selects the similarity-scan kernel variant used by lm_match* (0 = default; bits 0-1: features per load block;
  * bit 3 (value 8): no pruning, the plain exhaustive scan; bit 4 (value 16): wave-level pruning only, without the
  * per-lane exec masking; bit 5 (value 32): per-lane pruning also for one-modality detectors, which default to the

@@ -47,6 +47,8 @@ TUNE_BLUR_STRIP = 12
 TUNE_WORK_WEIGHT = 13
 TUNE_SORT_SPLIT = 14
 TUNE_SCAN_LIST_ORDER = 15
+TUNE_SCAN_FORM = 16
+TUNE_SCAN1_MIN_THRESHOLD = 17
 
 
 class Rect(C.Structure):
@@ -77,7 +79,7 @@ EXPORTS = [
     "lm_rendezvous_broadcast", "lm_normal_lut_is_substitute",
     "lm_set_scan_stats", "lm_get_scan_stats", "lm_color_check_counts",
     "lm_match_batch_classes", "lm_match_prepared", "lm_match_begin_classes", "lm_device_pci_bus_id",
-    "lm_get_exchange_profile", "lm_get_stage_counts", "lm_get_scan_lane_stats", "lm_match_classes",
+    "lm_get_exchange_profile", "lm_get_stage_counts", "lm_get_scan_lane_stats", "lm_get_scan_form_stats", "lm_match_classes",
     "lm_time_scan_batch",
     "lm_selftest_float_tail",
     "lm_upload_frame_pinned_shifted", "lm_stage_reserve", "lm_stage_rows", "lm_upload_staged", "lm_match_collect",
@@ -185,6 +187,7 @@ def load_library(path=None):
     lib.lm_device_pci_bus_id.argtypes = [vp, C.c_char_p, sz]
     lib.lm_get_exchange_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.lm_get_stage_counts.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.lm_get_scan_form_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.lm_get_scan_lane_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.lm_upload_frame_pinned_shifted.argtypes = [vp, i, vp, sz, vp, sz, i, i]
     lib.lm_stage_reserve.argtypes = [vp, i, i]
@@ -872,6 +875,13 @@ class Detector:
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self.lib.lm_get_scan_lane_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def get_scan_form_stats(self):
+        """(scan launches that took the bit-plane kernel, all scan launches, survivors of its miss bound since set_scan_stats(),
+        lanes per frame of the last scan launch -- 0: the nibble kernel)."""
+        v = (C.c_int64 * 4)()
+        self._check(self.lib.lm_get_scan_form_stats(self.h, v))
+        return tuple(int(x) for x in v)
 
     def set_scan_variant(self, variant):
         self._check(self.lib.lm_set_scan_variant(self.h, variant))

@@ -41,7 +41,9 @@ struct LmLevelGeom {
                        //    the low nibble of byte k); strides below stay in bytes, bank offsets are in nibbles
     u32 wh;            // W*H = positions per linear memory
     u32 ori_stride;    // response arena: T*T*wh (256-aligned) + pad; unused for spread arenas
-    u32 mod_stride;    // response arena: 8*ori_stride; spread arena: T*T*wh (256-aligned) + pad
+    u32 plane_ori;     // r05, nibble levels: bytes between the 8 miss-bit planes of a modality (k_scan1: one bit per position, T*T*wh / 8 bytes
+                       //    (256-aligned) + pad), which follow its 8 response memories; 0: none
+    u32 mod_stride;    // response arena: 8*ori_stride + 8*plane_ori; spread arena: T*T*wh (256-aligned) + pad
     u32 zero_off;      // offset (inside the level arena) of a zero block of `pad` bytes
     u32 arena_bytes;   // M*mod_stride + zero block
 };

@@ -157,6 +157,7 @@ struct lm_detector {
     u32* d_plan = nullptr;        // k_refine_plan output, one per lane: [8][cap] slots + [8] lengths + [8][cap + 1] running sums + [8][cap] first entries
     int plan_stride_cap = 0;
     u64* d_resp_tab = nullptr;
+    int miss_delta = 3;           // 4 - the largest response below 4 of the similarity table (ensure_luts)
     u32* d_sim_lut = nullptr;
     u8* d_normal_lut = nullptr;
     bool luts_dirty = true;
@@ -166,6 +167,15 @@ struct lm_detector {
     u32* d_item_t = nullptr; u32* d_item_chunk = nullptr;
     u32* d_scan_off = nullptr; int* d_scan_P = nullptr; int* d_scan_n = nullptr;
     int* d_t_global = nullptr; int* d_t_class = nullptr;
+    // bit-plane scan (k_scan1): the concatenated offset lists, and the work items of the lane counts used so far
+    u32* d_off1 = nullptr; u32* d_offn = nullptr;
+    struct Items1 { int L = 0; u32* d_t = nullptr; u32* d_chunk = nullptr; std::vector<int> begin; };
+    std::vector<Items1> items1;
+    int scan_form = 0;               // LM_TUNE_SCAN_FORM: 0 = by cost (default), 1 = always the nibble scan k_scan4, 2 = the bit-plane scan k_scan1 whenever the level has planes
+    float scan1_min_threshold = 50.0f;   // below this similarity threshold the miss bound keeps too many positions alive: k_scan4 (LM_TUNE_SCAN1_MIN_THRESHOLD)
+    long long cnt_scan1_launches = 0; int last_scan1_lanes = 0;
+    unsigned long long* d_surv[LM_NLANES] = {};      // k_scan1's survivor queues, one per lane, allocated on a lane's first bit-plane scan
+    u32 surv_cap = 1u << 20;
     LmRefMeta* d_ref_meta[LM_MAX_LEVELS] = {};
     LmRefFeat* d_ref_feat[LM_MAX_LEVELS] = {};
     // scratch for stage hooks
@@ -203,6 +213,9 @@ bool any_lane_busy(const lm_detector* d) {
 void free_device_bank(lm_detector* d) {
     hipFree(d->d_item_t); hipFree(d->d_item_chunk); hipFree(d->d_scan_off); hipFree(d->d_scan_P);
     hipFree(d->d_scan_n); hipFree(d->d_t_global); hipFree(d->d_t_class);
+    hipFree(d->d_off1); hipFree(d->d_offn); d->d_off1 = d->d_offn = nullptr;
+    for (auto& it : d->items1) { hipFree(it.d_t); hipFree(it.d_chunk); }
+    d->items1.clear();
     d->d_item_t = d->d_item_chunk = d->d_scan_off = nullptr;
     d->d_scan_P = d->d_scan_n = d->d_t_global = d->d_t_class = nullptr;
     for (int l = 0; l < LM_MAX_LEVELS; ++l) {
@@ -282,7 +295,7 @@ int ensure_device(lm_detector* d) {
     }
     // pinned staging for pageable sources is allocated on a slot's first staged upload (ensure_staging): a
     // streaming server that hands over pinned frames (lm_upload_frame_pinned) never needs it
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_resp_tab), 256 * sizeof(u64)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_resp_tab), 256 * sizeof(u64) + 256));   // + the miss masks of the 256 spread bytes (d_lm_fast's planes)
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_scan_stat), 4096 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(d->d_scan_stat, 0, 4096 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_sim_lut), 256));
@@ -296,15 +309,20 @@ int ensure_device(lm_detector* d) {
 
 int ensure_luts(lm_detector* d) {
     if (!d->luts_dirty) return LM_OK;
-    u64 tab[256];
+    u64 tab[256 + 32];
+    u8* miss = reinterpret_cast<u8*>(tab + 256);       // bit o of miss[v]: orientation o's response to the spread byte v is below 4
+    int below4 = 0;                                    // the largest response below 4 the table can give
     for (int v = 0; v < 256; ++v) {
         u64 e = 0;
+        miss[v] = 0;
         for (int o = 0; o < 8; ++o) {
             u8 r = std::max(d->sim_lut[32 * o + (v & 15)], d->sim_lut[32 * o + 16 + (v >> 4)]);
             e |= (u64)r << (8 * o);
+            if (r < 4) { miss[v] |= (u8)(1u << o); below4 = std::max(below4, (int)r); }
         }
         tab[v] = e;
     }
+    d->miss_delta = 4 - below4;                        // what a missed feature costs at least (k_scan1's bound): 3 with the default table
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(d->d_resp_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d->d_sim_lut, d->sim_lut, 256, hipMemcpyHostToDevice));
@@ -335,6 +353,10 @@ int ensure_bank(lm_detector* d) {
     if ((rc = upload_vec(&d->d_scan_off, d->hb.scan_off))) return rc;
     if ((rc = upload_vec(&d->d_scan_P, d->hb.scan_P))) return rc;
     if ((rc = upload_vec(&d->d_scan_n, d->hb.scan_n))) return rc;
+    if (d->hb.fpad1) {
+        if ((rc = upload_vec(&d->d_off1, d->hb.off1))) return rc;
+        if ((rc = upload_vec(&d->d_offn, d->hb.offn))) return rc;
+    }
     if ((rc = upload_vec(&d->d_t_global, d->hb.t_global))) return rc;
     if ((rc = upload_vec(&d->d_t_class, d->hb.t_class))) return rc;
     for (int l = 0; l + 1 < d->cfg.pyramid_levels; ++l) {
@@ -375,10 +397,10 @@ void enqueue_lm(lm_detector* d, hipStream_t st, int first, int n, int l, int m) 
     const int sp = g.spread_only ? 1 : g.nibble ? 2 : 0;
     u8* dst = d->lm(first, l) + (size_t)m * g.mod_stride;
     if (m == 0 || l == 0)
-        lmk_linear_memories(st, d->quant(first, l, m), g.w, 0, sp, g.w, g.h, g.T, d->d_resp_tab, dst, g.ori_stride, fs, fs, n);
+        lmk_linear_memories(st, d->quant(first, l, m), g.w, 0, sp, g.w, g.h, g.T, d->d_resp_tab, dst, g.ori_stride, fs, fs, n, g.plane_ori);
     else   // level l of the depth modality reads the quantised image of level l-1 at (2y, 2x)
         lmk_linear_memories(st, d->quant(first, l - 1, 1), d->lw[l - 1], 1, sp, g.w, g.h, g.T, d->d_resp_tab, dst,
-                            g.ori_stride, fs, fs, n);
+                            g.ori_stride, fs, fs, n, g.plane_ori);
 }
 
 // How many 640 x 480 frames one frame of this detector counts as in the few-frame / batch kernel selection (at least 1).
@@ -413,7 +435,7 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
         pa.lm_d0 = d->lm(first, 0) + d->geom[0].mod_stride; pa.lm_d1 = d->lm(first, 1) + d->geom[1].mod_stride;
         pa.w = d->lw[0]; pa.h = d->lh[0];
         pa.weak_threshold = c.weak_threshold; pa.dist_thr = c.distance_threshold; pa.diff_thr = c.difference_threshold;
-        pa.normal_lut = d->d_normal_lut; pa.resp_tab = d->d_resp_tab; pa.ori_stride1 = d->geom[1].ori_stride;
+        pa.normal_lut = d->d_normal_lut; pa.resp_tab = d->d_resp_tab; pa.ori_stride1 = d->geom[1].ori_stride; pa.plane_ori1 = d->geom[1].plane_ori;
         pa.slot_stride = fs; pa.nslots = n;
         auto mode = [&](int l) { return d->geom[l].spread_only ? 1 : d->geom[l].nibble ? 2 : 0; };
         const bool onehot = M == 2 ? normal_lut_onehot(d) : true;
@@ -450,12 +472,15 @@ void fill_raw_thr(int* tab, float threshold) {
     for (int n = 0; n < 128; ++n) tab[n] = static_cast<int>(2 * n + (threshold / 100.f) * (2 * n) + 0.5f);
 }
 
-struct ItemRange { int lo, n; };
+struct ItemRange { int lo, n; int t_lo, t_hi; };   // items of the nibble / byte scan, and the bank-local templates they belong to
 int item_range(lm_detector* d, int class_idx, ItemRange* r) {
     const int nc = (int)d->bank.classes.size();
     if (class_idx >= nc || class_idx < -1) return fail(LM_ERR_INVALID, "class index out of range");
-    if (class_idx < 0) { r->lo = 0; r->n = (int)d->hb.item_t.size(); }
-    else { r->lo = d->hb.class_item_lo[class_idx]; r->n = d->hb.class_item_hi[class_idx] - r->lo; }
+    if (class_idx < 0) { r->lo = 0; r->n = (int)d->hb.item_t.size(); r->t_lo = 0; r->t_hi = (int)d->hb.t_global.size(); }
+    else {
+        r->lo = d->hb.class_item_lo[class_idx]; r->n = d->hb.class_item_hi[class_idx] - r->lo;
+        r->t_lo = d->hb.class_t_lo[class_idx]; r->t_hi = d->hb.class_t_hi[class_idx];
+    }
     return LM_OK;
 }
 
@@ -472,21 +497,64 @@ int item_ranges(lm_detector* d, std::vector<int>& classes, std::vector<ItemRange
     if (classes.empty() || classes[0] < 0) {
         if (classes.size() > 1) return fail(LM_ERR_INVALID, "class index -1 (all classes) cannot be combined with others");
         classes.assign(1, -1);
-        out.push_back(ItemRange{0, (int)d->hb.item_t.size()});
+        out.push_back(ItemRange{0, (int)d->hb.item_t.size(), 0, (int)d->hb.t_global.size()});
         return LM_OK;
     }
     for (int c : classes) {
         const int lo = d->hb.class_item_lo[c], hi = d->hb.class_item_hi[c];
-        if (!out.empty() && out.back().lo + out.back().n == lo) out.back().n += hi - lo;
-        else out.push_back(ItemRange{lo, hi - lo});
+        if (!out.empty() && out.back().lo + out.back().n == lo && out.back().t_hi == d->hb.class_t_lo[c]) { out.back().n += hi - lo; out.back().t_hi = d->hb.class_t_hi[c]; }
+        else out.push_back(ItemRange{lo, hi - lo, d->hb.class_t_lo[c], d->hb.class_t_hi[c]});
     }
     return LM_OK;
 }
 
-LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r) {
+// Which scan a launch over `nslots` frames takes (r05).  The bit-plane scan k_scan1 issues about as many vector instructions per
+// wave and feature as the nibble scan k_scan4, and a wave of either is one work item for a group of frames: 64 / L1 frames of
+// chunks of 128 L1 - 31 positions there, two frames of chunks of 1016 here.  So the form with fewer waves wins; L1 is the lane count
+// with the fewest.  k_scan1 needs a margin (its waves stop when the LAST of their frames is out of reach, and the survivors' exact
+// sums come on top), and a threshold high enough for the miss bound to bite.  Returns L1, or 0 for k_scan4 / k_scan.
+int pick_scan1_lanes(const lm_detector* d, int nslots) {
+    const LmLevelGeom& g = d->geom[d->cfg.pyramid_levels - 1];
+    if (!g.nibble || !g.plane_ori || !d->hb.fpad1 || d->scan_form == 1) return 0;
+    if (d->scan_form != 2 && !(d->raw_thr_for >= d->scan1_min_threshold)) return 0;
+    // measured r05 (profiles/r05_ab_experiments.log, three lanes): colour-only config 3 +9 % (the scan launch 389 -> 296 us per 128 frames), but
+    // RGB-D config 2 -2 % and config 5 -18 %: with two modalities the exact deficits of k_scan4's pruning stop a work item after 29-46 % of its
+    // features, the miss bound after 66-84 %.  By cost = one modality only.
+    if (d->scan_form != 2 && d->cfg.num_modalities != 1) return 0;
+    long long best = -1; int bestL = 0;
+    for (int L1 = 1; L1 <= 64; ++L1) {
+        const int G1 = 64 / L1;
+        // a wave's buffer descriptor starts at its group's first frame: the last frame's arena must end below 2^31 bytes
+        if ((size_t)(G1 - 1) * d->frame_stride + g.arena_bytes >= 0x7FFFFFFFull) continue;
+        const long long waves = d->hb.items1_by_L[L1] * ((nslots + G1 - 1) / G1);
+        if (best < 0 || waves < best) { best = waves; bestL = L1; }
+    }
+    if (bestL == 0) return 0;
+    const long long waves4 = (long long)d->hb.item_t.size() * ((nslots + 1) / 2);
+    if (d->scan_form != 2 && best * 5 > waves4 * 4) return 0;
+    return bestL;
+}
+
+// the work items of k_scan1 for L1 lanes per frame, built and uploaded on first use
+int ensure_items1(lm_detector* d, int L1, const lm_detector::Items1** out) {
+    for (const auto& it : d->items1) if (it.L == L1) { *out = &it; return LM_OK; }
+    std::vector<u32> t, c;
+    lm_detector::Items1 it;
+    it.L = L1;
+    lmh::build_items1(d->hb, L1, t, c, it.begin);
+    int rc;
+    if ((rc = upload_vec(&it.d_t, t))) return rc;
+    if ((rc = upload_vec(&it.d_chunk, c))) { hipFree(it.d_t); return rc; }
+    d->items1.push_back(std::move(it));
+    *out = &d->items1.back();
+    return LM_OK;
+}
+
+LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots = 1) {
     const int L = d->cfg.pyramid_levels;
     const LmLevelGeom& g = d->geom[L - 1];
     LmScanArgs a;
+    a.L1 = 0; a.G1 = 1; a.L1_rcp16 = 0; a.delta_rcp16 = 0; a.off1 = a.offn = nullptr; a.fpad1 = 0; a.no_exact = 0; a.surv = nullptr; a.surv_cap = 0;
     a.lm = d->lm(first, L - 1); a.lm_slot_stride = d->frame_stride;
     a.item_t = d->d_item_t; a.item_chunk = d->d_item_chunk;
     a.item_lo = r.lo; a.n_items = r.n;
@@ -499,6 +567,20 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r) {
     a.cand = reinterpret_cast<LmCand*>(d->aux(first, d->off_cand));
     a.aux_slot_stride = d->aux_stride;
     a.cand_cap = d->max_cand;
+    const int L1 = pick_scan1_lanes(d, nslots);
+    const lm_detector::Items1* it = nullptr;
+    if (L1 && ensure_items1(d, L1, &it) == LM_OK) {
+        a.L1 = L1; a.G1 = 64 / L1;
+        a.L1_rcp16 = (65536u + (u32)L1 - 1u) / (u32)L1;
+        a.delta_rcp16 = (65536u + (u32)d->miss_delta - 1u) / (u32)d->miss_delta;
+        a.off1 = d->d_off1; a.offn = d->d_offn; a.fpad1 = d->hb.fpad1;
+        a.item_t = it->d_t; a.item_chunk = it->d_chunk;
+        a.item_lo = it->begin[(size_t)r.t_lo]; a.n_items = it->begin[(size_t)r.t_hi] - a.item_lo;
+        unsigned long long*& q = d->d_surv[d->active];
+        if (!q && hipMalloc(reinterpret_cast<void**>(&q), (1 + (size_t)d->surv_cap) * sizeof(unsigned long long)) != hipSuccess) { q = nullptr; (void)hipGetLastError(); }
+        a.surv = q; a.surv_cap = d->surv_cap;       // (no queue: the waves take their survivors' exact sums themselves)
+        if (g.wh >= (1u << 20) || nslots > 4096) a.surv = nullptr;      // the entry's 20-bit position / 12-bit slot
+    }
     return a;
 }
 
@@ -552,7 +634,11 @@ int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, cons
     if (timed) HIP_TRY(hipEventRecord(d->ev[1], d->stream));
     // one scan launch per run of neighbouring classes; the launches append to the same candidate lists
     for (const ItemRange& r : ranges)
-        if (r.n > 0) { lmk_scan(d->stream, make_scan_args(d, first, r), d->scan_variant, n); d->cnt_scan_launches += 1; }
+        if (r.n > 0) {
+            const LmScanArgs sa = make_scan_args(d, first, r, n);
+            lmk_scan(d->stream, sa, d->scan_variant, n);
+            d->cnt_scan_launches += 1; d->cnt_scan1_launches += sa.L1 ? 1 : 0; d->last_scan1_lanes = sa.L1;
+        }
     if (timed) HIP_TRY(hipEventRecord(d->ev[2], d->stream));
     if (L == 1) {
         lmk_emit_unrefined(d->stream, make_refine_args(d, first, 0, threshold), n);
@@ -1001,10 +1087,15 @@ int lm_create(const lm_config* cfg, lm_detector** out) {
         // responses are <= 4: the scanned level packs two positions per byte when the linearize fast path applies
         g.nibble = (!g.spread_only && !(c.flags & LM_FLAG_BYTE_RESPONSES) && lmk_nibble_supported(w, h, T)) ? 1 : 0;
         size_t ori = align_up(((size_t)T * T * g.wh) >> g.nibble, 256) + pad;
-        size_t mod = g.spread_only ? ori : 8 * ori;
+        // r05: next to the nibble memories one miss BIT per position and orientation (k_scan1); a scan may start wh - 1 bits into the last
+        // plane's last memory and its 64 lanes read 128 bits each
+        size_t plane = g.nibble ? align_up(((size_t)T * T * g.wh + 7) / 8 + ((size_t)g.wh + 64 * 128) / 8 + 64, 256) : 0;
+        if (g.nibble && (size_t)c.num_modalities * (8 * ori + 8 * plane) + pad > 0x1FFFFFFFull) plane = 0;     // bit offsets are 32-bit
+        size_t mod = g.spread_only ? ori : 8 * ori + 8 * plane;
         size_t arena = (size_t)c.num_modalities * mod + pad;
         if (arena > (g.spread_only ? 0x1FFFFFFFull : g.nibble ? 0x7FFFFFFFull : 0xFFFFFFFFull)) { delete d; return fail(LM_ERR_INVALID, "frame too large for the arena offset encoding"); }
         g.ori_stride = (u32)ori;
+        g.plane_ori = (u32)plane;
         g.mod_stride = (u32)mod;
         g.zero_off = (u32)((size_t)c.num_modalities * g.mod_stride);
         g.arena_bytes = (u32)arena;
@@ -1031,6 +1122,7 @@ void lm_destroy(lm_detector* d) {
         for (auto& cs : d->copy_stream) if (cs) hipStreamDestroy(cs);
         hipFree(d->frame_arena); hipFree(d->aux_arena); hipHostFree(d->host_blocks);
         hipFree(d->d_raw_thr); hipHostFree(d->h_raw_thr); hipFree(d->d_plan);
+        for (auto& q : d->d_surv) { hipFree(q); q = nullptr; }
         activate_lane(d, 0);
         for (auto& ev : d->blocking_ev) if (ev) hipEventDestroy(ev);
         for (auto& ev : d->ev) if (ev) hipEventDestroy(ev);
@@ -1373,6 +1465,8 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
         case LM_TUNE_WORK_WEIGHT: if (value < 0 || value > 1) break; d->work_weight_by_pixels = value; return LM_OK;
         case LM_TUNE_SORT_SPLIT: if (value < 0 || value > 2) break; d->sort_split_mode = value; return LM_OK;
         case LM_TUNE_SCAN_LIST_ORDER: if (value < 0 || value > 3) break; d->scan_list_order = value; d->bank_dirty = true; return LM_OK;
+        case LM_TUNE_SCAN_FORM: if (value < 0 || value > 2) break; d->scan_form = value; return LM_OK;
+        case LM_TUNE_SCAN1_MIN_THRESHOLD: if (value < 0 || value > 100) break; d->scan1_min_threshold = (float)value; return LM_OK;
         default: return fail(LM_ERR_INVALID, "unknown tuning key");
     }
     return fail(LM_ERR_INVALID, "tuning value out of range");
@@ -2541,7 +2635,7 @@ int lm_time_scan_batch(lm_detector* d, int first_slot, int n_slots, float thresh
     ItemRange r;
     if ((rc = item_range(d, class_idx, &r))) return rc;
     if ((rc = enqueue_threshold(d, threshold))) return rc;
-    LmScanArgs a = make_scan_args(d, first_slot, r);
+    LmScanArgs a = make_scan_args(d, first_slot, r, n_slots);
     a.cand_cap = 0;
     for (int i = 0; i < 2; ++i) lmk_scan(d->stream, a, variant, n_slots);
     HIP_TRY(hipEventRecord(d->ev[0], d->stream));
@@ -2675,6 +2769,20 @@ int lm_get_scan_lane_stats(lm_detector* d, uint64_t* lane_loads_issued, uint64_t
     for (int i = 0; i < 1024; ++i) { a += h[4 * i + 2]; b += h[4 * i + 1]; }
     if (lane_loads_issued) *lane_loads_issued = a;
     if (lane_loads_unpruned) *lane_loads_unpruned = 64ull * b;
+    return LM_OK;
+}
+
+int lm_get_scan_form_stats(lm_detector* d, int64_t out[4]) {
+    int rc;
+    if (!out) return fail(LM_ERR_INVALID, "null argument");
+    if ((rc = ready_for_compute(d))) return rc;
+    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+    std::vector<unsigned long long> h(4096);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h.data(), d->d_scan_stat, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long sv = 0;
+    for (int i = 0; i < 1024; ++i) sv += h[4 * i + 3];
+    out[0] = d->cnt_scan1_launches; out[1] = d->cnt_scan_launches; out[2] = (int64_t)sv; out[3] = d->last_scan1_lanes;
     return LM_OK;
 }
 

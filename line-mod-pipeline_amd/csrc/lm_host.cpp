@@ -127,6 +127,14 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
     out.class_t_lo.assign(nc, 0); out.class_t_hi.assign(nc, 0);
     out.class_alg_bytes.assign(nc, 0.0);
     out.class_load_bytes.assign(nc, 0.0);
+    const bool planes = gl.nibble && gl.plane_ori != 0;
+    if (planes) out.fpad1 = (std::min(M * maxf, 2 * LM_MAX_FEATURES) + 3) / 4 * 4;
+    // a list entry's bit offset from its nibble offset: the planes of a modality follow its 8 response memories
+    auto plane_bit_off = [&](u32 noff) {
+        const u32 base = noff / 2u, m = base / gl.mod_stride, label = (base - m * gl.mod_stride) / gl.ori_stride;
+        const u32 rest = noff - 2u * (m * gl.mod_stride + label * gl.ori_stride);
+        return 8u * (m * gl.mod_stride + 8u * gl.ori_stride + label * gl.plane_ori) + rest;
+    };
     for (int ci = 0; ci < nc; ++ci) {
         const ClassEntry& c = bank.classes[ci];
         int lo, hi;
@@ -220,6 +228,16 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
                 }
                 for (; k < out.fpad; ++k) out.scan_off.push_back(osc * gl.zero_off);
             }
+            if (planes) {
+                const size_t b1 = out.off1.size();
+                for (int m = 0; m < M; ++m) {
+                    const int k = (cnt_packed >> (8 + 8 * m)) & 0xFF;
+                    const size_t lb = ((size_t)ti * M + m) * out.fpad;
+                    for (int q = 0; q < k; ++q) { out.offn.push_back(out.scan_off[lb + q]); out.off1.push_back(plane_bit_off(out.scan_off[lb + q])); }
+                }
+                while (out.off1.size() < b1 + (size_t)out.fpad1) { out.offn.push_back(2u * gl.zero_off); out.off1.push_back(8u * gl.zero_off); }
+                for (int L1 = 1; L1 <= 64; ++L1) out.items1_by_L[L1] += (P + (128 * L1 - 31) - 1) / (128 * L1 - 31);
+            }
             const int chunk = gl.nibble ? LM_SCAN4_CHUNK : LM_SCAN_CHUNK;
             out.scan_P.push_back(P);
             out.scan_n.push_back(n_total | cnt_packed);   // n (bits 0-7) | in-bounds features of modality 0 / 1 (bits 8-15 / 16-23)
@@ -259,6 +277,16 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
         out.class_item_hi[ci] = (int)out.item_t.size();
     }
     return true;
+}
+
+void build_items1(const DeviceBankHost& hb, int L, std::vector<u32>& item_t, std::vector<u32>& item_chunk, std::vector<int>& begin) {
+    const int chunk = 128 * L - 31;
+    item_t.clear(); item_chunk.clear(); begin.clear();
+    for (size_t t = 0; t < hb.scan_P.size(); ++t) {
+        begin.push_back((int)item_t.size());
+        for (int ch = 0; ch * chunk < hb.scan_P[t]; ++ch) { item_t.push_back((u32)t); item_chunk.push_back((u32)ch); }
+    }
+    begin.push_back((int)item_t.size());
 }
 
 void build_hull_table(const Bank& bank, int M, HullTable& out) {

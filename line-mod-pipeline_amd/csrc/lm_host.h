@@ -53,7 +53,15 @@ struct DeviceBankHost {
     std::vector<double> class_load_bytes;          // bytes the scan's vector loads request per frame, per class
     std::vector<LmRefMeta> ref_meta[LM_MAX_LEVELS];
     std::vector<LmRefFeat> ref_feat[LM_MAX_LEVELS];
+    // bit-plane scan (k_scan1, r05; only when the scanned level has planes): the in-bounds features of all modalities as ONE list per
+    // template, in the lists' order -- bit offsets of the miss planes and the same features' nibble offsets
+    int fpad1 = 0;
+    std::vector<u32> off1, offn;                   // [nt][fpad1]
+    long long items1_by_L[65] = {};                // work items when a frame takes L lanes: sum over templates of ceil(P / (128 L - 31))
 };
+// k_scan1's work items for L lanes per frame (chunks of 128 L - 31 positions), template-major like item_t / item_chunk; begin[t] =
+// first item of bank-local template t (begin[nt] = number of items)
+void build_items1(const DeviceBankHost& hb, int L, std::vector<u32>& item_t, std::vector<u32>& item_chunk, std::vector<int>& begin);
 
 // Contiguous template_id range of shard `rank` of `size` for a class of n templates.
 inline void shard_range(int n, int rank, int size, int* lo, int* hi) {

@@ -41,7 +41,7 @@ void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_
 bool lmk_nibble_supported(int w, int h, int T);
 void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, int mode, int w, int h, int T,
                          const u64* resp_tab, u8* lm, u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
-                         int nslots);
+                         int nslots, u32 plane_ori = 0);
 
 struct LmScanArgs {
     const u8* lm;            // lowest level arena of slot 0
@@ -60,8 +60,18 @@ struct LmScanArgs {
     LmCand* cand;
     size_t aux_slot_stride;
     u32 cand_cap;
-    unsigned long long* stat; // optional [1024][2] counters: features loaded / features an unpruned scan loads (k_scan4)
+    unsigned long long* stat; // optional [1024][4] counters: features loaded / features an unpruned scan loads / lane-loads issued / (k_scan1) survivors whose exact sums were taken
     int wgs_per_slot, nslots; // filled by lmk_scan
+    // bit-plane form (k_scan1, r05), L1 != 0: item_t / item_chunk are then the items of chunks of 128 L1 - 31 positions
+    int L1, G1;               // lanes per frame, frames per wave (64 / L1)
+    u32 L1_rcp16;             // ceil(65536 / L1): lane / L1 = (lane * L1_rcp16) >> 16 for lane < 64
+    u32 delta_rcp16;          // ceil(65536 / delta), delta = 4 - the largest response below 4 of the similarity table
+    const u32* off1;          // [nt][fpad1] BIT offsets of the features' miss planes in the arena (all modalities, one list)
+    const u32* offn;          // [nt][fpad1] the same features' nibble offsets (exact sums of the survivors)
+    int fpad1;
+    int no_exact;             // measurement only (scan variant bit 7, WRONG lists): the survivors' exact sums are skipped
+    unsigned long long* surv; // survivor queue of the launch's stream: [0] = entries appended (may exceed the capacity), [1 + i] = template << 32 |
+    u32 surv_cap;             //    slot << 20 | position; k_scan1_exact takes their exact sums.  null / overflow: the wave does it itself
 };
 // a11+a12+a13: similarity scan over the lowest level fused with the threshold scan.
 // variant selects the unroll depth of the feature loop (0: 8 loads in flight, 1: 4, 2: 2).
@@ -146,6 +156,7 @@ struct LmPhaseArgs {
     float weak_threshold; int dist_thr, diff_thr;
     const u8* normal_lut; const u64* resp_tab;
     u32 ori_stride1;                                 // bytes between the response memories of level 1 (nibble packed)
+    u32 plane_ori1;                                  // bytes between level 1's miss-bit planes (behind the 8 response memories of a modality), 0: none
     size_t slot_stride; int nslots;
 };
 bool lmk_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0, int mode1, bool lut_onehot);

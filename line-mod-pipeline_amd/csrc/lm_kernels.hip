@@ -1922,6 +1922,19 @@ __global__ __launch_bounds__(256) void k_linear_memories(const u8* __restrict__ 
     }
 }
 
+// 8 x 8 bit transpose: in, byte i of (x | y << 32) = row i, bit o = column o; out, byte o holds bit i = in(i, o).  The three
+// swap steps of the classic recursive transpose (2 x 2 blocks of 1, 2 and 4 bits), on two dwords.
+__device__ __host__ __forceinline__ void bit_transpose8(u32& x, u32& y) {
+    u32 t;
+    t = (y ^ (y >> 7)) & 0x00AA00AAu; y = y ^ t ^ (t << 7);
+    t = (x ^ (x >> 7)) & 0x00AA00AAu; x = x ^ t ^ (t << 7);
+    t = (y ^ (y >> 14)) & 0x0000CCCCu; y = y ^ t ^ (t << 14);
+    t = (x ^ (x >> 14)) & 0x0000CCCCu; x = x ^ t ^ (t << 14);
+    t = (y & 0xF0F0F0F0u) | ((x >> 4) & 0x0F0F0F0Fu);
+    x = ((y << 4) & 0xF0F0F0F0u) | (x & 0x0F0F0F0Fu);
+    y = t;
+}
+
 // ------------------------------------------------------------------------------------------------
 // a6-a10, fast path: T and the segment width are compile-time (the reference's T = 2, 5, 8 plus 4), so
 // every index division is by a constant, and the separable OR runs on dwords (4 pixels per op, byte
@@ -1934,7 +1947,7 @@ template <int T, int SEG, int SRC_SHIFT, int MODE>
 __device__ __forceinline__ void d_lm_fast(const u32 vblock, const u8* __restrict__ q0, int qpitch, int w, int h,
                                                   const u64* __restrict__ resp_tab, u8* __restrict__ lm0,
                                                   u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
-                                                  int nseg, int nslots) {
+                                                  int nseg, int nslots, u32 plane_ori = 0) {
     constexpr int ROWS = 2 * T - 1;
     constexpr int TW = SEG * T;                    // pixels per segment
     constexpr int NDW = (TW + T - 1 + 3) / 4;      // source dwords per row including the right halo
@@ -1942,6 +1955,7 @@ __device__ __forceinline__ void d_lm_fast(const u32 vblock, const u8* __restrict
     constexpr int NLOAD = (ROWS * PD + 255) / 256;
     constexpr bool SPREAD_ONLY = MODE == 1;
     __shared__ u64 tab[SPREAD_ONLY ? 1 : 256];
+    __shared__ u8 tabu[MODE == 2 ? 256 : 1];       // MODE 2 with planes: orientations whose response to a spread byte is BELOW 4 (behind resp_tab)
     __shared__ u32 qs[ROWS][PD];
     __shared__ u32 ho[ROWS][PD];
     __shared__ u32 sp[T][PD];
@@ -1958,6 +1972,7 @@ __device__ __forceinline__ void d_lm_fast(const u32 vblock, const u8* __restrict
     const int px0 = col0 * T, y0 = band * T;
 
     if (!SPREAD_ONLY) tab[tid] = resp_tab[tid];
+    if (MODE == 2 && plane_ori) tabu[tid] = reinterpret_cast<const u8*>(resp_tab + 256)[tid];
     {
         u32 v[NLOAD];
 #pragma unroll
@@ -2031,6 +2046,23 @@ __device__ __forceinline__ void d_lm_fast(const u32 vblock, const u8* __restrict
                 u32 hi2 = __builtin_amdgcn_perm(b3, b2, sel) << 16;
                 *reinterpret_cast<u32*>(dst + (size_t)(o + 4) * ori_stride) = lo2 | hi2;
             }
+            if (plane_ori) {
+                // r05, k_scan1's bit planes: per orientation one BIT per position, set where the response is below 4 (a "miss");
+                // the 8 columns of this unit are one byte of each of the 8 planes -- an 8 x 8 bit transpose of the 8 miss masks
+                u32 x = 0, y = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    x |= (u32)tabu[row[(8 * k8 + i) * T + c0]] << (8 * i);
+                    y |= (u32)tabu[row[(8 * k8 + 4 + i) * T + c0]] << (8 * i);
+                }
+                bit_transpose8(x, y);
+                u8* pl = lm + 8 * (size_t)ori_stride + (((size_t)g * wh + (size_t)band * W + col0 + 8 * k8) >> 3);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    pl[(size_t)o * plane_ori] = (u8)(x >> (8 * o));
+                    pl[(size_t)(o + 4) * plane_ori] = (u8)(y >> (8 * o));
+                }
+            }
         }
         return;
     }
@@ -2068,8 +2100,8 @@ template <int T, int SEG, int SRC_SHIFT, int MODE>
 __global__ __launch_bounds__(256) void k_lm_fast(const u8* __restrict__ q0, int qpitch, int w, int h,
                                                   const u64* __restrict__ resp_tab, u8* __restrict__ lm0,
                                                   u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
-                                                  int nseg, int nslots) {
-    d_lm_fast<T, SEG, SRC_SHIFT, MODE>(blockIdx.x, q0, qpitch, w, h, resp_tab, lm0, ori_stride, q_slot_stride, lm_slot_stride, nseg, nslots);
+                                                  int nseg, int nslots, u32 plane_ori) {
+    d_lm_fast<T, SEG, SRC_SHIFT, MODE>(blockIdx.x, q0, qpitch, w, h, resp_tab, lm0, ori_stride, q_slot_stride, lm_slot_stride, nseg, nslots, plane_ori);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2233,7 +2265,7 @@ __global__ __launch_bounds__(256) void k_phase(LmPhaseArgs a, LmPhaseGrid pg) {
         if (b < e0) d_cvote(b, a.cs0 + a3_0, a.w, a.h, a.qc0, fs, fs, pg.g[0], a.nslots);
         else if (b < e1) d_corient(b - e0, a.cs1, w1, h1, thr2, a.cs1 + a3_1, nullptr, fs, fs, pg.g[1], a.nslots);
         else if (b < e2) d_lm_fast<5, 128, 0, 1>(b - e1, a.qd0, a.w, a.w, a.h, a.resp_tab, a.lm_d0, 0u, fs, fs, pg.g[2], a.nslots);
-        else d_lm_fast<8, 40, 1, 2>(b - e2, a.qd0, a.w, w1, h1, a.resp_tab, a.lm_d1, a.ori_stride1, fs, fs, pg.g[3], a.nslots);
+        else d_lm_fast<8, 40, 1, 2>(b - e2, a.qd0, a.w, w1, h1, a.resp_tab, a.lm_d1, a.ori_stride1, fs, fs, pg.g[3], a.nslots, a.plane_ori1);
     } else {
         if (b < e0) d_cvote(b, a.cs1 + a3_1, w1, h1, a.qc1, fs, fs, pg.g[0], a.nslots);
         else if (T0 == 5) d_lm_fast<5, 128, 0, 1>(b - e0, a.qc0, a.w, a.w, a.h, a.resp_tab, a.lm_c0, 0u, fs, fs, pg.g[1], a.nslots);
@@ -2277,7 +2309,7 @@ __global__ __launch_bounds__(256, 2) void k_bphase(LmPhaseArgs a, LmPhaseGrid pg
             else d_lm_spread2(b - e0, a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, pg.g[1], n);
         }
         else if (b < e2) d_lm_spread5(b - e1, a.qd0, a.w, a.w, a.h, a.lm_d0, fs, fs, pg.g[2], n);
-        else d_lm_fast<8, 40, 1, 2>(b - e2, a.qd0, a.w, w1, h1, a.resp_tab, a.lm_d1, a.ori_stride1, fs, fs, pg.g[3], n);
+        else d_lm_fast<8, 40, 1, 2>(b - e2, a.qd0, a.w, w1, h1, a.resp_tab, a.lm_d1, a.ori_stride1, fs, fs, pg.g[3], n, a.plane_ori1);
     }
 }
 
@@ -2306,7 +2338,7 @@ __global__ __launch_bounds__(256, PART == 1 ? 2 : 1) void k_bsplit(LmPhaseArgs a
     } else {
         if (b < e0) d_lm_spread5(b, a.qc0, a.w, a.w, a.h, a.lm_c0, fs, fs, pg.g[0], n);
         else if (b < e1) d_lm_spread5(b - e0, a.qd0, a.w, a.w, a.h, a.lm_d0, fs, fs, pg.g[1], n);
-        else d_lm_fast<8, 40, 1, 2>(b - e1, a.qd0, a.w, w1, h1, a.resp_tab, a.lm_d1, a.ori_stride1, fs, fs, pg.g[2], n);
+        else d_lm_fast<8, 40, 1, 2>(b - e1, a.qd0, a.w, w1, h1, a.resp_tab, a.lm_d1, a.ori_stride1, fs, fs, pg.g[2], n, a.plane_ori1);
     }
 }
 
@@ -2605,6 +2637,276 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
             cd.y = r * a.T + offset;
             cd.sim = __fadd_rn(__fdiv_rn(__fmul_rn((float)raw, 100.f), (float)(4 * n)), 0.5f);
             cand[pos] = cd;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a11-a13, bit-plane form of the hot kernel (r05; LmScanArgs::L1 != 0).  k_scan4 adds every response of every feature at every
+// position -- 4 bits a position, 14 vector instructions per feature and 32 positions -- although all the threshold scan wants
+// to know is WHERE the sum exceeds the threshold.  A response is 4 only where the feature's orientation itself is present; every
+// other response is at most 4 - delta (delta = 3 with the default table: 1 for a neighbouring orientation, 0 otherwise).  So a
+// position that has MISSED (response below 4) more than m_max = (4 F - threshold - 1) / delta of a template's F in-bounds
+// features cannot exceed the threshold whatever the missed responses were.  This kernel only counts misses:
+//   * the producer (d_lm_fast, MODE 2 + planes) keeps, next to the nibble memories, one BIT per position and orientation --
+//     1 = a miss -- in the same linear order; a lane's 16-byte load is 128 positions, lanes 0 .. L-1 of a frame cover a chunk of
+//     128 L - 31 positions (the last 31 positions of a lane's window need the next lane's first dword: v_mov_dpp), and a wave
+//     carries the same work item (template, chunk) for G = 64 / L FRAMES: feature offset and bit shift are wave-uniform
+//     scalars, the shift is undone by v_alignbit_b32 (5 instructions per feature and 128 positions);
+//   * the misses are counted bit-sliced: c[b] holds bit b of the counters of 32 positions; eight features enter per round
+//     through a carry-save tree (7 full adders = 2 v_bitop3_b32 each, 4 half adders, one OR: 23 instructions per dword, 2.9 per
+//     feature) -- 16.5 vector instructions per feature and 128 positions with the shift-undo, against 57 in k_scan4;
+//   * the counters start at 127 - m_max, so bit 7 says "more than m_max misses": the dead flag of a position (sticky: the
+//     counter cannot pass 255).  Invalid positions start dead.  After every round a lane whose four flag dwords are all ones is
+//     dead and leaves the exec mask of the loads (per-lane pruning as in k_scan4), and the wave stops when no lane is left;
+//   * the positions alive after the last feature are a superset of the candidates (the bound is exact when no response was 0).
+//     Their exact sums come from the nibble memories, the wave working on one survivor at a time: lane f adds feature f's
+//     response, a DPP reduction gives the sum, and only sums above the threshold are emitted -- the candidate list is the one
+//     k_scan4 writes (tests/test_gpu_match.py, the fuzzer).
+// a.stat: [0] += features loaded, [1] += features an unpruned scan would load, [2] += lane-loads issued, [3] += survivors.
+// ------------------------------------------------------------------------------------------------
+// full adder of three bit vectors on gfx950's three-input truth-table instruction: sum = a ^ b ^ c (0x96), carry = majority (0xE8)
+__device__ __forceinline__ void bs_fa(u32& c, u32 a, u32 b, u32& cy) {
+    cy = __builtin_amdgcn_bitop3_b32(c, a, b, 0xE8);
+    c = __builtin_amdgcn_bitop3_b32(c, a, b, 0x96);
+}
+template <int LEV, int NIN>
+__device__ __forceinline__ void bs_level(u32 (&c)[8], const u32 (&in)[8]) {
+    if constexpr (NIN == 0) {
+        return;
+    } else if constexpr (LEV == 7) {
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) c[7] |= in[i];
+    } else {
+        u32 out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        constexpr int NP = NIN / 2;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) bs_fa(c[LEV], in[2 * i], in[2 * i + 1], out[i]);
+        if constexpr (NIN & 1) { out[NP] = c[LEV] & in[NIN - 1]; c[LEV] ^= in[NIN - 1]; }
+        bs_level<LEV + 1, NP + (NIN & 1)>(c, out);
+    }
+}
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {   // all lanes active
+    v += (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    v += (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    v += (u32)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    v += (u32)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true);   // row_mirror: every lane holds its row's sum
+    return (u32)__builtin_amdgcn_readlane((int)v, 0) + (u32)__builtin_amdgcn_readlane((int)v, 16) +
+           (u32)__builtin_amdgcn_readlane((int)v, 32) + (u32)__builtin_amdgcn_readlane((int)v, 48);
+}
+template <int NF>
+__device__ __forceinline__ void s1_load(const __amdgpu_buffer_rsrc_t rsrc, u32 lane_base, const u32* __restrict__ offs, u32 cbase,
+                                        bool act, u32x4 (&v)[8], u32 (&sh)[8]) {
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+        const u32 o = offs[k] + cbase;
+        sh[k] = o & 31u;
+        if (act) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_base, (o >> 5) << 2, 0);
+    }
+}
+template <int NF>
+__device__ __forceinline__ void s1_compute(bool act, const u32x4 (&v)[8], const u32 (&sh)[8], u32 (&c)[4][8]) {
+    if (!act) return;
+    u32 x[4][8];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+        const u32 nx = next_lane(v[k][0]);
+        x[0][k] = __builtin_amdgcn_alignbit(v[k][1], v[k][0], sh[k]);
+        x[1][k] = __builtin_amdgcn_alignbit(v[k][2], v[k][1], sh[k]);
+        x[2][k] = __builtin_amdgcn_alignbit(v[k][3], v[k][2], sh[k]);
+        x[3][k] = __builtin_amdgcn_alignbit(nx, v[k][3], sh[k]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bs_level<0, NF>(c[q], x[q]);
+}
+template <int NF>
+__device__ __forceinline__ void s1_round(const __amdgpu_buffer_rsrc_t rsrc, u32 lane_base, const u32* __restrict__ offs, u32 cbase,
+                                         bool act, u32 (&c)[4][8]) {
+    u32x4 v[8];
+    u32 sh[8];
+    s1_load<NF>(rsrc, lane_base, offs, cbase, act, v, sh);
+    s1_compute<NF>(act, v, sh, c);
+}
+
+__global__ __launch_bounds__(256) void k_scan1(LmScanArgs a) {
+    const int lane = threadIdx.x & 63;
+    const u32 ngroups = ((u32)a.nslots + (u32)a.G1 - 1u) / (u32)a.G1;
+    u32 grp, wg;
+    xcd_slot_tile((u32)a.wgs_per_slot, ngroups, grp, wg);
+    if (grp >= ngroups) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((wg * 256u + threadIdx.x) >> 6));
+    if (wave >= a.n_items) return;
+    const u32 ti = a.item_t[a.item_lo + wave];
+    const u32 chunk = a.item_chunk[a.item_lo + wave];
+    const int cnt = a.scan_n[ti];
+    const int n = cnt & 0xFF;
+    const int F = ((cnt >> 8) & 0xFF) + ((cnt >> 16) & 0xFF);    // in-bounds features of all modalities
+    const int thr = a.raw_thr_by_n[n];
+    const int K0 = 4 * F - thr - 1;                              // what the misses may cost in total
+    if (K0 < 0) return;                                          // even F exact responses stay at or below the threshold
+    int mmax = (int)(((u32)K0 * a.delta_rcp16) >> 16);           // K0 / delta
+    if (mmax > 127) mmax = 127;
+    const u32 pre = (u32)(127 - mmax);
+    const int L = a.L1, CH = 128 * L - 31;
+    const int fr = (int)(((u32)lane * a.L1_rcp16) >> 16), li = lane - fr * L;    // frame of the group, lane of the frame
+    const u32 slot0 = grp * (u32)a.G1;
+    const u32 slot = slot0 + (u32)fr;
+    const bool have = fr < a.G1 && slot < (u32)a.nslots;
+    const int P = a.scan_P[ti];
+    const u32 cbase = chunk * (u32)CH;                                            // first position of the item
+    const int j0 = (int)cbase + li * 128;                                         // first position of this lane
+    int valid = have ? min(P, (int)((chunk + 1u) * (u32)CH)) - j0 : 0;
+    valid = valid < 0 ? 0 : (valid > 128 ? 128 : valid);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u8*>(a.lm + (size_t)slot0 * a.lm_slot_stride), 0, 0x7FFFFFFF, 0x00020000);
+    const u32 lane_base = (have ? (u32)fr * (u32)a.lm_slot_stride : 0u) + (u32)li * 16u;   // (a lane without a frame may still feed its left neighbour: any mapped address)
+    u32 c[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int b = 0; b < 7; ++b) c[q][b] = ((pre >> b) & 1u) ? 0xFFFFFFFFu : 0u;
+        const int vq = valid - 32 * q;
+        c[q][7] = vq >= 32 ? 0u : (vq > 0 ? ~((1u << vq) - 1u) : 0xFFFFFFFFu);      // invalid positions start dead
+    }
+    unsigned long long alive = __ballot(valid > 0);
+    if (!alive) return;
+    bool act = (((alive | (alive << 1)) >> lane) & 1ull) != 0;
+    const u32* offs = a.off1 + (size_t)ti * a.fpad1;
+    u32 lane_loads = 0;
+    int f = 0;
+    bool pruned = false;
+#define S1_TEST()                                                                                                   \
+    {                                                                                                               \
+        const unsigned long long left = __ballot((c[0][7] & c[1][7] & c[2][7] & c[3][7]) != 0xFFFFFFFFu) & alive;   \
+        if (!left) pruned = true;                                                                                   \
+        else { alive = left; act = (((left | (left << 1)) >> lane) & 1ull) != 0; }                                  \
+    }
+    // (r05, measured: the next round's loads issued before this round is counted -- two register sets, 152 VGPRs, three waves per SIMD --
+    // take 162 instead of 130 us per 96-frame launch; the waves of a SIMD hide each other's loads better than a wave hides its own)
+    for (; f + 8 <= F && !pruned; f += 8) {
+        lane_loads += 8u * (u32)__popcll(alive | (alive << 1));
+        s1_round<8>(rsrc, lane_base, offs + f, cbase, act, c);
+        if (f + 8 > mmax && f + 8 < F) S1_TEST()                 // (nothing can be dead before mmax + 1 features are in)
+    }
+    if (!pruned) {
+        if (F - f >= 4) { lane_loads += 4u * (u32)__popcll(alive | (alive << 1)); s1_round<4>(rsrc, lane_base, offs + f, cbase, act, c); f += 4; }
+        if (F - f >= 2) { lane_loads += 2u * (u32)__popcll(alive | (alive << 1)); s1_round<2>(rsrc, lane_base, offs + f, cbase, act, c); f += 2; }
+        if (F - f >= 1) { lane_loads += (u32)__popcll(alive | (alive << 1)); s1_round<1>(rsrc, lane_base, offs + f, cbase, act, c); f += 1; }
+    }
+#undef S1_TEST
+    // survivors: positions never flagged (a dead or idle lane's flags are all ones)
+    u32 h[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[q] = pruned ? 0u : ~c[q][7];
+    unsigned long long hl = __ballot((h[0] | h[1] | h[2] | h[3]) != 0u);
+    if (a.stat && lane == 0) {
+        atomicAdd(&a.stat[4 * (blockIdx.x & 1023u)], (unsigned long long)f);
+        atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 1], (unsigned long long)F);
+        atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 2], (unsigned long long)lane_loads);
+    }
+    if (!hl || a.no_exact) return;
+    if (a.surv) {
+        // the survivors go to the stream's queue (k_scan1_exact, one lane per survivor); a lane whose reservation does not fit keeps its
+        // hits for the loop below
+        const u32 nh = (u32)(__popc(h[0]) + __popc(h[1]) + __popc(h[2]) + __popc(h[3]));
+        if (nh) {
+            const unsigned long long at = atomicAdd(a.surv, (unsigned long long)nh);
+            if (at + nh <= (unsigned long long)a.surv_cap) {
+                unsigned long long* q = a.surv + 1 + at;
+                const unsigned long long hi = ((unsigned long long)ti << 32) | ((unsigned long long)slot << 20);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    for (u32 w = h[k]; w; w &= w - 1) *q++ = hi | (unsigned long long)(u32)(j0 + 32 * k + (__ffs((int)w) - 1));
+                h[0] = h[1] = h[2] = h[3] = 0;
+                if (a.stat) atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 3], (unsigned long long)nh);
+            } else {
+                atomicAdd(a.surv, (unsigned long long)0 - (unsigned long long)nh);     // (give the reservation back: the count stays the number of entries)
+            }
+        }
+        hl = __ballot((h[0] | h[1] | h[2] | h[3]) != 0u);
+        if (!hl) return;
+    }
+    // exact sums of the survivors from the nibble memories, one survivor at a time: lane k adds features k and k + 64
+    const u32* offn = a.offn + (size_t)ti * a.fpad1;
+    const u32 on0 = lane < F ? offn[lane] : 0u, on1 = lane + 64 < F ? offn[lane + 64] : 0u;
+    const int offset = a.T / 2 + (a.T % 2 - 1);
+    u32 n_surv = 0;
+    while (hl) {
+        const int src = __ffsll((long long)hl) - 1;
+        const u32 w0 = (u32)__builtin_amdgcn_readlane((int)h[0], src), w1 = (u32)__builtin_amdgcn_readlane((int)h[1], src);
+        const u32 w2 = (u32)__builtin_amdgcn_readlane((int)h[2], src), w3 = (u32)__builtin_amdgcn_readlane((int)h[3], src);
+        const int q = w0 ? 0 : (w1 ? 1 : (w2 ? 2 : 3));
+        const u32 wq = w0 ? w0 : (w1 ? w1 : (w2 ? w2 : w3));
+        const int b = __ffs((int)wq) - 1;
+        const int j = __builtin_amdgcn_readlane(j0, src) + 32 * q + b;
+        const u32 sl = (u32)__builtin_amdgcn_readlane((int)slot, src);
+        if (lane == src) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) h[k] = (k == q) ? (h[k] & ~(1u << b)) : h[k];
+        }
+        const u8* nb = a.lm + (size_t)sl * a.lm_slot_stride;
+        u32 v = 0;
+        if (lane < F) { const u32 ad = on0 + (u32)j; const u32 by = nb[ad >> 1]; v = (ad & 1u) ? (by >> 4) : (by & 15u); }
+        if (lane + 64 < F) { const u32 ad = on1 + (u32)j; const u32 by = nb[ad >> 1]; v += (ad & 1u) ? (by >> 4) : (by & 15u); }
+        const int raw = (int)wave_sum_u32(v);
+        n_surv += 1;
+        if (raw > thr && lane == 0) {
+            LmDevHeader* hdr = reinterpret_cast<LmDevHeader*>(reinterpret_cast<u8*>(a.hdr) + (size_t)sl * a.aux_slot_stride);
+            LmCand* cand = reinterpret_cast<LmCand*>(reinterpret_cast<u8*>(a.cand) + (size_t)sl * a.aux_slot_stride);
+            const u32 pos = atomicAdd(&hdr->cand_count, 1u);
+            if (pos < a.cand_cap) {
+                const int r = j / a.W, cc = j - r * a.W;
+                LmCand cd;
+                cd.ti = ti;
+                cd.x = cc * a.T + offset;
+                cd.y = r * a.T + offset;
+                cd.sim = __fadd_rn(__fdiv_rn(__fmul_rn((float)raw, 100.f), (float)(4 * n)), 0.5f);
+                cand[pos] = cd;
+            }
+        }
+        hl = __ballot((h[0] | h[1] | h[2] | h[3]) != 0u);
+    }
+    if (a.stat && lane == 0) atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 3], (unsigned long long)n_surv);
+}
+
+// Second half of the bit-plane scan: the exact sums of the queued survivors, one lane each (neighbours in the queue are neighbouring
+// positions of one template: their nibble loads share lines).  Sums above the threshold become candidates exactly as k_scan4 emits them.
+__global__ __launch_bounds__(256) void k_scan1_exact(LmScanArgs a) {
+    const unsigned long long total = a.surv[0];
+    const u32 n = total < (unsigned long long)a.surv_cap ? (u32)total : a.surv_cap;
+    const int offset = a.T / 2 + (a.T % 2 - 1);
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const unsigned long long e = a.surv[1 + i];
+        const u32 ti = (u32)(e >> 32), sl = ((u32)e) >> 20, j = (u32)e & 0xFFFFFu;
+        const int cnt = a.scan_n[ti];
+        const int nn = cnt & 0xFF;
+        const int F = ((cnt >> 8) & 0xFF) + ((cnt >> 16) & 0xFF);
+        const int thr = a.raw_thr_by_n[nn];
+        const u32* offn = a.offn + (size_t)ti * a.fpad1;
+        const u8* nb = a.lm + (size_t)sl * a.lm_slot_stride;
+        int raw = 0;
+        int f = 0;
+        for (; f + 8 <= F; f += 8) {
+            u32 by[8], ad[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { ad[k] = offn[f + k] + j; by[k] = nb[ad[k] >> 1]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) raw += (int)((ad[k] & 1u) ? (by[k] >> 4) : (by[k] & 15u));
+        }
+        for (; f < F; ++f) { const u32 ad = offn[f] + j; const u32 by = nb[ad >> 1]; raw += (int)((ad & 1u) ? (by >> 4) : (by & 15u)); }
+        if (raw > thr) {
+            LmDevHeader* hdr = reinterpret_cast<LmDevHeader*>(reinterpret_cast<u8*>(a.hdr) + (size_t)sl * a.aux_slot_stride);
+            LmCand* cand = reinterpret_cast<LmCand*>(reinterpret_cast<u8*>(a.cand) + (size_t)sl * a.aux_slot_stride);
+            const u32 pos = atomicAdd(&hdr->cand_count, 1u);
+            if (pos < a.cand_cap) {
+                const int r = (int)j / a.W, cc = (int)j - r * a.W;
+                LmCand cd;
+                cd.ti = ti;
+                cd.x = cc * a.T + offset;
+                cd.y = r * a.T + offset;
+                cd.sim = __fadd_rn(__fdiv_rn(__fmul_rn((float)raw, 100.f), (float)(4 * nn)), 0.5f);
+                cand[pos] = cd;
+            }
         }
     }
 }
@@ -3653,13 +3955,13 @@ void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_
 template <int T, int SEG>
 static void lm_fast_launch(hipStream_t s, const u8* q, int qpitch, int src_shift, int mode, int w, int h,
                            const u64* resp_tab, u8* lm, u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
-                           int nslots) {
+                           int nslots, u32 plane_ori) {
     const int W = w / T;
     const int nseg = (W + SEG - 1) / SEG;
     dim3 grid((unsigned)(nseg * (h / T) * nslots), 1, 1);
 #define LMF(SH, MD)                                                                                           \
     hipLaunchKernelGGL((k_lm_fast<T, SEG, SH, MD>), grid, dim3(256), 0, s, q, qpitch, w, h, resp_tab, lm, ori_stride, \
-                       q_slot_stride, lm_slot_stride, nseg, nslots)
+                       q_slot_stride, lm_slot_stride, nseg, nslots, mode == 2 ? plane_ori : 0u)
     if (src_shift) { if (mode == 1) LMF(1, 1); else if (mode == 2) LMF(1, 2); else LMF(1, 0); }
     else           { if (mode == 1) LMF(0, 1); else if (mode == 2) LMF(0, 2); else LMF(0, 0); }
 #undef LMF
@@ -3673,13 +3975,13 @@ bool lmk_nibble_supported(int w, int h, int T) {
 
 void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, int mode, int w, int h, int T,
                          const u64* resp_tab, u8* lm, u32 ori_stride, size_t q_slot_stride, size_t lm_slot_stride,
-                         int nslots) {
+                         int nslots, u32 plane_ori) {
     const int W = w / T;
     const bool spread_only = mode == 1;
     const bool aligned = (w % 4 == 0) && (W % 4 == 0) && (qpitch % 4 == 0) && (((uintptr_t)q & 3) == 0) &&
                          (q_slot_stride % 4 == 0);
     if (aligned) {
-#define LMF_ARGS s, q, qpitch, src_shift, mode, w, h, resp_tab, lm, ori_stride, q_slot_stride, lm_slot_stride, nslots
+#define LMF_ARGS s, q, qpitch, src_shift, mode, w, h, resp_tab, lm, ori_stride, q_slot_stride, lm_slot_stride, nslots, plane_ori
         switch (T) {
             case 2:
                 if (mode == 1 && !src_shift && (w % 32) == 0 && (h % 2) == 0 && (qpitch % 16) == 0 && (((uintptr_t)q & 15) == 0) &&
@@ -3763,7 +4065,7 @@ void lmk_preprocess_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
     LmPhaseGrid p4 = {{(u32)(g_vote1 * n), b_lm0, 0u, 0u}, {g_vote1, seg0, 0, 0}};
     if (T0 == 5) launch(k_phase<4, 5>, p4); else launch(k_phase<4, 2>, p4);
     hipLaunchKernelGGL((k_lm_fast<8, 40, 0, 2>), dim3(b_lm1), dim3(256), 0, s, a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1,
-                       a.slot_stride, a.slot_stride, seg1, n);
+                       a.slot_stride, a.slot_stride, seg1, n, a.plane_ori1);
 }
 
 bool lmk_batch_phases_supported(const LmPhaseArgs& a, int T0, int T1, int mode0, int mode1, bool lut_onehot) {
@@ -3836,7 +4138,7 @@ void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
         }
     }
     hipLaunchKernelGGL((k_lm_fast<8, 40, 0, 2>), dim3(b_lm1), dim3(256), 0, s, a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1,
-                       a.slot_stride, a.slot_stride, seg1, n);
+                       a.slot_stride, a.slot_stride, seg1, n, a.plane_ori1);
 }
 
 void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
@@ -3845,6 +4147,16 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
     a.nslots = nslots;
     const int G = (a.n_items + 3) / 4;               // one wave per work item
     a.wgs_per_slot = G;
+    if (a.L1) {
+        // k_scan1: a wave scans its item for a GROUP of G1 slots (XCD affinity per group when the group count allows)
+        const int ngroups = (nslots + a.G1 - 1) / a.G1;
+        a.no_exact = (variant & 128) ? 1 : 0;
+        if (variant & 256) a.surv = nullptr;             // A/B: the waves take their survivors' exact sums themselves
+        if (a.surv) (void)hipMemsetAsync(a.surv, 0, sizeof(unsigned long long), s);
+        hipLaunchKernelGGL(k_scan1, dim3((unsigned)(G * ngroups), 1, 1), dim3(256), 0, s, a);
+        if (a.surv && !a.no_exact) hipLaunchKernelGGL(k_scan1_exact, dim3(1024), dim3(256), 0, s, a);
+        return;
+    }
     if (a.nibble) {
         // k_scan4: a wave scans its item for a PAIR of slots; 1-D grid with XCD affinity per pair
         const int npairs = (nslots + 1) / 2;

@@ -432,6 +432,7 @@ def test_scan_pruning_is_exact(lm, orc, synth, color_only, thr):
     record by record, and the pruned scan really loads fewer features at a high threshold."""
     bgr, depth = synth.make_frame(640, 480, seed=77)
     d, o = _pair(lm, orc, color_only, frame_slots=4)
+    d.set_tuning(lm.TUNE_SCAN_FORM, 1)                              # this test is about k_scan4's pruning rules (k_scan1: tests/test_gpu_scan_planes.py)
     dep = None if color_only else depth
     q = _quantized(o, bgr, depth, color_only)
     M = 1 if color_only else 2

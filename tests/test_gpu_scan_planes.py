@@ -1,0 +1,127 @@
+"""The bit-plane scan k_scan1 (r05, LM_TUNE_SCAN_FORM) against the oracle and against the nibble scan k_scan4: the same candidate
+lists and match lists, bit for bit -- whatever the frame size (one or several chunks per template, few or many lanes per frame),
+the number of frames in the call (full and ragged groups of frames per wave), the threshold, the modality count and the
+similarity table (the miss bound follows the table's largest response below 4)."""
+import numpy as np
+import pytest
+
+from conftest import assert_matches_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _quantized(o, bgr, depth, color_only):
+    o.prepare(bgr, None if color_only else depth)
+    out = {}
+    for l in range(2):
+        w, h = bgr.shape[1] >> l, bgr.shape[0] >> l
+        for m in range(1 if color_only else 2):
+            out[(l, m)] = o.stage(0, l, m).reshape(h, w)
+    return out
+
+
+def _setup(lm, orc, synth, color_only, size, T, n_templates, slots, seed, nf=63, size_range=(48, 160)):
+    w, h = size
+    size_range = (min(size_range[0], h // 6), min(size_range[1], h // 3))
+    d = lm.Detector(lm.default_config(color_only=color_only, width=w, height=h, T=T, frame_slots=slots))
+    o = orc.Detector(color_only=color_only, T=T)
+    frames = [synth.make_frame(w, h, seed=seed + k) for k in range(min(slots, 3))]
+    q = _quantized(o, frames[0][0], frames[0][1], color_only)
+    M = 1 if color_only else 2
+    descs, feats, _ = synth.make_bank(n_templates, M, 2, seed=seed + 100, quantized=q, crop_fraction=0.3, frame_size=(w, h), T0=T[0],
+                                      num_features=nf, size_range=size_range)
+    d.add_class("c", descs, feats); o.add_class("c", descs, feats)
+    return d, o, frames
+
+
+@pytest.mark.parametrize("color_only,size,T,thr", [
+    (False, (640, 480), [5, 8], 80.0),       # config 2's shape: 1200 positions per memory, one chunk, 9-10 lanes per frame
+    (True, (640, 480), [2, 8], 85.0),
+    (False, (384, 256), [4, 8], 75.0),       # 384 positions per memory: 3-4 lanes per frame, 16+ frames per wave
+    (True, (1280, 960), [2, 8], 88.0),       # 4800 positions per memory
+    (False, (640, 480), [4, 4], 80.0),       # T = 4 at the scanned level: 4800 positions
+    (False, (640, 480), [5, 8], 55.0),       # a low threshold: many survivors of the miss bound
+    (False, (640, 480), [5, 8], 97.0),
+])
+def test_scan1_candidates_and_matches(lm, orc, synth, color_only, size, T, thr):
+    nb = 9
+    d, o, frames = _setup(lm, orc, synth, color_only, size, T, 60, nb, seed=900)
+    dep = lambda k: None if color_only else frames[k % len(frames)][1]
+    bgr = lambda k: frames[k % len(frames)][0]
+    exp_m = [o.match(bgr(k), dep(k), thr, threads=8, cap=1 << 18) for k in range(len(frames))]
+    o.prepare(bgr(0), dep(0))
+    exp_c = o.scan_candidates(thr, threads=8)
+    # one frame, the candidate list record by record
+    d.upload_frame(0, bgr(0), dep(0)); d.prepare_slot(0)
+    d.set_tuning(lm.TUNE_SCAN_FORM, 1)
+    assert np.array_equal(d.stage_scan(0, thr), exp_c)
+    d.set_tuning(lm.TUNE_SCAN_FORM, 2)
+    d.set_scan_stats(True)
+    assert np.array_equal(d.stage_scan(0, thr), exp_c)
+    loaded, unpruned = d.get_scan_stats()
+    assert 0 < loaded <= unpruned
+    d.set_scan_stats(False)
+    # whole matches, every group shape: 1 frame, a ragged group, several groups
+    for n in (1, 2, 5, nb):
+        for k in range(n):
+            d.upload_frame(k, bgr(k), dep(k))
+        before = d.get_scan_form_stats()
+        got, cnt = d.match_batch(n, thr, cap_per_frame=1 << 15)
+        after = d.get_scan_form_stats()
+        assert after[0] - before[0] == after[1] - before[1] >= 1 and after[3] > 0       # every scan launch was k_scan1
+        for k in range(n):
+            assert_matches_equal(got[k, :cnt[k]], exp_m[k % len(frames)])
+    # the default picks by cost: the lists are the same either way
+    d.set_tuning(lm.TUNE_SCAN_FORM, 0)
+    got, cnt = d.match_batch(nb, thr, cap_per_frame=1 << 15)
+    for k in range(nb):
+        assert_matches_equal(got[k, :cnt[k]], exp_m[k % len(frames)])
+    d.close()
+
+
+def test_scan1_similarity_tables(lm, orc, synth):
+    """The miss bound is 4 - the table's largest response below 4: tables whose misses cost 1, 2, 3 or 4, and a table without a 4."""
+    d, o, frames = _setup(lm, orc, synth, False, (640, 480), [5, 8], 50, 4, seed=950)
+    base = orc.similarity_lut()
+    tables = [base]
+    for lo, hi in ((3, 4), (2, 4), (0, 4), (1, 3)):      # (response of a neighbouring orientation, of the orientation itself)
+        t = base.copy()
+        t[base == 1] = lo; t[base == 4] = hi
+        tables.append(t)
+    bgr, dep = frames[0]
+    for t in tables:
+        d.set_similarity_lut(t); o.set_similarity_lut(t)
+        for thr in (70.0, 90.0):
+            exp = o.match(bgr, dep, thr, threads=8, cap=1 << 18)
+            o.prepare(bgr, dep)
+            exp_c = o.scan_candidates(thr, threads=8)
+            for form in (1, 2):
+                d.set_tuning(lm.TUNE_SCAN_FORM, form)
+                for k in range(4):
+                    d.upload_frame(k, bgr, dep)
+                d.prepare_slot(0)
+                assert np.array_equal(d.stage_scan(0, thr), exp_c), (form, thr)
+                got, cnt = d.match_batch(4, thr, cap_per_frame=1 << 15)
+                for k in range(4):
+                    assert_matches_equal(got[k, :cnt[k]], exp)
+    d.close()
+
+
+def test_scan1_few_features_and_classes(lm, orc, synth):
+    """Templates of few features (tail rounds of 4, 2 and 1), a class list (one launch per run of classes) and the per-class calls."""
+    for nf in (63, 21, 13, 9, 2):
+        d, o, frames = _setup(lm, orc, synth, False, (640, 480), [5, 8], 30, 8, seed=970 + nf, nf=nf)
+        bgr, dep = frames[0]
+        q = _quantized(o, bgr, dep, False)
+        d2, f2, _ = synth.make_bank(17, 2, 2, seed=1234 + nf, quantized=q, crop_fraction=0.5, frame_size=(640, 480), T0=5, num_features=nf)
+        d.add_class("c2", d2, f2); o.add_class("c2", d2, f2)
+        d.set_tuning(lm.TUNE_SCAN_FORM, 2)
+        for k in range(8):
+            d.upload_frame(k, bgr, dep)
+        for thr in (60.0, 85.0):
+            for classes in ([-1], [1], [0], [1, 0]):
+                exp = o.match(bgr, dep, thr, class_idx=classes[0] if len(classes) == 1 else -1, threads=8, cap=1 << 18)
+                got, cnt = d.match_batch_classes(0, 8, thr, classes, cap_per_frame=max(len(exp), 1))
+                for k in range(8):
+                    assert cnt[k] == len(exp) and got[k, :cnt[k]].tobytes() == exp.tobytes(), (nf, thr, classes, k)
+        d.close()
