@@ -644,6 +644,24 @@ def main():
                                "launch; tools/collect_counters.sh) x the calibrated request size, over THIS run's clean launch "
                                "duration (HIP events)" % Bl})
             roofline["l2_counters"] = lc
+        sq = next((v for k, v in l2c["kernels"].items() if kernel_is(k, kernel) and v.get("SQ_ACTIVE_INST_VALU") and v.get("GRBM_GUI_ACTIVE") and v.get("avg_us")), None)
+        if kernel == "k_scan1" and sq and not args.no_prune and not args.scan_variant:
+            # the bit-plane scan moves a quarter of k_scan4's bytes per position and feature: its binding roof is the vector issue rate.  VALU-active
+            # SIMD cycles (SQ_ACTIVE_INST_VALU x 4, counter file of this command) over THIS run's clean scan time -- which contains the survivors'
+            # exact sums (k_scan1_exact) -- against 1024 SIMDs x the shader clock under load (GRBM_GUI_ACTIVE of the kernel / 8 XCDs / its duration)
+            inst = max(sq.get("GRBM_GUI_ACTIVE_instances", 1), 1)
+            clock_ghz = sq["GRBM_GUI_ACTIVE"] / (8.0 if inst == 1 else inst) / sq["avg_us"] / 1e3
+            ach = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (ol_us * 1e3)                  # G SIMD-cycles per second
+            roofline["l2_rate"] = {"achieved": roofline["achieved"], "peak": L2_PEAK_GBS, "frac": roofline["frac"], "unit": "GB/s"}
+            roofline.update({"bound": "valu", "achieved": round(ach, 1), "peak": round(N_SIMD * clock_ghz, 1), "unit": "G SIMD-cycles/s",
+                             "frac": round(ach / (N_SIMD * clock_ghz), 4),
+                             "valu": {"SQ_ACTIVE_INST_VALU_per_launch": sq["SQ_ACTIVE_INST_VALU"], "SQ_INSTS_VALU_per_launch": sq.get("SQ_INSTS_VALU"),
+                                      "shader_clock_GHz_under_load": round(clock_ghz, 3), "kernel_avg_us_in_counter_file": sq["avg_us"],
+                                      "source": l2c["source"],
+                                      "note": "k_scan1 counts misses on one bit per position and orientation: its vector loads ask the L2 for a fraction of "
+                                              "what k_scan4's do (l2_rate beside this), and the kernel is bound by vector issue -- the carry-save adders of "
+                                              "the bit-sliced counters and the shift-undo; frac = share of the chip's SIMD cycles in which a vector "
+                                              "instruction executes, over the clean time of the whole scan stage"}})
         ref_us = one_lane["stage_us"][2] / max(one_lane["launches"], 1)
         rr = from_counters("k_refine<", ref_us)
         if rr:
@@ -734,6 +752,12 @@ def why_l2(runner, wl, traffic, alg_bytes, ctr, kernel):
            "a wave scans two frames, an XCD works on one slot pair at a time: %.2f MB + %.2f MB of bank offsets against a 4 MB L2 per XCD"
            % (lm_bytes / 1e6, M, W1, H1, 2 * lm_bytes / 1e6, bank / 1e6))
     fits = 2 * lm_bytes + bank <= 4.0e6
+    if kernel == "k_scan1":
+        planes = M * 8 * W1 * H1 // 8
+        msg = ("bit-plane scan: the scanned level per frame is %.2f MB of miss planes (%d modalities x 8 orientations x %d x %d positions / 8) next to the "
+               "%.2f MB of nibble memories, which only the survivors' exact sums (k_scan1_exact) read; a wave scans a group of frames, an XCD works on "
+               "one group at a time; the L2 -> L1 figure is reported as l2_rate, the binding roof is vector issue (valu)" % (planes / 1e6, M, W1, H1, lm_bytes / 1e6))
+        fits = True
     if traffic is not None and alg_bytes:
         msg += "; measured HBM-side traffic of the kernel %.1f MB per launch = %.2f %% of the algorithmic bytes" % (traffic / 1e6, 100.0 * traffic / alg_bytes)
     hit = None
@@ -742,7 +766,9 @@ def why_l2(runner, wl, traffic, alg_bytes, ctr, kernel):
             if kernel_is(k, kernel) and v.get("TCC_HIT_sum") is not None and v.get("TCC_MISS_sum") is not None and v["TCC_HIT_sum"] + v["TCC_MISS_sum"] > 0:
                 hit = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
                 msg += ", measured L2 hit rate %.1f %%" % (100.0 * hit)
-    if fits:
+    if kernel == "k_scan1":
+        pass
+    elif fits:
         msg += ("; the working set fits the L2, so the kernel is bound by what its vector loads request from the L2s against the guide's 34.5 TB/s "
                 "aggregate L2 rate")
     elif hit is not None and hit >= 0.95:
@@ -1022,14 +1048,14 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
-COUNTER_KEYS = ("baseline_config", "frames_per_launch", "threshold", "templates_per_gpu", "scan_variant", "no_prune", "byte_responses",
+COUNTER_KEYS = ("baseline_config", "frames_per_launch", "threshold", "templates_per_gpu", "scan_variant", "scan_form", "no_prune", "byte_responses",
                 "kernel_source_sha16")
 
 
 def counters_meta(args, templates_per_gpu, frames_per_launch):
     """What a committed counter file must agree with before bench.py lets it describe this run."""
     return {"baseline_config": args.config, "frames_per_launch": frames_per_launch, "threshold": args.threshold,
-            "templates_per_gpu": templates_per_gpu, "scan_variant": args.scan_variant, "no_prune": bool(args.no_prune),
+            "templates_per_gpu": templates_per_gpu, "scan_variant": args.scan_variant, "scan_form": max(args.scan_form, 0), "no_prune": bool(args.no_prune),
             "byte_responses": bool(args.byte_responses), "kernel_source_sha16": kernel_source_sha16()}
 
 

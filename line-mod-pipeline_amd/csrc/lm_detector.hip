@@ -577,7 +577,7 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots = 1
         a.item_t = it->d_t; a.item_chunk = it->d_chunk;
         a.item_lo = it->begin[(size_t)r.t_lo]; a.n_items = it->begin[(size_t)r.t_hi] - a.item_lo;
         unsigned long long*& q = d->d_surv[d->active];
-        if (!q && hipMalloc(reinterpret_cast<void**>(&q), (1 + (size_t)d->surv_cap) * sizeof(unsigned long long)) != hipSuccess) { q = nullptr; (void)hipGetLastError(); }
+        if (!q && hipMalloc(reinterpret_cast<void**>(&q), (8 + (size_t)d->surv_cap) * sizeof(unsigned long long)) != hipSuccess) { q = nullptr; (void)hipGetLastError(); }
         a.surv = q; a.surv_cap = d->surv_cap;       // (no queue: the waves take their survivors' exact sums themselves)
         if (g.wh >= (1u << 20) || nslots > 4096) a.surv = nullptr;      // the entry's 20-bit position / 12-bit slot
     }

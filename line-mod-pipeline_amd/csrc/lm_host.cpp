@@ -128,7 +128,7 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
     out.class_alg_bytes.assign(nc, 0.0);
     out.class_load_bytes.assign(nc, 0.0);
     const bool planes = gl.nibble && gl.plane_ori != 0;
-    if (planes) out.fpad1 = (std::min(M * maxf, 2 * LM_MAX_FEATURES) + 3) / 4 * 4;
+    if (planes) out.fpad1 = (std::min(M * maxf, 2 * LM_MAX_FEATURES) + 7) / 8 * 8;       // (k_scan1_exact reads whole batches of eight: the padding is the zero block)
     // a list entry's bit offset from its nibble offset: the planes of a modality follow its 8 response memories
     auto plane_bit_off = [&](u32 noff) {
         const u32 base = noff / 2u, m = base / gl.mod_stride, label = (base - m * gl.mod_stride) / gl.ori_stride;

@@ -70,7 +70,7 @@ struct LmScanArgs {
     const u32* offn;          // [nt][fpad1] the same features' nibble offsets (exact sums of the survivors)
     int fpad1;
     int no_exact;             // measurement only (scan variant bit 7, WRONG lists): the survivors' exact sums are skipped
-    unsigned long long* surv; // survivor queue of the launch's stream: [0] = entries appended (may exceed the capacity), [1 + i] = template << 32 |
+    unsigned long long* surv; // survivor queues of the launch's stream, one per XCD: [0..7] = entries appended, [8 + x * (surv_cap / 8) + i] = template << 32 |
     u32 surv_cap;             //    slot << 20 | position; k_scan1_exact takes their exact sums.  null / overflow: the wave does it itself
 };
 // a11+a12+a13: similarity scan over the lowest level fused with the threshold scan.

@@ -2810,9 +2810,12 @@ __global__ __launch_bounds__(256) void k_scan1(LmScanArgs a) {
         // hits for the loop below
         const u32 nh = (u32)(__popc(h[0]) + __popc(h[1]) + __popc(h[2]) + __popc(h[3]));
         if (nh) {
-            const unsigned long long at = atomicAdd(a.surv, (unsigned long long)nh);
-            if (at + nh <= (unsigned long long)a.surv_cap) {
-                unsigned long long* q = a.surv + 1 + at;
+            // eight queues, one per XCD when the groups are dealt to the XCDs (group g runs on XCD g % 8): k_scan1_exact's workgroups of XCD x
+            // take queue x, whose entries name the few frames that XCD has just scanned -- their nibble memories then meet in ITS L2
+            const u32 cap8 = a.surv_cap >> 3, qx = grp & 7u;
+            const unsigned long long at = atomicAdd(a.surv + qx, (unsigned long long)nh);
+            if (at + nh <= (unsigned long long)cap8) {
+                unsigned long long* q = a.surv + 8 + (size_t)qx * cap8 + at;
                 const unsigned long long hi = ((unsigned long long)ti << 32) | ((unsigned long long)slot << 20);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -2820,7 +2823,7 @@ __global__ __launch_bounds__(256) void k_scan1(LmScanArgs a) {
                 h[0] = h[1] = h[2] = h[3] = 0;
                 if (a.stat) atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 3], (unsigned long long)nh);
             } else {
-                atomicAdd(a.surv, (unsigned long long)0 - (unsigned long long)nh);     // (give the reservation back: the count stays the number of entries)
+                atomicAdd(a.surv + qx, (unsigned long long)0 - (unsigned long long)nh);     // (give the reservation back)
             }
         }
         hl = __ballot((h[0] | h[1] | h[2] | h[3]) != 0u);
@@ -2872,11 +2875,13 @@ __global__ __launch_bounds__(256) void k_scan1(LmScanArgs a) {
 // Second half of the bit-plane scan: the exact sums of the queued survivors, one lane each (neighbours in the queue are neighbouring
 // positions of one template: their nibble loads share lines).  Sums above the threshold become candidates exactly as k_scan4 emits them.
 __global__ __launch_bounds__(256) void k_scan1_exact(LmScanArgs a) {
-    const unsigned long long total = a.surv[0];
-    const u32 n = total < (unsigned long long)a.surv_cap ? (u32)total : a.surv_cap;
+    const u32 cap8 = a.surv_cap >> 3, qx = blockIdx.x & 7u;           // workgroup b runs on XCD b % 8: queue b % 8
+    const unsigned long long total = a.surv[qx];
+    const u32 n = total < (unsigned long long)cap8 ? (u32)total : cap8;   // (a reservation in flight when its neighbour overflowed may have left the count above the entries: the wave took those itself)
+    const unsigned long long* queue = a.surv + 8 + (size_t)qx * cap8;
     const int offset = a.T / 2 + (a.T % 2 - 1);
-    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const unsigned long long e = a.surv[1 + i];
+    for (u32 i = (blockIdx.x >> 3) * 256u + threadIdx.x; i < n; i += (gridDim.x >> 3) * 256u) {
+        const unsigned long long e = queue[i];
         const u32 ti = (u32)(e >> 32), sl = ((u32)e) >> 20, j = (u32)e & 0xFFFFFu;
         const int cnt = a.scan_n[ti];
         const int nn = cnt & 0xFF;
@@ -2884,16 +2889,23 @@ __global__ __launch_bounds__(256) void k_scan1_exact(LmScanArgs a) {
         const int thr = a.raw_thr_by_n[nn];
         const u32* offn = a.offn + (size_t)ti * a.fpad1;
         const u8* nb = a.lm + (size_t)sl * a.lm_slot_stride;
+        // batches of eight features: the lists are padded to a multiple of eight with offsets of the arena's zero block (response 0), so there is
+        // no tail of single, dependent loads; the next batch's offsets are requested before this batch's responses
         int raw = 0;
-        int f = 0;
-        for (; f + 8 <= F; f += 8) {
+        u32 on[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) on[k] = offn[k];
+        for (int f = 0; f < F; f += 8) {
             u32 by[8], ad[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { ad[k] = offn[f + k] + j; by[k] = nb[ad[k] >> 1]; }
+            for (int k = 0; k < 8; ++k) { ad[k] = on[k] + j; by[k] = nb[ad[k] >> 1]; }
+            if (f + 8 < F) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) on[k] = offn[f + 8 + k];
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) raw += (int)((ad[k] & 1u) ? (by[k] >> 4) : (by[k] & 15u));
         }
-        for (; f < F; ++f) { const u32 ad = offn[f] + j; const u32 by = nb[ad >> 1]; raw += (int)((ad & 1u) ? (by >> 4) : (by & 15u)); }
         if (raw > thr) {
             LmDevHeader* hdr = reinterpret_cast<LmDevHeader*>(reinterpret_cast<u8*>(a.hdr) + (size_t)sl * a.aux_slot_stride);
             LmCand* cand = reinterpret_cast<LmCand*>(reinterpret_cast<u8*>(a.cand) + (size_t)sl * a.aux_slot_stride);
@@ -4152,7 +4164,7 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
         const int ngroups = (nslots + a.G1 - 1) / a.G1;
         a.no_exact = (variant & 128) ? 1 : 0;
         if (variant & 256) a.surv = nullptr;             // A/B: the waves take their survivors' exact sums themselves
-        if (a.surv) (void)hipMemsetAsync(a.surv, 0, sizeof(unsigned long long), s);
+        if (a.surv) (void)hipMemsetAsync(a.surv, 0, 8 * sizeof(unsigned long long), s);
         hipLaunchKernelGGL(k_scan1, dim3((unsigned)(G * ngroups), 1, 1), dim3(256), 0, s, a);
         if (a.surv && !a.no_exact) hipLaunchKernelGGL(k_scan1_exact, dim3(1024), dim3(256), 0, s, a);
         return;

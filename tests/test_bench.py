@@ -172,7 +172,7 @@ def test_counter_files_are_used_only_for_the_command_they_were_collected_with(tm
     sha = bench.kernel_source_sha16()
     assert len(sha) == 16 and sha == bench.kernel_source_sha16()
     meta = {"baseline_config": 2, "frames_per_launch": 96, "threshold": 80.0, "templates_per_gpu": 3000, "scan_variant": 0,
-            "no_prune": False, "byte_responses": False, "kernel_source_sha16": sha}
+            "scan_form": 0, "no_prune": False, "byte_responses": False, "kernel_source_sha16": sha}
     assert bench.load_counters(meta, str(tmp_path)) == (None, "no profiles/*_counters_c2.json committed")
     kernels = {
         "k_scan4<6, true, 2, false>": {"calls": 33, "avg_us": 167.0, "hbm_bytes_per_launch": 60e6, "TCP_TCC_READ_REQ_sum": 32.4e6,
