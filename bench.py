@@ -956,6 +956,8 @@ def latency(args, lm):
     try:
         synth = importlib.import_module("line-mod-pipeline_amd.synth")
         d = lm.Detector(lm.default_config(color_only=True, width=W, height=H, frame_slots=8))
+        if args.scan_form >= 0:
+            d.set_tuning(lm.TUNE_SCAN_FORM, args.scan_form)
         frames = [synth.make_frame(W, H, seed=1234 + i) for i in range(8)]
         q = quantized_from_gpu(d, frames[0][0], None, 1)
         descs, feats, _ = synth.make_bank(NT, 1, 2, seed=4321, quantized=q, crop_fraction=0.1, frame_size=(W, H), T0=d.get_T(0))

@@ -258,8 +258,9 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
 #define LM_TUNE_SCAN_LIST_ORDER 15
 /* LM_TUNE_SCAN_FORM (r05): which kernel scans the lowest level when it keeps nibble-packed memories: 0 (default) = by cost -- the
  *   bit-plane scan k_scan1 (counts the features a position MISSES on one bit per position and orientation, then takes the exact
- *   sums of the few positions the miss bound leaves: k_scan1_exact) for detectors of ONE modality, when it needs at least a fifth
- *   fewer waves than the nibble scan k_scan4 and the threshold is at least LM_TUNE_SCAN1_MIN_THRESHOLD (measured: +9 % on the
+ *   sums of the few positions the miss bound leaves: k_scan1_exact) for detectors of ONE modality and calls of at least 8 frames
+ *   (and a whole group of frames per wave), when it needs at least a fifth fewer waves than the nibble scan k_scan4 and the
+ *   threshold is at least LM_TUNE_SCAN1_MIN_THRESHOLD (measured: +9-10 % on the
  *   colour-only 1280 x 960 workload, a loss with two modalities, where k_scan4's exact pruning stops far sooner than the miss
  *   bound); 1 = always k_scan4; 2 = k_scan1 whenever the level has planes.  The candidate lists, and therefore every result, are
  *   the same. */

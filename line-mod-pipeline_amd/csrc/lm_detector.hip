@@ -521,6 +521,9 @@ int pick_scan1_lanes(const lm_detector* d, int nslots) {
     // RGB-D config 2 -2 % and config 5 -18 %: with two modalities the exact deficits of k_scan4's pruning stop a work item after 29-46 % of its
     // features, the miss bound after 66-84 %.  By cost = one modality only.
     if (d->scan_form != 2 && d->cfg.num_modalities != 1) return 0;
+    // ... and batches only: its three launches (queue reset, k_scan1, k_scan1_exact) cost a single 640 x 480 frame 29 instead of 15 us of scan
+    // (the reference's one-frame call: 100 against 89 us per call)
+    if (d->scan_form != 2 && nslots < 8) return 0;
     long long best = -1; int bestL = 0;
     for (int L1 = 1; L1 <= 64; ++L1) {
         const int G1 = 64 / L1;
@@ -531,7 +534,7 @@ int pick_scan1_lanes(const lm_detector* d, int nslots) {
     }
     if (bestL == 0) return 0;
     const long long waves4 = (long long)d->hb.item_t.size() * ((nslots + 1) / 2);
-    if (d->scan_form != 2 && best * 5 > waves4 * 4) return 0;
+    if (d->scan_form != 2 && (best * 5 > waves4 * 4 || nslots < 64 / bestL)) return 0;      // (and whole groups of frames)
     return bestL;
 }
 

@@ -41,7 +41,8 @@ static void make_geom(const lm_config& c, LmLevelGeom* geom) {   // as lm_create
         g.spread_only = l + 1 < c.pyramid_levels; g.nibble = g.spread_only ? 0 : 1;
         const size_t pad = ((size_t)g.wh + 16 * (size_t)g.W + 2 * LM_SCAN_CHUNK + 64 + 255) / 256 * 256;
         const size_t ori = ((((size_t)g.T * g.T * g.wh) >> g.nibble) + 255) / 256 * 256 + pad;
-        g.ori_stride = (u32)ori; g.mod_stride = (u32)(g.spread_only ? ori : 8 * ori);
+        const size_t plane = g.nibble ? (((size_t)g.T * g.T * g.wh + 7) / 8 + ((size_t)g.wh + 64 * 128) / 8 + 64 + 255) / 256 * 256 : 0;   // r05: the miss planes
+        g.ori_stride = (u32)ori; g.plane_ori = (u32)plane; g.mod_stride = (u32)(g.spread_only ? ori : 8 * ori + 8 * plane);
         g.zero_off = (u32)((size_t)c.num_modalities * g.mod_stride); g.arena_bytes = g.zero_off + (u32)pad;
     }
 }
@@ -62,6 +63,46 @@ static void digest(const lmh::Bank& bank, const lm_config& cfg) {
             std::vector<u32> a(base.begin() + (ptrdiff_t)at, base.begin() + (ptrdiff_t)(at + fpad)), b(hb.scan_off.begin() + (ptrdiff_t)at, hb.scan_off.begin() + (ptrdiff_t)(at + fpad));
             std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
             if (a != b) { std::printf("scan list order %d is not a permutation of the ascending list at %zu\n", order, at); std::abort(); }
+        }
+    }
+    // r05, the bit-plane scan's lists (order 3 is in hb): per template the in-bounds features of all modalities once, every bit offset inside a
+    // miss plane of the right modality and orientation and at the same position as its nibble offset; padding = the zero block; work items for L
+    // lanes per frame cover every template's positions exactly once
+    {
+        const LmLevelGeom& g = geom[cfg.pyramid_levels - 1];
+        const int M = cfg.num_modalities;
+        const size_t nt = hb.scan_P.size();
+        if (hb.fpad1 <= 0 || hb.fpad1 % 8 || hb.off1.size() != nt * (size_t)hb.fpad1 || hb.offn.size() != hb.off1.size()) { std::printf("bit-plane lists have the wrong shape\n"); std::abort(); }
+        for (size_t t = 0; t < nt; ++t) {
+            const int cnt = hb.scan_n[t];
+            int F = 0;
+            std::vector<u32> want;
+            for (int m = 0; m < M; ++m) {
+                const int k = (cnt >> (8 + 8 * m)) & 0xFF;
+                for (int q = 0; q < k; ++q) want.push_back(hb.scan_off[(t * M + m) * (size_t)hb.fpad + q]);
+                F += k;
+            }
+            for (int f = 0; f < hb.fpad1; ++f) {
+                const u32 on = hb.offn[t * hb.fpad1 + f], ob = hb.off1[t * hb.fpad1 + f];
+                if (f >= F) { if (on != 2u * g.zero_off || ob != 8u * g.zero_off) { std::printf("bit-plane list padding is not the zero block\n"); std::abort(); } continue; }
+                if (on != want[(size_t)f]) { std::printf("nibble offset %d of template %zu differs from the per-modality list\n", f, t); std::abort(); }
+                const u32 m = (on / 2u) / g.mod_stride, rel = on / 2u - m * g.mod_stride, label = rel / g.ori_stride;
+                const u32 pos = on - 2u * (m * g.mod_stride + label * g.ori_stride);                 // position inside the orientation's T * T memories
+                const u32 plane0 = 8u * (m * g.mod_stride + 8u * g.ori_stride + label * g.plane_ori);
+                if (label > 7 || pos >= (u32)(g.T * g.T) * g.wh || ob != plane0 + pos) { std::printf("bit offset %d of template %zu is not its nibble offset's position in the miss plane\n", f, t); std::abort(); }
+            }
+        }
+        for (int L1 : {1, 3, 8, 9, 10, 38, 64}) {
+            std::vector<u32> it, ic; std::vector<int> begin;
+            lmh::build_items1(hb, L1, it, ic, begin);
+            if ((long long)it.size() != hb.items1_by_L[L1] || begin.size() != nt + 1 || begin.back() != (int)it.size()) { std::printf("items of %d lanes per frame: wrong count\n", L1); std::abort(); }
+            const int chunk = 128 * L1 - 31;
+            for (size_t t = 0; t < nt; ++t) {
+                const int n = begin[t + 1] - begin[t];
+                if (n != (hb.scan_P[t] + chunk - 1) / chunk) { std::printf("items of %d lanes per frame: template %zu has %d chunks\n", L1, t, n); std::abort(); }
+                for (int k = 0; k < n; ++k)
+                    if (it[(size_t)begin[t] + k] != (u32)t || ic[(size_t)begin[t] + k] != (u32)k) { std::printf("items of %d lanes per frame: not template-major\n", L1); std::abort(); }
+            }
         }
     }
     lmh::HullTable ht;
