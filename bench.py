@@ -131,6 +131,7 @@ class Runner:
             det.set_tuning(lm.TUNE_SCAN_FORM, args.scan_form)
         if args.no_prune:
             det.set_scan_variant(8)
+            det.set_tuning(lm.TUNE_SCAN_FORM, 1)          # the exhaustive scan is k_scan4's (k_scan1 always prunes): the request-size calibration runs on it
         elif args.scan_variant:
             det.set_scan_variant(args.scan_variant)
         for i, (bgr, depth) in enumerate(self.frames):

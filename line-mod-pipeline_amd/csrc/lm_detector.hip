@@ -48,6 +48,7 @@ struct Slot {
     u8* h_bgr = nullptr;     // pinned upload staging
     u16* h_depth = nullptr;
     bool has_frame = false;
+    bool planes = false;     // ... and that pass wrote the scanned level's miss planes (k_scan1 may read them)
     bool prepared = false;   // a3-a10 have run on the frame the slot holds with the LUTs / thresholds now in force (lm_match_prepared)
     // Uploads run on the detector's copy stream: ev_up is recorded behind the slot's H2D copies, up_seq is the
     // upload's ticket (0 = never uploaded through the copy stream).  Copies complete in ticket order.
@@ -174,6 +175,7 @@ struct lm_detector {
     int scan_form = 0;               // LM_TUNE_SCAN_FORM: 0 = by cost (default), 1 = always the nibble scan k_scan4, 2 = the bit-plane scan k_scan1 whenever the level has planes
     float scan1_min_threshold = 50.0f;   // below this similarity threshold the miss bound keeps too many positions alive: k_scan4 (LM_TUNE_SCAN1_MIN_THRESHOLD)
     long long cnt_scan1_launches = 0; int last_scan1_lanes = 0;
+    bool emit_planes = false;        // the pre-processing being enqueued writes the miss planes (set per call by enqueue_preprocess)
     unsigned long long* d_surv[LM_NLANES] = {};      // k_scan1's survivor queues, one per lane, allocated on a lane's first bit-plane scan
     u32 surv_cap = 1u << 20;
     LmRefMeta* d_ref_meta[LM_MAX_LEVELS] = {};
@@ -390,6 +392,21 @@ void enqueue_depth_pyramid(lm_detector* d, int first, int n) {
 
 int wait_uploads(lm_detector* d, hipStream_t stream, int first, int n, unsigned long long* seqs);
 
+// The miss planes of the scanned level are written (by the pass that writes its nibble memories) only where the bit-plane scan can run: they
+// cost k_lm_fast a second set of scattered stores (measured r05: 16.2 -> 24.4 us per 96-frame launch of config 2, 70 -> 115 us per 128 frames
+// of config 3).  By cost that is a call of 8+ frames on a one-modality detector (pick_scan1_lanes); LM_TUNE_SCAN_FORM 2 asks for them always,
+// 1 never.  A slot remembers whether its pass wrote them (Slot::planes): k_scan1 never reads planes of an older frame.
+bool planes_wanted(const lm_detector* d, int n) {
+    if (d->scan_form == 1) return false;
+    if (d->scan_form == 2) return true;
+    return d->cfg.num_modalities == 1 && n >= 8;
+}
+u32 plane_stride_in_use(const lm_detector* d, int level) {
+    const LmLevelGeom& g = d->geom[level];
+    if (!g.plane_ori || !d->emit_planes) return 0u;
+    return g.plane_ori;
+}
+
 // one modality's linear memories of level l (a6-a10)
 void enqueue_lm(lm_detector* d, hipStream_t st, int first, int n, int l, int m) {
     const size_t fs = d->frame_stride;
@@ -397,10 +414,10 @@ void enqueue_lm(lm_detector* d, hipStream_t st, int first, int n, int l, int m) 
     const int sp = g.spread_only ? 1 : g.nibble ? 2 : 0;
     u8* dst = d->lm(first, l) + (size_t)m * g.mod_stride;
     if (m == 0 || l == 0)
-        lmk_linear_memories(st, d->quant(first, l, m), g.w, 0, sp, g.w, g.h, g.T, d->d_resp_tab, dst, g.ori_stride, fs, fs, n, g.plane_ori);
+        lmk_linear_memories(st, d->quant(first, l, m), g.w, 0, sp, g.w, g.h, g.T, d->d_resp_tab, dst, g.ori_stride, fs, fs, n, plane_stride_in_use(d, l));
     else   // level l of the depth modality reads the quantised image of level l-1 at (2y, 2x)
         lmk_linear_memories(st, d->quant(first, l - 1, 1), d->lw[l - 1], 1, sp, g.w, g.h, g.T, d->d_resp_tab, dst,
-                            g.ori_stride, fs, fs, n, g.plane_ori);
+                            g.ori_stride, fs, fs, n, plane_stride_in_use(d, l));
 }
 
 // How many 640 x 480 frames one frame of this detector counts as in the few-frame / batch kernel selection (at least 1).
@@ -412,6 +429,8 @@ int slot_weight(const lm_detector* d) {
 
 // a3-a10 on the frames resident in slots [first, first + n).
 void enqueue_preprocess(lm_detector* d, int first, int n) {
+    d->emit_planes = planes_wanted(d, n) && d->geom[d->cfg.pyramid_levels - 1].plane_ori != 0;
+    for (int i = 0; i < n; ++i) d->slots[first + i].planes = d->emit_planes;
     const lm_config& c = d->cfg;
     const int M = c.num_modalities, L = c.pyramid_levels;
     const size_t fs = d->frame_stride;
@@ -435,7 +454,7 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
         pa.lm_d0 = d->lm(first, 0) + d->geom[0].mod_stride; pa.lm_d1 = d->lm(first, 1) + d->geom[1].mod_stride;
         pa.w = d->lw[0]; pa.h = d->lh[0];
         pa.weak_threshold = c.weak_threshold; pa.dist_thr = c.distance_threshold; pa.diff_thr = c.difference_threshold;
-        pa.normal_lut = d->d_normal_lut; pa.resp_tab = d->d_resp_tab; pa.ori_stride1 = d->geom[1].ori_stride; pa.plane_ori1 = d->geom[1].plane_ori;
+        pa.normal_lut = d->d_normal_lut; pa.resp_tab = d->d_resp_tab; pa.ori_stride1 = d->geom[1].ori_stride; pa.plane_ori1 = plane_stride_in_use(d, 1);
         pa.slot_stride = fs; pa.nslots = n;
         auto mode = [&](int l) { return d->geom[l].spread_only ? 1 : d->geom[l].nibble ? 2 : 0; };
         const bool onehot = M == 2 ? normal_lut_onehot(d) : true;
@@ -513,9 +532,10 @@ int item_ranges(lm_detector* d, std::vector<int>& classes, std::vector<ItemRange
 // chunks of 128 L1 - 31 positions there, two frames of chunks of 1016 here.  So the form with fewer waves wins; L1 is the lane count
 // with the fewest.  k_scan1 needs a margin (its waves stop when the LAST of their frames is out of reach, and the survivors' exact
 // sums come on top), and a threshold high enough for the miss bound to bite.  Returns L1, or 0 for k_scan4 / k_scan.
-int pick_scan1_lanes(const lm_detector* d, int nslots) {
+int pick_scan1_lanes(const lm_detector* d, int first, int nslots) {
     const LmLevelGeom& g = d->geom[d->cfg.pyramid_levels - 1];
     if (!g.nibble || !g.plane_ori || !d->hb.fpad1 || d->scan_form == 1) return 0;
+    for (int i = 0; i < nslots; ++i) if (!d->slots[first + i].planes) return 0;      // (a frame prepared by a call that did not write them)
     if (d->scan_form != 2 && !(d->raw_thr_for >= d->scan1_min_threshold)) return 0;
     // measured r05 (profiles/r05_ab_experiments.log, three lanes): colour-only config 3 +9 % (the scan launch 389 -> 296 us per 128 frames), but
     // RGB-D config 2 -2 % and config 5 -18 %: with two modalities the exact deficits of k_scan4's pruning stop a work item after 29-46 % of its
@@ -570,7 +590,7 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots = 1
     a.cand = reinterpret_cast<LmCand*>(d->aux(first, d->off_cand));
     a.aux_slot_stride = d->aux_stride;
     a.cand_cap = d->max_cand;
-    const int L1 = pick_scan1_lanes(d, nslots);
+    const int L1 = pick_scan1_lanes(d, first, nslots);
     const lm_detector::Items1* it = nullptr;
     if (L1 && ensure_items1(d, L1, &it) == LM_OK) {
         a.L1 = L1; a.G1 = 64 / L1;
@@ -1468,7 +1488,12 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
         case LM_TUNE_WORK_WEIGHT: if (value < 0 || value > 1) break; d->work_weight_by_pixels = value; return LM_OK;
         case LM_TUNE_SORT_SPLIT: if (value < 0 || value > 2) break; d->sort_split_mode = value; return LM_OK;
         case LM_TUNE_SCAN_LIST_ORDER: if (value < 0 || value > 3) break; d->scan_list_order = value; d->bank_dirty = true; return LM_OK;
-        case LM_TUNE_SCAN_FORM: if (value < 0 || value > 2) break; d->scan_form = value; return LM_OK;
+        case LM_TUNE_SCAN_FORM:
+            if (value < 0 || value > 2) break;
+            if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
+            d->scan_form = value;
+            for (Slot& sl : d->slots) sl.prepared = false;          // (prepared slots may lack the miss planes the new form reads)
+            return LM_OK;
         case LM_TUNE_SCAN1_MIN_THRESHOLD: if (value < 0 || value > 100) break; d->scan1_min_threshold = (float)value; return LM_OK;
         default: return fail(LM_ERR_INVALID, "unknown tuning key");
     }
@@ -2567,7 +2592,11 @@ int lm_stage_scan(lm_detector* d, int slot, float threshold, int class_idx, int3
     ItemRange r;
     if ((rc = item_range(d, class_idx, &r))) return rc;
     if ((rc = enqueue_threshold(d, threshold))) return rc;
-    lmk_scan(d->stream, make_scan_args(d, slot, r), d->scan_variant, 1);
+    {
+        const LmScanArgs sa = make_scan_args(d, slot, r);
+        lmk_scan(d->stream, sa, d->scan_variant, 1);
+        d->last_scan1_lanes = sa.L1;
+    }
     LmDevHeader h;
     HIP_TRY(hipMemcpyAsync(&h, d->aux(slot, d->off_hdr), sizeof(h), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));

@@ -56,6 +56,7 @@ def test_scan1_candidates_and_matches(lm, orc, synth, color_only, size, T, thr):
     d.set_tuning(lm.TUNE_SCAN_FORM, 1)
     assert np.array_equal(d.stage_scan(0, thr), exp_c)
     d.set_tuning(lm.TUNE_SCAN_FORM, 2)
+    d.prepare_slot(0)                                    # (the miss planes are written only for the form that reads them)
     d.set_scan_stats(True)
     assert np.array_equal(d.stage_scan(0, thr), exp_c)
     loaded, unpruned = d.get_scan_stats()
@@ -101,6 +102,7 @@ def test_scan1_similarity_tables(lm, orc, synth):
                     d.upload_frame(k, bgr, dep)
                 d.prepare_slot(0)
                 assert np.array_equal(d.stage_scan(0, thr), exp_c), (form, thr)
+                assert (d.get_scan_form_stats()[3] > 0) == (form == 2)
                 got, cnt = d.match_batch(4, thr, cap_per_frame=1 << 15)
                 for k in range(4):
                     assert_matches_equal(got[k, :cnt[k]], exp)
