@@ -2022,45 +2022,57 @@ __device__ __forceinline__ void d_lm_fast(const u32 vblock, const u8* __restrict
     }
     __syncthreads();
     if (MODE == 2) {
-        // linearize, nibble-packed: unit = (row-in-band j, column phase c0, 8 consecutive memory columns)
-        constexpr int C8 = SEG / 8;
-        for (int u = tid; u < T * T * C8; u += 256) {
-            const int k8 = u % C8, g = u / C8;
+        // linearize, nibble-packed: unit = (row-in-band j, column phase c0, UW consecutive memory columns).  UW = 8: one dword per orientation
+        // (and one byte per miss plane); segments whose width is a multiple of 16 take UW = 16 (r05): an 8-byte store per orientation and a
+        // 2-byte store per plane -- the kernel is bound by the number of its scattered stores, not by their bytes
+        constexpr int UW = (SEG % 16 == 0) ? 16 : 8;
+        constexpr int NH = UW / 8;
+        constexpr int CU = SEG / UW;
+        for (int u = tid; u < T * T * CU; u += 256) {
+            const int ku = u % CU, g = u / CU;
             const int j = g / T, c0 = g - j * T;
-            if (8 * k8 >= ncols) continue;
+            if (UW * ku >= ncols) continue;
             const u8* row = reinterpret_cast<const u8*>(&sp[j][0]);
-            u64 e[4];
+            u32 nd[NH][8], pb[NH][8];        // per half of the unit: the nibble dword / the miss byte of every orientation
 #pragma unroll
-            for (int i = 0; i < 4; ++i)   // byte o of e[i] = response o of columns 2i (low nibble) and 2i+1
-                e[i] = tab[row[(8 * k8 + 2 * i) * T + c0]] | (tab[row[(8 * k8 + 2 * i + 1) * T + c0]] << 4);
-            const u32 a0 = (u32)e[0], a1 = (u32)e[1], a2 = (u32)e[2], a3 = (u32)e[3];
-            const u32 b0 = (u32)(e[0] >> 32), b1 = (u32)(e[1] >> 32), b2 = (u32)(e[2] >> 32), b3 = (u32)(e[3] >> 32);
-            u8* dst = lm + (((size_t)g * wh + (size_t)band * W + col0 + 8 * k8) >> 1);
+            for (int h = 0; h < NH; ++h) {
+                const int k8 = NH * ku + h;
+                u64 e[4];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                const u32 sel = (u32)o | ((u32)(o + 4) << 8);
-                u32 lo = __builtin_amdgcn_perm(a1, a0, sel) & 0xFFFFu;
-                u32 hi = __builtin_amdgcn_perm(a3, a2, sel) << 16;
-                *reinterpret_cast<u32*>(dst + (size_t)o * ori_stride) = lo | hi;
-                u32 lo2 = __builtin_amdgcn_perm(b1, b0, sel) & 0xFFFFu;
-                u32 hi2 = __builtin_amdgcn_perm(b3, b2, sel) << 16;
-                *reinterpret_cast<u32*>(dst + (size_t)(o + 4) * ori_stride) = lo2 | hi2;
-            }
-            if (plane_ori) {
-                // r05, k_scan1's bit planes: per orientation one BIT per position, set where the response is below 4 (a "miss");
-                // the 8 columns of this unit are one byte of each of the 8 planes -- an 8 x 8 bit transpose of the 8 miss masks
-                u32 x = 0, y = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    x |= (u32)tabu[row[(8 * k8 + i) * T + c0]] << (8 * i);
-                    y |= (u32)tabu[row[(8 * k8 + 4 + i) * T + c0]] << (8 * i);
-                }
-                bit_transpose8(x, y);
-                u8* pl = lm + 8 * (size_t)ori_stride + (((size_t)g * wh + (size_t)band * W + col0 + 8 * k8) >> 3);
+                for (int i = 0; i < 4; ++i)   // byte o of e[i] = response o of columns 2i (low nibble) and 2i+1
+                    e[i] = tab[row[(8 * k8 + 2 * i) * T + c0]] | (tab[row[(8 * k8 + 2 * i + 1) * T + c0]] << 4);
+                const u32 a0 = (u32)e[0], a1 = (u32)e[1], a2 = (u32)e[2], a3 = (u32)e[3];
+                const u32 b0 = (u32)(e[0] >> 32), b1 = (u32)(e[1] >> 32), b2 = (u32)(e[2] >> 32), b3 = (u32)(e[3] >> 32);
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
-                    pl[(size_t)o * plane_ori] = (u8)(x >> (8 * o));
-                    pl[(size_t)(o + 4) * plane_ori] = (u8)(y >> (8 * o));
+                    const u32 sel = (u32)o | ((u32)(o + 4) << 8);
+                    nd[h][o] = (__builtin_amdgcn_perm(a1, a0, sel) & 0xFFFFu) | (__builtin_amdgcn_perm(a3, a2, sel) << 16);
+                    nd[h][o + 4] = (__builtin_amdgcn_perm(b1, b0, sel) & 0xFFFFu) | (__builtin_amdgcn_perm(b3, b2, sel) << 16);
+                }
+                if (plane_ori) {
+                    // r05, k_scan1's bit planes: per orientation one BIT per position, set where the response is below 4 (a "miss");
+                    // 8 columns are one byte of each of the 8 planes -- an 8 x 8 bit transpose of the 8 miss masks
+                    u32 x = 0, y = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        x |= (u32)tabu[row[(8 * k8 + i) * T + c0]] << (8 * i);
+                        y |= (u32)tabu[row[(8 * k8 + 4 + i) * T + c0]] << (8 * i);
+                    }
+                    bit_transpose8(x, y);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) { pb[h][o] = (x >> (8 * o)) & 0xFFu; pb[h][o + 4] = (y >> (8 * o)) & 0xFFu; }
+                }
+            }
+            const size_t pos = (size_t)g * wh + (size_t)band * W + col0 + UW * ku;
+            u8* dst = lm + (pos >> 1);
+            u8* pl = lm + 8 * (size_t)ori_stride + (pos >> 3);
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                if (NH == 2) *reinterpret_cast<u32x2*>(dst + (size_t)o * ori_stride) = u32x2{nd[0][o], nd[NH - 1][o]};
+                else *reinterpret_cast<u32*>(dst + (size_t)o * ori_stride) = nd[0][o];
+                if (plane_ori) {
+                    if (NH == 2) *reinterpret_cast<unsigned short*>(pl + (size_t)o * plane_ori) = (unsigned short)(pb[0][o] | (pb[NH - 1][o] << 8));
+                    else pl[(size_t)o * plane_ori] = (u8)pb[0][o];
                 }
             }
         }
@@ -4015,7 +4027,12 @@ void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, 
                     return;
                 }
                 lm_fast_launch<5, 128>(LMF_ARGS); return;
-            case 8: lm_fast_launch<8, 40>(LMF_ARGS); return;
+            case 8:
+                // r05: whole segments of 80 columns take 16-column units (half the scattered stores); everything else 40-column segments
+                if (mode == 2 && (W % 80) == 0 && (((size_t)W * (h / 8)) % 16) == 0 && (((uintptr_t)lm & 7) == 0) && (lm_slot_stride % 8) == 0 && (ori_stride % 8) == 0 && (plane_ori % 2) == 0) {
+                    lm_fast_launch<8, 80>(LMF_ARGS); return;
+                }
+                lm_fast_launch<8, 40>(LMF_ARGS); return;
             default: break;
         }
 #undef LMF_ARGS
@@ -4148,6 +4165,14 @@ void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
             if (tall) { if (!bp) launch(k_bphase<1, 2, 32, 32>, p1); launch(k_bphase<2, 2, 32, 32>, p2); launch(k_bphase<3, 2, 32, 32>, p3); }
             else { if (!bp) launch(k_bphase<1, 2, 16, 16>, p1); launch(k_bphase<2, 2, 16, 16>, p2); launch(k_bphase<3, 2, 16, 16>, p3); }
         }
+    }
+    const int W1 = w1 / 8;
+    if ((W1 % 80) == 0 && (((size_t)W1 * (h1 / 8)) % 16) == 0 && (((uintptr_t)a.lm_c1 & 7) == 0) && (a.slot_stride % 8) == 0 && (a.ori_stride1 % 8) == 0 && (a.plane_ori1 % 2) == 0) {
+        // (16-column units: half the scattered stores, see d_lm_fast MODE 2)
+        const int seg80 = W1 / 80;
+        hipLaunchKernelGGL((k_lm_fast<8, 80, 0, 2>), dim3((unsigned)(seg80 * (h1 / 8) * n)), dim3(256), 0, s, a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1,
+                           a.slot_stride, a.slot_stride, seg80, n, a.plane_ori1);
+        return;
     }
     hipLaunchKernelGGL((k_lm_fast<8, 40, 0, 2>), dim3(b_lm1), dim3(256), 0, s, a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1,
                        a.slot_stride, a.slot_stride, seg1, n, a.plane_ori1);
