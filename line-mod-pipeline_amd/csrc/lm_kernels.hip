@@ -2023,9 +2023,10 @@ __device__ __forceinline__ void d_lm_fast(const u32 vblock, const u8* __restrict
     __syncthreads();
     if (MODE == 2) {
         // linearize, nibble-packed: unit = (row-in-band j, column phase c0, UW consecutive memory columns).  UW = 8: one dword per orientation
-        // (and one byte per miss plane); segments whose width is a multiple of 16 take UW = 16 (r05): an 8-byte store per orientation and a
-        // 2-byte store per plane -- the kernel is bound by the number of its scattered stores, not by their bytes
-        constexpr int UW = (SEG % 16 == 0) ? 16 : 8;
+        // (and one byte per miss plane); k_lm_fast<8, 80, ..> -- launched only for rows of whole 80-column segments -- takes UW = 16 (r05): an
+        // 8-byte store per orientation and a 2-byte store per plane: the kernel is bound by the number of its scattered stores, not by their
+        // bytes.  (A 16-column unit on a segment whose last part is 8 columns wide would write into the next row: the fuzzer's catch.)
+        constexpr int UW = (T == 8 && SEG == 80) ? 16 : 8;     // (only the launch that guarantees whole 80-column segments and the stores' alignment)
         constexpr int NH = UW / 8;
         constexpr int CU = SEG / UW;
         for (int u = tid; u < T * T * CU; u += 256) {

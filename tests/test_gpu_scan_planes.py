@@ -127,3 +127,37 @@ def test_scan1_few_features_and_classes(lm, orc, synth):
                 for k in range(8):
                     assert cnt[k] == len(exp) and got[k, :cnt[k]].tobytes() == exp.tobytes(), (nf, thr, classes, k)
         d.close()
+
+
+@pytest.mark.parametrize("color_only,size,T", [
+    (False, (576, 432), [4, 4]),      # 72 memory columns at T = 4: segments of 64 + 8 columns (the fuzzer's catch: a 16-column unit must not run over the row end)
+    (False, (576, 472), [4, 4]),
+    (True, (1280, 960), [2, 8]),      # 80 memory columns at T = 8: k_lm_fast<8, 80, ..> with 16-column units
+    (False, (1280, 960), [5, 8]),
+    (False, (640, 480), [5, 8]),
+])
+def test_linear_memories_after_a_batch_call(lm, orc, synth, color_only, size, T):
+    """The batch kernels' linear memories (what lm_match_batch leaves in the slots) against the oracle, every level and modality, with
+    the miss planes being written beside them (scan form 2) and without (1); then the scan on them."""
+    w, h = size
+    nb = 16
+    d = lm.Detector(lm.default_config(color_only=color_only, width=w, height=h, T=T, frame_slots=nb))
+    o = orc.Detector(color_only=color_only, T=T)
+    frames = [synth.make_frame(w, h, seed=400 + k) for k in range(2)]
+    q = _quantized(o, frames[0][0], frames[0][1], color_only)
+    M = 1 if color_only else 2
+    descs, feats, _ = synth.make_bank(20, M, 2, seed=77, quantized=q, crop_fraction=0.5, frame_size=(w, h), T0=T[0])
+    d.add_class("c", descs, feats); o.add_class("c", descs, feats)
+    exp = [o.match(f[0], None if color_only else f[1], 85.0, threads=8, cap=1 << 18) for f in frames]
+    for form in (2, 1):
+        d.set_tuning(lm.TUNE_SCAN_FORM, form)
+        for k in range(nb):
+            d.upload_frame(k, frames[k % 2][0], None if color_only else frames[k % 2][1])
+        got, cnt = d.match_batch(nb, 85.0, cap_per_frame=1 << 15)
+        for k in (0, 1, nb - 1):
+            assert_matches_equal(got[k, :cnt[k]], exp[k % 2])
+            o.prepare(frames[k % 2][0], None if color_only else frames[k % 2][1])
+            for level in range(2):
+                for mod in range(M):
+                    assert np.array_equal(d.debug_read(k, 2, level, mod), o.stage(2, level, mod)), (form, k, level, mod)
+    d.close()
