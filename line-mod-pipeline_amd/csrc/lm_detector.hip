@@ -158,7 +158,7 @@ struct lm_detector {
     u32* d_plan = nullptr;        // k_refine_plan output, one per lane: [8][cap] slots + [8] lengths + [8][cap + 1] running sums + [8][cap] first entries
     int plan_stride_cap = 0;
     u64* d_resp_tab = nullptr;
-    int miss_delta = 3;           // 4 - the largest response below 4 of the similarity table (ensure_luts)
+    int miss_delta = 1;           // 4 - the largest response below 4 of the similarity table (ensure_luts; upstream's table: a neighbouring orientation scores 3)
     u32* d_sim_lut = nullptr;
     u8* d_normal_lut = nullptr;
     bool luts_dirty = true;
@@ -324,7 +324,7 @@ int ensure_luts(lm_detector* d) {
         }
         tab[v] = e;
     }
-    d->miss_delta = 4 - below4;                        // what a missed feature costs at least (k_scan1's bound): 3 with the default table
+    d->miss_delta = 4 - below4;                        // what a missed feature costs at least (k_scan1's bound): 1 with upstream's table (responses 0 .. 4)
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(d->d_resp_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d->d_sim_lut, d->sim_lut, 256, hipMemcpyHostToDevice));

@@ -2658,7 +2658,7 @@ __global__ __launch_bounds__(256) void k_scan4(LmScanArgs a) {
 // a11-a13, bit-plane form of the hot kernel (r05; LmScanArgs::L1 != 0).  k_scan4 adds every response of every feature at every
 // position -- 4 bits a position, 14 vector instructions per feature and 32 positions -- although all the threshold scan wants
 // to know is WHERE the sum exceeds the threshold.  A response is 4 only where the feature's orientation itself is present; every
-// other response is at most 4 - delta (delta = 3 with the default table: 1 for a neighbouring orientation, 0 otherwise).  So a
+// other response is at most 4 - delta (delta = 1 with upstream's table, whose responses are 4, 3, 2, 1, 0 by angular distance).  So a
 // position that has MISSED (response below 4) more than m_max = (4 F - threshold - 1) / delta of a template's F in-bounds
 // features cannot exceed the threshold whatever the missed responses were.  This kernel only counts misses:
 //   * the producer (d_lm_fast, MODE 2 + planes) keeps, next to the nibble memories, one BIT per position and orientation --
