@@ -177,6 +177,7 @@ struct lm_detector {
     long long cnt_scan1_launches = 0; int last_scan1_lanes = 0;
     bool emit_planes = false;        // the pre-processing being enqueued writes the miss planes (set per call by enqueue_preprocess)
     unsigned long long* d_surv[LM_NLANES] = {};      // k_scan1's survivor queues, one per lane, allocated on a lane's first bit-plane scan
+    int surv_set[LM_NLANES] = {};                    // which of a queue's two counter sets the lane's next scan launch uses (the other is zeroed behind it)
     u32 surv_cap = 1u << 20;
     LmRefMeta* d_ref_meta[LM_MAX_LEVELS] = {};
     LmRefFeat* d_ref_feat[LM_MAX_LEVELS] = {};
@@ -577,7 +578,7 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots = 1
     const int L = d->cfg.pyramid_levels;
     const LmLevelGeom& g = d->geom[L - 1];
     LmScanArgs a;
-    a.L1 = 0; a.G1 = 1; a.L1_rcp16 = 0; a.delta_rcp16 = 0; a.off1 = a.offn = nullptr; a.fpad1 = 0; a.no_exact = 0; a.surv = nullptr; a.surv_cap = 0;
+    a.L1 = 0; a.G1 = 1; a.L1_rcp16 = 0; a.delta_rcp16 = 0; a.off1 = a.offn = nullptr; a.fpad1 = 0; a.no_exact = 0; a.surv = nullptr; a.surv_cap = 0; a.surv_set = 0;
     a.lm = d->lm(first, L - 1); a.lm_slot_stride = d->frame_stride;
     a.item_t = d->d_item_t; a.item_chunk = d->d_item_chunk;
     a.item_lo = r.lo; a.n_items = r.n;
@@ -600,11 +601,24 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots = 1
         a.item_t = it->d_t; a.item_chunk = it->d_chunk;
         a.item_lo = it->begin[(size_t)r.t_lo]; a.n_items = it->begin[(size_t)r.t_hi] - a.item_lo;
         unsigned long long*& q = d->d_surv[d->active];
-        if (!q && hipMalloc(reinterpret_cast<void**>(&q), (8 + (size_t)d->surv_cap) * sizeof(unsigned long long)) != hipSuccess) { q = nullptr; (void)hipGetLastError(); }
+        if (!q) {
+            if (hipMalloc(reinterpret_cast<void**>(&q), (16 + (size_t)d->surv_cap) * sizeof(unsigned long long)) != hipSuccess) { q = nullptr; (void)hipGetLastError(); }
+            else if (hipMemset(q, 0, 16 * sizeof(unsigned long long)) != hipSuccess) { hipFree(q); q = nullptr; (void)hipGetLastError(); }
+            d->surv_set[d->active] = 0;
+        }
         a.surv = q; a.surv_cap = d->surv_cap;       // (no queue: the waves take their survivors' exact sums themselves)
+        a.surv_set = d->surv_set[d->active];
         if (g.wh >= (1u << 20) || nslots > 4096) a.surv = nullptr;      // the entry's 20-bit position / 12-bit slot
     }
     return a;
+}
+
+// after every launch of lmk_scan with these arguments: the lane's next bit-plane scan takes the other set of queue counters (this launch's
+// k_scan1_exact has zeroed it)
+void scan_launched(lm_detector* d, LmScanArgs& a) {
+    if (!a.L1 || !a.surv) return;
+    d->surv_set[d->active] ^= 1;
+    a.surv_set = d->surv_set[d->active];
 }
 
 LmRefineArgs make_refine_args(lm_detector* d, int first, int level, float threshold) {
@@ -658,8 +672,9 @@ int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, cons
     // one scan launch per run of neighbouring classes; the launches append to the same candidate lists
     for (const ItemRange& r : ranges)
         if (r.n > 0) {
-            const LmScanArgs sa = make_scan_args(d, first, r, n);
+            LmScanArgs sa = make_scan_args(d, first, r, n);
             lmk_scan(d->stream, sa, d->scan_variant, n);
+            scan_launched(d, sa);
             d->cnt_scan_launches += 1; d->cnt_scan1_launches += sa.L1 ? 1 : 0; d->last_scan1_lanes = sa.L1;
         }
     if (timed) HIP_TRY(hipEventRecord(d->ev[2], d->stream));
@@ -2593,9 +2608,10 @@ int lm_stage_scan(lm_detector* d, int slot, float threshold, int class_idx, int3
     if ((rc = item_range(d, class_idx, &r))) return rc;
     if ((rc = enqueue_threshold(d, threshold))) return rc;
     {
-        const LmScanArgs sa = make_scan_args(d, slot, r);
+        LmScanArgs sa = make_scan_args(d, slot, r);
         lmk_scan(d->stream, sa, d->scan_variant, 1);
         d->last_scan1_lanes = sa.L1;
+        scan_launched(d, sa);
     }
     LmDevHeader h;
     HIP_TRY(hipMemcpyAsync(&h, d->aux(slot, d->off_hdr), sizeof(h), hipMemcpyDeviceToHost, d->stream));
@@ -2632,9 +2648,9 @@ int lm_time_scan(lm_detector* d, int slot, float threshold, int class_idx, int i
     if ((rc = enqueue_threshold(d, threshold))) return rc;
     LmScanArgs a = make_scan_args(d, slot, r);
     a.cand_cap = 0;  // timing only: count candidates, store none (the list would overflow across iterations)
-    for (int i = 0; i < 3; ++i) lmk_scan(d->stream, a, variant, 1);
+    for (int i = 0; i < 3; ++i) { lmk_scan(d->stream, a, variant, 1); scan_launched(d, a); }
     HIP_TRY(hipEventRecord(d->ev[0], d->stream));
-    for (int i = 0; i < iters; ++i) lmk_scan(d->stream, a, variant, 1);
+    for (int i = 0; i < iters; ++i) { lmk_scan(d->stream, a, variant, 1); scan_launched(d, a); }
     HIP_TRY(hipEventRecord(d->ev[1], d->stream));
     HIP_TRY(hipMemsetAsync(d->aux(slot, d->off_hdr), 0, sizeof(LmDevHeader), d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
@@ -2669,9 +2685,9 @@ int lm_time_scan_batch(lm_detector* d, int first_slot, int n_slots, float thresh
     if ((rc = enqueue_threshold(d, threshold))) return rc;
     LmScanArgs a = make_scan_args(d, first_slot, r, n_slots);
     a.cand_cap = 0;
-    for (int i = 0; i < 2; ++i) lmk_scan(d->stream, a, variant, n_slots);
+    for (int i = 0; i < 2; ++i) { lmk_scan(d->stream, a, variant, n_slots); scan_launched(d, a); }
     HIP_TRY(hipEventRecord(d->ev[0], d->stream));
-    for (int i = 0; i < iters; ++i) lmk_scan(d->stream, a, variant, n_slots);
+    for (int i = 0; i < iters; ++i) { lmk_scan(d->stream, a, variant, n_slots); scan_launched(d, a); }
     HIP_TRY(hipEventRecord(d->ev[1], d->stream));
     for (int i = 0; i < n_slots; ++i) HIP_TRY(hipMemsetAsync(d->aux(first_slot + i, d->off_hdr), 0, sizeof(LmDevHeader), d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));

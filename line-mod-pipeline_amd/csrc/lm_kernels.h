@@ -70,8 +70,9 @@ struct LmScanArgs {
     const u32* offn;          // [nt][fpad1] the same features' nibble offsets (exact sums of the survivors)
     int fpad1;
     int no_exact;             // measurement only (scan variant bit 7, WRONG lists): the survivors' exact sums are skipped
-    unsigned long long* surv; // survivor queues of the launch's stream, one per XCD: [0..7] = entries appended, [8 + x * (surv_cap / 8) + i] = template << 32 |
-    u32 surv_cap;             //    slot << 20 | position; k_scan1_exact takes their exact sums.  null / overflow: the wave does it itself
+    unsigned long long* surv; // survivor queues of the launch's stream, one per XCD: [16 + x * (surv_cap / 8) + i] = template << 32 | slot << 20 | position;
+    u32 surv_cap;             //    k_scan1_exact takes their exact sums (null / overflow: the wave does it itself).  [8 * surv_set + x] = entries appended
+    int surv_set;             //    to queue x: two sets of counters, a launch uses one and its k_scan1_exact zeroes the other for the next launch
 };
 // a11+a12+a13: similarity scan over the lowest level fused with the threshold scan.
 // variant selects the unroll depth of the feature loop (0: 8 loads in flight, 1: 4, 2: 2).

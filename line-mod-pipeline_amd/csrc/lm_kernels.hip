@@ -2826,9 +2826,10 @@ __global__ __launch_bounds__(256) void k_scan1(LmScanArgs a) {
             // eight queues, one per XCD when the groups are dealt to the XCDs (group g runs on XCD g % 8): k_scan1_exact's workgroups of XCD x
             // take queue x, whose entries name the few frames that XCD has just scanned -- their nibble memories then meet in ITS L2
             const u32 cap8 = a.surv_cap >> 3, qx = grp & 7u;
-            const unsigned long long at = atomicAdd(a.surv + qx, (unsigned long long)nh);
+            unsigned long long* qcount = a.surv + 8 * a.surv_set + qx;
+            const unsigned long long at = atomicAdd(qcount, (unsigned long long)nh);
             if (at + nh <= (unsigned long long)cap8) {
-                unsigned long long* q = a.surv + 8 + (size_t)qx * cap8 + at;
+                unsigned long long* q = a.surv + 16 + (size_t)qx * cap8 + at;
                 const unsigned long long hi = ((unsigned long long)ti << 32) | ((unsigned long long)slot << 20);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -2836,7 +2837,7 @@ __global__ __launch_bounds__(256) void k_scan1(LmScanArgs a) {
                 h[0] = h[1] = h[2] = h[3] = 0;
                 if (a.stat) atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 3], (unsigned long long)nh);
             } else {
-                atomicAdd(a.surv + qx, (unsigned long long)0 - (unsigned long long)nh);     // (give the reservation back)
+                atomicAdd(qcount, (unsigned long long)0 - (unsigned long long)nh);     // (give the reservation back)
             }
         }
         hl = __ballot((h[0] | h[1] | h[2] | h[3]) != 0u);
@@ -2889,9 +2890,10 @@ __global__ __launch_bounds__(256) void k_scan1(LmScanArgs a) {
 // positions of one template: their nibble loads share lines).  Sums above the threshold become candidates exactly as k_scan4 emits them.
 __global__ __launch_bounds__(256) void k_scan1_exact(LmScanArgs a) {
     const u32 cap8 = a.surv_cap >> 3, qx = blockIdx.x & 7u;           // workgroup b runs on XCD b % 8: queue b % 8
-    const unsigned long long total = a.surv[qx];
-    const u32 n = total < (unsigned long long)cap8 ? (u32)total : cap8;   // (a reservation in flight when its neighbour overflowed may have left the count above the entries: the wave took those itself)
-    const unsigned long long* queue = a.surv + 8 + (size_t)qx * cap8;
+    const unsigned long long total = a.surv[8 * a.surv_set + qx];
+    const u32 n = total < (unsigned long long)cap8 ? (u32)total : cap8;
+    const unsigned long long* queue = a.surv + 16 + (size_t)qx * cap8;
+    if (blockIdx.x < 8 && threadIdx.x == 0) a.surv[8 * (a.surv_set ^ 1) + blockIdx.x] = 0;      // the other counter set, for the stream's next launch (no memset between the launches)
     const int offset = a.T / 2 + (a.T % 2 - 1);
     for (u32 i = (blockIdx.x >> 3) * 256u + threadIdx.x; i < n; i += (gridDim.x >> 3) * 256u) {
         const unsigned long long e = queue[i];
@@ -4189,8 +4191,9 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
         // k_scan1: a wave scans its item for a GROUP of G1 slots (XCD affinity per group when the group count allows)
         const int ngroups = (nslots + a.G1 - 1) / a.G1;
         a.no_exact = (variant & 128) ? 1 : 0;
+        // (the two measurement variants do not run k_scan1_exact, which re-arms the other counter set for the stream's next launch: re-arm both here)
+        if (a.surv && (a.no_exact || (variant & 256))) (void)hipMemsetAsync(a.surv, 0, 16 * sizeof(unsigned long long), s);
         if (variant & 256) a.surv = nullptr;             // A/B: the waves take their survivors' exact sums themselves
-        if (a.surv) (void)hipMemsetAsync(a.surv, 0, 8 * sizeof(unsigned long long), s);
         hipLaunchKernelGGL(k_scan1, dim3((unsigned)(G * ngroups), 1, 1), dim3(256), 0, s, a);
         if (a.surv && !a.no_exact) hipLaunchKernelGGL(k_scan1_exact, dim3(1024), dim3(256), 0, s, a);
         return;
