@@ -161,3 +161,36 @@ def test_linear_memories_after_a_batch_call(lm, orc, synth, color_only, size, T)
                 for mod in range(M):
                     assert np.array_equal(d.debug_read(k, 2, level, mod), o.stage(2, level, mod)), (form, k, level, mod)
     d.close()
+
+
+def test_scan_form_by_cost_and_key_validation(lm, orc, synth):
+    """LM_TUNE_SCAN_FORM 0 picks the bit-plane scan for batches (8+ frames, whole groups) of a one-modality detector and the nibble scan for a
+    single frame and for two modalities; the keys reject values outside their range and a change while a lane has a match in flight."""
+    d, o, frames = _setup(lm, orc, synth, True, (640, 480), [2, 8], 40, 16, seed=990)
+    for k in range(16):
+        d.upload_frame(k, frames[k % 3][0], None)
+    d.match_batch(16, 85.0, cap_per_frame=1 << 15)
+    assert d.get_scan_form_stats()[3] > 0                      # 16 colour-only frames: k_scan1
+    d.match_batch(1, 85.0, cap_per_frame=1 << 15)
+    assert d.get_scan_form_stats()[3] == 0                     # one frame: k_scan4 (three launches instead of one would double its scan time)
+    d.match_batch(16, 48.0, cap_per_frame=1 << 15)
+    assert d.get_scan_form_stats()[3] == 0                     # below LM_TUNE_SCAN1_MIN_THRESHOLD (50): too many survivors of the miss bound
+    d.set_tuning(lm.TUNE_SCAN1_MIN_THRESHOLD, 40)
+    d.match_batch(16, 48.0, cap_per_frame=1 << 15)
+    assert d.get_scan_form_stats()[3] > 0
+    for key, bad in ((lm.TUNE_SCAN_FORM, -1), (lm.TUNE_SCAN_FORM, 3), (lm.TUNE_SCAN1_MIN_THRESHOLD, 101), (lm.TUNE_SCAN1_MIN_THRESHOLD, -1)):
+        with pytest.raises(lm.LinemodError):
+            d.set_tuning(key, bad)
+    d.match_begin(0, 0, 8, 85.0)
+    with pytest.raises(lm.LinemodError):
+        d.set_tuning(lm.TUNE_SCAN_FORM, 2)                     # the slots in flight were prepared for the other form
+    out = np.zeros((8, 1 << 12), lm.MATCH_DTYPE); cnt = np.zeros(8, np.int32)
+    d.match_end(0, 1 << 12, out=out, counts=cnt)
+    d.set_tuning(lm.TUNE_SCAN_FORM, 2)
+    d.close()
+    d2, o2, frames2 = _setup(lm, orc, synth, False, (640, 480), [5, 8], 40, 16, seed=991)
+    for k in range(16):
+        d2.upload_frame(k, frames2[k % 3][0], frames2[k % 3][1])
+    d2.match_batch(16, 85.0, cap_per_frame=1 << 15)
+    assert d2.get_scan_form_stats()[3] == 0                    # two modalities: k_scan4's exact pruning stops sooner than the miss bound
+    d2.close()
