@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <chrono>
 #include <deque>
@@ -57,7 +58,7 @@ HighLevelLineMOD::HighLevelLineMOD(CameraParameters const& cam, TemplateGenerati
     cfg.device = ts.device;
     cfg.shard_rank = ts.shardRank;
     cfg.shard_size = ts.shardSize;
-    cfg.frame_slots = kBatchSlots * kBatchSets;      // two slot sets: a batch matching while the one before it is post-processed
+    cfg.frame_slots = kBatchSlots * kBatchSets;      // slot sets: a batch is transferred and matched while the ones before it are matched / post-processed
     if (lm_create(&cfg, &detector) != LM_OK) {
         delete templates; delete modelTemplates; delete modProps;
         throw std::runtime_error(lm_last_error());
@@ -257,6 +258,7 @@ bool HighLevelLineMOD::detectTemplatesBatchBegin(std::vector<std::vector<Image>>
             if (urc != LM_OK) { error = lm_last_error(); if (b.staging) for (WorkerPool::Group& g : b.staging->frame) st.pool->wait(g); return false; }
             continue;
         }
+        std::vector<std::function<void()>> copies;          // a frame's staging tasks in one submission (WorkerPool::submit_many)
         for (int r0 = 0; r0 < videoHeight; r0 += rows_per_task) {
             const int r1 = std::min<int>(r0 + rows_per_task, videoHeight);
             lm_detector* det = detector;
@@ -265,13 +267,14 @@ bool HighLevelLineMOD::detectTemplatesBatchBegin(std::vector<std::vector<Image>>
             const size_t cs = color.stride, ds = match_depth ? match_depth->stride : 0;
             const int sx = color.shift_x, sy = color.shift_y, slot = first + i;
             Batch::Staging* sg = b.staging.get();
-            st.pool->submit(sg->frame[i], [det, slot, cp, cs, dp, ds, sx, sy, r0, r1, sg] {
+            copies.push_back([det, slot, cp, cs, dp, ds, sx, sy, r0, r1, sg] {
                 const clk::time_point t0 = clk::now();
                 const int rc = lm_stage_rows(det, slot, cp, cs, dp, ds, sx, sy, r0, r1);
                 if (rc != LM_OK) sg->rc.store(rc);
                 sg->ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count());
-            }, true);
+            });
         }
+        st.pool->submit_many(b.staging->frame[i], std::move(copies), true);
     }
     st.inflight.push_back(std::move(b));
     st.set_busy[set] = true;
@@ -352,10 +355,12 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
     // the NEXT batch, if its Begin was deferred (completed below, right after this batch's lists are in)
     double driven = 0;                    // (seconds of this End spent on the next batch's Begin: accounted as upload, not as post-processing)
     auto drive_next = [&] {
-        if (st.inflight.empty() || st.inflight.front().begun) return;
-        const clk::time_point t = clk::now();
-        (void)finishBegin(st.inflight.front());
-        driven += secs(t, clk::now());
+        for (Batch& nb : st.inflight) {       // (oldest first: every batch whose Begin was deferred)
+            if (nb.begun) continue;
+            const clk::time_point t = clk::now();
+            (void)finishBegin(nb);
+            driven += secs(t, clk::now());
+        }
     };
     const int n = b.n, first = b.set * kBatchSlots;
     const size_t nc = b.classes.size();
@@ -400,10 +405,11 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
     for (int i = 0; i < n; ++i) for (size_t c = 0; c < nc; ++c) { units.emplace_back(detector, ps); units.back().c = c; units.back().i = i; }
     std::vector<PostProcessor::Times> frame_times((size_t)n * nc);
     WorkerPool::Group grouping;
+    std::vector<std::function<void()>> grouping_tasks;
     for (int i = 0; i < n; ++i) {
         stageTimes.matches += counts[(size_t)i];
         for (size_t c = 0; c < nc; ++c)              // one task per (frame, class): 24 tasks for config 5's batch of 8 x 3 (a frame's three at once left half the pool idle)
-        st.pool->submit(grouping, [&, i, c] {
+        grouping_tasks.push_back([&, i, c] {
             const lm_match_t* m = buf.data() + cap * (size_t)i;
             {
                 // the mixed list is in the total order; a class's sub-list keeps it.  Match::operator== compares x, y, similarity and
@@ -440,7 +446,10 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
             }
         });
     }
+    st.pool->submit_many(grouping, std::move(grouping_tasks));
     st.pool->wait(grouping);
+    static const bool post_trace = std::getenv("LM_POST_TRACE") != nullptr;      // where a batch's post-processing spends its wall time (stderr)
+    const clk::time_point t_grouped = clk::now();
     if (!grouping.error.empty()) { error = grouping.error; return false; }
     bool any = false;
     for (size_t c = 0; c < nc; ++c) for (int i = 0; i < n; ++i) any = any || !out_matches[c][(size_t)i].empty();
@@ -530,7 +539,10 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
             std::vector<int64_t> gin(todo.size()), gboth(todo.size());
             const clk::time_point t_c = clk::now();
             int crc = lm_color_check_begin_slots(detector, slot_of.data(), units[a].props.lowerColorRange, units[a].props.upperColorRange, todo.data(), todo.size());
-            if (crc == LM_OK && first_range) waves.start(true);      // while the GPU counts: the first wave of every group (all ranges' groups: their walks wait for the tokens)
+            const clk::time_point t_cb = clk::now();
+            if (crc == LM_OK && first_range) waves.start(true);
+            const clk::time_point t_ws = clk::now();
+            if (post_trace) std::fprintf(stderr, "post-trace: colour check begun in %.0f us (%zu matches), first wave submitted in %.0f us\n", secs(t_c, t_cb) * 1e6, todo.size(), secs(t_cb, t_ws) * 1e6);      // while the GPU counts: the first wave of every group (all ranges' groups: their walks wait for the tokens)
             if (crc == LM_OK) crc = lm_color_check_end(detector, gin.data(), gboth.data());
             if (crc != LM_OK) {
                 // loud, never a silent switch of implementation (frames of more than 4992 rows: setGpuColorCheck(false))
@@ -549,11 +561,15 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
             }
         }
         waves.start(true);                // (no live unit at all: nothing to start; otherwise a no-op)
+        const clk::time_point t_rel = clk::now();
         waves.release_tokens();           // every count is in
+        if (post_trace) std::fprintf(stderr, "post-trace: grouping %.0f us, colour counts in after %.0f us more, tokens released in %.0f us\n", secs(t_post, t_grouped) * 1e6, secs(t_grouped, t_rel) * 1e6, secs(t_rel, clk::now()) * 1e6);
     } else {
         waves.start(false);
     }
+    const clk::time_point t_w = clk::now();
     st.pool->wait(finishing);
+    if (post_trace) std::fprintf(stderr, "post-trace: waited %.0f us for the walks (%zu groups)\n", secs(t_w, clk::now()) * 1e6, n_groups);
     if (!finishing.error.empty()) { error = finishing.error; return false; }
     for (const PostProcessor::Times& t : frame_times) PostProcessor::times().add(t);
     for (GroupState& r : runs) {

@@ -117,7 +117,8 @@ public:
     bool detectTemplatesBatchEnd(std::vector<std::vector<std::vector<lm_match_t>>>& out_matches,
                                  std::vector<std::vector<std::vector<std::vector<ObjectPose>>>>& out_poses);
     int batchesInFlight() const;
-    static constexpr int kBatchSets = 2;
+    static constexpr int kBatchSets = 3;     // (r05: two until the host's share of a batch fell below the link's + the GPU's; with three, a batch's transfer, the match of the one before
+                                             //  it and the post-processing of the one before that run at the same time)
     // colour checks of the post-processing on the GPU (default) or on the host (the reference's one-match-at-a-time way)
     void setGpuColorCheck(bool on) { gpuColorCheck = on; }
     bool usesGpuColorCheck() const { return gpuColorCheck; }

@@ -159,39 +159,46 @@ void translate_u16(const uint16_t* src, int w, int h, int ox, int oy, std::vecto
 // 65535 -- as one dense vector, plus two by-products of the same pass (r05): the smallest value and how many values lie below `below`.
 #if defined(__x86_64__)
 // (a 16-bit lane counts one element in sixteen: no overflow for rows below 2^20 pixels)
-__attribute__((target("avx2"))) static void crop_row_avx2(const uint16_t* r, int n, uint16_t* o, uint16_t below, uint16_t* mn, size_t* cnt) {
+__attribute__((target("avx2"))) static void crop_row_avx2(const uint16_t* r, int n, uint16_t* o, uint16_t below, uint16_t top, uint16_t* mn, size_t* cnt, size_t* cnt_in) {
     const __m256i lim = _mm256_set1_epi16((short)below), fe = _mm256_set1_epi16((short)0xFFFE), zero = _mm256_setzero_si256();
-    __m256i vmin = _mm256_set1_epi16((short)0xFFFF), acc = zero;
+    const __m256i span = _mm256_set1_epi16((short)(uint16_t)(top >= below ? top - below : 0));
+    __m256i vmin = _mm256_set1_epi16((short)0xFFFF), acc = zero, acc_in = zero;
     int x = 0;
     for (; x + 16 <= n; x += 16) {
         const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(r + x));
         const __m256i t = _mm256_or_si256(v, _mm256_cmpeq_epi16(_mm256_and_si256(v, fe), zero));       // v <= 1 -> 65535
         _mm256_storeu_si256(reinterpret_cast<__m256i*>(o + x), t);
         vmin = _mm256_min_epu16(vmin, t);
-        acc = _mm256_sub_epi16(acc, _mm256_andnot_si256(_mm256_cmpeq_epi16(_mm256_max_epu16(t, lim), t), _mm256_set1_epi16(-1)));   // t < below: max(t, below) != t
+        const __m256i ge = _mm256_cmpeq_epi16(_mm256_max_epu16(t, lim), t);                              // t >= below
+        acc = _mm256_sub_epi16(acc, _mm256_andnot_si256(ge, _mm256_set1_epi16(-1)));                      // t < below: max(t, below) != t
+        const __m256i off = _mm256_sub_epi16(t, lim);                                                     // below <= t <= top: t >= below and t - below <= top - below
+        acc_in = _mm256_sub_epi16(acc_in, _mm256_and_si256(ge, _mm256_cmpeq_epi16(_mm256_min_epu16(off, span), off)));
     }
     alignas(32) uint16_t a[16];
     _mm256_store_si256(reinterpret_cast<__m256i*>(a), acc); for (uint16_t q : a) *cnt += q;
+    _mm256_store_si256(reinterpret_cast<__m256i*>(a), acc_in); for (uint16_t q : a) *cnt_in += q;
     _mm256_store_si256(reinterpret_cast<__m256i*>(a), vmin); for (uint16_t q : a) *mn = std::min(*mn, q);
-    for (; x < n; ++x) { const uint16_t t = r[x] > 1 ? r[x] : (uint16_t)65535; o[x] = t; *mn = std::min(*mn, t); *cnt += t < below; }
+    for (; x < n; ++x) { const uint16_t t = r[x] > 1 ? r[x] : (uint16_t)65535; o[x] = t; *mn = std::min(*mn, t); *cnt += t < below; *cnt_in += (t >= below && t <= top); }
 }
 #endif
-static void crop_row(const uint16_t* r, int n, uint16_t* o, uint16_t below, uint16_t* mn, size_t* cnt) {
+static void crop_row(const uint16_t* r, int n, uint16_t* o, uint16_t below, uint16_t top, uint16_t* mn, size_t* cnt, size_t* cnt_in) {
 #if defined(__x86_64__)
     static const bool avx2 = __builtin_cpu_supports("avx2");
-    if (avx2) { crop_row_avx2(r, n, o, below, mn, cnt); return; }
+    if (avx2 && top >= below) { crop_row_avx2(r, n, o, below, top, mn, cnt, cnt_in); return; }
 #endif
-    for (int x = 0; x < n; ++x) { const uint16_t t = r[x] > 1 ? r[x] : (uint16_t)65535; o[x] = t; *mn = std::min(*mn, t); *cnt += t < below; }
+    for (int x = 0; x < n; ++x) { const uint16_t t = r[x] > 1 ? r[x] : (uint16_t)65535; o[x] = t; *mn = std::min(*mn, t); *cnt += t < below; *cnt_in += (t >= below && t <= top); }
 }
 
 // (shift_x, shift_y): `depth` is the frame before a translation by that many pixels with zeros shifted in; bb is in the translated frame.
 // Returns the element count (0: empty crop).
-static size_t crop_depth(const uint16_t* depth, int w, int h, Rect bb, int shift_x, int shift_y, std::vector<uint16_t>& v, uint16_t below, uint16_t* mn, size_t* cnt_below) {
+// by-products: *mn = the smallest value, *cnt_below = values below `below`, *cnt_in = values in [below, top] (the shifted-in / invalid 65535s count when top is 65535)
+static size_t crop_depth(const uint16_t* depth, int w, int h, Rect bb, int shift_x, int shift_y, std::vector<uint16_t>& v, uint16_t below, uint16_t top, uint16_t* mn, size_t* cnt_below, size_t* cnt_in) {
     shift_x = std::max(-w, std::min(w, shift_x)); shift_y = std::max(-h, std::min(h, shift_y));   // (beyond the frame: all zeros either way; no overflow in w + shift)
     int x0 = std::max(bb.x, 0), y0 = std::max(bb.y, 0);
     int x1 = (int)std::min<long long>((long long)bb.x + bb.width, w), y1 = (int)std::min<long long>((long long)bb.y + bb.height, h);   // cv::Mat ROI would assert; we clip
-    *mn = 65535; *cnt_below = 0;
+    *mn = 65535; *cnt_below = 0; *cnt_in = 0;
     if (x1 <= x0 || y1 <= y0) return 0;
+    size_t filled = 0;                                                          // 65535s written without a source pixel
     const size_t rw = (size_t)(x1 - x0), n = rw * (size_t)(y1 - y0);
     v.resize(n);
     uint16_t* o = v.data();
@@ -200,21 +207,23 @@ static size_t crop_depth(const uint16_t* depth, int w, int h, Rect bb, int shift
     const int sx0 = std::min(std::max(std::max(shift_x, 0), x0), x1), sx1 = std::max(std::min(std::min(w + shift_x, w), x1), sx0);
     for (int y = y0; y < y1; ++y) {
         const int sy = y - shift_y;
-        if (sy < 0 || sy >= h) { for (size_t x = 0; x < rw; ++x) o[x] = 65535; o += rw; continue; }
+        if (sy < 0 || sy >= h) { for (size_t x = 0; x < rw; ++x) o[x] = 65535; o += rw; filled += rw; continue; }
         const uint16_t* r = depth + (size_t)sy * w;                            // source row; translated column x reads r[x - shift_x] (indexed from the row base: ADVICE r4)
         for (int x = x0; x < sx0; ++x) o[x - x0] = 65535;
-        if (sx1 > sx0) crop_row(r + (sx0 - shift_x), sx1 - sx0, o + (sx0 - x0), below, mn, cnt_below);
+        if (sx1 > sx0) crop_row(r + (sx0 - shift_x), sx1 - sx0, o + (sx0 - x0), below, top, mn, cnt_below, cnt_in);
         for (int x = sx1; x < x1; ++x) o[x - x0] = 65535;
+        filled += (size_t)(sx0 - x0) + (size_t)(x1 - sx1);
         o += rw;
     }
+    if (top == 65535) *cnt_in += filled;
     return n;
 }
 
 uint16_t median_mat(const uint16_t* depth, int w, int h, Rect bb, uint8_t position, int shift_x, int shift_y) {
     static thread_local std::vector<uint16_t> v;      // (one buffer per thread: a call per match, thousands per frame batch)
     if (position == 0) return 65535;
-    uint16_t mn; size_t cb;
-    const size_t n = crop_depth(depth, w, h, bb, shift_x, shift_y, v, 0, &mn, &cb);
+    uint16_t mn; size_t cb, ci;
+    const size_t n = crop_depth(depth, w, h, bb, shift_x, shift_y, v, 0, 65535, &mn, &cb, &ci);
     if (n == 0) return 65535;
     std::nth_element(v.begin(), v.begin() + (ptrdiff_t)(n / 4), v.end());
     return v[n / position];
@@ -224,20 +233,22 @@ uint16_t median_mat(const uint16_t* depth, int w, int h, Rect bb, uint8_t positi
 // depth check, :437-457).  The reference's value is v[n / position] AFTER nth_element(begin, begin + n / 4, end): an element at or
 // before the nth position, so (for position >= 4) it is at most the (n / 4)-th order statistic and at least the smallest element --
 // WHICH of those elements it is depends on the library's partition order, which is why the value itself must come from the very same
-// std::nth_element.  But when more than n / 4 elements lie below win_lo the (n / 4)-th order statistic does, and when the smallest
-// element lies above win_hi everything does: the verdict "outside" is then certain without the selection (r05: one vectorised pass
-// over the crop instead of the partition passes; exact, never a different verdict or value).  Returns true and *median when inside.
+// std::nth_element.  But when more than n / 4 elements lie below win_lo the (n / 4)-th order statistic does, and when NO element lies inside
+// the window none of the n / 4 + 1 smallest can (those that are not below win_lo are then above win_hi -- the smallest element above win_hi
+// is the special case): the verdict "outside" is then certain without the selection (r05: one vectorised pass over the crop instead of
+// the partition passes; exact, never a different verdict or value).  Returns true and *median when inside.
 bool median_mat_in_window(const uint16_t* depth, int w, int h, Rect bb, uint8_t position, int shift_x, int shift_y, int win_lo, int win_hi,
                           uint16_t* median, bool* decided_early) {
     static thread_local std::vector<uint16_t> v;
     if (decided_early) *decided_early = false;
     uint16_t m = 65535;
     if (position != 0) {
-        uint16_t mn; size_t cb;
+        uint16_t mn; size_t cb, ci;
         const uint16_t below = (uint16_t)std::max(0, std::min(win_lo, 65535));
-        const size_t n = crop_depth(depth, w, h, bb, shift_x, shift_y, v, below, &mn, &cb);
+        const uint16_t top = (uint16_t)std::max(0, std::min(win_hi, 65535));
+        const size_t n = crop_depth(depth, w, h, bb, shift_x, shift_y, v, below, top, &mn, &cb, &ci);
         if (n != 0) {
-            if (position >= 4 && win_lo <= 65535 && (cb >= n / 4 + 1 || (int)mn > win_hi)) { if (decided_early) *decided_early = true; return false; }
+            if (position >= 4 && win_lo <= 65535 && win_hi >= win_lo && win_hi >= 0 && (cb >= n / 4 + 1 || ci == 0)) { if (decided_early) *decided_early = true; return false; }
             std::nth_element(v.begin(), v.begin() + (ptrdiff_t)(n / 4), v.end());
             m = v[n / position];
         }

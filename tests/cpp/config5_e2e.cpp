@@ -214,14 +214,17 @@ int main(int argc, char** argv) {
                 }
                 continue;
             }
-            if (!pd.detectBatchBegin(bt[0], all_names)) { std::printf("detectBatchBegin failed: %s\n", pd.lastError().c_str()); return 1; }
+            // all slot sets in flight (HighLevelLineMOD::kBatchSets = 3 batches), then one End per batch; passes 2 and 3 keep only two in flight
+            const int ahead = pass == 1 ? HighLevelLineMOD::kBatchSets - 1 : 1;
+            for (int bi = 0; bi < ahead; ++bi)
+                if (!pd.detectBatchBegin(bt[bi], all_names)) { std::printf("detectBatchBegin failed: %s\n", pd.lastError().c_str()); return 1; }
             for (int bi = 0; bi < 3; ++bi) {
-                if (bi + 1 < 3 && !pd.detectBatchBegin(bt[bi + 1], all_names)) { std::printf("detectBatchBegin failed: %s\n", pd.lastError().c_str()); return 1; }
-                if (bi == 0) {     // a third batch in flight is refused, loudly, and the stream goes on
-                    const bool third = pd.detectBatchBegin(bt[2], all_names);
-                    std::printf("stream %s third_begin_refused %d\n", tag, third ? 0 : 1);
-                    if (third) return 1;
-                }
+                if (bi + ahead < 3 && !pd.detectBatchBegin(bt[bi + ahead], all_names)) { std::printf("detectBatchBegin failed: %s\n", pd.lastError().c_str()); return 1; }
+                if (bi == 0 && pass == 1) {     // one batch more than there are slot sets is refused, loudly, and the stream goes on
+                    const bool extra = pd.detectBatchBegin(bt[2], all_names);
+                    std::printf("stream %s third_begin_refused %d\n", tag, extra ? 0 : 1);
+                    if (extra) return 1;
+                } else if (bi == 0) std::printf("stream %s third_begin_refused 1\n", tag);
                 if (!pd.detectBatchEnd(1, poses)) { std::printf("detectBatchEnd failed: %s\n", pd.lastError().c_str()); return 1; }
                 dump(tag, bi, poses);
             }

@@ -129,6 +129,8 @@ int main(int argc, char** argv) {
         }
     }
 
+    const char* ahead_env = std::getenv("LM_E2E_AHEAD");
+    const int ahead_cfg = std::max(1, std::min(HighLevelLineMOD::kBatchSets - 1, ahead_env ? std::atoi(ahead_env) : HighLevelLineMOD::kBatchSets - 1));
     auto run = [&](Pass& p, std::vector<std::vector<Image>>* bt, bool pipelined) -> bool {
         Poses out;
         p.poses.clear();
@@ -143,19 +145,23 @@ int main(int argc, char** argv) {
                 if (it >= warm) p.poses.push_back(out);
             }
         } else {
-            if (!pd.detectBatchBegin(bt[0], names)) { std::fprintf(stderr, "detectBatchBegin failed: %s\n", pd.lastError().c_str()); return false; }
+            // `ahead` batches are begun before the oldest is collected: all the slot sets but one stay in flight behind the batch being post-processed
+            // (LM_E2E_AHEAD: 1 = r05's first streamed form, two batches in flight).  The two host batches alternate; they are only read.
+            const int ahead = ahead_cfg;
+            for (int k = 0; k < ahead; ++k)
+                if (!pd.detectBatchBegin(bt[k & 1], names)) { std::fprintf(stderr, "detectBatchBegin failed: %s\n", pd.lastError().c_str()); return false; }
             for (int it = 0; it < total_it; ++it) {
-                // the clock starts with the stream full: batch `warm` is in flight, as batch total_it (never collected inside the region) will be
+                // the clock starts with the stream full, as it is when the region ends (the batches begun last are never collected inside it)
                 if (it == warm) { line.resetTimes(); PostProcessor::resetTimes(); lm_set_profiling(line.handle(), 1); t0 = clk::now(); }
                 if (sleep_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(sleep_us));     // experiment: is the GPU done when nobody asks?
-                if (!pd.detectBatchBegin(bt[(it + 1) & 1], names)) { std::fprintf(stderr, "detectBatchBegin failed: %s\n", pd.lastError().c_str()); return false; }
+                if (!pd.detectBatchBegin(bt[(it + ahead) & 1], names)) { std::fprintf(stderr, "detectBatchBegin failed: %s\n", pd.lastError().c_str()); return false; }
                 if (!pd.detectBatchEnd(1, out)) { std::fprintf(stderr, "detectBatchEnd failed: %s\n", pd.lastError().c_str()); return false; }
                 if (it >= warm) p.poses.push_back(out);
             }
         }
         p.total = std::chrono::duration<double>(clk::now() - t0).count();
         p.st = line.times(); p.pt = PostProcessor::times();
-        if (pipelined) { Poses drop; if (!pd.detectBatchEnd(1, drop)) { std::fprintf(stderr, "detectBatchEnd failed: %s\n", pd.lastError().c_str()); return false; } }
+        if (pipelined) for (int k = 0; k < ahead_cfg; ++k) { Poses drop; if (!pd.detectBatchEnd(1, drop)) { std::fprintf(stderr, "detectBatchEnd failed: %s\n", pd.lastError().c_str()); return false; } }
         int64_t launches = 0, frames = 0;
         lm_get_profile(line.handle(), p.gpu_us, nullptr, &launches, &frames);
         p.gpu_frames = frames;
