@@ -919,7 +919,7 @@ def pose_e2e(args, runner, lm, hot_path_us_per_frame_resident):
         ser, pip, pin = g["serial"], g["pipelined"], g["pipelined_pinned"]
         total = pip["us_per_frame"]
         res = {"value": round(1e6 / total, 1),
-               "unit": "frames/s through PoseDetection::detectBatchBegin / detectBatchEnd, pageable frames, steady state (batches of %d frames, two in flight; %d host threads)" % (nf, g["host_threads"]),
+               "unit": "frames/s through PoseDetection::detectBatchBegin / detectBatchEnd, pageable frames, steady state (batches of %d frames, up to three in flight; %d host threads)" % (nf, g["host_threads"]),
                "us_per_frame": total,
                "us_per_frame_serial": ser["us_per_frame"], "us_per_frame_pipelined_pinned_frames": pin["us_per_frame"],
                "poses_identical_across_passes": g["poses_identical_across_passes"],
@@ -933,7 +933,7 @@ def pose_e2e(args, runner, lm, hot_path_us_per_frame_resident):
                "classes": g["classes"], "templates": g["templates"], "frames": nf, "iterations": g["iterations"], "host_threads": g["host_threads"],
                "note": "the reference's call pattern (PoseDetection.cpp:45-126, HighLevelLinemod.cpp:157-175,206-253,424-515) on the bench's bank and frames, three passes over the same "
                        "batches with bit-identical poses: serial = one detectBatch at a time (r04's figure: shift + upload + match + post-processing as a sum); pipelined = "
-                       "detectBatchBegin(k + 1) before detectBatchEnd(k) on two slot sets / lanes: the staging copies (pool, shift applied while copying), the transfer and the "
+                       "detectBatchBegin(k + 2) before detectBatchEnd(k) on three slot sets / lanes: the staging copies (pool, shift applied while copying), the transfer and the "
                        "GPU hot path of batch k + 1 run behind the host post-processing of batch k; pipelined_pinned = the same with frames in pinned memory (row-offset DMA copy, no "
                        "staging).  Post-processing = per-frame grouping on the pool, the colour counts of the whole batch in one GPU call on the colour-check stream, then depth "
                        "check + poses of the independent match groups on the pool (by-part figures are CPU time summed over the threads).  gpu_hot_path = HIP-event spans of "
