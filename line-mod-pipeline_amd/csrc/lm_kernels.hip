@@ -1166,12 +1166,20 @@ __device__ __forceinline__ void cg_labels(const CgRow& A, const CgRow& B, const 
     // three bytes further / back from an even pair is (O[d].hi, O[d+1].lo) / O[d-1], from an odd pair E[d+1] / (E[d-1].hi, E[d].lo)
     u32 P[56];   // (dx, dy) i16 pair per byte position, window bytes 4 .. 51
     int M[56];
+    // r05: dy = VD[wb - 3] + 2 VD[wb] + VD[wb + 3] = H[wb - 3] + H[wb] with H[wb] = VD[wb] + VD[wb + 3]: the pair sums are shared by neighbouring
+    // positions -- per pair of registers 6 instead of 8 instructions (He: alignbit + add, Ho: add, dye: add, dyo: alignbit + add)
+    u32 He[13], Ho[13];
+#pragma unroll
+    for (int d = 0; d <= 12; ++d) {
+        He[d] = pk_add_i16(vde[d], __builtin_amdgcn_alignbit(vdo[d + 1], vdo[d], 16));     // even pair (4d, 4d + 2) + the positions 3 bytes further (4d + 3, 4d + 5)
+        Ho[d] = pk_add_i16(vdo[d], vde[d + 1]);                                            // odd pair (4d + 1, 4d + 3) + (4d + 4, 4d + 6)
+    }
 #pragma unroll
     for (int d = 1; d <= 12; ++d) {
         const u32 dxe = pk_sub_i16(__builtin_amdgcn_alignbit(vso[d + 1], vso[d], 16), vso[d - 1]);
         const u32 dxo = pk_sub_i16(vse[d + 1], __builtin_amdgcn_alignbit(vse[d], vse[d - 1], 16));
-        const u32 dye = pk_add_i16(pk_add_i16(vdo[d - 1], __builtin_amdgcn_alignbit(vdo[d + 1], vdo[d], 16)), pk_add_i16(vde[d], vde[d]));
-        const u32 dyo = pk_add_i16(pk_add_i16(__builtin_amdgcn_alignbit(vde[d], vde[d - 1], 16), vde[d + 1]), pk_add_i16(vdo[d], vdo[d]));
+        const u32 dye = pk_add_i16(Ho[d - 1], He[d]);                                      // H at (4d - 3, 4d - 1) = the odd pair d - 1
+        const u32 dyo = pk_add_i16(__builtin_amdgcn_alignbit(He[d], He[d - 1], 16), Ho[d]);  // H at (4d - 2, 4d) = (even pair d - 1).hi, (even pair d).lo
         P[4 * d + 0] = __builtin_amdgcn_perm(dye, dxe, 0x05040100u); P[4 * d + 1] = __builtin_amdgcn_perm(dyo, dxo, 0x05040100u);
         P[4 * d + 2] = __builtin_amdgcn_perm(dye, dxe, 0x07060302u); P[4 * d + 3] = __builtin_amdgcn_perm(dyo, dxo, 0x07060302u);
 #pragma unroll
