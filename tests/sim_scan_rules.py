@@ -1,9 +1,9 @@
-"""Counting experiment for the scan's stopping rules (no GPU; the oracle is the data source -- a tool, not product code):
+"""Counting experiment for the scan's stopping rules (kept under tests/ because it drives the oracle; not collected by pytest; no GPU):
 for templates x frames of the config-2 workload, after how many features does a work item stop under
   (a) k_scan4's exact rule (partial sum + 4 x features to come <= threshold at every position), tested every 6 features, 2 frames per wave;
   (b) k_scan1's miss bound (misses > (4 F - thr - 1) / 3), every 8 features, G frames per wave;
   (c) the exact deficit (3 x misses + zeros) every 4 features, G frames per wave (the two-plane form DESIGN section 8 costs).
-usage: python tools/sim_scan_rules.py [templates] [frames] [G]"""
+usage: python tests/sim_scan_rules.py [templates] [frames] [G]"""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
