@@ -505,7 +505,9 @@ int lm_get_scan_form_stats(lm_detector* det, int64_t out[4]);
 /* Selects the similarity-scan kernel variant used by lm_match* (0 = default; bits 0-1: features per load block;
  * bit 3 (value 8): no pruning, the plain exhaustive scan; bit 4 (value 16): wave-level pruning only, without the
  * per-lane exec masking; bit 5 (value 32): per-lane pruning also for one-modality detectors, which default to the
- * wave-level rule; see lm_kernels.hip). */
+ * wave-level rule; see lm_kernels.hip).  Bits 0-5 address the nibble scan k_scan4.  Measurement only, for the bit-plane scan k_scan1:
+ * bit 7 (value 128): the survivors' exact sums are skipped (WRONG lists, the time of the miss counting alone); bit 8 (value 256): the
+ * waves take their survivors' exact sums themselves instead of queueing them for k_scan1_exact (same lists). */
 int lm_set_scan_variant(lm_detector* det, int variant);
 
 #ifdef __cplusplus
