@@ -28,6 +28,31 @@ int main(int argc, char** argv) {
     auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return seed >> 8; };
     WorkerPool pool(threads);
     CHECK(pool.threads() == threads);
+    // ---- r05: submit_many -- every task runs exactly once, a group's error is kept, and with a single-threaded pool (the caller runs everything
+    // in wait) the queue order is visible: a batch submitted at the FRONT runs before what was queued earlier, in its own order
+    {
+        WorkerPool::Group g;
+        std::vector<std::atomic<int>> ran(300);
+        for (auto& r : ran) r.store(0);
+        std::vector<std::function<void()>> fns;
+        for (int i = 0; i < 300; ++i) fns.push_back([&ran, i] { ran[(size_t)i].fetch_add(1); if (i == 7) throw std::runtime_error("task seven"); });
+        pool.submit_many(g, std::move(fns));
+        CHECK(fns.empty());
+        pool.wait(g);
+        for (auto& r : ran) CHECK(r.load() == 1);
+        CHECK(g.error == "task seven");
+        WorkerPool one(1);
+        WorkerPool::Group h;
+        std::vector<int> order;
+        std::vector<std::function<void()>> back, front;
+        for (int i = 0; i < 4; ++i) back.push_back([&order, i] { order.push_back(100 + i); });
+        for (int i = 0; i < 3; ++i) front.push_back([&order, i] { order.push_back(i); });
+        one.submit_many(h, std::move(back));
+        one.submit_many(h, std::move(front), true);
+        one.submit_many(h, std::vector<std::function<void()>>());        // (nothing: no wake-up, no count)
+        one.wait(h);
+        CHECK((order == std::vector<int>{0, 1, 2, 100, 101, 102, 103}));
+    }
     for (int round = 0; round < rounds; ++round) {
         const size_t G = 1 + rnd() % 40;
         std::vector<size_t> len(G), stop(G);
