@@ -72,6 +72,15 @@ def test_scan1_candidates_and_matches(lm, orc, synth, color_only, size, T, thr):
         assert after[0] - before[0] == after[1] - before[1] >= 1 and after[3] > 0       # every scan launch was k_scan1
         for k in range(n):
             assert_matches_equal(got[k, :cnt[k]], exp_m[k % len(frames)])
+    # the survivors' exact sums taken by the waves themselves (scan variant bit 8: what a wave does when its reservation in the survivor queue
+    # does not fit) give the same lists
+    d.set_scan_variant(256)
+    got, cnt = d.match_batch(nb, thr, cap_per_frame=1 << 15)
+    for k in range(nb):
+        assert_matches_equal(got[k, :cnt[k]], exp_m[k % len(frames)])
+    d.prepare_slot(0)
+    assert np.array_equal(d.stage_scan(0, thr), exp_c)
+    d.set_scan_variant(0)
     # the default picks by cost: the lists are the same either way
     d.set_tuning(lm.TUNE_SCAN_FORM, 0)
     got, cnt = d.match_batch(nb, thr, cap_per_frame=1 << 15)
