@@ -49,6 +49,7 @@ struct Slot {
     u16* h_depth = nullptr;
     bool has_frame = false;
     bool planes = false;     // ... and that pass wrote the scanned level's miss planes (k_scan1 may read them)
+    bool spread_low = false; // ... and ONE spread byte per position INSTEAD of the response memories: only k_scan1 can scan this slot
     bool prepared = false;   // a3-a10 have run on the frame the slot holds with the LUTs / thresholds now in force (lm_match_prepared)
     // Uploads run on the detector's copy stream: ev_up is recorded behind the slot's H2D copies, up_seq is the
     // upload's ticket (0 = never uploaded through the copy stream).  Copies complete in ticket order.
@@ -176,6 +177,8 @@ struct lm_detector {
     float scan1_min_threshold = 50.0f;   // below this similarity threshold the miss bound keeps too many positions alive: k_scan4 (LM_TUNE_SCAN1_MIN_THRESHOLD)
     long long cnt_scan1_launches = 0; int last_scan1_lanes = 0;
     bool emit_planes = false;        // the pre-processing being enqueued writes the miss planes (set per call by enqueue_preprocess)
+    bool emit_spread_low = false;    // ... and the spread byte instead of the response memories (the call's scan is k_scan1 by the rule below)
+    u32* d_offs3 = nullptr;          // [nt][fpad1] orientation << 29 | spread-memory offset of the bit-plane scan's features
     unsigned long long* d_surv[LM_NLANES] = {};      // k_scan1's survivor queues, one per lane, allocated on a lane's first bit-plane scan
     int surv_set[LM_NLANES] = {};                    // which of a queue's two counter sets the lane's next scan launch uses (the other is zeroed behind it)
     u32 surv_cap = 1u << 20;
@@ -216,7 +219,7 @@ bool any_lane_busy(const lm_detector* d) {
 void free_device_bank(lm_detector* d) {
     hipFree(d->d_item_t); hipFree(d->d_item_chunk); hipFree(d->d_scan_off); hipFree(d->d_scan_P);
     hipFree(d->d_scan_n); hipFree(d->d_t_global); hipFree(d->d_t_class);
-    hipFree(d->d_off1); hipFree(d->d_offn); d->d_off1 = d->d_offn = nullptr;
+    hipFree(d->d_off1); hipFree(d->d_offn); hipFree(d->d_offs3); d->d_off1 = d->d_offn = d->d_offs3 = nullptr;
     for (auto& it : d->items1) { hipFree(it.d_t); hipFree(it.d_chunk); }
     d->items1.clear();
     d->d_item_t = d->d_item_chunk = d->d_scan_off = nullptr;
@@ -359,6 +362,7 @@ int ensure_bank(lm_detector* d) {
     if (d->hb.fpad1) {
         if ((rc = upload_vec(&d->d_off1, d->hb.off1))) return rc;
         if ((rc = upload_vec(&d->d_offn, d->hb.offn))) return rc;
+        if ((rc = upload_vec(&d->d_offs3, d->hb.offs3))) return rc;
     }
     if ((rc = upload_vec(&d->d_t_global, d->hb.t_global))) return rc;
     if ((rc = upload_vec(&d->d_t_class, d->hb.t_class))) return rc;
@@ -405,7 +409,7 @@ bool planes_wanted(const lm_detector* d, int n) {
 u32 plane_stride_in_use(const lm_detector* d, int level) {
     const LmLevelGeom& g = d->geom[level];
     if (!g.plane_ori || !d->emit_planes) return 0u;
-    return g.plane_ori;
+    return g.plane_ori | (d->emit_spread_low ? 0x80000000u : 0u);      // (bit 31: d_lm_fast writes the spread byte instead of the response memories)
 }
 
 // one modality's linear memories of level l (a6-a10)
@@ -429,9 +433,13 @@ int slot_weight(const lm_detector* d) {
 }
 
 // a3-a10 on the frames resident in slots [first, first + n).
+int scan1_rule(const lm_detector* d, int nslots, bool forced);
 void enqueue_preprocess(lm_detector* d, int first, int n) {
     d->emit_planes = planes_wanted(d, n) && d->geom[d->cfg.pyramid_levels - 1].plane_ori != 0;
-    for (int i = 0; i < n; ++i) d->slots[first + i].planes = d->emit_planes;
+    // by cost, when this call's own scan will be k_scan1: no response memories at all (k_lm_fast is bound by the number of its stores), the
+    // second stage of the scan reads the spread byte through the table.  Such a slot can only be scanned by k_scan1 afterwards.
+    d->emit_spread_low = d->emit_planes && d->scan_form == 0 && !d->bank_dirty && scan1_rule(d, n, false) > 0;
+    for (int i = 0; i < n; ++i) { d->slots[first + i].planes = d->emit_planes; d->slots[first + i].spread_low = d->emit_spread_low; }
     const lm_config& c = d->cfg;
     const int M = c.num_modalities, L = c.pyramid_levels;
     const size_t fs = d->frame_stride;
@@ -533,10 +541,21 @@ int item_ranges(lm_detector* d, std::vector<int>& classes, std::vector<ItemRange
 // chunks of 128 L1 - 31 positions there, two frames of chunks of 1016 here.  So the form with fewer waves wins; L1 is the lane count
 // with the fewest.  k_scan1 needs a margin (its waves stop when the LAST of their frames is out of reach, and the survivors' exact
 // sums come on top), and a threshold high enough for the miss bound to bite.  Returns L1, or 0 for k_scan4 / k_scan.
-int pick_scan1_lanes(const lm_detector* d, int first, int nslots) {
+// forced: the lane count with the fewest waves whatever the rules say (slots without response memories)
+int scan1_rule(const lm_detector* d, int nslots, bool forced) {
     const LmLevelGeom& g = d->geom[d->cfg.pyramid_levels - 1];
-    if (!g.nibble || !g.plane_ori || !d->hb.fpad1 || d->scan_form == 1) return 0;
-    for (int i = 0; i < nslots; ++i) if (!d->slots[first + i].planes) return 0;      // (a frame prepared by a call that did not write them)
+    if (!g.nibble || !g.plane_ori || !d->hb.fpad1) return 0;
+    if (forced) {
+        long long best = -1; int bestL = 0;
+        for (int L1 = 1; L1 <= 64; ++L1) {
+            const int G1 = 64 / L1;
+            if ((size_t)(G1 - 1) * d->frame_stride + g.arena_bytes >= 0x7FFFFFFFull) continue;
+            const long long waves = d->hb.items1_by_L[L1] * ((nslots + G1 - 1) / G1);
+            if (best < 0 || waves < best) { best = waves; bestL = L1; }
+        }
+        return bestL;
+    }
+    if (d->scan_form == 1) return 0;
     if (d->scan_form != 2 && !(d->raw_thr_for >= d->scan1_min_threshold)) return 0;
     // measured r05 (profiles/r05_ab_experiments.log, three lanes): colour-only config 3 +9 % (the scan launch 389 -> 296 us per 128 frames), but
     // RGB-D config 2 -2 % and config 5 -18 %: with two modalities the exact deficits of k_scan4's pruning stop a work item after 29-46 % of its
@@ -559,6 +578,15 @@ int pick_scan1_lanes(const lm_detector* d, int first, int nslots) {
     return bestL;
 }
 
+// ... for these slots: -1 = they cannot be scanned together (some keep only the spread byte, others have no planes)
+int pick_scan1_lanes(const lm_detector* d, int first, int nslots) {
+    bool all_planes = true, any_spread = false;
+    for (int i = 0; i < nslots; ++i) { all_planes = all_planes && d->slots[first + i].planes; any_spread = any_spread || d->slots[first + i].spread_low; }
+    if (any_spread) return all_planes ? scan1_rule(d, nslots, true) : -1;
+    if (!all_planes) return 0;                   // (a frame prepared by a call that did not write them)
+    return scan1_rule(d, nslots, false);
+}
+
 // the work items of k_scan1 for L1 lanes per frame, built and uploaded on first use
 int ensure_items1(lm_detector* d, int L1, const lm_detector::Items1** out) {
     for (const auto& it : d->items1) if (it.L == L1) { *out = &it; return LM_OK; }
@@ -578,7 +606,7 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots = 1
     const int L = d->cfg.pyramid_levels;
     const LmLevelGeom& g = d->geom[L - 1];
     LmScanArgs a;
-    a.L1 = 0; a.G1 = 1; a.L1_rcp16 = 0; a.delta_rcp16 = 0; a.off1 = a.offn = nullptr; a.fpad1 = 0; a.no_exact = 0; a.surv = nullptr; a.surv_cap = 0; a.surv_set = 0;
+    a.L1 = 0; a.G1 = 1; a.L1_rcp16 = 0; a.delta_rcp16 = 0; a.off1 = a.offn = nullptr; a.fpad1 = 0; a.no_exact = 0; a.surv = nullptr; a.surv_cap = 0; a.surv_set = 0; a.exact_spread = 0; a.offs3 = nullptr; a.resp_tab = nullptr;
     a.lm = d->lm(first, L - 1); a.lm_slot_stride = d->frame_stride;
     a.item_t = d->d_item_t; a.item_chunk = d->d_item_chunk;
     a.item_lo = r.lo; a.n_items = r.n;
@@ -593,11 +621,12 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots = 1
     a.cand_cap = d->max_cand;
     const int L1 = pick_scan1_lanes(d, first, nslots);
     const lm_detector::Items1* it = nullptr;
-    if (L1 && ensure_items1(d, L1, &it) == LM_OK) {
+    if (L1 > 0 && ensure_items1(d, L1, &it) == LM_OK) {
         a.L1 = L1; a.G1 = 64 / L1;
         a.L1_rcp16 = (65536u + (u32)L1 - 1u) / (u32)L1;
         a.delta_rcp16 = (65536u + (u32)d->miss_delta - 1u) / (u32)d->miss_delta;
         a.off1 = d->d_off1; a.offn = d->d_offn; a.fpad1 = d->hb.fpad1;
+        a.exact_spread = d->slots[first].spread_low ? 1 : 0; a.offs3 = d->d_offs3; a.resp_tab = d->d_resp_tab;
         a.item_t = it->d_t; a.item_chunk = it->d_chunk;
         a.item_lo = it->begin[(size_t)r.t_lo]; a.n_items = it->begin[(size_t)r.t_hi] - a.item_lo;
         unsigned long long*& q = d->d_surv[d->active];
@@ -668,6 +697,8 @@ int enqueue_threshold(lm_detector* d, float threshold) {
 // a11-a15 on prepared linear memories; the sort kernel publishes the results to host-mapped memory.
 int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, const std::vector<ItemRange>& ranges, bool timed) {
     const int L = d->cfg.pyramid_levels;
+    if (pick_scan1_lanes(d, first, n) < 0)
+        return fail(LM_ERR_INVALID, "the slots were prepared by calls of different scan forms (some keep only the spread byte of the scanned level): match them apart or upload again");
     if (timed) HIP_TRY(hipEventRecord(d->ev[1], d->stream));
     // one scan launch per run of neighbouring classes; the launches append to the same candidate lists
     for (const ItemRange& r : ranges)
@@ -2587,8 +2618,9 @@ int lm_debug_read(lm_detector* d, int slot, int what, int level, int modality, u
         if (size_out) *size_out = n;
         if (out) {
             if (cap < n) return fail(LM_ERR_INVALID, "buffer too small");
-            if (g.spread_only) {
-                // refinement levels hold the spread memory; expand it with the response LUT here (debug path)
+            if (g.spread_only || (level == d->cfg.pyramid_levels - 1 && d->slots[slot].spread_low)) {
+                // refinement levels hold the spread memory (and so does the scanned level of a slot prepared for the bit-plane scan alone);
+                // expand it with the response LUT here (debug path)
                 std::vector<u8> sp(blk);
                 HIP_TRY(hipMemcpy(sp.data(), d->lm(slot, level) + (size_t)modality * g.mod_stride, blk, hipMemcpyDeviceToHost));
                 for (int o = 0; o < 8; ++o)

@@ -233,9 +233,15 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
                 for (int m = 0; m < M; ++m) {
                     const int k = (cnt_packed >> (8 + 8 * m)) & 0xFF;
                     const size_t lb = ((size_t)ti * M + m) * out.fpad;
-                    for (int q = 0; q < k; ++q) { out.offn.push_back(out.scan_off[lb + q]); out.off1.push_back(plane_bit_off(out.scan_off[lb + q])); }
+                    for (int q = 0; q < k; ++q) {
+                        const u32 noff = out.scan_off[lb + q];
+                        out.offn.push_back(noff); out.off1.push_back(plane_bit_off(noff));
+                        const u32 base = noff / 2u, mm = base / gl.mod_stride, label = (base - mm * gl.mod_stride) / gl.ori_stride;
+                        out.offs3.push_back((label << 29) | (mm * gl.mod_stride + (noff - 2u * (mm * gl.mod_stride + label * gl.ori_stride))));
+                    }
                 }
-                while (out.off1.size() < b1 + (size_t)out.fpad1) { out.offn.push_back(2u * gl.zero_off); out.off1.push_back(8u * gl.zero_off); }
+                // (padding: the zero block through orientation 0 -- response 0 whatever the table, it maps an empty spread byte to 0)
+                while (out.off1.size() < b1 + (size_t)out.fpad1) { out.offn.push_back(2u * gl.zero_off); out.off1.push_back(8u * gl.zero_off); out.offs3.push_back(gl.zero_off); }
                 for (int L1 = 1; L1 <= 64; ++L1) out.items1_by_L[L1] += (P + (128 * L1 - 31) - 1) / (128 * L1 - 31);
             }
             const int chunk = gl.nibble ? LM_SCAN4_CHUNK : LM_SCAN_CHUNK;

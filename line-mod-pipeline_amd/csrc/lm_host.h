@@ -56,7 +56,7 @@ struct DeviceBankHost {
     // bit-plane scan (k_scan1, r05; only when the scanned level has planes): the in-bounds features of all modalities as ONE list per
     // template, in the lists' order -- bit offsets of the miss planes and the same features' nibble offsets
     int fpad1 = 0;
-    std::vector<u32> off1, offn;                   // [nt][fpad1]
+    std::vector<u32> off1, offn, offs3;            // [nt][fpad1]; offs3: orientation << 29 | byte offset of the feature in the modality's spread memory (the level written without response memories)
     long long items1_by_L[65] = {};                // work items when a frame takes L lanes: sum over templates of ceil(P / (128 L - 31))
 };
 // k_scan1's work items for L lanes per frame (chunks of 128 L - 31 positions), template-major like item_t / item_chunk; begin[t] =

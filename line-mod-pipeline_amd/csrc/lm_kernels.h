@@ -73,6 +73,9 @@ struct LmScanArgs {
     unsigned long long* surv; // survivor queues of the launch's stream, one per XCD: [16 + x * (surv_cap / 8) + i] = template << 32 | slot << 20 | position;
     u32 surv_cap;             //    k_scan1_exact takes their exact sums (null / overflow: the wave does it itself).  [8 * surv_set + x] = entries appended
     int surv_set;             //    to queue x: two sets of counters, a launch uses one and its k_scan1_exact zeroes the other for the next launch
+    int exact_spread;         // 1: the slots keep ONE spread byte per position instead of the response memories (d_lm_fast, bit 31 of plane_ori): the exact
+    const u32* offs3;         //    sums go through the response table.  offs3 [nt][fpad1]: orientation << 29 | byte offset of the feature's spread memory
+    const u64* resp_tab;      //    [256] responses of the 8 orientations to a spread byte
 };
 // a11+a12+a13: similarity scan over the lowest level fused with the threshold scan.
 // variant selects the unroll depth of the feature loop (0: 8 loads in flight, 1: 4, 2: 2).

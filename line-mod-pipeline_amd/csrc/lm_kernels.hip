@@ -2037,26 +2037,44 @@ __device__ __forceinline__ void d_lm_fast(const u32 vblock, const u8* __restrict
         constexpr int UW = (T == 8 && SEG == 80) ? 16 : 8;     // (only the launch that guarantees whole 80-column segments and the stores' alignment)
         constexpr int NH = UW / 8;
         constexpr int CU = SEG / UW;
+        // r05, bit 31 of plane_ori: the level's response memories are NOT written -- the bit-plane scan reads the planes, and its second stage takes
+        // the few exact sums it needs from ONE byte per position (the spread byte, linearised like a refinement level's memory at the start
+        // of the modality's block) through the response table: a 16-byte store per 16 positions instead of eight 8-byte stores
+        const bool spread_low = (plane_ori >> 31) != 0;
+        plane_ori &= 0x7FFFFFFFu;
         for (int u = tid; u < T * T * CU; u += 256) {
             const int ku = u % CU, g = u / CU;
             const int j = g / T, c0 = g - j * T;
             if (UW * ku >= ncols) continue;
             const u8* row = reinterpret_cast<const u8*>(&sp[j][0]);
             u32 nd[NH][8], pb[NH][8];        // per half of the unit: the nibble dword / the miss byte of every orientation
+            u32 sb[NH][2];                   // ... / its eight spread bytes
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 const int k8 = NH * ku + h;
-                u64 e[4];
+                if (spread_low) {
+                    sb[h][0] = sb[h][1] = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)   // byte o of e[i] = response o of columns 2i (low nibble) and 2i+1
-                    e[i] = tab[row[(8 * k8 + 2 * i) * T + c0]] | (tab[row[(8 * k8 + 2 * i + 1) * T + c0]] << 4);
-                const u32 a0 = (u32)e[0], a1 = (u32)e[1], a2 = (u32)e[2], a3 = (u32)e[3];
-                const u32 b0 = (u32)(e[0] >> 32), b1 = (u32)(e[1] >> 32), b2 = (u32)(e[2] >> 32), b3 = (u32)(e[3] >> 32);
+                    for (int i = 0; i < 4; ++i) {
+                        sb[h][0] |= (u32)row[(8 * k8 + i) * T + c0] << (8 * i);
+                        sb[h][1] |= (u32)row[(8 * k8 + 4 + i) * T + c0] << (8 * i);
+                    }
+                }
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    const u32 sel = (u32)o | ((u32)(o + 4) << 8);
-                    nd[h][o] = (__builtin_amdgcn_perm(a1, a0, sel) & 0xFFFFu) | (__builtin_amdgcn_perm(a3, a2, sel) << 16);
-                    nd[h][o + 4] = (__builtin_amdgcn_perm(b1, b0, sel) & 0xFFFFu) | (__builtin_amdgcn_perm(b3, b2, sel) << 16);
+                for (int o = 0; o < 8; ++o) nd[h][o] = 0;
+                if (!spread_low) {
+                    u64 e[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)   // byte o of e[i] = response o of columns 2i (low nibble) and 2i+1
+                        e[i] = tab[row[(8 * k8 + 2 * i) * T + c0]] | (tab[row[(8 * k8 + 2 * i + 1) * T + c0]] << 4);
+                    const u32 a0 = (u32)e[0], a1 = (u32)e[1], a2 = (u32)e[2], a3 = (u32)e[3];
+                    const u32 b0 = (u32)(e[0] >> 32), b1 = (u32)(e[1] >> 32), b2 = (u32)(e[2] >> 32), b3 = (u32)(e[3] >> 32);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const u32 sel = (u32)o | ((u32)(o + 4) << 8);
+                        nd[h][o] = (__builtin_amdgcn_perm(a1, a0, sel) & 0xFFFFu) | (__builtin_amdgcn_perm(a3, a2, sel) << 16);
+                        nd[h][o + 4] = (__builtin_amdgcn_perm(b1, b0, sel) & 0xFFFFu) | (__builtin_amdgcn_perm(b3, b2, sel) << 16);
+                    }
                 }
                 if (plane_ori) {
                     // r05, k_scan1's bit planes: per orientation one BIT per position, set where the response is below 4 (a "miss");
@@ -2075,10 +2093,16 @@ __device__ __forceinline__ void d_lm_fast(const u32 vblock, const u8* __restrict
             const size_t pos = (size_t)g * wh + (size_t)band * W + col0 + UW * ku;
             u8* dst = lm + (pos >> 1);
             u8* pl = lm + 8 * (size_t)ori_stride + (pos >> 3);
+            if (spread_low) {
+                if (NH == 2) *reinterpret_cast<u32x4*>(lm + pos) = u32x4{sb[0][0], sb[0][1], sb[NH - 1][0], sb[NH - 1][1]};
+                else *reinterpret_cast<u32x2*>(lm + pos) = u32x2{sb[0][0], sb[0][1]};
+            }
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
-                if (NH == 2) *reinterpret_cast<u32x2*>(dst + (size_t)o * ori_stride) = u32x2{nd[0][o], nd[NH - 1][o]};
-                else *reinterpret_cast<u32*>(dst + (size_t)o * ori_stride) = nd[0][o];
+                if (!spread_low) {
+                    if (NH == 2) *reinterpret_cast<u32x2*>(dst + (size_t)o * ori_stride) = u32x2{nd[0][o], nd[NH - 1][o]};
+                    else *reinterpret_cast<u32*>(dst + (size_t)o * ori_stride) = nd[0][o];
+                }
                 if (plane_ori) {
                     if (NH == 2) *reinterpret_cast<unsigned short*>(pl + (size_t)o * plane_ori) = (unsigned short)(pb[0][o] | (pb[NH - 1][o] << 8));
                     else pl[(size_t)o * plane_ori] = (u8)pb[0][o];
@@ -2852,7 +2876,7 @@ __global__ __launch_bounds__(256) void k_scan1(LmScanArgs a) {
         if (!hl) return;
     }
     // exact sums of the survivors from the nibble memories, one survivor at a time: lane k adds features k and k + 64
-    const u32* offn = a.offn + (size_t)ti * a.fpad1;
+    const u32* offn = (a.exact_spread ? a.offs3 : a.offn) + (size_t)ti * a.fpad1;
     const u32 on0 = lane < F ? offn[lane] : 0u, on1 = lane + 64 < F ? offn[lane + 64] : 0u;
     const int offset = a.T / 2 + (a.T % 2 - 1);
     u32 n_surv = 0;
@@ -2871,8 +2895,13 @@ __global__ __launch_bounds__(256) void k_scan1(LmScanArgs a) {
         }
         const u8* nb = a.lm + (size_t)sl * a.lm_slot_stride;
         u32 v = 0;
+        if (a.exact_spread) {     // (on0 / on1 are then the spread offsets with the orientation in bits 29 .. 31)
+            if (lane < F) v = (u32)((a.resp_tab[nb[(on0 & 0x1FFFFFFFu) + (u32)j]] >> (8u * (on0 >> 29))) & 0xFFu);
+            if (lane + 64 < F) v += (u32)((a.resp_tab[nb[(on1 & 0x1FFFFFFFu) + (u32)j]] >> (8u * (on1 >> 29))) & 0xFFu);
+        } else {
         if (lane < F) { const u32 ad = on0 + (u32)j; const u32 by = nb[ad >> 1]; v = (ad & 1u) ? (by >> 4) : (by & 15u); }
         if (lane + 64 < F) { const u32 ad = on1 + (u32)j; const u32 by = nb[ad >> 1]; v += (ad & 1u) ? (by >> 4) : (by & 15u); }
+        }
         const int raw = (int)wave_sum_u32(v);
         n_surv += 1;
         if (raw > thr && lane == 0) {
@@ -2897,6 +2926,8 @@ __global__ __launch_bounds__(256) void k_scan1(LmScanArgs a) {
 // Second half of the bit-plane scan: the exact sums of the queued survivors, one lane each (neighbours in the queue are neighbouring
 // positions of one template: their nibble loads share lines).  Sums above the threshold become candidates exactly as k_scan4 emits them.
 __global__ __launch_bounds__(256) void k_scan1_exact(LmScanArgs a) {
+    __shared__ u64 tabs[256];                                          // the response table (exact_spread)
+    if (a.exact_spread) { tabs[threadIdx.x] = a.resp_tab[threadIdx.x]; __syncthreads(); }
     const u32 cap8 = a.surv_cap >> 3, qx = blockIdx.x & 7u;           // workgroup b runs on XCD b % 8: queue b % 8
     const unsigned long long total = a.surv[8 * a.surv_set + qx];
     const u32 n = total < (unsigned long long)cap8 ? (u32)total : cap8;
@@ -2910,8 +2941,22 @@ __global__ __launch_bounds__(256) void k_scan1_exact(LmScanArgs a) {
         const int nn = cnt & 0xFF;
         const int F = ((cnt >> 8) & 0xFF) + ((cnt >> 16) & 0xFF);
         const int thr = a.raw_thr_by_n[nn];
+        int raw_out = 0;
         const u32* offn = a.offn + (size_t)ti * a.fpad1;
         const u8* nb = a.lm + (size_t)sl * a.lm_slot_stride;
+        if (a.exact_spread) {
+            // the level keeps ONE byte per position (the spread byte): response = table[spread byte], byte = the feature's orientation
+            const u32* offs = a.offs3 + (size_t)ti * a.fpad1;
+            int raws = 0;
+            for (int f = 0; f < F; f += 8) {
+                u32 sv[8], of[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { of[k] = offs[f + k]; sv[k] = nb[(of[k] & 0x1FFFFFFFu) + j]; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) raws += (int)((tabs[sv[k]] >> (8u * (of[k] >> 29))) & 0xFFu);
+            }
+            raw_out = raws;
+        } else {
         // batches of eight features: the lists are padded to a multiple of eight with offsets of the arena's zero block (response 0), so there is
         // no tail of single, dependent loads; the next batch's offsets are requested before this batch's responses
         int raw = 0;
@@ -2929,6 +2974,9 @@ __global__ __launch_bounds__(256) void k_scan1_exact(LmScanArgs a) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) raw += (int)((ad[k] & 1u) ? (by[k] >> 4) : (by[k] & 15u));
         }
+        raw_out = raw;
+        }
+        const int raw = raw_out;
         if (raw > thr) {
             LmDevHeader* hdr = reinterpret_cast<LmDevHeader*>(reinterpret_cast<u8*>(a.hdr) + (size_t)sl * a.aux_slot_stride);
             LmCand* cand = reinterpret_cast<LmCand*>(reinterpret_cast<u8*>(a.cand) + (size_t)sl * a.aux_slot_stride);
@@ -4040,7 +4088,7 @@ void lmk_linear_memories(hipStream_t s, const u8* q, int qpitch, int src_shift, 
                 lm_fast_launch<5, 128>(LMF_ARGS); return;
             case 8:
                 // r05: whole segments of 80 columns take 16-column units (half the scattered stores); everything else 40-column segments
-                if (mode == 2 && (W % 80) == 0 && (((size_t)W * (h / 8)) % 16) == 0 && (((uintptr_t)lm & 7) == 0) && (lm_slot_stride % 8) == 0 && (ori_stride % 8) == 0 && (plane_ori % 2) == 0) {
+                if (mode == 2 && (W % 80) == 0 && (((size_t)W * (h / 8)) % 16) == 0 && (((uintptr_t)lm & 15) == 0) && (lm_slot_stride % 16) == 0 && (ori_stride % 8) == 0 && (plane_ori % 2) == 0) {
                     lm_fast_launch<8, 80>(LMF_ARGS); return;
                 }
                 lm_fast_launch<8, 40>(LMF_ARGS); return;
@@ -4178,7 +4226,7 @@ void lmk_preprocess_batch_phases(hipStream_t s, const LmPhaseArgs& a, int T0) {
         }
     }
     const int W1 = w1 / 8;
-    if ((W1 % 80) == 0 && (((size_t)W1 * (h1 / 8)) % 16) == 0 && (((uintptr_t)a.lm_c1 & 7) == 0) && (a.slot_stride % 8) == 0 && (a.ori_stride1 % 8) == 0 && (a.plane_ori1 % 2) == 0) {
+    if ((W1 % 80) == 0 && (((size_t)W1 * (h1 / 8)) % 16) == 0 && (((uintptr_t)a.lm_c1 & 15) == 0) && (a.slot_stride % 16) == 0 && (a.ori_stride1 % 8) == 0 && (a.plane_ori1 % 2) == 0) {
         // (16-column units: half the scattered stores, see d_lm_fast MODE 2)
         const int seg80 = W1 / 80;
         hipLaunchKernelGGL((k_lm_fast<8, 80, 0, 2>), dim3((unsigned)(seg80 * (h1 / 8) * n)), dim3(256), 0, s, a.qc1, w1, w1, h1, a.resp_tab, a.lm_c1, a.ori_stride1,

@@ -72,7 +72,7 @@ static void digest(const lmh::Bank& bank, const lm_config& cfg) {
         const LmLevelGeom& g = geom[cfg.pyramid_levels - 1];
         const int M = cfg.num_modalities;
         const size_t nt = hb.scan_P.size();
-        if (hb.fpad1 <= 0 || hb.fpad1 % 8 || hb.off1.size() != nt * (size_t)hb.fpad1 || hb.offn.size() != hb.off1.size()) { std::printf("bit-plane lists have the wrong shape\n"); std::abort(); }
+        if (hb.fpad1 <= 0 || hb.fpad1 % 8 || hb.off1.size() != nt * (size_t)hb.fpad1 || hb.offn.size() != hb.off1.size() || hb.offs3.size() != hb.off1.size()) { std::printf("bit-plane lists have the wrong shape\n"); std::abort(); }
         for (size_t t = 0; t < nt; ++t) {
             const int cnt = hb.scan_n[t];
             int F = 0;
@@ -84,11 +84,13 @@ static void digest(const lmh::Bank& bank, const lm_config& cfg) {
             }
             for (int f = 0; f < hb.fpad1; ++f) {
                 const u32 on = hb.offn[t * hb.fpad1 + f], ob = hb.off1[t * hb.fpad1 + f];
-                if (f >= F) { if (on != 2u * g.zero_off || ob != 8u * g.zero_off) { std::printf("bit-plane list padding is not the zero block\n"); std::abort(); } continue; }
+                const u32 os = hb.offs3[t * hb.fpad1 + f];
+                if (f >= F) { if (on != 2u * g.zero_off || ob != 8u * g.zero_off || os != g.zero_off) { std::printf("bit-plane list padding is not the zero block\n"); std::abort(); } continue; }
                 if (on != want[(size_t)f]) { std::printf("nibble offset %d of template %zu differs from the per-modality list\n", f, t); std::abort(); }
                 const u32 m = (on / 2u) / g.mod_stride, rel = on / 2u - m * g.mod_stride, label = rel / g.ori_stride;
                 const u32 pos = on - 2u * (m * g.mod_stride + label * g.ori_stride);                 // position inside the orientation's T * T memories
                 const u32 plane0 = 8u * (m * g.mod_stride + 8u * g.ori_stride + label * g.plane_ori);
+                if (os != ((label << 29) | (m * g.mod_stride + pos))) { std::printf("spread offset %d of template %zu is not its nibble offset's orientation and position\n", f, t); std::abort(); }
                 if (label > 7 || pos >= (u32)(g.T * g.T) * g.wh || ob != plane0 + pos) { std::printf("bit offset %d of template %zu is not its nibble offset's position in the miss plane\n", f, t); std::abort(); }
             }
         }
