@@ -263,7 +263,9 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
  *   threshold is at least LM_TUNE_SCAN1_MIN_THRESHOLD (measured: +9-10 % on the
  *   colour-only 1280 x 960 workload, a loss with two modalities, where k_scan4's exact pruning stops far sooner than the miss
  *   bound); 1 = always k_scan4; 2 = k_scan1 whenever the level has planes.  The candidate lists, and therefore every result, are
- *   the same. */
+ *   the same.  Under 0, a call whose own scan is k_scan1 writes the scanned level of its slots as one spread byte + the bit planes,
+ *   WITHOUT the response memories: those slots are scanned by k_scan1 from then on (also by lm_match_prepared at a lower threshold),
+ *   and a call that mixes them with slots prepared without planes is refused (LM_ERR_INVALID). */
 #define LM_TUNE_SCAN_FORM 16
 /* LM_TUNE_SCAN1_MIN_THRESHOLD (r05): similarity threshold in percent (0..100, default 50) below which LM_TUNE_SCAN_FORM 0 keeps
  *   k_scan4: the lower the threshold the more positions survive the miss bound and need their exact sums. */
