@@ -180,6 +180,21 @@ def test_scan_form_by_cost_and_key_validation(lm, orc, synth):
         d.upload_frame(k, frames[k % 3][0], None)
     d.match_batch(16, 85.0, cap_per_frame=1 << 15)
     assert d.get_scan_form_stats()[3] > 0                      # 16 colour-only frames: k_scan1
+    # the call's scan was k_scan1 by cost: its slots hold the spread byte + the planes, no response memories.  They are scanned by k_scan1 from
+    # then on -- also by a prepared match below the threshold rule -- and lm_debug_read still shows the same linear memories
+    exp60 = o.match(frames[1][0], None, 60.0, threads=8, cap=1 << 18)
+    d.set_tuning(lm.TUNE_SCAN1_MIN_THRESHOLD, 70)
+    got, cnt = d.match_prepared(0, 16, 60.0, [-1], cap_per_frame=1 << 15)
+    assert d.get_scan_form_stats()[3] > 0
+    assert cnt[1] == len(exp60) and got[1, :cnt[1]].tobytes() == exp60.tobytes()
+    d.set_tuning(lm.TUNE_SCAN1_MIN_THRESHOLD, 50)
+    o.prepare(frames[2][0], None)
+    assert np.array_equal(d.debug_read(2, 2, 1, 0), o.stage(2, 1, 0))
+    d.upload_frame(0, frames[0][0], None); d.prepare_slot(0)   # one frame: prepared without planes -> cannot be scanned together with the others
+    with pytest.raises(lm.LinemodError):
+        d.match_prepared(0, 16, 85.0, [-1], cap_per_frame=1 << 12)
+    got, cnt = d.match_prepared(1, 15, 85.0, [-1], cap_per_frame=1 << 14)          # ... apart they can
+    assert d.get_scan_form_stats()[3] > 0
     d.match_batch(1, 85.0, cap_per_frame=1 << 15)
     assert d.get_scan_form_stats()[3] == 0                     # one frame: k_scan4 (three launches instead of one would double its scan time)
     d.match_batch(16, 48.0, cap_per_frame=1 << 15)
