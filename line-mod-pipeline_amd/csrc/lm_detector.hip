@@ -578,11 +578,15 @@ int scan1_rule(const lm_detector* d, int nslots, bool forced) {
     return bestL;
 }
 
-// ... for these slots: -1 = they cannot be scanned together (some keep only the spread byte, others have no planes)
+// ... for these slots: -1 = they cannot be scanned together.  A launch reads ONE layout of the scanned level (LmScanArgs::exact_spread), so slots
+// that keep only the spread byte mix neither with slots without planes nor with slots that have planes AND response memories.
 int pick_scan1_lanes(const lm_detector* d, int first, int nslots) {
-    bool all_planes = true, any_spread = false;
-    for (int i = 0; i < nslots; ++i) { all_planes = all_planes && d->slots[first + i].planes; any_spread = any_spread || d->slots[first + i].spread_low; }
-    if (any_spread) return all_planes ? scan1_rule(d, nslots, true) : -1;
+    bool all_planes = true, any_spread = false, all_spread = true;
+    for (int i = 0; i < nslots; ++i) {
+        const auto& sl = d->slots[first + i];
+        all_planes = all_planes && sl.planes; any_spread = any_spread || sl.spread_low; all_spread = all_spread && sl.spread_low;
+    }
+    if (any_spread) return (all_planes && all_spread) ? scan1_rule(d, nslots, true) : -1;
     if (!all_planes) return 0;                   // (a frame prepared by a call that did not write them)
     return scan1_rule(d, nslots, false);
 }
@@ -640,6 +644,14 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots = 1
         if (g.wh >= (1u << 20) || nslots > 4096) a.surv = nullptr;      // the entry's 20-bit position / 12-bit slot
     }
     return a;
+}
+
+// Slots that keep only the spread byte of the scanned level have no response memories: k_scan4 would read garbage there.  When the bit-plane
+// form could not be set up for them (no work items: allocation failure, no lane count fits) the match fails instead.
+int check_scan_args(const lm_detector* d, int first, const LmScanArgs& a) {
+    if (!a.L1 && d->slots[first].spread_low)
+        return fail(LM_ERR_HIP, "the slots keep only the spread byte of the scanned level and the bit-plane scan could not be set up for them: upload the frames again");
+    return LM_OK;
 }
 
 // after every launch of lmk_scan with these arguments: the lane's next bit-plane scan takes the other set of queue counters (this launch's
@@ -704,6 +716,7 @@ int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, cons
     for (const ItemRange& r : ranges)
         if (r.n > 0) {
             LmScanArgs sa = make_scan_args(d, first, r, n);
+            if (int rc = check_scan_args(d, first, sa)) return rc;
             lmk_scan(d->stream, sa, d->scan_variant, n);
             scan_launched(d, sa);
             d->cnt_scan_launches += 1; d->cnt_scan1_launches += sa.L1 ? 1 : 0; d->last_scan1_lanes = sa.L1;
@@ -2654,6 +2667,7 @@ int lm_stage_scan(lm_detector* d, int slot, float threshold, int class_idx, int3
     if ((rc = enqueue_threshold(d, threshold))) return rc;
     {
         LmScanArgs sa = make_scan_args(d, slot, r);
+        if ((rc = check_scan_args(d, slot, sa))) return rc;
         lmk_scan(d->stream, sa, d->scan_variant, 1);
         d->last_scan1_lanes = sa.L1;
         scan_launched(d, sa);
@@ -2692,6 +2706,7 @@ int lm_time_scan(lm_detector* d, int slot, float threshold, int class_idx, int i
     if ((rc = item_range(d, class_idx, &r))) return rc;
     if ((rc = enqueue_threshold(d, threshold))) return rc;
     LmScanArgs a = make_scan_args(d, slot, r);
+    if ((rc = check_scan_args(d, slot, a))) return rc;
     a.cand_cap = 0;  // timing only: count candidates, store none (the list would overflow across iterations)
     for (int i = 0; i < 3; ++i) { lmk_scan(d->stream, a, variant, 1); scan_launched(d, a); }
     HIP_TRY(hipEventRecord(d->ev[0], d->stream));
@@ -2729,6 +2744,7 @@ int lm_time_scan_batch(lm_detector* d, int first_slot, int n_slots, float thresh
     if ((rc = item_range(d, class_idx, &r))) return rc;
     if ((rc = enqueue_threshold(d, threshold))) return rc;
     LmScanArgs a = make_scan_args(d, first_slot, r, n_slots);
+    if ((rc = check_scan_args(d, first_slot, a))) return rc;
     a.cand_cap = 0;
     for (int i = 0; i < 2; ++i) { lmk_scan(d->stream, a, variant, n_slots); scan_launched(d, a); }
     HIP_TRY(hipEventRecord(d->ev[0], d->stream));
@@ -2901,6 +2917,14 @@ int lm_device_pci_bus_id(lm_detector* d, char* out, size_t cap) {
     return LM_OK;
 }
 
-int lm_set_scan_variant(lm_detector* d, int variant) { if (!d) return LM_ERR_INVALID; d->scan_variant = variant; return LM_OK; }
+// Only variants whose lists are the default's may be set on the product path: bits 6 and 7 skip work (no shift-undo / no exact
+// sums of the survivors) and exist for lm_time_scan* alone, which take their variant as an argument and store no candidates.
+int lm_set_scan_variant(lm_detector* d, int variant) {
+    if (!d) return fail(LM_ERR_INVALID, "null detector");
+    if (variant < 0 || (variant & ~LM_SCAN_VARIANT_SETTABLE))
+        return fail(LM_ERR_INVALID, "scan variant " + std::to_string(variant) + " changes the match lists (bits 6 / 7 are timing experiments of lm_time_scan* only) or is unknown");
+    d->scan_variant = variant;
+    return LM_OK;
+}
 
 }  // extern "C"

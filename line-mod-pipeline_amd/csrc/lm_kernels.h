@@ -79,6 +79,9 @@ struct LmScanArgs {
 };
 // a11+a12+a13: similarity scan over the lowest level fused with the threshold scan.
 // variant selects the unroll depth of the feature loop (0: 8 loads in flight, 1: 4, 2: 2).
+// The variants lm_set_scan_variant accepts: bits 0-5 (k_scan4's load blocks and pruning rules) and bit 8 (k_scan1's survivors summed by the
+// wave itself) leave the candidate lists as they are; bits 6 / 7 skip work and belong to lm_time_scan* alone.
+#define LM_SCAN_VARIANT_SETTABLE (0x3F | 0x100)
 void lmk_scan(hipStream_t s, const LmScanArgs& a, int variant, int nslots);
 
 struct LmRefineArgs {

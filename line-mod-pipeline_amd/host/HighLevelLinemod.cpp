@@ -284,7 +284,18 @@ bool HighLevelLineMOD::detectTemplatesBatchBegin(std::vector<std::vector<Image>>
     // this batch (finishBegin) while its own colour check is on the GPU -- the host's share of an upload disappears behind work that is
     // waiting anyway (r05: "in Begin" 68-160 us per frame with pageable frames before this).
     bool ok = true;
-    if (st.inflight.size() == 1) ok = finishBegin(st.inflight.back());
+    if (st.inflight.size() == 1) {
+        ok = finishBegin(st.inflight.back());
+        if (!ok) {
+            // a Begin that reports failure leaves nothing in flight -- the serial callers (detectTemplatesBatch, PoseDetection::detectBatch)
+            // return without calling End, and every later call would otherwise fail with "batches are in flight".  finishBegin has waited for the
+            // batch's staging tasks, and a failed lm_match_begin_classes leaves its lane idle.
+            error = st.inflight.back().begin_error;
+            st.set_busy[set] = false;
+            st.next_set = set;
+            st.inflight.pop_back();
+        }
+    }
     stageTimes.upload += secs(t_up, clk::now());
     return ok;
 }
@@ -297,7 +308,9 @@ bool HighLevelLineMOD::finishBegin(Batch& b) {
     Stream& st = *stream_;
     const clk::time_point t0 = clk::now();
     const int n = b.n, first = b.set * kBatchSlots, set = b.set;
-    auto failed = [&](const std::string& why) { b.begin_error = why; error = why; stageTimes.upload += std::chrono::duration<double>(clk::now() - t0).count(); return false; };
+    // (the failure is kept in the batch: the caller that RETURNS it -- Begin, or the End of this batch -- sets lastError(); an End that only drives
+    // the next batch's Begin on must not report that batch's failure as its own)
+    auto failed = [&](const std::string& why) { b.begin_error = why; stageTimes.upload += std::chrono::duration<double>(clk::now() - t0).count(); return false; };
     // the tasks were queued at the FRONT one after the other, so the pool takes them last frame first: frames are waited for, and sent,
     // in that order -- the transfer of a frame runs while the rows of the next ones are still being copied
     for (int i = n - 1; i >= 0; --i) {

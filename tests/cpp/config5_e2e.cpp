@@ -234,6 +234,21 @@ int main(int argc, char** argv) {
         line.setGpuColorCheck(true);
         lm_host_free(pin);
     }
+    // ---- a Begin whose second half fails (here: a class the bank does not hold -> lm_match_begin_classes refuses) leaves nothing in
+    // flight, so the serial API goes on working: the next detectBatch gives the poses of the first one
+    {
+        std::vector<std::vector<std::vector<lm_match_t>>> mm;
+        std::vector<std::vector<std::vector<std::vector<ObjectPose>>>> gg;
+        const bool bad = line.detectTemplatesBatch(frames, std::vector<uint16_t>{99}, mm, gg);
+        const int left = line.batchesInFlight();
+        const bool said = !line.lastError().empty();
+        std::vector<std::vector<ObjectPose>> poses;
+        const bool again = pd.detectBatch(frames, std::string(names[0]), 1, poses);
+        size_t found = 0;
+        if (again) for (int i = 0; i < NF; ++i) found += poses[(size_t)i].size();
+        std::printf("recovery failed_begin_refused %d in_flight %d error_text %d next_call_ok %d poses %zu\n", bad ? 0 : 1, left, said ? 1 : 0, again ? 1 : 0, found);
+        if (!again) std::printf("detectBatch after a failed Begin: %s\n", pd.lastError().c_str());
+    }
     if (!line.lastError().empty() && line.lastError() != "no batch in flight") std::printf("last error: %s\n", line.lastError().c_str());
     return 0;
 }

@@ -194,3 +194,15 @@ def test_merge_matches_equals_oracle_merge(lm, orc):
 def test_struct_layouts(lm, orc):
     assert lm.MATCH_DTYPE.itemsize == 20 and lm.FEATURE_DTYPE.itemsize == 12 and lm.DESC_DTYPE.itemsize == 16
     assert C.sizeof(lm.Config) == 4 * 22   # 22 int32/float fields of lm_config
+
+
+def test_scan_variant_refuses_list_changing_bits(lm):
+    """r06: lm_set_scan_variant accepts only variants that leave the match lists as they are (no GPU needed: it is a host-side check)."""
+    d = lm.Detector(color_only=True)
+    for ok in (0, 1, 2, 8, 16, 32, 63, 256, 256 | 34):
+        d.set_scan_variant(ok)
+    for bad in (64, 72, 128, 384, 512, -1):
+        with pytest.raises(lm.LinemodError):
+            d.set_scan_variant(bad)
+    d.set_scan_variant(0)
+    d.close()

@@ -56,6 +56,24 @@ def test_bench_config3_line():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("config,batch", [(2, 32), (3, 32)])
+def test_bench_accepts_its_line_on_the_timed_buffers(config, batch):
+    """r06 (VERDICT r5 #1b): cpu_baseline compares what the TIMED lanes wrote into their own result buffers in the last timed step (frames 0..3 of
+    lane 0, the first frame of the other lane) with the oracle -- for config 3 that is the bit-plane scan on 16-frame launches -- and says so."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(config), "--steps", "4", "--warmup", "1", "--batch", str(batch),
+                        "--lanes", "2", "--templates", "300", "--no-h2d", "--no-latency", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    cb = d["cpu_baseline"]
+    assert "error" not in cb, cb
+    assert cb["timed_buffers_checked"] == [0, 1, 2, 3, batch // 2] and "TIMED lanes' own result buffers" in cb["sample"]
+    assert cb["value"] > 0 and cb["kind"] == "port"
+    if config == 3:
+        assert d["roofline"]["kernel"] == "k_scan1" and "k_scan1" in cb["sample"]
+
+
+@pytest.mark.gpu
 def test_bench_rccl_single_rank_communicator():
     """The whole gathered path (k_pack_lists, 2 x ncclAllGather per lane-step, merge of the owned frames) through a
     single-rank RCCL communicator: what a 1-GPU box can run of the N > 1 path."""

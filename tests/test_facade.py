@@ -203,6 +203,9 @@ def test_config5_pose_detection_batch_end_to_end(lm, tmp_path):
     assert sum(1 for l in passes["serial"] if int(l.split()[l.split().index("poses") + 1]) > 0) >= 60                             # the objects are found in all three batches
     for tag in ("piped", "pinned", "hostcc"):
         assert "stream %s third_begin_refused 1" % tag in out and "stream %s end_without_batch_refused 1" % tag in out
+    # r06: a Begin that fails in its second half leaves nothing in flight; the serial API recovers
+    rec = [l.split() for l in out if l.startswith("recovery ")][0]
+    assert rec[1:9] == ["failed_begin_refused", "1", "in_flight", "0", "error_text", "1", "next_call_ok", "1"] and int(rec[10]) >= 6, rec
     found = 0
     for l in gpu:
         t = l.split()

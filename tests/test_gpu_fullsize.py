@@ -156,3 +156,97 @@ def test_config5_three_classes_8100_templates_each_1280x960_rgbd(lm, orc, synth)
             pc, pn = per[c]
             assert_matches_equal(class_sublist(mixed, c), pc[i, :pn[i]])
     d.close()
+
+
+# ---- r06 (VERDICT r5 #1a): the launch forms the bench lines TIME, at the configurations' stated sizes ---------------------------------
+def _check_batch(lm, d, o, frames, M, thr, n, want_scan1, cap=1 << 15, class_idx=0):
+    """`n` resident frames (the distinct `frames` in rotation) through ONE lm_match_batch call and through two lanes of
+    lm_match_begin / lm_match_end; every frame's list against the oracle's.  want_scan1: True = every scan launch of the calls must have been
+    the bit-plane kernel k_scan1, False = none, None = whichever the cost rule picks."""
+    nd = len(frames)
+    dep = lambda k: frames[k % nd][1] if M == 2 else None
+    exp = [o.match(frames[k][0], dep(k), thr, class_idx, threads=THREADS, cap=1 << 18) for k in range(nd)]
+    assert sum(len(e) for e in exp) > 0
+    for k in range(n):
+        d.upload_frame(k, frames[k % nd][0], dep(k))
+    d.upload_wait(-1)
+
+    def forms(before, after):
+        launches, scan1 = after[1] - before[1], after[0] - before[0]
+        assert launches >= 1
+        if want_scan1 is True:
+            assert scan1 == launches and after[3] > 0, (before, after)
+        elif want_scan1 is False:
+            assert scan1 == 0 and after[3] == 0, (before, after)
+    before = d.get_scan_form_stats()
+    got, cnt = d.match_batch(n, thr, class_idx, cap_per_frame=cap)
+    forms(before, d.get_scan_form_stats())
+    for k in range(n):
+        assert_matches_equal(got[k, :cnt[k]], exp[k % nd])
+    # two lanes in flight, as bench.py drives them (the slots are still prepared; lm_match_begin runs a3-a15 again)
+    h = n // 2
+    before = d.get_scan_form_stats()
+    d.match_begin(0, 0, h, thr, class_idx)
+    d.match_begin(1, h, n - h, thr, class_idx)
+    g0, c0 = d.match_end(0, cap_per_frame=cap, n_slots=h)
+    g1, c1 = d.match_end(1, cap_per_frame=cap, n_slots=n - h)
+    forms(before, d.get_scan_form_stats())
+    for k in range(h):
+        assert_matches_equal(g0[k, :c0[k]], exp[k % nd])
+    for k in range(n - h):
+        assert_matches_equal(g1[k, :c1[k]], exp[(h + k) % nd])
+    return exp
+
+
+@pytest.mark.parametrize("fixed", [False, True])
+def test_config3_batch_bit_plane_scan_at_stated_size(lm, orc, synth, fixed):
+    """BASELINE config 3 AS THE BENCH RUNS IT: a batch of 32 resident frames (four distinct) of 1280x960 colour-only, 3000 templates, under
+    the default LM_TUNE_SCAN_FORM 0 -- the cost rule must pick the bit-plane scan k_scan1 with the spread-byte second stage (the slots keep
+    no response memories) -- thresholds 80 and 65, variable and fixed geometry, lm_match_batch and two lanes of lm_match_begin / _end: every
+    frame's list equals the oracle's.  Then the candidate list of the forced bit-plane form (LM_TUNE_SCAN_FORM 2) record by record."""
+    W, H, M, NB = 1280, 960, 1, 32
+    frames = [synth.make_frame(W, H, seed=2234 + i) for i in range(4)]
+    d = lm.Detector(color_only=True, width=W, height=H, frame_slots=NB)
+    o = orc.Detector(color_only=True)
+    q = _oracle_quantized(o, frames[0][0], None, M)
+    descs, feats, crops = synth.make_bank(3000, M, 2, seed=77, fixed_l0_size=(192, 192) if fixed else None,
+                                          size_range=(96, 320), quantized=q, crop_fraction=0.1, frame_size=(W, H),
+                                          T0=d.get_T(0))
+    d.add_class("shiny.ply", descs, feats)
+    o.add_class("shiny.ply", descs, feats)
+    d.set_scan_stats(True)
+    _check_batch(lm, d, o, frames, M, 80.0, NB, True)
+    assert d.get_scan_form_stats()[2] > 0                      # survivors had their exact sums taken (k_scan1_exact / the waves)
+    d.set_scan_stats(False)
+    _check_batch(lm, d, o, frames[:2], M, 65.0, NB, True, cap=1 << 16)
+    # a11-a13 alone under the forced form, at this size
+    d.set_tuning(lm.TUNE_SCAN_FORM, 2)
+    for k, thr in ((0, 80.0), (3, 80.0), (1, 65.0)):
+        d.upload_frame(k, frames[k][0], None)
+        d.prepare_slot(k)
+        o.prepare(frames[k][0], None)
+        assert np.array_equal(d.stage_scan(k, thr, 0), o.scan_candidates(thr, 0, threads=THREADS))
+        assert d.get_scan_form_stats()[3] > 0
+    d.close()
+
+
+@pytest.mark.parametrize("fixed", [False, True])
+def test_config2_batch_of_96_frames_at_stated_size(lm, orc, synth, fixed):
+    """BASELINE config 2 AS THE BENCH RUNS IT: ONE call over 96 resident frames (four distinct) of 640x480 RGB-D, 3000 templates -- the
+    batch pre-processing kernels and one scan launch over 96 frames --, threshold 80, and two lanes of 48; every frame's list equals the
+    oracle's whatever scan form the cost rule picks, and again with either form forced."""
+    W, H, M, NB = 640, 480, 2, 96
+    frames = [synth.make_frame(W, H, seed=1234 + i) for i in range(4)]
+    d = lm.Detector(color_only=False, width=W, height=H, frame_slots=NB)
+    o = orc.Detector(color_only=False)
+    q = _oracle_quantized(o, frames[0][0], frames[0][1], M)
+    descs, feats, crops = synth.make_bank(3000, M, 2, seed=4321, fixed_l0_size=(96, 96) if fixed else None, quantized=q,
+                                          crop_fraction=0.1, frame_size=(W, H), T0=d.get_T(0))
+    d.add_class("synthetic.ply", descs, feats)
+    o.add_class("synthetic.ply", descs, feats)
+    _check_batch(lm, d, o, frames, M, 80.0, NB, None)
+    d.set_tuning(lm.TUNE_SCAN_FORM, 1)
+    _check_batch(lm, d, o, frames, M, 80.0, NB, False)
+    d.set_tuning(lm.TUNE_SCAN_FORM, 2)
+    _check_batch(lm, d, o, frames, M, 80.0, NB, True)
+    d.close()

@@ -218,3 +218,55 @@ def test_scan_form_by_cost_and_key_validation(lm, orc, synth):
     d2.match_batch(16, 85.0, cap_per_frame=1 << 15)
     assert d2.get_scan_form_stats()[3] == 0                    # two modalities: k_scan4's exact pruning stops sooner than the miss bound
     d2.close()
+
+
+def test_slots_with_planes_and_slots_with_spread_bytes_do_not_mix(lm, orc, synth):
+    """r06: a launch reads ONE layout of the scanned level.  Slots 0..7 matched by cost at threshold 85 keep only the spread byte (+ planes),
+    slots 8..15 matched under the forced form at a threshold below the cost rule's keep the response memories (+ planes): one prepared call over
+    all 16 is refused; apart, each half gives the oracle's lists."""
+    d, o, frames = _setup(lm, orc, synth, True, (640, 480), [2, 8], 40, 16, seed=993)
+    for k in range(16):
+        d.upload_frame(k, frames[k % 3][0], None)
+    exp85 = [o.match(f[0], None, 85.0, threads=8, cap=1 << 18) for f in frames]
+    exp40 = [o.match(f[0], None, 40.0, threads=8, cap=1 << 18) for f in frames]
+    d.match_begin(0, 0, 8, 85.0); d.match_end(0, 1 << 15, n_slots=8)          # by cost: k_scan1, no response memories in slots 0..7
+    assert d.get_scan_form_stats()[3] > 0
+    d.set_tuning(lm.TUNE_SCAN_FORM, 2)                                        # forced: planes AND response memories in slots 8..15
+    d.match_begin(0, 8, 8, 40.0); d.match_end(0, 1 << 15, n_slots=8)
+    d.set_tuning(lm.TUNE_SCAN_FORM, 0)
+    with pytest.raises(lm.LinemodError):
+        d.match_prepared(0, 16, 85.0, [-1], cap_per_frame=1 << 15)
+    with pytest.raises(lm.LinemodError):
+        d.match_prepared(4, 8, 85.0, [-1], cap_per_frame=1 << 15)
+    got, cnt = d.match_prepared(0, 8, 40.0, [-1], cap_per_frame=1 << 15)      # (spread-byte slots: k_scan1 whatever the threshold rule says)
+    for k in range(8):
+        assert_matches_equal(got[k, :cnt[k]], exp40[k % 3])
+    got, cnt = d.match_prepared(8, 8, 85.0, [-1], cap_per_frame=1 << 15)
+    for k in range(8):
+        assert_matches_equal(got[k, :cnt[k]], exp85[(8 + k) % 3])
+    d.close()
+
+
+def test_scan_variants_that_change_the_lists_are_refused(lm, orc, synth):
+    """r06 (VERDICT r5 #1c): lm_set_scan_variant takes only variants whose lists are variant 0's; the two timing experiments that skip work
+    (bit 6: no shift-undo, bit 7: no exact sums of the survivors) are arguments of lm_time_scan / lm_time_scan_batch alone."""
+    d, o, frames = _setup(lm, orc, synth, True, (640, 480), [2, 8], 30, 8, seed=994)
+    for bad in (64, 8 | 64, 128, 128 | 256, 512, -1, 1 << 20):
+        with pytest.raises(lm.LinemodError):
+            d.set_scan_variant(bad)
+    for k in range(8):
+        d.upload_frame(k, frames[k % 3][0], None)
+    exp = [o.match(f[0], None, 85.0, threads=8, cap=1 << 18) for f in frames]
+    for ok in (0, 1, 2, 8, 16, 32, 34, 256, 0):
+        d.set_scan_variant(ok)
+        got, cnt = d.match_batch(8, 85.0, cap_per_frame=1 << 15)
+        for k in range(8):
+            assert_matches_equal(got[k, :cnt[k]], exp[k % 3])
+    # the timing hooks still take them (candidates counted, none stored) and leave the detector's lists alone
+    d.set_tuning(lm.TUNE_SCAN_FORM, 2)
+    got, cnt = d.match_batch(8, 85.0, cap_per_frame=1 << 15)
+    assert d.time_scan_batch(0, 8, 85.0, iters=2, variant=128) > 0
+    got, cnt = d.match_prepared(0, 8, 85.0, [-1], cap_per_frame=1 << 15)
+    for k in range(8):
+        assert_matches_equal(got[k, :cnt[k]], exp[k % 3])
+    d.close()
