@@ -221,27 +221,34 @@ def test_scan_form_by_cost_and_key_validation(lm, orc, synth):
 
 
 def test_slots_with_planes_and_slots_with_spread_bytes_do_not_mix(lm, orc, synth):
-    """r06: a launch reads ONE layout of the scanned level.  Slots 0..7 matched by cost at threshold 85 keep only the spread byte (+ planes),
-    slots 8..15 matched under the forced form at a threshold below the cost rule's keep the response memories (+ planes): one prepared call over
-    all 16 is refused; apart, each half gives the oracle's lists."""
+    """r06: a launch reads ONE layout of the scanned level.  Under the default form, slots 0..7 matched at threshold 85 keep only the
+    spread byte (+ planes: the call's scan is k_scan1 by cost); slots 8..15 matched at threshold 40 -- below LM_TUNE_SCAN1_MIN_THRESHOLD, so the
+    call's scan is k_scan4 -- keep the response memories (+ planes: 8 colour-only frames).  One prepared call over slots of both kinds is
+    refused; apart, each half gives the oracle's lists at either threshold."""
     d, o, frames = _setup(lm, orc, synth, True, (640, 480), [2, 8], 40, 16, seed=993)
     for k in range(16):
         d.upload_frame(k, frames[k % 3][0], None)
     exp85 = [o.match(f[0], None, 85.0, threads=8, cap=1 << 18) for f in frames]
     exp40 = [o.match(f[0], None, 40.0, threads=8, cap=1 << 18) for f in frames]
-    d.match_begin(0, 0, 8, 85.0); d.match_end(0, 1 << 15, n_slots=8)          # by cost: k_scan1, no response memories in slots 0..7
+    d.match_begin(0, 0, 8, 85.0)
+    got, cnt = d.match_end(0, 1 << 15, n_slots=8)
+    assert d.get_scan_form_stats()[3] > 0                                     # k_scan1 by cost: no response memories in slots 0..7
+    for k in range(8):
+        assert_matches_equal(got[k, :cnt[k]], exp85[k % 3])
+    d.match_begin(0, 8, 8, 40.0)
+    got, cnt = d.match_end(0, 1 << 16, n_slots=8)
+    assert d.get_scan_form_stats()[3] == 0                                    # k_scan4: planes AND response memories in slots 8..15
+    for k in range(8):
+        assert_matches_equal(got[k, :cnt[k]], exp40[(8 + k) % 3])
+    for first, n in ((0, 16), (4, 8), (7, 2)):
+        with pytest.raises(lm.LinemodError) as e:
+            d.match_prepared(first, n, 85.0, [-1], cap_per_frame=1 << 15)
+        assert "different scan forms" in str(e.value)
+    got, cnt = d.match_prepared(0, 8, 40.0, [-1], cap_per_frame=1 << 16)      # (spread-byte slots: k_scan1 whatever the threshold rule says)
     assert d.get_scan_form_stats()[3] > 0
-    d.set_tuning(lm.TUNE_SCAN_FORM, 2)                                        # forced: planes AND response memories in slots 8..15
-    d.match_begin(0, 8, 8, 40.0); d.match_end(0, 1 << 15, n_slots=8)
-    d.set_tuning(lm.TUNE_SCAN_FORM, 0)
-    with pytest.raises(lm.LinemodError):
-        d.match_prepared(0, 16, 85.0, [-1], cap_per_frame=1 << 15)
-    with pytest.raises(lm.LinemodError):
-        d.match_prepared(4, 8, 85.0, [-1], cap_per_frame=1 << 15)
-    got, cnt = d.match_prepared(0, 8, 40.0, [-1], cap_per_frame=1 << 15)      # (spread-byte slots: k_scan1 whatever the threshold rule says)
     for k in range(8):
         assert_matches_equal(got[k, :cnt[k]], exp40[k % 3])
-    got, cnt = d.match_prepared(8, 8, 85.0, [-1], cap_per_frame=1 << 15)
+    got, cnt = d.match_prepared(8, 8, 85.0, [-1], cap_per_frame=1 << 15)      # (planes + response memories: either kernel may scan them)
     for k in range(8):
         assert_matches_equal(got[k, :cnt[k]], exp85[(8 + k) % 3])
     d.close()
