@@ -265,7 +265,14 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
  *   bound); 1 = always k_scan4; 2 = k_scan1 whenever the level has planes.  The candidate lists, and therefore every result, are
  *   the same.  Under 0, a call whose own scan is k_scan1 writes the scanned level of its slots as one spread byte + the bit planes,
  *   WITHOUT the response memories: those slots are scanned by k_scan1 from then on (also by lm_match_prepared at a lower threshold),
- *   and a call that mixes them with slots prepared without planes is refused (LM_ERR_INVALID). */
+ *   and a call that mixes them with slots prepared without planes is refused (LM_ERR_INVALID).
+ *   r06: 3 = the bit-plane scan with a frame's planes in LDS (k_scanl) wherever they fit -- the scanned level's planes of all modalities
+ *   within 153 600 bytes: 640 x 480 RGB-D at T = {5, 8} exactly --, k_scan1 where they do not.  One 1024-thread workgroup copies a frame's
+ *   planes into its CU's LDS, counts misses from there (k_scan1 on such frames is bound by the L2 -> L1 line rate: every frame and feature
+ *   is two 128-byte lines) and takes the survivors' exact sums from the frame's spread bytes, in LDS as well, in the same launch.  Under 0
+ *   it is picked for calls of at least 16 frames at a threshold of at least LM_TUNE_SCAN1_MIN_THRESHOLD, for one modality or two; its
+ *   slots too keep the spread byte + the planes instead of the response memories.  lm_get_scan_form_stats reports 1000 + the workgroups
+ *   per frame as the "lanes per frame" of such a launch. */
 #define LM_TUNE_SCAN_FORM 16
 /* LM_TUNE_SCAN1_MIN_THRESHOLD (r05): similarity threshold in percent (0..100, default 50) below which LM_TUNE_SCAN_FORM 0 keeps
  *   k_scan4: the lower the threshold the more positions survive the miss bound and need their exact sums. */

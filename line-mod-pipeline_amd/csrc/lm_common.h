@@ -26,6 +26,12 @@ typedef uint64_t u64;
 #define LM_SCAN4_CHUNK 1016     // nibble scan: positions per work item (half a wave: 32 lanes x 32 positions, the last 8 are
                                 // polluted by the other half's data); two items per wave
 #define LM_SCAN_FPAD 8          // feature lists are padded to a multiple of this with zero-block offsets
+// r06, the bit-plane scan with the planes in LDS (k_scanl): a 1024-thread workgroup keeps ONE frame's miss planes of all modalities -- and, for the
+// second stage, the frame's spread bytes in their place -- in the CU's 160 KB of LDS
+#define LM_SCANL_LDS_BYTES 163840   // the whole LDS of a gfx950 CU
+#define LM_SCANL_IMAGE_MAX 153600   // bytes of the planes (= of the spread bytes): M * T*T*wh = M * level pixels (640 x 480 RGB-D at level 1: exactly this)
+#define LM_SCANL_TABLE_BYTES 2048   // behind the image: the response table of the second stage (a zero block during the first)
+#define LM_SCANL_POS_BITS 15        // survivor entry: template << 15 | position
 #define LM_SORT_CAP 4096        // matches sorted on the device (LDS); more are sorted by the host
 #define LM_SORT_CHUNK 1024      // split form of the device sort: keys per chunk workgroup (LM_SORT_CAP / LM_SORT_CHUNK workgroups per frame)
 #define LM_INLINE_MATCHES 2048  // records the sort kernel also writes straight into host-mapped memory

@@ -173,12 +173,16 @@ struct lm_detector {
     u32* d_off1 = nullptr; u32* d_offn = nullptr;
     struct Items1 { int L = 0; u32* d_t = nullptr; u32* d_chunk = nullptr; std::vector<int> begin; };
     std::vector<Items1> items1;
-    int scan_form = 0;               // LM_TUNE_SCAN_FORM: 0 = by cost (default), 1 = always the nibble scan k_scan4, 2 = the bit-plane scan k_scan1 whenever the level has planes
+    int scan_form = 0;               // LM_TUNE_SCAN_FORM: 0 = by cost (default), 1 = always the nibble scan k_scan4, 2 = the bit-plane scan k_scan1 whenever the level has planes,
+                                     //    3 = the bit-plane scan with the planes in LDS (k_scanl) wherever a frame's planes fit (k_scan1 where they do not)
     float scan1_min_threshold = 50.0f;   // below this similarity threshold the miss bound keeps too many positions alive: k_scan4 (LM_TUNE_SCAN1_MIN_THRESHOLD)
     long long cnt_scan1_launches = 0; int last_scan1_lanes = 0;
     bool emit_planes = false;        // the pre-processing being enqueued writes the miss planes (set per call by enqueue_preprocess)
     bool emit_spread_low = false;    // ... and the spread byte instead of the response memories (the call's scan is k_scan1 by the rule below)
     u32* d_offs3 = nullptr;          // [nt][fpad1] orientation << 29 | spread-memory offset of the bit-plane scan's features
+    // r06, the bit-plane scan with a frame's planes in LDS (k_scanl; hb.lds_ok): the lists in the LDS image's layout and the lane items
+    u32* d_offl = nullptr; u32* d_offsl = nullptr; u32* d_litem = nullptr;
+    int scanl_min_slots = 16;        // by cost (LM_TUNE_SCAN_FORM 0) from this many frames per call
     unsigned long long* d_surv[LM_NLANES] = {};      // k_scan1's survivor queues, one per lane, allocated on a lane's first bit-plane scan
     int surv_set[LM_NLANES] = {};                    // which of a queue's two counter sets the lane's next scan launch uses (the other is zeroed behind it)
     u32 surv_cap = 1u << 20;
@@ -220,6 +224,7 @@ void free_device_bank(lm_detector* d) {
     hipFree(d->d_item_t); hipFree(d->d_item_chunk); hipFree(d->d_scan_off); hipFree(d->d_scan_P);
     hipFree(d->d_scan_n); hipFree(d->d_t_global); hipFree(d->d_t_class);
     hipFree(d->d_off1); hipFree(d->d_offn); hipFree(d->d_offs3); d->d_off1 = d->d_offn = d->d_offs3 = nullptr;
+    hipFree(d->d_offl); hipFree(d->d_offsl); hipFree(d->d_litem); d->d_offl = d->d_offsl = d->d_litem = nullptr;
     for (auto& it : d->items1) { hipFree(it.d_t); hipFree(it.d_chunk); }
     d->items1.clear();
     d->d_item_t = d->d_item_chunk = d->d_scan_off = nullptr;
@@ -364,6 +369,11 @@ int ensure_bank(lm_detector* d) {
         if ((rc = upload_vec(&d->d_offn, d->hb.offn))) return rc;
         if ((rc = upload_vec(&d->d_offs3, d->hb.offs3))) return rc;
     }
+    if (d->hb.lds_ok) {
+        if ((rc = upload_vec(&d->d_offl, d->hb.offl))) return rc;
+        if ((rc = upload_vec(&d->d_offsl, d->hb.offsl))) return rc;
+        if ((rc = upload_vec(&d->d_litem, d->hb.litem))) return rc;
+    }
     if ((rc = upload_vec(&d->d_t_global, d->hb.t_global))) return rc;
     if ((rc = upload_vec(&d->d_t_class, d->hb.t_class))) return rc;
     for (int l = 0; l + 1 < d->cfg.pyramid_levels; ++l) {
@@ -401,10 +411,17 @@ int wait_uploads(lm_detector* d, hipStream_t stream, int first, int n, unsigned 
 // cost k_lm_fast a second set of scattered stores (measured r05: 16.2 -> 24.4 us per 96-frame launch of config 2, 70 -> 115 us per 128 frames
 // of config 3).  By cost that is a call of 8+ frames on a one-modality detector (pick_scan1_lanes); LM_TUNE_SCAN_FORM 2 asks for them always,
 // 1 never.  A slot remembers whether its pass wrote them (Slot::planes): k_scan1 never reads planes of an older frame.
+int scanl_rule(const lm_detector* d, int nslots);
+// the scanned level's planes of all modalities fit the LDS image of k_scanl (lm_host.cpp build_device_bank: the same test, there with the bank's size)
+bool scanl_geom_ok(const lm_detector* d) {
+    const LmLevelGeom& g = d->geom[d->cfg.pyramid_levels - 1];
+    const u32 ttwh = (u32)g.T * (u32)g.T * g.wh;
+    return g.nibble && g.plane_ori && (ttwh % 128u) == 0 && (size_t)d->cfg.num_modalities * ttwh <= LM_SCANL_IMAGE_MAX && g.wh <= (1u << LM_SCANL_POS_BITS);
+}
 bool planes_wanted(const lm_detector* d, int n) {
     if (d->scan_form == 1) return false;
-    if (d->scan_form == 2) return true;
-    return d->cfg.num_modalities == 1 && n >= 8;
+    if (d->scan_form >= 2) return true;
+    return (d->cfg.num_modalities == 1 && n >= 8) || scanl_rule(d, n) > 0;
 }
 u32 plane_stride_in_use(const lm_detector* d, int level) {
     const LmLevelGeom& g = d->geom[level];
@@ -438,7 +455,8 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
     d->emit_planes = planes_wanted(d, n) && d->geom[d->cfg.pyramid_levels - 1].plane_ori != 0;
     // by cost, when this call's own scan will be k_scan1: no response memories at all (k_lm_fast is bound by the number of its stores), the
     // second stage of the scan reads the spread byte through the table.  Such a slot can only be scanned by k_scan1 afterwards.
-    d->emit_spread_low = d->emit_planes && d->scan_form == 0 && !d->bank_dirty && scan1_rule(d, n, false) > 0;
+    d->emit_spread_low = d->emit_planes && ((d->scan_form == 0 && !d->bank_dirty && (scanl_rule(d, n) > 0 || scan1_rule(d, n, false) > 0)) ||
+                                            (d->scan_form == 3 && scanl_geom_ok(d)));      // (3: whatever the bank; a bank k_scanl cannot take is scanned by k_scan1)
     for (int i = 0; i < n; ++i) { d->slots[first + i].planes = d->emit_planes; d->slots[first + i].spread_low = d->emit_spread_low; }
     const lm_config& c = d->cfg;
     const int M = c.num_modalities, L = c.pyramid_levels;
@@ -556,14 +574,15 @@ int scan1_rule(const lm_detector* d, int nslots, bool forced) {
         return bestL;
     }
     if (d->scan_form == 1) return 0;
-    if (d->scan_form != 2 && !(d->raw_thr_for >= d->scan1_min_threshold)) return 0;
+    const bool asked = d->scan_form >= 2;      // (3: the LDS form where a frame's planes fit, this kernel where they do not)
+    if (!asked && !(d->raw_thr_for >= d->scan1_min_threshold)) return 0;
     // measured r05 (profiles/r05_ab_experiments.log, three lanes): colour-only config 3 +9 % (the scan launch 389 -> 296 us per 128 frames), but
     // RGB-D config 2 -2 % and config 5 -18 %: with two modalities the exact deficits of k_scan4's pruning stop a work item after 29-46 % of its
     // features, the miss bound after 66-84 %.  By cost = one modality only.
-    if (d->scan_form != 2 && d->cfg.num_modalities != 1) return 0;
+    if (!asked && d->cfg.num_modalities != 1) return 0;
     // ... and batches only: its three launches (queue reset, k_scan1, k_scan1_exact) cost a single 640 x 480 frame 29 instead of 15 us of scan
     // (the reference's one-frame call: 100 against 89 us per call)
-    if (d->scan_form != 2 && nslots < 8) return 0;
+    if (!asked && nslots < 8) return 0;
     long long best = -1; int bestL = 0;
     for (int L1 = 1; L1 <= 64; ++L1) {
         const int G1 = 64 / L1;
@@ -574,8 +593,34 @@ int scan1_rule(const lm_detector* d, int nslots, bool forced) {
     }
     if (bestL == 0) return 0;
     const long long waves4 = (long long)d->hb.item_t.size() * ((nslots + 1) / 2);
-    if (d->scan_form != 2 && (best * 5 > waves4 * 4 || nslots < 64 / bestL)) return 0;      // (and whole groups of frames)
+    if (!asked && (best * 5 > waves4 * 4 || nslots < 64 / bestL)) return 0;      // (and whole groups of frames)
     return bestL;
+}
+
+// r06: the bit-plane scan with the frame's planes in LDS (k_scanl).  Workgroups per frame: about three rounds of the chip's 256 CUs (a workgroup
+// takes a CU's whole LDS), at most 16 per frame (every one copies the frame's planes and spread bytes: 300 KB), and no more than leave every
+// wave of a workgroup a work item.
+int scanl_shares(const lm_detector* d, int nslots, int n_litems) {
+    int R = (768 + nslots / 2) / std::max(nslots, 1);
+    R = std::max(1, std::min(R, 16));
+    const int n_w = (n_litems + 63) / 64;
+    return std::max(1, std::min(R, n_w / 16));
+}
+// ... by cost (LM_TUNE_SCAN_FORM 0): where a frame's planes fit LDS, for calls of enough frames to fill the chip with such workgroups, at thresholds
+// at which the miss bound bites.  Returns the shares per frame, 0 = another form.  (LM_TUNE_SCAN_FORM 3 asks for it wherever it can run.)
+int scanl_rule(const lm_detector* d, int nslots) {
+    if (d->bank_dirty || !d->hb.lds_ok || !d->d_litem) return 0;
+    const LmLevelGeom& g = d->geom[d->cfg.pyramid_levels - 1];
+    if (!g.nibble || !g.plane_ori) return 0;
+    if (d->scan_form == 1 || d->scan_form == 2) return 0;
+    if (d->scan_form == 0 && (!(d->raw_thr_for >= d->scan1_min_threshold) || nslots < d->scanl_min_slots)) return 0;
+    return scanl_shares(d, nslots, (int)d->hb.litem.size());
+}
+// ... for prepared slots: all of them keep the planes and the spread bytes (the form reads both)
+int pick_scanl(const lm_detector* d, int first, int nslots, int n_litems) {
+    if (d->bank_dirty || !d->hb.lds_ok || !d->d_litem || d->scan_form == 2 || d->scan_form == 1 || n_litems <= 0) return 0;
+    for (int i = 0; i < nslots; ++i) if (!d->slots[first + i].planes || !d->slots[first + i].spread_low) return 0;
+    return scanl_shares(d, nslots, n_litems);
 }
 
 // ... for these slots: -1 = they cannot be scanned together.  A launch reads ONE layout of the scanned level (LmScanArgs::exact_spread), so slots
@@ -623,6 +668,22 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots = 1
     a.cand = reinterpret_cast<LmCand*>(d->aux(first, d->off_cand));
     a.aux_slot_stride = d->aux_stride;
     a.cand_cap = d->max_cand;
+    a.lds_form = 0; a.R = 1; a.offl = a.offsl = a.litem = nullptr; a.litem_lo = a.n_litems = 0; a.pb = a.mod_stride = a.planes_off = a.plane_ori = a.tbl_bytes = a.queue_cap = 0;
+    {
+        const int lo = d->hb.lds_ok ? d->hb.lbegin[(size_t)r.t_lo] : 0, nl = d->hb.lds_ok ? d->hb.lbegin[(size_t)r.t_hi] - lo : 0;
+        const int R = pick_scanl(d, first, nslots, nl);
+        if (R > 0) {
+            a.lds_form = 1; a.R = R;
+            a.offl = d->d_offl; a.offsl = d->d_offsl; a.litem = d->d_litem; a.litem_lo = lo; a.n_litems = nl;
+            a.pb = (u32)g.T * (u32)g.T * g.wh / 8u; a.mod_stride = g.mod_stride; a.planes_off = 8u * g.ori_stride; a.plane_ori = g.plane_ori;
+            const u32 img = (u32)a.M * 8u * a.pb;
+            a.tbl_bytes = std::max<u32>(LM_SCANL_TABLE_BYTES, (((g.wh + 127u) / 128u) * 16u + 32u + 15u) & ~15u);
+            a.queue_cap = std::min<u32>((LM_SCANL_LDS_BYTES - img - a.tbl_bytes - 16u) / 4u, 1u << 16);
+            a.delta_rcp16 = (65536u + (u32)d->miss_delta - 1u) / (u32)d->miss_delta;
+            a.fpad1 = d->hb.fpad1; a.exact_spread = 1; a.offs3 = d->d_offs3; a.resp_tab = d->d_resp_tab;
+            return a;
+        }
+    }
     const int L1 = pick_scan1_lanes(d, first, nslots);
     const lm_detector::Items1* it = nullptr;
     if (L1 > 0 && ensure_items1(d, L1, &it) == LM_OK) {
@@ -649,7 +710,7 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots = 1
 // Slots that keep only the spread byte of the scanned level have no response memories: k_scan4 would read garbage there.  When the bit-plane
 // form could not be set up for them (no work items: allocation failure, no lane count fits) the match fails instead.
 int check_scan_args(const lm_detector* d, int first, const LmScanArgs& a) {
-    if (!a.L1 && d->slots[first].spread_low)
+    if (!a.L1 && !a.lds_form && d->slots[first].spread_low)
         return fail(LM_ERR_HIP, "the slots keep only the spread byte of the scanned level and the bit-plane scan could not be set up for them: upload the frames again");
     return LM_OK;
 }
@@ -719,7 +780,7 @@ int enqueue_match_stages(lm_detector* d, int first, int n, float threshold, cons
             if (int rc = check_scan_args(d, first, sa)) return rc;
             lmk_scan(d->stream, sa, d->scan_variant, n);
             scan_launched(d, sa);
-            d->cnt_scan_launches += 1; d->cnt_scan1_launches += sa.L1 ? 1 : 0; d->last_scan1_lanes = sa.L1;
+            d->cnt_scan_launches += 1; d->cnt_scan1_launches += (sa.L1 || sa.lds_form) ? 1 : 0; d->last_scan1_lanes = sa.lds_form ? 1000 + sa.R : sa.L1;
         }
     if (timed) HIP_TRY(hipEventRecord(d->ev[2], d->stream));
     if (L == 1) {
@@ -1561,7 +1622,7 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
         case LM_TUNE_SORT_SPLIT: if (value < 0 || value > 2) break; d->sort_split_mode = value; return LM_OK;
         case LM_TUNE_SCAN_LIST_ORDER: if (value < 0 || value > 3) break; d->scan_list_order = value; d->bank_dirty = true; return LM_OK;
         case LM_TUNE_SCAN_FORM:
-            if (value < 0 || value > 2) break;
+            if (value < 0 || value > 3) break;
             if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
             d->scan_form = value;
             for (Slot& sl : d->slots) sl.prepared = false;          // (prepared slots may lack the miss planes the new form reads)
@@ -2669,7 +2730,7 @@ int lm_stage_scan(lm_detector* d, int slot, float threshold, int class_idx, int3
         LmScanArgs sa = make_scan_args(d, slot, r);
         if ((rc = check_scan_args(d, slot, sa))) return rc;
         lmk_scan(d->stream, sa, d->scan_variant, 1);
-        d->last_scan1_lanes = sa.L1;
+        d->last_scan1_lanes = sa.lds_form ? 1000 + sa.R : sa.L1;
         scan_launched(d, sa);
     }
     LmDevHeader h;

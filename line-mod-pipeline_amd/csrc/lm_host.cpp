@@ -129,6 +129,9 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
     out.class_load_bytes.assign(nc, 0.0);
     const bool planes = gl.nibble && gl.plane_ori != 0;
     if (planes) out.fpad1 = (std::min(M * maxf, 2 * LM_MAX_FEATURES) + 7) / 8 * 8;       // (k_scan1_exact reads whole batches of eight: the padding is the zero block)
+    // r06: the LDS image of a frame's planes (k_scanl) -- [modality][orientation][pb bytes], pb = T*T*wh / 8, nothing between the planes
+    const u32 ttwh = (u32)gl.T * (u32)gl.T * gl.wh, pb = ttwh / 8u;
+    out.lds_ok = planes && (ttwh % 128u) == 0 && (size_t)M * ttwh <= LM_SCANL_IMAGE_MAX && gl.wh <= (1u << LM_SCANL_POS_BITS);
     // a list entry's bit offset from its nibble offset: the planes of a modality follow its 8 response memories
     auto plane_bit_off = [&](u32 noff) {
         const u32 base = noff / 2u, m = base / gl.mod_stride, label = (base - m * gl.mod_stride) / gl.ori_stride;
@@ -240,6 +243,18 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
                         out.offs3.push_back((label << 29) | (mm * gl.mod_stride + (noff - 2u * (mm * gl.mod_stride + label * gl.ori_stride))));
                     }
                 }
+                if (out.lds_ok) {
+                    for (size_t q = b1; q < out.off1.size(); ++q) {
+                        const u32 e3 = out.offs3[q], label = e3 >> 29, so = e3 & 0x1FFFFFFFu, mm = so / gl.mod_stride, rest = so - mm * gl.mod_stride;     // rest = memory * wh + cell
+                        const u32 bit = 8u * (mm * 8u + label) * pb + rest;
+                        out.offl.push_back((((bit >> 5) << 2) << 8) | (bit & 31u));
+                        out.offsl.push_back((label << 29) | (mm * ttwh + rest));
+                    }
+                    // (padding: the image's zero block, right behind the planes; the second stage stops at a template's own feature count)
+                    while (out.offl.size() < b1 + (size_t)out.fpad1) { out.offl.push_back(((u32)M * ttwh) << 8); out.offsl.push_back(0u); }
+                    out.lbegin.push_back((int)out.litem.size());
+                    for (int un = 0; un * 128 < P; ++un) out.litem.push_back((ti << 8) | (u32)un);
+                }
                 // (padding: the zero block through orientation 0 -- response 0 whatever the table, it maps an empty spread byte to 0)
                 while (out.off1.size() < b1 + (size_t)out.fpad1) { out.offn.push_back(2u * gl.zero_off); out.off1.push_back(8u * gl.zero_off); out.offs3.push_back(gl.zero_off); }
                 for (int L1 = 1; L1 <= 64; ++L1) out.items1_by_L[L1] += (P + (128 * L1 - 31) - 1) / (128 * L1 - 31);
@@ -281,6 +296,10 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
         }
         out.class_t_hi[ci] = (int)out.t_global.size();
         out.class_item_hi[ci] = (int)out.item_t.size();
+    }
+    if (out.lds_ok) {
+        out.lbegin.push_back((int)out.litem.size());
+        if (out.t_global.size() >= (1u << (32 - LM_SCANL_POS_BITS)) || out.litem.empty()) out.lds_ok = false;     // (the survivor entry's template field)
     }
     return true;
 }

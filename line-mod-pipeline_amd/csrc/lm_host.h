@@ -58,6 +58,14 @@ struct DeviceBankHost {
     int fpad1 = 0;
     std::vector<u32> off1, offn, offs3;            // [nt][fpad1]; offs3: orientation << 29 | byte offset of the feature in the modality's spread memory (the level written without response memories)
     long long items1_by_L[65] = {};                // work items when a frame takes L lanes: sum over templates of ceil(P / (128 L - 31))
+    // r06, the same scan with a frame's planes in LDS (k_scanl; lds_ok: the level's planes of all modalities fit LM_SCANL_IMAGE_MAX bytes, a plane is a
+    // whole number of 16-byte pieces, positions and templates fit the survivor entry): the lists once more in the LDS image's layout
+    // [modality][orientation][T*T*wh / 8 bytes], without the arena's pads
+    bool lds_ok = false;
+    std::vector<u32> offl;                         // [nt][fpad1] (LDS byte address of the dword holding the feature's first bit) << 8 | bit shift; pad: the zero block
+    std::vector<u32> offsl;                        // [nt][fpad1] orientation << 29 | byte offset in the LDS image of the spread bytes [modality][T*T*wh]
+    std::vector<u32> litem;                        // lane items, template-major: template << 8 | unit of 128 positions
+    std::vector<int> lbegin;                       // [nt + 1] first lane item of a bank-local template
 };
 // k_scan1's work items for L lanes per frame (chunks of 128 L - 31 positions), template-major like item_t / item_chunk; begin[t] =
 // first item of bank-local template t (begin[nt] = number of items)

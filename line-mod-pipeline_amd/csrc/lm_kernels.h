@@ -76,6 +76,17 @@ struct LmScanArgs {
     int exact_spread;         // 1: the slots keep ONE spread byte per position instead of the response memories (d_lm_fast, bit 31 of plane_ori): the exact
     const u32* offs3;         //    sums go through the response table.  offs3 [nt][fpad1]: orientation << 29 | byte offset of the feature's spread memory
     const u64* resp_tab;      //    [256] responses of the 8 orientations to a spread byte
+    // r06, the bit-plane scan with a frame's planes in LDS (k_scanl), lds_form != 0: one 1024-thread workgroup = (frame, share of the templates)
+    int lds_form, R;          // R: workgroups per frame
+    const u32* offl;          // [nt][fpad1] (LDS byte address of the feature's first dword) << 8 | bit shift
+    const u32* offsl;         // [nt][fpad1] orientation << 29 | offset in the LDS image of the spread bytes
+    const u32* litem;         // lane items: template << 8 | unit of 128 positions
+    int litem_lo, n_litems;   // the launch's lane items
+    u32 pb;                   // bytes of one miss plane, T*T*wh / 8
+    u32 mod_stride, planes_off, plane_ori;   // arena: modality block stride, offset of a block's planes (8 * ori_stride), stride between them
+    u32 tbl_bytes;            // LDS behind the image: zeros during the first stage (the padded list entries of ANY unit read them: ceil(wh / 128) * 16 + 32 bytes
+                              //    at least), the response table during the second; then 16 bytes of queue header and the queue
+    u32 queue_cap;            // survivor entries the LDS queue holds
 };
 // a11+a12+a13: similarity scan over the lowest level fused with the threshold scan.
 // variant selects the unroll depth of the feature loop (0: 8 loads in flight, 1: 4, 2: 2).

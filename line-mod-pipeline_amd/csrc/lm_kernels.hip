@@ -3013,6 +3013,232 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
     return v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// a11-a13, the bit-plane scan with a frame's planes in LDS (r06; LmScanArgs::lds_form).  k_scan1 on 640 x 480 frames is bound by the
+// L2 -> L1 line rate, not by vector issue: the 8-9 lanes of a frame read 128-144 contiguous bytes of a plane at an arbitrary dword
+// offset, i.e. TWO 128-byte lines for every frame and feature (0.93 of the 34.5 TB/s by the request count).  But ALL the miss planes of
+// such a frame -- 8 orientations x 76 800 bits x 2 modalities = 153 600 bytes -- fit the 160 KB of LDS of one CU.  So:
+//   * a workgroup of 1024 threads owns (frame, share r of R of the templates): it copies the frame's planes into LDS once (16-byte pieces,
+//     the arena's pads dropped) and scans its templates from there -- no L2 -> L1 traffic at all in the loop but the feature lists;
+//   * a LANE is one lane item = (template, unit of 128 positions), the items template-major, 64 consecutive items per wave: 8 templates x 8
+//     units for 995 positions.  The feature's LDS address and bit shift are per lane (one table entry per feature and template, loaded
+//     eight at a time: addr << 8 | shift, the unit's 16 bytes added; v_alignbit_b32 takes the entry itself as its shift operand); the five
+//     dwords come by two ds_read2_b32 + one ds_read_b32 (measured, tools/microbench/lds_unaligned.hip: a dword-aligned ds_read_b128 costs 64
+//     cycles per wave, this form 23) -- the fifth dword too, so a lane needs nothing from its neighbour and a chunk has no 31-position tail;
+//   * counters, flag bit, per-lane pruning and the wave's stop as in k_scan1 (the bound is per lane now: the templates of a wave may differ
+//     in their feature counts; the lists are padded with entries of a zero block = "no miss");
+//   * second stage in the SAME launch: the survivors go to a queue in LDS (template << 15 | position); when all waves are done the
+//     workgroup replaces the planes by the frame's SPREAD bytes (the same number of bytes: one per position and modality, written by
+//     d_lm_fast's spread_low form) and the response table, and takes the survivors' exact sums from LDS -- 62 byte gathers per survivor cost
+//     a few LDS cycles each instead of a 128-byte line lookup in the vector L1 (k_scan1_exact: 49 us per 96-frame launch of config 2).  A
+//     wave whose survivors do not fit the queue takes their sums itself from the arena (k_scan1's fallback).
+// The candidate lists are k_scan4's, record for record.  a.stat as k_scan1.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void scanl_emit(const LmScanArgs& a, u32 sl, u32 ti, int j, int raw, int n) {
+    LmDevHeader* hdr = reinterpret_cast<LmDevHeader*>(reinterpret_cast<u8*>(a.hdr) + (size_t)sl * a.aux_slot_stride);
+    LmCand* cand = reinterpret_cast<LmCand*>(reinterpret_cast<u8*>(a.cand) + (size_t)sl * a.aux_slot_stride);
+    const u32 pos = atomicAdd(&hdr->cand_count, 1u);
+    if (pos < a.cand_cap) {
+        const int offset = a.T / 2 + (a.T % 2 - 1);
+        const int r = j / a.W, cc = j - r * a.W;
+        LmCand cd;
+        cd.ti = ti;
+        cd.x = cc * a.T + offset;
+        cd.y = r * a.T + offset;
+        cd.sim = __fadd_rn(__fdiv_rn(__fmul_rn((float)raw, 100.f), (float)(4 * n)), 0.5f);
+        cand[pos] = cd;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_scanl(LmScanArgs a) {
+    extern __shared__ u32x4 scanl_lds[];
+    u8* lds = reinterpret_cast<u8*>(scanl_lds);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 slot, r;
+    {
+        const u32 R = (u32)a.R, B = (u32)a.nslots, b = blockIdx.x;
+        if ((B & 7u) == 0) { const u32 x = b & 7u, k = b >> 3; slot = x + 8u * (k / R); r = k - (k / R) * R; }     // a frame's workgroups on ONE XCD: its planes come from HBM once
+        else { slot = b / R; r = b - slot * R; }
+    }
+    if (slot >= (u32)a.nslots) return;
+    const u8* arena = a.lm + (size_t)slot * a.lm_slot_stride;
+    const u32 IMG = (u32)a.M * 8u * a.pb;                    // bytes of the planes = of the spread bytes
+    u32* qcount = reinterpret_cast<u32*>(lds + IMG + a.tbl_bytes);
+    u32* queue = qcount + 4;
+    // ---- the frame's planes -> LDS
+    {
+        const u32 per = a.pb >> 4, total = (u32)a.M * 8u * per;
+        for (u32 i = (u32)tid; i < total; i += 1024u) {
+            const u32 pl = i / per, k = i - pl * per, m = pl >> 3, o = pl & 7u;
+            scanl_lds[i] = *reinterpret_cast<const u32x4*>(arena + (size_t)m * a.mod_stride + a.planes_off + (size_t)o * a.plane_ori + 16u * k);
+        }
+        for (u32 i = (u32)tid; i < (a.tbl_bytes >> 2); i += 1024u) reinterpret_cast<u32*>(lds + IMG)[i] = 0u;     // the zero block of the padded list entries
+        if (tid == 0) *qcount = 0u;
+    }
+    __syncthreads();
+    const u32 n_w = ((u32)a.n_litems + 63u) >> 6;
+    const __amdgpu_buffer_rsrc_t rs_off = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(a.offl), 0, 0x7FFFFFFF, 0x00020000);
+    unsigned long long st_f = 0, st_F = 0, st_l = 0, st_s = 0;
+    for (u32 wi = r * 16u + (u32)wave; wi < n_w; wi += 16u * (u32)a.R) {
+        const u32 idx = wi * 64u + (u32)lane;
+        const bool has = idx < (u32)a.n_litems;
+        const u32 it = has ? a.litem[a.litem_lo + (int)idx] : 0u;
+        const u32 ti = it >> 8, unit = it & 255u;
+        const int cnt = has ? a.scan_n[ti] : 0;
+        const int n = cnt & 0xFF;
+        const int F = ((cnt >> 8) & 0xFF) + ((cnt >> 16) & 0xFF);
+        const int thr = a.raw_thr_by_n[n];
+        const int K0 = 4 * F - thr - 1;                              // what the misses may cost in total
+        int mmax = K0 >= 0 ? (int)(((u32)K0 * a.delta_rcp16) >> 16) : 0;
+        if (mmax > 127) mmax = 127;
+        const u32 pre = (u32)(127 - mmax);
+        const int P = has ? a.scan_P[ti] : 0;
+        const int j0 = (int)unit * 128;
+        int valid = (has && K0 >= 0) ? P - j0 : 0;
+        valid = valid < 0 ? 0 : (valid > 128 ? 128 : valid);
+        unsigned long long alive = __ballot(valid > 0);
+        if (!alive) continue;
+        u32 c[4][8];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            const u32 bit = (u32)__builtin_amdgcn_sbfe((int)pre, (u32)b, 1u);   // 0 / ~0
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q][b] = bit;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int vq = valid - 32 * q;
+            c[q][7] = vq >= 32 ? 0u : (vq > 0 ? ~((1u << vq) - 1u) : 0xFFFFFFFFu);      // invalid positions start dead
+        }
+        const int Fw = (int)wave_max_u32(valid > 0 ? (u32)F : 0u);
+        const int first_test = 127 - (int)wave_max_u32(valid > 0 ? pre : 0u);            // the smallest miss budget of the wave: nothing dies before
+        const u32 voff = ti * (u32)a.fpad1 * 4u;
+        const u32 unit_add = (unit * 16u) << 8;
+        bool act = valid > 0, pruned = false;
+        int f = 0;
+        for (; f < Fw && !pruned; f += 8) {
+            st_l += 8u * (u32)__popcll(alive);
+            if (act) {
+                const u32x4 e0 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, (u32)f * 4u, 0);
+                const u32x4 e1 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, (u32)f * 4u + 16u, 0);
+                const u32 e[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
+                u32 v[8][5];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const u32* p = reinterpret_cast<const u32*>(lds + ((e[k] + unit_add) >> 8));
+                    v[k][0] = p[0]; v[k][1] = p[1]; v[k][2] = p[2]; v[k][3] = p[3]; v[k][4] = p[4];
+                }
+                u32 x[4][8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[q][k] = __builtin_amdgcn_alignbit(v[k][q + 1], v[k][q], e[k]);   // (the instruction takes bits 4..0 of the entry)
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bs_level<0, 8>(c[q], x[q]);
+            }
+            if (f + 8 > first_test && f + 8 < Fw) {
+                const unsigned long long left = __ballot((c[0][7] & c[1][7] & c[2][7] & c[3][7]) != 0xFFFFFFFFu) & alive;
+                if (!left) pruned = true;
+                else { alive = left; act = ((left >> lane) & 1ull) != 0; }
+            }
+        }
+        st_f += (unsigned long long)(f < Fw ? f : Fw); st_F += (unsigned long long)Fw;
+        // survivors: positions never flagged (a dead or idle lane's flags are all ones)
+        u32 h[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = (pruned || !act) ? 0u : ~c[q][7];
+        const u32 nh = (u32)(__popc(h[0]) + __popc(h[1]) + __popc(h[2]) + __popc(h[3]));
+        if (nh && !a.no_exact) {
+            const u32 at = atomicAdd(qcount, nh);
+            if (at + nh <= a.queue_cap) {
+                u32* q = queue + at;
+                const u32 hi = ti << LM_SCANL_POS_BITS;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    for (u32 w = h[k]; w; w &= w - 1) *q++ = hi | (u32)(j0 + 32 * k + (__ffs((int)w) - 1));
+                h[0] = h[1] = h[2] = h[3] = 0;
+                st_s += nh;
+            } else {
+                atomicSub(qcount, nh);                                       // (give the reservation back: the wave takes these sums itself)
+            }
+        }
+        unsigned long long hl = a.no_exact ? 0ull : __ballot((h[0] | h[1] | h[2] | h[3]) != 0u);
+        while (hl) {
+            // queue full: the exact sum of one survivor at a time from the arena's spread bytes, lane k adds features k and k + 64 (k_scan1's fallback)
+            const int src = __ffsll((long long)hl) - 1;
+            const u32 w0 = (u32)__builtin_amdgcn_readlane((int)h[0], src), w1 = (u32)__builtin_amdgcn_readlane((int)h[1], src);
+            const u32 w2 = (u32)__builtin_amdgcn_readlane((int)h[2], src), w3 = (u32)__builtin_amdgcn_readlane((int)h[3], src);
+            const int q = w0 ? 0 : (w1 ? 1 : (w2 ? 2 : 3));
+            const u32 wq = w0 ? w0 : (w1 ? w1 : (w2 ? w2 : w3));
+            const int b = __ffs((int)wq) - 1;
+            const int j = __builtin_amdgcn_readlane(j0, src) + 32 * q + b;
+            const u32 sti = (u32)__builtin_amdgcn_readlane((int)ti, src);
+            const int sF = __builtin_amdgcn_readlane(F, src), sn = __builtin_amdgcn_readlane(n, src), sthr = __builtin_amdgcn_readlane(thr, src);
+            if (lane == src) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h[k] = (k == q) ? (h[k] & ~(1u << b)) : h[k];
+            }
+            const u32* o3 = a.offs3 + (size_t)sti * a.fpad1;
+            u32 vv = 0;
+            if (lane < sF) { const u32 on = o3[lane]; vv = (u32)((a.resp_tab[arena[(on & 0x1FFFFFFFu) + (u32)j]] >> (8u * (on >> 29))) & 0xFFu); }
+            if (lane + 64 < sF) { const u32 on = o3[lane + 64]; vv += (u32)((a.resp_tab[arena[(on & 0x1FFFFFFFu) + (u32)j]] >> (8u * (on >> 29))) & 0xFFu); }
+            const int raw = (int)wave_sum_u32(vv);
+            st_s += (lane == 0) ? 1u : 0u;
+            if (raw > sthr && lane == 0) scanl_emit(a, slot, sti, j, raw, sn);
+            hl = __ballot((h[0] | h[1] | h[2] | h[3]) != 0u);
+        }
+    }
+    if (a.stat) {
+        // per-lane partial counts of the survivors, per-wave counts of the rest (lane 0 holds them)
+        unsigned long long sv = st_s;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) sv += (unsigned long long)__shfl_xor((long long)sv, sft, 64);
+        if (lane == 0) {
+            atomicAdd(&a.stat[4 * (blockIdx.x & 1023u)], st_f);
+            atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 1], st_F);
+            atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 2], st_l);
+            atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 3], sv);
+        }
+    }
+    if (a.no_exact) return;
+    // ---- second stage: the frame's spread bytes take the planes' place, the survivors' exact sums come from LDS
+    __syncthreads();
+    const u32 qn = min(*qcount, a.queue_cap);
+    if (qn == 0) return;                                          // (workgroup-uniform)
+    {
+        const u32 per = (a.pb * 8u) >> 4, total = (u32)a.M * per;  // T*T*wh bytes per modality, at the start of its block
+        for (u32 i = (u32)tid; i < total; i += 1024u) {
+            const u32 m = i / per, k = i - m * per;
+            scanl_lds[i] = *reinterpret_cast<const u32x4*>(arena + (size_t)m * a.mod_stride + 16u * k);
+        }
+        if (tid < 256) reinterpret_cast<u64*>(lds + IMG)[tid] = a.resp_tab[tid];
+    }
+    __syncthreads();
+    const u8* tabs = lds + IMG;
+    for (u32 i = (u32)tid; i < qn; i += 1024u) {
+        const u32 e = queue[i];
+        const u32 ti = e >> LM_SCANL_POS_BITS, j = e & ((1u << LM_SCANL_POS_BITS) - 1u);
+        const int cnt = a.scan_n[ti];
+        const int n = cnt & 0xFF;
+        const int F = ((cnt >> 8) & 0xFF) + ((cnt >> 16) & 0xFF);
+        const int thr = a.raw_thr_by_n[n];
+        const u32* of = a.offsl + (size_t)ti * a.fpad1;
+        int raw = 0;
+        for (int f = 0; f < F; f += 8) {
+            u32 o[8], sv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = of[f + k];                                      // (the lists are padded to whole batches of eight)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sv[k] = lds[(o[k] & 0x1FFFFFFFu) + j];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) raw += (f + k < F) ? (int)tabs[sv[k] * 8u + (o[k] >> 29)] : 0;
+        }
+        if (raw > thr) scanl_emit(a, slot, ti, (int)j, raw, n);
+    }
+}
+
+
 __device__ __forceinline__ void emit_key(const LmRefineArgs& a, LmDevHeader* hdr, u64* keys, u32 ti, int x, int y,
                                          float sim) {
     u32 slot = atomicAdd(&hdr->match_count, 1u);
@@ -4243,6 +4469,17 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
     a.nslots = nslots;
     const int G = (a.n_items + 3) / 4;               // one wave per work item
     a.wgs_per_slot = G;
+    if (a.lds_form) {
+        // k_scanl: one 1024-thread workgroup = (frame, share of the templates), the frame's planes in ALL of the CU's LDS
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_scanl), hipFuncAttributeMaxDynamicSharedMemorySize, LM_SCANL_LDS_BYTES) != hipSuccess) { (void)hipGetLastError(); }
+            raised = true;
+        }
+        a.no_exact = (variant & 128) ? 1 : 0;
+        hipLaunchKernelGGL(k_scanl, dim3((unsigned)(nslots * a.R), 1, 1), dim3(1024), LM_SCANL_LDS_BYTES, s, a);
+        return;
+    }
     if (a.L1) {
         // k_scan1: a wave scans its item for a GROUP of G1 slots (XCD affinity per group when the group count allows)
         const int ngroups = (nslots + a.G1 - 1) / a.G1;

@@ -5,7 +5,7 @@ similarity table (the miss bound follows the table's largest response below 4)."
 import numpy as np
 import pytest
 
-from conftest import assert_matches_equal
+from conftest import assert_matches_equal, class_sublist
 
 pytestmark = pytest.mark.gpu
 
@@ -276,4 +276,95 @@ def test_scan_variants_that_change_the_lists_are_refused(lm, orc, synth):
     got, cnt = d.match_prepared(0, 8, 85.0, [-1], cap_per_frame=1 << 15)
     for k in range(8):
         assert_matches_equal(got[k, :cnt[k]], exp[k % 3])
+    d.close()
+
+
+# ---- r06: the bit-plane scan with a frame's planes in LDS (k_scanl, LM_TUNE_SCAN_FORM 3) ------------------------------------------------------
+@pytest.mark.parametrize("color_only,size,T,thr,fits", [
+    (False, (640, 480), [5, 8], 80.0, True),      # config 2's shape: 153 600 bytes of planes, the whole LDS; 8 units of 128 positions per template
+    (True, (640, 480), [2, 8], 85.0, True),       # one modality: half the image
+    (False, (384, 256), [4, 8], 75.0, True),      # 384 positions per memory: 3 units per template, 21 templates per wave
+    (False, (640, 480), [4, 4], 80.0, True),      # T = 4 at the scanned level: 4800 positions per memory, up to 38 units per template
+    (False, (640, 480), [5, 8], 97.0, True),
+    (False, (640, 480), [5, 8], 30.0, True),      # a flood of survivors: the LDS queue overflows, the waves take the sums themselves
+    (True, (1280, 960), [2, 8], 88.0, False),     # 307 200 bytes of planes: does not fit, form 3 runs k_scan1
+])
+def test_scanl_candidates_and_matches(lm, orc, synth, color_only, size, T, thr, fits):
+    nb = 9
+    d, o, frames = _setup(lm, orc, synth, color_only, size, T, 60, nb, seed=1900)
+    dep = lambda k: None if color_only else frames[k % len(frames)][1]
+    bgr = lambda k: frames[k % len(frames)][0]
+    exp_m = [o.match(bgr(k), dep(k), thr, threads=8, cap=1 << 18) for k in range(len(frames))]
+    o.prepare(bgr(0), dep(0))
+    exp_c = o.scan_candidates(thr, threads=8, cap=1 << 20)
+    d.set_tuning(lm.TUNE_SCAN_FORM, 3)
+    d.upload_frame(0, bgr(0), dep(0)); d.prepare_slot(0)
+    d.set_scan_stats(True)
+    assert np.array_equal(d.stage_scan(0, thr, cap=1 << 20), exp_c)
+    loaded, unpruned = d.get_scan_stats()
+    st = d.get_scan_form_stats()
+    assert 0 < loaded <= unpruned and (st[3] >= 1000) == fits and st[3] > 0, st
+    assert st[2] >= len(exp_c)                              # the survivors of the miss bound are a superset of the candidates
+    d.set_scan_stats(False)
+    # the linear memories lm_debug_read shows are the oracle's although the slot keeps spread bytes + planes only
+    for level in range(2):
+        for mod in range(1 if color_only else 2):
+            assert np.array_equal(d.debug_read(0, 2, level, mod), o.stage(2, level, mod))
+    for n in (1, 2, 5, nb):
+        for k in range(n):
+            d.upload_frame(k, bgr(k), dep(k))
+        before = d.get_scan_form_stats()
+        got, cnt = d.match_batch(n, thr, cap_per_frame=1 << 16)
+        after = d.get_scan_form_stats()
+        assert after[0] - before[0] == after[1] - before[1] >= 1 and (after[3] >= 1000) == fits
+        for k in range(n):
+            assert_matches_equal(got[k, :cnt[k]], exp_m[k % len(frames)])
+    # two lanes at once, and the prepared slots once more by the default rule (the slots keep no response memories: a bit-plane form either way)
+    d.match_begin(0, 0, 4, thr); d.match_begin(1, 4, 5, thr)
+    g0, c0 = d.match_end(0, 1 << 16, n_slots=4)
+    g1, c1 = d.match_end(1, 1 << 16, n_slots=5)
+    for k in range(4):
+        assert_matches_equal(g0[k, :c0[k]], exp_m[k % len(frames)])
+    for k in range(5):
+        assert_matches_equal(g1[k, :c1[k]], exp_m[(4 + k) % len(frames)])
+    d.close()
+
+
+def test_scanl_similarity_tables_and_class_ranges(lm, orc, synth):
+    """k_scanl with similarity tables whose misses cost 1, 2, 3 or 4 (the miss bound follows the table) and with a class list: the lane items
+    of a class range start at the class's first template."""
+    d, o, frames = _setup(lm, orc, synth, False, (640, 480), [5, 8], 50, 4, seed=1950)
+    bgr, dep = frames[0]
+    q = _quantized(o, bgr, dep, False)
+    for c in (1, 2):
+        descs, feats, _ = synth.make_bank(17 + 5 * c, 2, 2, seed=2000 + c, quantized=q, crop_fraction=0.4, frame_size=(640, 480), T0=5)
+        d.add_class("c%d" % c, descs, feats); o.add_class("c%d" % c, descs, feats)
+    d.set_tuning(lm.TUNE_SCAN_FORM, 3)
+    base = orc.similarity_lut()
+    tables = [base]
+    for lo, hi in ((3, 4), (2, 4), (0, 4), (1, 3)):
+        t = base.copy()
+        t[base == 1] = lo; t[base == 4] = hi
+        tables.append(t)
+    for t in tables:
+        d.set_similarity_lut(t); o.set_similarity_lut(t)
+        for thr in (70.0, 90.0):
+            for k in range(4):
+                d.upload_frame(k, bgr, dep)
+            got, cnt = d.match_batch_classes(0, 4, thr, [-1], cap_per_frame=1 << 16)
+            assert d.get_scan_form_stats()[3] >= 1000
+            exp = o.match(bgr, dep, thr, -1, threads=8, cap=1 << 18)
+            for k in range(4):
+                assert_matches_equal(got[k, :cnt[k]], exp)
+            per_class = [o.match(bgr, dep, thr, c, threads=8, cap=1 << 18) for c in range(3)]
+            for cls in ([1], [0, 2], [2]):
+                got, cnt = d.match_prepared(0, 4, thr, cls, cap_per_frame=1 << 16)
+                assert d.get_scan_form_stats()[3] >= 1000
+                for k in (0, 3):
+                    for c in cls:
+                        assert_matches_equal(class_sublist(got[k, :cnt[k]], c), per_class[c])
+            o.prepare(bgr, dep)
+            d.prepare_slot(0)
+            for ci in (-1, 0, 1, 2):
+                assert np.array_equal(d.stage_scan(0, thr, ci, cap=1 << 20), o.scan_candidates(thr, ci, threads=8, cap=1 << 20))
     d.close()
