@@ -372,7 +372,7 @@ int ensure_bank(lm_detector* d) {
     if (d->hb.lds_ok) {
         if ((rc = upload_vec(&d->d_offl, d->hb.offl))) return rc;
         if ((rc = upload_vec(&d->d_offsl, d->hb.offsl))) return rc;
-        if ((rc = upload_vec(&d->d_litem, d->hb.litem))) return rc;
+        if ((rc = upload_vec(&d->d_litem, d->hb.lrec))) return rc;      // (the lane items with their templates' records: 16 bytes each)
     }
     if ((rc = upload_vec(&d->d_t_global, d->hb.t_global))) return rc;
     if ((rc = upload_vec(&d->d_t_class, d->hb.t_class))) return rc;
@@ -603,6 +603,7 @@ int scan1_rule(const lm_detector* d, int nslots, bool forced) {
 int scanl_shares(const lm_detector* d, int nslots, int n_litems) {
     int R = (768 + nslots / 2) / std::max(nslots, 1);
     R = std::max(1, std::min(R, 16));
+    if (const char* ev = getenv("LM_SCANL_R")) R = std::max(1, atoi(ev));       // (experiments)
     const int n_w = (n_litems + 63) / 64;
     return std::max(1, std::min(R, n_w / 16));
 }
@@ -668,7 +669,7 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots = 1
     a.cand = reinterpret_cast<LmCand*>(d->aux(first, d->off_cand));
     a.aux_slot_stride = d->aux_stride;
     a.cand_cap = d->max_cand;
-    a.lds_form = 0; a.R = 1; a.offl = a.offsl = a.litem = nullptr; a.litem_lo = a.n_litems = 0; a.pb = a.mod_stride = a.planes_off = a.plane_ori = a.tbl_bytes = a.queue_cap = 0;
+    a.dbg = 0; a.lds_form = 0; a.R = 1; a.offl = a.offsl = a.litem = nullptr; a.litem_lo = a.n_litems = 0; a.pb = a.mod_stride = a.planes_off = a.plane_ori = a.tbl_bytes = a.queue_cap = 0;
     {
         const int lo = d->hb.lds_ok ? d->hb.lbegin[(size_t)r.t_lo] : 0, nl = d->hb.lds_ok ? d->hb.lbegin[(size_t)r.t_hi] - lo : 0;
         const int R = pick_scanl(d, first, nslots, nl);
@@ -678,7 +679,7 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots = 1
             a.pb = (u32)g.T * (u32)g.T * g.wh / 8u; a.mod_stride = g.mod_stride; a.planes_off = 8u * g.ori_stride; a.plane_ori = g.plane_ori;
             const u32 img = (u32)a.M * 8u * a.pb;
             a.tbl_bytes = std::max<u32>(LM_SCANL_TABLE_BYTES, (((g.wh + 127u) / 128u) * 16u + 32u + 15u) & ~15u);
-            a.queue_cap = std::min<u32>((LM_SCANL_LDS_BYTES - img - a.tbl_bytes - 16u) / 4u, 1u << 16);
+            a.queue_cap = std::min<u32>((LM_SCANL_LDS_BYTES - img - a.tbl_bytes - 16u - 512u) / 4u, 1u << 16);      // (16: queue header, 512: the raw thresholds)
             a.delta_rcp16 = (65536u + (u32)d->miss_delta - 1u) / (u32)d->miss_delta;
             a.fpad1 = d->hb.fpad1; a.exact_spread = 1; a.offs3 = d->d_offs3; a.resp_tab = d->d_resp_tab;
             return a;

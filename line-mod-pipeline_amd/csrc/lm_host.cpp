@@ -109,6 +109,7 @@ int Bank::add_class(const std::string& id, int n_templates, const lm_template_de
 //   refine (levels above the lowest, upstream similarityLocal()): the same offset for the
 //     unshifted feature plus (x, y) for the bounds test after the patch offset is applied.
 // ------------------------------------------------------------------------------------------------
+void schedule_lds_lists(DeviceBankHost& out);
 bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom* geom, DeviceBankHost& out,
                        int scan_list_order, std::string& err) {
     const int M = cfg.num_modalities, L = cfg.pyramid_levels;
@@ -144,6 +145,9 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
         shard_range((int)c.pyramids.size(), cfg.shard_rank, cfg.shard_size, &lo, &hi);
         out.class_t_lo[ci] = (int)out.t_global.size();
         out.class_item_lo[ci] = (int)out.item_t.size();
+        // (k_scanl: a class starts a fresh wave item, so that the lanes that meet in one LDS access are the same whichever classes a launch scans;
+        // the fillers are "no item")
+        if (out.lds_ok) while (out.litem.size() % 64u) out.litem.push_back(0xFFFFFFFFu);
         for (int tid = lo; tid < hi; ++tid) {
             const TemplatePyramid& tp = c.pyramids[tid];
             if ((int)tp.size() != L * M) { err = "template pyramid size mismatch"; return false; }
@@ -301,7 +305,67 @@ bool build_device_bank(const Bank& bank, const lm_config& cfg, const LmLevelGeom
         out.lbegin.push_back((int)out.litem.size());
         if (out.t_global.size() >= (1u << (32 - LM_SCANL_POS_BITS)) || out.litem.empty()) out.lds_ok = false;     // (the survivor entry's template field)
     }
+    if (out.lds_ok) {
+        schedule_lds_lists(out);
+        out.lrec.assign(out.litem.size() * 4u, 0u);
+        for (size_t i = 0; i < out.litem.size(); ++i) {
+            const u32 it = out.litem[i];
+            out.lrec[4 * i] = it;
+            if (it != 0xFFFFFFFFu) { out.lrec[4 * i + 1] = (u32)out.scan_n[it >> 8]; out.lrec[4 * i + 2] = (u32)out.scan_P[it >> 8]; }
+        }
+    }
     return true;
+}
+
+// r06: the ORDER of k_scanl's lists against LDS bank conflicts.  A lane reads the dwords D + 4 u + q of a feature's plane (D: the feature's first dword,
+// u: the lane's unit, q = 0..4), one ds_read_b32-sized access per q; the hardware serves 32 lanes per cycle from 32 banks.  The lanes of ONE template hit
+// the eight banks = (D + q) mod 4; two templates of a 32-lane group whose features have the same D mod 4 at the same step collide on all of them
+// (measured: 25 of 109 us per 96-frame launch of config 2 are conflict cycles; four templates at random residues serve an access in 2.1 cycles instead of
+// 1).  The sums do not depend on the order of a list, so every template's list is permuted -- greedily, first fit in its own (farthest-point) order -- such
+// that at each step its residue differs from those of the templates it shares a 32-lane group with.  Only the order of `offl` changes.
+void schedule_lds_lists(DeviceBankHost& out) {
+    const size_t nt = out.t_global.size();
+    const int fp = out.fpad1;
+    auto residue = [](u32 e) { return (int)(((e >> 8) >> 2) & 3u); };
+    std::vector<u32> tmp((size_t)fp);
+    std::vector<char> used((size_t)fp);
+    for (size_t t = 0; t < nt; ++t) {
+        const int lb = out.lbegin[t], le = out.lbegin[t + 1];
+        // lane items of template t: [lb, le) minus trailing fillers; none: nothing to schedule
+        int last = le;
+        while (last > lb && out.litem[(size_t)last - 1] == 0xFFFFFFFFu) --last;
+        if (last <= lb) continue;
+        const int g_first = lb / 32;
+        // neighbours: earlier templates with a lane in one of this template's groups (they are scheduled already)
+        std::vector<size_t> nb;
+        for (size_t p = t; p-- > 0 && nb.size() < 8;) {
+            int pl = out.lbegin[p + 1];
+            while (pl > out.lbegin[p] && out.litem[(size_t)pl - 1] == 0xFFFFFFFFu) --pl;
+            if (pl <= out.lbegin[p]) continue;
+            if ((pl - 1) / 32 < g_first) break;
+            nb.push_back(p);
+        }
+        if (nb.empty()) continue;
+        u32* list = out.offl.data() + t * (size_t)fp;
+        // the list's real entries = the template's in-bounds features (the padding, entries of the zero block, stays at the end)
+        const int cnt = out.scan_n[t];
+        const int nreal = std::min(fp, ((cnt >> 8) & 0xFF) + ((cnt >> 16) & 0xFF));
+        std::fill(used.begin(), used.end(), 0);
+        for (int k = 0; k < nreal; ++k) {
+            bool taken[4] = {false, false, false, false};
+            for (size_t p : nb) taken[residue(out.offl[p * (size_t)fp + (size_t)k])] = true;
+            int pick = -1, first = -1;
+            for (int q = 0; q < nreal; ++q) {
+                if (used[(size_t)q]) continue;
+                if (first < 0) first = q;
+                if (!taken[residue(list[q])]) { pick = q; break; }
+            }
+            if (pick < 0) pick = first;
+            used[(size_t)pick] = 1;
+            tmp[(size_t)k] = list[pick];
+        }
+        for (int k = 0; k < nreal; ++k) list[k] = tmp[(size_t)k];
+    }
 }
 
 void build_items1(const DeviceBankHost& hb, int L, std::vector<u32>& item_t, std::vector<u32>& item_chunk, std::vector<int>& begin) {

@@ -64,7 +64,8 @@ struct DeviceBankHost {
     bool lds_ok = false;
     std::vector<u32> offl;                         // [nt][fpad1] (LDS byte address of the dword holding the feature's first bit) << 8 | bit shift; pad: the zero block
     std::vector<u32> offsl;                        // [nt][fpad1] orientation << 29 | byte offset in the LDS image of the spread bytes [modality][T*T*wh]
-    std::vector<u32> litem;                        // lane items, template-major: template << 8 | unit of 128 positions
+    std::vector<u32> litem;                        // lane items, template-major: template << 8 | unit of 128 positions (0xFFFFFFFF: a filler)
+    std::vector<u32> lrec;                         // [n lane items][4] the same with the template's records: item, scan_n, scan_P, 0 -- ONE load per lane item
     std::vector<int> lbegin;                       // [nt + 1] first lane item of a bank-local template
 };
 // k_scan1's work items for L lanes per frame (chunks of 128 L - 31 positions), template-major like item_t / item_chunk; begin[t] =

@@ -80,13 +80,14 @@ struct LmScanArgs {
     int lds_form, R;          // R: workgroups per frame
     const u32* offl;          // [nt][fpad1] (LDS byte address of the feature's first dword) << 8 | bit shift
     const u32* offsl;         // [nt][fpad1] orientation << 29 | offset in the LDS image of the spread bytes
-    const u32* litem;         // lane items: template << 8 | unit of 128 positions
+    const u32* litem;         // lane items [.][4]: template << 8 | unit of 128 positions (0xFFFFFFFF: none), the template's scan_n, scan_P, 0
     int litem_lo, n_litems;   // the launch's lane items
     u32 pb;                   // bytes of one miss plane, T*T*wh / 8
     u32 mod_stride, planes_off, plane_ori;   // arena: modality block stride, offset of a block's planes (8 * ori_stride), stride between them
     u32 tbl_bytes;            // LDS behind the image: zeros during the first stage (the padded list entries of ANY unit read them: ceil(wh / 128) * 16 + 32 bytes
                               //    at least), the response table during the second; then 16 bytes of queue header and the queue
     u32 queue_cap;            // survivor entries the LDS queue holds
+    int dbg;                  // timing experiments of lm_time_scan_batch only (variant bits 9..11), WRONG lists: see k_scanl
 };
 // a11+a12+a13: similarity scan over the lowest level fused with the threshold scan.
 // variant selects the unroll depth of the feature loop (0: 8 loads in flight, 1: 4, 2: 2).

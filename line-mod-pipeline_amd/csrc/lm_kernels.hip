@@ -3050,6 +3050,7 @@ __device__ __forceinline__ void scanl_emit(const LmScanArgs& a, u32 sl, u32 ti, 
     }
 }
 
+__device__ __forceinline__ u32 tabs_at(const u8* lds, u32 img, u32 sv, u32 ori) { return lds[img + sv * 8u + ori]; }
 __global__ __launch_bounds__(1024) void k_scanl(LmScanArgs a) {
     extern __shared__ u32x4 scanl_lds[];
     u8* lds = reinterpret_cast<u8*>(scanl_lds);
@@ -3063,36 +3064,65 @@ __global__ __launch_bounds__(1024) void k_scanl(LmScanArgs a) {
     if (slot >= (u32)a.nslots) return;
     const u8* arena = a.lm + (size_t)slot * a.lm_slot_stride;
     const u32 IMG = (u32)a.M * 8u * a.pb;                    // bytes of the planes = of the spread bytes
+    // LDS behind the image: [tbl_bytes: zeros, later the response table][16: queue header][512: raw thresholds by feature count][queue]
     u32* qcount = reinterpret_cast<u32*>(lds + IMG + a.tbl_bytes);
-    u32* queue = qcount + 4;
-    // ---- the frame's planes -> LDS
+    const int* thr_tab = reinterpret_cast<const int*>(qcount + 4);
+    u32* queue = qcount + 4 + 128;
+    const u32 n_w = ((u32)a.n_litems + 63u) >> 6;
+    // share r owns the wave items r + R j.  A wave takes j = wave, then whatever comes next from a counter in LDS, ONE item ahead (its 16-byte record --
+    // item, feature counts, positions -- is requested as soon as the item is taken and arrives while the current item is counted): the waves of a workgroup
+    // finish within one item of each other (measured: static strides left a wave waiting 18 % of the workgroup's time at the barrier before the second
+    // stage, taking items two ahead 21 %).  The first item is requested before the planes are copied.
+    const unsigned long long tm0 = __builtin_readcyclecounter();
+    const u32 n_share = n_w > r ? (n_w - r + (u32)a.R - 1u) / (u32)a.R : 0u;
+    const u32x4 no_item = {0xFFFFFFFFu, 0u, 0u, 0u};
+    auto item_at = [&](u32 j) -> u32x4 {
+        const u32 idx = (r + (u32)a.R * j) * 64u + (u32)lane;
+        return (j < n_share && idx < (u32)a.n_litems) ? reinterpret_cast<const u32x4*>(a.litem)[(size_t)a.litem_lo + idx] : no_item;
+    };
+    u32 j_cur = (u32)wave;
+    u32x4 rec_cur = item_at(j_cur);
+    // ---- the frame's planes -> LDS: wave w copies plane w % (8 M) (16-byte pieces, the loads of a whole pass in flight before the stores)
     {
-        const u32 per = a.pb >> 4, total = (u32)a.M * 8u * per;
-        for (u32 i = (u32)tid; i < total; i += 1024u) {
-            const u32 pl = i / per, k = i - pl * per, m = pl >> 3, o = pl & 7u;
-            scanl_lds[i] = *reinterpret_cast<const u32x4*>(arena + (size_t)m * a.mod_stride + a.planes_off + (size_t)o * a.plane_ori + 16u * k);
+        const u32 per = a.pb >> 4, np = (u32)a.M * 8u, wpp = 16u / np;       // pieces per plane; planes; waves per plane (M = 1: 2, M = 2: 1)
+        const u32 pl = (u32)wave % np, part = (u32)wave / np, m = pl >> 3, o = pl & 7u;
+        const u8* src = arena + (size_t)m * a.mod_stride + a.planes_off + (size_t)o * a.plane_ori;
+        u32x4* dst = scanl_lds + (size_t)pl * per;
+        const u32 stride = 64u * wpp;
+        if (part < wpp && a.dbg != 3) {
+            // (a frame's workgroups run on one XCD at the same time: each starts its copy at another place, so that they do not queue at one L2 channel)
+            const u32 rot = (r * per) / (u32)a.R;
+            for (u32 k0 = (u32)lane + 64u * part; k0 < per; k0 += 8u * stride) {
+                u32x4 t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const u32 k = k0 + (u32)q * stride, kk = k + rot < per ? k + rot : k + rot - per; t[q] = k < per ? *reinterpret_cast<const u32x4*>(src + 16u * kk) : u32x4{0, 0, 0, 0}; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const u32 k = k0 + (u32)q * stride, kk = k + rot < per ? k + rot : k + rot - per; if (k < per) dst[kk] = t[q]; }
+            }
         }
         for (u32 i = (u32)tid; i < (a.tbl_bytes >> 2); i += 1024u) reinterpret_cast<u32*>(lds + IMG)[i] = 0u;     // the zero block of the padded list entries
-        if (tid == 0) *qcount = 0u;
+        if (tid < 128) const_cast<int*>(thr_tab)[tid] = a.raw_thr_by_n[tid];
+        if (tid == 0) { qcount[0] = 0u; qcount[1] = 16u; }                   // (queue length; next item of the share that no wave has taken)
     }
     __syncthreads();
-    const u32 n_w = ((u32)a.n_litems + 63u) >> 6;
+    const unsigned long long tm1 = __builtin_readcyclecounter();
     const __amdgpu_buffer_rsrc_t rs_off = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(a.offl), 0, 0x7FFFFFFF, 0x00020000);
     unsigned long long st_f = 0, st_F = 0, st_l = 0, st_s = 0;
-    for (u32 wi = r * 16u + (u32)wave; wi < n_w; wi += 16u * (u32)a.R) {
-        const u32 idx = wi * 64u + (u32)lane;
-        const bool has = idx < (u32)a.n_litems;
-        const u32 it = has ? a.litem[a.litem_lo + (int)idx] : 0u;
-        const u32 ti = it >> 8, unit = it & 255u;
-        const int cnt = has ? a.scan_n[ti] : 0;
+    for (; j_cur < n_share; ) {
+        // this item's record is in registers; the next item is taken now and its record arrives during the loop
+        const u32 it = rec_cur[0];
+        const int cnt = (int)rec_cur[1], P = (int)rec_cur[2];
+        j_cur = (u32)__builtin_amdgcn_readfirstlane((int)(lane == 0 ? atomicAdd(qcount + 1, 1u) : 0u));
+        rec_cur = item_at(j_cur);
+        const bool has = it != 0xFFFFFFFFu;
+        const u32 ti = has ? it >> 8 : 0u, unit = has ? it & 255u : 0u;
         const int n = cnt & 0xFF;
         const int F = ((cnt >> 8) & 0xFF) + ((cnt >> 16) & 0xFF);
-        const int thr = a.raw_thr_by_n[n];
+        const int thr = thr_tab[n & 127];
         const int K0 = 4 * F - thr - 1;                              // what the misses may cost in total
         int mmax = K0 >= 0 ? (int)(((u32)K0 * a.delta_rcp16) >> 16) : 0;
         if (mmax > 127) mmax = 127;
         const u32 pre = (u32)(127 - mmax);
-        const int P = has ? a.scan_P[ti] : 0;
         const int j0 = (int)unit * 128;
         int valid = (has && K0 >= 0) ? P - j0 : 0;
         valid = valid < 0 ? 0 : (valid > 128 ? 128 : valid);
@@ -3110,24 +3140,39 @@ __global__ __launch_bounds__(1024) void k_scanl(LmScanArgs a) {
             const int vq = valid - 32 * q;
             c[q][7] = vq >= 32 ? 0u : (vq > 0 ? ~((1u << vq) - 1u) : 0xFFFFFFFFu);      // invalid positions start dead
         }
-        const int Fw = (int)wave_max_u32(valid > 0 ? (u32)F : 0u);
-        const int first_test = 127 - (int)wave_max_u32(valid > 0 ? pre : 0u);            // the smallest miss budget of the wave: nothing dies before
+        // (wave-uniform, and told so: the round loop's bounds and the lists' scalar offsets hang on them)
+        const int Fw = __builtin_amdgcn_readfirstlane((int)wave_max_u32(valid > 0 ? (u32)F : 0u));
+        const int first_test = 127 - __builtin_amdgcn_readfirstlane((int)wave_max_u32(valid > 0 ? pre : 0u));            // the smallest miss budget of the wave: nothing dies before
         const u32 voff = ti * (u32)a.fpad1 * 4u;
         const u32 unit_add = (unit * 16u) << 8;
-        bool act = valid > 0, pruned = false;
+        const u32 keep5 = (j0 + 128 >= P || lane == 63) ? 0u : 0xFFFFFFFFu;
+        // EVERY lane reads and counts in every round, dead or not: the kernel is bound by vector issue, not by LDS cycles (measured: dropping a fifth of
+        // the LDS accesses changed nothing), and exec-masked rounds cost the compiler 43 moves + 20 selects per round to merge a skipped round's
+        // counters with a counted one's.  A dead lane's flags stay all ones (the flag bit is sticky), a lane without an item reads template 0's planes.
+        bool pruned = false;
         int f = 0;
+        // (the list entries of the NEXT round are requested before this round's LDS reads: a round's global round trip hides behind the round before it)
+        u32x4 n0 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, 0u, 0), n1 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, 16u, 0);
         for (; f < Fw && !pruned; f += 8) {
             st_l += 8u * (u32)__popcll(alive);
-            if (act) {
-                const u32x4 e0 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, (u32)f * 4u, 0);
-                const u32x4 e1 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, (u32)f * 4u + 16u, 0);
+            {
+                const u32x4 e0 = n0, e1 = n1;
+                // (past the last round: the same entries once more -- a branch here would bring the merges back)
+                const u32 nf = (u32)(f + 8 < Fw ? f + 8 : f) * 4u;
+                n0 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, nf, 0);
+                n1 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, nf + 16u, 0);
                 const u32 e[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
                 u32 v[8][5];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const u32* p = reinterpret_cast<const u32*>(lds + ((e[k] + unit_add) >> 8));
-                    v[k][0] = p[0]; v[k][1] = p[1]; v[k][2] = p[2]; v[k][3] = p[3]; v[k][4] = p[4];
+                    v[k][0] = p[0]; v[k][1] = p[1]; v[k][2] = p[2]; v[k][3] = p[3];
                 }
+                // the fifth dword is the next lane's first (the next unit of the same template) -- a DPP move instead of a fifth LDS access --
+                // except in a template's LAST unit, whose neighbour belongs to another template: there it counts as "no miss"
+                // for every feature.  That only weakens the bound of the unit's last positions (a few more survivors; the second stage decides).
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k][4] = next_lane(v[k][0]) & keep5;       // (an AND, not a select: the DPP move must run on the last units' lanes too -- they are its sources)
                 u32 x[4][8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -3140,14 +3185,14 @@ __global__ __launch_bounds__(1024) void k_scanl(LmScanArgs a) {
             if (f + 8 > first_test && f + 8 < Fw) {
                 const unsigned long long left = __ballot((c[0][7] & c[1][7] & c[2][7] & c[3][7]) != 0xFFFFFFFFu) & alive;
                 if (!left) pruned = true;
-                else { alive = left; act = ((left >> lane) & 1ull) != 0; }
+                else alive = left;
             }
         }
         st_f += (unsigned long long)(f < Fw ? f : Fw); st_F += (unsigned long long)Fw;
         // survivors: positions never flagged (a dead or idle lane's flags are all ones)
         u32 h[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) h[q] = (pruned || !act) ? 0u : ~c[q][7];
+        for (int q = 0; q < 4; ++q) h[q] = (pruned || !((alive >> lane) & 1ull)) ? 0u : ~c[q][7];
         const u32 nh = (u32)(__popc(h[0]) + __popc(h[1]) + __popc(h[2]) + __popc(h[3]));
         if (nh && !a.no_exact) {
             const u32 at = atomicAdd(qcount, nh);
@@ -3189,7 +3234,8 @@ __global__ __launch_bounds__(1024) void k_scanl(LmScanArgs a) {
             hl = __ballot((h[0] | h[1] | h[2] | h[3]) != 0u);
         }
     }
-    if (a.stat) {
+    const unsigned long long tm2 = __builtin_readcyclecounter();
+    if (a.stat && a.dbg != 7) {
         // per-lane partial counts of the survivors, per-wave counts of the rest (lane 0 holds them)
         unsigned long long sv = st_s;
 #pragma unroll
@@ -3204,37 +3250,77 @@ __global__ __launch_bounds__(1024) void k_scanl(LmScanArgs a) {
     if (a.no_exact) return;
     // ---- second stage: the frame's spread bytes take the planes' place, the survivors' exact sums come from LDS
     __syncthreads();
+    const unsigned long long tm3 = __builtin_readcyclecounter();
     const u32 qn = min(*qcount, a.queue_cap);
     if (qn == 0) return;                                          // (workgroup-uniform)
+    // a LANE takes a survivor.  All 64 entries of its template's list are requested at once (sixteen 16-byte loads in flight) and BEFORE the spread
+    // bytes are copied: the one global round trip of the stage hides behind the copy; the 2 x 62 byte gathers per survivor are LDS accesses.  (A wave per
+    // survivor -- lane k takes feature k, a DPP sum -- measured 30 % slower: 20 dependent chains of LDS reads and cross-lane sums per wave.)
+    const u32 F_MASK = 0x1FFFFFFFu;
+    u32x4 ent[16];
+    u32 e_cur = 0xFFFFFFFFu;
+    int cn_cur = 0;
+    auto request = [&](u32 i, int half) {
+        e_cur = i < qn ? queue[i] : 0xFFFFFFFFu;
+        const u32 ti = e_cur >> LM_SCANL_POS_BITS;
+        if (e_cur != 0xFFFFFFFFu) {
+            cn_cur = a.scan_n[ti];
+            const u32x4* of = reinterpret_cast<const u32x4*>(a.offsl + (size_t)ti * a.fpad1) + 16 * half;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) ent[q] = (64 * half + 4 * q < a.fpad1) ? of[q] : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto partial = [&](int F, u32 j, int half) -> int {
+        int raw = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const u32 o = ent[q][c4];
+                if (64 * half + 4 * q + c4 < F) raw += (int)tabs_at(lds, IMG, (u32)lds[(o & F_MASK) + j], o >> 29);
+            }
+        }
+        return raw;
+    };
+    u32 i0 = (u32)tid;
+    request(i0, 0);
     {
-        const u32 per = (a.pb * 8u) >> 4, total = (u32)a.M * per;  // T*T*wh bytes per modality, at the start of its block
-        for (u32 i = (u32)tid; i < total; i += 1024u) {
-            const u32 m = i / per, k = i - m * per;
-            scanl_lds[i] = *reinterpret_cast<const u32x4*>(arena + (size_t)m * a.mod_stride + 16u * k);
+        const u32 per = (a.pb * 8u) >> 4;                          // 16-byte pieces of a modality's spread bytes (T*T*wh, at the start of its block)
+        for (int m = 0; m < (a.dbg == 2 ? 0 : a.M); ++m) {
+            const u8* src = arena + (size_t)m * a.mod_stride;
+            u32x4* dst = scanl_lds + (size_t)m * per;
+            const u32 rot = (r * per) / (u32)a.R;
+            for (u32 k0 = (u32)tid; k0 < per; k0 += 4u * 1024u) {
+                u32x4 t[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const u32 k = k0 + (u32)q * 1024u, kk = k + rot < per ? k + rot : k + rot - per; t[q] = k < per ? *reinterpret_cast<const u32x4*>(src + 16u * kk) : u32x4{0, 0, 0, 0}; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const u32 k = k0 + (u32)q * 1024u, kk = k + rot < per ? k + rot : k + rot - per; if (k < per) dst[kk] = t[q]; }
+            }
         }
         if (tid < 256) reinterpret_cast<u64*>(lds + IMG)[tid] = a.resp_tab[tid];
     }
     __syncthreads();
-    const u8* tabs = lds + IMG;
-    for (u32 i = (u32)tid; i < qn; i += 1024u) {
-        const u32 e = queue[i];
+    const unsigned long long tm4 = __builtin_readcyclecounter();
+    if (a.dbg == 1) return;
+    for (; i0 < qn; ) {
+        const u32 e = e_cur;
         const u32 ti = e >> LM_SCANL_POS_BITS, j = e & ((1u << LM_SCANL_POS_BITS) - 1u);
-        const int cnt = a.scan_n[ti];
-        const int n = cnt & 0xFF;
-        const int F = ((cnt >> 8) & 0xFF) + ((cnt >> 16) & 0xFF);
-        const int thr = a.raw_thr_by_n[n];
-        const u32* of = a.offsl + (size_t)ti * a.fpad1;
-        int raw = 0;
-        for (int f = 0; f < F; f += 8) {
-            u32 o[8], sv[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = of[f + k];                                      // (the lists are padded to whole batches of eight)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) sv[k] = lds[(o[k] & 0x1FFFFFFFu) + j];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) raw += (f + k < F) ? (int)tabs[sv[k] * 8u + (o[k] >> 29)] : 0;
-        }
-        if (raw > thr) scanl_emit(a, slot, ti, (int)j, raw, n);
+        const int n = cn_cur & 0xFF;
+        const int F = ((cn_cur >> 8) & 0xFF) + ((cn_cur >> 16) & 0xFF);
+        int raw = partial(F, j, 0);
+        if (F > 64) { request(i0, 1); raw += partial(F, j, 1); }       // (more than 64 in-bounds features: the second half of the list)
+        if (raw > thr_tab[n & 127]) scanl_emit(a, slot, ti, (int)j, raw, n);
+        i0 += 1024u;
+        if (i0 < qn) request(i0, 0);
+    }
+    if (a.stat && a.dbg == 7 && lane == 0) {
+        // timing experiment: reference-clock ticks of the phases, per wave: planes copy, counting, wait for the other waves, spread copy, exact sums
+        const unsigned long long tm5 = __builtin_readcyclecounter();
+        atomicAdd(&a.stat[4 * (blockIdx.x & 1023u)], tm1 - tm0);
+        atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 1], tm2 - tm1);
+        atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 2], (tm3 - tm2) + ((tm4 - tm3) << 32));
+        atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 3], tm5 - tm4);
     }
 }
 
@@ -4477,6 +4563,7 @@ void lmk_scan(hipStream_t s, const LmScanArgs& a_in, int variant, int nslots) {
             raised = true;
         }
         a.no_exact = (variant & 128) ? 1 : 0;
+        a.dbg = (variant >> 9) & 7;
         hipLaunchKernelGGL(k_scanl, dim3((unsigned)(nslots * a.R), 1, 1), dim3(1024), LM_SCANL_LDS_BYTES, s, a);
         return;
     }

@@ -33,7 +33,7 @@ for form in (1, 2, 3):
         kept = d.get_scan_stats(); lanes = d.get_scan_lane_stats(); fs = d.get_scan_form_stats()
         d.set_scan_stats(False)
         res = {}
-        for v in ((0,) if form == 1 else (0, 128)):
+        for v in ((0,) if form == 1 else (0, 128) if form == 2 else (0, 128, 512, 1024, 128 | 1536, 128 | 2048)):
             res[v] = min(d.time_scan_batch(0, n, thr, iters=20, variant=v) for _ in range(3))
         print("config %d form %d n %3d L1 %2d | scan %s us per launch = %s us per frame | kept %.3f lanes %.3f | survivors/frame %.0f | matches0 %d" % (
             cfgn, form, n, st[3], {k: round(v, 1) for k, v in res.items()}, {k: round(v / n, 3) for k, v in res.items()},
