@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 L2_PEAK_GBS = 34500.0     # MI355X_MICROARCH.md, "L2 (per XCD)": ~34.5 TB/s aggregate
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+LDS_B32_PEAK_GBS = 75000.0  # MI355X_MICROARCH.md, "LDS": aggregate rate of ds_read_b32-sized reads with every CU streaming (~75 TB/s; b64 / b128: ~150 TB/s)
 PCIE_PEAK_GBS = 63.0      # MI355X_MICROARCH.md, "Host link": PCIe Gen5 x16, 63 GB/s (spec)
 
 CONFIGS = {
@@ -428,7 +429,7 @@ def main():
     ap.add_argument("--no-blur-pyr", action="store_true", help="A/B knob: level-0 blur and pyrDown as two launches (LM_TUNE_BLUR_PYR = 0)")
     ap.add_argument("--sort-split", type=int, default=-1, choices=(-1, 0, 1, 2), help="A/B knob: LM_TUNE_SORT_SPLIT (0 one workgroup per frame, 1 chunk workgroups + merge launch, 2 adaptive = default)")
     ap.add_argument("--scan-list-order", type=int, default=-1, choices=(-1, 0, 1, 2, 3), help="A/B knob: LM_TUNE_SCAN_LIST_ORDER (0 ascending offsets, 1 round-robin over orientations, 2 descending, 3 farthest-point = default)")
-    ap.add_argument("--scan-form", type=int, default=-1, choices=(-1, 0, 1, 2), help="A/B knob: LM_TUNE_SCAN_FORM (0 by cost = default, 1 the nibble scan k_scan4, 2 the bit-plane scan k_scan1)")
+    ap.add_argument("--scan-form", type=int, default=-1, choices=(-1, 0, 1, 2, 3), help="A/B knob: LM_TUNE_SCAN_FORM (0 by cost = default, 1 the nibble scan k_scan4, 2 the bit-plane scan k_scan1)")
     ap.add_argument("--no-work-weight", action="store_true", help="A/B knob: few-frame / batch kernel selection by frame count alone (LM_TUNE_WORK_WEIGHT = 0, r03)")
     ap.add_argument("--no-pose-e2e", action="store_true", help="config 5: skip the pose_e2e leg (PoseDetection::detectBatch end to end, tools/pose_e2e_bench.cpp)")
     ap.add_argument("--pose-e2e-iters", type=int, default=20)
@@ -573,7 +574,10 @@ def main():
         n_matches0 = rep["matches0"]
 
     # ---- roofline of the dominant kernel (similarity scan)
-    kernel = "k_scan1" if one_lane.get("scan1_lanes_per_frame") else ("k_scan4" if not args.byte_responses else "k_scan")
+    lanes1 = one_lane.get("scan1_lanes_per_frame") or 0
+    # (lm_get_scan_form_stats: 0 = the nibble scan k_scan4, 1..64 = lanes per frame of the bit-plane scan k_scan1, 1000 + shares per frame = the bit-plane scan
+    # with a frame's planes in LDS, k_scanl)
+    kernel = "k_scanl" if lanes1 >= 1000 else "k_scan1" if lanes1 else ("k_scan4" if not args.byte_responses else "k_scan")
     runner.scan_kernel_name = kernel
     kept = one_lane.get("features_loaded_fraction", 1.0)
     kept_lanes = one_lane.get("lane_loads_fraction", kept)
@@ -596,9 +600,10 @@ def main():
         return nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
 
     wl_cfg = CONFIGS[args.config]
+    first_peak = LDS_B32_PEAK_GBS if kernel == "k_scanl" else L2_PEAK_GBS
     roofline = {
-        "bound": "l2", "achieved": round(rate(l2_bytes, ol_us), 1), "peak": L2_PEAK_GBS, "unit": "GB/s",
-        "frac": round(rate(l2_bytes, ol_us) / L2_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "bound": "lds" if kernel == "k_scanl" else "l2", "achieved": round(rate(l2_bytes, ol_us), 1), "peak": first_peak, "unit": "GB/s",
+        "frac": round(rate(l2_bytes, ol_us) / first_peak, 4), "traffic": traffic, "traffic_source": traffic_src,
         "kernel": kernel, "avg_launch_us": round(ol_us, 2), "frames_per_launch": Bl, "load_bytes_per_launch": l2_bytes,
         "pruning": {"enabled": not args.no_prune and not args.byte_responses, "feature_loads_kept": round(kept, 4),
                     "lane_loads_kept": round(kept_lanes, 4),
@@ -648,7 +653,7 @@ def main():
                     "TCC_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None}
 
         lc = from_counters(kernel, ol_us)
-        if lc and not args.no_prune and not args.scan_variant:
+        if lc and not args.no_prune and not args.scan_variant and kernel != "k_scanl":      # (k_scanl reads its planes from LDS: the L2 -> L1 rate says nothing about it)
             # The line's headline fraction comes from COUNTERS when a committed pass of this very command exists: L1 -> L2 read
             # requests x the calibrated request size (128 B: a request moves a whole line) over this run's clean launch
             # duration.  The r02 model -- bytes the loads NAME, 16 B per active lane -- stays beside it as `load_model`.
@@ -664,20 +669,30 @@ def main():
                                "duration (HIP events)" % Bl})
             roofline["l2_counters"] = lc
         sq = next((v for k, v in l2c["kernels"].items() if kernel_is(k, kernel) and v.get("SQ_ACTIVE_INST_VALU") and v.get("GRBM_GUI_ACTIVE") and v.get("avg_us")), None)
-        if kernel == "k_scan1" and sq and not args.no_prune and not args.scan_variant:
+        if kernel in ("k_scan1", "k_scanl") and sq and not args.no_prune and not args.scan_variant:
             # the bit-plane scan moves a quarter of k_scan4's bytes per position and feature: its binding roof is the vector issue rate.  VALU-active
             # SIMD cycles (SQ_ACTIVE_INST_VALU x 4, counter file of this command) over THIS run's clean scan time -- which contains the survivors'
             # exact sums (k_scan1_exact) -- against 1024 SIMDs x the shader clock under load (GRBM_GUI_ACTIVE of the kernel / 8 XCDs / its duration)
             inst = max(sq.get("GRBM_GUI_ACTIVE_instances", 1), 1)
             clock_ghz = sq["GRBM_GUI_ACTIVE"] / (8.0 if inst == 1 else inst) / sq["avg_us"] / 1e3
             ach = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (ol_us * 1e3)                  # G SIMD-cycles per second
-            roofline["l2_rate"] = {"achieved": roofline["achieved"], "peak": L2_PEAK_GBS, "frac": roofline["frac"], "unit": "GB/s"}
+            if kernel == "k_scanl":
+                roofline["lds_rate"] = {"achieved": roofline["achieved"], "peak": LDS_B32_PEAK_GBS, "frac": roofline["frac"], "unit": "GB/s",
+                                        "note": "bytes the counting loop reads from LDS (16 per lane and feature: two ds_read2_b32; the fifth dword is a DPP move) over the clean "
+                                                "time of the whole scan launch, against the guide's aggregate rate of 4-byte LDS reads (75 TB/s)"}
+            else:
+                roofline["l2_rate"] = {"achieved": roofline["achieved"], "peak": L2_PEAK_GBS, "frac": roofline["frac"], "unit": "GB/s"}
             roofline.update({"bound": "valu", "achieved": round(ach, 1), "peak": round(N_SIMD * clock_ghz, 1), "unit": "G SIMD-cycles/s",
                              "frac": round(ach / (N_SIMD * clock_ghz), 4),
                              "valu": {"SQ_ACTIVE_INST_VALU_per_launch": sq["SQ_ACTIVE_INST_VALU"], "SQ_INSTS_VALU_per_launch": sq.get("SQ_INSTS_VALU"),
                                       "shader_clock_GHz_under_load": round(clock_ghz, 3), "kernel_avg_us_in_counter_file": sq["avg_us"],
                                       "source": l2c["source"],
-                                      "note": "k_scan1 counts misses on one bit per position and orientation: its vector loads ask the L2 for a fraction of "
+                                      "note": ("k_scanl counts misses on one bit per position and orientation from planes held in LDS (lds_rate beside this) and "
+                                               "takes the survivors' exact sums from LDS in the same launch; the counting loop is bound by vector issue -- the "
+                                               "carry-save adders of the bit-sliced counters and the shift-undo; frac = share of the chip's SIMD cycles in which "
+                                               "a vector instruction executes, over the clean time of the whole launch (copies, barriers and second stage included)")
+                                      if kernel == "k_scanl" else
+                                              "k_scan1 counts misses on one bit per position and orientation: its vector loads ask the L2 for a fraction of "
                                               "what k_scan4's do (l2_rate beside this), and the kernel is bound by vector issue -- the carry-save adders of "
                                               "the bit-sliced counters and the shift-undo; frac = share of the chip's SIMD cycles in which a vector "
                                               "instruction executes, over the clean time of the whole scan stage"}})
@@ -771,6 +786,13 @@ def why_l2(runner, wl, traffic, alg_bytes, ctr, kernel):
            "a wave scans two frames, an XCD works on one slot pair at a time: %.2f MB + %.2f MB of bank offsets against a 4 MB L2 per XCD"
            % (lm_bytes / 1e6, M, W1, H1, 2 * lm_bytes / 1e6, bank / 1e6))
     fits = 2 * lm_bytes + bank <= 4.0e6
+    if kernel == "k_scanl":
+        planes = M * 8 * W1 * H1 // 8
+        msg = ("bit-plane scan with the planes in LDS: a 1024-thread workgroup copies ONE frame's %.1f KB of miss planes (%d modalities x 8 orientations x %d x %d positions "
+               "/ 8) into its CU's 160 KB of LDS and counts misses from there, then replaces them by the frame's %.1f KB of spread bytes and takes the survivors' exact sums "
+               "from LDS as well -- the loop reads nothing from L2 but the templates' feature lists; the binding roof is vector issue (valu), the LDS read rate is reported "
+               "as lds_rate" % (planes / 1e3, M, W1, H1, M * W1 * H1 / 1e3))
+        fits = True
     if kernel == "k_scan1":
         planes = M * 8 * W1 * H1 // 8
         msg = ("bit-plane scan: the scanned level per frame is %.2f MB of miss planes (%d modalities x 8 orientations x %d x %d positions / 8) next to the "
@@ -785,7 +807,7 @@ def why_l2(runner, wl, traffic, alg_bytes, ctr, kernel):
             if kernel_is(k, kernel) and v.get("TCC_HIT_sum") is not None and v.get("TCC_MISS_sum") is not None and v["TCC_HIT_sum"] + v["TCC_MISS_sum"] > 0:
                 hit = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
                 msg += ", measured L2 hit rate %.1f %%" % (100.0 * hit)
-    if kernel == "k_scan1":
+    if kernel in ("k_scan1", "k_scanl"):
         pass
     elif fits:
         msg += ("; the working set fits the L2, so the kernel is bound by what its vector loads request from the L2s against the guide's 34.5 TB/s "

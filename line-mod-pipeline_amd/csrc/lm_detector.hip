@@ -182,7 +182,7 @@ struct lm_detector {
     u32* d_offs3 = nullptr;          // [nt][fpad1] orientation << 29 | spread-memory offset of the bit-plane scan's features
     // r06, the bit-plane scan with a frame's planes in LDS (k_scanl; hb.lds_ok): the lists in the LDS image's layout and the lane items
     u32* d_offl = nullptr; u32* d_offsl = nullptr; u32* d_litem = nullptr;
-    int scanl_min_slots = 16;        // by cost (LM_TUNE_SCAN_FORM 0) from this many frames per call
+    int scanl_min_slots = 24;        // by cost (LM_TUNE_SCAN_FORM 0) from this many frames per call (measured: 16 frames 35.5 us against k_scan4's 35.3, 32 frames 43.4 against 57.5)
     unsigned long long* d_surv[LM_NLANES] = {};      // k_scan1's survivor queues, one per lane, allocated on a lane's first bit-plane scan
     int surv_set[LM_NLANES] = {};                    // which of a queue's two counter sets the lane's next scan launch uses (the other is zeroed behind it)
     u32 surv_cap = 1u << 20;
@@ -597,15 +597,23 @@ int scan1_rule(const lm_detector* d, int nslots, bool forced) {
     return bestL;
 }
 
-// r06: the bit-plane scan with the frame's planes in LDS (k_scanl).  Workgroups per frame: about three rounds of the chip's 256 CUs (a workgroup
-// takes a CU's whole LDS), at most 16 per frame (every one copies the frame's planes and spread bytes: 300 KB), and no more than leave every
-// wave of a workgroup a work item.
+// r06: the bit-plane scan with the frame's planes in LDS (k_scanl).  Workgroups (shares of the lane items) per frame: a workgroup takes a CU's whole
+// LDS, so the chip runs 256 at a time; each pays a fixed price (the two copies of 150 KB, two barriers, the wait for its last wave: about 14 us)
+// plus about 10 us per wave item of its busiest wave.  Measured on config 2's workload (tools/probe_scanl_R.py, profiles/r06_ab_experiments.log):
+// the best share count fills ONE round of the chip up to 64 frames and two beyond (32 frames: 8 shares, 64: 4, 96: 5, 128: 4); below 4 shares
+// a workgroup's survivors no longer fit its LDS queue.  The model below reproduces those choices.
 int scanl_shares(const lm_detector* d, int nslots, int n_litems) {
-    int R = (768 + nslots / 2) / std::max(nslots, 1);
-    R = std::max(1, std::min(R, 16));
-    if (const char* ev = getenv("LM_SCANL_R")) R = std::max(1, atoi(ev));       // (experiments)
     const int n_w = (n_litems + 63) / 64;
-    return std::max(1, std::min(R, n_w / 16));
+    const int r_max = std::max(1, std::min(32, n_w / 16));        // (every wave of a workgroup gets an item)
+    const int r_min = std::min(4, r_max);
+    int best = r_min; double best_t = -1;
+    for (int R = r_min; R <= r_max; ++R) {
+        const double x = (double)nslots * R / 256.0, rounds = std::max(1.0, 0.7 * std::ceil(x) + 0.3 * x);
+        const double t = rounds * (14.2 + 9.8 * ((n_w + 16 * R - 1) / (16 * R)));
+        if (best_t < 0 || t < best_t - 1e-9) { best_t = t; best = R; }
+    }
+    if (const char* ev = getenv("LM_SCANL_R")) best = std::max(1, atoi(ev));       // (experiments)
+    return best;
 }
 // ... by cost (LM_TUNE_SCAN_FORM 0): where a frame's planes fit LDS, for calls of enough frames to fill the chip with such workgroups, at thresholds
 // at which the miss bound bites.  Returns the shares per frame, 0 = another form.  (LM_TUNE_SCAN_FORM 3 asks for it wherever it can run.)

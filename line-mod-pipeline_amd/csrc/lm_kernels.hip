@@ -3154,7 +3154,7 @@ __global__ __launch_bounds__(1024) void k_scanl(LmScanArgs a) {
         // (the list entries of the NEXT round are requested before this round's LDS reads: a round's global round trip hides behind the round before it)
         u32x4 n0 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, 0u, 0), n1 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, 16u, 0);
         for (; f < Fw && !pruned; f += 8) {
-            st_l += 8u * (u32)__popcll(alive);
+            st_l += 8u * 64u;                                   // (every lane reads: see above)
             {
                 const u32x4 e0 = n0, e1 = n1;
                 // (past the last round: the same entries once more -- a branch here would bring the merges back)

@@ -84,7 +84,7 @@ while time.time() - t0 < budget:
     thr = float(rng.choice([60.0, 75.0, 85.0, 40.0]))
     variant = int(rng.choice([0, 0, 32, 8, 1, 34, 9, 16, 17, 18]))   # load-block sizes; per-lane pruning (default), none (bit 3), wave-level (bit 4)
     d.set_scan_variant(variant)
-    d.set_tuning(lm.TUNE_SCAN_FORM, int(rng.choice([0, 1, 2, 2])))        # r05: nibble scan / bit-plane scan (by cost, forced either way)
+    d.set_tuning(lm.TUNE_SCAN_FORM, int(rng.choice([0, 1, 2, 3, 3])))        # r05 / r06: nibble scan / bit-plane scan / bit-plane scan with the planes in LDS (by cost, forced)
     got = d.match(bgr, None if color_only else depth, thr, cap=1 << 18)
     exp = o.match(bgr, None if color_only else depth, thr, threads=8, cap=1 << 18)
     assert got.tobytes() == exp.tobytes(), ("match", color_only, T, w, h, n, thr, variant, len(got), len(exp))
@@ -94,7 +94,7 @@ while time.time() - t0 < budget:
         d.set_tuning(lm.TUNE_BLUR_PYR, int(rng.choice([0, 1, 2, 3])))         # level-0 blur + pyrDown apart, in one launch back to back, or dealt out evenly
         d.set_tuning(lm.TUNE_BLUR_STRIP, int(rng.choice([0, 16, 32, 64])))      # rows per blur strip inside k_blur_pyr
         d.set_tuning(lm.TUNE_SCAN_LIST_ORDER, int(rng.choice([0, 1, 2, 3])))    # order of the scan's feature lists (same sums)
-        d.set_tuning(lm.TUNE_SCAN_FORM, int(rng.choice([0, 1, 2, 2])))
+        d.set_tuning(lm.TUNE_SCAN_FORM, int(rng.choice([0, 1, 2, 3, 3])))
         # r05: every way a frame reaches a slot -- the one-call upload, the staged upload (rows in random pieces; a zero shift here, the
         # shifted forms are swept in tests/test_gpu_stream.py) -- and the lists once more through lm_match_collect
         staged = bool(rng.integers(0, 2))

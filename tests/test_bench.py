@@ -74,6 +74,20 @@ def test_bench_accepts_its_line_on_the_timed_buffers(config, batch):
 
 
 @pytest.mark.gpu
+def test_bench_config2_default_takes_the_lds_scan():
+    """r06: config 2's lane-steps (640x480 RGB-D, 32 frames here) take the bit-plane scan with the planes in LDS by the default cost rule; the line names
+    the kernel, prices it against the LDS read rate (no counter file matches this small command) and is accepted on the timed buffers."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "2", "--steps", "4", "--warmup", "1", "--batch", "64",
+                        "--lanes", "2", "--templates", "600", "--no-h2d", "--no-latency", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    rf = d["roofline"]
+    assert rf["kernel"] == "k_scanl" and rf["bound"] in ("lds", "valu") and rf["scan1_lanes_per_frame"] >= 1000 and 0 < rf["frac"] < 1
+    assert "error" not in d["cpu_baseline"] and "k_scanl" in d["cpu_baseline"]["sample"]
+
+
+@pytest.mark.gpu
 def test_bench_rccl_single_rank_communicator():
     """The whole gathered path (k_pack_lists, 2 x ncclAllGather per lane-step, merge of the owned frames) through a
     single-rank RCCL communicator: what a 1-GPU box can run of the N > 1 path."""

@@ -244,9 +244,21 @@ def test_config2_batch_of_96_frames_at_stated_size(lm, orc, synth, fixed):
                                           crop_fraction=0.1, frame_size=(W, H), T0=d.get_T(0))
     d.add_class("synthetic.ply", descs, feats)
     o.add_class("synthetic.ply", descs, feats)
-    _check_batch(lm, d, o, frames, M, 80.0, NB, None)
+    _check_batch(lm, d, o, frames, M, 80.0, NB, True)                 # r06: by cost the bit-plane scan with the planes in LDS (k_scanl) ...
+    assert d.get_scan_form_stats()[3] >= 1000                          # ... also for the 48-frame lanes
     d.set_tuning(lm.TUNE_SCAN_FORM, 1)
     _check_batch(lm, d, o, frames, M, 80.0, NB, False)
     d.set_tuning(lm.TUNE_SCAN_FORM, 2)
     _check_batch(lm, d, o, frames, M, 80.0, NB, True)
+    assert 0 < d.get_scan_form_stats()[3] < 1000                       # k_scan1
+    d.set_tuning(lm.TUNE_SCAN_FORM, 3)
+    _check_batch(lm, d, o, frames[:2], M, 65.0, NB, True, cap=1 << 16)
+    assert d.get_scan_form_stats()[3] >= 1000
+    # a11-a13 alone, the candidate list of k_scanl record by record
+    for k, thr in ((0, 80.0), (3, 80.0), (1, 65.0)):
+        d.upload_frame(k, frames[k][0], frames[k][1])
+        d.prepare_slot(k)
+        o.prepare(frames[k][0], frames[k][1])
+        assert np.array_equal(d.stage_scan(k, thr, 0), o.scan_candidates(thr, 0, threads=THREADS))
+        assert d.get_scan_form_stats()[3] >= 1000
     d.close()

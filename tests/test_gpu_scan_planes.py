@@ -202,7 +202,7 @@ def test_scan_form_by_cost_and_key_validation(lm, orc, synth):
     d.set_tuning(lm.TUNE_SCAN1_MIN_THRESHOLD, 40)
     d.match_batch(16, 48.0, cap_per_frame=1 << 15)
     assert d.get_scan_form_stats()[3] > 0
-    for key, bad in ((lm.TUNE_SCAN_FORM, -1), (lm.TUNE_SCAN_FORM, 3), (lm.TUNE_SCAN1_MIN_THRESHOLD, 101), (lm.TUNE_SCAN1_MIN_THRESHOLD, -1)):
+    for key, bad in ((lm.TUNE_SCAN_FORM, -1), (lm.TUNE_SCAN_FORM, 4), (lm.TUNE_SCAN1_MIN_THRESHOLD, 101), (lm.TUNE_SCAN1_MIN_THRESHOLD, -1)):
         with pytest.raises(lm.LinemodError):
             d.set_tuning(key, bad)
     d.match_begin(0, 0, 8, 85.0)
