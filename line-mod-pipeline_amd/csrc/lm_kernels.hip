@@ -3607,6 +3607,12 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
     u32 s01[2] = {0, 0}, s23[2] = {0, 0};
     const int dcol = bx[1] - bx[0];                                   // wave-uniform
     const bool same_rows = by[0] == by[1] && dcol >= 0 && dcol <= 4;
+    // r06: refine_one's exact pruning for the pair: every 16 features the wave takes each candidate's best partial sum of its
+    // patch; a candidate whose (best + 4 x features to come) * 100 / (4 n) stays below the threshold -- the final test's own float expression --
+    // is out.  Both out: the pair stops.  One out: the other is finished alone (refine_one from its first feature: at most the features loaded so
+    // far are read twice, a candidate that dies does so after a quarter of its list on average).
+    int f_left = mt.nfeat_total;
+    const float denom = (float)(4 * mt.nfeat_total);
     for (int m = 0; m < a.M; ++m) {
         // (selects, not mt.count[m]: a runtime index into the struct copy would put it into scratch memory)
         const int cnt = (int)(m == 0 ? mt.count[0] : mt.count[1]);
@@ -3658,6 +3664,23 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
             for (int k = 0; k < RP_BATCH; ++k)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) { s01[c] += q01[c][k]; s23[c] += q23[c][k]; }
+            f_left -= min(RP_BATCH, cnt - f);
+            if (PRUNE_REFINE && (f & RP_BATCH) && f_left > 0) {       // every second batch
+                bool out[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const u32 mx = pk_max_u16(s01[c], s23[c]);
+                    const u32 best_now = wave_max_u32(max(mx & 0xFFFFu, mx >> 16));
+                    out[c] = __fdiv_rn(__fmul_rn((float)(int)(best_now + 4u * (u32)f_left), 100.f), denom) < a.threshold;
+                }
+                if (out[0] || out[1]) {
+                    if (out[0] && lane == 0) cand[i].ti = LM_DROPPED;
+                    if (out[1] && lane == 0) cand[i + 1].ti = LM_DROPPED;
+                    if (!out[0]) refine_one<LAST, W4>(a, slot, i, resp, lane);
+                    if (!out[1]) refine_one<LAST, W4>(a, slot, i + 1, resp, lane);
+                    return;
+                }
+            }
         }
     }
 #pragma unroll

@@ -168,13 +168,19 @@ SoftRender::SoftRender(const CameraParameters& cam) : width(cam.videoWidth), hei
 }
 
 void SoftRender::render(const Mesh& mesh, Vec3 cam, std::vector<uint8_t>& bgr, std::vector<uint16_t>& depth) const {
+    // translateCam (:334-345)
+    if (cam.x == 0 && cam.z == 0) { cam.x = 0.000001f; cam.z = 0.000001f; }
+    const Mat4 view = lookAt(cam, Vec3{0, 0, 0}, Vec3{0, 1, 0});
+    render_view(mesh, view.m, bgr, depth);
+}
+
+void SoftRender::render_view(const Mesh& mesh, const float view_m[4][4], std::vector<uint8_t>& bgr, std::vector<uint16_t>& depth) const {
     const int W = width, H = height;
     bgr.assign((size_t)W * H * 3, 0);
     depth.assign((size_t)W * H, 0);
     std::vector<float> zbuf((size_t)W * H, 1.0f);   // glClear depth = 1, GL_LESS
-    // translateCam (:334-345)
-    if (cam.x == 0 && cam.z == 0) { cam.x = 0.000001f; cam.z = 0.000001f; }
-    Mat4 view = lookAt(cam, Vec3{0, 0, 0}, Vec3{0, 1, 0});
+    Mat4 view;
+    std::memcpy(view.m, view_m, sizeof(view.m));
     Mat4 P;
     std::memcpy(P.m, proj, sizeof(proj));
     Mat4 vp = mul(P, view);   // the reference computes modelMat but never applies it (`viewProj = projection * view`)

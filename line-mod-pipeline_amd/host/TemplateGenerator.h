@@ -51,6 +51,9 @@ public:
     explicit SoftRender(const CameraParameters& cam);
     // renderColorToFrontBuff + renderDepthToFrontBuff (camera-position overloads, :49-69, :97-117)
     void render(const Mesh& mesh, Vec3 camPosition, std::vector<uint8_t>& bgr, std::vector<uint16_t>& depth) const;
+    // the same rasteriser under a given view matrix (column-major like glm): renderDepthToFrontBuff(modelIndice, rotMat, traVec) of the reference's
+    // Benchmark (:116-141) builds one from a pose; the Hodan-error test renders the ground-truth and the estimated pose with it
+    void render_view(const Mesh& mesh, const float view[4][4], std::vector<uint8_t>& bgr, std::vector<uint16_t>& depth) const;
     int width, height;
 
 private:
