@@ -182,6 +182,7 @@ struct lm_detector {
     u32* d_offs3 = nullptr;          // [nt][fpad1] orientation << 29 | spread-memory offset of the bit-plane scan's features
     // r06, the bit-plane scan with a frame's planes in LDS (k_scanl; hb.lds_ok): the lists in the LDS image's layout and the lane items
     u32* d_offl = nullptr; u32* d_offsl = nullptr; u32* d_litem = nullptr;
+    unsigned long long* d_refine_stat = nullptr;     // LM_REFINE_STAT=1: k_refine's counting experiment (printed by lm_destroy)
     int scanl_min_slots = 24;        // by cost (LM_TUNE_SCAN_FORM 0) from this many frames per call (measured: 16 frames 35.5 us against k_scan4's 35.3, 32 frames 43.4 against 57.5)
     unsigned long long* d_surv[LM_NLANES] = {};      // k_scan1's survivor queues, one per lane, allocated on a lane's first bit-plane scan
     int surv_set[LM_NLANES] = {};                    // which of a queue's two counter sets the lane's next scan launch uses (the other is zeroed behind it)
@@ -312,6 +313,10 @@ int ensure_device(lm_detector* d) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_sim_lut), 256));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_normal_lut), 2 * 8000 + 16));    // the table, then its labels as rank codes (LMK_NORMAL_CODE_OFFSET) + a zero entry for indices outside the table
     HIP_TRY(hipDeviceSynchronize());
+    if (const char* ev = getenv("LM_REFINE_STAT")) {
+        if (atoi(ev) > 0 && hipMalloc(reinterpret_cast<void**>(&d->d_refine_stat), 8 * sizeof(unsigned long long)) == hipSuccess)
+            (void)hipMemset(d->d_refine_stat, 0, 8 * sizeof(unsigned long long));
+    }
     d->dev_ready = true;
     d->luts_dirty = true;
     d->bank_dirty = true; d->hulls_dirty = true;
@@ -747,6 +752,7 @@ LmRefineArgs make_refine_args(lm_detector* d, int first, int level, float thresh
     a.threshold = threshold;
     a.t_global = d->d_t_global; a.t_class = d->d_t_class;
     a.plan = nullptr; a.plan_cap = 0;
+    a.stat = d->d_refine_stat;
     return a;
 }
 
@@ -1278,6 +1284,13 @@ void lm_destroy(lm_detector* d) {
     if (d->dev_ready) {
         hipSetDevice(d->cfg.device);
         hipDeviceSynchronize();
+        if (d->d_refine_stat) {
+            unsigned long long h[8] = {};
+            if (hipMemcpy(h, d->d_refine_stat, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "LM_REFINE_STAT: refined alone %llu, in pairs %llu | pair candidates pruned %llu (both of a pair: %llu pairs) | single candidates pruned %llu | dropped by the final test %llu\n",
+                        h[0], h[1], h[2], h[3], h[4], h[5]);
+            hipFree(d->d_refine_stat);
+        }
         for (Slot& s : d->slots) {
             if (s.h_bgr) hipHostFree(s.h_bgr);
             if (s.h_depth) hipHostFree(s.h_depth);

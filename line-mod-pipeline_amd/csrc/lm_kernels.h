@@ -116,6 +116,8 @@ struct LmRefineArgs {
     const u32* plan;         // slot -> XCD plan of k_refine_plan ([8][plan_cap] slots + [8] lengths), or nullptr
     int plan_cap;
     int blocks_per_slot, nslots;  // filled by lmk_refine
+    unsigned long long* stat;     // counting experiment (LM_REFINE_STAT=1): [0] candidates refined alone, [1] in pairs, [2] pair candidates the pruning dropped, [3] pairs in which BOTH were,
+                                  //   [4] single candidates the pruning dropped, [5] candidates dropped by the final test; nullptr otherwise
 };
 // Balanced slot -> XCD lists for lmk_refine from the slots' candidate counts (nslots <= 1024, nslots % 8 == 0).
 void lmk_refine_plan(hipStream_t s, const LmRefineArgs& a, int nslots, u32* plan, int plan_cap);

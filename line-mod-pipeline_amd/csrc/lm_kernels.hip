@@ -3498,6 +3498,7 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
     int off_x = bx * T, off_y = by * T;
     const u32 shift = (u32)(by * W + bx);   // two's complement: feature offset + shift >= 0 for kept features
     u32 s01 = 0, s23 = 0;   // u16 pairs: patch positions {0, 1} and {2, 3} of this lane (sums <= 126 * 4)
+    if (a.stat && lane == 0) atomicAdd(&a.stat[0], 1ull);
     // Exact pruning, as in the scan: the candidate survives only if its best patch position reaches `threshold`, and a
     // feature adds at most 4.  Every 16 features the wave takes the maximum partial sum of the patch; once even
     // (maximum + 4 x features to come) * 100 / (4 n) < threshold -- the very float expression of the final test, which
@@ -3536,6 +3537,7 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
     }
     if (dead) {
         if (lane == 0) cand[i].ti = LM_DROPPED;
+        if (a.stat && lane == 0) atomicAdd(&a.stat[4], 1ull);
         return;
     }
     // first maximum in row-major order: key = score << 8 | (255 - index)
@@ -3553,6 +3555,7 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
     float sim = __fdiv_rn(__fmul_rn((float)best, 100.f), (float)(4 * mt.nfeat_total));
     if (lane == 0) {
         if (sim < a.threshold) {
+            if (a.stat) atomicAdd(&a.stat[5], 1ull);
             cand[i].ti = LM_DROPPED;
         } else if (LAST) {
             emit_key(a, hdr, keys, ti, nx, ny, sim);
@@ -3605,6 +3608,7 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
         shift[c] = (u32)(by[c] * W + bx[c]);
     }
     u32 s01[2] = {0, 0}, s23[2] = {0, 0};
+    if (a.stat && lane == 0) atomicAdd(&a.stat[1], 2ull);
     const int dcol = bx[1] - bx[0];                                   // wave-uniform
     const bool same_rows = by[0] == by[1] && dcol >= 0 && dcol <= 4;
     // r06: refine_one's exact pruning for the pair: every 16 features the wave takes each candidate's best partial sum of its
@@ -3674,6 +3678,7 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
                     out[c] = __fdiv_rn(__fmul_rn((float)(int)(best_now + 4u * (u32)f_left), 100.f), denom) < a.threshold;
                 }
                 if (out[0] || out[1]) {
+                    if (a.stat && lane == 0) { atomicAdd(&a.stat[2], (unsigned long long)(out[0] + out[1])); if (out[0] && out[1]) atomicAdd(&a.stat[3], 1ull); }
                     if (out[0] && lane == 0) cand[i].ti = LM_DROPPED;
                     if (out[1] && lane == 0) cand[i + 1].ti = LM_DROPPED;
                     if (!out[0]) refine_one<LAST, W4>(a, slot, i, resp, lane);
@@ -3697,6 +3702,7 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
         const float sim = __fdiv_rn(__fmul_rn((float)best, 100.f), (float)(4 * mt.nfeat_total));
         if (lane == 0) {
             if (sim < a.threshold) {
+                if (a.stat) atomicAdd(&a.stat[5], 1ull);
                 cand[i + c].ti = LM_DROPPED;
             } else if (LAST) {
                 emit_key(a, hdr, keys, ti, nx, ny, sim);
