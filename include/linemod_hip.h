@@ -350,6 +350,19 @@ int lm_color_check_begin_slots(lm_detector* det, const int32_t* slot_of_match, c
                                const lm_match_t* matches, size_t n);
 int lm_color_check_end(lm_detector* det, int64_t* in_hull, int64_t* in_both);
 
+/* r06: the depth check's early verdicts on the GPU (the reference's medianMat + depthCheck, HighLevelLinemod.cpp:336-349,437-457).  The check wants to
+ * know whether v[n / 5] after std::nth_element(v, v + n / 4) -- v the crop of the (translated) depth frame under the template's bounding box with depths
+ * <= 1 replaced by 65535 -- lies inside the window [lo, hi] of medians that pass |depthDiff| < stepSize.  That element is one of the n / 4 + 1 smallest:
+ * when more than n / 4 values lie below lo, or none lies inside [lo, hi], the verdict "outside" is certain without the selection.  For every query this
+ * call counts, in the frame resident in slot `slot`, the values of the crop [x0, x1) x [y0, y1) (the caller clips it to the frame) below lo and inside
+ * [lo, hi] -- one wave per query on the colour-check stream, beside the lanes.  The host then runs std::nth_element (it must stay the host library's: WHICH
+ * of those elements comes back is implementation-defined) only for the checks no early verdict decides.  Detectors without a depth modality keep no
+ * depth frame on the device: LM_ERR_INVALID.  begin / end as the colour check's halves (one depth query list in flight per detector, independent of a
+ * colour check in flight). */
+typedef struct lm_depth_query { int32_t x0, y0, x1, y1; int32_t lo, hi; int32_t slot; int32_t reserved; } lm_depth_query;
+int lm_depth_counts_begin(lm_detector* det, const lm_depth_query* queries, size_t n);
+int lm_depth_counts_end(lm_detector* det, uint32_t* below, uint32_t* inside);
+
 /* ---- multi-GPU: template-bank shards + the ONE exchange step of the path ------------------------
  * One process per GPU; every rank creates its detector with lm_config.shard_rank / shard_size (contiguous template_id
  * ranges, global ids preserved), uploads the SAME frames and calls the same sequence of lm_match_begin_gathered /

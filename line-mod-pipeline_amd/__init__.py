@@ -22,6 +22,7 @@ MATCH_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("similarity", "<f4"), ("tem
                         ("class_idx", "<i4")])
 FEATURE_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("label", "<i4")])
 DESC_DTYPE = np.dtype([("width", "<i4"), ("height", "<i4"), ("pyramid_level", "<i4"), ("num_features", "<i4")])
+DEPTH_QUERY_DTYPE = np.dtype([("x0", "<i4"), ("y0", "<i4"), ("x1", "<i4"), ("y1", "<i4"), ("lo", "<i4"), ("hi", "<i4"), ("slot", "<i4"), ("reserved", "<i4")])   # lm_depth_query
 
 
 class Config(C.Structure):
@@ -84,6 +85,7 @@ EXPORTS = [
     "lm_selftest_float_tail",
     "lm_upload_frame_pinned_shifted", "lm_stage_reserve", "lm_stage_rows", "lm_upload_staged", "lm_match_collect",
     "lm_color_check_counts_slots", "lm_color_check_begin_slots", "lm_color_check_end", "lm_color_mask_prepare",
+    "lm_depth_counts_begin", "lm_depth_counts_end",
 ]
 
 _lib = None
@@ -197,6 +199,8 @@ def load_library(path=None):
     lib.lm_color_check_counts_slots.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, sz, vp, vp]
     lib.lm_color_check_begin_slots.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, sz]
     lib.lm_color_check_end.argtypes = [vp, vp, vp]
+    lib.lm_depth_counts_begin.argtypes = [vp, vp, C.c_size_t]
+    lib.lm_depth_counts_end.argtypes = [vp, vp, vp]
     lib.lm_color_mask_prepare.argtypes = [vp, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if path is None:
         _lib = lib
@@ -825,6 +829,15 @@ class Detector:
         lo, hi = (C.c_double * 3)(*lower_hsv), (C.c_double * 3)(*upper_hsv)
         self._check(self.lib.lm_color_check_counts_slots(self.h, _ptr(sl), lo, hi, _ptr(m), len(m), _ptr(a), _ptr(b)))
         return a, b
+
+    def depth_counts(self, queries):
+        """r06: per query (DEPTH_QUERY_DTYPE: crop x0, y0, x1, y1 of the frame resident in `slot`, window lo..hi) the number of crop values below lo and
+        inside [lo, hi], depths <= 1 counted as 65535 -- the depth check's early verdicts (lm_depth_counts_begin / _end)."""
+        q = np.ascontiguousarray(queries, DEPTH_QUERY_DTYPE)
+        below = np.zeros(len(q), np.uint32); inside = np.zeros(len(q), np.uint32)
+        self._check(self.lib.lm_depth_counts_begin(self.h, _ptr(q) if len(q) else None, len(q)))
+        self._check(self.lib.lm_depth_counts_end(self.h, _ptr(below) if len(q) else None, _ptr(inside) if len(q) else None))
+        return below, inside
 
     def color_mask_prepare(self, lane, first_slot, n_slots, lower_hsv, upper_hsv):
         """The slots' colour masks for one HSV range on `lane`'s stream, ahead of the match begun on that lane next."""

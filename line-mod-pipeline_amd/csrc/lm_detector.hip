@@ -132,6 +132,9 @@ struct lm_detector {
     hipStream_t cc_stream = nullptr;
     u8* cc_dev = nullptr; u8* cc_host = nullptr; size_t cc_cap = 0;       // room for cc_cap matches: records | slot index | two counts
     size_t cc_pending = 0; bool cc_inflight = false;                      // lm_color_check_begin_slots enqueued a check of cc_pending matches
+    u8* dc_dev = nullptr; u8* dc_host = nullptr; size_t dc_cap = 0;       // r06, lm_depth_counts_begin: room for dc_cap queries | two counts each
+    size_t dc_pending = 0; bool dc_inflight = false;
+    hipEvent_t cc_done = nullptr, dc_done = nullptr;                      // behind the colour check's / the depth counts' last copy: their `end` waits for the event, not the stream
     LmComm* comm[LM_NLANES] = {};   // one communicator per lane: the lanes' collectives never wait for each other
     int comm_recs_per_frame = 0;
     Gather gather[LM_NLANES];
@@ -1322,6 +1325,9 @@ void lm_destroy(lm_detector* d) {
         hipFree(d->d_hull_class_base); hipFree(d->d_hull_off); hipFree(d->d_hull_xy); hipFree(d->d_hsv_div);
         if (d->cc_stream) hipStreamDestroy(d->cc_stream);
         hipFree(d->cc_dev); if (d->cc_host) hipHostFree(d->cc_host);
+        hipFree(d->dc_dev); if (d->dc_host) hipHostFree(d->dc_host);
+        if (d->cc_done) hipEventDestroy(d->cc_done);
+        if (d->dc_done) hipEventDestroy(d->dc_done);
         hipFree(d->d_resp_tab); hipFree(d->d_sim_lut); hipFree(d->d_normal_lut); hipFree(d->d_scratch);
     }
     delete d;
@@ -1901,6 +1907,8 @@ static int ensure_colour_check(lm_detector* d, size_t n) {
             HIP_TRY(hipStreamCreateWithFlags(&d->cc_stream, hipStreamNonBlocking));
         }
     }
+    if (!d->cc_done) HIP_TRY(hipEventCreateWithFlags(&d->cc_done, hipEventDisableTiming));
+    if (!d->dc_done) HIP_TRY(hipEventCreateWithFlags(&d->dc_done, hipEventDisableTiming));
     if (n > d->cc_cap) {
         const size_t cap = std::max<size_t>(align_up(n, 4096), 16384);
         const size_t bytes = cap * (sizeof(lm_match_t) + sizeof(int) + 2 * sizeof(long long));
@@ -1988,6 +1996,7 @@ static int colour_check_enqueue(lm_detector* d, const int32_t* slot_of, int one_
         return fail(LM_ERR_INVALID, "frame too tall for the GPU colour check (more than 4992 rows): use the host colour check");
     }
     HIP_TRY(hipMemcpyAsync(d->cc_host + off_out, a.out, n * 2 * sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(d->cc_done, st));
     d->cc_pending = n; d->cc_inflight = true;
     return LM_OK;
 }
@@ -1998,7 +2007,7 @@ static int colour_check_finish(lm_detector* d, int64_t* in_hull, int64_t* in_bot
     d->cc_inflight = false; d->cc_pending = 0;
     if (n && (!in_hull || !in_both)) { (void)hipStreamSynchronize(d->cc_stream); return fail(LM_ERR_INVALID, "null argument"); }
     HIP_TRY(hipSetDevice(d->cfg.device));
-    HIP_TRY(hipStreamSynchronize(d->cc_stream));
+    HIP_TRY(hipEventSynchronize(d->cc_done));          // (the event behind this check's last copy: depth counts enqueued behind it are not waited for, r06)
     HIP_TRY(hipGetLastError());
     const size_t off_out = d->cc_cap * sizeof(lm_match_t) + d->cc_cap * sizeof(int);
     const long long* out = reinterpret_cast<const long long*>(d->cc_host + off_out);
@@ -2070,6 +2079,76 @@ int lm_color_check_counts_slots(lm_detector* d, const int32_t* slot_of_match, co
                                 const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both) {
     if (n && !slot_of_match) return fail(LM_ERR_INVALID, "null argument");
     return colour_check(d, slot_of_match, 0, lower_hsv, upper_hsv, matches, n, in_hull, in_both);
+}
+
+// ---- r06: the depth check's counts for a batch of queries (include/linemod_hip.h lm_depth_counts_begin) -----------------------------------
+int lm_depth_counts_begin(lm_detector* d, const lm_depth_query* q, size_t n) {
+    int rc;
+    if ((rc = ready_for_compute(d))) return rc;
+    if (d->dc_inflight) return fail(LM_ERR_INVALID, "depth counts are in flight: call lm_depth_counts_end first");
+    if (n && !q) return fail(LM_ERR_INVALID, "null argument");
+    if (d->cfg.num_modalities < 2) return fail(LM_ERR_INVALID, "the detector keeps no depth frame on the device (no depth modality)");
+    static_assert(sizeof(lm_depth_query) == sizeof(LmDepthQuery), "lm_depth_query layout");
+    const int S = (int)d->slots.size(), W = d->cfg.width, H = d->cfg.height;
+    std::vector<char> used((size_t)S, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const lm_depth_query& e = q[i];
+        if (e.slot < 0 || e.slot >= S) return fail(LM_ERR_INVALID, "slot out of range");
+        if (e.x0 < 0 || e.y0 < 0 || e.x1 > W || e.y1 > H || e.x1 < e.x0 || e.y1 < e.y0) return fail(LM_ERR_INVALID, "query " + std::to_string(i) + ": crop outside the frame");
+        used[(size_t)e.slot] = 1;
+    }
+    for (int sl = 0; sl < S; ++sl) {
+        if (!used[(size_t)sl]) continue;
+        if (!d->slots[(size_t)sl].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
+    }
+    d->dc_pending = 0; d->dc_inflight = true;
+    if (n == 0) return LM_OK;
+    if ((rc = ensure_colour_check(d, 0))) { d->dc_inflight = false; return rc; }      // (the stream)
+    if (n > d->dc_cap) {
+        const size_t cap = std::max<size_t>(align_up(n, 4096), 16384);
+        const size_t bytes = cap * (sizeof(LmDepthQuery) + 2 * sizeof(u32));
+        u8* dev = nullptr; u8* host = nullptr;
+        if (hipStreamSynchronize(d->cc_stream) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&dev), bytes) != hipSuccess) { d->dc_inflight = false; (void)hipGetLastError(); return fail(LM_ERR_HIP, "allocation of the depth counts' buffers failed"); }
+        if (hipHostMalloc(reinterpret_cast<void**>(&host), bytes) != hipSuccess) { (void)hipFree(dev); d->dc_inflight = false; (void)hipGetLastError(); return fail(LM_ERR_HIP, "hipHostMalloc of the depth counts' buffers failed"); }
+        (void)hipFree(d->dc_dev); if (d->dc_host) (void)hipHostFree(d->dc_host);
+        d->dc_dev = dev; d->dc_host = host; d->dc_cap = cap;
+    }
+    hipStream_t st = d->cc_stream;
+    auto bail = [&](hipError_t e) { d->dc_inflight = false; (void)hipStreamSynchronize(st); return fail(LM_ERR_HIP, hipGetErrorString(e)); };
+    // the frames' uploads (copy streams) must have landed before the kernel reads them
+    for (int sl = 0; sl < S; ++sl) {
+        const Slot& s = d->slots[(size_t)sl];
+        if (used[(size_t)sl] && s.up_seq > d->up_seq_done[s.up_stream]) { const hipError_t e = hipStreamWaitEvent(st, s.ev_up, 0); if (e != hipSuccess) return bail(e); }
+    }
+    const size_t off_out = d->dc_cap * sizeof(LmDepthQuery);
+    std::memcpy(d->dc_host, q, n * sizeof(LmDepthQuery));
+    hipError_t e = hipMemcpyAsync(d->dc_dev, d->dc_host, n * sizeof(LmDepthQuery), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return bail(e);
+    LmDepthArgs a;
+    a.depth = d->depth(0); a.slot_stride = d->frame_stride; a.w = W; a.h = H;
+    a.q = reinterpret_cast<const LmDepthQuery*>(d->dc_dev); a.n = (u32)n;
+    a.out = reinterpret_cast<u32*>(d->dc_dev + off_out);
+    lmk_depth_counts(st, a);
+    e = hipMemcpyAsync(d->dc_host + off_out, a.out, n * 2 * sizeof(u32), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return bail(e);
+    e = hipEventRecord(d->dc_done, st);
+    if (e != hipSuccess) return bail(e);
+    d->dc_pending = n;
+    return LM_OK;
+}
+
+int lm_depth_counts_end(lm_detector* d, uint32_t* below, uint32_t* inside) {
+    if (!d || !d->dc_inflight) return fail(LM_ERR_INVALID, "no depth counts in flight");
+    const size_t n = d->dc_pending;
+    d->dc_inflight = false; d->dc_pending = 0;
+    if (n == 0) return LM_OK;
+    if (!below || !inside) { (void)hipStreamSynchronize(d->cc_stream); return fail(LM_ERR_INVALID, "null argument"); }
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    HIP_TRY(hipEventSynchronize(d->dc_done));
+    HIP_TRY(hipGetLastError());
+    const u32* out = reinterpret_cast<const u32*>(d->dc_host + d->dc_cap * sizeof(LmDepthQuery));
+    for (size_t i = 0; i < n; ++i) { below[i] = out[2 * i]; inside[i] = out[2 * i + 1]; }
+    return LM_OK;
 }
 
 // ---- multi-GPU exchange: RCCL all-gather of the per-shard lists ---------------------------------

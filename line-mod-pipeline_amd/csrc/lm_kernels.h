@@ -205,3 +205,15 @@ struct LmHullArgs {
 };
 // false: the frame has more rows than the kernel's per-wave row table fits into LDS (nothing was launched)
 bool lmk_hull_counts(hipStream_t s, const LmHullArgs& a);
+
+// r06, the depth check's early verdicts on the GPU (medianMat, HighLevelLinemod.cpp:336-349,437-457): per query the crop [x0, x1) x [y0, y1) of a resident
+// depth frame with depths <= 1 counted as 65535 -- how many values lie below `lo`, how many inside [lo, hi]
+struct LmDepthQuery { int x0, y0, x1, y1; int lo, hi; int slot; int pad; };      // (same layout as lm_depth_query of the C ABI)
+struct LmDepthArgs {
+    const u16* depth;            // depth image of slot 0 (the resident, already translated frame)
+    size_t slot_stride;          // bytes between the slots' frames
+    int w, h;
+    const LmDepthQuery* q; u32 n;
+    u32* out;                    // [n][2]: values below lo, values in [lo, hi]
+};
+void lmk_depth_counts(hipStream_t s, const LmDepthArgs& a);

@@ -4181,6 +4181,46 @@ __global__ __launch_bounds__(256) void k_hull_counts(LmHullArgs a) {
 }
 
 // materialises the NN pyramid of the depth modality's quantised image (levels >= 2, stage hooks)
+// r06: the by-products of the host's crop pass (PostProcess.cpp crop_depth) for a whole batch of depth checks: one wave per query, rows of the crop
+// one after the other, 64 columns at a time.  t = depth <= 1 ? 65535 : depth (threshold(.., 1, 65535) inverted and added; the zeros the principal-point
+// shift moved in are depths <= 1 like every hole); counted: t < lo, lo <= t <= hi.  The host then knows the verdict "outside the window" of about four
+// checks in five without touching the frame (more than n / 4 values below the window, or none inside it) and runs std::nth_element for the rest.
+__global__ __launch_bounds__(256) void k_depth_counts(LmDepthArgs a) {
+    // one WORKGROUP per query (a crop is tens of thousands of pixels: one wave per query walked 600 dependent row segments and took hundreds of
+    // microseconds, A/B r06): thread t takes the 8-pixel pieces t, t + 256, .. of the crop, eight independent 2-byte loads in flight each
+    __shared__ u32 acc[2];
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const u32 qi = blockIdx.x;
+    if (tid < 2) acc[tid] = 0u;
+    __syncthreads();
+    const LmDepthQuery q = a.q[qi];
+    const u16* img = reinterpret_cast<const u16*>(reinterpret_cast<const u8*>(a.depth) + (size_t)q.slot * a.slot_stride);
+    const int cw = q.x1 - q.x0, ch = q.y1 - q.y0;
+    const int pr = (cw + 7) >> 3;                      // pieces per row
+    const int np = pr * ch;
+    u32 below = 0, inside = 0;
+    for (int p = tid; p < np; p += 256) {
+        const int r = p / pr, c = (p - r * pr) << 3;
+        const u16* src = img + (size_t)(q.y0 + r) * a.w + q.x0 + c;
+        const int m = cw - c < 8 ? cw - c : 8;
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = k < m ? (int)src[k] : 2;      // (a value that counts nowhere is substituted below)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = v[k] <= 1 ? 65535 : v[k];
+            const bool ok = k < m;
+            below += (ok && t < q.lo) ? 1u : 0u;
+            inside += (ok && t >= q.lo && t <= q.hi) ? 1u : 0u;
+        }
+    }
+    below = wave_sum_u32(below);
+    inside = wave_sum_u32(inside);
+    if (lane == 0) { atomicAdd(&acc[0], below); atomicAdd(&acc[1], inside); }
+    __syncthreads();
+    if (tid == 0) { a.out[2 * qi] = acc[0]; a.out[2 * qi + 1] = acc[1]; }
+}
+
 __global__ void k_nn_half(const u8* __restrict__ src0, int sp, u8* __restrict__ dst0, int dw, int dh,
                           size_t slot_stride) {
     const u8* src = slot_ptr(src0, slot_stride);
@@ -4687,6 +4727,11 @@ bool lmk_hull_counts(hipStream_t s, const LmHullArgs& a) {
     }
     hipLaunchKernelGGL(k_hull_counts, dim3((a.n + 3) / 4), dim3(256), shmem, s, a);
     return true;
+}
+
+void lmk_depth_counts(hipStream_t s, const LmDepthArgs& a) {
+    if (a.n == 0) return;
+    hipLaunchKernelGGL(k_depth_counts, dim3(a.n), dim3(256), 0, s, a);
 }
 
 void lmk_pack_lists(hipStream_t s, const LmPackArgs& a) {

@@ -412,11 +412,14 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
     // ---- step 1, pool (one task per frame): split the mixed list by class, per (class, frame) the grouping (host only)
     struct Unit { size_t c = 0; int i = 0; bool live = false; PostProcessor pp; PostProcessor::Prepared prep; const std::vector<TemplatePose>* tpl = nullptr;
                   const uint16_t* depth = nullptr; std::vector<uint16_t> dense; ModelProperties props; const std::vector<lm_match_t>* matches = nullptr;
+                  std::vector<lm_depth_query> dq;      // r06: the depth checks' GPU queries of the unit's matches (built with the grouping, on the pool)
                   Unit(lm_detector* d, const PostProcessSettings& s) : pp(d, s) {} };
     std::vector<Unit> units;
     units.reserve(nc * (size_t)n);
     for (int i = 0; i < n; ++i) for (size_t c = 0; c < nc; ++c) { units.emplace_back(detector, ps); units.back().c = c; units.back().i = i; }
     std::vector<PostProcessor::Times> frame_times((size_t)n * nc);
+    // r06: the depth checks' early verdicts from GPU counts -- by default only when this is the one batch in flight (setGpuDepthCounts)
+    const bool depth_counts_on = !onlyColorModality && settings.useDepthImprovement && (gpuDepthCounts == 2 || (gpuDepthCounts == 1 && st.inflight.empty()));
     WorkerPool::Group grouping;
     std::vector<std::function<void()>> grouping_tasks;
     for (int i = 0; i < n; ++i) {
@@ -454,7 +457,10 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
                         u.depth = u.dense.data();
                     }
                 }
-                if (gpuColorCheck) u.prep = u.pp.prepare_groups(dst, *u.tpl, &frame_times[(size_t)i * nc + c]);   // the colour counts follow, one GPU call per HSV range
+                if (gpuColorCheck) {
+                    u.prep = u.pp.prepare_groups(dst, *u.tpl, &frame_times[(size_t)i * nc + c]);   // the colour counts follow, one GPU call per HSV range
+                    if (depth_counts_on && u.depth) u.pp.depth_queries(u.prep, *u.tpl, first + i, u.dq);
+                }
                 else u.prep = u.pp.prepare(dst, static_cast<const uint8_t*>(color.data), color.stride, *u.tpl, u.props, -1, &frame_times[(size_t)i * nc + c]);
             }
         });
@@ -497,12 +503,13 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
                 ++at;
             }
     }
+    std::atomic<bool> depth_ready{false};          // r06: the depth checks' GPU counts are in (they arrive after the walks have started)
     WorkerPool::Group finishing;
     GroupWaves waves(*st.pool, finishing, lengths,
         // a match's checks, on any pool thread.  early (the first wave, before the GPU's colour counts are back): the depth check runs ahead
         // of the colour verdict; otherwise the depth check only runs behind a passed colour check, as in the reference (the host colour
         // check computes its verdict here)
-        [&runs](size_t gi, size_t k, bool early) {
+        [&runs, &depth_ready](size_t gi, size_t k, bool early) {
             GroupState& r = runs[gi];
             const Unit& u = *r.u;
             const uint32_t idx = u.prep.groups[r.g].matchIndices[k];
@@ -510,7 +517,7 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
             PostProcessor::MatchVerdict& v = r.v[k];
             PostProcessor::Times t;
             if ((size_t)m.template_id < u.tpl->size()) {
-                if (!early) { v.colour_ok = u.pp.colour_ok(u.prep, idx, m); if (v.colour_ok) u.pp.depth_part(m, u.depth, *u.tpl, v, &t); }
+                if (!early) { v.colour_ok = u.pp.colour_ok(u.prep, idx, m); if (v.colour_ok) u.pp.depth_part(u.prep, idx, m, u.depth, *u.tpl, v, &t, depth_ready.load(std::memory_order_acquire)); }
                 else u.pp.depth_part(m, u.depth, *u.tpl, v, &t);
             }
             r.add(t);
@@ -531,6 +538,25 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
             return done;
         });
     for (Unit& u : units) if (u.live) u.matches = &out_matches[u.c][(size_t)u.i];
+    // r06: the depth checks' early verdicts for ALL matches of the surviving groups, counted on the GPU in one launch ahead of the colour work on the same
+    // stream (the frames are resident, translated as the depth check wants them): about four checks in five then need no pass over the frame at all
+    std::vector<lm_depth_query> dq;
+    std::vector<size_t> dq_at(units.size(), 0);
+    bool depth_begun = false;
+    if (gpuColorCheck && depth_counts_on) {
+        for (size_t a = 0; a < units.size(); ++a) {
+            dq_at[a] = dq.size();
+            if (units[a].live) dq.insert(dq.end(), units[a].dq.begin(), units[a].dq.end());
+        }
+    }
+    // (the counts are enqueued BEHIND the first colour check on the stream and collected after the walks have been released: nothing waits for them --
+    // a check evaluated before they are in takes the host's own crop pass, same verdict; measured r06: waiting for them ahead of the release cost 55 us
+    // per batch alone and 40-50 us per frame in the streamed steady state, where the next batch's kernels hold the GPU)
+    auto begin_depth_counts = [&] {
+        if (depth_begun || dq.empty()) return;
+        if (lm_depth_counts_begin(detector, dq.data(), dq.size()) == LM_OK) depth_begun = true;
+        else error = lm_last_error();          // (the host's own crop pass decides then: same verdicts)
+    };
     if (gpuColorCheck) {
         // the units by HSV range; the first range's check is asynchronous
         std::vector<char> done(units.size(), 0);
@@ -553,6 +579,7 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
             const clk::time_point t_c = clk::now();
             int crc = lm_color_check_begin_slots(detector, slot_of.data(), units[a].props.lowerColorRange, units[a].props.upperColorRange, todo.data(), todo.size());
             const clk::time_point t_cb = clk::now();
+            if (first_range) begin_depth_counts();
             if (crc == LM_OK && first_range) waves.start(true);
             const clk::time_point t_ws = clk::now();
             if (post_trace) std::fprintf(stderr, "post-trace: colour check begun in %.0f us (%zu matches), first wave submitted in %.0f us\n", secs(t_c, t_cb) * 1e6, todo.size(), secs(t_cb, t_ws) * 1e6);      // while the GPU counts: the first wave of every group (all ranges' groups: their walks wait for the tokens)
@@ -575,7 +602,17 @@ bool HighLevelLineMOD::detectTemplatesBatchEnd(std::vector<std::vector<std::vect
         }
         waves.start(true);                // (no live unit at all: nothing to start; otherwise a no-op)
         const clk::time_point t_rel = clk::now();
-        waves.release_tokens();           // every count is in
+        waves.release_tokens();           // every colour count is in
+        begin_depth_counts();             // (no colour range at all: still collected below)
+        if (depth_begun) {
+            std::vector<uint32_t> below(dq.size()), inside(dq.size());
+            if (lm_depth_counts_end(detector, below.data(), inside.data()) == LM_OK) {
+                for (size_t a = 0; a < units.size(); ++a)
+                    if (units[a].live && !units[a].dq.empty())
+                        PostProcessor::set_depth_counts(units[a].prep, dq.data() + dq_at[a], below.data() + dq_at[a], inside.data() + dq_at[a]);
+                depth_ready.store(true, std::memory_order_release);
+            } else error = lm_last_error();
+        }
         if (post_trace) std::fprintf(stderr, "post-trace: grouping %.0f us, colour counts in after %.0f us more, tokens released in %.0f us\n", secs(t_post, t_grouped) * 1e6, secs(t_grouped, t_rel) * 1e6, secs(t_rel, clk::now()) * 1e6);
     } else {
         waves.start(false);

@@ -121,6 +121,11 @@ public:
                                              //  it and the post-processing of the one before that run at the same time)
     // colour checks of the post-processing on the GPU (default) or on the host (the reference's one-match-at-a-time way)
     void setGpuColorCheck(bool on) { gpuColorCheck = on; }
+    // r06: the depth checks' early verdicts from counts taken on the GPU (lm_depth_counts_begin) in the streamed / batched path; off: every check's crop pass
+    // runs on the host (same verdicts, same poses)
+    // 0: never; 1 (default): when no other batch is in flight (the serial detectBatch: -8 % per frame, measured r06 -- in the streamed steady state the
+    // next batch's kernels hold the GPU and the counts buy the post-processing nothing); 2: always.
+    void setGpuDepthCounts(int mode) { gpuDepthCounts = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
     bool usesGpuColorCheck() const { return gpuColorCheck; }
     // host threads of detectTemplatesBatch's post-processing (r04): the groups of all (class, frame) pairs of a batch are independent
     // once their colour counts are known, and the reference's depth check (an nth_element over the template's bounding box per
@@ -181,6 +186,7 @@ private:
     std::vector<ModelProperties>* modProps;                   // :169
     std::string error;
     bool gpuColorCheck = true;
+    int gpuDepthCounts = 1;
     int postThreads = 0;
     StageTimes stageTimes;
     struct Stream;                       // the batches in flight + the pool (HighLevelLinemod.cpp)

@@ -403,19 +403,52 @@ static inline int32_t depth_diff(int med, const TemplatePose& tp, float depthOff
     return (int32_t)((float)((int32_t)med - (int32_t)tp.medianDepth) - depthOffset);
 }
 
-bool PostProcessor::depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth, bool* decided_early) const {
+void PostProcessor::depth_window(const TemplatePose& tp, int* win_lo, int* win_hi) const {
+    // the medians that pass |depthDiff| < stepSize are an interval [lo, hi] of 0 .. 65535 (depth_diff is monotone): two bisections
+    const int32_t step = (int32_t)st.stepSize;
+    int lo = 0, hi = 65536;                              // lo: first median with depthDiff > -step
+    while (lo < hi) { const int mid = (lo + hi) / 2; if (depth_diff(mid, tp, st.depthOffset) > -step) hi = mid; else lo = mid + 1; }
+    *win_lo = lo;
+    lo = -1; hi = 65535;                                 // hi: last median with depthDiff < step
+    while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (depth_diff(mid, tp, st.depthOffset) < step) lo = mid; else hi = mid - 1; }
+    *win_hi = lo;
+}
+
+void PostProcessor::depth_queries(const Prepared& p, const std::vector<TemplatePose>& templates, int slot, std::vector<lm_depth_query>& out) const {
+    const int w = st.videoWidth, h = st.videoHeight;
+    for (const lm_match_t& m : p.todo) {
+        lm_depth_query q;
+        std::memset(&q, 0, sizeof(q));
+        q.slot = slot;
+        if ((size_t)m.template_id < templates.size() && st.useDepthImprovement) {
+            const TemplatePose& tp = templates[(size_t)m.template_id];
+            int lo, hi;
+            depth_window(tp, &lo, &hi);
+            // the crop exactly as crop_depth clips it; the window exactly as median_mat_in_window clamps it
+            const int x0 = std::max(m.x, 0), y0 = std::max(m.y, 0);
+            const int x1 = (int)std::min<long long>((long long)m.x + tp.bb[2], w), y1 = (int)std::min<long long>((long long)m.y + tp.bb[3], h);
+            if (x1 > x0 && y1 > y0 && lo <= hi && lo <= 65535 && hi >= 0) {
+                q.x0 = x0; q.y0 = y0; q.x1 = x1; q.y1 = y1;
+                q.lo = std::max(0, std::min(lo, 65535)); q.hi = std::max(0, std::min(hi, 65535));
+            }
+        }
+        out.push_back(q);
+    }
+}
+
+bool PostProcessor::depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth, bool* decided_early,
+                                const uint32_t* counts) const {
     const TemplatePose& tp = t[(size_t)m.template_id];
     if (decided_early) *decided_early = false;
     if (st.useDepthImprovement) {
         Rect bb{m.x, m.y, tp.bb[2], tp.bb[3]};
-        // the medians that pass |depthDiff| < stepSize are an interval [lo, hi] of 0 .. 65535 (depth_diff is monotone): two bisections
         const int32_t step = (int32_t)st.stepSize;
-        int lo = 0, hi = 65536;                              // lo: first median with depthDiff > -step
-        while (lo < hi) { const int mid = (lo + hi) / 2; if (depth_diff(mid, tp, st.depthOffset) > -step) hi = mid; else lo = mid + 1; }
-        const int win_lo = lo;
-        lo = -1; hi = 65535;                                 // hi: last median with depthDiff < step
-        while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (depth_diff(mid, tp, st.depthOffset) < step) lo = mid; else hi = mid - 1; }
-        const int win_hi = lo;
+        int win_lo, win_hi;
+        depth_window(tp, &win_lo, &win_hi);
+        // r06: median_mat_in_window's early verdict from the GPU's counts of this very crop and window (a query with an empty crop or window carries
+        // size 0 and decides nothing): more than n / 4 values below the window, or none inside it
+        if (counts && counts[2] != 0 && win_lo <= win_hi && win_lo <= 65535 && win_hi >= 0 &&
+            ((size_t)counts[0] >= (size_t)counts[2] / 4 + 1 || counts[1] == 0)) { if (decided_early) *decided_early = true; return false; }
         uint16_t med = 0;
         if (win_lo > win_hi || !median_mat_in_window(depth, st.videoWidth, st.videoHeight, bb, 5, depth_ox, depth_oy, win_lo, win_hi, &med, decided_early)) return false;
         const int32_t depthDiff = depth_diff(med, tp, st.depthOffset);
@@ -504,6 +537,11 @@ bool PostProcessor::colour_ok(const Prepared& p, uint32_t idx, const lm_match_t&
 }
 
 void PostProcessor::depth_part(const lm_match_t& m, const uint16_t* depth_rows, const std::vector<TemplatePose>& templates, MatchVerdict& v, Times* tm) const {
+    depth_part(Prepared(), 0, m, depth_rows, templates, v, tm);
+}
+
+void PostProcessor::depth_part(const Prepared& p, uint32_t idx, const lm_match_t& m, const uint16_t* depth_rows, const std::vector<TemplatePose>& templates, MatchVerdict& v, Times* tm,
+                               bool use_counts) const {
     using clk = std::chrono::steady_clock;
     v.depth_done = true; v.depth_ok = true;
     if ((size_t)m.template_id >= templates.size()) return;
@@ -511,7 +549,10 @@ void PostProcessor::depth_part(const lm_match_t& m, const uint16_t* depth_rows, 
     if (!depth_rows) return;
     const clk::time_point t_d = clk::now();
     bool early = false;
-    v.depth_ok = depth_check(m, depth_rows, templates, &v.tempDepth, &early);
+    uint32_t cnt[3];
+    const bool have = use_counts && p.depth_counts && idx < p.gpos.size() && p.gpos[idx] != (size_t)-1;
+    if (have) { const size_t g = p.gpos[idx]; cnt[0] = p.dbelow[g]; cnt[1] = p.dinside[g]; cnt[2] = p.dsize[g]; }
+    v.depth_ok = depth_check(m, depth_rows, templates, &v.tempDepth, &early, have ? cnt : nullptr);
     if (tm) { tm->depth += std::chrono::duration<double>(clk::now() - t_d).count(); tm->depth_checks += 1; tm->depth_decided_early += early ? 1 : 0; }
 }
 

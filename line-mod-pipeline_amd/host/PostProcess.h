@@ -117,6 +117,9 @@ public:
         std::vector<lm_match_t> todo;             // the matches whose counts are wanted, in gpos order (prepare_groups)
         std::vector<uint8_t> color_mask;          // host colour check: the frame's HSV in-range mask
         bool gpu = false, failed = false;
+        // r06: the depth check's GPU counts (lm_depth_counts_begin), [gpos[match index]]: crop values below the pass window, inside it, and the crop's size
+        std::vector<uint32_t> dbelow, dinside, dsize;
+        bool depth_counts = false;
     };
     // tm: where the call's times go (nullptr = the calling thread's times(); pool tasks hand in their own block)
     Prepared prepare(const std::vector<lm_match_t>& matches, const uint8_t* bgr, size_t bgr_stride,
@@ -128,6 +131,16 @@ public:
     static void set_counts(Prepared& p, const int64_t* in_hull, const int64_t* in_both) {
         p.gin.assign(in_hull, in_hull + p.todo.size()); p.gboth.assign(in_both, in_both + p.todo.size()); p.gpu = true;
     }
+    // r06: one lm_depth_query per match of p.todo, for the frame resident in `slot` (the translated frame: match coordinates as they are): the crop under
+    // the template's bounding box clipped to the frame, and the window of medians that pass the depth check.  A query whose crop is empty or whose
+    // window is (x1 == x0: nothing is counted, the host decides).  set_depth_counts: the counts come back in the same order.
+    void depth_queries(const Prepared& p, const std::vector<TemplatePose>& templates, int slot, std::vector<lm_depth_query>& out) const;
+    static void set_depth_counts(Prepared& p, const lm_depth_query* q, const uint32_t* below, const uint32_t* inside) {
+        const size_t n = p.todo.size();
+        p.dbelow.assign(below, below + n); p.dinside.assign(inside, inside + n); p.dsize.resize(n);
+        for (size_t i = 0; i < n; ++i) p.dsize[i] = (uint32_t)(q[i].x1 - q[i].x0) * (uint32_t)(q[i].y1 - q[i].y0);
+        p.depth_counts = true;
+    }
     std::vector<ObjectPose> finish_group(const Prepared& p, size_t group, const std::vector<lm_match_t>& matches, const uint16_t* dense_depth,
                                          const std::vector<TemplatePose>& templates, Times* tm) const;
     // finish_group in pieces (r05): a match's two checks are pure functions of the frame and may be evaluated ahead of the sequential
@@ -138,6 +151,10 @@ public:
     struct MatchVerdict { bool colour_ok = false, depth_done = false, depth_ok = true; int32_t tempDepth = 0; };
     bool colour_ok(const Prepared& p, uint32_t idx, const lm_match_t& m) const;
     void depth_part(const lm_match_t& m, const uint16_t* dense_depth, const std::vector<TemplatePose>& templates, MatchVerdict& v, Times* tm) const;
+    // ... with the GPU's counts of match idx (p.depth_counts): the verdict "outside the window" without touching the frame when they decide it
+    // (use_counts: the caller has seen the counts arrive -- HighLevelLineMOD's walks start before they do and look at a flag)
+    void depth_part(const Prepared& p, uint32_t idx, const lm_match_t& m, const uint16_t* dense_depth, const std::vector<TemplatePose>& templates, MatchVerdict& v, Times* tm,
+                    bool use_counts = true) const;
     bool accept_range(const Prepared& p, size_t group, const std::vector<lm_match_t>& matches, const std::vector<TemplatePose>& templates,
                       size_t from, size_t to, const MatchVerdict* v, std::vector<ObjectPose>& objPoses, Times* tm) const;
     // the two counts of colorCheck for one match, on the host (also the checker of the GPU path)
@@ -152,7 +169,10 @@ private:
     bool color_check(const lm_match_t& m, const std::vector<uint8_t>& color_mask) const;                    // :424-434
     std::string error;
     // decided_early (r05): the verdict "fails" came from median_mat_in_window's bounds, without the selection
-    bool depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth, bool* decided_early = nullptr) const;  // :437-457
+    // counts (r06): {values of the crop below the window, inside it, crop size} from the GPU, or nullptr
+    bool depth_check(const lm_match_t& m, const uint16_t* depth, const std::vector<TemplatePose>& t, int32_t* tempDepth, bool* decided_early = nullptr,
+                     const uint32_t* counts = nullptr) const;  // :437-457
+    void depth_window(const TemplatePose& tp, int* win_lo, int* win_hi) const;      // the medians that pass |depthDiff| < stepSize: [lo, hi] (empty: lo > hi)
     ObjectPose make_pose(const lm_match_t& m, const std::vector<TemplatePose>& t, int32_t tempDepth) const; // :459-515
     lm_detector* det;
     PostProcessSettings st;

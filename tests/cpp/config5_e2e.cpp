@@ -203,9 +203,10 @@ int main(int argc, char** argv) {
                 }
         };
         std::vector<std::vector<std::vector<ObjectPose>>> poses;
-        for (int pass = 0; pass < 4; ++pass) {       // 0 serial, 1 streamed pageable, 2 streamed pinned, 3 streamed with the host colour check
-            const char* tag = pass == 0 ? "serial" : pass == 1 ? "piped" : pass == 2 ? "pinned" : "hostcc";
+        for (int pass = 0; pass < 6; ++pass) {       // 0 serial, 1 streamed pageable, 2 streamed pinned, 3 streamed with the host colour check, r06: 4 the depth checks' early verdicts never / 5 always from GPU counts
+            const char* tag = pass == 0 ? "serial" : pass == 1 ? "piped" : pass == 2 ? "pinned" : pass == 3 ? "hostcc" : pass == 4 ? "hostdc" : "gpudc";
             line.setGpuColorCheck(pass != 3);
+            line.setGpuDepthCounts(pass == 4 ? 0 : pass == 5 ? 2 : 1);
             std::vector<std::vector<Image>> bt[3] = {make(0, pass == 2), make(1, pass == 2), make(2, pass == 2)};
             if (pass == 0) {
                 for (int bi = 0; bi < 3; ++bi) {
@@ -232,6 +233,7 @@ int main(int argc, char** argv) {
             std::printf("stream %s end_without_batch_refused %d\n", tag, pd.detectBatchEnd(1, none) ? 0 : 1);
         }
         line.setGpuColorCheck(true);
+        line.setGpuDepthCounts(1);
         lm_host_free(pin);
     }
     // ---- a Begin whose second half fails (here: a class the bank does not hold -> lm_match_begin_classes refuses) leaves nothing in

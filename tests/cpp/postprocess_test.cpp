@@ -152,6 +152,24 @@ int main() {
                     if (in) CHECK(got == want);
                     if (!e && !in) CHECK(got == want);
                     early += e; inside += in; outside_late += (!in && !e); ++total;
+                    // r06: the same early verdict from counts taken on the TRANSLATED frame -- what k_depth_counts counts on the resident frame for a query
+                    // built like PostProcessor::depth_queries (crop clipped to the frame, window clamped to 0 .. 65535): it must be the host's own, crop by crop
+                    {
+                        std::vector<uint16_t> tr;
+                        translate_u16(d.data(), W, H, ox, oy, tr);
+                        const int x0 = std::max(bb.x, 0), y0 = std::max(bb.y, 0), x1 = std::min(bb.x + bb.width, W), y1 = std::min(bb.y + bb.height, H);
+                        bool early2 = false;
+                        if (x1 > x0 && y1 > y0 && lo <= hi && lo <= 65535 && hi >= 0) {
+                            const int cl = std::max(0, std::min(lo, 65535)), ch = std::max(0, std::min(hi, 65535));
+                            size_t cb = 0, ci = 0;
+                            const size_t n = (size_t)(x1 - x0) * (size_t)(y1 - y0);
+                            for (int y = y0; y < y1; ++y)
+                                for (int x = x0; x < x1; ++x) { const int v = tr[(size_t)y * W + x], t = v <= 1 ? 65535 : v; cb += t < cl; ci += (t >= cl && t <= ch); }
+                            early2 = cb >= n / 4 + 1 || ci == 0;
+                        }
+                        CHECK(early2 == e);
+                        if (early2) CHECK(!in);
+                    }
                 }
             }
         }

@@ -233,14 +233,15 @@ def test_config5_pose_detection_batch_end_to_end(lm, tmp_path):
     # counts of a whole batch in one call on the colour-check stream, staging copies and depth checks on the pool -- give the SAME
     # poses, to the last printed digit, as one detectBatch per batch: with pageable frames, with pinned frames (row-offset DMA copy
     # instead of the shifted staging copy) and with the host colour check
-    passes = {tag: [l.split(" ", 2)[2] for l in out if l.startswith("stream %s batch" % tag)] for tag in ("serial", "piped", "pinned", "hostcc")}
+    passes = {tag: [l.split(" ", 2)[2] for l in out if l.startswith("stream %s batch" % tag)] for tag in ("serial", "piped", "pinned", "hostcc", "hostdc", "gpudc")}
     assert len(passes["serial"]) == 3 * 24
     tail = lambda l: l[l.index(" poses "):]                                                             # "poses n t .. q .. bb .."
     key = lambda l: tuple(l.split()[l.split().index("frame") + 1:l.split().index("frame") + 4:2])     # (frame, class)
     assert {key(l): tail(l) for l in passes["serial"][:24]} == {key(l): tail(l) for l in gpu}           # batch 0 = the detectBatch call above
     assert passes["piped"] == passes["serial"] and passes["pinned"] == passes["serial"] and passes["hostcc"] == passes["serial"]
+    assert passes["hostdc"] == passes["serial"] and passes["gpudc"] == passes["serial"]       # r06: the depth checks' early verdicts from GPU counts (never / always / when alone): same poses
     assert sum(1 for l in passes["serial"] if int(l.split()[l.split().index("poses") + 1]) > 0) >= 60                             # the objects are found in all three batches
-    for tag in ("piped", "pinned", "hostcc"):
+    for tag in ("piped", "pinned", "hostcc", "hostdc", "gpudc"):
         assert "stream %s third_begin_refused 1" % tag in out and "stream %s end_without_batch_refused 1" % tag in out
     # r06: a Begin that fails in its second half leaves nothing in flight; the serial API recovers
     rec = [l.split() for l in out if l.startswith("recovery ")][0]

@@ -452,3 +452,65 @@ def test_colour_check_of_a_batch_in_one_call_beside_a_busy_lane(lm, orc, synth):
     a5, b5 = d.color_check_counts(5, lo, hi, lists[0])                   # the same frame in a slot that never had a prepared mask
     assert np.array_equal(a4, a5) and np.array_equal(b4, b5)
     d.close()
+
+
+def test_depth_counts_of_a_batch_in_one_call(lm, synth):
+    """r06: lm_depth_counts_begin / _end -- per query the crop's values below the window and inside it, depths <= 1 counted as 65535 -- against numpy on
+    frames with holes, in several slots, also through a shifted upload (the resident frame is the translated one) and beside a busy lane; refusals."""
+    W, H = 640, 480
+    d = lm.Detector(lm.default_config(color_only=False, width=W, height=H, frame_slots=6))
+    rng = np.random.default_rng(5)
+    frames = []
+    for k in range(4):
+        bgr, depth = synth.make_frame(W, H, seed=700 + k)
+        depth = depth.copy()
+        depth[rng.integers(0, H, 4000), rng.integers(0, W, 4000)] = rng.integers(0, 2, 4000)       # holes: 0 and 1
+        frames.append((bgr, depth))
+    resident = []
+    for k in range(3):
+        d.upload_frame(k, *frames[k]); resident.append(frames[k][1])
+    sx, sy = 12, -9
+    d.upload_frame_shifted(3, frames[3][0], frames[3][1], sx, sy)
+    tr = np.zeros_like(frames[3][1])
+    ys, xs = max(sy, 0), max(sx, 0)
+    tr[ys:H + min(sy, 0), xs:W + min(sx, 0)] = frames[3][1][max(-sy, 0):H - max(sy, 0), max(-sx, 0):W - max(sx, 0)]
+    resident.append(tr)
+    d.upload_wait(-1)
+    n = 3000
+    q = np.zeros(n, lm.DEPTH_QUERY_DTYPE)
+    q["slot"] = rng.integers(0, 4, n)
+    q["x0"] = rng.integers(0, W - 1, n); q["y0"] = rng.integers(0, H - 1, n)
+    q["x1"] = np.minimum(q["x0"] + rng.integers(0, 300, n), W); q["y1"] = np.minimum(q["y0"] + rng.integers(0, 260, n), H)
+    q["lo"] = rng.integers(0, 1400, n); q["hi"] = np.minimum(q["lo"] + rng.integers(0, 400, n), 65535)
+    q["lo"][::17] = 65535; q["hi"][::17] = 65535                     # the holes' own value
+    q["lo"][::19] = 0
+    q[5]["x1"] = q[5]["x0"]                                           # an empty crop
+    q[6] = (0, 0, W, H, 600, 900, 2, 0)                               # the whole frame
+    # beside a busy lane: a match of the slots 4..5 is in flight while the counts of slots 0..3 are taken
+    d.upload_frame(4, *frames[0]); d.upload_frame(5, *frames[1])
+    descs, feats, _ = synth.make_bank(50, 2, 2, seed=3, frame_size=(W, H), T0=5)
+    d.add_class("c", descs, feats)
+    d.match_begin(1, 4, 2, 85.0)
+    below, inside = d.depth_counts(q)
+    d.match_end(1, 4096, n_slots=2)
+    for i in range(n):
+        crop = resident[q[i]["slot"]][q[i]["y0"]:q[i]["y1"], q[i]["x0"]:q[i]["x1"]].astype(np.int64)
+        t = np.where(crop <= 1, 65535, crop)
+        assert below[i] == int((t < q[i]["lo"]).sum()) and inside[i] == int(((t >= q[i]["lo"]) & (t <= q[i]["hi"])).sum()), (i, q[i])
+    assert below.sum() > 0 and inside.sum() > 0
+    b0, i0 = d.depth_counts(q[:0])
+    assert len(b0) == 0
+    bad = q[:2].copy(); bad[1]["x1"] = W + 1
+    with pytest.raises(lm.LinemodError):
+        d.depth_counts(bad)
+    bad = q[:2].copy(); bad[0]["slot"] = 6
+    with pytest.raises(lm.LinemodError):
+        d.depth_counts(bad)
+    below2, inside2 = d.depth_counts(q)                               # (a refused call leaves nothing in flight)
+    assert np.array_equal(below2, below) and np.array_equal(inside2, inside)
+    d.close()
+    c = lm.Detector(lm.default_config(color_only=True, width=W, height=H, frame_slots=2))
+    c.upload_frame(0, frames[0][0], None)
+    with pytest.raises(lm.LinemodError):
+        c.depth_counts(q[:4])                                         # no depth frame on the device
+    c.close()

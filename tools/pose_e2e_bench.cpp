@@ -88,6 +88,8 @@ int main(int argc, char** argv) {
         line.setColorRange((uint16_t)c, lo, hi);
     }
     line.setGpuColorCheck(!host_colour);
+    if (std::getenv("LM_E2E_HOST_DEPTH_COUNTS")) line.setGpuDepthCounts(0);
+    if (std::getenv("LM_E2E_GPU_DEPTH_COUNTS")) line.setGpuDepthCounts(2);      // A/B (r06): the depth checks' early verdicts from the host's own crop pass
     line.setPostThreads(threads);
     std::ifstream f(raw, std::ios::binary);
     const size_t cb = (size_t)W * H * 3, db = (size_t)W * H * 2;
