@@ -2715,20 +2715,21 @@ __device__ __forceinline__ void bs_fa(u32& c, u32 a, u32 b, u32& cy) {
     cy = __builtin_amdgcn_bitop3_b32(c, a, b, 0xE8);
     c = __builtin_amdgcn_bitop3_b32(c, a, b, 0x96);
 }
-template <int LEV, int NIN>
+// TOP: the counters' flag bit (7: they count to 127; 5 (r06, k_scanl): to 31 -- two half adders fewer per round and dword)
+template <int LEV, int NIN, int TOP = 7>
 __device__ __forceinline__ void bs_level(u32 (&c)[8], const u32 (&in)[8]) {
     if constexpr (NIN == 0) {
         return;
-    } else if constexpr (LEV == 7) {
+    } else if constexpr (LEV == TOP) {
 #pragma unroll
-        for (int i = 0; i < NIN; ++i) c[7] |= in[i];
+        for (int i = 0; i < NIN; ++i) c[TOP] |= in[i];
     } else {
         u32 out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         constexpr int NP = NIN / 2;
 #pragma unroll
         for (int i = 0; i < NP; ++i) bs_fa(c[LEV], in[2 * i], in[2 * i + 1], out[i]);
         if constexpr (NIN & 1) { out[NP] = c[LEV] & in[NIN - 1]; c[LEV] ^= in[NIN - 1]; }
-        bs_level<LEV + 1, NP + (NIN & 1)>(c, out);
+        bs_level<LEV + 1, NP + (NIN & 1), TOP>(c, out);
     }
 }
 __device__ __forceinline__ u32 wave_sum_u32(u32 v) {   // all lanes active
@@ -3050,6 +3051,70 @@ __device__ __forceinline__ void scanl_emit(const LmScanArgs& a, u32 sl, u32 ti, 
     }
 }
 
+// One lane item's rounds (k_scanl): counters of TOP + 1 bits, their flag = bit TOP, preset to 2^TOP - 1 - (misses allowed).  Returns true when the whole wave
+// stopped early; flags[q] = the flag dword of positions 32 q .. 32 q + 31 otherwise; f = features counted.
+template <int TOP>
+__device__ __forceinline__ bool scanl_rounds(const u8* lds, const __amdgpu_buffer_rsrc_t rs_off, u32 voff, u32 unit_add, u32 keep5, u32 pre, int valid, int Fw,
+                                             int first_test, unsigned long long& alive, u32 (&flags)[4], int& f_out) {
+    u32 c[4][8];
+#pragma unroll
+    for (int b = 0; b < TOP; ++b) {
+        const u32 bit = (u32)__builtin_amdgcn_sbfe((int)pre, (u32)b, 1u);   // 0 / ~0
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q][b] = bit;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int vq = valid - 32 * q;
+        c[q][TOP] = vq >= 32 ? 0u : (vq > 0 ? ~((1u << vq) - 1u) : 0xFFFFFFFFu);      // invalid positions start dead
+    }
+    // EVERY lane reads and counts in every round, dead or not: the kernel is bound by vector issue, not by LDS cycles (measured: dropping a fifth of
+    // the LDS accesses changed nothing), and exec-masked rounds cost the compiler 43 moves + 20 selects per round to merge a skipped round's
+    // counters with a counted one's.  A dead lane's flags stay all ones (the flag bit is sticky), a lane without an item reads template 0's planes.
+    bool pruned = false;
+    int f = 0;
+    // (the list entries of the NEXT round are requested before this round's LDS reads: a round's global round trip hides behind the round before it)
+    u32x4 n0 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, 0u, 0), n1 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, 16u, 0);
+    for (; f < Fw && !pruned; f += 8) {
+        {
+            const u32x4 e0 = n0, e1 = n1;
+            // (past the last round: the same entries once more -- a branch here would bring the merges back)
+            const u32 nf = (u32)(f + 8 < Fw ? f + 8 : f) * 4u;
+            n0 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, nf, 0);
+            n1 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, nf + 16u, 0);
+            const u32 e[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
+            u32 v[8][5];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const u32* p = reinterpret_cast<const u32*>(lds + ((e[k] + unit_add) >> 8));
+                v[k][0] = p[0]; v[k][1] = p[1]; v[k][2] = p[2]; v[k][3] = p[3];
+            }
+            // the fifth dword is the next lane's first (the next unit of the same template) -- a DPP move instead of a fifth LDS access --
+            // except in a template's LAST unit, whose neighbour belongs to another template: there it counts as "no miss"
+            // for every feature.  That only weakens the bound of the unit's last positions (a few more survivors; the second stage decides).
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k][4] = next_lane(v[k][0]) & keep5;       // (an AND, not a select: the DPP move must run on the last units' lanes too -- they are its sources)
+            u32 x[4][8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q][k] = __builtin_amdgcn_alignbit(v[k][q + 1], v[k][q], e[k]);   // (the instruction takes bits 4..0 of the entry)
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bs_level<0, 8, TOP>(c[q], x[q]);
+        }
+        if (f + 8 > first_test && f + 8 < Fw) {
+            const unsigned long long left = __ballot((c[0][TOP] & c[1][TOP] & c[2][TOP] & c[3][TOP]) != 0xFFFFFFFFu) & alive;
+            if (!left) pruned = true;
+            else alive = left;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) flags[q] = c[q][TOP];
+    f_out = f;
+    return pruned;
+}
+
 __device__ __forceinline__ u32 tabs_at(const u8* lds, u32 img, u32 sv, u32 ori) { return lds[img + sv * 8u + ori]; }
 __global__ __launch_bounds__(1024) void k_scanl(LmScanArgs a) {
     extern __shared__ u32x4 scanl_lds[];
@@ -3128,71 +3193,26 @@ __global__ __launch_bounds__(1024) void k_scanl(LmScanArgs a) {
         valid = valid < 0 ? 0 : (valid > 128 ? 128 : valid);
         unsigned long long alive = __ballot(valid > 0);
         if (!alive) continue;
-        u32 c[4][8];
-#pragma unroll
-        for (int b = 0; b < 7; ++b) {
-            const u32 bit = (u32)__builtin_amdgcn_sbfe((int)pre, (u32)b, 1u);   // 0 / ~0
-#pragma unroll
-            for (int q = 0; q < 4; ++q) c[q][b] = bit;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int vq = valid - 32 * q;
-            c[q][7] = vq >= 32 ? 0u : (vq > 0 ? ~((1u << vq) - 1u) : 0xFFFFFFFFu);      // invalid positions start dead
-        }
         // (wave-uniform, and told so: the round loop's bounds and the lists' scalar offsets hang on them)
         const int Fw = __builtin_amdgcn_readfirstlane((int)wave_max_u32(valid > 0 ? (u32)F : 0u));
+        const int mm_hi = __builtin_amdgcn_readfirstlane((int)wave_max_u32(valid > 0 ? (u32)mmax : 0u));
         const int first_test = 127 - __builtin_amdgcn_readfirstlane((int)wave_max_u32(valid > 0 ? pre : 0u));            // the smallest miss budget of the wave: nothing dies before
         const u32 voff = ti * (u32)a.fpad1 * 4u;
         const u32 unit_add = (unit * 16u) << 8;
         const u32 keep5 = (j0 + 128 >= P || lane == 63) ? 0u : 0xFFFFFFFFu;
-        // EVERY lane reads and counts in every round, dead or not: the kernel is bound by vector issue, not by LDS cycles (measured: dropping a fifth of
-        // the LDS accesses changed nothing), and exec-masked rounds cost the compiler 43 moves + 20 selects per round to merge a skipped round's
-        // counters with a counted one's.  A dead lane's flags stay all ones (the flag bit is sticky), a lane without an item reads template 0's planes.
-        bool pruned = false;
-        int f = 0;
-        // (the list entries of the NEXT round are requested before this round's LDS reads: a round's global round trip hides behind the round before it)
-        u32x4 n0 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, 0u, 0), n1 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, 16u, 0);
-        for (; f < Fw && !pruned; f += 8) {
-            st_l += 8u * 64u;                                   // (every lane reads: see above)
-            {
-                const u32x4 e0 = n0, e1 = n1;
-                // (past the last round: the same entries once more -- a branch here would bring the merges back)
-                const u32 nf = (u32)(f + 8 < Fw ? f + 8 : f) * 4u;
-                n0 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, nf, 0);
-                n1 = __builtin_amdgcn_raw_buffer_load_b128(rs_off, voff, nf + 16u, 0);
-                const u32 e[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
-                u32 v[8][5];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const u32* p = reinterpret_cast<const u32*>(lds + ((e[k] + unit_add) >> 8));
-                    v[k][0] = p[0]; v[k][1] = p[1]; v[k][2] = p[2]; v[k][3] = p[3];
-                }
-                // the fifth dword is the next lane's first (the next unit of the same template) -- a DPP move instead of a fifth LDS access --
-                // except in a template's LAST unit, whose neighbour belongs to another template: there it counts as "no miss"
-                // for every feature.  That only weakens the bound of the unit's last positions (a few more survivors; the second stage decides).
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k][4] = next_lane(v[k][0]) & keep5;       // (an AND, not a select: the DPP move must run on the last units' lanes too -- they are its sources)
-                u32 x[4][8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) x[q][k] = __builtin_amdgcn_alignbit(v[k][q + 1], v[k][q], e[k]);   // (the instruction takes bits 4..0 of the entry)
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bs_level<0, 8>(c[q], x[q]);
-            }
-            if (f + 8 > first_test && f + 8 < Fw) {
-                const unsigned long long left = __ballot((c[0][7] & c[1][7] & c[2][7] & c[3][7]) != 0xFFFFFFFFu) & alive;
-                if (!left) pruned = true;
-                else alive = left;
-            }
-        }
+        u32 flags[4];
+        bool pruned;
+        int f;
+        // counters of 6 bits (flag = bit 5) when no template of the wave may miss more than 31 features -- the usual case: 24 at threshold 80 with 62
+        // features -- two half adders fewer per round and dword; 8 bits otherwise
+        if (mm_hi <= 31) pruned = scanl_rounds<5>(lds, rs_off, voff, unit_add, keep5, (u32)(31 - mmax), valid, Fw, first_test, alive, flags, f);
+        else pruned = scanl_rounds<7>(lds, rs_off, voff, unit_add, keep5, pre, valid, Fw, first_test, alive, flags, f);
+        st_l += (unsigned long long)f * 64ull;                                   // (every lane reads in every round)
         st_f += (unsigned long long)(f < Fw ? f : Fw); st_F += (unsigned long long)Fw;
         // survivors: positions never flagged (a dead or idle lane's flags are all ones)
         u32 h[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) h[q] = (pruned || !((alive >> lane) & 1ull)) ? 0u : ~c[q][7];
+        for (int q = 0; q < 4; ++q) h[q] = (pruned || !((alive >> lane) & 1ull)) ? 0u : ~flags[q];
         const u32 nh = (u32)(__popc(h[0]) + __popc(h[1]) + __popc(h[2]) + __popc(h[3]));
         if (nh && !a.no_exact) {
             const u32 at = atomicAdd(qcount, nh);
