@@ -277,6 +277,10 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
 /* LM_TUNE_SCAN1_MIN_THRESHOLD (r05): similarity threshold in percent (0..100, default 50) below which LM_TUNE_SCAN_FORM 0 keeps
  *   k_scan4: the lower the threshold the more positions survive the miss bound and need their exact sums. */
 #define LM_TUNE_SCAN1_MIN_THRESHOLD 17
+/* LM_TUNE_CGRAD_LEVELS (r06): 1 (default) = a batch's colour-gradient orientation + vote passes of pyramid levels 0 and 1 run in ONE launch (level 1 of a
+ *   640 x 480 frame is a handful of waves: behind level 0's workgroups they fill idle SIMDs instead of a launch of their own that leaves half the chip
+ *   without a wave); 0 = one launch per level (r02-r05).  Same labels either way. */
+#define LM_TUNE_CGRAD_LEVELS 18
 int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 /* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame

@@ -507,8 +507,20 @@ void enqueue_preprocess(lm_detector* d, int first, int n) {
     // batches: the level-0 blur and pyrDown 0 -> 1 share one slot-interleaved launch (the raw image comes from HBM once)
     const bool blur_pyr = L >= 2 && lmk_blur_pyrdown(d->stream, d->bgr(first, 0), d->lw[0], d->lh[0], d->cscratch(first, 0), d->bgr(first, 1),
                                                       d->quant(first, 0, 0), fs, n);
+    // r06: two levels, level-0 blur + pyrDown done: the level-1 blur next, then BOTH levels' gradients in one grid (k_cgrad_levels: level 1's few waves fill the
+    // idle SIMDs of level 0's last round instead of a launch of their own)
+    bool grads_done = false;
+    if (L == 2 && blur_pyr && d->lw[1] * 2 == d->lw[0] && d->lh[1] * 2 == d->lh[0] && lmk_cgrad_levels_wanted(d->lw[0], d->lh[0], n) &&
+        lmk_color_blur(d->stream, d->bgr(first, 1), d->lw[1], d->lh[1], d->cscratch(first, 1), fs, n)) {
+        grads_done = lmk_cgrad_levels(d->stream, d->cscratch(first, 0), d->lw[0], d->lh[0], d->quant(first, 0, 0), d->cscratch(first, 1), d->lw[1], d->lh[1],
+                                      d->quant(first, 1, 0), c.weak_threshold, fs, n);
+        if (!grads_done)     // (the blur of level 1 is in its scratch: the gradients one launch per level)
+            for (int l = 0; l < L; ++l) lmk_color_quantize(d->stream, d->bgr(first, l), d->lw[l], d->lh[l], c.weak_threshold, d->quant(first, l, 0), nullptr, d->cscratch(first, l), fs, n, true);
+        grads_done = true;
+    }
     for (int l = 0; l < L; ++l) {
         if (l > 0 && !(l == 1 && blur_pyr)) lmk_pyrdown(d->stream, d->bgr(first, l - 1), d->lw[l - 1], d->lh[l - 1], d->bgr(first, l), fs, n);
+        if (!grads_done)
         lmk_color_quantize(d->stream, d->bgr(first, l), d->lw[l], d->lh[l], c.weak_threshold, d->quant(first, l, 0),
                            nullptr, d->cscratch(first, l), fs, n, l == 0 && blur_pyr);
         if (M == 2 && l == 0)
@@ -1656,6 +1668,7 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
             for (Slot& sl : d->slots) sl.prepared = false;          // (prepared slots may lack the miss planes the new form reads)
             return LM_OK;
         case LM_TUNE_SCAN1_MIN_THRESHOLD: if (value < 0 || value > 100) break; d->scan1_min_threshold = (float)value; return LM_OK;
+        case LM_TUNE_CGRAD_LEVELS: if (value < 0 || value > 1) break; lmk_set_cgrad_levels(value); return LM_OK;
         default: return fail(LM_ERR_INVALID, "unknown tuning key");
     }
     return fail(LM_ERR_INVALID, "tuning value out of range");

@@ -23,6 +23,11 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
 // launch, so that the raw image is read from HBM once.  false: shape not supported, nothing launched (the caller launches
 // the two kernels itself).
 bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0, u8* bgr1, u8* quant0, size_t slot_stride, int nslots);
+// r06: a batch's level-0 and level-1 gradients in one grid (the level-1 blur must have run): see lm_kernels.hip k_cgrad_levels
+bool lmk_color_blur(hipStream_t s, const u8* bgr, int w, int h, u8* scratch, size_t slot_stride, int nslots);
+bool lmk_cgrad_levels_wanted(int w0, int h0, int nslots);
+bool lmk_cgrad_levels(hipStream_t s, const u8* S0, int w0, int h0, u8* q0, const u8* S1, int w1, int h1, u8* q1, float weak_threshold, size_t slot_stride, int nslots);
+void lmk_set_cgrad_levels(int v);
 void lmk_set_blur_pyr(int v);
 void lmk_set_blur_pyr_interleave(int v);
 void lmk_set_slot_weight(int w);   // frames count `w` times in the few-frame / batch kernel selection of this host thread's launches (1 = 640 x 480 frames)

@@ -1294,6 +1294,19 @@ __global__ __launch_bounds__(256, 2) void k_cgrad(const u8* __restrict__ s0, int
     d_cgrad<STRIP>(blockIdx.x, s0, w, h, ithr, quant0, tmp_stride, out_stride, gblocks, nslots);
 }
 
+// r06: the orientation + vote passes of level 0 AND level 1 in ONE grid.  Level 1 of a 640 x 480 frame is 5 waves of 16-row strips (10
+// of 8-row strips): a launch of its own leaves more than half of the SIMDs without a wave (k_cgrad<8>: 37 us per 96 frames at VALU busy 0.39 for a quarter of
+// the pixels that cost k_cgrad<16> 68 us).  Behind level 0's workgroups in the same grid its strips fill the last round's idle SIMDs instead.  Needs the level-1
+// blur BEFORE the level-0 gradient (lm_detector.hip enqueue_preprocess orders the launches so).
+template <int STRIP>
+__global__ __launch_bounds__(256, 2) void k_cgrad_levels(const u8* __restrict__ s0, int w0, int h0, u8* __restrict__ q0, int g0,
+                                                         const u8* __restrict__ s1, int w1, int h1, u8* __restrict__ q1, int g1,
+                                                         int ithr, size_t slot_stride, int nslots) {
+    const u32 e0 = (u32)g0 * (u32)nslots;
+    if (blockIdx.x < e0) d_cgrad<STRIP>(blockIdx.x, s0, w0, h0, ithr, q0, slot_stride, slot_stride, g0, nslots);
+    else d_cgrad<8>(blockIdx.x - e0, s1, w1, h1, ithr, q1, slot_stride, slot_stride, g1, nslots);      // (8-row strips: short workgroups at the end of the grid -- the tail is one of THEM long)
+}
+
 // ------------------------------------------------------------------------------------------------
 // a5  DepthNormal::process -> quantizedNormals + medianBlur(5).  64x8 outputs per workgroup; the
 // depth tile (+-7) and the raw normals (+-2) live in LDS.
@@ -4414,6 +4427,45 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
     }
     dim3 grid((w + CT_W - 1) / CT_W, (h + CT_H - 1) / CT_H, nslots);
     hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, w, h, thr2, quant, mag, slot_stride);
+}
+
+// r06: the two halves of lmk_color_quantize for batches whose level-0 and level-1 gradients share a grid.  lmk_color_blur: the level's Gaussian blur into
+// `scratch` alone (false: this shape takes the fused LDS-tiled kernel, nothing launched).  lmk_cgrad_levels: orientation + vote of both levels from their blurred
+// images (false: not a batch / shape not supported, nothing launched).
+bool lmk_color_blur(hipStream_t s, const u8* bgr, int w, int h, u8* scratch, size_t slot_stride, int nslots) {
+    if (!(scratch && (w % 16) == 0 && ((uintptr_t)bgr & 15) == 0 && ((uintptr_t)scratch & 15) == 0 && (slot_stride % 16) == 0)) return false;
+    u8* S = scratch;
+    if ((g_cblur_variant == 4 || mx_auto(w, h, nslots)) && ((w * 3) % 32) == 0 && h >= 1) {
+        const int gx = (w * 3 + 4 * MX_WAVE_BYTES - 1) / (4 * MX_WAVE_BYTES);
+        const int strip_rows = mx_strip_rows();
+        const int gy = (h + strip_rows - 1) / strip_rows;
+        hipLaunchKernelGGL(k_cblur_mx, dim3((unsigned)(gx * gy * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, gx, gy, strip_rows, nslots);
+        return true;
+    }
+    if (g_cblur_variant == 1 || (g_cblur_variant == 0 && sel_slots(nslots) < 16)) return false;
+    if (h > 640) {
+        const int n_w = (((w * 3 / 16) * ((h + 31) / 32) + 61) / 62 + 3) / 4;
+        hipLaunchKernelGGL(k_cblur_sh<32>, dim3((unsigned)(n_w * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, n_w, nslots);
+    } else {
+        const int n_w = (((w * 3 / 16) * ((h + CBS_STRIP - 1) / CBS_STRIP) + 61) / 62 + 3) / 4;
+        hipLaunchKernelGGL(k_cblur_sh<CBS_STRIP>, dim3((unsigned)(n_w * nslots)), dim3(256), 0, s, bgr, w, h, S, slot_stride, slot_stride, n_w, nslots);
+    }
+    return true;
+}
+static int g_cgrad_levels = 1;       // LM_TUNE_CGRAD_LEVELS: 1 (default) the two levels' gradients of a batch in one grid, 0 one launch per level
+void lmk_set_cgrad_levels(int v) { g_cgrad_levels = v; }
+bool lmk_cgrad_levels_wanted(int w0, int h0, int nslots) {
+    return g_cgrad_levels != 0 && (g_cgrad_variant == 0 || g_cgrad_variant == 2) && sel_slots(nslots) >= 16 && (w0 % 32) == 0 && (h0 % 2) == 0 && h0 <= 640;
+}
+bool lmk_cgrad_levels(hipStream_t s, const u8* S0, int w0, int h0, u8* q0, const u8* S1, int w1, int h1, u8* q1, float weak_threshold, size_t slot_stride, int nslots) {
+    if (!lmk_cgrad_levels_wanted(w0, h0, nslots)) return false;
+    if ((((uintptr_t)S0 | (uintptr_t)S1 | (uintptr_t)q0 | (uintptr_t)q1) & 15) != 0 || (slot_stride % 16) != 0 || (w1 % 16) != 0) return false;
+    const float thr2 = weak_threshold * weak_threshold;
+    const int ithr = thr2 >= 2147483648.f ? INT_MAX : (int)floorf(thr2);
+    auto blocks = [&](int w, int h, int strip) { return ((((w / 16) * ((h + strip - 1) / strip) + 61) / 62) + 3) / 4; };
+    const int g0 = blocks(w0, h0, CG_STRIP), g1 = blocks(w1, h1, 8);
+    hipLaunchKernelGGL(k_cgrad_levels<CG_STRIP>, dim3((unsigned)((g0 + g1) * nslots)), dim3(256), 0, s, S0, w0, h0, q0, g0, S1, w1, h1, q1, g1, ithr, slot_stride, nslots);
+    return true;
 }
 
 void lmk_depth_quantize(hipStream_t s, const u16* depth, int w, int h, int dist_thr, int diff_thr, const u8* lut,

@@ -93,6 +93,7 @@ while time.time() - t0 < budget:
         d.set_tuning(lm.TUNE_BATCH_PHASES, int(rng.choice([0, 1, 2])))     # 16+ frames: level-fused batch launches or one per kernel
         d.set_tuning(lm.TUNE_BLUR_PYR, int(rng.choice([0, 1, 2, 3])))         # level-0 blur + pyrDown apart, in one launch back to back, or dealt out evenly
         d.set_tuning(lm.TUNE_BLUR_STRIP, int(rng.choice([0, 16, 32, 64])))      # rows per blur strip inside k_blur_pyr
+        d.set_tuning(lm.TUNE_CGRAD_LEVELS, int(rng.choice([0, 1])))             # r06: the two levels' gradients of a batch in one launch or two
         d.set_tuning(lm.TUNE_SCAN_LIST_ORDER, int(rng.choice([0, 1, 2, 3])))    # order of the scan's feature lists (same sums)
         d.set_tuning(lm.TUNE_SCAN_FORM, int(rng.choice([0, 1, 2, 3, 3])))
         # r05: every way a frame reaches a slot -- the one-call upload, the staged upload (rows in random pieces; a zero shift here, the

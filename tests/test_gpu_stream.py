@@ -262,6 +262,7 @@ def test_batches_take_one_launch_per_dependency_level(lm, orc, synth, color_only
         d.set_tuning(lm.TUNE_BATCH_PHASES, phases)
         d.set_tuning(lm.TUNE_BLUR_STRIP, (0, 16, 32, 64)[(phases + 2 * pairs + blur_pyr) % 4])      # rows per blur strip inside k_blur_pyr
         d.set_tuning(lm.TUNE_BLUR_PYR, blur_pyr)     # level-0 blur + pyrDown apart (0), in one launch back to back per slot (1), or dealt out evenly (2)
+        d.set_tuning(lm.TUNE_CGRAD_LEVELS, (phases + pairs) % 2)      # r06: the two levels' gradients in one launch (1) or one launch per level (0); used when phases == 0
         for nb in (n, 16):
             out, cnt = d.match_batch(nb, THR, 0)
             for k in range(nb):
@@ -278,6 +279,7 @@ def test_batches_take_one_launch_per_dependency_level(lm, orc, synth, color_only
                     assert np.array_equal(d.debug_read(k, 2, level, mod), o.stage(2, level, mod)), (phases, blur_pyr, pairs, k, level, mod)
     d.set_tuning(lm.TUNE_BLUR_PYR, 3)
     d.set_tuning(lm.TUNE_BLUR_STRIP, 0)
+    d.set_tuning(lm.TUNE_CGRAD_LEVELS, 1)
     d.close()
 
 
