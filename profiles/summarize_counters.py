@@ -4,7 +4,7 @@ requests and L2 hits (TCP_* / TCC_*), vector-ALU activity (SQ_*), and the comman
 file ONLY for the command and the kernel sources it was collected with (a stale file must not describe another workload).
 
   python profiles/summarize_counters.py <out.json> <bench json line of the one-lane run> <kernel-stats dir> \
-         [F=<dir of --pmc FETCH_SIZE>] [W=<dir WRITE_SIZE>] [TCP=<dir>] [TCC=<dir>] [SQ=<dir>] [TCPNP=<dir TCP pass of --no-prune>] \
+         [F=<dir of --pmc FETCH_SIZE>] [W=<dir WRITE_SIZE>] [TCP=<dir>] [TCC=<dir>] [SQ=<dir>] [LDS=<dir>] [TCPNP=<dir TCP pass of --no-prune>] \
          [NPJSON=<bench json line of the --no-prune run>]
 
 Units / corrections (MI355X_MICROARCH.md, "HBM" and "rocprofv3 PMC"): FETCH_SIZE and WRITE_SIZE are in KB (x 1024); on gfx950
@@ -71,7 +71,7 @@ def main():
     ks = kernel_stats(stats_dir)
     for k, v in ks.items():
         res["kernels"][k] = dict(v)
-    passes = {p: counters(opt[p]) for p in ("F", "W", "TCP", "TCC", "SQ") if p in opt}
+    passes = {p: counters(opt[p]) for p in ("F", "W", "TCP", "TCC", "SQ", "LDS") if p in opt}      # (LDS, r06: SQ_INSTS_LDS, SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT -- k_scanl reads its planes from LDS)
     for p, tab in passes.items():
         for k, cs in tab.items():
             e = res["kernels"].setdefault(k, {})

@@ -129,3 +129,38 @@ def test_comm_init_failure_leaves_nothing_behind(lm, orc, synth):
     _gathered_lists(d, lm, 0, 0, 2, 80.0)
     d.comm_destroy()
     d.close()
+
+
+@pytest.mark.parametrize("color_only,form,slots", [(True, 0, 16), (True, 2, 8), (False, 3, 8), (False, 0, 32)])
+def test_gathered_call_through_the_bit_plane_scans(lm, orc, synth, color_only, form, slots):
+    """r06: the gathered path (k_pack_lists + 2 x ncclAllGather on a single-rank communicator) behind the bit-plane scans -- a colour-only
+    detector whose 16-frame call takes k_scan1 by cost (8 frames: forced), an RGB-D detector under the LDS-resident form k_scanl (forced on 8 frames, by cost on 32):
+    the gathered lists equal lm_match_batch's and the oracle's."""
+    d = lm.Detector(color_only=color_only, width=W, height=H, frame_slots=slots)
+    o = orc.Detector(color_only=color_only)
+    frames = [synth.make_frame(W, H, seed=140 + i) for i in range(4)]
+    dep = lambda k: None if color_only else frames[k % 4][1]
+    o.prepare(frames[0][0], dep(0))
+    M = 1 if color_only else 2
+    q = {(l, m): o.stage(0, l, m).reshape(H >> l, W >> l) for l in range(2) for m in range(M)}
+    descs, feats, _ = synth.make_bank(150, M, 2, seed=5, quantized=q, crop_fraction=0.3, frame_size=(W, H), T0=d.get_T(0))
+    d.add_class("c", descs, feats); o.add_class("c", descs, feats)
+    for i in range(slots):
+        d.upload_frame(i, frames[i % 4][0], dep(i))
+    thr = 82.0
+    exp = [o.match(frames[k][0], dep(k), thr, 0, threads=8) for k in range(4)]
+    assert sum(len(e) for e in exp) > 4
+    d.set_tuning(lm.TUNE_SCAN_FORM, form)
+    d.comm_init(0, 1, "127.0.0.1", _free_port())
+    before = d.get_scan_form_stats()
+    got = _gathered_lists(d, lm, 0, 0, slots, thr)
+    after = d.get_scan_form_stats()
+    assert after[0] - before[0] >= 1                                    # the launch was a bit-plane scan ...
+    assert (after[3] >= 1000) == (not color_only)                       # ... k_scanl for the RGB-D detector, k_scan1 for the colour-only one
+    for i in range(slots):
+        assert_matches_equal(got[i], exp[i % 4])
+    ref, c = d.match_batch(slots, thr, 0, cap_per_frame=1 << 14)
+    for i in range(slots):
+        assert_matches_equal(ref[i, :c[i]], got[i])
+    d.comm_destroy()
+    d.close()
