@@ -649,6 +649,8 @@ int scanl_rule(const lm_detector* d, int nslots) {
 int pick_scanl(const lm_detector* d, int first, int nslots, int n_litems) {
     if (d->bank_dirty || !d->hb.lds_ok || !d->d_litem || d->scan_form == 2 || d->scan_form == 1 || n_litems <= 0) return 0;
     for (int i = 0; i < nslots; ++i) if (!d->slots[first + i].planes || !d->slots[first + i].spread_low) return 0;
+    // (by cost: calls of few frames stay with k_scan1, which such slots can take as well -- the threshold rule no longer matters: a bit-plane form it is)
+    if (d->scan_form == 0 && nslots < d->scanl_min_slots) return 0;
     return scanl_shares(d, nslots, n_litems);
 }
 
