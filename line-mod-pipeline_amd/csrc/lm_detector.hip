@@ -58,6 +58,7 @@ struct Slot {
     unsigned long long up_seq = 0;
     int up_stream = 0;               // which copy stream carried the upload (tickets are per stream)
     bool mask_ready = false;         // the slot's colour bit mask holds inRange(HSV(frame), mask_lo, mask_hi) of the frame the slot holds (lm_color_mask_prepare)
+    int mask_lane = -1;              // ... written on that lane's stream (its mask_done event orders a later colour check behind the launch)
     int mask_lo[3] = {0, 0, 0}, mask_hi[3] = {0, 0, 0};
     bool staging_open = false;       // lm_stage_reserve has run: lm_stage_rows may fill the staging buffers, lm_upload_staged sends them
     bool matched = false;            // a match on the frame the slot holds has completed: its lists are still in the slot's result block (lm_match_collect)
@@ -134,6 +135,8 @@ struct lm_detector {
     size_t cc_pending = 0; bool cc_inflight = false;                      // lm_color_check_begin_slots enqueued a check of cc_pending matches
     u8* dc_dev = nullptr; u8* dc_host = nullptr; size_t dc_cap = 0;       // r06, lm_depth_counts_begin: room for dc_cap queries | two counts each
     size_t dc_pending = 0; bool dc_inflight = false;
+    int cc_lo = 0, cc_hi = -1, dc_lo = 0, dc_hi = -1;                   // slots a colour check / depth counts in flight read: no upload goes there
+    hipEvent_t mask_done[LM_NLANES] = {};                                // behind the mask launch of lm_color_mask_prepare on a lane: a colour check that reuses the masks waits for it
     hipEvent_t cc_done = nullptr, dc_done = nullptr;                      // behind the colour check's / the depth counts' last copy: their `end` waits for the event, not the stream
     LmComm* comm[LM_NLANES] = {};   // one communicator per lane: the lanes' collectives never wait for each other
     int comm_recs_per_frame = 0;
@@ -414,6 +417,12 @@ void enqueue_depth_pyramid(lm_detector* d, int first, int n) {
 }
 
 int wait_uploads(lm_detector* d, hipStream_t stream, int first, int n, unsigned long long* seqs);
+// an upload must not overwrite a frame that a colour check / depth-count call in flight is reading on the colour-check stream
+int refuse_checked_slots(const lm_detector* d, int first, int n) {
+    if (d->cc_inflight && d->cc_pending && first <= d->cc_hi && d->cc_lo < first + n) return fail(LM_ERR_INVALID, "slot is read by a colour check in flight: call lm_color_check_end first");
+    if (d->dc_inflight && d->dc_pending && first <= d->dc_hi && d->dc_lo < first + n) return fail(LM_ERR_INVALID, "slot is read by depth counts in flight: call lm_depth_counts_end first");
+    return LM_OK;
+}
 
 // The miss planes of the scanned level are written (by the pass that writes its nibble memories) only where the bit-plane scan can run: they
 // cost k_lm_fast a second set of scattered stores (measured r05: 16.2 -> 24.4 us per 96-frame launch of config 2, 70 -> 115 us per 128 frames
@@ -1055,6 +1064,7 @@ int upload_frame(lm_detector* d, int slot, const uint8_t* bgr, size_t bgr_stride
     if (bgr_stride < (size_t)c.width * 3 || depth_stride < (size_t)c.width * 2) return fail(LM_ERR_INVALID, "stride smaller than a row");
     for (const lm_detector::Lane& ln : d->lanes)
         if (ln.busy && slot >= ln.first && slot < ln.first + ln.n) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
+    if (int crc = refuse_checked_slots(d, slot, 1)) return crc;
     int rc;
     s.prepared = false; s.matched = false; s.mask_ready = false; s.staging_open = false;
     shift_x = clamp_shift(shift_x, c.width); shift_y = clamp_shift(shift_y, c.height);     // (beyond: an all-zero frame either way)
@@ -1340,6 +1350,7 @@ void lm_destroy(lm_detector* d) {
         if (d->cc_stream) hipStreamDestroy(d->cc_stream);
         hipFree(d->cc_dev); if (d->cc_host) hipHostFree(d->cc_host);
         hipFree(d->dc_dev); if (d->dc_host) hipHostFree(d->dc_host);
+        for (hipEvent_t& ev : d->mask_done) if (ev) hipEventDestroy(ev);
         if (d->cc_done) hipEventDestroy(d->cc_done);
         if (d->dc_done) hipEventDestroy(d->dc_done);
         hipFree(d->d_resp_tab); hipFree(d->d_sim_lut); hipFree(d->d_normal_lut); hipFree(d->d_scratch);
@@ -1516,6 +1527,7 @@ int lm_upload_frames_pinned(lm_detector* d, int first_slot, int n_slots, const u
     if (frame_stride < fb) return fail(LM_ERR_INVALID, "frame stride smaller than a frame");
     for (const lm_detector::Lane& ln : d->lanes)
         if (ln.busy && first_slot < ln.first + ln.n && ln.first < first_slot + n_slots) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
+    if (int crc = refuse_checked_slots(d, first_slot, n_slots)) return crc;
     for (int i = 0; i < n_slots; ++i) if ((rc = wait_slot_upload(d, d->slots[first_slot + i]))) return rc;
     // one strided transfer: row i = host frame i ([colour | depth] dense), destination pitch = the arena's slot stride
     const int cs = (first_slot / n_slots) % d->n_copy_streams;   // consecutive runs of n_slots slots take turns on the copy streams
@@ -1550,6 +1562,7 @@ int lm_stage_reserve(lm_detector* d, int first_slot, int n_slots) {
     if ((rc = check_slots(d, first_slot, n_slots))) return rc;
     for (const lm_detector::Lane& ln : d->lanes)
         if (ln.busy && first_slot < ln.first + ln.n && ln.first < first_slot + n_slots) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
+    if (int crc = refuse_checked_slots(d, first_slot, n_slots)) return crc;
     for (int i = 0; i < n_slots; ++i) {
         Slot& s = d->slots[first_slot + i];
         if ((rc = wait_slot_upload(d, s))) return rc;
@@ -1587,6 +1600,7 @@ int lm_upload_staged(lm_detector* d, int slot) {
     if (!s.staging_open) return fail(LM_ERR_INVALID, "lm_stage_reserve first");
     for (const lm_detector::Lane& ln : d->lanes)
         if (ln.busy && slot >= ln.first && slot < ln.first + ln.n) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
+    if (int crc = refuse_checked_slots(d, slot, 1)) return crc;
     const lm_config& c = d->cfg;
     const int cs = slot % d->n_copy_streams;
     hipStream_t st = d->copy_stream[cs];
@@ -1998,6 +2012,16 @@ static int colour_check_enqueue(lm_detector* d, const int32_t* slot_of, int one_
     if (!prepared) {
         lmk_hsv_mask(st, d->bgr(s_lo, 0), d->cfg.width, d->cfg.height, rg, d->d_hsv_div, mask, d->cmask_wpr, d->frame_stride, d->frame_stride, s_hi - s_lo + 1);
         for (int sl = s_lo; sl <= s_hi; ++sl) d->slots[(size_t)sl].mask_ready = false;      // (overwritten for this call's range; not recorded as prepared)
+    } else {
+        // the masks were written on a lane's stream (lm_color_mask_prepare): the hull kernel waits for that launch, whether or not the lane's match was
+        // collected in between
+        bool waited[LM_NLANES] = {};
+        for (int sl = s_lo; sl <= s_hi; ++sl) {
+            const Slot& sm = d->slots[(size_t)sl];
+            if (!used[(size_t)sl] || sm.mask_lane < 0 || sm.mask_lane >= LM_NLANES || waited[sm.mask_lane] || !d->mask_done[sm.mask_lane]) continue;
+            HIP_TRY(hipStreamWaitEvent(st, d->mask_done[sm.mask_lane], 0));
+            waited[sm.mask_lane] = true;
+        }
     }
     LmHullArgs a;
     a.matches = reinterpret_cast<const LmOutMatch*>(d->cc_dev); a.n = (u32)n;
@@ -2012,7 +2036,7 @@ static int colour_check_enqueue(lm_detector* d, const int32_t* slot_of, int one_
     }
     HIP_TRY(hipMemcpyAsync(d->cc_host + off_out, a.out, n * 2 * sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(d->cc_done, st));
-    d->cc_pending = n; d->cc_inflight = true;
+    d->cc_pending = n; d->cc_inflight = true; d->cc_lo = s_lo; d->cc_hi = s_hi;
     return LM_OK;
 }
 
@@ -2063,9 +2087,11 @@ int lm_color_mask_prepare(lm_detector* d, int lane, int first_slot, int n_slots,
     if (!rc) {
         u32* mask = reinterpret_cast<u32*>(d->frame_arena + (size_t)first_slot * d->frame_stride + d->off_cmask);
         lmk_hsv_mask(d->stream, d->bgr(first_slot, 0), d->cfg.width, d->cfg.height, rg, d->d_hsv_div, mask, d->cmask_wpr, d->frame_stride, d->frame_stride, n_slots);
+        if (!d->mask_done[lane]) HIP_TRY(hipEventCreateWithFlags(&d->mask_done[lane], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(d->mask_done[lane], d->stream));
         for (int i = 0; i < n_slots; ++i) {
             Slot& s = d->slots[first_slot + i];
-            s.mask_ready = true;
+            s.mask_ready = true; s.mask_lane = lane;
             for (int k = 0; k < 3; ++k) { s.mask_lo[k] = rg.lo[k]; s.mask_hi[k] = rg.hi[k]; }
         }
     }
@@ -2149,6 +2175,8 @@ int lm_depth_counts_begin(lm_detector* d, const lm_depth_query* q, size_t n) {
     e = hipEventRecord(d->dc_done, st);
     if (e != hipSuccess) return bail(e);
     d->dc_pending = n;
+    d->dc_lo = S; d->dc_hi = -1;
+    for (int sl = 0; sl < S; ++sl) if (used[(size_t)sl]) { d->dc_lo = std::min(d->dc_lo, sl); d->dc_hi = std::max(d->dc_hi, sl); }
     return LM_OK;
 }
 

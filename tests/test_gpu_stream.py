@@ -453,6 +453,24 @@ def test_colour_check_of_a_batch_in_one_call_beside_a_busy_lane(lm, orc, synth):
     d.upload_frame(5, *frames[3])
     a5, b5 = d.color_check_counts(5, lo, hi, lists[0])                   # the same frame in a slot that never had a prepared mask
     assert np.array_equal(a4, a5) and np.array_equal(b4, b5)
+    # r06: (i) masks prepared on a lane whose match is never begun: the check that reuses them waits for the mask launch (an event behind it) and
+    # counts the same; (ii) while a colour check is in flight no upload goes to a slot it reads, any other slot is free; after its end the slot is free again
+    for k in range(4):
+        d.upload_frame(k, *frames[k % 4])
+    d.color_mask_prepare(2, 0, 4, lo, hi)
+    a6, b6 = d.color_check_counts_slots(slot_of, lo, hi, allm)
+    assert np.array_equal(a6, np.concatenate([s[0] for s in single])) and np.array_equal(b6, np.concatenate([s[1] for s in single]))
+    import ctypes as C
+    m = np.ascontiguousarray(allm); sl = np.ascontiguousarray(slot_of)
+    clo, chi = (C.c_double * 3)(*lo), (C.c_double * 3)(*hi)
+    d._check(d.lib.lm_color_check_begin_slots(d.h, sl.ctypes.data_as(C.c_void_p), clo, chi, m.ctypes.data_as(C.c_void_p), len(m)))
+    with pytest.raises(lm.LinemodError):
+        d.upload_frame(1, *frames[2])
+    d.upload_frame(6, *frames[2])
+    a7, b7 = np.zeros(len(m), np.int64), np.zeros(len(m), np.int64)
+    d._check(d.lib.lm_color_check_end(d.h, a7.ctypes.data_as(C.c_void_p), b7.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(a7, a6) and np.array_equal(b7, b6)
+    d.upload_frame(1, *frames[2])
     d.close()
 
 
