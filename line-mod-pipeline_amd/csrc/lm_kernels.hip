@@ -1298,13 +1298,15 @@ __global__ __launch_bounds__(256, 2) void k_cgrad(const u8* __restrict__ s0, int
 // of 8-row strips): a launch of its own leaves more than half of the SIMDs without a wave (k_cgrad<8>: 37 us per 96 frames at VALU busy 0.39 for a quarter of
 // the pixels that cost k_cgrad<16> 68 us).  Behind level 0's workgroups in the same grid its strips fill the last round's idle SIMDs instead.  Needs the level-1
 // blur BEFORE the level-0 gradient (lm_detector.hip enqueue_preprocess orders the launches so).
-template <int STRIP>
+// S0 / S1: rows per strip of the two levels (level 0 as a launch of its own would choose; level 1: 8 -- short workgroups at the end of the grid, the tail is
+// one of THEM long -- or 16 when level 1 alone brings enough waves to fill the chip)
+template <int S0, int S1>
 __global__ __launch_bounds__(256, 2) void k_cgrad_levels(const u8* __restrict__ s0, int w0, int h0, u8* __restrict__ q0, int g0,
                                                          const u8* __restrict__ s1, int w1, int h1, u8* __restrict__ q1, int g1,
                                                          int ithr, size_t slot_stride, int nslots) {
     const u32 e0 = (u32)g0 * (u32)nslots;
-    if (blockIdx.x < e0) d_cgrad<STRIP>(blockIdx.x, s0, w0, h0, ithr, q0, slot_stride, slot_stride, g0, nslots);
-    else d_cgrad<8>(blockIdx.x - e0, s1, w1, h1, ithr, q1, slot_stride, slot_stride, g1, nslots);      // (8-row strips: short workgroups at the end of the grid -- the tail is one of THEM long)
+    if (blockIdx.x < e0) d_cgrad<S0>(blockIdx.x, s0, w0, h0, ithr, q0, slot_stride, slot_stride, g0, nslots);
+    else d_cgrad<S1>(blockIdx.x - e0, s1, w1, h1, ithr, q1, slot_stride, slot_stride, g1, nslots);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2873,18 +2875,17 @@ __global__ __launch_bounds__(256) void k_scan1(LmScanArgs a) {
             // take queue x, whose entries name the few frames that XCD has just scanned -- their nibble memories then meet in ITS L2
             const u32 cap8 = a.surv_cap >> 3, qx = grp & 7u;
             unsigned long long* qcount = a.surv + 8 * a.surv_set + qx;
+            // (r06: the counter only grows.  r05 gave a reservation that did not fit back by a subtraction; a later subtraction of another wave could pull
+            // the counter below entries a third wave had written in between -- found in k_scanl, which had the same code, as one candidate of 4 M lost on
+            // a frame whose queues fill.  Now a reservation that does not fit entirely writes as many survivors as fit; the rest stay with the wave.)
             const unsigned long long at = atomicAdd(qcount, (unsigned long long)nh);
-            if (at + nh <= (unsigned long long)cap8) {
-                unsigned long long* q = a.surv + 16 + (size_t)qx * cap8 + at;
-                const unsigned long long hi = ((unsigned long long)ti << 32) | ((unsigned long long)slot << 20);
+            u32 fit = at >= (unsigned long long)cap8 ? 0u : (u32)min((unsigned long long)nh, (unsigned long long)cap8 - at);
+            if (a.stat && fit) atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 3], (unsigned long long)fit);
+            unsigned long long* q = a.surv + 16 + (size_t)qx * cap8 + at;
+            const unsigned long long hi = ((unsigned long long)ti << 32) | ((unsigned long long)slot << 20);
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    for (u32 w = h[k]; w; w &= w - 1) *q++ = hi | (unsigned long long)(u32)(j0 + 32 * k + (__ffs((int)w) - 1));
-                h[0] = h[1] = h[2] = h[3] = 0;
-                if (a.stat) atomicAdd(&a.stat[4 * (blockIdx.x & 1023u) + 3], (unsigned long long)nh);
-            } else {
-                atomicAdd(qcount, (unsigned long long)0 - (unsigned long long)nh);     // (give the reservation back)
-            }
+            for (int k = 0; k < 4; ++k)
+                for (; h[k] && fit; --fit) { const int b = __ffs((int)h[k]) - 1; *q++ = hi | (unsigned long long)(u32)(j0 + 32 * k + b); h[k] &= h[k] - 1u; }
         }
         hl = __ballot((h[0] | h[1] | h[2] | h[3]) != 0u);
         if (!hl) return;
@@ -3228,18 +3229,18 @@ __global__ __launch_bounds__(1024) void k_scanl(LmScanArgs a) {
         for (int q = 0; q < 4; ++q) h[q] = (pruned || !((alive >> lane) & 1ull)) ? 0u : ~flags[q];
         const u32 nh = (u32)(__popc(h[0]) + __popc(h[1]) + __popc(h[2]) + __popc(h[3]));
         if (nh && !a.no_exact) {
+            // The counter only grows: a reservation that does not fit (entirely) fills the queue's last entries with as many of its survivors as fit and
+            // leaves the rest to the wave's own sums below -- every entry below min(counter, capacity) is written.  (r06, first form: a reservation that
+            // did not fit was given BACK by an atomic subtract; another wave's later subtract could then pull the counter below entries a third wave had
+            // written in between -- one candidate of 4 M lost, on the one frame whose workgroups fill their queues: tools/stress_batch_parity.py.)
             const u32 at = atomicAdd(qcount, nh);
-            if (at + nh <= a.queue_cap) {
-                u32* q = queue + at;
-                const u32 hi = ti << LM_SCANL_POS_BITS;
+            u32 fit = at >= a.queue_cap ? 0u : min(nh, a.queue_cap - at);
+            st_s += fit;
+            u32* q = queue + at;
+            const u32 hi = ti << LM_SCANL_POS_BITS;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    for (u32 w = h[k]; w; w &= w - 1) *q++ = hi | (u32)(j0 + 32 * k + (__ffs((int)w) - 1));
-                h[0] = h[1] = h[2] = h[3] = 0;
-                st_s += nh;
-            } else {
-                atomicSub(qcount, nh);                                       // (give the reservation back: the wave takes these sums itself)
-            }
+            for (int k = 0; k < 4; ++k)
+                for (; h[k] && fit; --fit) { const int b = __ffs((int)h[k]) - 1; *q++ = hi | (u32)(j0 + 32 * k + b); h[k] &= h[k] - 1u; }
         }
         unsigned long long hl = a.no_exact ? 0ull : __ballot((h[0] | h[1] | h[2] | h[3]) != 0u);
         while (hl) {
@@ -4455,16 +4456,25 @@ bool lmk_color_blur(hipStream_t s, const u8* bgr, int w, int h, u8* scratch, siz
 static int g_cgrad_levels = 1;       // LM_TUNE_CGRAD_LEVELS: 1 (default) the two levels' gradients of a batch in one grid, 0 one launch per level
 void lmk_set_cgrad_levels(int v) { g_cgrad_levels = v; }
 bool lmk_cgrad_levels_wanted(int w0, int h0, int nslots) {
-    return g_cgrad_levels != 0 && (g_cgrad_variant == 0 || g_cgrad_variant == 2) && sel_slots(nslots) >= 16 && (w0 % 32) == 0 && (h0 % 2) == 0 && h0 <= 640;
+    return g_cgrad_levels != 0 && (g_cgrad_variant == 0 || g_cgrad_variant == 2 || g_cgrad_variant == 3) && sel_slots(nslots) >= 16 && (w0 % 32) == 0 && (h0 % 2) == 0;
 }
 bool lmk_cgrad_levels(hipStream_t s, const u8* S0, int w0, int h0, u8* q0, const u8* S1, int w1, int h1, u8* q1, float weak_threshold, size_t slot_stride, int nslots) {
     if (!lmk_cgrad_levels_wanted(w0, h0, nslots)) return false;
     if ((((uintptr_t)S0 | (uintptr_t)S1 | (uintptr_t)q0 | (uintptr_t)q1) & 15) != 0 || (slot_stride % 16) != 0 || (w1 % 16) != 0) return false;
     const float thr2 = weak_threshold * weak_threshold;
     const int ithr = thr2 >= 2147483648.f ? INT_MAX : (int)floorf(thr2);
-    auto blocks = [&](int w, int h, int strip) { return ((((w / 16) * ((h + strip - 1) / strip) + 61) / 62) + 3) / 4; };
-    const int g0 = blocks(w0, h0, CG_STRIP), g1 = blocks(w1, h1, 8);
-    hipLaunchKernelGGL(k_cgrad_levels<CG_STRIP>, dim3((unsigned)((g0 + g1) * nslots)), dim3(256), 0, s, S0, w0, h0, q0, g0, S1, w1, h1, q1, g1, ithr, slot_stride, nslots);
+    auto waves = [&](int w, int h, int strip) { return ((w / 16) * ((h + strip - 1) / strip) + 61) / 62; };
+    auto blocks = [&](int w, int h, int strip) { return (waves(w, h, strip) + 3) / 4; };
+    // level 0's strip as lmk_color_quantize chooses it for a launch of its own; level 1: 16 rows when it alone fills the chip, 8 otherwise
+    const int s0 = (g_cgrad_variant == 3 || (h0 > 640 && (long)waves(w0, h0, 32) * nslots >= 3072)) ? 32 : ((long)waves(w0, h0, CG_STRIP) * nslots >= 1536 ? CG_STRIP : 8);
+    const int s1 = (long)waves(w1, h1, 16) * nslots >= 1536 ? 16 : 8;
+    const int g0 = blocks(w0, h0, s0), g1 = blocks(w1, h1, s1);
+    const dim3 grid((unsigned)((g0 + g1) * nslots));
+#define LM_CGL(A, B) hipLaunchKernelGGL((k_cgrad_levels<A, B>), grid, dim3(256), 0, s, S0, w0, h0, q0, g0, S1, w1, h1, q1, g1, ithr, slot_stride, nslots)
+    if (s0 == 32) { if (s1 == 16) LM_CGL(32, 16); else LM_CGL(32, 8); }
+    else if (s0 == CG_STRIP) { if (s1 == 16) LM_CGL(CG_STRIP, 16); else LM_CGL(CG_STRIP, 8); }
+    else LM_CGL(8, 8);
+#undef LM_CGL
     return true;
 }
 

@@ -368,3 +368,27 @@ def test_scanl_similarity_tables_and_class_ranges(lm, orc, synth):
             for ci in (-1, 0, 1, 2):
                 assert np.array_equal(d.stage_scan(0, thr, ci, cap=1 << 20), o.scan_candidates(thr, ci, threads=8, cap=1 << 20))
     d.close()
+
+
+def test_scanl_full_queues_many_times(lm, orc, synth):
+    """r06: a workgroup of k_scanl whose survivors FILL its LDS queue (1916 entries) -- concurrent reservations at the capacity, partial fits, the waves' own
+    sums for the rest -- must lose nothing: 24 copies of one frame against a bank cut from it, at a threshold low enough for thousands of survivors per
+    workgroup, 12 times over; every list equals the oracle's.  (The first form of the queue gave failed reservations back by an atomic subtract and lost one
+    candidate in four million on config 2's heavy frame: profiles/r06_ab_experiments.log section 5.)"""
+    d, o, frames = _setup(lm, orc, synth, False, (640, 480), [5, 8], 400, 24, seed=2100)
+    bgr, dep = frames[0]
+    thr = 62.0
+    exp = o.match(bgr, dep, thr, threads=8, cap=1 << 19)
+    assert len(exp) > 200
+    for k in range(24):
+        d.upload_frame(k, bgr, dep)
+    d.set_tuning(lm.TUNE_SCAN_FORM, 3)
+    d.set_scan_stats(True)
+    got, cnt = d.match_batch(24, thr, cap_per_frame=1 << 16)
+    assert d.get_scan_form_stats()[3] >= 1000 and d.get_scan_form_stats()[2] > 24 * 3000      # thousands of survivors per frame: the queues overflow
+    d.set_scan_stats(False)
+    for rep in range(12):
+        got, cnt = d.match_batch(24, thr, cap_per_frame=1 << 16)
+        for k in range(24):
+            assert cnt[k] == len(exp) and got[k, :cnt[k]].tobytes() == exp.tobytes(), (rep, k, cnt[k], len(exp))
+    d.close()
