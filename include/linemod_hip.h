@@ -531,7 +531,7 @@ int lm_get_scan_form_stats(lm_detector* det, int64_t out[4]);
 /* Selects the similarity-scan kernel variant used by lm_match* (0 = default; bits 0-1: features per load block;
  * bit 3 (value 8): no pruning, the plain exhaustive scan; bit 4 (value 16): wave-level pruning only, without the
  * per-lane exec masking; bit 5 (value 32): per-lane pruning also for one-modality detectors, which default to the
- * wave-level rule; see lm_kernels.hip).  Bits 0-5 address the nibble scan k_scan4; bit 8 (value 256), the bit-plane scan k_scan1: the
+ * wave-level rule; see lm_k_scan.hip).  Bits 0-5 address the nibble scan k_scan4; bit 8 (value 256), the bit-plane scan k_scan1: the
  * waves take their survivors' exact sums themselves instead of queueing them for k_scan1_exact.  Every variant this call accepts gives
  * the SAME lists as variant 0.  The two timing experiments that skip work -- bit 6 (value 64, with bit 3: k_scan4 without its shift-undo)
  * and bit 7 (value 128: k_scan1 without the survivors' exact sums) -- and unknown bits are refused with LM_ERR_INVALID (r06): they exist

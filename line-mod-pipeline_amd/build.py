@@ -11,9 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "liblinemod_hip.so")
-HIP_SOURCES = ["lm_kernels.hip", "lm_detector.hip", "lm_comm.hip"]
+HIP_SOURCES = ["lm_k_preprocess.hip", "lm_k_scan.hip", "lm_k_refine.hip", "lm_k_post.hip",
+               "lm_detector.hip", "lm_detector_post.hip", "lm_detector_gather.hip", "lm_detector_io.hip", "lm_detector_debug.hip", "lm_comm.hip"]
 CXX_SOURCES = ["lm_host.cpp", "lm_extract.cpp", "lm_yaml.cpp"]
-HEADERS = ["lm_common.h", "lm_kernels.h", "lm_host.h", "lm_extract.h", "lm_median25.h", "lm_yaml.h", "lm_comm.h",
+HEADERS = ["lm_common.h", "lm_kernels.h", "lm_dev.h", "lm_dev_color.h", "lm_dev_depth.h", "lm_dev_memories.h", "lm_detector_impl.h", "lm_host.h", "lm_extract.h", "lm_median25.h", "lm_yaml.h", "lm_comm.h",
            os.path.join("..", "..", "include", "linemod_hip.h")]
 # -ffp-contract=off: the two float islands (fastAtan2 polynomial, normal normalisation, raw threshold)
 # must round exactly like the oracle, which is built the same way.
@@ -37,7 +38,7 @@ def build(force=False, verbose=False):
     for h in headers:
         if not os.path.exists(h):
             raise FileNotFoundError("header missing from the checkout: " + h)
-    objs = []
+    objs, cmds = [], []
     for src in HIP_SOURCES + CXX_SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
@@ -50,10 +51,23 @@ def build(force=False, verbose=False):
                 cmd += ["--offload-arch=" + ARCH]
             else:
                 cmd += ["-x", "c++"]
-            cmd += ["-c", sp, "-o", obj]
+            cmds.append(cmd + ["-c", sp, "-o", obj])
+    # the translation units are independent (r06: the kernel source is split by stage): compile them side by side, bounded by the CPUs
+    # this process may use and by LM_BUILD_JOBS
+    if cmds:
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 1
+        jobs = max(1, min(len(cmds), int(os.environ.get("LM_BUILD_JOBS", "0")) or min(ncpu, 8)))
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=jobs) as ex:
+            list(ex.map(run, cmds))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-lz", "-ldl"]
         if verbose:

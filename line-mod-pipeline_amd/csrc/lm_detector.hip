@@ -5,222 +5,12 @@
 // 33-34,41-42 ctor; :93 addTemplate; :152 match; :115,181 getTemplates; :55,60,65 class queries).
 // There is no CPU fallback: every compute entry point needs a HIP device and fails with
 // LM_ERR_NO_DEVICE otherwise.
-#include <hip/hip_runtime.h>
+#include "lm_detector_impl.h"
 
-#include <algorithm>
-#include <climits>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-#include <mutex>
-
-#include "../../include/linemod_hip.h"
-#include "lm_common.h"
-#include "lm_extract.h"
-#include <thread>
-
-#include "lm_host.h"
-#include "lm_yaml.h"
-#include "lm_kernels.h"
-#include "lm_comm.h"
-
-namespace {
+namespace lmd {
 
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
-
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail(LM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
-    } while (0)
-
-inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-#define LM_NCOPY 4
-#define LM_NLANES 4      // lanes per detector (lm_match_begin / lm_match_end): HIP streams whose stages overlap
-
-struct Slot {
-    u8* h_bgr = nullptr;     // pinned upload staging
-    u16* h_depth = nullptr;
-    bool has_frame = false;
-    bool planes = false;     // ... and that pass wrote the scanned level's miss planes (k_scan1 may read them)
-    bool spread_low = false; // ... and ONE spread byte per position INSTEAD of the response memories: only k_scan1 can scan this slot
-    bool prepared = false;   // a3-a10 have run on the frame the slot holds with the LUTs / thresholds now in force (lm_match_prepared)
-    // Uploads run on the detector's copy stream: ev_up is recorded behind the slot's H2D copies, up_seq is the
-    // upload's ticket (0 = never uploaded through the copy stream).  Copies complete in ticket order.
-    hipEvent_t ev_up = nullptr;
-    hipEvent_t ev_bgr = nullptr;     // recorded behind the colour image alone (RGB-D: the depth copy follows it)
-    unsigned long long up_seq = 0;
-    int up_stream = 0;               // which copy stream carried the upload (tickets are per stream)
-    bool mask_ready = false;         // the slot's colour bit mask holds inRange(HSV(frame), mask_lo, mask_hi) of the frame the slot holds (lm_color_mask_prepare)
-    int mask_lane = -1;              // ... written on that lane's stream (its mask_done event orders a later colour check behind the launch)
-    int mask_lo[3] = {0, 0, 0}, mask_hi[3] = {0, 0, 0};
-    bool staging_open = false;       // lm_stage_reserve has run: lm_stage_rows may fill the staging buffers, lm_upload_staged sends them
-    bool matched = false;            // a match on the frame the slot holds has completed: its lists are still in the slot's result block (lm_match_collect)
-};
-
-}  // namespace
-
-struct lm_detector {
-    lm_config cfg;
-    LmLevelGeom geom[LM_MAX_LEVELS];
-    int lw[LM_MAX_LEVELS], lh[LM_MAX_LEVELS];
-    u8 sim_lut[256];
-    u8 normal_lut[8000];
-    int lut_onehot = -1;          // cached: every NORMAL_LUT entry is 0 or one-hot (-1 = not evaluated)
-    bool normal_lut_substitute = true;   // the built-in table (NOT OpenCV's normal_lut.i) is active: lm_set_normal_lut clears it
-    lmh::Bank bank;
-
-    // ---- device state
-    bool dev_ready = false;
-    // The fields stream / ev / d_raw_thr / h_raw_thr / raw_thr_for below always belong to the ACTIVE lane
-    // (activate_lane swaps them); lane 0 is active outside lm_match_begin / lm_match_end.
-    struct Lane {
-        hipStream_t stream = nullptr;
-        hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        int* d_raw_thr = nullptr;
-        int* h_raw_thr = nullptr;
-        float raw_thr_for = -1.0f;
-        bool created = false, busy = false, timed = false;
-        hipEvent_t ev_done = nullptr;    // recorded behind the last command of the lane's match in flight (lm_match_end waits for IT, see wait_lane_done)
-        int first = 0, n = 0;
-        std::vector<int> classes;                       // class list of the match in flight ({-1} = all classes)
-        unsigned long long waited_seq[LM_NCOPY] = {};   // newest upload ticket per copy stream this lane's stream waits for
-    };
-    Lane lanes[LM_NLANES];
-    int active = 0;
-    hipEvent_t blocking_ev[LM_NLANES] = {};           // LM_FLAG_BLOCKING_SYNC: one per lane
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0..4] stage boundaries, [5] behind the exchange
-    // H2D copies of lm_upload_frame* go through their own stream so that the frames of step k + 1 travel while
-    // the lanes compute step k; a lane's stream waits (hipStreamWaitEvent) for the newest upload among its slots.
-    // LM_NCOPY copy streams (slot -> stream round-robin): one in-order stream moved 0.6-0.9 MB copies at 25.6 GB/s
-    // (per-copy set-up of the DMA engine), several streams keep several engines busy.
-    hipStream_t copy_stream[LM_NCOPY] = {};
-    unsigned long long up_seq_next[LM_NCOPY], up_seq_done[LM_NCOPY];   // per stream: next ticket / newest ticket known landed
-    unsigned long long waited_seq[LM_NCOPY] = {};                      // ACTIVE lane's copy of Lane::waited_seq
-    int n_copy_streams = LM_NCOPY;
-    int stage_chunks = 1;                                  // pageable source: pieces of the staging memcpy (each piece is its own
-                                                           // async copy; measured: every extra hipMemcpyAsync costs more than the overlap wins)
-    std::vector<Slot> slots;
-    // frame arena: [slot][bgr[l] | depth | quant[l][m] | lm[l]]
-    u8* frame_arena = nullptr;
-    size_t frame_stride = 0;
-    size_t off_bgr[LM_MAX_LEVELS] = {}, off_depth = 0, off_quant[LM_MAX_LEVELS][2] = {}, off_lm[LM_MAX_LEVELS] = {};
-    // colour-quantisation scratch S | qn: one region for level 0, one (sized for level 1) shared by the levels above,
-    // and the rank-code image of the depth passes -- disjoint, so independent kernels of one dependency level may run in one launch (k_phase)
-    size_t off_cscratch = 0, off_cscratch1 = 0, off_dscratch = 0;
-    // ---- multi-GPU exchange: RCCL communicator + per-lane gather buffers
-    struct Gather {
-        int* d_cnt = nullptr; LmOutMatch* d_rec = nullptr;          // this rank's packed lists (k_pack_lists)
-        int* d_all_cnt = nullptr; LmOutMatch* d_all_rec = nullptr;  // all ranks', rank-major
-        int* h_all_cnt = nullptr; LmOutMatch* h_all_rec = nullptr;  // pinned host copies
-        bool active = false;                                        // the lane's match in flight ends with a gather
-        u32 cap_lane = 0;
-    };
-    // ---- f1 colour check on the GPU: hulls of every template, HSV division tables, per-slot colour bit mask
-    bool hulls_dirty = true;
-    u32* d_hull_class_base = nullptr; u32* d_hull_off = nullptr; int16_t* d_hull_xy = nullptr;
-    int* d_hsv_div = nullptr;
-    size_t off_cmask = 0; int cmask_wpr = 0;
-    // r05: the colour check has its own (high-priority) stream and buffers, so that it runs beside the lanes: the post-processing of
-    // batch k overlaps the match of batch k + 1 (HighLevelLineMOD::detectTemplatesBatchBegin / End)
-    hipStream_t cc_stream = nullptr;
-    u8* cc_dev = nullptr; u8* cc_host = nullptr; size_t cc_cap = 0;       // room for cc_cap matches: records | slot index | two counts
-    size_t cc_pending = 0; bool cc_inflight = false;                      // lm_color_check_begin_slots enqueued a check of cc_pending matches
-    u8* dc_dev = nullptr; u8* dc_host = nullptr; size_t dc_cap = 0;       // r06, lm_depth_counts_begin: room for dc_cap queries | two counts each
-    size_t dc_pending = 0; bool dc_inflight = false;
-    int cc_lo = 0, cc_hi = -1, dc_lo = 0, dc_hi = -1;                   // slots a colour check / depth counts in flight read: no upload goes there
-    hipEvent_t mask_done[LM_NLANES] = {};                                // behind the mask launch of lm_color_mask_prepare on a lane: a colour check that reuses the masks waits for it
-    hipEvent_t cc_done = nullptr, dc_done = nullptr;                      // behind the colour check's / the depth counts' last copy: their `end` waits for the event, not the stream
-    LmComm* comm[LM_NLANES] = {};   // one communicator per lane: the lanes' collectives never wait for each other
-    int comm_recs_per_frame = 0;
-    Gather gather[LM_NLANES];
-    double* d_red = nullptr;   // small device buffer of lm_comm_max / lm_comm_barrier
-    int batch_phases = 2;            // calls of 16+ frames run a3-a10 as launches of level-fused batch kernels (lmk_preprocess_batch_phases):
-                                     // 0 never, 1 always, 2 (default) when no other lane has work in flight -- measured r03: alone on the
-                                     // chip the fused launches win (config 2: 4.81 -> 4.66, config 3: 8.54 -> 8.06 us per frame), beside two
-                                     // other lanes the separate launches interleave better (config 2: 145 K against 140 K detections/s)
-    int scan_list_order = 3;         // LM_TUNE_SCAN_LIST_ORDER (lm_host.h build_device_bank)
-    int sort_split_mode = 2;         // device sort: 0 one workgroup per frame (r03), 1 always the split form (chunk workgroups + merge launch),
-                                     // 2 (default) the split form while the recently collected lists were longer than LM_SORT_CHUNK keys
-    int sort_long_score = 0;         // see note_sort_length
-    int work_weight_by_pixels = 1;   // r04: the selection below counts a frame as level-0 pixels / (640 x 480) frames (LM_TUNE_WORK_WEIGHT = 0: by frame count, r03)
-    int phase_max_slots = 15;        // calls of up to this many frames run a3-a10 as one launch per dependency level (LmPhaseArgs)
-    // aux arena: [slot][LmDevHeader | cand | keys | out]
-    u8* aux_arena = nullptr;
-    size_t aux_stride = 0;
-    size_t off_hdr = 0, off_cand = 0, off_keys = 0, off_out = 0;
-    // host-mapped result blocks
-    u8* host_blocks = nullptr;
-    size_t host_stride = 0;
-    int* d_raw_thr = nullptr;
-    int* h_raw_thr = nullptr;
-    float raw_thr_for = -1.0f;
-    u32* d_plan = nullptr;        // k_refine_plan output, one per lane: [8][cap] slots + [8] lengths + [8][cap + 1] running sums + [8][cap] first entries
-    int plan_stride_cap = 0;
-    u64* d_resp_tab = nullptr;
-    int miss_delta = 1;           // 4 - the largest response below 4 of the similarity table (ensure_luts; upstream's table: a neighbouring orientation scores 3)
-    u32* d_sim_lut = nullptr;
-    u8* d_normal_lut = nullptr;
-    bool luts_dirty = true;
-    // ---- device bank
-    bool bank_dirty = true;
-    lmh::DeviceBankHost hb;
-    u32* d_item_t = nullptr; u32* d_item_chunk = nullptr;
-    u32* d_scan_off = nullptr; int* d_scan_P = nullptr; int* d_scan_n = nullptr;
-    int* d_t_global = nullptr; int* d_t_class = nullptr;
-    // bit-plane scan (k_scan1): the concatenated offset lists, and the work items of the lane counts used so far
-    u32* d_off1 = nullptr; u32* d_offn = nullptr;
-    struct Items1 { int L = 0; u32* d_t = nullptr; u32* d_chunk = nullptr; std::vector<int> begin; };
-    std::vector<Items1> items1;
-    int scan_form = 0;               // LM_TUNE_SCAN_FORM: 0 = by cost (default), 1 = always the nibble scan k_scan4, 2 = the bit-plane scan k_scan1 whenever the level has planes,
-                                     //    3 = the bit-plane scan with the planes in LDS (k_scanl) wherever a frame's planes fit (k_scan1 where they do not)
-    float scan1_min_threshold = 50.0f;   // below this similarity threshold the miss bound keeps too many positions alive: k_scan4 (LM_TUNE_SCAN1_MIN_THRESHOLD)
-    long long cnt_scan1_launches = 0; int last_scan1_lanes = 0;
-    bool emit_planes = false;        // the pre-processing being enqueued writes the miss planes (set per call by enqueue_preprocess)
-    bool emit_spread_low = false;    // ... and the spread byte instead of the response memories (the call's scan is k_scan1 by the rule below)
-    u32* d_offs3 = nullptr;          // [nt][fpad1] orientation << 29 | spread-memory offset of the bit-plane scan's features
-    // r06, the bit-plane scan with a frame's planes in LDS (k_scanl; hb.lds_ok): the lists in the LDS image's layout and the lane items
-    u32* d_offl = nullptr; u32* d_offsl = nullptr; u32* d_litem = nullptr;
-    unsigned long long* d_refine_stat = nullptr;     // LM_REFINE_STAT=1: k_refine's counting experiment (printed by lm_destroy)
-    int scanl_min_slots = 24;        // by cost (LM_TUNE_SCAN_FORM 0) from this many frames per call (measured: 16 frames 35.5 us against k_scan4's 35.3, 32 frames 43.4 against 57.5)
-    unsigned long long* d_surv[LM_NLANES] = {};      // k_scan1's survivor queues, one per lane, allocated on a lane's first bit-plane scan
-    int surv_set[LM_NLANES] = {};                    // which of a queue's two counter sets the lane's next scan launch uses (the other is zeroed behind it)
-    u32 surv_cap = 1u << 20;
-    LmRefMeta* d_ref_meta[LM_MAX_LEVELS] = {};
-    LmRefFeat* d_ref_feat[LM_MAX_LEVELS] = {};
-    // scratch for stage hooks
-    void* d_scratch = nullptr; size_t scratch_bytes = 0;
-    u32 max_cand = 0, max_match = 0;
-    int scan_variant = 0;
-    bool scan_stats = false;                        // lm_set_scan_stats: the scan counts the features it loads
-    unsigned long long* d_scan_stat = nullptr;      // [1024][4]: features loaded per wave, features of an exhaustive scan, lane-loads issued
-    // live profile of lm_match* (lm_set_profiling): per-stage HIP-event time, scan launches and bytes
-    bool profiling = false;
-    double prof_us[4] = {0, 0, 0, 0};
-    double prof_scan_bytes = 0;
-    long long prof_launches = 0, prof_frames = 0;
-    long long prof_exch_fallbacks = 0;                           // lane-steps that needed the sized second exchange
-    double prof_exch_us = 0; long long prof_exch_launches = 0;   // pack + 2 x all-gather + D2H of the gathered path (ev[4] -> ev[5])
-    long long cnt_preprocess_frames = 0, cnt_scan_launches = 0, cnt_refine_launches = 0, cnt_sort_launches = 0;   // lm_get_stage_counts
-
-    u8* bgr(int slot, int l) const { return frame_arena + (size_t)slot * frame_stride + off_bgr[l]; }
-    u16* depth(int slot) const { return reinterpret_cast<u16*>(frame_arena + (size_t)slot * frame_stride + off_depth); }
-    u8* quant(int slot, int l, int m) const { return frame_arena + (size_t)slot * frame_stride + off_quant[l][m]; }
-    u8* lm(int slot, int l) const { return frame_arena + (size_t)slot * frame_stride + off_lm[l]; }
-    u8* cscratch(int slot, int l = 0) const { return frame_arena + (size_t)slot * frame_stride + (l == 0 ? off_cscratch : off_cscratch1); }
-    u8* dscratch(int slot) const { return frame_arena + (size_t)slot * frame_stride + off_dscratch; }
-    u8* aux(int slot, size_t off) const { return aux_arena + (size_t)slot * aux_stride + off; }
-    LmHostBlock* host_block(int slot) const { return reinterpret_cast<LmHostBlock*>(host_blocks + (size_t)slot * host_stride); }
-};
-
-namespace {
 
 bool any_lane_busy(const lm_detector* d) {
     for (const lm_detector::Lane& ln : d->lanes) if (ln.busy) return true;
@@ -242,13 +32,6 @@ void free_device_bank(lm_detector* d) {
     }
 }
 
-template <typename T>
-int upload_vec(T** dptr, const std::vector<T>& v) {
-    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(dptr), bytes));
-    if (!v.empty()) HIP_TRY(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    return LM_OK;
-}
 
 int ensure_device(lm_detector* d) {
     if (d->dev_ready) {
@@ -349,7 +132,7 @@ int ensure_luts(lm_detector* d) {
     HIP_TRY(hipMemcpy(d->d_resp_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d->d_sim_lut, d->sim_lut, 256, hipMemcpyHostToDevice));
     {
-        // k_dnormal writes the label's RANK CODE (lm_kernels.hip, a5 streaming form): looked up directly from a second table
+        // k_dnormal writes the label's RANK CODE (lm_dev_depth.h, a5 streaming form): looked up directly from a second table
         u8 both[2 * 8000 + 16] = {};                      // [LMK_NORMAL_CODE_OFFSET + 8000 ..] = 0: the code of an index outside the table
         std::memcpy(both, d->normal_lut, 8000);
         for (int i = 0; i < 8000; ++i) {
@@ -547,7 +330,6 @@ void fill_raw_thr(int* tab, float threshold) {
     for (int n = 0; n < 128; ++n) tab[n] = static_cast<int>(2 * n + (threshold / 100.f) * (2 * n) + 0.5f);
 }
 
-struct ItemRange { int lo, n; int t_lo, t_hi; };   // items of the nibble / byte scan, and the bank-local templates they belong to
 int item_range(lm_detector* d, int class_idx, ItemRange* r) {
     const int nc = (int)d->bank.classes.size();
     if (class_idx >= nc || class_idx < -1) return fail(LM_ERR_INVALID, "class index out of range");
@@ -691,7 +473,7 @@ int ensure_items1(lm_detector* d, int L1, const lm_detector::Items1** out) {
     return LM_OK;
 }
 
-LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots = 1) {
+LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots) {
     const int L = d->cfg.pyramid_levels;
     const LmLevelGeom& g = d->geom[L - 1];
     LmScanArgs a;
@@ -860,8 +642,8 @@ int enqueue_upload_wait(lm_detector* d, int first, int n) {
 
 // `classes` is normalised in place (item_ranges).  prepared: the slots' a3-a10 results are current (checked by the
 // caller): a11-a15 only.
-int enqueue_match(lm_detector* d, int first, int n, float threshold, std::vector<int>& classes, bool timed = false,
-                  bool prepared = false) {
+int enqueue_match(lm_detector* d, int first, int n, float threshold, std::vector<int>& classes, bool timed,
+                  bool prepared) {
     std::vector<ItemRange> ranges;
     int rc;
     if ((rc = item_ranges(d, classes, ranges))) return rc;
@@ -875,19 +657,12 @@ int enqueue_match(lm_detector* d, int first, int n, float threshold, std::vector
     }
     return enqueue_match_stages(d, first, n, threshold, ranges, timed);
 }
-int enqueue_match(lm_detector* d, int first, int n, float threshold, int class_idx, bool timed = false) {
+int enqueue_match(lm_detector* d, int first, int n, float threshold, int class_idx, bool timed) {
     std::vector<int> classes(1, class_idx);
     return enqueue_match(d, first, n, threshold, classes, timed);
 }
 
 inline bool key_less(const u64* a, const u64* b) { return a[0] < b[0] || (a[0] == b[0] && a[1] < b[1]); }
-
-// The device sort's split form pays for lists longer than one chunk, and a launch lasts as long as its longest list: the score says
-// whether any of the last 4096 collected frames had such a list.
-inline void note_sort_length(lm_detector* d, u32 match_count) {
-    const int is_long = match_count > LM_SORT_CHUNK && match_count <= LM_SORT_CAP;
-    d->sort_long_score = is_long ? 4096 : std::max(d->sort_long_score - 1, 0);
-}
 
 // Delivers the sorted unique matches of one slot (the stream has been synchronised).
 int collect_slot(lm_detector* d, int slot, lm_match_t* out, size_t cap, size_t* n_out) {
@@ -1156,7 +931,7 @@ int ensure_lane(lm_detector* d, int l) {
     return LM_OK;
 }
 
-void account_profile(lm_detector* d, int n, const std::vector<int>& classes, bool gathered = false) {
+void account_profile(lm_detector* d, int n, const std::vector<int>& classes, bool gathered) {
     for (int k = 0; k < 4; ++k) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, d->ev[k], d->ev[k + 1]) == hipSuccess) d->prof_us[k] += (double)ms * 1000.0;
@@ -1220,7 +995,7 @@ int run_match(lm_detector* d, int first, int n, float threshold, int class_idx) 
     return run_match(d, first, n, threshold, std::vector<int>(1, class_idx));
 }
 
-}  // namespace
+}  // namespace lmd
 
 // ================================================================================================
 // C ABI
@@ -1304,7 +1079,6 @@ int lm_create(const lm_config* cfg, lm_detector** out) {
     return LM_OK;
 }
 
-static void free_gather(lm_detector* d);
 
 void lm_destroy(lm_detector* d) {
     if (!d) return;
@@ -1806,7 +1580,6 @@ int lm_synchronize(lm_detector* d) {
     return LM_OK;
 }
 
-static int enqueue_gather(lm_detector* d, int lane, int first, int n);
 
 static int begin_lane(lm_detector* d, int lane, int first_slot, int n_slots, float threshold, std::vector<int> classes, bool gathered) {
     int rc;
@@ -1896,1240 +1669,6 @@ int lm_match_collect(lm_detector* d, int first_slot, int n_slots, lm_match_t* ou
     for (int i = 0; i < n_slots; ++i)
         if (!d->slots[first_slot + i].matched) return fail(LM_ERR_INVALID, "slot " + std::to_string(first_slot + i) + " holds no completed match");
     return collect_range(d, first_slot, n_slots, out, cap_per_frame, counts);
-}
-
-// ---- f1: colour check of many matches of one resident frame (HighLevelLinemod.cpp:113-135,159-161,424-434) ------
-static int ensure_hulls(lm_detector* d) {
-    if (!d->hulls_dirty) return LM_OK;
-    HIP_TRY(hipDeviceSynchronize());
-    hipFree(d->d_hull_class_base); hipFree(d->d_hull_off); hipFree(d->d_hull_xy);
-    d->d_hull_class_base = d->d_hull_off = nullptr; d->d_hull_xy = nullptr;
-    lmh::HullTable ht;
-    lmh::build_hull_table(d->bank, d->cfg.num_modalities, ht);
-    for (size_t t = 0; t + 1 < ht.hull_off.size(); ++t)
-        if (ht.hull_off[t + 1] - ht.hull_off[t] > LM_HULL_MAX) return fail(LM_ERR_INVALID, "template hull with more than 128 vertices");
-    int rc;
-    if ((rc = upload_vec(&d->d_hull_class_base, ht.class_base))) return rc;
-    if ((rc = upload_vec(&d->d_hull_off, ht.hull_off))) return rc;
-    if ((rc = upload_vec(&d->d_hull_xy, ht.hull_xy))) return rc;
-    if (!d->d_hsv_div) {
-        // cv::cvtColor's 8-bit RGB2HSV tables: sdiv_table[i] = round((255 << 12) / i), hdiv_table180[i] = round((180 << 12) / (6 i))
-        std::vector<int> tab(512, 0);
-        for (int i = 1; i < 256; ++i) {
-            tab[(size_t)i] = (int)std::lrint((255 << 12) / (1.0 * i));
-            tab[256 + (size_t)i] = (int)std::lrint((180 << 12) / (6.0 * i));
-        }
-        if ((rc = upload_vec(&d->d_hsv_div, tab))) return rc;
-    }
-    d->hulls_dirty = false;
-    return LM_OK;
-}
-
-// The colour check's own stream and buffers (r05): nothing of it touches a lane, so it runs while other lanes match other slots.
-static int ensure_colour_check(lm_detector* d, size_t n) {
-    if (!d->cc_stream) {
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
-        // highest priority: a handful of short launches that the host waits for must not queue behind a lane's long kernels
-        if (hipStreamCreateWithPriority(&d->cc_stream, hipStreamNonBlocking, hi) != hipSuccess) {
-            (void)hipGetLastError();
-            HIP_TRY(hipStreamCreateWithFlags(&d->cc_stream, hipStreamNonBlocking));
-        }
-    }
-    if (!d->cc_done) HIP_TRY(hipEventCreateWithFlags(&d->cc_done, hipEventDisableTiming));
-    if (!d->dc_done) HIP_TRY(hipEventCreateWithFlags(&d->dc_done, hipEventDisableTiming));
-    if (n > d->cc_cap) {
-        const size_t cap = std::max<size_t>(align_up(n, 4096), 16384);
-        const size_t bytes = cap * (sizeof(lm_match_t) + sizeof(int) + 2 * sizeof(long long));
-        HIP_TRY(hipStreamSynchronize(d->cc_stream));
-        u8* dev = nullptr; u8* host = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), bytes));
-        if (hipHostMalloc(reinterpret_cast<void**>(&host), bytes) != hipSuccess) { (void)hipFree(dev); return fail(LM_ERR_HIP, "hipHostMalloc of the colour check's buffers failed"); }
-        (void)hipFree(d->cc_dev); if (d->cc_host) (void)hipHostFree(d->cc_host);
-        d->cc_dev = dev; d->cc_host = host; d->cc_cap = cap;
-    }
-    return LM_OK;
-}
-
-// slot_of: per match the slot its frame is resident in, or nullptr = all in `one_slot`.
-static int colour_check_enqueue(lm_detector* d, const int32_t* slot_of, int one_slot, const double lower_hsv[3], const double upper_hsv[3],
-                                const lm_match_t* matches, size_t n) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if (d->cc_inflight) return fail(LM_ERR_INVALID, "a colour check is in flight: call lm_color_check_end first");
-    if (!lower_hsv || !upper_hsv || (n && !matches)) return fail(LM_ERR_INVALID, "null argument");
-    const int S = (int)d->slots.size();
-    int s_lo = S, s_hi = -1;
-    std::vector<char> used((size_t)S, 0);
-    if (!slot_of) {
-        if ((rc = check_slots(d, one_slot, 1))) return rc;
-        used[(size_t)one_slot] = 1; s_lo = s_hi = one_slot;
-    } else {
-        for (size_t i = 0; i < n; ++i) {
-            if (slot_of[i] < 0 || slot_of[i] >= S) return fail(LM_ERR_INVALID, "slot out of range");
-            used[(size_t)slot_of[i]] = 1; s_lo = std::min(s_lo, slot_of[i]); s_hi = std::max(s_hi, slot_of[i]);
-        }
-    }
-    if (n == 0) return LM_OK;
-    for (int sl = s_lo; sl <= s_hi; ++sl) {
-        if (!used[(size_t)sl]) continue;
-        if (!d->slots[(size_t)sl].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
-        for (const lm_detector::Lane& ln : d->lanes)
-            if (ln.busy && sl >= ln.first && sl < ln.first + ln.n) return fail(LM_ERR_INVALID, "slot belongs to a match in flight: call lm_match_end first");
-    }
-    if (d->hulls_dirty && any_lane_busy(d)) return fail(LM_ERR_INVALID, "the bank changed while a lane has a match in flight: call lm_match_end first");
-    if ((rc = ensure_hulls(d))) return rc;
-    const int nc = (int)d->bank.classes.size();
-    for (size_t i = 0; i < n; ++i) {
-        const lm_match_t& m = matches[i];
-        if (m.class_idx < 0 || m.class_idx >= nc || m.template_id < 0 || m.template_id >= (int)d->bank.classes[(size_t)m.class_idx].pyramids.size())
-            return fail(LM_ERR_INVALID, "match " + std::to_string(i) + " names a template the bank does not hold");
-    }
-    if ((rc = ensure_colour_check(d, n))) return rc;
-    hipStream_t st = d->cc_stream;
-    // the frames' uploads (copy streams) must have landed before the mask kernel reads them
-    for (int sl = s_lo; sl <= s_hi; ++sl) {
-        const Slot& s = d->slots[(size_t)sl];
-        if (used[(size_t)sl] && s.up_seq > d->up_seq_done[s.up_stream]) HIP_TRY(hipStreamWaitEvent(st, s.ev_up, 0));
-    }
-    const size_t off_slot = d->cc_cap * sizeof(lm_match_t), off_out = off_slot + d->cc_cap * sizeof(int);
-    std::memcpy(d->cc_host, matches, n * sizeof(lm_match_t));
-    if (slot_of) { int* hs = reinterpret_cast<int*>(d->cc_host + off_slot); for (size_t i = 0; i < n; ++i) hs[i] = slot_of[i] - s_lo; }
-    HIP_TRY(hipMemcpyAsync(d->cc_dev, d->cc_host, n * sizeof(lm_match_t), hipMemcpyHostToDevice, st));
-    if (slot_of) HIP_TRY(hipMemcpyAsync(d->cc_dev + off_slot, d->cc_host + off_slot, n * sizeof(int), hipMemcpyHostToDevice, st));
-    LmHsvRange rg;
-    for (int k = 0; k < 3; ++k) { rg.lo[k] = (int)std::lrint(lower_hsv[k]); rg.hi[k] = (int)std::lrint(upper_hsv[k]); }
-    // ONE mask launch for the slots [s_lo, s_hi] (a slot in between that the list does not name costs a mask nobody reads) -- unless
-    // every named slot's mask was prepared for this very range beside its match (lm_color_mask_prepare)
-    u32* mask = reinterpret_cast<u32*>(d->frame_arena + (size_t)s_lo * d->frame_stride + d->off_cmask);
-    bool prepared = true;
-    for (int sl = s_lo; sl <= s_hi && prepared; ++sl) {
-        const Slot& s = d->slots[(size_t)sl];
-        if (!used[(size_t)sl]) continue;
-        prepared = s.mask_ready;
-        for (int k = 0; k < 3 && prepared; ++k) prepared = s.mask_lo[k] == rg.lo[k] && s.mask_hi[k] == rg.hi[k];
-    }
-    if (!prepared) {
-        lmk_hsv_mask(st, d->bgr(s_lo, 0), d->cfg.width, d->cfg.height, rg, d->d_hsv_div, mask, d->cmask_wpr, d->frame_stride, d->frame_stride, s_hi - s_lo + 1);
-        for (int sl = s_lo; sl <= s_hi; ++sl) d->slots[(size_t)sl].mask_ready = false;      // (overwritten for this call's range; not recorded as prepared)
-    } else {
-        // the masks were written on a lane's stream (lm_color_mask_prepare): the hull kernel waits for that launch, whether or not the lane's match was
-        // collected in between
-        bool waited[LM_NLANES] = {};
-        for (int sl = s_lo; sl <= s_hi; ++sl) {
-            const Slot& sm = d->slots[(size_t)sl];
-            if (!used[(size_t)sl] || sm.mask_lane < 0 || sm.mask_lane >= LM_NLANES || waited[sm.mask_lane] || !d->mask_done[sm.mask_lane]) continue;
-            HIP_TRY(hipStreamWaitEvent(st, d->mask_done[sm.mask_lane], 0));
-            waited[sm.mask_lane] = true;
-        }
-    }
-    LmHullArgs a;
-    a.matches = reinterpret_cast<const LmOutMatch*>(d->cc_dev); a.n = (u32)n;
-    a.class_base = d->d_hull_class_base; a.hull_off = d->d_hull_off; a.hull_xy = d->d_hull_xy;
-    a.mask = mask; a.wpr = d->cmask_wpr; a.w = d->cfg.width; a.h = d->cfg.height;
-    a.match_slot = slot_of ? reinterpret_cast<const int*>(d->cc_dev + off_slot) : nullptr;
-    a.mask_slot_words = d->frame_stride / 4;
-    a.out = reinterpret_cast<long long*>(d->cc_dev + off_out);
-    if (!lmk_hull_counts(st, a)) {
-        (void)hipStreamSynchronize(st);
-        return fail(LM_ERR_INVALID, "frame too tall for the GPU colour check (more than 4992 rows): use the host colour check");
-    }
-    HIP_TRY(hipMemcpyAsync(d->cc_host + off_out, a.out, n * 2 * sizeof(long long), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipEventRecord(d->cc_done, st));
-    d->cc_pending = n; d->cc_inflight = true; d->cc_lo = s_lo; d->cc_hi = s_hi;
-    return LM_OK;
-}
-
-static int colour_check_finish(lm_detector* d, int64_t* in_hull, int64_t* in_both) {
-    if (!d || !d->cc_inflight) return fail(LM_ERR_INVALID, "no colour check in flight");
-    const size_t n = d->cc_pending;
-    d->cc_inflight = false; d->cc_pending = 0;
-    if (n && (!in_hull || !in_both)) { (void)hipStreamSynchronize(d->cc_stream); return fail(LM_ERR_INVALID, "null argument"); }
-    HIP_TRY(hipSetDevice(d->cfg.device));
-    HIP_TRY(hipEventSynchronize(d->cc_done));          // (the event behind this check's last copy: depth counts enqueued behind it are not waited for, r06)
-    HIP_TRY(hipGetLastError());
-    const size_t off_out = d->cc_cap * sizeof(lm_match_t) + d->cc_cap * sizeof(int);
-    const long long* out = reinterpret_cast<const long long*>(d->cc_host + off_out);
-    for (size_t i = 0; i < n; ++i) { in_hull[i] = out[2 * i]; in_both[i] = out[2 * i + 1]; }
-    return LM_OK;
-}
-
-static int colour_check(lm_detector* d, const int32_t* slot_of, int one_slot, const double lower_hsv[3], const double upper_hsv[3],
-                        const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both) {
-    if (n && (!in_hull || !in_both)) return fail(LM_ERR_INVALID, "null argument");
-    int rc;
-    if ((rc = colour_check_enqueue(d, slot_of, one_slot, lower_hsv, upper_hsv, matches, n))) return rc;
-    if (!d->cc_inflight) return LM_OK;       // n == 0
-    return colour_check_finish(d, in_hull, in_both);
-}
-
-// The colour masks of slots [first_slot, first_slot + n_slots) for one HSV range, enqueued on `lane`'s stream AHEAD of the match that
-// the caller begins on that lane next (lm_match_begin*): when the lane has been collected the masks are there, and a colour check of
-// those slots for the same range skips its mask launch -- only the hull launch is left between lm_match_end and the counts.
-int lm_color_mask_prepare(lm_detector* d, int lane, int first_slot, int n_slots, const double lower_hsv[3], const double upper_hsv[3]) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if (lane < 0 || lane >= LM_NLANES) return fail(LM_ERR_INVALID, "lane out of range (0 .. 3)");
-    if ((rc = check_slots(d, first_slot, n_slots))) return rc;
-    if (!lower_hsv || !upper_hsv || n_slots <= 0) return fail(LM_ERR_INVALID, "bad argument");
-    if (d->lanes[lane].busy) return fail(LM_ERR_INVALID, "lane is busy: prepare the masks before lm_match_begin");
-    for (const lm_detector::Lane& ln : d->lanes)
-        if (ln.busy && first_slot < ln.first + ln.n && ln.first < first_slot + n_slots) return fail(LM_ERR_INVALID, "slot belongs to a match in flight");
-    for (int i = 0; i < n_slots; ++i)
-        if (!d->slots[first_slot + i].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot " + std::to_string(first_slot + i));
-    if (d->hulls_dirty && any_lane_busy(d)) return fail(LM_ERR_INVALID, "the bank changed while a lane has a match in flight: call lm_match_end first");
-    if ((rc = ensure_hulls(d))) return rc;                 // (also uploads the HSV division tables)
-    if ((rc = ensure_lane(d, lane))) return rc;
-    LmHsvRange rg;
-    for (int k = 0; k < 3; ++k) { rg.lo[k] = (int)std::lrint(lower_hsv[k]); rg.hi[k] = (int)std::lrint(upper_hsv[k]); }
-    activate_lane(d, lane);
-    rc = enqueue_upload_wait(d, first_slot, n_slots);
-    if (!rc) {
-        u32* mask = reinterpret_cast<u32*>(d->frame_arena + (size_t)first_slot * d->frame_stride + d->off_cmask);
-        lmk_hsv_mask(d->stream, d->bgr(first_slot, 0), d->cfg.width, d->cfg.height, rg, d->d_hsv_div, mask, d->cmask_wpr, d->frame_stride, d->frame_stride, n_slots);
-        if (!d->mask_done[lane]) HIP_TRY(hipEventCreateWithFlags(&d->mask_done[lane], hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(d->mask_done[lane], d->stream));
-        for (int i = 0; i < n_slots; ++i) {
-            Slot& s = d->slots[first_slot + i];
-            s.mask_ready = true; s.mask_lane = lane;
-            for (int k = 0; k < 3; ++k) { s.mask_lo[k] = rg.lo[k]; s.mask_hi[k] = rg.hi[k]; }
-        }
-    }
-    activate_lane(d, 0);
-    return rc;
-}
-
-int lm_color_check_counts(lm_detector* d, int slot, const double lower_hsv[3], const double upper_hsv[3],
-                          const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both) {
-    return colour_check(d, nullptr, slot, lower_hsv, upper_hsv, matches, n, in_hull, in_both);
-}
-
-int lm_color_check_begin_slots(lm_detector* d, const int32_t* slot_of_match, const double lower_hsv[3], const double upper_hsv[3],
-                               const lm_match_t* matches, size_t n) {
-    if (n && !slot_of_match) return fail(LM_ERR_INVALID, "null argument");
-    if (n == 0) { if (d) { if (d->cc_inflight) return fail(LM_ERR_INVALID, "a colour check is in flight: call lm_color_check_end first"); d->cc_inflight = true; d->cc_pending = 0; } return d ? LM_OK : fail(LM_ERR_INVALID, "null detector"); }
-    return colour_check_enqueue(d, slot_of_match, 0, lower_hsv, upper_hsv, matches, n);
-}
-
-int lm_color_check_end(lm_detector* d, int64_t* in_hull, int64_t* in_both) {
-    if (d && d->cc_inflight && d->cc_pending == 0) { d->cc_inflight = false; return LM_OK; }     // an empty list was begun: nothing was enqueued
-    return colour_check_finish(d, in_hull, in_both);
-}
-
-int lm_color_check_counts_slots(lm_detector* d, const int32_t* slot_of_match, const double lower_hsv[3], const double upper_hsv[3],
-                                const lm_match_t* matches, size_t n, int64_t* in_hull, int64_t* in_both) {
-    if (n && !slot_of_match) return fail(LM_ERR_INVALID, "null argument");
-    return colour_check(d, slot_of_match, 0, lower_hsv, upper_hsv, matches, n, in_hull, in_both);
-}
-
-// ---- r06: the depth check's counts for a batch of queries (include/linemod_hip.h lm_depth_counts_begin) -----------------------------------
-int lm_depth_counts_begin(lm_detector* d, const lm_depth_query* q, size_t n) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if (d->dc_inflight) return fail(LM_ERR_INVALID, "depth counts are in flight: call lm_depth_counts_end first");
-    if (n && !q) return fail(LM_ERR_INVALID, "null argument");
-    if (d->cfg.num_modalities < 2) return fail(LM_ERR_INVALID, "the detector keeps no depth frame on the device (no depth modality)");
-    static_assert(sizeof(lm_depth_query) == sizeof(LmDepthQuery), "lm_depth_query layout");
-    const int S = (int)d->slots.size(), W = d->cfg.width, H = d->cfg.height;
-    std::vector<char> used((size_t)S, 0);
-    for (size_t i = 0; i < n; ++i) {
-        const lm_depth_query& e = q[i];
-        if (e.slot < 0 || e.slot >= S) return fail(LM_ERR_INVALID, "slot out of range");
-        if (e.x0 < 0 || e.y0 < 0 || e.x1 > W || e.y1 > H || e.x1 < e.x0 || e.y1 < e.y0) return fail(LM_ERR_INVALID, "query " + std::to_string(i) + ": crop outside the frame");
-        used[(size_t)e.slot] = 1;
-    }
-    for (int sl = 0; sl < S; ++sl) {
-        if (!used[(size_t)sl]) continue;
-        if (!d->slots[(size_t)sl].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
-    }
-    d->dc_pending = 0; d->dc_inflight = true;
-    if (n == 0) return LM_OK;
-    if ((rc = ensure_colour_check(d, 0))) { d->dc_inflight = false; return rc; }      // (the stream)
-    if (n > d->dc_cap) {
-        const size_t cap = std::max<size_t>(align_up(n, 4096), 16384);
-        const size_t bytes = cap * (sizeof(LmDepthQuery) + 2 * sizeof(u32));
-        u8* dev = nullptr; u8* host = nullptr;
-        if (hipStreamSynchronize(d->cc_stream) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&dev), bytes) != hipSuccess) { d->dc_inflight = false; (void)hipGetLastError(); return fail(LM_ERR_HIP, "allocation of the depth counts' buffers failed"); }
-        if (hipHostMalloc(reinterpret_cast<void**>(&host), bytes) != hipSuccess) { (void)hipFree(dev); d->dc_inflight = false; (void)hipGetLastError(); return fail(LM_ERR_HIP, "hipHostMalloc of the depth counts' buffers failed"); }
-        (void)hipFree(d->dc_dev); if (d->dc_host) (void)hipHostFree(d->dc_host);
-        d->dc_dev = dev; d->dc_host = host; d->dc_cap = cap;
-    }
-    hipStream_t st = d->cc_stream;
-    auto bail = [&](hipError_t e) { d->dc_inflight = false; (void)hipStreamSynchronize(st); return fail(LM_ERR_HIP, hipGetErrorString(e)); };
-    // the frames' uploads (copy streams) must have landed before the kernel reads them
-    for (int sl = 0; sl < S; ++sl) {
-        const Slot& s = d->slots[(size_t)sl];
-        if (used[(size_t)sl] && s.up_seq > d->up_seq_done[s.up_stream]) { const hipError_t e = hipStreamWaitEvent(st, s.ev_up, 0); if (e != hipSuccess) return bail(e); }
-    }
-    const size_t off_out = d->dc_cap * sizeof(LmDepthQuery);
-    std::memcpy(d->dc_host, q, n * sizeof(LmDepthQuery));
-    hipError_t e = hipMemcpyAsync(d->dc_dev, d->dc_host, n * sizeof(LmDepthQuery), hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return bail(e);
-    LmDepthArgs a;
-    a.depth = d->depth(0); a.slot_stride = d->frame_stride; a.w = W; a.h = H;
-    a.q = reinterpret_cast<const LmDepthQuery*>(d->dc_dev); a.n = (u32)n;
-    a.out = reinterpret_cast<u32*>(d->dc_dev + off_out);
-    lmk_depth_counts(st, a);
-    e = hipMemcpyAsync(d->dc_host + off_out, a.out, n * 2 * sizeof(u32), hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) return bail(e);
-    e = hipEventRecord(d->dc_done, st);
-    if (e != hipSuccess) return bail(e);
-    d->dc_pending = n;
-    d->dc_lo = S; d->dc_hi = -1;
-    for (int sl = 0; sl < S; ++sl) if (used[(size_t)sl]) { d->dc_lo = std::min(d->dc_lo, sl); d->dc_hi = std::max(d->dc_hi, sl); }
-    return LM_OK;
-}
-
-int lm_depth_counts_end(lm_detector* d, uint32_t* below, uint32_t* inside) {
-    if (!d || !d->dc_inflight) return fail(LM_ERR_INVALID, "no depth counts in flight");
-    const size_t n = d->dc_pending;
-    d->dc_inflight = false; d->dc_pending = 0;
-    if (n == 0) return LM_OK;
-    if (!below || !inside) { (void)hipStreamSynchronize(d->cc_stream); return fail(LM_ERR_INVALID, "null argument"); }
-    HIP_TRY(hipSetDevice(d->cfg.device));
-    HIP_TRY(hipEventSynchronize(d->dc_done));
-    HIP_TRY(hipGetLastError());
-    const u32* out = reinterpret_cast<const u32*>(d->dc_host + d->dc_cap * sizeof(LmDepthQuery));
-    for (size_t i = 0; i < n; ++i) { below[i] = out[2 * i]; inside[i] = out[2 * i + 1]; }
-    return LM_OK;
-}
-
-// ---- multi-GPU exchange: RCCL all-gather of the per-shard lists ---------------------------------
-static void free_gather(lm_detector* d) {
-    for (auto& g : d->gather) {
-        hipFree(g.d_cnt); hipFree(g.d_rec); hipFree(g.d_all_cnt); hipFree(g.d_all_rec);
-        if (g.h_all_cnt) hipHostFree(g.h_all_cnt);
-        if (g.h_all_rec) hipHostFree(g.h_all_rec);
-        g = lm_detector::Gather();
-    }
-    hipFree(d->d_red); d->d_red = nullptr;
-}
-
-int lm_comm_init(lm_detector* d, int rank, int world, const char* addr, int port, int recs_per_frame_cap) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    if (d->comm[0]) return fail(LM_ERR_INVALID, "communicator already initialised");
-    if (world < 1 || rank < 0 || rank >= world) return fail(LM_ERR_INVALID, "bad rank / world size");
-    if (recs_per_frame_cap <= 0) recs_per_frame_cap = 256;
-    if (recs_per_frame_cap > LM_SORT_CAP) recs_per_frame_cap = LM_SORT_CAP;
-    // Buffers first, communicators last: a failure on the way leaves NOTHING behind (no communicator without its
-    // buffers -- lm_match_begin_gathered keys on comm[0] -- and the call can simply be repeated).
-    const size_t S = d->slots.size(), R = (size_t)world, cap = (size_t)recs_per_frame_cap * S;
-    auto alloc_all = [&]() -> int {
-        for (auto& g : d->gather) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_cnt), (S + 1) * sizeof(int)));
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_rec), cap * sizeof(LmOutMatch)));
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_all_cnt), R * (S + 1) * sizeof(int)));
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_all_rec), R * cap * sizeof(LmOutMatch)));
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g.h_all_cnt), R * (S + 1) * sizeof(int)));
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g.h_all_rec), R * cap * sizeof(LmOutMatch)));
-        }
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_red), 64 * sizeof(double)));   // [0, 32) send | [32, 64) receive
-        return LM_OK;
-    };
-    if ((rc = alloc_all())) { const std::string msg = g_err; free_gather(d); return fail(rc, msg); }
-    // ONE rendezvous for the ids of all lanes' communicators (rank 0 draws them), then the ncclCommInitRank calls in
-    // lane order on every rank.
-    LmComm* cs[LM_NLANES] = {};
-    unsigned char ids[LM_NLANES][LM_NCCL_ID_BYTES] = {};
-    std::string err;
-    bool ok = true;
-    for (int l = 0; l < LM_NLANES && ok; ++l) {
-        cs[l] = new LmComm();
-        ok = cs[l]->load(err) && (rank != 0 || cs[l]->unique_id(ids[l], err));
-    }
-    if (ok) ok = lm_tcp_broadcast(rank, world, addr ? addr : "127.0.0.1", port, 120, ids, sizeof(ids), err);
-    for (int l = 0; l < LM_NLANES && ok; ++l) ok = cs[l]->init_rank(rank, world, ids[l], err);
-    if (!ok) {
-        for (auto& c : cs) delete c;
-        free_gather(d);
-        return fail(LM_ERR_HIP, err);
-    }
-    for (int l = 0; l < LM_NLANES; ++l) d->comm[l] = cs[l];
-    d->comm_recs_per_frame = recs_per_frame_cap;
-    return LM_OK;
-}
-
-int lm_rendezvous_broadcast(int rank, int world, const char* addr, int port, void* buf, size_t n, int timeout_s) {
-    if (!buf || world < 1 || rank < 0 || rank >= world) return fail(LM_ERR_INVALID, "bad argument");
-    std::string err;
-    if (!lm_tcp_broadcast(rank, world, addr ? addr : "127.0.0.1", port, timeout_s > 0 ? timeout_s : 60, buf, n, err)) return fail(LM_ERR_IO, err);
-    return LM_OK;
-}
-
-int lm_comm_destroy(lm_detector* d) {
-    if (!d) return fail(LM_ERR_INVALID, "null detector");
-    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    if (d->comm[0]) {
-        hipSetDevice(d->cfg.device);
-        hipDeviceSynchronize();
-        for (auto& c : d->comm) { delete c; c = nullptr; }
-        free_gather(d);
-    }
-    return LM_OK;
-}
-
-int lm_comm_info(const lm_detector* d, int* rank, int* world) {
-    if (!d || !d->comm[0]) return fail(LM_ERR_INVALID, "no communicator");
-    if (rank) *rank = d->comm[0]->rank;
-    if (world) *world = d->comm[0]->world;
-    return LM_OK;
-}
-
-// element-wise maximum over the ranks of n <= 32 doubles; returns when every rank's value has arrived
-int lm_comm_max(lm_detector* d, double* v, int n) {
-    if (!d || !d->comm[0] || !v || n < 1 || n > 32) return fail(LM_ERR_INVALID, "bad argument");
-    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    HIP_TRY(hipSetDevice(d->cfg.device));
-    std::string err;
-    HIP_TRY(hipMemcpyAsync(d->d_red, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, d->stream));
-    if (!d->comm[0]->all_reduce_max_f64(d->d_red, d->d_red + 32, (size_t)n, d->stream, err)) return fail(LM_ERR_HIP, err);
-    HIP_TRY(hipMemcpyAsync(v, d->d_red + 32, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    return LM_OK;
-}
-
-// every rank's device is idle and every rank has reached this call
-int lm_comm_barrier(lm_detector* d) {
-    if (!d || !d->comm[0]) return fail(LM_ERR_INVALID, "no communicator");
-    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    HIP_TRY(hipSetDevice(d->cfg.device));
-    HIP_TRY(hipDeviceSynchronize());
-    double one = 1.0;
-    int rc = lm_comm_max(d, &one, 1);
-    if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    return LM_OK;
-}
-
-// behind k_sort_unique on the active lane's stream: pack the lane's sorted lists, all-gather their lengths and the
-// packed records (fixed capacity per rank, so no host round trip sits between the two collectives), copy both to
-// pinned host memory.
-static int enqueue_gather(lm_detector* d, int lane, int first, int n) {
-    lm_detector::Gather& g = d->gather[lane];
-    LmComm* comm = d->comm[lane];
-    const size_t R = (size_t)comm->world;
-    g.cap_lane = (u32)d->comm_recs_per_frame * (u32)n;
-    LmPackArgs pa;
-    pa.hdr = reinterpret_cast<const LmDevHeader*>(d->aux(first, d->off_hdr));
-    pa.out = reinterpret_cast<const LmOutMatch*>(d->aux(first, d->off_out));
-    pa.aux_slot_stride = d->aux_stride;
-    pa.nslots = n; pa.cap_total = g.cap_lane; pa.cnt = g.d_cnt; pa.rec = g.d_rec;
-    lmk_pack_lists(d->stream, pa);
-    std::string err;
-    const size_t cb = (size_t)(n + 1) * sizeof(int), rb = (size_t)g.cap_lane * sizeof(LmOutMatch);
-    if (!comm->all_gather(g.d_cnt, g.d_all_cnt, cb, d->stream, err)) return fail(LM_ERR_HIP, err);
-    if (!comm->all_gather(g.d_rec, g.d_all_rec, rb, d->stream, err)) return fail(LM_ERR_HIP, err);
-    // only the lengths come to the host here: lm_match_end_gathered then fetches, per rank, exactly the records of the frames
-    // THIS rank merges (a contiguous piece of every rank's packed run) -- with R ranks 1 / R of the real records instead of
-    // R x the gather capacity over the PCIe link every lane-step
-    HIP_TRY(hipMemcpyAsync(g.h_all_cnt, g.d_all_cnt, R * cb, hipMemcpyDeviceToHost, d->stream));
-    if (d->profiling) HIP_TRY(hipEventRecord(d->ev[5], d->stream));   // exchange span = ev[4] (behind the sort) -> ev[5]
-    HIP_TRY(hipGetLastError());
-    return LM_OK;
-}
-
-// The sized second exchange of the gathered path: some rank's lists did not fit the fixed-capacity gather, or a frame was
-// left to the host sort (> LM_SORT_CAP matches).  The single-GPU path returns such lists (collect_slot), so the sharded
-// one must too (the reference consumes ALL matches, HighLevelLinemod.cpp:206-253).  Every rank: collect its own lists
-// on the host (host sort where needed), all-gather the exact per-frame counts, all-gather the packed records in buffers
-// sized to the largest rank, merge the owned frames.  Synchronous, on the lane's own communicator and stream; this is
-// the slow path of low thresholds, not of the benchmark.
-static int gather_fallback(lm_detector* d, int lane, int first, int n, int f0, int f1, lm_match_t* out, size_t cap,
-                           int32_t* counts, size_t* n_out) {
-    lm_detector::Gather& g = d->gather[lane];
-    LmComm* comm = d->comm[lane];
-    const size_t R = (size_t)comm->world;
-    hipStream_t st = d->lanes[lane].stream ? d->lanes[lane].stream : d->stream;
-    if (lane == 0) st = d->stream;
-    // 1. this rank's lists, exact
-    std::vector<lm_match_t> mine;
-    std::vector<int32_t> my_cnt((size_t)n + 1, 0);
-    int local_rc = LM_OK;
-    std::string local_msg;
-    for (int i = 0; i < n; ++i) {
-        size_t k = 0;
-        int rc = collect_slot(d, first + i, nullptr, 0, &k);           // length (runs the host sort for host-sorted frames)
-        if (!rc) {
-            const size_t at = mine.size();
-            mine.resize(at + k);
-            rc = collect_slot(d, first + i, mine.data() + at, k, &k);
-        }
-        if (rc && !local_rc) { local_rc = rc; local_msg = g_err; }
-        my_cnt[(size_t)i] = (int32_t)k;
-    }
-    my_cnt[(size_t)n] = local_rc ? 4 : 0;                               // status travels with the counts: all ranks agree
-    // 2. exact counts of every rank
-    std::string err;
-    const size_t cb = (size_t)(n + 1) * sizeof(int);
-    HIP_TRY(hipMemcpyAsync(g.d_cnt, my_cnt.data(), cb, hipMemcpyHostToDevice, st));
-    if (!comm->all_gather(g.d_cnt, g.d_all_cnt, cb, st, err)) return fail(LM_ERR_HIP, err);
-    HIP_TRY(hipMemcpyAsync(g.h_all_cnt, g.d_all_cnt, R * cb, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    std::vector<int32_t> cnt(R * (size_t)n);
-    uint64_t max_total64 = 1;
-    {
-        int st_all = 0, bad = -1, pf0 = 0, pf1 = 0;
-        const int prc = lm_gather_plan(g.h_all_cnt, (int)R, n, comm->rank, &st_all, &bad, &pf0, &pf1, cnt.data(), nullptr, nullptr);
-        if (prc) return prc;
-        if (st_all) {
-            if (local_rc) return fail(local_rc, local_msg);
-            return fail(LM_ERR_OVERFLOW, "rank " + std::to_string(bad) + " could not deliver its match lists");
-        }
-        (void)lm_gather_max_total(cnt.data(), (int)R, n, &max_total64);
-    }
-    const size_t max_total = (size_t)max_total64;
-    // 3. records, in buffers sized to the largest rank
-    // A rank-local failure here (an allocation on a nearly full device, a failed copy) must not leave the other ranks blocked in
-    // the sized all-gather: every rank reports whether it is ready, the flags are all-gathered, and all ranks go on
-    // or give up TOGETHER.
-    LmOutMatch *d_send = nullptr, *d_recv = nullptr;
-    std::vector<lm_match_t> all;
-    hipError_t he = hipMalloc(reinterpret_cast<void**>(&d_send), max_total * sizeof(LmOutMatch));
-    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_recv), R * max_total * sizeof(LmOutMatch));
-    bool host_ok = true;
-    try { all.resize(R * max_total); } catch (const std::bad_alloc&) { host_ok = false; }
-    if (he == hipSuccess && host_ok && !mine.empty())
-        he = hipMemcpyAsync(d_send, mine.data(), mine.size() * sizeof(lm_match_t), hipMemcpyHostToDevice, st);
-    int32_t ready = (he == hipSuccess && host_ok) ? 0 : 1;
-    std::vector<int32_t> ready_all(R, 0);
-    bool ok = true;
-    hipError_t fe = hipMemcpyAsync(g.d_cnt, &ready, sizeof(ready), hipMemcpyHostToDevice, st);
-    if (fe == hipSuccess) ok = comm->all_gather(g.d_cnt, g.d_all_cnt, sizeof(int32_t), st, err);
-    if (fe == hipSuccess && ok) fe = hipMemcpyAsync(ready_all.data(), g.d_all_cnt, R * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-    if (fe == hipSuccess && ok) fe = hipStreamSynchronize(st);
-    int not_ready = -1;
-    for (size_t r = 0; r < R; ++r) if (ready_all[r] && not_ready < 0) not_ready = (int)r;
-    if (!ok || fe != hipSuccess || not_ready >= 0) {
-        (void)hipFree(d_send); (void)hipFree(d_recv);
-        if (!ok) return fail(LM_ERR_HIP, err);
-        if (fe != hipSuccess) return fail(LM_ERR_HIP, std::string("sized exchange (readiness): ") + hipGetErrorString(fe));
-        if (he != hipSuccess) return fail(LM_ERR_HIP, std::string("sized exchange buffers: ") + hipGetErrorString(he));
-        if (!host_ok) return fail(LM_ERR_HIP, "sized exchange: host buffer allocation failed");
-        return fail(LM_ERR_HIP, "rank " + std::to_string(not_ready) + " could not set up the sized exchange; all ranks gave up together");
-    }
-    ok = comm->all_gather(d_send, d_recv, max_total * sizeof(LmOutMatch), st, err);
-    if (ok) he = hipMemcpyAsync(all.data(), d_recv, all.size() * sizeof(lm_match_t), hipMemcpyDeviceToHost, st);
-    if (he == hipSuccess && ok) he = hipStreamSynchronize(st);
-    (void)hipFree(d_send); (void)hipFree(d_recv);
-    if (!ok) return fail(LM_ERR_HIP, err);
-    if (he != hipSuccess) return fail(LM_ERR_HIP, std::string("sized exchange: ") + hipGetErrorString(he));
-    // 4. merge the frames this rank owns
-    return lm_merge_frames(all.data(), max_total, cnt.data(), (int)R, n, f0, f1, out, cap, counts, n_out);
-}
-
-int lm_match_end_gathered(lm_detector* d, int lane, lm_match_t* out, size_t cap, int32_t* counts, int* first_frame,
-                          int* n_frames, size_t* n_out) {
-    if (!d) return fail(LM_ERR_INVALID, "null detector");
-    if (lane < 0 || lane >= LM_NLANES) return fail(LM_ERR_INVALID, "lane out of range (0 .. 3)");
-    lm_detector::Lane& ln = d->lanes[lane];
-    lm_detector::Gather& g = d->gather[lane];
-    if (!ln.busy || !g.active) return fail(LM_ERR_INVALID, "lane has no gathered match in flight");
-    HIP_TRY(hipSetDevice(d->cfg.device));
-    activate_lane(d, lane);
-    const int wrc = wait_lane_done(d, ln);
-    if (!wrc && ln.timed) account_profile(d, ln.n, ln.classes, true);
-    activate_lane(d, 0);
-    ln.busy = false; g.active = false;
-    if (wrc) return wrc;
-    const int n = ln.n, R = d->comm[0]->world, rank = d->comm[0]->rank;
-    const int f0 = (int)((long long)n * rank / R), f1 = (int)((long long)n * (rank + 1) / R);
-    if (first_frame) *first_frame = f0;
-    if (n_frames) *n_frames = f1 - f0;
-    for (int i = 0; i < n; ++i) note_sort_length(d, d->host_block(ln.first + i)->hdr.match_count);
-    // The status words every rank gathered are identical on all ranks, so all ranks take the same branch below (the
-    // fallback holds collectives): lm_gather_plan (lm_host.cpp, host-only and unit-tested at R = 2, 3, 8) reads them.
-    int status = 0, bad_rank = -1, pf0 = 0, pf1 = 0;
-    std::vector<int32_t> cnt((size_t)R * n);
-    std::vector<uint64_t> piece_start((size_t)R), piece_len((size_t)R);
-    {
-        const int prc = lm_gather_plan(g.h_all_cnt, R, n, rank, &status, &bad_rank, &pf0, &pf1, cnt.data(), piece_start.data(), piece_len.data());
-        if (prc) return prc;
-    }
-    if (status & 4) {
-        if (bad_rank == rank)      // this shard's own capacity overflow: same message as the ungathered path
-            for (int i = 0; i < n; ++i) {
-                const LmHeader h = d->host_block(ln.first + i)->hdr;
-                if (h.cand_count > d->max_cand || h.match_count > d->max_match) { size_t dummy; return collect_slot(d, ln.first + i, nullptr, 0, &dummy); }
-            }
-        return fail(LM_ERR_OVERFLOW, "rank " + std::to_string(bad_rank) + " overflowed its candidate / match capacity (raise lm_config.max_candidates / max_matches)");
-    }
-    if (status == 0) {
-        // the owned frames' records of every rank: frames are packed in order, so they are ONE contiguous piece per rank
-        activate_lane(d, lane);
-        int crc = LM_OK;
-        for (int r = 0; r < R && !crc; ++r) {
-            const size_t start = (size_t)piece_start[(size_t)r], len = (size_t)piece_len[(size_t)r];
-            if (start + len > (size_t)g.cap_lane) { crc = fail(LM_ERR_INVALID, "gathered counts exceed the gather capacity"); break; }
-            if (!len) continue;
-            const size_t at = (size_t)r * g.cap_lane + start;
-            if (hipMemcpyAsync(g.h_all_rec + at, g.d_all_rec + at, len * sizeof(LmOutMatch), hipMemcpyDeviceToHost, d->stream) != hipSuccess)
-                crc = fail(LM_ERR_HIP, "D2H of the gathered records failed");
-        }
-        if (!crc) crc = wait_stream(d);
-        activate_lane(d, 0);
-        if (crc) return crc;
-        return lm_merge_frames(reinterpret_cast<const lm_match_t*>(g.h_all_rec), g.cap_lane, cnt.data(), R, n, f0, f1, out, cap, counts, n_out);
-    }
-    d->prof_exch_fallbacks += 1;
-    return gather_fallback(d, lane, ln.first, n, f0, f1, out, cap, counts, n_out);
-}
-
-// 8e bookkeeping of the gathered path, host-only (lm_match_end_gathered and its sized fallback call it; tests/test_dist.py drives
-// it at R = 2, 3, 8 on synthetic gathered buffers).  all_cnt: what the all-gather of the lengths delivers, R runs of n + 1 ints
-// -- cnt[i] = records of frame i in that rank's packed run, [n] = the rank's status word (bit 0 lists did not fit the fixed
-// capacity, bit 1 a frame was left to the host sort, bit 2 the shard overflowed its own capacity).  Out: the OR of the status
-// words, the first rank with bit 2 set (or -1), the frames [f0, f1) rank `rank` merges, counts as [R][n], and per rank the
-// piece of its packed run that holds exactly the owned frames (start, len in records; frames are packed in order).
-int lm_gather_plan(const int32_t* all_cnt, int n_ranks, int n_frames, int rank, int* status, int* bad_rank, int* f0, int* f1,
-                   int32_t* counts, uint64_t* piece_start, uint64_t* piece_len) {
-    if (!all_cnt || n_ranks < 1 || n_frames < 0 || rank < 0 || rank >= n_ranks) return fail(LM_ERR_INVALID, "bad argument");
-    const int n = n_frames, R = n_ranks;
-    const int lo = (int)((long long)n * rank / R), hi = (int)((long long)n * (rank + 1) / R);
-    int st = 0, bad = -1;
-    for (int r = 0; r < R; ++r) {
-        const int32_t* c = all_cnt + (size_t)r * (size_t)(n + 1);
-        st |= c[n];
-        if ((c[n] & 4) && bad < 0) bad = r;
-        uint64_t start = 0, len = 0;
-        for (int i = 0; i < n; ++i) {
-            if (c[i] < 0) return fail(LM_ERR_INVALID, "negative count in the gathered lengths");
-            if (counts) counts[(size_t)r * n + i] = c[i];
-            if (i < lo) start += (uint64_t)c[i];
-            else if (i < hi) len += (uint64_t)c[i];
-        }
-        if (piece_start) piece_start[r] = start;
-        if (piece_len) piece_len[r] = len;
-    }
-    if (status) *status = st;
-    if (bad_rank) *bad_rank = bad;
-    if (f0) *f0 = lo;
-    if (f1) *f1 = hi;
-    return LM_OK;
-}
-
-// Records of the largest rank's packed run (at least 1): the per-rank buffer size of the sized second exchange.
-int lm_gather_max_total(const int32_t* counts, int n_ranks, int n_frames, uint64_t* max_total) {
-    if (!counts || !max_total || n_ranks < 1 || n_frames < 0) return fail(LM_ERR_INVALID, "bad argument");
-    uint64_t best = 1;
-    for (int r = 0; r < n_ranks; ++r) {
-        uint64_t tot = 0;
-        for (int i = 0; i < n_frames; ++i) {
-            if (counts[(size_t)r * n_frames + i] < 0) return fail(LM_ERR_INVALID, "negative count");
-            tot += (uint64_t)counts[(size_t)r * n_frames + i];
-        }
-        best = std::max(best, tot);
-    }
-    *max_total = best;
-    return LM_OK;
-}
-
-int lm_merge_matches(const lm_match_t* lists, const int32_t* counts, int n_lists, size_t stride, lm_match_t* out,
-                     size_t cap, size_t* n_out) {
-    if (!lists || !counts || n_lists < 0) return fail(LM_ERR_INVALID, "null argument");
-    std::vector<lm_match_t> all;
-    for (int i = 0; i < n_lists; ++i) {
-        if (counts[i] < 0 || (size_t)counts[i] > stride) return fail(LM_ERR_INVALID, "count exceeds stride");
-        all.insert(all.end(), lists + (size_t)i * stride, lists + (size_t)i * stride + counts[i]);
-    }
-    lmh::sort_unique(all);
-    if (n_out) *n_out = all.size();
-    if (out && !all.empty() && cap) std::memcpy(out, all.data(), std::min(all.size(), cap) * sizeof(lm_match_t));
-    if (all.size() > cap && out) return fail(LM_ERR_OVERFLOW, "output buffer too small");
-    return LM_OK;
-}
-
-// Per-frame lists at a fixed stride -> one contiguous run (what travels in the shard all-gather).
-int lm_pack_matches(const lm_match_t* recs, size_t stride, const int32_t* counts, int n_frames, lm_match_t* out,
-                    size_t cap, size_t* n_out) {
-    if (!recs || !counts || n_frames < 0) return fail(LM_ERR_INVALID, "null argument");
-    size_t total = 0;
-    for (int i = 0; i < n_frames; ++i) {
-        if (counts[i] < 0 || (size_t)counts[i] > stride) return fail(LM_ERR_INVALID, "count exceeds stride");
-        total += (size_t)counts[i];
-    }
-    if (n_out) *n_out = total;
-    if (!out) return LM_OK;
-    if (total > cap) return fail(LM_ERR_OVERFLOW, "output buffer too small");
-    size_t pos = 0;
-    for (int i = 0; i < n_frames; ++i) {
-        std::memcpy(out + pos, recs + (size_t)i * stride, (size_t)counts[i] * sizeof(lm_match_t));
-        pos += (size_t)counts[i];
-    }
-    return LM_OK;
-}
-
-// The merge step of a whole batch after the all-gather: rank r's packed run starts at packed + r * rank_stride
-// and holds its frames back to back (counts[r * n_frames + i] records for frame i).  Frame i of the output is the
-// R-way merge + adjacent-unique of the R sorted lists (pairwise std::merge), frames are spread over a few host
-// threads; output packed the same way with out_counts[i].
-int lm_merge_batch(const lm_match_t* packed, size_t rank_stride, const int32_t* counts, int n_ranks, int n_frames,
-                   lm_match_t* out, size_t cap, int32_t* out_counts, size_t* n_out) {
-    return lm_merge_frames(packed, rank_stride, counts, n_ranks, n_frames, 0, n_frames, out, cap, out_counts, n_out);
-}
-
-// Only the frames [frame_lo, frame_hi) of the batch: the ranks share the merge work by frame (rank r merges the
-// frames it owns; every rank still holds the gathered lists of all frames).  out_counts has frame_hi - frame_lo entries.
-int lm_merge_frames(const lm_match_t* packed, size_t rank_stride, const int32_t* counts, int n_ranks, int n_frames,
-                    int frame_lo, int frame_hi, lm_match_t* out, size_t cap, int32_t* out_counts, size_t* n_out) {
-    if (!packed || !counts || !out_counts || n_ranks <= 0 || n_frames < 0) return fail(LM_ERR_INVALID, "bad argument");
-    if (frame_lo < 0 || frame_hi < frame_lo || frame_hi > n_frames) return fail(LM_ERR_INVALID, "bad frame range");
-    const size_t R = (size_t)n_ranks, F = (size_t)n_frames;
-    const size_t lo = (size_t)frame_lo, hi = (size_t)frame_hi, Fo = hi - lo;
-    std::vector<size_t> start(R * F);      // start of (rank, frame) inside the rank's run
-    std::vector<size_t> bound(Fo + 1, 0);  // upper bound of the merged output of the owned frames before unique
-    for (size_t r = 0; r < R; ++r) {
-        size_t pos = 0;
-        for (size_t i = 0; i < F; ++i) {
-            const int32_t c = counts[r * F + i];
-            if (c < 0) return fail(LM_ERR_INVALID, "negative count");
-            start[r * F + i] = pos;
-            pos += (size_t)c;
-            if (i >= lo && i < hi) bound[i - lo + 1] += (size_t)c;
-        }
-        if (pos > rank_stride) return fail(LM_ERR_INVALID, "counts exceed rank_stride");
-    }
-    for (size_t i = 0; i < Fo; ++i) bound[i + 1] += bound[i];
-    std::vector<lm_match_t> tmp(bound[Fo]);
-    auto work = [&](size_t a0, size_t a1) {
-        std::vector<lm_match_t> a, b;
-        for (size_t k = a0; k < a1; ++k) {
-            const size_t i = lo + k;
-            a.clear();
-            for (size_t r = 0; r < R; ++r) {
-                const lm_match_t* src = packed + r * rank_stride + start[r * F + i];
-                const size_t c = (size_t)counts[r * F + i];
-                b.resize(a.size() + c);
-                std::merge(a.begin(), a.end(), src, src + c, b.begin(), lmh::match_less);
-                a.swap(b);
-            }
-            a.erase(std::unique(a.begin(), a.end(), lmh::match_eq), a.end());
-            std::copy(a.begin(), a.end(), tmp.begin() + (ptrdiff_t)bound[k]);
-            out_counts[k] = (int32_t)a.size();
-        }
-    };
-    const size_t nthreads = std::min<size_t>(bound[Fo] >= 50000 ? 4 : 1, std::max(1u, std::thread::hardware_concurrency()));
-    if (nthreads <= 1) work(0, Fo);
-    else {
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < nthreads; ++t) th.emplace_back(work, Fo * t / nthreads, Fo * (t + 1) / nthreads);
-        for (auto& x : th) x.join();
-    }
-    size_t total = 0;
-    for (size_t i = 0; i < Fo; ++i) total += (size_t)out_counts[i];
-    if (n_out) *n_out = total;
-    if (out) {
-        if (total > cap) return fail(LM_ERR_OVERFLOW, "output buffer too small");
-        size_t pos = 0;
-        for (size_t i = 0; i < Fo; ++i) {
-            std::memcpy(out + pos, tmp.data() + bound[i], (size_t)out_counts[i] * sizeof(lm_match_t));
-            pos += (size_t)out_counts[i];
-        }
-    }
-    return LM_OK;
-}
-
-int lm_save_bank(const lm_detector* d, const char* path) {
-    if (!d || !path) return fail(LM_ERR_INVALID, "null argument");
-    std::string err;
-    if (!lmh::save_bank(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
-    return LM_OK;
-}
-int lm_load_bank(lm_detector* d, const char* path) {
-    if (d && any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    if (!d || !path) return fail(LM_ERR_INVALID, "null argument");
-    std::string err;
-    if (!lmh::load_bank(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
-    d->bank_dirty = true; d->hulls_dirty = true;
-    return LM_OK;
-}
-
-int lm_save_yaml(const lm_detector* d, const char* path) {
-    if (!d || !path) return fail(LM_ERR_INVALID, "null argument");
-    std::string err;
-    if (!lmy::save_templates_yaml(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
-    return LM_OK;
-}
-int lm_load_yaml(lm_detector* d, const char* path) {
-    if (d && any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    if (!d || !path) return fail(LM_ERR_INVALID, "null argument");
-    std::string err;
-    if (!lmy::load_templates_yaml(d->bank, d->cfg, path, err)) return fail(LM_ERR_IO, err);
-    d->bank_dirty = true; d->hulls_dirty = true;
-    for (Slot& sl : d->slots) sl.prepared = false;   // the file's modality parameters (thresholds) replaced the detector's: a3-a10 results are stale
-    if (d->cfg.num_modalities == 2 && d->normal_lut_substitute) {
-        static bool warned = false;
-        if (!warned) {
-            warned = true;
-            std::fprintf(stderr, "liblinemod_hip: warning: %s holds DepthNormal templates, but the built-in NORMAL_LUT is a "
-                                 "substitute for OpenCV's normal_lut.i (SURVEY.md A.4): a bank WRITTEN BY OpenCV will be scored "
-                                 "against differently quantised normals.  Install the real table with lm_set_normal_lut, or "
-                                 "regenerate the bank with this library.\n", path);
-        }
-    }
-    return LM_OK;
-}
-
-// Top-level scalars / number lists of a cv::FileStorage YAML file (linemod_settings.yml, models/<name>.yml,
-// benchmark/pose0.yml): the host glue reads its settings through these.
-// Returns the status code (LM_ERR_IO: unreadable / unparsable file; LM_ERR_INVALID: no such key) and the node.
-static int yaml_top(const char* path, const char* key, lmy::Node& root, const lmy::Node** out) {
-    std::string text, err;
-    *out = nullptr;
-    if (!lmy::read_text_file(path, text, err)) return fail(LM_ERR_IO, err);
-    if (!lmy::parse(text, root, err)) return fail(LM_ERR_IO, std::string(path) + ": " + err);
-    const lmy::Node* n = root.get(key);
-    if (!n) return fail(LM_ERR_INVALID, std::string("no key '") + key + "' in " + path);
-    *out = n;
-    return LM_OK;
-}
-int lm_yaml_numbers(const char* path, const char* key, double* out, size_t cap, size_t* n_out) {
-    if (!path || !key) return fail(LM_ERR_INVALID, "null argument");
-    lmy::Node root;
-    const lmy::Node* n = nullptr;
-    int rc;
-    if ((rc = yaml_top(path, key, root, &n))) return rc;
-    if (n->kind == lmy::Node::Map && n->get("data")) n = n->get("data");   // !!opencv-matrix
-    std::vector<double> v;
-    double d;
-    if (n->kind == lmy::Node::Nums) v = n->nums;
-    else if (n->number(&d)) v.push_back(d);
-    else return fail(LM_ERR_INVALID, std::string("'") + key + "' is not numeric");
-    if (n_out) *n_out = v.size();
-    if (out) {
-        if (cap < v.size()) return fail(LM_ERR_INVALID, "buffer too small");
-        for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
-    }
-    return LM_OK;
-}
-int lm_yaml_string(const char* path, const char* key, char* out, size_t cap) {
-    if (!path || !key || !out || !cap) return fail(LM_ERR_INVALID, "null argument");
-    lmy::Node root;
-    const lmy::Node* n = nullptr;
-    int rc;
-    if ((rc = yaml_top(path, key, root, &n))) return rc;
-    if (n->kind != lmy::Node::Scalar) return fail(LM_ERR_INVALID, std::string("'") + key + "' is not a scalar");
-    if (n->scalar.size() + 1 > cap) return fail(LM_ERR_INVALID, "buffer too small");
-    std::memcpy(out, n->scalar.c_str(), n->scalar.size() + 1);
-    return LM_OK;
-}
-
-// ---- stage hooks ---------------------------------------------------------------------------------
-int lm_stage_color_quantize(lm_detector* d, const uint8_t* bgr, int w, int h, float weak_threshold, uint8_t* quantized,
-                            float* magnitude) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if (!bgr || !quantized || w <= 0 || h <= 0) return fail(LM_ERR_INVALID, "bad argument");
-    size_t px = (size_t)w * h;
-    size_t o_q = align_up(px * 3 + 256, 256), o_m = o_q + align_up(px, 256), o_s = o_m + align_up(px * 4, 256);
-    if ((rc = ensure_scratch(d, o_s + lmk_color_scratch_bytes(w, h)))) return rc;
-    u8* base = static_cast<u8*>(d->d_scratch);
-    hipStream_t st = d->stream;
-    HIP_TRY(hipMemcpyAsync(base, bgr, px * 3, hipMemcpyHostToDevice, st));
-    lmk_color_quantize(st, base, w, h, weak_threshold, base + o_q, magnitude ? reinterpret_cast<float*>(base + o_m) : nullptr,
-                       base + o_s, 0, 1);
-    HIP_TRY(hipMemcpyAsync(quantized, base + o_q, px, hipMemcpyDeviceToHost, st));
-    if (magnitude) HIP_TRY(hipMemcpyAsync(magnitude, base + o_m, px * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipGetLastError());
-    return LM_OK;
-}
-
-int lm_stage_pyrdown(lm_detector* d, const uint8_t* bgr, int w, int h, uint8_t* out) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if (!bgr || !out || w < 2 || h < 2) return fail(LM_ERR_INVALID, "bad argument");
-    size_t px = (size_t)w * h, opx = (size_t)(w / 2) * (h / 2);
-    size_t o_o = align_up(px * 3, 256);
-    if ((rc = ensure_scratch(d, o_o + opx * 3))) return rc;
-    u8* base = static_cast<u8*>(d->d_scratch);
-    hipStream_t st = d->stream;
-    HIP_TRY(hipMemcpyAsync(base, bgr, px * 3, hipMemcpyHostToDevice, st));
-    lmk_pyrdown(st, base, w, h, base + o_o, 0, 1);
-    HIP_TRY(hipMemcpyAsync(out, base + o_o, opx * 3, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipGetLastError());
-    return LM_OK;
-}
-
-int lm_stage_depth_quantize(lm_detector* d, const uint16_t* depth, int w, int h, uint8_t* quantized) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if (!depth || !quantized || w <= 0 || h <= 0) return fail(LM_ERR_INVALID, "bad argument");
-    size_t px = (size_t)w * h;
-    size_t o_q = align_up(px * 2, 256), o_s = o_q + align_up(px, 256);
-    if ((rc = ensure_scratch(d, o_s + px))) return rc;
-    u8* base = static_cast<u8*>(d->d_scratch);
-    hipStream_t st = d->stream;
-    HIP_TRY(hipMemcpyAsync(base, depth, px * 2, hipMemcpyHostToDevice, st));
-    lmk_depth_quantize(st, reinterpret_cast<u16*>(base), w, h, d->cfg.distance_threshold, d->cfg.difference_threshold,
-                       d->d_normal_lut, normal_lut_onehot(d), base + o_q, base + o_s, 0, 1);
-    HIP_TRY(hipMemcpyAsync(quantized, base + o_q, px, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipGetLastError());
-    return LM_OK;
-}
-
-int lm_stage_linear_memories(lm_detector* d, const uint8_t* quantized, int w, int h, int T, uint8_t* out) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if (!quantized || !out || w <= 0 || h <= 0 || T <= 0 || w % T || h % T) return fail(LM_ERR_INVALID, "bad argument");
-    size_t px = (size_t)w * h;
-    size_t o_l = align_up(px, 256);
-    if ((rc = ensure_scratch(d, o_l + 8 * px))) return rc;
-    u8* base = static_cast<u8*>(d->d_scratch);
-    hipStream_t st = d->stream;
-    HIP_TRY(hipMemcpyAsync(base, quantized, px, hipMemcpyHostToDevice, st));
-    lmk_linear_memories(st, base, w, 0, 0, w, h, T, d->d_resp_tab, base + o_l, (u32)px, 0, 0, 1);  // dense: ori_stride = T*T*W*H
-    HIP_TRY(hipMemcpyAsync(out, base + o_l, 8 * px, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipGetLastError());
-    return LM_OK;
-}
-
-int lm_prepare_slot(lm_detector* d, int slot) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = check_slots(d, slot, 1))) return rc;
-    if (!d->slots[slot].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
-    if ((rc = enqueue_upload_wait(d, slot, 1))) return rc;
-    enqueue_preprocess(d, slot, 1);
-    d->cnt_preprocess_frames += 1;
-    if ((rc = wait_stream(d))) return rc;
-    HIP_TRY(hipGetLastError());
-    d->slots[slot].prepared = true;
-    return LM_OK;
-}
-
-int lm_debug_read(lm_detector* d, int slot, int what, int level, int modality, uint8_t* out, size_t cap, size_t* size_out) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = check_slots(d, slot, 1))) return rc;
-    if (level < 0 || level >= d->cfg.pyramid_levels || modality < 0 || modality >= d->cfg.num_modalities)
-        return fail(LM_ERR_INVALID, "level/modality out of range");
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    const LmLevelGeom& g = d->geom[level];
-    if (what == 0) {
-        size_t n = (size_t)g.w * g.h;
-        if (size_out) *size_out = n;
-        if (modality == 1 && level > 0) {  // materialise the NN pyramid of the depth modality on demand
-            enqueue_depth_pyramid(d, slot, 1);
-            HIP_TRY(hipStreamSynchronize(d->stream));
-        }
-        if (out) HIP_TRY(hipMemcpy(out, d->quant(slot, level, modality), std::min(n, cap), hipMemcpyDeviceToHost));
-        return LM_OK;
-    }
-    if (what == 1) {  // spread linear memory [memory][pos] (refinement levels only)
-        size_t blk = (size_t)g.T * g.T * g.wh;
-        if (!g.spread_only) return fail(LM_ERR_INVALID, "the lowest level keeps response memories, not the spread memory");
-        if (size_out) *size_out = blk;
-        if (out) {
-            if (cap < blk) return fail(LM_ERR_INVALID, "buffer too small");
-            HIP_TRY(hipMemcpy(out, d->lm(slot, level) + (size_t)modality * g.mod_stride, blk, hipMemcpyDeviceToHost));
-        }
-        return LM_OK;
-    }
-    if (what == 2) {
-        size_t blk = (size_t)g.T * g.T * g.wh;
-        size_t n = 8 * blk;
-        if (size_out) *size_out = n;
-        if (out) {
-            if (cap < n) return fail(LM_ERR_INVALID, "buffer too small");
-            if (g.spread_only || (level == d->cfg.pyramid_levels - 1 && d->slots[slot].spread_low)) {
-                // refinement levels hold the spread memory (and so does the scanned level of a slot prepared for the bit-plane scan alone);
-                // expand it with the response LUT here (debug path)
-                std::vector<u8> sp(blk);
-                HIP_TRY(hipMemcpy(sp.data(), d->lm(slot, level) + (size_t)modality * g.mod_stride, blk, hipMemcpyDeviceToHost));
-                for (int o = 0; o < 8; ++o)
-                    for (size_t i = 0; i < blk; ++i)
-                        out[o * blk + i] = std::max(d->sim_lut[32 * o + (sp[i] & 15)], d->sim_lut[32 * o + 16 + (sp[i] >> 4)]);
-            } else if (g.nibble) {
-                std::vector<u8> pk(blk / 2);
-                for (int o = 0; o < 8; ++o) {
-                    HIP_TRY(hipMemcpy(pk.data(), d->lm(slot, level) + (size_t)modality * g.mod_stride + (size_t)o * g.ori_stride,
-                                      blk / 2, hipMemcpyDeviceToHost));
-                    for (size_t i = 0; i < blk / 2; ++i) { out[o * blk + 2 * i] = pk[i] & 15; out[o * blk + 2 * i + 1] = pk[i] >> 4; }
-                }
-            } else {
-                for (int o = 0; o < 8; ++o)
-                    HIP_TRY(hipMemcpy(out + o * blk, d->lm(slot, level) + (size_t)modality * g.mod_stride + (size_t)o * g.ori_stride, blk,
-                                      hipMemcpyDeviceToHost));
-            }
-        }
-        return LM_OK;
-    }
-    return fail(LM_ERR_INVALID, "unknown buffer id");
-}
-
-int lm_stage_scan(lm_detector* d, int slot, float threshold, int class_idx, int32_t* out, size_t cap_records, size_t* n_out) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = check_slots(d, slot, 1))) return rc;
-    if ((rc = ensure_bank(d))) return rc;
-    ItemRange r;
-    if ((rc = item_range(d, class_idx, &r))) return rc;
-    if ((rc = enqueue_threshold(d, threshold))) return rc;
-    {
-        LmScanArgs sa = make_scan_args(d, slot, r);
-        if ((rc = check_scan_args(d, slot, sa))) return rc;
-        lmk_scan(d->stream, sa, d->scan_variant, 1);
-        d->last_scan1_lanes = sa.lds_form ? 1000 + sa.R : sa.L1;
-        scan_launched(d, sa);
-    }
-    LmDevHeader h;
-    HIP_TRY(hipMemcpyAsync(&h, d->aux(slot, d->off_hdr), sizeof(h), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemset(d->aux(slot, d->off_hdr), 0, sizeof(LmDevHeader)));  // re-arm the counters ourselves
-    if (h.cand_count > d->max_cand) return fail(LM_ERR_OVERFLOW, "candidate buffer overflow");
-    std::vector<LmCand> cand(h.cand_count);
-    if (h.cand_count) HIP_TRY(hipMemcpy(cand.data(), d->aux(slot, d->off_cand), cand.size() * sizeof(LmCand), hipMemcpyDeviceToHost));
-    struct Rec { int32_t tid, cls, x, y; };
-    std::vector<Rec> recs(cand.size());
-    for (size_t i = 0; i < cand.size(); ++i)
-        recs[i] = Rec{d->hb.t_global[cand[i].ti], d->hb.t_class[cand[i].ti], cand[i].x, cand[i].y};
-    std::sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) {
-        if (a.cls != b.cls) return a.cls < b.cls;
-        if (a.tid != b.tid) return a.tid < b.tid;
-        if (a.y != b.y) return a.y < b.y;
-        return a.x < b.x;
-    });
-    if (n_out) *n_out = recs.size();
-    if (out) std::memcpy(out, recs.data(), std::min(recs.size(), cap_records) * sizeof(Rec));
-    return LM_OK;
-}
-
-int lm_time_scan(lm_detector* d, int slot, float threshold, int class_idx, int iters, int variant, double* avg_us_out,
-                 double* algorithmic_bytes_out) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = check_slots(d, slot, 1))) return rc;
-    if ((rc = ensure_bank(d))) return rc;
-    if (iters <= 0) return fail(LM_ERR_INVALID, "iters must be positive");
-    ItemRange r;
-    if ((rc = item_range(d, class_idx, &r))) return rc;
-    if ((rc = enqueue_threshold(d, threshold))) return rc;
-    LmScanArgs a = make_scan_args(d, slot, r);
-    if ((rc = check_scan_args(d, slot, a))) return rc;
-    a.cand_cap = 0;  // timing only: count candidates, store none (the list would overflow across iterations)
-    for (int i = 0; i < 3; ++i) { lmk_scan(d->stream, a, variant, 1); scan_launched(d, a); }
-    HIP_TRY(hipEventRecord(d->ev[0], d->stream));
-    for (int i = 0; i < iters; ++i) { lmk_scan(d->stream, a, variant, 1); scan_launched(d, a); }
-    HIP_TRY(hipEventRecord(d->ev[1], d->stream));
-    HIP_TRY(hipMemsetAsync(d->aux(slot, d->off_hdr), 0, sizeof(LmDevHeader), d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    HIP_TRY(hipGetLastError());
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
-    if (avg_us_out) *avg_us_out = (double)ms * 1000.0 / iters;
-    if (algorithmic_bytes_out) {
-        double b = 0;
-        if (class_idx < 0) for (double v : d->hb.class_alg_bytes) b += v;
-        else b = d->hb.class_alg_bytes[class_idx];
-        *algorithmic_bytes_out = b;
-    }
-    return LM_OK;
-}
-
-// The scan kernel alone over a BATCH of prepared slots (one launch = n_slots frames, as a lane-step launches it), candidates
-// counted but not stored.  `variant` as lm_set_scan_variant; 8 | 64 = exhaustive scan WITHOUT the shift-undo instructions
-// (wrong sums -- a timing experiment only).
-int lm_time_scan_batch(lm_detector* d, int first_slot, int n_slots, float threshold, int class_idx, int iters, int variant,
-                       double* avg_us_out) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = check_slots(d, first_slot, n_slots))) return rc;
-    if ((rc = ensure_bank(d))) return rc;
-    if (iters <= 0 || n_slots <= 0) return fail(LM_ERR_INVALID, "iters and n_slots must be positive");
-    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    for (int i = 0; i < n_slots; ++i)
-        if (!d->slots[first_slot + i].prepared) return fail(LM_ERR_INVALID, "slot " + std::to_string(first_slot + i) + " is not prepared");
-    ItemRange r;
-    if ((rc = item_range(d, class_idx, &r))) return rc;
-    if ((rc = enqueue_threshold(d, threshold))) return rc;
-    LmScanArgs a = make_scan_args(d, first_slot, r, n_slots);
-    if ((rc = check_scan_args(d, first_slot, a))) return rc;
-    a.cand_cap = 0;
-    for (int i = 0; i < 2; ++i) { lmk_scan(d->stream, a, variant, n_slots); scan_launched(d, a); }
-    HIP_TRY(hipEventRecord(d->ev[0], d->stream));
-    for (int i = 0; i < iters; ++i) { lmk_scan(d->stream, a, variant, n_slots); scan_launched(d, a); }
-    HIP_TRY(hipEventRecord(d->ev[1], d->stream));
-    for (int i = 0; i < n_slots; ++i) HIP_TRY(hipMemsetAsync(d->aux(first_slot + i, d->off_hdr), 0, sizeof(LmDevHeader), d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    HIP_TRY(hipGetLastError());
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
-    if (avg_us_out) *avg_us_out = (double)ms * 1000.0 / iters;
-    return LM_OK;
-}
-
-// Self-test of k_dnormal's float tail (lm_kernels.hip dn_rcp / dn_sqrt): every float of the tail's domain through the short
-// sequences and through the compiler's correctly rounded 1.0f / x and sqrtf (__builtin_sqrtf: v_sqrt_f32 + its +-1 ulp fix-up) on
-// this device; out[0] / out[1] = floats that differ, out[2] = floats on which the bare v_sqrt_f32 differs (information), out[3..5] = the same
-// for the longer sequences used before (v_rcp + six steps; v_sqrt + fix-up) and for v_sqrt + one v_rsq step, out[6..7] = 0.
-int lm_selftest_float_tail(lm_detector* d, uint64_t out[8]) {
-    int rc;
-    if (!out) return fail(LM_ERR_INVALID, "null argument");
-    if ((rc = ready_for_compute(d))) return rc;
-    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    unsigned long long* dev = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), 8 * sizeof(unsigned long long)));
-    hipError_t e = hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), d->stream);
-    unsigned long long host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (e == hipSuccess) { lmk_selftest_float_tail(d->stream, dev); e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, d->stream); }
-    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
-    if (e == hipSuccess) e = hipGetLastError();
-    (void)hipFree(dev);
-    if (e != hipSuccess) return fail(LM_ERR_HIP, hipGetErrorString(e));
-    for (int k = 0; k < 8; ++k) out[k] = host[k];
-    return LM_OK;
-}
-
-int lm_time_stages(lm_detector* d, int slot, float threshold, int class_idx, int iters, double out_us[4]) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = check_slots(d, slot, 1))) return rc;
-    if ((rc = ensure_bank(d))) return rc;
-    if (iters <= 0 || !out_us) return fail(LM_ERR_INVALID, "bad argument");
-    if (!d->slots[slot].has_frame) return fail(LM_ERR_INVALID, "no frame uploaded to slot");
-    double acc[4] = {0, 0, 0, 0};
-    for (int it = 0; it < iters; ++it) {
-        if ((rc = enqueue_match(d, slot, 1, threshold, class_idx, true))) return rc;
-        HIP_TRY(hipStreamSynchronize(d->stream));
-        for (int k = 0; k < 4; ++k) {
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, d->ev[k], d->ev[k + 1]));
-            acc[k] += (double)ms * 1000.0;
-        }
-    }
-    for (int k = 0; k < 4; ++k) out_us[k] = acc[k] / iters;
-    return LM_OK;
-}
-
-int lm_last_counts(lm_detector* d, int slot, uint32_t* candidates, uint32_t* matches_before_unique) {
-    if (!d || !d->dev_ready || slot < 0 || slot >= (int)d->slots.size()) return fail(LM_ERR_INVALID, "bad argument");
-    const LmHeader& h = d->host_block(slot)->hdr;
-    if (candidates) *candidates = h.cand_count;
-    if (matches_before_unique) *matches_before_unique = h.match_count;
-    return LM_OK;
-}
-
-int lm_set_profiling(lm_detector* d, int enable) {
-    if (!d) return fail(LM_ERR_INVALID, "null detector");
-    d->profiling = enable != 0;
-    for (double& v : d->prof_us) v = 0;
-    d->prof_scan_bytes = 0; d->prof_launches = 0; d->prof_frames = 0;
-    d->prof_exch_us = 0; d->prof_exch_launches = 0; d->prof_exch_fallbacks = 0;
-    d->cnt_preprocess_frames = d->cnt_scan_launches = d->cnt_refine_launches = d->cnt_sort_launches = 0;
-    return LM_OK;
-}
-
-int lm_get_profile(lm_detector* d, double stage_us[4], double* scan_algorithmic_bytes, int64_t* launches, int64_t* frames) {
-    if (!d) return fail(LM_ERR_INVALID, "null detector");
-    if (stage_us) for (int k = 0; k < 4; ++k) stage_us[k] = d->prof_us[k];
-    if (scan_algorithmic_bytes) *scan_algorithmic_bytes = d->prof_scan_bytes;
-    if (launches) *launches = d->prof_launches;
-    if (frames) *frames = d->prof_frames;
-    return LM_OK;
-}
-
-int lm_scan_load_bytes(lm_detector* d, int class_idx, double* bytes_per_frame) {
-    int rc;
-    if (!d || !bytes_per_frame) return fail(LM_ERR_INVALID, "null argument");
-    if ((rc = ready_for_compute(d))) return rc;
-    if ((rc = ensure_bank(d))) return rc;
-    const int nc = (int)d->hb.class_load_bytes.size();
-    if (class_idx >= nc || class_idx < -1) return fail(LM_ERR_INVALID, "class index out of range");
-    double b = 0;
-    if (class_idx < 0) for (double v : d->hb.class_load_bytes) b += v;
-    else b = d->hb.class_load_bytes[class_idx];
-    *bytes_per_frame = b;
-    return LM_OK;
-}
-
-int lm_set_scan_stats(lm_detector* d, int enable) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(d->d_scan_stat, 0, 4096 * sizeof(unsigned long long)));
-    d->scan_stats = enable != 0;
-    return LM_OK;
-}
-
-int lm_get_scan_stats(lm_detector* d, uint64_t* features_loaded, uint64_t* features_unpruned) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    std::vector<unsigned long long> h(4096);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(h.data(), d->d_scan_stat, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    unsigned long long a = 0, b = 0;
-    for (int i = 0; i < 1024; ++i) { a += h[4 * i]; b += h[4 * i + 1]; }
-    if (features_loaded) *features_loaded = a;
-    if (features_unpruned) *features_unpruned = b;
-    return LM_OK;
-}
-
-int lm_get_scan_lane_stats(lm_detector* d, uint64_t* lane_loads_issued, uint64_t* lane_loads_unpruned) {
-    int rc;
-    if ((rc = ready_for_compute(d))) return rc;
-    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    std::vector<unsigned long long> h(4096);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(h.data(), d->d_scan_stat, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    unsigned long long a = 0, b = 0;
-    for (int i = 0; i < 1024; ++i) { a += h[4 * i + 2]; b += h[4 * i + 1]; }
-    if (lane_loads_issued) *lane_loads_issued = a;
-    if (lane_loads_unpruned) *lane_loads_unpruned = 64ull * b;
-    return LM_OK;
-}
-
-int lm_get_scan_form_stats(lm_detector* d, int64_t out[4]) {
-    int rc;
-    if (!out) return fail(LM_ERR_INVALID, "null argument");
-    if ((rc = ready_for_compute(d))) return rc;
-    if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
-    std::vector<unsigned long long> h(4096);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(h.data(), d->d_scan_stat, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    unsigned long long sv = 0;
-    for (int i = 0; i < 1024; ++i) sv += h[4 * i + 3];
-    out[0] = d->cnt_scan1_launches; out[1] = d->cnt_scan_launches; out[2] = (int64_t)sv; out[3] = d->last_scan1_lanes;
-    return LM_OK;
-}
-
-int lm_get_exchange_profile(lm_detector* d, double* exchange_us, int64_t* launches, int64_t* fallbacks) {
-    if (!d) return fail(LM_ERR_INVALID, "null detector");
-    if (exchange_us) *exchange_us = d->prof_exch_us;
-    if (launches) *launches = d->prof_exch_launches;
-    if (fallbacks) *fallbacks = d->prof_exch_fallbacks;
-    return LM_OK;
-}
-
-int lm_get_stage_counts(lm_detector* d, int64_t out[4]) {
-    if (!d || !out) return fail(LM_ERR_INVALID, "null argument");
-    out[0] = d->cnt_preprocess_frames; out[1] = d->cnt_scan_launches; out[2] = d->cnt_refine_launches; out[3] = d->cnt_sort_launches;
-    return LM_OK;
-}
-
-int lm_device_pci_bus_id(lm_detector* d, char* out, size_t cap) {
-    int rc;
-    if (!out || cap < 16) return fail(LM_ERR_INVALID, "buffer too small");
-    if ((rc = ready_for_compute(d))) return rc;
-    HIP_TRY(hipDeviceGetPCIBusId(out, (int)cap, d->cfg.device));
-    return LM_OK;
-}
-
-// Only variants whose lists are the default's may be set on the product path: bits 6 and 7 skip work (no shift-undo / no exact
-// sums of the survivors) and exist for lm_time_scan* alone, which take their variant as an argument and store no candidates.
-int lm_set_scan_variant(lm_detector* d, int variant) {
-    if (!d) return fail(LM_ERR_INVALID, "null detector");
-    if (variant < 0 || (variant & ~LM_SCAN_VARIANT_SETTABLE))
-        return fail(LM_ERR_INVALID, "scan variant " + std::to_string(variant) + " changes the match lists (bits 6 / 7 are timing experiments of lm_time_scan* only) or is unknown");
-    d->scan_variant = variant;
-    return LM_OK;
 }
 
 }  // extern "C"

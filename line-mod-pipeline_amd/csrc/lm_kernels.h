@@ -1,4 +1,5 @@
-// lm_kernels.h -- host-callable launchers of the gfx950 kernels in lm_kernels.hip.
+// lm_kernels.h -- host-callable launchers of the gfx950 kernels in lm_k_preprocess.hip (a3-a10), lm_k_scan.hip (a11-a13),
+// lm_k_refine.hip (a14-a15, 8e) and lm_k_post.hip (f1).
 // Every launcher processes `nslots` consecutive frame slots (grid.z) whose buffers are `*_slot_stride`
 // bytes apart; pass stride 0 / nslots 1 for a single set of buffers.
 #pragma once
@@ -23,7 +24,7 @@ void lmk_color_quantize(hipStream_t s, const u8* bgr, int w, int h, float weak_t
 // launch, so that the raw image is read from HBM once.  false: shape not supported, nothing launched (the caller launches
 // the two kernels itself).
 bool lmk_blur_pyrdown(hipStream_t s, const u8* bgr0, int w, int h, u8* scratch0, u8* bgr1, u8* quant0, size_t slot_stride, int nslots);
-// r06: a batch's level-0 and level-1 gradients in one grid (the level-1 blur must have run): see lm_kernels.hip k_cgrad_levels
+// r06: a batch's level-0 and level-1 gradients in one grid (the level-1 blur must have run): see lm_dev_color.h k_cgrad_levels
 bool lmk_color_blur(hipStream_t s, const u8* bgr, int w, int h, u8* scratch, size_t slot_stride, int nslots);
 bool lmk_cgrad_levels_wanted(int w0, int h0, int nslots);
 bool lmk_cgrad_levels(hipStream_t s, const u8* S0, int w0, int h0, u8* q0, const u8* S1, int w1, int h1, u8* q1, float weak_threshold, size_t slot_stride, int nslots);

@@ -1,4 +1,4 @@
-"""The fused gradient kernel (k_cgrad, lm_kernels.hip) replaces fastAtan2 + rint by an integer rule:
+"""The fused gradient kernel (k_cgrad, lm_dev_color.h) replaces fastAtan2 + rint by an integer rule:
 
     s = (1282 min > 255 max) + (1384 min > 925 max),  q = |dy| > |dx| ? 4 - s : s,  label = (sign(dx) != sign(dy) ? -q : q) & 7
 
