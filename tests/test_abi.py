@@ -206,3 +206,16 @@ def test_scan_variant_refuses_list_changing_bits(lm):
             d.set_scan_variant(bad)
     d.set_scan_variant(0)
     d.close()
+
+
+def test_build_lists_cover_every_source_file():
+    """r06: the kernel and detector sources are split by stage; a source or header missing from build.py's lists would build a library without it (or
+    rebuild too little).  Every csrc/*.hip / *.cpp is compiled, every csrc/*.h is a dependency of the objects."""
+    import glob
+    import importlib
+    b = importlib.import_module("line-mod-pipeline_amd.build")
+    on_disk = {os.path.basename(p) for p in glob.glob(os.path.join(b.CSRC, "*")) if os.path.isfile(p)}
+    compiled = set(b.HIP_SOURCES) | set(b.CXX_SOURCES)
+    assert {f for f in on_disk if f.endswith((".hip", ".cpp"))} == compiled
+    headers = {os.path.basename(h) for h in b.HEADERS}
+    assert {f for f in on_disk if f.endswith(".h")} <= headers
