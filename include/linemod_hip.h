@@ -281,6 +281,11 @@ int lm_set_stage_chunks(lm_detector* det, int chunks);
  *   640 x 480 frame is a handful of waves: behind level 0's workgroups they fill idle SIMDs instead of a launch of their own that leaves half the chip
  *   without a wave); 0 = one launch per level (r02-r05).  Same labels either way. */
 #define LM_TUNE_CGRAD_LEVELS 18
+/* LM_TUNE_SURVIVOR_QUEUE (r06): entries of a lane's survivor queues of the bit-plane scan k_scan1 (64 .. 16 777 216, rounded up to a multiple of 8; default
+ *   1 048 576 = 131 072 per XCD queue; 8 bytes each, allocated on a lane's first bit-plane scan).  A wave whose survivors do not fit takes their exact sums itself, so
+ *   the lists never depend on the value; small values exist for the tests that drive the full-queue path (concurrent reservations at the capacity, partial
+ *   fits).  Setting it waits for the device and frees the queues of all lanes. */
+#define LM_TUNE_SURVIVOR_QUEUE 19
 int lm_set_tuning(lm_detector* det, int key, int value);
 int lm_match_slot(lm_detector* det, int slot, float threshold, int class_idx, lm_match_t* out, size_t cap, size_t* n_out);
 /* Matches slots [0, n_slots) back-to-back on the detector's streams; out is n_slots * cap_per_frame

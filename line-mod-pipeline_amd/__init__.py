@@ -51,6 +51,7 @@ TUNE_SCAN_LIST_ORDER = 15
 TUNE_SCAN_FORM = 16
 TUNE_SCAN1_MIN_THRESHOLD = 17
 TUNE_CGRAD_LEVELS = 18
+TUNE_SURVIVOR_QUEUE = 19
 
 
 class Rect(C.Structure):

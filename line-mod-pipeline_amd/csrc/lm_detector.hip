@@ -1459,6 +1459,15 @@ int lm_set_tuning(lm_detector* d, int key, int value) {
             return LM_OK;
         case LM_TUNE_SCAN1_MIN_THRESHOLD: if (value < 0 || value > 100) break; d->scan1_min_threshold = (float)value; return LM_OK;
         case LM_TUNE_CGRAD_LEVELS: if (value < 0 || value > 1) break; lmk_set_cgrad_levels(value); return LM_OK;
+        case LM_TUNE_SURVIVOR_QUEUE:
+            if (value < 64 || value > (1 << 24)) break;
+            if (d->dev_ready) {       // no lane is busy (checked above); the queues' re-arming stores ran inside the matches that have ended
+                HIP_TRY(hipSetDevice(d->cfg.device));
+                HIP_TRY(hipDeviceSynchronize());
+                for (int l = 0; l < LM_NLANES; ++l) { if (d->d_surv[l]) hipFree(d->d_surv[l]); d->d_surv[l] = nullptr; d->surv_set[l] = 0; }
+            }
+            d->surv_cap = ((u32)value + 7u) & ~7u;
+            return LM_OK;
         default: return fail(LM_ERR_INVALID, "unknown tuning key");
     }
     return fail(LM_ERR_INVALID, "tuning value out of range");

@@ -96,6 +96,7 @@ while time.time() - t0 < budget:
         d.set_tuning(lm.TUNE_CGRAD_LEVELS, int(rng.choice([0, 1])))             # r06: the two levels' gradients of a batch in one launch or two
         d.set_tuning(lm.TUNE_SCAN_LIST_ORDER, int(rng.choice([0, 1, 2, 3])))    # order of the scan's feature lists (same sums)
         d.set_tuning(lm.TUNE_SCAN_FORM, int(rng.choice([0, 1, 2, 3, 3])))
+        d.set_tuning(lm.TUNE_SURVIVOR_QUEUE, int(rng.choice([1 << 20, 1 << 20, 64, 200, 4096])))   # r06: k_scan1's survivor queues, also far too small (partial fits, the waves' own sums)
         # r05: every way a frame reaches a slot -- the one-call upload, the staged upload (rows in random pieces; a zero shift here, the
         # shifted forms are swept in tests/test_gpu_stream.py) -- and the lists once more through lm_match_collect
         staged = bool(rng.integers(0, 2))

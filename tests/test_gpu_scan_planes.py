@@ -392,3 +392,36 @@ def test_scanl_full_queues_many_times(lm, orc, synth):
         for k in range(24):
             assert cnt[k] == len(exp) and got[k, :cnt[k]].tobytes() == exp.tobytes(), (rep, k, cnt[k], len(exp))
     d.close()
+
+
+@pytest.mark.parametrize("color_only", [True, False])
+def test_scan1_full_queues_many_times(lm, orc, synth, color_only):
+    """r06: k_scan1's survivor queues at their capacity.  The default queues (131 072 entries per XCD) never fill in the suite, so the code the round
+    changed -- a reservation that does not fit writes as many survivors as fit, the wave sums the rest itself, the counter only grows -- ran nowhere;
+    LM_TUNE_SURVIVOR_QUEUE shrinks them to 64 entries per XCD queue, every launch overflows all eight, and every list must still equal the oracle's,
+    12 times over (both second stages: nibble memories for the RGB-D detector's mixed call, spread bytes for the colour-only one)."""
+    d, o, frames = _setup(lm, orc, synth, color_only, (640, 480), [5, 8], 400, 16, seed=2200)
+    bgr, dep = frames[0][0], (None if color_only else frames[0][1])
+    thr = 62.0
+    exp = o.match(bgr, dep, thr, threads=8, cap=1 << 19)
+    assert len(exp) > 100
+    for k in range(16):
+        d.upload_frame(k, bgr, dep)
+    with pytest.raises(lm.LinemodError):
+        d.set_tuning(lm.TUNE_SURVIVOR_QUEUE, 8)
+    d.set_tuning(lm.TUNE_SCAN_FORM, 2)
+    d.set_tuning(lm.TUNE_SURVIVOR_QUEUE, 512)
+    d.set_scan_stats(True)
+    got, cnt = d.match_batch(16, thr, cap_per_frame=1 << 16)
+    st = d.get_scan_form_stats()
+    assert st[0] >= 1 and 0 < st[3] < 1000 and st[2] > 16 * 1000        # k_scan1 ran, thousands of survivors per frame against 512 queue entries
+    d.set_scan_stats(False)
+    for rep in range(12):
+        got, cnt = d.match_batch(16, thr, cap_per_frame=1 << 16)
+        for k in range(16):
+            assert cnt[k] == len(exp) and got[k, :cnt[k]].tobytes() == exp.tobytes(), (rep, k, cnt[k], len(exp))
+    d.set_tuning(lm.TUNE_SURVIVOR_QUEUE, 1 << 20)                      # back to the default: the queues are re-allocated on the next scan
+    got, cnt = d.match_batch(16, thr, cap_per_frame=1 << 16)
+    for k in range(16):
+        assert cnt[k] == len(exp) and got[k, :cnt[k]].tobytes() == exp.tobytes()
+    d.close()
