@@ -76,8 +76,9 @@ while time.time() - t0 < budget:
     q = {(l, m): o.stage(0, l, m).reshape(h >> l, w >> l) for l in range(2) for m in range(M)}
     n = int(rng.integers(5, 120))
     try:
+        nfeat = int(rng.choice([63, 63, 63, 42, 21, 9]))                # r06: also tail rounds of the bit-plane scans (63 is upstream's maximum per template)
         descs, feats, _ = synth.make_bank(n, M, 2, seed=int(rng.integers(1 << 30)), quantized=q, crop_fraction=0.3,
-                                          frame_size=(w, h), T0=T[0])
+                                          frame_size=(w, h), T0=T[0], num_features=nfeat)
     except Exception:
         d.close(); continue
     d.add_class("c", descs, feats); o.add_class("c", descs, feats)

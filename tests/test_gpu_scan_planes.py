@@ -425,3 +425,53 @@ def test_scan1_full_queues_many_times(lm, orc, synth, color_only):
     for k in range(16):
         assert cnt[k] == len(exp) and got[k, :cnt[k]].tobytes() == exp.tobytes()
     d.close()
+
+
+def test_scanl_feature_counts(lm, orc, synth):
+    """r06: k_scanl with templates of few features (42, 21, 13, 9, 2 at level 0, i.e. 21 .. 1 per modality at the scanned level: lists padded with entries of
+    the zero block, tail rounds), with a second class and a class list, at two thresholds; and with MORE than 64 features at the scanned level -- a
+    one-level pyramid on a 320 x 240 frame scans level 0 itself, 63 features per modality = 126 per template: 16 rounds of eight, and the second stage
+    takes the second half of a survivor's list too (a lane requests 64 entries at once).  Lists and candidate lists equal the oracle's."""
+    for nf in (42, 21, 13, 9, 2):
+        d, o, frames = _setup(lm, orc, synth, False, (640, 480), [5, 8], 40, 8, seed=3070 + nf, nf=nf)
+        bgr, dep = frames[0]
+        q = _quantized(o, bgr, dep, False)
+        d2, f2, _ = synth.make_bank(17, 2, 2, seed=3234 + nf, quantized=q, crop_fraction=0.5, frame_size=(640, 480), T0=5, num_features=nf)
+        d.add_class("c2", d2, f2); o.add_class("c2", d2, f2)
+        d.set_tuning(lm.TUNE_SCAN_FORM, 3)
+        for k in range(8):
+            d.upload_frame(k, bgr, dep)
+        for thr in (60.0, 85.0):
+            for classes in ([-1], [1], [1, 0]):
+                exp = o.match(bgr, dep, thr, class_idx=classes[0] if len(classes) == 1 else -1, threads=8, cap=1 << 18)
+                got, cnt = d.match_batch_classes(0, 8, thr, classes, cap_per_frame=max(len(exp), 1))
+                assert d.get_scan_form_stats()[3] >= 1000, (nf, thr, classes)                      # k_scanl ran
+                for k in range(8):
+                    assert cnt[k] == len(exp) and got[k, :cnt[k]].tobytes() == exp.tobytes(), (nf, thr, classes, k, cnt[k], len(exp))
+            o.prepare(bgr, dep)
+            d.prepare_slot(0)
+            assert np.array_equal(d.stage_scan(0, thr, -1, cap=1 << 20), o.scan_candidates(thr, -1, threads=8, cap=1 << 20)), (nf, thr)
+        d.close()
+    # one pyramid level: the scanned level is level 0 with all 63 features per modality
+    w, h, T = 320, 240, [8]
+    d = lm.Detector(lm.default_config(color_only=False, width=w, height=h, T=T, frame_slots=8))
+    o = orc.Detector(color_only=False, T=T)
+    bgr, dep = synth.make_frame(w, h, seed=3333)
+    o.prepare(bgr, dep)
+    q = {(0, m): o.stage(0, 0, m).reshape(h, w) for m in range(2)}
+    descs, feats, _ = synth.make_bank(60, 2, 1, seed=3334, quantized=q, crop_fraction=0.4, frame_size=(w, h), T0=T[0], size_range=(40, 80))
+    d.add_class("c", descs, feats); o.add_class("c", descs, feats)
+    d.set_tuning(lm.TUNE_SCAN_FORM, 3)
+    for k in range(8):
+        d.upload_frame(k, bgr, dep)
+    for thr in (60.0, 80.0):
+        exp = o.match(bgr, dep, thr, threads=8, cap=1 << 18)
+        assert len(exp) > 0
+        got, cnt = d.match_batch(8, thr, cap_per_frame=max(len(exp), 1))
+        assert d.get_scan_form_stats()[3] >= 1000, thr                                              # k_scanl ran on the one-level pyramid
+        for k in range(8):
+            assert cnt[k] == len(exp) and got[k, :cnt[k]].tobytes() == exp.tobytes(), (thr, k, cnt[k], len(exp))
+        o.prepare(bgr, dep)
+        d.prepare_slot(0)
+        assert np.array_equal(d.stage_scan(0, thr, -1, cap=1 << 20), o.scan_candidates(thr, -1, threads=8, cap=1 << 20)), thr
+    d.close()
