@@ -118,13 +118,19 @@ __device__ __forceinline__ u32 wave_sum_u32(u32 v) {   // all lanes active
     return (u32)__builtin_amdgcn_readlane((int)v, 0) + (u32)__builtin_amdgcn_readlane((int)v, 16) +
            (u32)__builtin_amdgcn_readlane((int)v, 32) + (u32)__builtin_amdgcn_readlane((int)v, 48);
 }
+// all lanes active; the result is wave-uniform (four DPP steps inside a row of 16 lanes, the four rows' maxima combined on the scalar unit).  Until
+// round 6 this was six __shfl_xor steps = six dependent ds_bpermute_b32 round trips through the LDS crossbar per call -- k_scanl takes three maxima per
+// wave item, k_refine one per pruning test and candidate.
 __device__ __forceinline__ u32 wave_max_u32(u32 v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        u32 o = (u32)__shfl_xor((int)v, s, 64);
-        v = v > o ? v : o;
-    }
-    return v;
+    u32 o;
+    o = (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true); v = v > o ? v : o;     // quad_perm [1,0,3,2]
+    o = (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true); v = v > o ? v : o;     // quad_perm [2,3,0,1]
+    o = (u32)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true); v = v > o ? v : o;    // row_half_mirror
+    o = (u32)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true); v = v > o ? v : o;    // row_mirror: every lane holds its row's maximum
+    const u32 a = (u32)__builtin_amdgcn_readlane((int)v, 0), b = (u32)__builtin_amdgcn_readlane((int)v, 16);
+    const u32 c = (u32)__builtin_amdgcn_readlane((int)v, 32), d = (u32)__builtin_amdgcn_readlane((int)v, 48);
+    const u32 ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
 }
 
 }  // namespace

@@ -645,8 +645,9 @@ __device__ __forceinline__ void scanl_emit(const LmScanArgs& a, u32 sl, u32 ti, 
 
 // One lane item's rounds (k_scanl): counters of TOP + 1 bits, their flag = bit TOP, preset to 2^TOP - 1 - (misses allowed).  Returns true when the whole wave
 // stopped early; flags[q] = the flag dword of positions 32 q .. 32 q + 31 otherwise; f = features counted.
+typedef __attribute__((address_space(3))) u32 lds_u32_t;
 template <int TOP>
-__device__ __forceinline__ bool scanl_rounds(const u8* lds, const __amdgpu_buffer_rsrc_t rs_off, u32 voff, u32 unit_add, u32 keep5, u32 pre, int valid, int Fw,
+__device__ __forceinline__ bool scanl_rounds(const __amdgpu_buffer_rsrc_t rs_off, u32 voff, u32 unit_add, u32 keep5, u32 pre, int valid, int Fw,
                                              int first_test, unsigned long long& alive, u32 (&flags)[4], int& f_out) {
     u32 c[4][8];
 #pragma unroll
@@ -678,7 +679,9 @@ __device__ __forceinline__ bool scanl_rounds(const u8* lds, const __amdgpu_buffe
             u32 v[8][5];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const u32* p = reinterpret_cast<const u32*>(lds + ((e[k] + unit_add) >> 8));
+                // (an LDS address as an integer: unit_add carries the image's LDS base, so the entry's sum IS the address -- through the generic pointer
+                // the compiler added the base, a literal 0, once more per feature)
+                const lds_u32_t* p = (const lds_u32_t*)(unsigned long)((e[k] + unit_add) >> 8);
                 v[k][0] = p[0]; v[k][1] = p[1]; v[k][2] = p[2]; v[k][3] = p[3];
             }
             // the fifth dword is the next lane's first (the next unit of the same template) -- a DPP move instead of a fifth LDS access --
@@ -764,6 +767,7 @@ __global__ __launch_bounds__(1024) void k_scanl(LmScanArgs a) {
     __syncthreads();
     const unsigned long long tm1 = __builtin_readcyclecounter();
     const __amdgpu_buffer_rsrc_t rs_off = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(a.offl), 0, 0x7FFFFFFF, 0x00020000);
+    const u32 lds_base = (u32)(unsigned long)(__attribute__((address_space(3))) u32x4*)scanl_lds;      // LDS address of the image (0 unless the kernel gets static LDS one day)
     unsigned long long st_f = 0, st_F = 0, st_l = 0, st_s = 0;
     for (; j_cur < n_share; ) {
         // this item's record is in registers; the next item is taken now and its record arrives during the loop
@@ -790,15 +794,16 @@ __global__ __launch_bounds__(1024) void k_scanl(LmScanArgs a) {
         const int mm_hi = __builtin_amdgcn_readfirstlane((int)wave_max_u32(valid > 0 ? (u32)mmax : 0u));
         const int first_test = 127 - __builtin_amdgcn_readfirstlane((int)wave_max_u32(valid > 0 ? pre : 0u));            // the smallest miss budget of the wave: nothing dies before
         const u32 voff = ti * (u32)a.fpad1 * 4u;
-        const u32 unit_add = (unit * 16u) << 8;
-        const u32 keep5 = (j0 + 128 >= P || lane == 63) ? 0u : 0xFFFFFFFFu;
+        const u32 unit_add = (unit * 16u + lds_base) << 8;
+        u32 keep5 = (j0 + 128 >= P || lane == 63) ? 0u : 0xFFFFFFFFu;
+        asm volatile("" : "+v"(keep5));            // (a plain register to the optimiser: `& keep5` stays an AND, which takes the DPP move as its operand -- v_and_b32_dpp -- instead of a select behind a v_mov_b32_dpp)
         u32 flags[4];
         bool pruned;
         int f;
         // counters of 6 bits (flag = bit 5) when no template of the wave may miss more than 31 features -- the usual case: 24 at threshold 80 with 62
         // features -- two half adders fewer per round and dword; 8 bits otherwise
-        if (mm_hi <= 31) pruned = scanl_rounds<5>(lds, rs_off, voff, unit_add, keep5, (u32)(31 - mmax), valid, Fw, first_test, alive, flags, f);
-        else pruned = scanl_rounds<7>(lds, rs_off, voff, unit_add, keep5, pre, valid, Fw, first_test, alive, flags, f);
+        if (mm_hi <= 31) pruned = scanl_rounds<5>(rs_off, voff, unit_add, keep5, (u32)(31 - mmax), valid, Fw, first_test, alive, flags, f);
+        else pruned = scanl_rounds<7>(rs_off, voff, unit_add, keep5, pre, valid, Fw, first_test, alive, flags, f);
         st_l += (unsigned long long)f * 64ull;                                   // (every lane reads in every round)
         st_f += (unsigned long long)(f < Fw ? f : Fw); st_F += (unsigned long long)Fw;
         // survivors: positions never flagged (a dead or idle lane's flags are all ones)
