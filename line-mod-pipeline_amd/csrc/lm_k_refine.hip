@@ -164,9 +164,10 @@ __device__ __forceinline__ u32 rf_patch(const u8* __restrict__ lm, u32 se, u32 l
     const u32x2 d = ld8a4(lm + (t & ~3u));
     return __builtin_amdgcn_alignbyte(d[1], d[0], t);
 }
-__device__ __forceinline__ void rf_lookup(const u8* __restrict__ tab, u32 v, u32& p01, u32& p23) {
-    const u32 r0 = tab[v & 0xFFu], r1 = tab[(v >> 8) & 0xFFu], r2 = tab[(v >> 16) & 0xFFu], r3 = tab[v >> 24];
-    p01 = r0 | (r1 << 16); p23 = r2 | (r3 << 16);
+// (r06: the four responses stay four registers and are added as they are -- v_add3_u32 takes two features' responses at once, so a position costs half an
+// instruction per feature; packing them into u16 pairs first (r02-r05) cost two v_lshl_or_b32 per feature and candidate to save one add)
+__device__ __forceinline__ void rf_lookup(const u8* __restrict__ tab, u32 v, u32 (&r)[4]) {
+    r[0] = tab[v & 0xFFu]; r[1] = tab[(v >> 8) & 0xFFu]; r[2] = tab[(v >> 16) & 0xFFu]; r[3] = tab[v >> 24];
 }
 // One candidate of one slot: similarityLocal over the 16 x 16 patch, first-max argmax, rescore, threshold filter.
 template <bool LAST, bool W4>
@@ -191,7 +192,7 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
     int bx = x / T - 8, by = y / T - 8;
     int off_x = bx * T, off_y = by * T;
     const u32 shift = (u32)(by * W + bx);   // two's complement: feature offset + shift >= 0 for kept features
-    u32 s01 = 0, s23 = 0;   // u16 pairs: patch positions {0, 1} and {2, 3} of this lane (sums <= 126 * 4)
+    u32 s[4] = {0, 0, 0, 0};   // the sums of this lane's patch positions 0 .. 3 (<= 126 * 4)
     if (a.stat && lane == 0) atomicAdd(&a.stat[0], 1ull);
     // Exact pruning, as in the scan: the candidate survives only if its best patch position reaches `threshold`, and a
     // feature adds at most 4.  Every 16 features the wave takes the maximum partial sum of the patch; once even
@@ -213,17 +214,16 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
         const u32 eff = ok ? (ft.off & 0x1FFFFFFFu) + shift : a.g.zero_off;
         const u32 lab = ft.off >> 29;
         for (int f = 0; f < cnt; f += 8) {
-            u32 v[8], q01[8], q23[8];
+            u32 v[8], q[8][4];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = rf_patch<W4>(lm, (u32)__builtin_amdgcn_readlane((int)eff, f + k), lane_off);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) rf_lookup(resp[(u32)__builtin_amdgcn_readlane((int)lab, f + k)], v[k], q01[k], q23[k]);
+            for (int k = 0; k < 8; ++k) rf_lookup(resp[(u32)__builtin_amdgcn_readlane((int)lab, f + k)], v[k], q[k]);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { s01 += q01[k]; s23 += q23[k]; }
+            for (int k = 0; k < 8; k += 2) { s[0] += q[k][0] + q[k + 1][0]; s[1] += q[k][1] + q[k + 1][1]; s[2] += q[k][2] + q[k + 1][2]; s[3] += q[k][3] + q[k + 1][3]; }
             f_left -= min(8, cnt - f);
             if (PRUNE_REFINE && (f & 8) && f_left > 0) {       // every second batch of eight
-                const u32 mx = pk_max_u16(s01, s23);
-                const u32 best_now = wave_max_u32(max(mx & 0xFFFFu, mx >> 16));
+                const u32 best_now = wave_max_u32(max(max(s[0], s[1]), max(s[2], s[3])));
                 const float reach = __fdiv_rn(__fmul_rn((float)(int)(best_now + 4u * (u32)f_left), 100.f), denom);
                 if (reach < a.threshold) { dead = true; break; }
             }
@@ -236,10 +236,10 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
     }
     // first maximum in row-major order: key = score << 8 | (255 - index)
     u32 idx0 = (u32)lane * 4u;
-    u32 k0 = ((s01 & 0xFFFF) << 8) | (255u - idx0);
-    u32 k1 = ((s01 >> 16) << 8) | (254u - idx0);
-    u32 k2 = ((s23 & 0xFFFF) << 8) | (253u - idx0);
-    u32 k3 = ((s23 >> 16) << 8) | (252u - idx0);
+    u32 k0 = (s[0] << 8) | (255u - idx0);
+    u32 k1 = (s[1] << 8) | (254u - idx0);
+    u32 k2 = (s[2] << 8) | (253u - idx0);
+    u32 k3 = (s[3] << 8) | (252u - idx0);
     u32 k01 = k0 > k1 ? k0 : k1, k23 = k2 > k3 ? k2 : k3;
     u32 key = wave_max_u32(k01 > k23 ? k01 : k23);
     int best = (int)(key >> 8);
@@ -268,6 +268,7 @@ __device__ __forceinline__ void refine_one(const LmRefineArgs& a, u32 slot, u32 
 #ifndef RP_BATCH
 #define RP_BATCH 8   // features per load batch of refine_pair (x 2 candidates = loads in flight per wave)
 #endif
+static_assert(RP_BATCH % 2 == 0, "the responses are added two features at a time (v_add3_u32)");
 template <bool LAST, bool W4>
 __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32 i, const u8 (*resp)[256], int lane) {
     LmCand* cand = slot_ptr_s(a.cand, a.aux_slot_stride, slot);
@@ -301,7 +302,7 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
         off_x[c] = bx[c] * T; off_y[c] = by[c] * T;
         shift[c] = (u32)(by[c] * W + bx[c]);
     }
-    u32 s01[2] = {0, 0}, s23[2] = {0, 0};
+    u32 s[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     if (a.stat && lane == 0) atomicAdd(&a.stat[1], 2ull);
     const int dcol = bx[1] - bx[0];                                   // wave-uniform
     const bool same_rows = by[0] == by[1] && dcol >= 0 && dcol <= 4;
@@ -338,7 +339,7 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
         // wave-loads (the L1 spends 16 cycles on each, whatever it returns), one more select pair per feature.
         const bool share = W4 && same_rows && __all(lane >= cnt || (ok2[0] && ok2[1]));
         for (int f = 0; f < cnt; f += RP_BATCH) {
-            u32 v[2][RP_BATCH], q01[2][RP_BATCH], q23[2][RP_BATCH];
+            u32 v[2][RP_BATCH], q[2][RP_BATCH][4];
             if (share) {
 #pragma unroll
                 for (int k = 0; k < RP_BATCH; ++k) {
@@ -360,19 +361,20 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
             for (int k = 0; k < RP_BATCH; ++k) {
                 const u8* tab = resp[(u32)__builtin_amdgcn_readlane((int)lab, f + k)];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) rf_lookup(tab, v[c][k], q01[c][k], q23[c][k]);
+                for (int c = 0; c < 2; ++c) rf_lookup(tab, v[c][k], q[c][k]);
             }
 #pragma unroll
-            for (int k = 0; k < RP_BATCH; ++k)
+            for (int k = 0; k < RP_BATCH; k += 2)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) { s01[c] += q01[c][k]; s23[c] += q23[c][k]; }
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int p4 = 0; p4 < 4; ++p4) s[c][p4] += q[c][k][p4] + q[c][k + 1][p4];
             f_left -= min(RP_BATCH, cnt - f);
             if (PRUNE_REFINE_PAIR && (f & RP_BATCH) && f_left > 0) {       // every second batch
                 bool out[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const u32 mx = pk_max_u16(s01[c], s23[c]);
-                    const u32 best_now = wave_max_u32(max(mx & 0xFFFFu, mx >> 16));
+                    const u32 best_now = wave_max_u32(max(max(s[c][0], s[c][1]), max(s[c][2], s[c][3])));
                     out[c] = __fdiv_rn(__fmul_rn((float)(int)(best_now + 4u * (u32)f_left), 100.f), denom) < a.threshold;
                 }
                 if (out[0] || out[1]) {
@@ -389,8 +391,8 @@ __device__ __forceinline__ void refine_pair(const LmRefineArgs& a, u32 slot, u32
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const u32 idx0 = (u32)lane * 4u;
-        const u32 k0 = ((s01[c] & 0xFFFF) << 8) | (255u - idx0), k1 = ((s01[c] >> 16) << 8) | (254u - idx0);
-        const u32 k2 = ((s23[c] & 0xFFFF) << 8) | (253u - idx0), k3 = ((s23[c] >> 16) << 8) | (252u - idx0);
+        const u32 k0 = (s[c][0] << 8) | (255u - idx0), k1 = (s[c][1] << 8) | (254u - idx0);
+        const u32 k2 = (s[c][2] << 8) | (253u - idx0), k3 = (s[c][3] << 8) | (252u - idx0);
         const u32 k01 = k0 > k1 ? k0 : k1, k23 = k2 > k3 ? k2 : k3;
         const u32 key = wave_max_u32(k01 > k23 ? k01 : k23);
         const int best = (int)(key >> 8);
