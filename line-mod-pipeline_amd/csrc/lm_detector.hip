@@ -519,7 +519,10 @@ LmScanArgs make_scan_args(lm_detector* d, int first, ItemRange r, int nslots) {
         unsigned long long*& q = d->d_surv[d->active];
         if (!q) {
             if (hipMalloc(reinterpret_cast<void**>(&q), (16 + (size_t)d->surv_cap) * sizeof(unsigned long long)) != hipSuccess) { q = nullptr; (void)hipGetLastError(); }
-            else if (hipMemset(q, 0, 16 * sizeof(unsigned long long)) != hipSuccess) { hipFree(q); q = nullptr; (void)hipGetLastError(); }
+            // (on the lane's OWN stream: the lanes' streams are non-blocking, a hipMemset on the null stream is not ordered against them -- it could land after the
+            // lane's first k_scan1 had started counting its survivors, and k_scan1_exact then summed fewer than were queued: the rare lost match of a lane's FIRST
+            // bit-plane scan, tests/test_gpu_fullsize.py::test_config3_batch_bit_plane_scan_at_stated_size, about once in ten runs of the suite)
+            else if (hipMemsetAsync(q, 0, 16 * sizeof(unsigned long long), d->stream) != hipSuccess) { hipFree(q); q = nullptr; (void)hipGetLastError(); }
             d->surv_set[d->active] = 0;
         }
         a.surv = q; a.surv_cap = d->surv_cap;       // (no queue: the waves take their survivors' exact sums themselves)

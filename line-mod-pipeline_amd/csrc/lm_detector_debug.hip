@@ -170,7 +170,8 @@ int lm_stage_scan(lm_detector* d, int slot, float threshold, int class_idx, int3
     HIP_TRY(hipMemcpyAsync(&h, d->aux(slot, d->off_hdr), sizeof(h), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemset(d->aux(slot, d->off_hdr), 0, sizeof(LmDevHeader)));  // re-arm the counters ourselves
+    HIP_TRY(hipMemsetAsync(d->aux(slot, d->off_hdr), 0, sizeof(LmDevHeader), d->stream));  // re-arm the counters ourselves (on the stream the scan runs on: the null stream is not ordered against it)
+    HIP_TRY(hipStreamSynchronize(d->stream));
     if (h.cand_count > d->max_cand) return fail(LM_ERR_OVERFLOW, "candidate buffer overflow");
     std::vector<LmCand> cand(h.cand_count);
     if (h.cand_count) HIP_TRY(hipMemcpy(cand.data(), d->aux(slot, d->off_cand), cand.size() * sizeof(LmCand), hipMemcpyDeviceToHost));
@@ -343,6 +344,7 @@ int lm_set_scan_stats(lm_detector* d, int enable) {
     if (any_lane_busy(d)) return fail(LM_ERR_INVALID, "a lane has a match in flight: call lm_match_end first");
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(d->d_scan_stat, 0, 4096 * sizeof(unsigned long long)));
+    HIP_TRY(hipDeviceSynchronize());     // (the lanes' streams are non-blocking: the counters are zero before any later scan starts)
     d->scan_stats = enable != 0;
     return LM_OK;
 }

@@ -475,3 +475,28 @@ def test_scanl_feature_counts(lm, orc, synth):
         d.prepare_slot(0)
         assert np.array_equal(d.stage_scan(0, thr, -1, cap=1 << 20), o.scan_candidates(thr, -1, threads=8, cap=1 << 20)), thr
     d.close()
+
+
+def test_scan1_first_use_of_a_lanes_queue(lm, orc, synth):
+    """r06: a lane's survivor queue is allocated -- and its counters zeroed -- on the lane's first bit-plane scan.  The zeroing was a hipMemset on the null
+    stream, which is not ordered against the lanes' non-blocking streams: when the lane's stream was idle at that moment (its pre-processing over, or none to do)
+    k_scan1 started within microseconds of the fill and could count survivors before the counters were zeroed -- k_scan1_exact then summed fewer than were
+    queued (a lost match about once in ten runs of the suite, always a lane's first scan).  LM_TUNE_SURVIVOR_QUEUE frees the queues, so every repetition here IS
+    a first use, and lm_match_prepared launches the scan on an idle stream right behind the allocation."""
+    nb = 16
+    d, o, frames = _setup(lm, orc, synth, True, (640, 480), [5, 8], 300, nb, seed=2300)
+    bgr = frames[0][0]
+    thr = 70.0
+    exp = o.match(bgr, None, thr, threads=8, cap=1 << 19)
+    assert len(exp) > 50
+    for k in range(nb):
+        d.upload_frame(k, bgr, None)
+    d.set_tuning(lm.TUNE_SCAN_FORM, 2)
+    got, cnt = d.match_batch(nb, thr, cap_per_frame=1 << 15)       # prepares the slots
+    for rep in range(60):
+        d.set_tuning(lm.TUNE_SURVIVOR_QUEUE, (1 << 20) + 8 * (rep & 1))     # frees every lane's queue (and un-prepares nothing)
+        got, cnt = d.match_prepared(0, nb, thr, [-1], cap_per_frame=1 << 15)
+        for k in range(nb):
+            assert cnt[k] == len(exp) and got[k, :cnt[k]].tobytes() == exp.tobytes(), (rep, k, cnt[k], len(exp))
+    assert 0 < d.get_scan_form_stats()[3] < 1000                    # k_scan1 ran
+    d.close()
