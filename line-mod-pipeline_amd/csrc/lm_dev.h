@@ -71,15 +71,6 @@ __device__ __forceinline__ int mul_i24(int a, int b) {
     return r;
 }
 
-// (a << K) + b as ONE full-rate instruction the optimiser leaves alone (v_lshl_add_u32): C shift-adds by 8 and by 16 in a row are folded into a
-// multiply by 0x01010101 = v_mul_lo_u32, quarter rate
-template <int K>
-__device__ __forceinline__ u32 shl_add(u32 a, u32 b) {
-    u32 r;
-    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(K), "v"(b));
-    return r;
-}
-
 __device__ __forceinline__ int mad_i24(int a, int b, int c) {   // a * b + c, factors within 24 signed bits
     int r;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));

@@ -479,7 +479,7 @@ __device__ __forceinline__ void d_dmedian(const u32 vblock, const u8* __restrict
     for (int i = 0; i < ROWS + 4; ++i) {                  // image row y0 - 2 + i, replicated at the borders
         const int yy = clampi(y0 - 2 + i, 0, h - 1);
         // (32-bit offsets from the slot's base: a 64-bit multiply-add per row address is four quarter-rate instructions)
-        const u32 ro = (u32)mad_i24(yy, w, 8 * g);       // (rows and widths fit 24 bits: v_mad_i32_i24, full rate)
+        const u32 ro = (u32)yy * (u32)w + 8u * (u32)g;
         const u8* row = code + ro;
         const u32x2 c = *reinterpret_cast<const u32x2*>(row);
         u32 e[12];                                        // codes of pixels 8g-2 .. 8g+9
@@ -509,12 +509,10 @@ __device__ __forceinline__ void d_dmedian(const u32 vblock, const u8* __restrict
                 u32 o[2] = {0, 0};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    // x * 0x01010101 (byte prefix sums) as two shift-adds: a 32-bit multiply is quarter rate.  (r06: through shl_add(), which the
-                    // optimiser cannot see through -- it had folded the two C shift-adds back into ONE v_mul_lo_u32, 256 of them per lane and 16 rows,
-                    // a fifth of the kernel's issue cycles)
-                    const u32 e1 = shl_add<8>(sumE[k], sumE[k]), PE = shl_add<16>(e1, e1);    // prefix sums of ranks 0..3
-                    const u32 o0 = sumO[k] + (PE >> 24);                                       // carry the total of ranks 0..3 into byte 0 ...
-                    const u32 o1 = shl_add<8>(o0, o0), PO = shl_add<16>(o1, o1);               // ... and it propagates to every byte
+                    // x * 0x01010101 (byte prefix sums) as two shift-adds: a 32-bit multiply is quarter rate
+                    const u32 e1 = sumE[k] + (sumE[k] << 8), PE = e1 + (e1 << 16);      // prefix sums of ranks 0..3
+                    const u32 o0 = sumO[k] + (PE >> 24);                                 // carry the total of ranks 0..3 into byte 0 ...
+                    const u32 o1 = o0 + (o0 << 8), PO = o1 + (o1 << 16);                 // ... and it propagates to every byte
                     const u32 mE = (PE + 0x73737373u) & 0x80808080u;            // byte >= 13
                     const u32 mO = (PO + 0x73737373u) & 0x80808080u;
                     // The cumulative counts never decrease, so the ranks that reached 13 are exactly those from the median rank up:
@@ -523,7 +521,7 @@ __device__ __forceinline__ void d_dmedian(const u32 vblock, const u8* __restrict
                     const u32 res = 128u >> (u32)(__builtin_popcount(mE) + __builtin_popcount(mO));
                     o[k >> 2] |= res << (8 * (k & 3));
                 }
-                *reinterpret_cast<u32x2*>(quant + (u32)mad_i24(y, w, 8 * g)) = u32x2{o[0], o[1]};
+                *reinterpret_cast<u32x2*>(quant + ((u32)y * (u32)w + 8u * (u32)g)) = u32x2{o[0], o[1]};
             }
         }
     }
